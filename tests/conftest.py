@@ -1,0 +1,33 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+def csr_from(d, prefix=""):
+    from gardenia_amd.graphio import CSR
+    rp = np.ascontiguousarray(d[prefix + "rowptr"], dtype=np.uint64)
+    ci = np.ascontiguousarray(d[prefix + "colidx"], dtype=np.int32)
+    return CSR(len(rp) - 1, rp, ci)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import binding
+    binding.lib()
+    return binding

@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and oracle/_ref built by
+`make -C oracle ref`).  What gets committed is data only:
+  * graphs/*.mtx          -- the reference's own tiny fixture graphs (datasets/, test/graphs/)
+  * pr_trace_golden.json  -- the 15-line L1 trace of test/reference/graph-pr.mtx.out:13-28
+  * <kernel>_<case>.npz   -- graph arrays as built by the reference's loader + the labels its
+                             OpenMP solver produced + its verifier's verdict.
+Re-run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from gardenia_amd import graphio  # noqa: E402
+
+REF = "/root/reference"
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+GRAPHS = os.path.join(HERE, "graphs")
+
+
+def run(cmd, env=None):
+    e = dict(os.environ)
+    e["OMP_NUM_THREADS"] = "4"
+    if env:
+        e.update(env)
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=e, text=True)
+    if p.returncode != 0:
+        raise RuntimeError(f"{cmd} failed:\n{p.stdout}")
+    return p.stdout
+
+
+def load(prefix, name, dtype):
+    return np.fromfile(prefix + "." + name, dtype=dtype)
+
+
+def graph_arrays(out, rev):
+    d = {"rowptr": load(out, "rowptr", np.uint64), "colidx": load(out, "colidx", np.int32)}
+    if rev:
+        d["in_rowptr"] = load(out, "in_rowptr", np.uint64)
+        d["in_colidx"] = load(out, "in_colidx", np.int32)
+    return d
+
+
+def verdict(stdout):
+    if "Correct" in stdout:
+        return "Correct"
+    for w in ("Wrong", "POSSIBLE FAILURE", "Total Error"):
+        if w in stdout:
+            return w
+    return "none"
+
+
+def main():
+    os.makedirs(GRAPHS, exist_ok=True)
+    tmp = tempfile.mkdtemp(prefix="golden_")
+    # 1. the reference's own data fixtures (data files, not source)
+    for src, dst in [("datasets/test_bc.mtx", "test_bc.mtx"), ("test/graphs/pr.mtx", "test_pr.mtx"),
+                     ("datasets/test_cc.mtx", "test_cc.mtx"), ("datasets/chesapeake.mtx", "chesapeake.mtx"),
+                     ("datasets/4.mtx", "4.mtx"), ("datasets/4w.mtx", "4w.mtx")]:
+        shutil.copyfile(os.path.join(REF, src), os.path.join(GRAPHS, dst))
+    # 2. the pinned PageRank trace
+    lines = open(os.path.join(REF, "test/reference/graph-pr.mtx.out")).read().splitlines()
+    trace = [float(m.group(2)) for m in (re.match(r"^\s*(\d+)\s+([0-9.]+)$", l) for l in lines[12:27]) if m]
+    iters = int(re.search(r"iterations = (\d+)", lines[27]).group(1))
+    assert len(trace) == 15 and iters == 15
+    json.dump({"source": "test/reference/graph-pr.mtx.out:13-28", "trace": trace, "iterations": iters},
+              open(os.path.join(HERE, "pr_trace_golden.json"), "w"), indent=1)
+
+    # synthetic graphs in the reference's bin format (written by OUR writer, read by THEIR loader)
+    rm10 = graphio.rmat_graph(10, 16)
+    rm12 = graphio.rmat_graph(12, 16)
+    rm10s = graphio.symmetrize(rm10)
+    for name, g in [("rmat10", rm10), ("rmat12", rm12), ("rmat10s", rm10s)]:
+        graphio.write_bin(os.path.join(tmp, name), g)
+    ches_s = graphio.read_mtx(os.path.join(GRAPHS, "chesapeake.mtx"), True)
+    graphio.write_bin(os.path.join(tmp, "chesapeake_s"), ches_s)
+
+    def mtx(name):
+        return ("mtx", os.path.join(GRAPHS, name[:-4] if name.endswith(".mtx") else name))
+
+    def binp(name):
+        return ("bin", os.path.join(tmp, name))
+
+    # ---- BFS (reference solver = omp_beamer, needs the reverse graph) ----
+    for case, (ft, px), sym, rev, source in [
+            ("test_bc_dir", mtx("test_bc"), 0, 1, 0), ("test_bc_sym", mtx("test_bc"), 1, 0, 0),
+            ("chesapeake_sym", mtx("chesapeake"), 1, 0, 0), ("4_dir", mtx("4"), 0, 1, 0),
+            ("rmat10_dir", binp("rmat10"), 0, 1, graphio.first_nonisolated(rm10)),
+            ("rmat12_dir", binp("rmat12"), 0, 1, graphio.first_nonisolated(rm12))]:
+        out = os.path.join(tmp, "bfs_" + case)
+        so = run([os.path.join(REFBIN, "ref_bfs"), "solve", ft, px, str(sym), str(rev), out, str(source)])
+        d = graph_arrays(out, True)
+        np.savez_compressed(os.path.join(HERE, f"bfs_{case}.npz"), source=source, dist=load(out, "dist", np.int32),
+                            verdict=verdict(so), symmetrize=sym, **d)
+        assert verdict(so) == "Correct", so
+
+    # ---- PR ----
+    for case, (ft, px), sym in [("test_pr", mtx("test_pr"), 0), ("chesapeake_sym", mtx("chesapeake"), 1),
+                                ("rmat10", binp("rmat10"), 0), ("rmat12", binp("rmat12"), 0)]:
+        out = os.path.join(tmp, "pr_" + case)
+        so = run([os.path.join(REFBIN, "ref_pr"), "solve", ft, px, str(sym), "1", out])
+        tr = [float(x) for x in re.findall(r"^\s*\d+\s+([0-9.]+)$", so.split("Verifying")[0], re.M)]
+        it = int(re.search(r"iterations = (\d+)", so).group(1))
+        d = graph_arrays(out, True)
+        np.savez_compressed(os.path.join(HERE, f"pr_{case}.npz"), scores=load(out, "scores", np.float32),
+                            trace=np.array(tr), iterations=it, verdict=verdict(so), symmetrize=sym, **d)
+        assert verdict(so) == "Correct", so
+
+    # ---- SpMV (constants of spmv/main.cc, and seeded random values) ----
+    rng = np.random.default_rng(13)
+    for case, (ft, px), sym, rev, g_for_vals in [("test_bc", mtx("test_bc"), 0, 1, None),
+                                                 ("chesapeake_sym", mtx("chesapeake"), 1, 0, None),
+                                                 ("rmat10_rand", binp("rmat10"), 0, 1, rm10)]:
+        out = os.path.join(tmp, "spmv_" + case)
+        cmd = [os.path.join(REFBIN, "ref_spmv"), "solve", ft, px, str(sym), str(rev), out]
+        extra = {}
+        if g_for_vals is not None:
+            Ax = rng.random(g_for_vals.nnz, dtype=np.float32)
+            x = rng.random(g_for_vals.m, dtype=np.float32)
+            y0 = rng.random(g_for_vals.m, dtype=np.float32)
+            for n, a in (("Ax", Ax), ("x", x), ("y0", y0)):
+                a.tofile(os.path.join(tmp, f"spmv_{case}.{n}"))
+            cmd += [os.path.join(tmp, f"spmv_{case}.{n}") for n in ("Ax", "x", "y0")]
+            extra = {"Ax": Ax, "x": x, "y0": y0}
+        so = run(cmd)
+        d = graph_arrays(out, True)
+        np.savez_compressed(os.path.join(HERE, f"spmv_{case}.npz"), y=load(out, "y", np.float32),
+                            verdict=verdict(so), **extra, **d)
+        assert verdict(so) == "Correct", so
+
+    # ---- CC (SV and Afforest) ----
+    for case, (ft, px), sym, rev in [("test_cc_sym", mtx("test_cc"), 1, 0), ("chesapeake_sym", mtx("chesapeake"), 1, 0),
+                                     ("rmat10_sym", binp("rmat10s"), 1, 0), ("rmat10_dir", binp("rmat10"), 0, 1)]:
+        res = {}
+        for variant, exe in (("sv", "ref_cc"), ("afforest", "ref_cc_afforest")):
+            out = os.path.join(tmp, f"cc_{case}_{variant}")
+            so = run([os.path.join(REFBIN, exe), "solve", ft, px, str(sym), str(rev), out])
+            res["comp_" + variant] = load(out, "comp", np.int32)
+            res["verdict_" + variant] = verdict(so)
+            # NB: on a directed graph omp_base's SV only follows out-edges from the hooking side
+            # but the labels are still weakly-connected components (hook is symmetric in u,v).
+        d = graph_arrays(out, True)
+        np.savez_compressed(os.path.join(HERE, f"cc_{case}.npz"), symmetrize=sym, **res, **d)
+
+    # ---- TC (bin loader + USE_DAG orientation) ----
+    for case, px in [("chesapeake_sym", "chesapeake_s"), ("rmat10_sym", "rmat10s")]:
+        out = os.path.join(tmp, "tc_" + case)
+        so = run([os.path.join(REFBIN, "ref_tc"), os.path.join(tmp, px), out])
+        g = graphio.read_bin(os.path.join(tmp, px))
+        np.savez_compressed(os.path.join(HERE, f"tc_{case}.npz"), total=load(out, "total", np.uint64)[0],
+                            sym_rowptr=g.rowptr, sym_colidx=g.colidx,
+                            dag_rowptr=load(out, "rowptr", np.uint64), dag_colidx=load(out, "colidx", np.int32),
+                            verdict=verdict(so))
+        assert verdict(so) == "Correct", so
+
+    # ---- SSSP: only the reference VERIFIER builds (Dijkstra); record graphs, weights and the
+    #      distances that the verifier accepted ("Correct").
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle import binding as orc
+    for case, (ft, px), sym, rev, g, weighted in [
+            ("test_bc_unit", mtx("test_bc"), 0, 0, graphio.read_mtx(os.path.join(GRAPHS, "test_bc.mtx")), False),
+            ("chesapeake_unit", mtx("chesapeake"), 1, 0, ches_s, False),
+            ("rmat10_unit", binp("rmat10"), 0, 0, rm10, False),
+            ("rmat10_w255", binp("rmat10"), 0, 0, rm10, True)]:
+        source = graphio.first_nonisolated(g)
+        wt = (rng.integers(1, 256, size=g.nnz).astype(np.int32) if weighted
+              else np.ones(g.nnz, dtype=np.int32))
+        dist = orc.sssp_dijkstra(g, wt, source)
+        lab = os.path.join(tmp, f"sssp_{case}.dist")
+        wf = os.path.join(tmp, f"sssp_{case}.wt")
+        dist.tofile(lab)
+        wt.tofile(wf)
+        so = run([os.path.join(REFBIN, "ref_sssp_verify"), "verify", ft, px, str(sym), str(rev), lab,
+                  str(source), wf])
+        assert verdict(so) == "Correct", so
+        np.savez_compressed(os.path.join(HERE, f"sssp_{case}.npz"), rowptr=g.rowptr, colidx=g.colidx,
+                            weight=wt, source=source, dist=dist, verdict=verdict(so))
+    shutil.rmtree(tmp)
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
