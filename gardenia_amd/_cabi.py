@@ -1,0 +1,108 @@
+"""ctypes binding of gardenia_amd/lib/libgardenia_hip.so (the C-ABI of include/gardenia_hip.h).
+
+There is no CPU fallback: if the shared library is missing this module raises at import of
+the first symbol, and every entry point returns GDN_ERR_NO_DEVICE without a GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgardenia_hip.so")
+
+GDN_OK = 0
+GDN_ERR_INVALID = -1
+GDN_ERR_NO_DEVICE = -2
+GDN_ERR_HIP = -3
+GDN_ERR_OOM = -4
+GDN_ERR_OVERFLOW = -5
+
+
+class GdnStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("reserved", C.c_int32), ("solve_ms", C.c_double),
+                ("h2d_ms", C.c_double), ("prep_ms", C.c_double), ("edges_traversed", C.c_uint64),
+                ("last_error", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class GardeniaError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"libgardenia_hip status {status}: {msg}")
+        self.status = status
+
+
+_vp = C.c_void_p
+_i32 = C.c_int32
+_u64 = C.c_uint64
+_pp = C.POINTER(C.c_void_p)
+_st = C.POINTER(GdnStats)
+
+# name -> (restype, argtypes); must list every symbol of include/gardenia_hip.h
+PROTOTYPES = {
+    "gdn_last_error": (C.c_char_p, []),
+    "gdn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "gdn_set_device": (C.c_int, [C.c_int]),
+    "gdn_bfs": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _i32, _vp, _st]),
+    "gdn_pr": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, _i32, _st]),
+    "gdn_spmv": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
+    "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
+    "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
+    "gdn_cc": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
+    "gdn_graph_upload": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
+    "gdn_graph_wrap_dev": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
+    "gdn_graph_free": (C.c_int, [_vp]),
+    "gdn_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64), _pp, _pp]),
+    "gdn_graph_degrees_dev": (C.c_int, [_vp, _vp, _vp]),
+    "gdn_graph_transpose": (C.c_int, [_vp, _pp]),
+    "gdn_graph_slice_rows": (C.c_int, [_vp, _i32, _i32, _pp]),
+    "gdn_graph_download": (C.c_int, [_vp, _vp, _vp]),
+    "gdn_rmat_build": (C.c_int, [_i32, _i32, _u64, _i32, _pp, _pp]),
+    "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _pp]),
+    "gdn_pr_plan_free": (C.c_int, [_vp]),
+    "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gdn_pr_pull_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp]),
+    "gdn_pr_iter_bytes": (_u64, [_vp]),
+    "gdn_spmv_plan_create": (C.c_int, [_vp, _pp]),
+    "gdn_spmv_plan_free": (C.c_int, [_vp]),
+    "gdn_spmv_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gdn_spmv_bytes": (_u64, [_vp]),
+    "gdn_bfs_dev": (C.c_int, [_vp, _vp, _i32, _vp, _st]),
+    "gdn_sssp_dev": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _st]),
+    "gdn_cc_dev": (C.c_int, [_vp, _vp, _vp, _st]),
+    "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load the C-ABI library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C gardenia_amd/csrc).  gardenia_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != GDN_OK:
+        msg = lib().gdn_last_error()
+        raise GardeniaError(status, msg.decode() if msg else "")
+    return status
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().gdn_device_count(C.byref(n))
+    return n.value

@@ -1,0 +1,206 @@
+// gdn_common.hpp -- shared host/device plumbing of libgardenia_hip.so (gfx950 only).
+//
+// Device primitives here are the hand-written wave64 replacements for what the reference
+// takes from CUB/Thrust: cub::BlockScan<int,256>::ExclusiveSum
+// (include/worklistc.h:73, src/bfs/linear_lb.cu:152), cub::BlockReduce (src/pr/base.cu:48,
+// src/tc/gpu_base.cu:22) and the Worklist2 push (include/worklistc.h:66-113).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/gardenia_hip.h"
+
+#define GDN_WAVE 64
+#define GDN_BLOCK 256                 // threads per workgroup for every kernel (4 waves)
+#define GDN_WAVES_PER_BLOCK (GDN_BLOCK / GDN_WAVE)
+#define GDN_MYINFINITY 1000000000     // include/common.h:66
+#define GDN_DIST_INF 2147483647       // src/sssp/sssp.h:46 kDistInf as int32
+
+typedef uint64_t eoff_t;  // edge offsets: never held in 32 bits (RMAT-27 has 2^31 edges)
+typedef int32_t vid_t;
+
+// ------------------------------------------------------------------------------------------
+// host-side error plumbing: no exit(), thread-local message
+// ------------------------------------------------------------------------------------------
+void gdn_set_error(const char *fmt, ...);
+
+#define GDN_HIP(call)                                                                          \
+  do {                                                                                         \
+    hipError_t e__ = (call);                                                                   \
+    if (e__ != hipSuccess) {                                                                   \
+      gdn_set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__));     \
+      return (e__ == hipErrorOutOfMemory) ? GDN_ERR_OOM                                        \
+             : (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice) ? GDN_ERR_NO_DEVICE   \
+                                                                         : GDN_ERR_HIP;        \
+    }                                                                                          \
+  } while (0)
+
+#define GDN_TRY(call)               \
+  do {                              \
+    int s__ = (call);               \
+    if (s__ != GDN_OK) return s__;  \
+  } while (0)
+
+#define GDN_REQUIRE(cond, msg)                                       \
+  do {                                                               \
+    if (!(cond)) {                                                   \
+      gdn_set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, msg); \
+      return GDN_ERR_INVALID;                                        \
+    }                                                                \
+  } while (0)
+
+int gdn_require_device();
+
+// RAII device buffer (solver-private scratch)
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  DevBuf(const DevBuf &) = delete;
+  DevBuf &operator=(const DevBuf &) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  int alloc(size_t count) {
+    release();
+    n = count;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    if (e != hipSuccess) {
+      p = nullptr;
+      gdn_set_error("hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+    return GDN_OK;
+  }
+};
+
+struct HostTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  hipStream_t s;
+  explicit HostTimer(hipStream_t st = 0) : s(st) {
+    (void)hipEventCreate(&a);
+    (void)hipEventCreate(&b);
+  }
+  ~HostTimer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+  void start() { (void)hipEventRecord(a, s); }
+  double stop_ms() {
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, a, b);
+    return (double)ms;
+  }
+};
+
+struct gdn_graph {
+  int32_t m = 0;
+  uint64_t nnz = 0;
+  eoff_t *rowptr = nullptr;  // device, m+1
+  vid_t *colidx = nullptr;   // device, nnz
+  bool owned = false;
+};
+
+static inline unsigned gdn_nblocks(uint64_t n, unsigned per_block = GDN_BLOCK) {
+  uint64_t b = (n + per_block - 1) / per_block;
+  return (unsigned)(b == 0 ? 1 : b);
+}
+
+// device-wide helpers implemented in gdn_graph.hip
+int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n, hipStream_t s);
+int gdn_fill_i32(int32_t *d, int32_t v, size_t n, hipStream_t s);
+
+#ifdef __HIPCC__
+// ------------------------------------------------------------------------------------------
+// wave64 primitives
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned gdn_lane() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+__device__ __forceinline__ unsigned long long gdn_lanemask_lt() {
+  return (1ull << gdn_lane()) - 1ull;
+}
+
+template <typename T>
+__device__ __forceinline__ T gdn_wave_sum(T v) {  // every lane gets the total
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T gdn_wave_incl_scan(T v) {
+  const unsigned lane = gdn_lane();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    T p = __shfl_up(v, o, 64);
+    if (lane >= (unsigned)o) v += p;
+  }
+  return v;
+}
+
+// Block (256 threads) sum; result valid in every thread.  `scratch` = GDN_WAVES_PER_BLOCK Ts.
+template <typename T>
+__device__ __forceinline__ T gdn_block_sum(T v, T *scratch) {
+  v = gdn_wave_sum(v);
+  const unsigned w = threadIdx.x >> 6;
+  __syncthreads();
+  if (gdn_lane() == 0) scratch[w] = v;
+  __syncthreads();
+  T t = scratch[0];
+#pragma unroll
+  for (int i = 1; i < GDN_WAVES_PER_BLOCK; i++) t += scratch[i];
+  return t;
+}
+
+// Block exclusive scan; *total gets the block sum.  scratch = GDN_WAVES_PER_BLOCK Ts.
+// (replaces cub::BlockScan<int,256>::ExclusiveSum, include/worklistc.h:73)
+template <typename T>
+__device__ __forceinline__ T gdn_block_excl_scan(T v, T *scratch, T *total) {
+  T incl = gdn_wave_incl_scan(v);
+  const unsigned w = threadIdx.x >> 6;
+  __syncthreads();
+  if (gdn_lane() == 63) scratch[w] = incl;
+  __syncthreads();
+  T base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
+    T s = scratch[i];
+    if ((unsigned)i < w) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+// Wavefront-aggregated worklist push: ONE atomicAdd per wave, lanes take consecutive slots
+// by ballot + popcount prefix (replaces Worklist::push, include/worklistc.h:44-50 -- one
+// atomicAdd per item -- and Worklist2::push_1item's CUB block scan, :66-89).  Must be called
+// by every active lane of the wave with the same queue.  Overflow is reported through
+// *overflow instead of being dropped (worklistc.h:46-47 drops silently).
+__device__ __forceinline__ void gdn_wl_push(vid_t *queue, unsigned *count, unsigned capacity,
+                                            bool pred, vid_t item, unsigned *overflow) {
+  const unsigned long long mask = __ballot(pred);
+  if (mask == 0ull) return;
+  const unsigned lane = gdn_lane();
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)lane == leader) base = atomicAdd(count, (unsigned)__popcll(mask));
+  base = __shfl(base, leader, 64);
+  if (pred) {
+    const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
+    if (pos < capacity) queue[pos] = item;
+    else *overflow = 1u;
+  }
+}
+#endif  // __HIPCC__

@@ -1,0 +1,261 @@
+// gdn_graph.hip -- resident CSR graphs, error plumbing and the device-wide scan.
+//
+// Replaces the per-call cudaMalloc/cudaMemcpy of the whole CSR at the top of every reference
+// solver (src/bfs/linear_base.cu:42-51, src/pr/base.cu:83-99) with an explicit handle, so
+// iterations can be timed with the graph resident (SURVEY 8b "resident-graph variant").
+#include <stdarg.h>
+#include <string.h>
+
+#include "gdn_common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void gdn_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int gdn_require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    gdn_set_error("no HIP device available (%s); libgardenia_hip has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return GDN_ERR_NO_DEVICE;
+  }
+  return GDN_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// device-wide exclusive scan (u32 -> u64): reduce / scan-of-block-sums / down-sweep, all with
+// the wave64 block scan of gdn_common.hpp.  Used for row offsets (degree -> rowptr).
+// ------------------------------------------------------------------------------------------
+#define SCAN_IPT 8
+#define SCAN_TILE (GDN_BLOCK * SCAN_IPT)
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+scan_block_sums(const uint32_t *__restrict__ in, size_t n, eoff_t *__restrict__ block_sums) {
+  __shared__ eoff_t s[GDN_WAVES_PER_BLOCK];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+  eoff_t acc = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++) {
+    const size_t i = base + (size_t)k * GDN_BLOCK + threadIdx.x;
+    if (i < n) acc += in[i];
+  }
+  acc = gdn_block_sum(acc, s);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = acc;
+}
+
+// in-place exclusive scan of up to SCAN_TILE*? values by ONE block (loops over chunks)
+__global__ void __launch_bounds__(GDN_BLOCK)
+scan_single_block(eoff_t *__restrict__ data, size_t n) {
+  __shared__ eoff_t s[GDN_WAVES_PER_BLOCK];
+  eoff_t carry = 0;
+  for (size_t base = 0; base < n; base += GDN_BLOCK) {
+    const size_t i = base + threadIdx.x;
+    const eoff_t v = (i < n) ? data[i] : 0;
+    eoff_t total;
+    const eoff_t ex = gdn_block_excl_scan(v, s, &total);
+    if (i < n) data[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+scan_downsweep(const uint32_t *__restrict__ in, size_t n, const eoff_t *__restrict__ block_offsets,
+               eoff_t *__restrict__ out, eoff_t *__restrict__ total_out) {
+  __shared__ eoff_t s[GDN_WAVES_PER_BLOCK];
+  const size_t base = (size_t)blockIdx.x * SCAN_TILE;
+  // thread-contiguous items so the scan order is the array order
+  eoff_t v[SCAN_IPT];
+  eoff_t tsum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++) {
+    const size_t i = base + (size_t)threadIdx.x * SCAN_IPT + k;
+    v[k] = (i < n) ? in[i] : 0;
+    tsum += v[k];
+  }
+  eoff_t total;
+  eoff_t ex = gdn_block_excl_scan(tsum, s, &total) + block_offsets[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SCAN_IPT; k++) {
+    const size_t i = base + (size_t)threadIdx.x * SCAN_IPT + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+    if (i + 1 == n && total_out) *total_out = ex;  // out[n] = grand total
+  }
+}
+
+// d_out has n+1 entries: out[i] = sum in[0..i), out[n] = total.
+int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n, hipStream_t s) {
+  if (n == 0) {
+    GDN_HIP(hipMemsetAsync(d_out, 0, sizeof(eoff_t), s));
+    return GDN_OK;
+  }
+  const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  DevBuf<eoff_t> sums;
+  GDN_TRY(sums.alloc(nb));
+  hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, sums.p);
+  hipLaunchKernelGGL(scan_single_block, dim3(1), dim3(GDN_BLOCK), 0, s, sums.p, nb);
+  hipLaunchKernelGGL(scan_downsweep, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, sums.p, d_out,
+                     d_out + n);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipStreamSynchronize(s));  // sums is freed on return
+  return GDN_OK;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK) fill_i32_kernel(int32_t *d, int32_t v, size_t n) {
+  size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) d[i] = v;
+}
+
+int gdn_fill_i32(int32_t *d, int32_t v, size_t n, hipStream_t s) {
+  if (n == 0) return GDN_OK;
+  size_t nb = (n + GDN_BLOCK - 1) / GDN_BLOCK;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d, v, n);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+degrees_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int32_t *__restrict__ deg) {
+  const int32_t v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < m) deg[v] = (int32_t)(rowptr[v + 1] - rowptr[v]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+rebase_rowptr_kernel(const eoff_t *__restrict__ rowptr, int32_t row_lo, int32_t n, eoff_t *__restrict__ out) {
+  const int32_t i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i <= n) out[i] = rowptr[row_lo + i] - rowptr[row_lo];
+}
+
+extern "C" {
+
+const char *gdn_last_error(void) { return g_err; }
+
+int gdn_device_count(int *count) {
+  GDN_REQUIRE(count != nullptr, "count");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  *count = (e == hipSuccess) ? n : 0;
+  return GDN_OK;
+}
+
+int gdn_set_device(int device) {
+  GDN_TRY(gdn_require_device());
+  GDN_HIP(hipSetDevice(device));
+  return GDN_OK;
+}
+
+int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
+                     gdn_graph **out) {
+  GDN_REQUIRE(out != nullptr, "out");
+  *out = nullptr;
+  GDN_REQUIRE(m > 0, "m must be > 0");
+  GDN_REQUIRE(rowptr != nullptr, "rowptr");
+  GDN_REQUIRE(colidx != nullptr || nnz == 0, "colidx");
+  GDN_REQUIRE(rowptr[0] == 0 && rowptr[m] == nnz, "rowptr[0] must be 0 and rowptr[m] == nnz");
+  GDN_TRY(gdn_require_device());
+  gdn_graph *g = new gdn_graph();
+  g->m = m;
+  g->nnz = nnz;
+  g->owned = true;
+  hipError_t e = hipMalloc((void **)&g->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&g->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
+  if (e == hipSuccess) e = hipMemcpy(g->rowptr, rowptr, ((size_t)m + 1) * sizeof(eoff_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = hipMemcpy(g->colidx, colidx, nnz * sizeof(vid_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    gdn_set_error("gdn_graph_upload: %s", hipGetErrorString(e));
+    gdn_graph_free(g);
+    return e == hipErrorOutOfMemory ? GDN_ERR_OOM : GDN_ERR_HIP;
+  }
+  *out = g;
+  return GDN_OK;
+}
+
+int gdn_graph_wrap_dev(int32_t m, uint64_t nnz, const uint64_t *d_rowptr, const int32_t *d_colidx,
+                       gdn_graph **out) {
+  GDN_REQUIRE(out != nullptr, "out");
+  *out = nullptr;
+  GDN_REQUIRE(m > 0 && d_rowptr != nullptr, "m / d_rowptr");
+  GDN_TRY(gdn_require_device());
+  gdn_graph *g = new gdn_graph();
+  g->m = m;
+  g->nnz = nnz;
+  g->rowptr = const_cast<eoff_t *>(d_rowptr);
+  g->colidx = const_cast<vid_t *>(d_colidx);
+  g->owned = false;
+  *out = g;
+  return GDN_OK;
+}
+
+int gdn_graph_free(gdn_graph *g) {
+  if (!g) return GDN_OK;
+  if (g->owned) {
+    if (g->rowptr) (void)hipFree(g->rowptr);
+    if (g->colidx) (void)hipFree(g->colidx);
+  }
+  delete g;
+  return GDN_OK;
+}
+
+int gdn_graph_info(const gdn_graph *g, int32_t *m, uint64_t *nnz, const uint64_t **d_rowptr,
+                   const int32_t **d_colidx) {
+  GDN_REQUIRE(g != nullptr, "graph");
+  if (m) *m = g->m;
+  if (nnz) *nnz = g->nnz;
+  if (d_rowptr) *d_rowptr = g->rowptr;
+  if (d_colidx) *d_colidx = g->colidx;
+  return GDN_OK;
+}
+
+int gdn_graph_degrees_dev(const gdn_graph *g, int32_t *d_degree, void *stream) {
+  GDN_REQUIRE(g != nullptr && d_degree != nullptr, "graph / d_degree");
+  hipLaunchKernelGGL(degrees_kernel, dim3(gdn_nblocks((uint64_t)g->m)), dim3(GDN_BLOCK), 0,
+                     (hipStream_t)stream, g->rowptr, g->m, d_degree);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn_graph **out) {
+  GDN_REQUIRE(g != nullptr && out != nullptr, "graph / out");
+  *out = nullptr;
+  GDN_REQUIRE(0 <= row_lo && row_lo < row_hi && row_hi <= g->m, "row range");
+  eoff_t ends[2];
+  GDN_HIP(hipMemcpy(&ends[0], g->rowptr + row_lo, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&ends[1], g->rowptr + row_hi, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  gdn_graph *s = new gdn_graph();
+  s->m = row_hi - row_lo;
+  s->nnz = ends[1] - ends[0];
+  s->owned = true;
+  hipError_t e = hipMalloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&s->colidx, (s->nnz ? s->nnz : 1) * sizeof(vid_t));
+  if (e == hipSuccess && s->nnz)
+    e = hipMemcpy(s->colidx, g->colidx + ends[0], s->nnz * sizeof(vid_t), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) {
+    gdn_set_error("gdn_graph_slice_rows: %s", hipGetErrorString(e));
+    gdn_graph_free(s);
+    return e == hipErrorOutOfMemory ? GDN_ERR_OOM : GDN_ERR_HIP;
+  }
+  hipLaunchKernelGGL(rebase_rowptr_kernel, dim3(gdn_nblocks((uint64_t)s->m + 1)), dim3(GDN_BLOCK), 0, 0,
+                     g->rowptr, row_lo, s->m, s->rowptr);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipDeviceSynchronize());
+  *out = s;
+  return GDN_OK;
+}
+
+int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx) {
+  GDN_REQUIRE(g != nullptr, "graph");
+  if (rowptr) GDN_HIP(hipMemcpy(rowptr, g->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  if (colidx && g->nnz) GDN_HIP(hipMemcpy(colidx, g->colidx, g->nnz * sizeof(vid_t), hipMemcpyDeviceToHost));
+  return GDN_OK;
+}
+
+}  // extern "C"

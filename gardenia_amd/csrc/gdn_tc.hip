@@ -1,0 +1,231 @@
+// gdn_tc.hip -- triangle counting on the degree-oriented DAG.
+//
+// Reference path: TCSolver (src/tc/tc.h:7).  OpenMP src/tc/omp_base.cc:16-22 (for u, for v in
+// N(u): |N(u) ^ N(v)| by merge, include/VertexSet.h:65-76); CUDA src/tc/gpu_base.cu:11
+// warp_edge = one 32-lane warp per DAG edge, binary search of the shorter list in the longer
+// (include/graph_gpu.h:253 warp_intersect_cache, include/search.cuh:45) + CUB BlockReduce.
+// The orientation that the reference applies while loading (`Graph g(prefix, USE_DAG)`,
+// src/tc/main.cc:12 -> src/common/graph.cc:67-113) is done on the device here:
+//   keep[k] = deg[dst] > deg[src] || (deg equal && dst > src)        (graph.cc:80-81)
+//   pos     = exclusive_scan(keep)                                    (order preserving)
+//   dag.colidx[pos[k]] = colidx[k];  dag.rowptr[u] = pos[rowptr[u]]
+// Counting: one wavefront per source vertex u; for each v in N+(u) the 64 lanes stride over
+// N+(v) and binary-search N+(u) (which stays L1/L2 hot across all v); uint64 count reduced per
+// wave then one atomicAdd per workgroup.  The count is exact (integer sum).
+#include <string.h>
+
+#include "gdn_expand.hpp"
+
+struct TcKeepVis {
+  const vid_t *__restrict__ colidx;
+  const int32_t *__restrict__ deg;
+  unsigned *__restrict__ keep;
+  int32_t v;  // per-lane source vertex
+  __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t src = __shfl(v, owner, 64);
+    if (valid) {
+      const vid_t dst = colidx[k];
+      const int32_t ds = deg[src], dd = deg[dst];
+      keep[k] = (dd > ds || (dd == ds && dst > src)) ? 1u : 0u;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_keep_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, TcKeepVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_keep_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, TcKeepVis vis) {
+  vis.v = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_compact_kernel(const vid_t *__restrict__ colidx, const unsigned *__restrict__ keep,
+                  const eoff_t *__restrict__ pos, uint64_t nnz, vid_t *__restrict__ out) {
+  size_t k = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
+  for (; k < nnz; k += stride)
+    if (keep[k]) out[pos[k]] = colidx[k];
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ pos, int32_t m,
+                 eoff_t *__restrict__ out) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v <= (unsigned)m) out[v] = pos[rowptr[v]];
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
+                unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  const unsigned lane = gdn_lane();
+  const unsigned nwaves = gridDim.x * GDN_WAVES_PER_BLOCK;
+  unsigned long long count = 0;
+  for (unsigned u = blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); u < (unsigned)m; u += nwaves) {
+    const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
+    const int du = (int)(ue - ub);
+    if (du < 2) continue;  // the last out-neighbour in id/degree order closes no triangle alone
+    const vid_t *nu = colidx + ub;
+    for (eoff_t i = ub; i < ue; i++) {
+      const vid_t v = colidx[i];
+      const eoff_t vb = rowptr[v], ve = rowptr[v + 1];
+      for (eoff_t k0 = vb; k0 < ve; k0 += 64) {
+        const eoff_t k = k0 + lane;
+        if (k < ve) {
+          const vid_t w = colidx[k];
+          int lo = 0, hi = du - 1;
+          while (lo <= hi) {
+            const int mid = (lo + hi) >> 1;
+            const vid_t x = nu[mid];
+            if (x == w) {
+              count++;
+              break;
+            }
+            if (x < w) lo = mid + 1;
+            else hi = mid - 1;
+          }
+        }
+      }
+    }
+  }
+  count = gdn_block_sum(count, s_red);
+  if (threadIdx.x == 0 && count) atomicAdd(total, count);
+}
+
+int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n, hipStream_t s);
+
+// symmetric graph -> DAG (device arrays owned by the returned graph)
+static int tc_orient(const gdn_graph *g, gdn_graph **out) {
+  const int32_t m = g->m;
+  DevBuf<int32_t> deg;
+  DevBuf<unsigned> keep;
+  DevBuf<eoff_t> pos;
+  DevBuf<unsigned long long> bigitems;
+  DevBuf<unsigned> cnt;
+  const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+  const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+  GDN_TRY(deg.alloc(m));
+  GDN_TRY(keep.alloc(g->nnz));
+  GDN_TRY(pos.alloc(g->nnz + 1));
+  GDN_TRY(bigitems.alloc(bigcap));
+  GDN_TRY(cnt.alloc(2));
+  GDN_HIP(hipMemset(cnt.p, 0, 8));
+  GDN_TRY(gdn_graph_degrees_dev(g, deg.p, nullptr));
+  ExpBigList big;
+  big.items = bigitems.p;
+  big.capacity = bigcap;
+  big.count = cnt.p;
+  big.overflow = cnt.p + 1;
+  TcKeepVis vis;
+  vis.colidx = g->colidx;
+  vis.deg = deg.p;
+  vis.keep = keep.p;
+  vis.v = 0;
+  hipLaunchKernelGGL(tc_keep_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
+  hipLaunchKernelGGL(tc_keep_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+  GDN_HIP(hipGetLastError());
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(keep.p, pos.p, (size_t)g->nnz, 0));
+  eoff_t nnz_dag = 0;
+  GDN_HIP(hipMemcpy(&nnz_dag, pos.p + g->nnz, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  unsigned ovf[2];
+  GDN_HIP(hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost));
+  if (ovf[1]) {
+    gdn_set_error("gdn_tc: device worklist overflow");
+    return GDN_ERR_OVERFLOW;
+  }
+  gdn_graph *d = new gdn_graph();
+  d->m = m;
+  d->nnz = nnz_dag;
+  d->owned = true;
+  hipError_t e = hipMalloc((void **)&d->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&d->colidx, (nnz_dag ? nnz_dag : 1) * sizeof(vid_t));
+  if (e != hipSuccess) {
+    gdn_set_error("gdn_tc: %s", hipGetErrorString(e));
+    gdn_graph_free(d);
+    return GDN_ERR_OOM;
+  }
+  if (g->nnz) {
+    size_t nb = (g->nnz + GDN_BLOCK - 1) / GDN_BLOCK;
+    if (nb > 65536) nb = 65536;
+    hipLaunchKernelGGL(tc_compact_kernel, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, 0, g->colidx, keep.p, pos.p,
+                       g->nnz, d->colidx);
+  }
+  hipLaunchKernelGGL(tc_rowptr_kernel, dim3(gdn_nblocks((uint64_t)m + 1)), dim3(GDN_BLOCK), 0, 0, g->rowptr, pos.p, m,
+                     d->rowptr);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipDeviceSynchronize());
+  *out = d;
+  return GDN_OK;
+}
+
+extern "C" {
+
+int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats *stats) {
+  GDN_REQUIRE(g != nullptr && total != nullptr, "graph / total");
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  HostTimer tprep, tsolve;
+  const gdn_graph *dag = g;
+  gdn_graph *own = nullptr;
+  tprep.start();
+  if (!oriented) {
+    GDN_TRY(tc_orient(g, &own));
+    dag = own;
+  }
+  DevBuf<unsigned long long> d_total;
+  int rc = d_total.alloc(1);
+  if (rc == GDN_OK && hipMemset(d_total.p, 0, 8) != hipSuccess) rc = GDN_ERR_HIP;
+  st.prep_ms = tprep.stop_ms();
+  if (rc == GDN_OK) {
+    tsolve.start();  // src/tc/gpu_base.cu:52-58
+    unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK);
+    if (nb > 65536) nb = 65536;  // gpu_base.cu:39
+    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, d_total.p);
+    unsigned long long h = 0;
+    if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = GDN_ERR_HIP;
+    }
+    st.solve_ms = tsolve.stop_ms();
+    *total = h;
+    st.iterations = 1;
+    st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
+  }
+  if (own) gdn_graph_free(own);
+  if (stats) *stats = st;
+  return rc;
+}
+
+// Host API: one call == TCSolver(g, total) (src/tc/main.cc:17).
+int gdn_tc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx, int32_t oriented,
+           uint64_t *total, gdn_stats *stats) {
+  GDN_REQUIRE(m > 0 && rowptr && total, "null argument");
+  GDN_TRY(gdn_require_device());
+  HostTimer th2d;
+  th2d.start();
+  gdn_graph *g = nullptr;
+  GDN_TRY(gdn_graph_upload(m, nnz, rowptr, colidx, &g));
+  const double h2d = th2d.stop_ms();
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  int rc = gdn_tc_dev(g, oriented, total, &st);
+  st.h2d_ms = h2d;
+  gdn_graph_free(g);
+  if (stats) *stats = st;
+  return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+"""Host-side mirror of the reference's per-kernel Solver API on numpy arrays.
+
+Same names, argument meaning and in/out conventions as the reference harness
+(src/<kernel>/main.cc + <kernel>.h); each function is one call through the C-ABI of
+include/gardenia_hip.h into the HIP kernels.  `Graph` mirrors the accessor surface of
+include/csr_graph.h:265-306 that the solvers use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _cabi
+from .graphio import CSR, read_bin, read_mtx, transpose
+
+MYINFINITY = 1000000000   # include/common.h:66
+K_DIST_INF = 2147483647   # src/sssp/sssp.h:46 (UINT_MAX/2 as int)
+K_DAMP = np.float32(0.85) # src/pr/pr.h:6
+EPSILON = 0.0001          # src/pr/pr.h:5
+MAX_ITER = 100            # src/pr/pr.h:12
+
+
+class Graph:
+    """include/csr_graph.h Graph: (prefix, filetype, symmetrize, need_reverse) ctor :211-250."""
+
+    def __init__(self, prefix: Optional[str] = None, filetype: str = "bin", symmetrize: bool = False,
+                 need_reverse: bool = False, csr: Optional[CSR] = None, in_csr: Optional[CSR] = None):
+        if csr is None:
+            if filetype == "mtx":
+                csr = read_mtx(prefix + ".mtx", symmetrize)
+            elif filetype == "bin":
+                csr = read_bin(prefix)
+            else:
+                raise ValueError("filetype must be 'mtx' or 'bin'")
+        self._out = csr
+        self._directed = (not symmetrize) and need_reverse
+        self._in = None
+        if in_csr is not None:
+            self._in = in_csr
+        elif symmetrize:
+            self._in = csr  # csr_graph.h:241-245: reverse_* alias the forward arrays
+        elif need_reverse:
+            self._in = transpose(csr)
+
+    def V(self): return self._out.m
+    def E(self): return self._out.nnz
+    def out_rowptr(self): return self._out.rowptr
+    def out_colidx(self): return self._out.colidx
+    def has_reverse_graph(self): return self._in is not None
+    def is_directed(self): return self._directed
+    def in_rowptr(self): return self._in.rowptr
+    def in_colidx(self): return self._in.colidx
+    def get_degree(self, v): return int(self._out.rowptr[v + 1] - self._out.rowptr[v])
+    def out_degrees(self): return self._out.degrees()
+    def out_csr(self): return self._out
+    def in_csr(self): return self._in
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _arr(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def BFSSolver(g: Graph, source: int, dist: np.ndarray) -> dict:
+    """src/bfs/bfs.h:43.  dist: int32[m], pre-filled with MYINFINITY by the caller."""
+    assert dist.dtype == np.int32 and dist.flags.c_contiguous
+    rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    irp = ici = None
+    if g.has_reverse_graph():
+        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_bfs(g.V(), g.E(), _p(rp), _p(ci), _p(irp), _p(ici), source, _p(dist), C.byref(st)))
+    return st.as_dict()
+
+
+def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_iter=MAX_ITER) -> dict:
+    """src/pr/pr.h:31.  scores: float32[m], pre-filled with 1/m by the caller."""
+    assert scores.dtype == np.float32 and scores.flags.c_contiguous
+    irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    deg = _arr(g.out_degrees(), np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_pr(g.V(), g.E(), _p(irp), _p(ici), _p(deg), _p(scores), float(damping),
+                                   float(epsilon), int(max_iter), C.byref(st)))
+    return st.as_dict()
+
+
+def SpmvSolver(g: Graph, Ax: np.ndarray, x: np.ndarray, y: np.ndarray) -> dict:
+    """src/spmv/spmv.h:29.  y += A x over the rows of (in_rowptr, in_colidx)."""
+    assert y.dtype == np.float32 and y.flags.c_contiguous
+    irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    Ax, x = _arr(Ax, np.float32), _arr(x, np.float32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_spmv(g.V(), g.E(), _p(irp), _p(ici), _p(Ax), _p(x), _p(y), C.byref(st)))
+    return st.as_dict()
+
+
+def SSSPSolver(g: Graph, source: int, weight: np.ndarray, dist: np.ndarray, delta: int = 1) -> dict:
+    """src/sssp/sssp.h:47.  dist: int32[m] pre-filled with kDistInf."""
+    assert dist.dtype == np.int32 and dist.flags.c_contiguous
+    rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    w = _arr(weight, np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_sssp(g.V(), g.E(), _p(rp), _p(ci), _p(w), source, delta, _p(dist), C.byref(st)))
+    return st.as_dict()
+
+
+def TCSolver(g: Graph, oriented: bool = False):
+    """src/tc/tc.h:7.  Returns (total, stats); orientation (USE_DAG) is applied unless oriented."""
+    rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    total = C.c_uint64(0)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_tc(g.V(), g.E(), _p(rp), _p(ci), 1 if oriented else 0, C.byref(total), C.byref(st)))
+    return int(total.value), st.as_dict()
+
+
+def CCSolver(g: Graph, comp: np.ndarray) -> dict:
+    """src/cc/cc.h:28.  comp: int32[m] pre-filled with comp[i] = i."""
+    assert comp.dtype == np.int32 and comp.flags.c_contiguous
+    rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    irp = ici = None
+    if g.has_reverse_graph() and g.is_directed():
+        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_cc(g.V(), g.E(), _p(rp), _p(ci), _p(irp), _p(ici), _p(comp), C.byref(st)))
+    return st.as_dict()

@@ -1,0 +1,180 @@
+/* gardenia_hip.h -- C-ABI of libgardenia_hip.so: the MI355X (gfx950) drop-in for the CSR hot
+ * path of the GARDENIA benchmark (BFS, PageRank, SpMV, SSSP, TC, CC).
+ *
+ * Boundary: the reference has no FFI; its "plugin API" is link-time substitution of one
+ * XxxSolver symbol per kernel directory (src/<k>/Makefile picks the object;
+ * src/<k>/main.cc calls Solver then Verifier).  The entry points below have the raw-array
+ * shape of the reference's legacy solvers (m, nnz, row_offsets, column_indices,
+ * labels/values -- e.g. src/bfs/topo_base.cu:35, src/pr/vector.cu:83) with the widths of
+ * the live Graph class (include/csr_graph.h:50-51: uint64_t offsets, int32_t vertex ids).
+ * gardenia_amd/host/solvers.hpp adapts them 1:1 to the live `XxxSolver(Graph&, ...)`
+ * signatures, so a main.cc written like the reference's links unchanged.
+ *
+ * Conventions
+ *   - every function returns 0 (GDN_OK) or a negative gdn_status; nothing calls exit()
+ *     (the reference's CUDA_SAFE_CALL exits: include/cutil_subset.h:4-12);
+ *     gdn_last_error() returns a thread-local message for the last failure.
+ *   - "host API": all pointers are HOST pointers owned by the caller; label arrays are
+ *     in/out exactly as in the reference mains (dist pre-filled, scores = 1/m, comp[i] = i,
+ *     y accumulated into).
+ *   - "_dev API": all array pointers are DEVICE pointers on the current device, `stream` is
+ *     a hipStream_t passed as void* (NULL = default stream); calls are asynchronous.
+ *   - no torch / C++ types in any signature.
+ */
+#ifndef GARDENIA_HIP_H_
+#define GARDENIA_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum gdn_status {
+  GDN_OK = 0,
+  GDN_ERR_INVALID = -1,   /* bad argument (null pointer, m <= 0, source out of range ...) */
+  GDN_ERR_NO_DEVICE = -2, /* no HIP device: the product has no CPU fallback */
+  GDN_ERR_HIP = -3,       /* a HIP runtime call failed */
+  GDN_ERR_OOM = -4,       /* device allocation failed */
+  GDN_ERR_OVERFLOW = -5   /* a device worklist overflowed (never silently dropped) */
+} gdn_status;
+
+/* Per-call report.  solve_ms has the boundary of the reference's Timer (graph resident,
+ * first kernel .. final sync; src/pr/base.cu:108-128, src/bfs/linear_base.cu:62-80):
+ * it excludes h2d_ms (graph + label upload) and includes prep_ms only where stated. */
+typedef struct gdn_stats {
+  int32_t iterations;       /* PR iterations / BFS levels / CC rounds / SSSP phases */
+  int32_t reserved;
+  double solve_ms;
+  double h2d_ms;
+  double prep_ms;           /* solver-private layout preparation (tile tables, orientation) */
+  uint64_t edges_traversed; /* BFS/SSSP: sum of out-degrees of reached vertices; else nnz*iters */
+  double last_error;        /* PR: L1 change of the last iteration */
+} gdn_stats;
+
+const char *gdn_last_error(void);
+int gdn_device_count(int *count);
+int gdn_set_device(int device);
+
+/* ------------------------------------------------------------------------------------------
+ * Host API: one call == one reference XxxSolver call.
+ * ---------------------------------------------------------------------------------------- */
+
+/* replaces BFSSolver(Graph&, int source, DistT* dist): src/bfs/bfs.h:43; callers
+ * src/bfs/main.cc:22.  dist: in = MYINFINITY (1e9) everywhere (main.cc:21), out = hop count,
+ * unreachable stays 1e9.  in_rowptr/in_colidx nullable: when given (reverse or symmetrized
+ * graph) the direction-optimising path (src/bfs/omp_beamer.cc:97) is used. */
+int gdn_bfs(int32_t m, uint64_t nnz, const uint64_t *out_rowptr, const int32_t *out_colidx,
+            const uint64_t *in_rowptr, const int32_t *in_colidx, int32_t source, int32_t *dist,
+            gdn_stats *stats);
+
+/* replaces PRSolver(Graph&, ScoreT* scores): src/pr/pr.h:31; caller src/pr/main.cc:19.
+ * scores: in = 1/m (main.cc:17-18), out = PageRank.  Reference constants: damping kDamp 0.85
+ * (pr.h:6), epsilon EPSILON 1e-4 (pr.h:5), max_iter MAX_ITER 100 (pr.h:12).  out_degree[v] =
+ * Graph::get_degree(v) on the OUT-CSR (csr_graph.h:295); the gather runs over the IN-CSR. */
+int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in_colidx,
+           const int32_t *out_degree, float *scores, float damping, double epsilon, int32_t max_iter,
+           gdn_stats *stats);
+
+/* replaces SpmvSolver(Graph&, const ValueT* Ax, const ValueT* x, ValueT* y):
+ * src/spmv/spmv.h:29; caller src/spmv/main.cc:39.  y[i] += sum_k Ax[k]*x[Aj[k]] over the rows
+ * of (Ap, Aj) = g.in_rowptr()/g.in_colidx() (src/spmv/omp_base.cc:10-11). */
+int gdn_spmv(int32_t m, uint64_t nnz, const uint64_t *Ap, const int32_t *Aj, const float *Ax,
+             const float *x, float *y, gdn_stats *stats);
+
+/* replaces SSSPSolver(Graph&, int source, DistT* weight, DistT* dist, int delta):
+ * src/sssp/sssp.h:47; caller src/sssp/main.cc:27.  dist: in = kDistInf (INT_MAX,
+ * sssp.h:46), out = shortest distance.  weight[nnz] parallel to colidx, delta >= 1. */
+int gdn_sssp(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
+             const int32_t *weight, int32_t source, int32_t delta, int32_t *dist, gdn_stats *stats);
+
+/* replaces TCSolver(Graph&, uint64_t& total): src/tc/tc.h:7; caller src/tc/main.cc:17.
+ * oriented == 0: (rowptr, colidx) is a symmetric graph and the DAG orientation of
+ * src/common/graph.cc:67-113 is applied on the device first (as `Graph g(prefix, USE_DAG)`
+ * does, src/tc/main.cc:12); oriented != 0: already a DAG. */
+int gdn_tc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx, int32_t oriented,
+           uint64_t *total, gdn_stats *stats);
+
+/* replaces CCSolver(Graph&, CompT* comp): src/cc/cc.h:28; caller src/cc/main.cc:16.
+ * comp: in = i (main.cc:15), out = component label = minimum vertex id of the (weakly)
+ * connected component (fixpoint of src/cc/omp_base.cc:24-43).  in_* nullable (directed
+ * graphs pass the reverse graph like src/cc/omp_afforest.cc:64-76). */
+int gdn_cc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
+           const uint64_t *in_rowptr, const int32_t *in_colidx, int32_t *comp, gdn_stats *stats);
+
+/* ------------------------------------------------------------------------------------------
+ * Resident graphs (the reference re-uploads per Solver call: src/bfs/linear_base.cu:42-49).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gdn_graph gdn_graph;
+
+int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
+                     gdn_graph **out);
+/* wrap device arrays owned by the caller (e.g. torch tensors); nothing is copied */
+int gdn_graph_wrap_dev(int32_t m, uint64_t nnz, const uint64_t *d_rowptr, const int32_t *d_colidx,
+                       gdn_graph **out);
+int gdn_graph_free(gdn_graph *g);
+int gdn_graph_info(const gdn_graph *g, int32_t *m, uint64_t *nnz, const uint64_t **d_rowptr,
+                   const int32_t **d_colidx);
+/* out_degree[v] = rowptr[v+1]-rowptr[v] as int32 (Graph::get_degree, csr_graph.h:295) */
+int gdn_graph_degrees_dev(const gdn_graph *g, int32_t *d_degree, void *stream);
+/* reverse graph, csr_graph.h:170-194 build_reverse_graph (rows ascending) */
+int gdn_graph_transpose(const gdn_graph *g, gdn_graph **out);
+/* rows [row_lo,row_hi) as an independent graph (column ids stay global): the vertex-range
+ * shard one GPU holds in the multi-GPU PageRank/SpMV path */
+int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn_graph **out);
+/* download to caller-provided host arrays ((m+1) x u64, nnz x i32) */
+int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx);
+
+/* Device R-MAT generator + CSR builder (measurement input): Graph500 recipe of
+ * include/generator.h:81-114 on the counter-based RNG documented in gardenia_amd/graphio.py,
+ * cleaned like csr_graph.h:108,127,132-143 (self loops and duplicates dropped, rows ascending).
+ * Either output may be NULL. */
+int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute,
+                   gdn_graph **out_csr, gdn_graph **in_csr);
+
+/* ------------------------------------------------------------------------------------------
+ * _dev API -- PageRank (graph resident, vectors are device pointers)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct gdn_pr_plan gdn_pr_plan;
+
+/* in_csr: IN-CSR of the m_local rows this device owns (global row ids row_base ..
+ * row_base+m_local-1; column ids in [0,m_global)).  d_out_degree: m_local entries.
+ * Single GPU: row_base = 0, m_global = m_local. */
+int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
+                       int32_t row_base, gdn_pr_plan **plan);
+int gdn_pr_plan_free(gdn_pr_plan *plan);
+/* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */
+int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contrib, void *stream);
+/* one fused pull iteration (src/pr/base.cu:19 pull_step + :37 l1norm + next :14 contrib):
+ *   sum = SUM contrib_in[col]; new = base + damping*sum; diff += |new - scores[v]|;
+ *   scores[v] = new; contrib_out[row_base+v] = new/out_degree[v]
+ * contrib_in/out are m_global-sized and must be different buffers; d_diff receives the L1
+ * change of the local rows (double, deterministic reduction order). */
+int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                    double *d_diff, float damping, void *stream);
+/* algorithmic bytes of one pull iteration on this plan:
+ * 8(m+1) + 4 nnz [colidx] + 4 nnz [contrib gather] + 16 m */
+uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan);
+
+/* _dev API -- SpMV */
+typedef struct gdn_spmv_plan gdn_spmv_plan;
+int gdn_spmv_plan_create(const gdn_graph *csr, gdn_spmv_plan **plan);
+int gdn_spmv_plan_free(gdn_spmv_plan *plan);
+/* y[v] += SUM Ax[k]*x[Aj[k]]   (src/spmv/base.cu:13, warp.cu:26, vector.cu:27 superseded) */
+int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream);
+uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan);
+
+/* _dev API -- BFS / SSSP / CC / TC on resident graphs; label arrays are device pointers and
+ * are (re)initialised by the call.  Synchronous (they read frontier sizes every level like
+ * src/bfs/linear_base.cu:73). */
+int gdn_bfs_dev(const gdn_graph *out_csr, const gdn_graph *in_csr /*nullable*/, int32_t source,
+                int32_t *d_dist, gdn_stats *stats);
+int gdn_sssp_dev(const gdn_graph *csr, const int32_t *d_weight, int32_t source, int32_t delta,
+                 int32_t *d_dist, gdn_stats *stats);
+int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,
+               gdn_stats *stats);
+int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GARDENIA_HIP_H_ */

@@ -1,0 +1,58 @@
+"""CPU-side checks of the drop-in boundary: the library loads, exports every symbol that
+include/gardenia_hip.h declares, the ctypes table covers the header, and -- without a GPU --
+every compute entry point fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gardenia_amd import _cabi
+
+HEADER = os.path.join(ROOT, "include", "gardenia_hip.h")
+
+
+def declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gdn_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    syms = declared_symbols()
+    assert len(syms) >= 30
+    L = _cabi.lib()
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in gardenia_hip.h but not exported"
+        assert s in _cabi.PROTOTYPES, f"{s} has no ctypes prototype"
+    assert sorted(_cabi.PROTOTYPES) == syms
+
+
+def test_stats_struct_layout_matches_header():
+    assert C.sizeof(_cabi.GdnStats) == 48
+    assert _cabi.GdnStats.solve_ms.offset == 8 and _cabi.GdnStats.edges_traversed.offset == 32
+
+
+def test_no_cpu_fallback_without_gpu():
+    if _cabi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    from gardenia_amd import graphio, solvers
+    g = solvers.Graph(csr=graphio.rmat_graph(6, 4), need_reverse=True)
+    dist = np.full(g.V(), solvers.MYINFINITY, np.int32)
+    with pytest.raises(_cabi.GardeniaError) as ei:
+        solvers.BFSSolver(g, 0, dist)
+    assert ei.value.status == _cabi.GDN_ERR_NO_DEVICE
+    scores = np.full(g.V(), 1.0 / g.V(), np.float32)
+    with pytest.raises(_cabi.GardeniaError):
+        solvers.PRSolver(g, scores)
+    assert np.all(dist == solvers.MYINFINITY)  # nothing computed
+
+
+def test_invalid_arguments_are_reported_not_fatal():
+    L = _cabi.lib()
+    st = _cabi.GdnStats()
+    assert L.gdn_bfs(0, 0, None, None, None, None, 0, None, C.byref(st)) == _cabi.GDN_ERR_INVALID
+    assert b"invalid argument" in L.gdn_last_error()
+    assert L.gdn_pr(4, 0, None, None, None, None, 0.85, 1e-4, 100, None) == _cabi.GDN_ERR_INVALID

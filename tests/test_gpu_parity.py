@@ -1,0 +1,244 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against (a) the golden vectors
+produced by the reference itself and (b) the CPU oracle on seeded inputs.  Bit-exact for BFS
+depths, SSSP distances, CC labels and TC counts; PageRank/SpMV within 1e-4 relative
+(BASELINE.json north_star)."""
+import numpy as np
+import pytest
+
+from conftest import csr_from, golden
+from gardenia_amd import graphio, solvers
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-4  # north_star: "PR/SpMV within 1e-4 relative"
+
+
+def _graph(d, sym=False):
+    g = csr_from(d)
+    gi = csr_from(d, "in_") if "in_rowptr" in d else None
+    return solvers.Graph(csr=g, in_csr=gi, symmetrize=sym, need_reverse=gi is not None and not sym)
+
+
+# ------------------------------------------------------------------ BFS
+@pytest.mark.parametrize("case", ["test_bc_dir", "test_bc_sym", "chesapeake_sym", "4_dir", "rmat10_dir", "rmat12_dir"])
+@pytest.mark.parametrize("with_reverse", [True, False])
+def test_bfs_golden(case, with_reverse):
+    d = golden("bfs_" + case)
+    g = solvers.Graph(csr=csr_from(d), in_csr=csr_from(d, "in_") if with_reverse else None)
+    dist = np.full(g.V(), solvers.MYINFINITY, np.int32)
+    st = solvers.BFSSolver(g, int(d["source"]), dist)
+    assert np.array_equal(dist, d["dist"])
+    assert st["iterations"] >= 1
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(14, 16, 1), (16, 16, 2), (18, 8, 3)])
+def test_bfs_vs_oracle_rmat(orc, scale, ef, seed):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    gi = graphio.transpose(g)
+    s = graphio.first_nonisolated(g)
+    want = orc.bfs_serial(g, s)
+    for rev in (gi, None):
+        dist = np.full(g.m, solvers.MYINFINITY, np.int32)
+        st = solvers.BFSSolver(solvers.Graph(csr=g, in_csr=rev), s, dist)
+        assert np.array_equal(dist, want)
+        reached = want != solvers.MYINFINITY
+        assert st["edges_traversed"] == int(g.degrees()[reached].astype(np.int64).sum())
+
+
+def test_bfs_star_and_chain(orc):
+    # a hub with 20000 out-neighbours (big-row path) feeding a chain (many tiny levels)
+    n = 20001 + 300
+    src = np.concatenate([np.zeros(20000, np.int64), np.arange(20000, n - 1)])
+    dst = np.concatenate([np.arange(1, 20001), np.arange(20001, n)])
+    g = graphio.build_csr(n, src, dst)
+    dist = np.full(n, solvers.MYINFINITY, np.int32)
+    solvers.BFSSolver(solvers.Graph(csr=g, in_csr=graphio.transpose(g)), 0, dist)
+    assert np.array_equal(dist, orc.bfs_serial(g, 0))
+    assert dist[-1] == 301
+
+
+# ------------------------------------------------------------------ PR
+@pytest.mark.parametrize("case", ["test_pr", "chesapeake_sym", "rmat10", "rmat12"])
+def test_pr_golden(case):
+    d = golden("pr_" + case)
+    g = solvers.Graph(csr=csr_from(d), in_csr=csr_from(d, "in_"))
+    scores = np.full(g.V(), np.float32(1.0) / np.float32(g.V()), np.float32)
+    st = solvers.PRSolver(g, scores)
+    assert st["iterations"] == int(d["iterations"])
+    np.testing.assert_allclose(scores, d["scores"], rtol=REL_TOL, atol=0)
+    assert abs(st["last_error"] - d["trace"][-1]) < 5e-7
+
+
+def test_pr_trace_of_reference_repo():
+    import json, os
+    from conftest import GOLDEN
+    gold = json.load(open(os.path.join(GOLDEN, "pr_trace_golden.json")))
+    g = solvers.Graph(os.path.join(GOLDEN, "graphs", "test_pr"), "mtx", False, True)
+    scores = np.full(g.V(), np.float32(1.0) / np.float32(g.V()), np.float32)
+    st = solvers.PRSolver(g, scores)
+    assert st["iterations"] == gold["iterations"]
+    assert "%.6f" % st["last_error"] == "%.6f" % gold["trace"][-1]
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(14, 16, 5), (17, 16, 6), (12, 64, 7)])
+def test_pr_vs_oracle_rmat(orc, scale, ef, seed):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st = solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), scores)
+    assert st["iterations"] == it
+    np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+    assert orc.pr_verify_error(g, scores) < 1e-4  # PRVerifier criterion, src/pr/verifier.cc:53
+
+
+def test_pr_is_bitwise_reproducible():
+    g = graphio.rmat_graph(15, 16, seed=9)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    runs = []
+    for _ in range(3):
+        s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        solvers.PRSolver(G, s)
+        runs.append(s)
+    assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
+
+
+def test_pr_hub_row_spanning_tiles(orc):
+    # vertex 0 has 50000 in-neighbours: its row spans > 12 merge-path tiles
+    n = 60000
+    src = np.concatenate([np.arange(1, 50001), np.zeros(100, np.int64), np.arange(1, 2000)])
+    dst = np.concatenate([np.zeros(50000, np.int64), np.arange(50001, 50101), np.arange(2, 2001)])
+    g = graphio.build_csr(n, src, dst)
+    gi = graphio.transpose(g)
+    deg = np.maximum(g.degrees(), 0)
+    want = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+    orc.pr_iterate(gi, deg, want, 5)
+    scores = np.full(n, np.float32(1.0) / np.float32(n), np.float32)
+    solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), scores, epsilon=0.0, max_iter=5)
+    np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+
+
+# ------------------------------------------------------------------ SpMV
+@pytest.mark.parametrize("case", ["test_bc", "chesapeake_sym", "rmat10_rand"])
+def test_spmv_golden(orc, case):
+    d = golden("spmv_" + case)
+    gi = csr_from(d, "in_")
+    if "Ax" in d:
+        Ax, x, y0 = d["Ax"], d["x"], d["y0"]
+    else:
+        Ax, x, y0 = np.full(gi.nnz, 0.2, np.float32), np.full(gi.m, 0.3, np.float32), np.zeros(gi.m, np.float32)
+    y = np.array(y0, dtype=np.float32)
+    solvers.SpmvSolver(solvers.Graph(csr=csr_from(d), in_csr=gi), Ax, x, y)
+    np.testing.assert_allclose(y, d["y"], rtol=REL_TOL, atol=1e-30)
+    assert orc.spmv_max_rel_error(y, d["y"]) <= 5 * np.sqrt(np.finfo(np.float32).eps)  # SpmvVerifier
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(15, 16, 11), (18, 16, 12)])
+def test_spmv_vs_oracle_rmat(orc, scale, ef, seed):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    gi = graphio.transpose(g)
+    rng = np.random.default_rng(seed)
+    Ax, x = rng.random(gi.nnz, dtype=np.float32), rng.random(gi.m, dtype=np.float32)
+    y0 = rng.random(gi.m, dtype=np.float32)
+    want = orc.spmv(gi, Ax, x, y0)
+    y = y0.copy()
+    solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x, y)
+    np.testing.assert_allclose(y, want, rtol=REL_TOL, atol=0)
+    # linearity: A(2x) == 2 A x exactly in fp32 (power-of-two scaling)
+    y2 = np.zeros(gi.m, np.float32)
+    y1 = np.zeros(gi.m, np.float32)
+    solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x, y1)
+    solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x * np.float32(2), y2)
+    assert np.array_equal(y2, y1 * np.float32(2))
+
+
+# ------------------------------------------------------------------ SSSP
+@pytest.mark.parametrize("case", ["test_bc_unit", "chesapeake_unit", "rmat10_unit", "rmat10_w255"])
+@pytest.mark.parametrize("delta", [1, 7, 1 << 20])
+def test_sssp_golden(case, delta):
+    d = golden("sssp_" + case)
+    g = solvers.Graph(csr=csr_from(d))
+    dist = np.full(g.V(), solvers.K_DIST_INF, np.int32)
+    solvers.SSSPSolver(g, int(d["source"]), d["weight"], dist, delta)
+    assert np.array_equal(dist, d["dist"])
+
+
+@pytest.mark.parametrize("scale,ef,seed,delta", [(14, 16, 21, 1), (16, 16, 22, 32), (17, 8, 23, 100)])
+def test_sssp_vs_oracle_rmat(orc, scale, ef, seed, delta):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    rng = np.random.default_rng(seed)
+    wt = rng.integers(1, 256, size=g.nnz).astype(np.int32)  # GAP convention, generator.h:136
+    s = graphio.first_nonisolated(g)
+    want = orc.sssp_dijkstra(g, wt, s)
+    dist = np.full(g.m, solvers.K_DIST_INF, np.int32)
+    solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, dist, delta)
+    assert np.array_equal(dist, want)
+
+
+# ------------------------------------------------------------------ CC
+@pytest.mark.parametrize("case", ["test_cc_sym", "chesapeake_sym", "rmat10_sym", "rmat10_dir"])
+def test_cc_golden(orc, case):
+    d = golden("cc_" + case)
+    sym = bool(d["symmetrize"])
+    g = solvers.Graph(csr=csr_from(d), in_csr=csr_from(d, "in_"), symmetrize=sym, need_reverse=not sym)
+    comp = np.arange(g.V(), dtype=np.int32)
+    solvers.CCSolver(g, comp)
+    assert np.array_equal(comp, d["comp_sv"])
+    if sym:
+        assert orc.cc_verify(csr_from(d), comp)  # CCVerifier criterion
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(14, 4, 31), (16, 16, 32), (18, 2, 33)])
+def test_cc_vs_oracle_rmat(orc, scale, ef, seed):
+    g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
+    want, _ = orc.cc_sv(g)
+    comp = np.arange(g.m, dtype=np.int32)
+    solvers.CCSolver(solvers.Graph(csr=g, symmetrize=True), comp)
+    assert np.array_equal(comp, want)
+    # min-id property
+    assert np.all(comp <= np.arange(g.m)) and np.all(comp[comp] == comp)
+
+
+# ------------------------------------------------------------------ TC
+@pytest.mark.parametrize("case", ["chesapeake_sym", "rmat10_sym"])
+def test_tc_golden(case):
+    d = golden("tc_" + case)
+    total, st = solvers.TCSolver(solvers.Graph(csr=csr_from(d, "sym_"), symmetrize=True))
+    assert total == int(d["total"])
+    assert st["edges_traversed"] == len(d["dag_colidx"])
+    total2, _ = solvers.TCSolver(solvers.Graph(csr=csr_from(d, "dag_")), oriented=True)
+    assert total2 == int(d["total"])
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(13, 16, 41), (16, 8, 42)])
+def test_tc_vs_oracle_rmat(orc, scale, ef, seed):
+    g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
+    want = orc.tc(orc.tc_orient(g))
+    total, _ = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want
+
+
+# ------------------------------------------------------------------ device graph builder
+def test_device_rmat_matches_numpy_generator():
+    import ctypes as C
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    for scale, ef in [(10, 16), (14, 8)]:
+        want = graphio.rmat_graph(scale, ef)
+        want_in = graphio.transpose(want)
+        go, gi = C.c_void_p(), C.c_void_p()
+        _cabi.check(L.gdn_rmat_build(scale, ef, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+        for h, w in ((go, want), (gi, want_in)):
+            m, nnz = C.c_int32(), C.c_uint64()
+            _cabi.check(L.gdn_graph_info(h, C.byref(m), C.byref(nnz), None, None))
+            assert (m.value, nnz.value) == (w.m, w.nnz)
+            rp, ci = np.empty(w.m + 1, np.uint64), np.empty(w.nnz, np.int32)
+            _cabi.check(L.gdn_graph_download(h, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+            assert np.array_equal(rp, w.rowptr) and np.array_equal(ci, w.colidx)
+        gt = C.c_void_p()
+        _cabi.check(L.gdn_graph_transpose(go, C.byref(gt)))
+        rp, ci = np.empty(want.m + 1, np.uint64), np.empty(want.nnz, np.int32)
+        _cabi.check(L.gdn_graph_download(gt, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+        assert np.array_equal(rp, want_in.rowptr) and np.array_equal(ci, want_in.colidx)
+        for h in (go, gi, gt):
+            L.gdn_graph_free(h)
