@@ -19,6 +19,8 @@
 //
 // Row offsets are 64-bit end to end; everything tile-local is 16/32-bit.
 #pragma once
+#include <vector>
+
 #include "gdn_common.hpp"
 
 #define MP_IPT 16
@@ -37,6 +39,14 @@ struct MpPlan {
   DevBuf<float> tile_head;   // ntiles: partial sum of the tile's first row when it began earlier
   DevBuf<double> partial;    // ntiles + nfix_blocks (+ reduction scratch)
   DevBuf<double> red_scratch;
+  // optional per-launch timing of the dominant kernel (mp_tile_kernel) with HIP events on the
+  // launch stream; feeds bench.py's roofline.achieved
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // pairs
+  size_t ev_used = 0;
+  ~MpPlan() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
 };
 
 #ifdef __HIPCC__
@@ -267,11 +277,43 @@ static inline int mp_plan_build(MpPlan &p, const gdn_graph *g, hipStream_t s) {
   return GDN_OK;
 }
 
+// reset != 0: (re)arm per-launch timing with room for max_launches; reset == 0: wait for the
+// recorded events and report the summed duration of the dominant kernel and the launch count.
+static inline int mp_plan_timing(MpPlan &p, int reset, int max_launches, double *total_ms, int32_t *launches) {
+  if (reset) {
+    while (p.ev.size() < (size_t)max_launches * 2) {
+      hipEvent_t e;
+      GDN_HIP(hipEventCreate(&e));
+      p.ev.push_back(e);
+    }
+    p.ev_used = 0;
+    p.timing = max_launches > 0;
+    return GDN_OK;
+  }
+  double tot = 0;
+  for (size_t i = 0; i + 1 < p.ev_used; i += 2) {
+    GDN_HIP(hipEventSynchronize(p.ev[i + 1]));
+    float ms = 0;
+    GDN_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int32_t)(p.ev_used / 2);
+  p.timing = false;
+  return GDN_OK;
+}
+
 // One pass over the graph with Op; d_out (nullable) receives the reduced double.
 template <class Op>
 static inline int mp_run(MpPlan &p, const Op &op, double *d_out, hipStream_t s) {
+  const bool timed = p.timing && p.ev_used + 2 <= p.ev.size();
+  if (timed) GDN_HIP(hipEventRecord(p.ev[p.ev_used], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(mp_tile_kernel<Op>), dim3(p.ntiles), dim3(GDN_BLOCK), 0, s, p.rowptr,
                      p.colidx, p.tile_row.p, p.total_items, p.tile_carry.p, p.tile_head.p, p.partial.p, op);
+  if (timed) {
+    GDN_HIP(hipEventRecord(p.ev[p.ev_used + 1], s));
+    p.ev_used += 2;
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(mp_fixup_kernel<Op>), dim3(p.nfix_blocks), dim3(GDN_BLOCK), 0, s,
                      p.rowptr, p.tile_row.p, p.ntiles, p.tile_carry.p, p.tile_head.p,
                      p.partial.p + p.ntiles, op);

@@ -94,6 +94,12 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   return mp_run(plan->mp, op, d_diff, (hipStream_t)stream);
 }
 
+int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
+                            int32_t *launches) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+}
+
 uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan) {
   if (!plan) return 0;
   const uint64_t m = (uint64_t)plan->mp.m, nnz = plan->mp.nnz;

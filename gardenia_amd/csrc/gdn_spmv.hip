@@ -60,6 +60,12 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   return mp_run(plan->mp, op, nullptr, (hipStream_t)stream);
 }
 
+int gdn_spmv_plan_kernel_time(gdn_spmv_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
+                              int32_t *launches) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+}
+
 // 8(m+1) + 4 nnz [Aj] + 4 nnz [Ax] + 4 nnz [x gather] + 8 m [y r+w]
 uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan) {
   if (!plan) return 0;

@@ -1,0 +1,135 @@
+"""Vertex-range sharded pull PageRank across the GPUs of one node.
+
+The reference has no multi-GPU path; this is the MI355X-native addition the north star asks
+for: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI), rows of the
+in-CSR split into `world` contiguous vertex ranges of equal length, column ids global.
+Per iteration each rank
+
+  1. runs the fused pull kernel on its rows: reads the full contrib vector, writes its slice of
+     the next contrib vector and its local L1 change          (C-ABI gdn_pr_pull_dev)
+  2. all-gathers the next contrib vector in place               (one RCCL all-gather, m*4 B)
+  3. all-reduces the 8-byte L1 change                           (convergence test)
+
+The north star words step 2 as "all-reduce of the rank vector"; the all-gather moves half the
+bytes for the same result (each slice has exactly one writer).  BFS/SSSP stay single-GPU.
+
+`backend` abstracts the local kernel so that the orchestration (partition, buffer swap,
+collectives, convergence) is exercised by world_size-2 gloo tests on CPU with a test-side
+backend; the product backend is HipPageRankBackend (no CPU fallback inside this package).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+
+def vertex_range(rank: int, world: int, m: int) -> Tuple[int, int, int]:
+    """(lo, hi, chunk): rank owns rows [lo,hi); chunk = ceil(m/world) is the all-gather unit."""
+    chunk = (m + world - 1) // world
+    lo = min(rank * chunk, m)
+    hi = min(lo + chunk, m)
+    return lo, hi, chunk
+
+
+class ShardedPageRank:
+    def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None,
+                 damping: float = 0.85):
+        self.be = backend
+        self.m = m_global
+        self.rank, self.world, self.dist = rank, world, dist
+        self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
+        self.damping = damping
+        self.cur = 0  # index of the contrib buffer holding the current iteration's input
+        self.iterations = 0
+
+    def init_contrib(self):
+        """contrib = score/out_degree for the local rows, then gather (src/pr/base.cu:14)."""
+        self.be.contrib(self.cur)
+        self._gather(self.cur)
+
+    def _gather(self, which):
+        if self.world > 1:
+            full = self.be.contrib_full(which)
+            mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
+            self.dist.all_gather_into_tensor(full, mine)
+
+    def step(self):
+        """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
+        nxt = self.cur ^ 1
+        self.be.pull(self.cur, nxt, self.damping)
+        self._gather(nxt)
+        self.cur = nxt
+        self.iterations += 1
+
+    def global_diff(self) -> float:
+        """Sum of the local L1 changes of the LAST step over all ranks (blocking)."""
+        d = self.be.diff_tensor()
+        if self.world > 1:
+            self.dist.all_reduce(d)
+        return float(d.item())
+
+    def solve(self, epsilon: float = 1e-4, max_iter: int = 100) -> Tuple[int, float]:
+        """Iterate like src/pr/omp_base.cc:20-37; returns (iterations as printed, last error)."""
+        self.init_contrib()
+        err = 0.0
+        it = 0
+        for it in range(max_iter):
+            self.step()
+            err = self.global_diff()
+            if err < epsilon:
+                break
+        return it + 1, err
+
+
+class HipPageRankBackend:
+    """Local shard on one MI355X: torch device tensors + the _dev entry points of the C-ABI."""
+
+    def __init__(self, torch, in_csr_handle, out_degree_local, m_global: int, lo: int, hi: int, chunk: int,
+                 world: int, device):
+        from . import _cabi
+        self.torch, self._cabi, self.L = torch, _cabi, _cabi.lib()
+        self.device = device
+        self.m_local = hi - lo
+        self.out_degree = out_degree_local  # int32 device tensor, m_local
+        n_full = chunk * world
+        self.contribs = [torch.zeros(n_full, dtype=torch.float32, device=device) for _ in range(2)]
+        self.scores = torch.full((max(self.m_local, 1),), 1.0 / m_global, dtype=torch.float32, device=device)
+        self.diff = torch.zeros(1, dtype=torch.float64, device=device)
+        self.plan = C.c_void_p()
+        _cabi.check(self.L.gdn_pr_plan_create(in_csr_handle, C.c_void_p(out_degree_local.data_ptr()), m_global, lo,
+                                              C.byref(self.plan)))
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def contrib_full(self, which):
+        return self.contribs[which]
+
+    def diff_tensor(self):
+        return self.diff
+
+    def contrib(self, which):
+        self._cabi.check(self.L.gdn_pr_contrib_dev(self.plan, C.c_void_p(self.scores.data_ptr()),
+                                                   C.c_void_p(self.contribs[which].data_ptr()), self._stream()))
+
+    def pull(self, cin, cout, damping):
+        self._cabi.check(self.L.gdn_pr_pull_dev(self.plan, C.c_void_p(self.contribs[cin].data_ptr()),
+                                                C.c_void_p(self.scores.data_ptr()),
+                                                C.c_void_p(self.contribs[cout].data_ptr()),
+                                                C.c_void_p(self.diff.data_ptr()), float(damping), self._stream()))
+
+    def iter_bytes(self) -> int:
+        return int(self.L.gdn_pr_iter_bytes(self.plan))
+
+    def arm_kernel_timing(self, max_launches: int):
+        self._cabi.check(self.L.gdn_pr_plan_kernel_time(self.plan, 1, max_launches, None, None))
+
+    def read_kernel_timing(self):
+        tot, n = C.c_double(0), C.c_int32(0)
+        self._cabi.check(self.L.gdn_pr_plan_kernel_time(self.plan, 0, 0, C.byref(tot), C.byref(n)))
+        return tot.value, n.value
+
+    def close(self):
+        if self.plan:
+            self.L.gdn_pr_plan_free(self.plan)
+            self.plan = C.c_void_p()

@@ -151,6 +151,11 @@ int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contri
  * change of the local rows (double, deterministic reduction order). */
 int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
                     double *d_diff, float damping, void *stream);
+/* Per-launch HIP-event timing of the dominant kernel (the merge-path tile kernel) on the launch
+ * stream.  reset != 0 arms it for up to max_launches launches; reset == 0 waits for the events
+ * and reports their summed duration and count (bench.py roofline.achieved). */
+int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
+                            int32_t *launches);
 /* algorithmic bytes of one pull iteration on this plan:
  * 8(m+1) + 4 nnz [colidx] + 4 nnz [contrib gather] + 16 m */
 uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan);
@@ -161,6 +166,8 @@ int gdn_spmv_plan_create(const gdn_graph *csr, gdn_spmv_plan **plan);
 int gdn_spmv_plan_free(gdn_spmv_plan *plan);
 /* y[v] += SUM Ax[k]*x[Aj[k]]   (src/spmv/base.cu:13, warp.cu:26, vector.cu:27 superseded) */
 int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream);
+int gdn_spmv_plan_kernel_time(gdn_spmv_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
+                              int32_t *launches);
 uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan);
 
 /* _dev API -- BFS / SSSP / CC / TC on resident graphs; label arrays are device pointers and

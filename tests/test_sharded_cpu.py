@@ -1,0 +1,61 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo jobs run the product's sharded PageRank
+orchestration (partition, in-place all-gather of the contrib vector, all-reduce of the L1
+change, convergence test) with a numpy stand-in for the HIP kernel, and must reproduce the
+single-process oracle."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from gardenia_amd import graphio
+from gardenia_amd.sharded import vertex_range
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_vertex_range_partition():
+    for m, w in [(10, 2), (10, 3), (7, 8), (1 << 20, 8)]:
+        ranges = [vertex_range(r, w, m) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == m
+        for a, b in zip(ranges, ranges[1:]):
+            assert a[1] == b[0]
+        assert all(hi - lo <= c for lo, hi, c in ranges) and ranges[0][2] * w >= m
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_pagerank_gloo(orc, tmp_path, world):
+    scale, ef = 8, 8
+    out = str(tmp_path / "pr")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"),
+                                       str(scale), str(ef), out], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    # single-process oracle on the same graph
+    g = graphio.rmat_graph(scale, ef, seed=77)
+    m = g.m - 3
+    src, dst = graphio.csr_to_coo(g)
+    keep = (src < m) & (dst < m)
+    g = graphio.build_csr(m, src[keep], dst[keep])
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    got = np.concatenate([np.load(f"{out}.{r}.npy") for r in range(world)])
+    meta = np.load(f"{out}.meta.npy")
+    assert int(meta[0]) == it
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+    assert abs(meta[1] - trace[-1]) < 1e-9
