@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=int, default=27)
     ap.add_argument("--edge-factor", type=int, default=16)
+    ap.add_argument("--layout", choices=["auto", "csr", "pb"], default="auto",
+                    help="edge layout of the PageRank plan (include/gardenia_hip.h GDN_LAYOUT_*)")
     ap.add_argument("--no-bfs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -88,7 +90,15 @@ def main():
     sm, snnz = C.c_int32(), C.c_uint64()
     _cabi.check(L.gdn_graph_info(shard, C.byref(sm), C.byref(snnz), None, None))
     deg_local = out_degree[lo:hi].contiguous()
-    be = HipPageRankBackend(torch, shard, deg_local, m, lo, hi, chunk, world, device)
+    t0 = time.time()
+    be = HipPageRankBackend(torch, shard, deg_local, m, lo, hi, chunk, world, device,
+                            layout={"auto": -1, "csr": 0, "pb": 1}[args.layout])
+    torch.cuda.synchronize()
+    t_plan = time.time() - t0
+    layout_name = {0: "natural vertex order, in-CSR u64 offsets / i32 ids, merge-path tiles",
+                   1: "propagation-blocked tiles (source chunk of %d ids x destination bin of %d rows, u16 local "
+                      "ids, LDS-resident slices, 2^-62 fixed-point LDS accumulation)"
+                      % (1 << (be.log_blk // 100), 1 << (be.log_blk % 100))}[be.layout]
     pr = ShardedPageRank(be, m, rank, world, dist if world > 1 else None)
     pr.init_contrib()
 
@@ -107,8 +117,10 @@ def main():
         pr.step()
     barrier()
     elapsed = time.perf_counter() - t_start
-    ktot_ms, klaunches = be.read_kernel_timing()
+    (kA_ms, kB_ms), klaunches = be.read_kernel_timing()
+    ktot_ms = kA_ms + kB_ms
     last_err = pr.global_diff()
+    be.check()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -141,11 +153,14 @@ def main():
         "config": {"workload": "PageRank pull iteration on R-MAT scale %d, avg degree %d (Graph500 "
                                "A=.57 B=.19 C=.19, seed 27491095, self loops+duplicates dropped)"
                                % (args.scale, args.edge_factor),
-                   "vertices": m, "edges": nnz, "layout": "natural vertex order, in-CSR u64 offsets / i32 ids",
+                   "vertices": m, "edges": nnz, "layout": layout_name, "plan_build_s": t_plan,
                    "partition": "vertex-range x%d, RCCL all-gather of contrib" % world if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "mp_tile_kernel<PrOp>", "kernel_ms": k_avg_ms, "launches": klaunches,
+                     "kernel": "mp_tile_kernel<PrOp>" if be.layout == 0 else
+                     "pb_expand_kernel + pb_accumulate_kernel<PrOp> (one iteration = both)",
+                     "kernel_ms": k_avg_ms, "launches": klaunches,
+                     "kernel_ms_parts": [kA_ms / max(klaunches, 1), kB_ms / max(klaunches, 1)],
                      "algorithmic_bytes_per_launch": iter_bytes},
         "gteps_pr": value / 1e9, "pr_last_l1_change": last_err, "graph_build_s": t_build,
     }

@@ -17,6 +17,7 @@ GDN_ERR_NO_DEVICE = -2
 GDN_ERR_HIP = -3
 GDN_ERR_OOM = -4
 GDN_ERR_OVERFLOW = -5
+GDN_LAYOUT_AUTO, GDN_LAYOUT_CSR, GDN_LAYOUT_PB = -1, 0, 1
 
 
 class GdnStats(C.Structure):
@@ -60,7 +61,9 @@ PROTOTYPES = {
     "gdn_graph_slice_rows": (C.c_int, [_vp, _i32, _i32, _pp]),
     "gdn_graph_download": (C.c_int, [_vp, _vp, _vp]),
     "gdn_rmat_build": (C.c_int, [_i32, _i32, _u64, _i32, _pp, _pp]),
-    "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _pp]),
+    "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pp]),
+    "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
+    "gdn_pr_plan_check": (C.c_int, [_vp]),
     "gdn_pr_plan_free": (C.c_int, [_vp]),
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gdn_pr_pull_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp]),

@@ -16,6 +16,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "gdn_expand.hpp"
+#include "gdn_pb.hpp"
 
 #define RMAT_TA 2448131358u   // int(0.57 * 2^32)
 #define RMAT_TAB 3264175144u  // int(0.76 * 2^32)
@@ -115,12 +116,19 @@ __global__ void __launch_bounds__(GDN_BLOCK) zero_rowptr_kernel(eoff_t *rowptr, 
   if (i <= (unsigned)m) rowptr[i] = 0;
 }
 
-// sorted 64-bit keys (row<<32|col) -> owned CSR graph; drops self loops and duplicates
-static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n,
-                         int32_t m, int row_bits, gdn_graph **out) {
+static int bits_for(int32_t m) {
+  int b = 1;
+  while (b < 32 && (1ll << b) < (long long)m) b++;
+  return b;
+}
+
+// radix sort of the low `bits` bits; returns the buffer holding the result and frees the other
+static int sort_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n,
+                     unsigned bits, const unsigned long long **sorted_out) {
   rocprim::double_buffer<unsigned long long> db(ka.p, kb.p);
   size_t tmp_bytes = 0;
-  hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)n, 0u, (unsigned)(32 + row_bits), 0);
+  if (bits > 64) bits = 64;
+  hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)n, 0u, bits, 0);
   if (e != hipSuccess) {
     gdn_set_error("rocprim::radix_sort_keys(size query): %s", hipGetErrorString(e));
     return GDN_ERR_HIP;
@@ -128,7 +136,7 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
   {
     DevBuf<char> tmp;
     GDN_TRY(tmp.alloc(tmp_bytes));
-    e = rocprim::radix_sort_keys((void *)tmp.p, tmp_bytes, db, (size_t)n, 0u, (unsigned)(32 + row_bits), 0);
+    e = rocprim::radix_sort_keys((void *)tmp.p, tmp_bytes, db, (size_t)n, 0u, bits, 0);
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
       gdn_set_error("rocprim::radix_sort_keys: %s", hipGetErrorString(e));
@@ -136,9 +144,19 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
     }
   }
   const unsigned long long *sorted = db.current();
-  // free the non-current key buffer early: the flags/positions need the room at scale 27
+  // free the non-current key buffer early: what follows needs the room at scale 27
   if (sorted == ka.p) kb.release();
   else ka.release();
+  *sorted_out = sorted;
+  return GDN_OK;
+}
+
+// sorted 64-bit keys (row<<32|col) -> owned CSR graph; drops self loops and duplicates
+static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n,
+                         int32_t m, int row_bits, gdn_graph **out) {
+  const unsigned long long *sorted = nullptr;
+  GDN_TRY(sort_keys(ka, kb, n, (unsigned)(32 + row_bits), &sorted));
+  hipError_t e;
   DevBuf<unsigned> flag;
   DevBuf<eoff_t> pos;
   GDN_TRY(flag.alloc(n));
@@ -203,10 +221,236 @@ transpose_keys_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, Key
   gdn_expand_big_items(rowptr, big, vis);
 }
 
-static int bits_for(int32_t m) {
-  int b = 1;
-  while (b < 32 && (1ll << b) < (long long)m) b++;
-  return b;
+// ------------------------------------------------------------------------------------------
+// propagation-blocking layout (gdn_pb.hpp): edges sorted by (source chunk, destination bin,
+// destination row, source id)
+// ------------------------------------------------------------------------------------------
+struct PbKeyVis {
+  const vid_t *__restrict__ colidx;
+  unsigned long long *__restrict__ keys;
+  int log_chunk, log_bin;
+  int bin_bits;
+  int32_t v;
+  __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const unsigned row = (unsigned)__shfl(v, owner, 64);
+    if (valid) {
+      const unsigned col = (unsigned)colidx[k];
+      const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
+      const unsigned long long vl = row & ((1u << log_bin) - 1u), ul = col & ((1u << log_chunk) - 1u);
+      keys[k] = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | (vl << log_chunk) | ul;
+    }
+  }
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_keys_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, PbKeyVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_keys_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PbKeyVis vis) {
+  vis.v = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
+// tsu[t] = index of the first sorted key whose tile id (chunk*nbins + bin) is >= t
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_bounds_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int shift, int bin_bits,
+                 unsigned nbins, unsigned long long ntiles, eoff_t *__restrict__ tsu) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  const unsigned long long bmask = (1ull << bin_bits) - 1ull;
+  for (; i < n; i += stride) {
+    const unsigned long long k = keys[i] >> shift;
+    const long long t = (long long)((k >> bin_bits) * nbins + (k & bmask));
+    long long tp = -1;
+    if (i > 0) {
+      const unsigned long long kp = keys[i - 1] >> shift;
+      tp = (long long)((kp >> bin_bits) * nbins + (kp & bmask));
+    }
+    for (long long x = tp + 1; x <= t; x++) tsu[x] = i;
+    if (i + 1 == n)
+      for (long long x = t + 1; x <= (long long)ntiles; x++) tsu[x] = n;
+  }
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_fill_u64_kernel(eoff_t *p, unsigned long long n, eoff_t v) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_fill_u16_kernel(uint16_t *p, unsigned long long n, uint16_t v) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) p[i] = v;
+}
+
+// padded tile sizes in chunk-major (psz_c) and bin-major (psz_b) tile order
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_tile_sizes_kernel(const eoff_t *__restrict__ tsu, unsigned nchunks, unsigned nbins, uint32_t *__restrict__ psz_c,
+                     uint32_t *__restrict__ psz_b) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (t >= (unsigned long long)nchunks * nbins) return;
+  const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
+  const uint32_t sz = (uint32_t)(((tsu[t + 1] - tsu[t]) + 7) & ~(eoff_t)7);
+  psz_c[t] = sz;
+  psz_b[(unsigned long long)b * nchunks + c] = sz;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_ptrs_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, unsigned nchunks, unsigned nbins,
+               eoff_t *__restrict__ chunk_ptr, eoff_t *__restrict__ bin_ptr) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i <= nchunks) chunk_ptr[i] = pu[(unsigned long long)i * nbins];
+  if (i <= nbins) bin_ptr[i] = pv[(unsigned long long)i * nchunks];
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int log_chunk, int log_bin,
+                  int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
+                  const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
+                  uint16_t *__restrict__ V) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  const unsigned long long bmask = (1ull << bin_bits) - 1ull;
+  for (; i < n; i += stride) {
+    const unsigned long long k = keys[i];
+    const unsigned long long cb = k >> (log_chunk + log_bin);
+    const unsigned long long b = cb & bmask, c = cb >> bin_bits;
+    const unsigned long long t = c * nbins + b;
+    const unsigned long long off = i - tsu[t];
+    U[pu[t] + off] = (uint16_t)((unsigned)k & ((1u << log_chunk) - 1u));
+    V[pv[b * nchunks + c] + off] = (uint16_t)((unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u));
+  }
+}
+
+// group table: the q-th group of 8 of tile t in chunk-major order -> its group index in bin-major
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, unsigned nchunks, unsigned nbins,
+                 uint32_t *__restrict__ G) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (t >= (unsigned long long)nchunks * nbins) return;
+  const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
+  const eoff_t gu = pu[t] >> 3, ng = (pu[t + 1] - pu[t]) >> 3;
+  const eoff_t gv = pv[(unsigned long long)b * nchunks + c] >> 3;
+  for (eoff_t q = 0; q < ng; q++) G[gu + q] = (uint32_t)(gv + q);
+}
+
+int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p) {
+  GDN_REQUIRE(log_chunk >= 8 && log_chunk <= PB_MAX_LOG_CHUNK, "log_chunk");
+  GDN_REQUIRE(log_bin >= 8 && log_bin <= PB_MAX_LOG_BIN, "log_bin");
+  const int32_t m = g->m;
+  const unsigned long long n = g->nnz;
+  p.m_local = m;
+  p.m_global = m_global;
+  p.nnz = n;
+  p.log_chunk = log_chunk;
+  p.log_bin = log_bin;
+  p.nchunks = (unsigned)(((uint64_t)m_global + (1u << log_chunk) - 1) >> log_chunk);
+  p.nbins = (unsigned)(((uint64_t)m + (1u << log_bin) - 1) >> log_bin);
+  const int bin_bits = bits_for((int32_t)p.nbins);
+  const int chunk_bits = bits_for((int32_t)p.nchunks);
+  const unsigned long long ntiles = (unsigned long long)p.nchunks * p.nbins;
+  const unsigned long long gb = (n + GDN_BLOCK - 1) / GDN_BLOCK;
+  const unsigned grid_n = (unsigned)(gb > 262144ull ? 262144ull : (gb ? gb : 1));
+  DevBuf<eoff_t> tsu, pu, pv;
+  DevBuf<uint32_t> psz_c, psz_b;
+  GDN_TRY(tsu.alloc(ntiles + 1));
+  GDN_TRY(pu.alloc(ntiles + 1));
+  GDN_TRY(pv.alloc(ntiles + 1));
+  GDN_TRY(psz_c.alloc(ntiles));
+  GDN_TRY(psz_b.alloc(ntiles));
+  GDN_TRY(p.chunk_ptr.alloc((size_t)p.nchunks + 1));
+  GDN_TRY(p.bin_ptr.alloc((size_t)p.nbins + 1));
+  GDN_TRY(p.errflag.alloc(1));
+  GDN_HIP(hipMemset(p.errflag.p, 0, sizeof(unsigned)));
+  {
+    DevBuf<unsigned long long> ka, kb, bigitems;
+    DevBuf<unsigned> cnt;
+    const uint64_t bigcap64 = n / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+    const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+    GDN_TRY(ka.alloc(n));
+    GDN_TRY(kb.alloc(n));
+    GDN_TRY(bigitems.alloc(bigcap));
+    GDN_TRY(cnt.alloc(2));
+    GDN_HIP(hipMemset(cnt.p, 0, 8));
+    ExpBigList big;
+    big.items = bigitems.p;
+    big.capacity = bigcap;
+    big.count = cnt.p;
+    big.overflow = cnt.p + 1;
+    PbKeyVis vis;
+    vis.colidx = g->colidx;
+    vis.keys = ka.p;
+    vis.log_chunk = log_chunk;
+    vis.log_bin = log_bin;
+    vis.bin_bits = bin_bits;
+    vis.v = 0;
+    hipLaunchKernelGGL(pb_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
+    hipLaunchKernelGGL(pb_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+    GDN_HIP(hipGetLastError());
+    unsigned h[2];
+    GDN_HIP(hipMemcpy(h, cnt.p, 8, hipMemcpyDeviceToHost));
+    if (h[1]) {
+      gdn_set_error("pb_build: device worklist overflow");
+      return GDN_ERR_OVERFLOW;
+    }
+    bigitems.release();
+    const unsigned long long *sorted = nullptr;
+    GDN_TRY(sort_keys(ka, kb, n, (unsigned)(chunk_bits + bin_bits + log_chunk + log_bin), &sorted));
+    if (n == 0) {
+      hipLaunchKernelGGL(pb_fill_u64_kernel, dim3(gdn_nblocks(ntiles + 1)), dim3(GDN_BLOCK), 0, 0, tsu.p, ntiles + 1,
+                         (eoff_t)0);
+    } else {
+      hipLaunchKernelGGL(pb_bounds_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk + log_bin, bin_bits,
+                         p.nbins, ntiles, tsu.p);
+    }
+    hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, p.nchunks, p.nbins,
+                       psz_c.p, psz_b.p);
+    GDN_HIP(hipGetLastError());
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_c.p, pu.p, (size_t)ntiles, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_b.p, pv.p, (size_t)ntiles, 0));
+    eoff_t n_pad = 0;
+    GDN_HIP(hipMemcpy(&n_pad, pu.p + ntiles, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    p.n_pad = n_pad;
+    if ((n_pad >> 3) > 0xFFFFFFFFull) {
+      gdn_set_error("pb_build: more than 2^35 padded edges");
+      return GDN_ERR_INVALID;
+    }
+    hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(p.nchunks > p.nbins ? p.nchunks : p.nbins) + 1)),
+                       dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins, p.chunk_ptr.p, p.bin_ptr.p);
+    GDN_TRY(p.U.alloc(n_pad + 8));
+    GDN_TRY(p.V.alloc(n_pad + 8));
+    GDN_TRY(p.G.alloc((n_pad >> 3) + 1));
+    const unsigned long long fb = (n_pad + 8 + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p,
+                       n_pad + 8, (uint16_t)(1u << log_chunk));
+    GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + 8) * sizeof(uint16_t), 0));
+    if (n)
+      hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
+                         p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p);
+    hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
+                       p.G.p);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipDeviceSynchronize());
+  }  // key buffers freed here
+  GDN_TRY(p.vals.alloc(p.n_pad + 8));
+  GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
+  GDN_TRY(p.partial.alloc(p.nbins));
+  GDN_TRY(p.red_scratch.alloc(2 * ((size_t)p.nbins / 4096 + 2)));
+  GDN_HIP(hipDeviceSynchronize());
+  return GDN_OK;
 }
 
 extern "C" {

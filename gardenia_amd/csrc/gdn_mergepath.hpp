@@ -297,7 +297,7 @@ static inline int mp_plan_timing(MpPlan &p, int reset, int max_launches, double 
     GDN_HIP(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
     tot += ms;
   }
-  if (total_ms) *total_ms = tot;
+  if (total_ms) total_ms[0] = tot;
   if (launches) *launches = (int32_t)(p.ev_used / 2);
   p.timing = false;
   return GDN_OK;

@@ -1,0 +1,206 @@
+// gdn_pb.hpp -- propagation-blocked row reduction with LDS-resident slices (PageRank pull).
+//
+// Why: on MI355X a divergent 4-byte gather costs a vector-memory issue slot per cache line;
+// tools/gather_probe measures 54 G gathers/s out of a 512 MiB table and ~200 G/s even when the
+// table sits in L2 -- against 1.8 T dwords/s for coalesced streams.  A CSR pull iteration on
+// RMAT-27 is 2^31 such gathers (38 ms, profiles/r01_csr_*).  tools/lds_probe: random
+// ds_read_b32 runs at 4.2 T/s and ds_add_u64 at 2.9 T/s chip-wide (ds_add_f32 only 0.2 T/s).
+// The reference's own answer to the gather wall is cache / propagation blocking
+// (include/segmenting.h, include/prop_blocking.h, src/pr/push_pb.cu, src/pr/partition.cu);
+// this is the CDNA4 form of it, built around the 160 KB LDS instead of a cache:
+//
+//   edges are grouped into TILES (source chunk c, destination bin b): chunk = 2^log_chunk
+//   consecutive source ids (fp32 slice = 128 KB of LDS), bin = 2^log_bin consecutive
+//   destination rows (u64 accumulators = 128 KB of LDS).  Every tile is padded to a multiple
+//   of 8 edges.  Static data per (padded) edge:
+//     U[e]  u16  source id within its chunk, CHUNK-major order (pad = chunk size -> a 0.0 slot)
+//     V[e'] u16  destination row within its bin, BIN-major order (pad = 0)
+//     G[e/8] u32 for each group of 8 edges in chunk-major order: its group index in bin-major
+//   Per iteration:
+//   phase A (pb_expand_kernel, one workgroup per chunk): contrib[chunk] -> LDS (coalesced);
+//       one flat sweep over the chunk's groups: 16-byte U load, 8 LDS gathers, two 16-byte
+//       stores into the bin-major vals array at G[g].
+//   phase B (pb_accumulate_kernel, one workgroup per bin): ONE contiguous range of vals/V per
+//       bin streamed with 16-/8-byte loads; each value is converted to 2^-62 fixed point and
+//       added with ds_add_u64 (integer LDS atomics are 14x faster than float ones here, and
+//       integer addition is associative, so the sums are BITWISE REPRODUCIBLE); then the fused
+//       epilogue of the pull iteration over the bin's rows (coalesced).
+//   HBM traffic per edge ~ (2 + 0.5 + 4) + (4 + 2) = 12.5 B x 1.05 (padding), all streamed; no
+//   vector-memory gather or scatter is left on the path.
+//
+// Fixed point: PageRank contributions lie in [0,1] and every row sum is <= the total rank mass
+// <= 1 (no dangling redistribution in the reference, src/pr/omp_base.cc), so sum*2^62 fits a
+// u64; a contribution >= 2^-38 is represented exactly (24-bit mantissa), smaller ones are
+// truncated at 2^-62 = 2.2e-19 absolute.  That is MORE accurate than the reference's
+// sequential fp32 accumulation.  Out-of-range inputs raise an error flag instead of wrapping.
+#pragma once
+#include <vector>
+
+#include "gdn_common.hpp"
+
+#define PB_THREADS 1024
+#define PB_WAVES (PB_THREADS / 64)
+#define PB_MAX_LOG_CHUNK 15  // 32768 floats = 128 KB of LDS
+#define PB_MAX_LOG_BIN 14    // 16384 u64    = 128 KB of LDS
+#define PB_FIX_SHIFT 62
+
+struct PbPlan {
+  int32_t m_local = 0;   // destination rows
+  int32_t m_global = 0;  // source ids
+  uint64_t nnz = 0;
+  int log_chunk = 0, log_bin = 0;
+  uint32_t nchunks = 0, nbins = 0;
+  uint64_t n_pad = 0;             // padded edge count (multiple of 8) = length of U, V, vals
+  DevBuf<uint16_t> U;             // chunk-major
+  DevBuf<uint32_t> G;             // n_pad / 8
+  DevBuf<uint16_t> V;             // bin-major
+  DevBuf<float> vals;             // bin-major
+  DevBuf<eoff_t> chunk_ptr;       // nchunks + 1, element units (multiples of 8)
+  DevBuf<eoff_t> bin_ptr;         // nbins + 1, element units (multiples of 8)
+  DevBuf<double> partial;         // nbins
+  DevBuf<double> red_scratch;
+  DevBuf<unsigned> errflag;       // 1 word: fixed-point range violation
+  bool timing = false;
+  std::vector<hipEvent_t> ev;  // triples: start, after A, after B
+  size_t ev_used = 0;
+  ~PbPlan() {
+    for (hipEvent_t e : ev) (void)hipEventDestroy(e);
+  }
+};
+
+// implemented in gdn_build.hip (uses the radix sort)
+int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p);
+
+#ifdef __HIPCC__
+typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short pb_u16x4 __attribute__((ext_vector_type(4)));
+typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
+
+// phase A: vals[8*G[g] + i] = x[chunk*CH + U[8*g + i]]
+static __global__ void __launch_bounds__(PB_THREADS)
+pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
+                 const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, float *__restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];
+  const unsigned ch = 1u << log_chunk;
+  const unsigned c = blockIdx.x;
+  const size_t base = (size_t)c << log_chunk;
+  for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
+    const size_t g = base + i;
+    s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+  }
+  if (threadIdx.x == 0) s_x[ch] = 0.0f;  // zero slot for pad edges
+  __syncthreads();
+  const eoff_t g0 = chunk_ptr[c] >> 3, g1 = chunk_ptr[c + 1] >> 3;
+  const pb_u16x8 *U8 = reinterpret_cast<const pb_u16x8 *>(U);
+  pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
+  constexpr int UNR = 4;
+  for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
+    pb_u16x8 u[UNR];
+    unsigned d[UNR];
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        u[r] = __builtin_nontemporal_load(U8 + gg);
+        d[r] = __builtin_nontemporal_load(G + gg);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        pb_f32x4 lo, hi;
+        lo.x = s_x[u[r].s0];
+        lo.y = s_x[u[r].s1];
+        lo.z = s_x[u[r].s2];
+        lo.w = s_x[u[r].s3];
+        hi.x = s_x[u[r].s4];
+        hi.y = s_x[u[r].s5];
+        hi.z = s_x[u[r].s6];
+        hi.w = s_x[u[r].s7];
+        X4[2 * (size_t)d[r]] = lo;
+        X4[2 * (size_t)d[r] + 1] = hi;
+      }
+    }
+  }
+}
+
+// float in [0,1] -> 2^-62 fixed point (truncating); flags anything else
+__device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad) {
+  const unsigned bits = __float_as_uint(v);
+  const int e = (int)(bits >> 23);  // biased exponent, sign must be 0
+  if (e > 127 || (e == 127 && (bits & 0x7FFFFFu))) {
+    bad = 1u;  // > 1.0, negative, inf or nan
+    return 0ull;
+  }
+  if (e == 0) return 0ull;  // zero / denormal
+  const unsigned long long mant = (unsigned long long)((bits & 0x7FFFFFu) | 0x800000u);
+  const int sh = e - 127 - 23 + PB_FIX_SHIFT;  // value = mant * 2^(e-150); * 2^62
+  return sh >= 0 ? (mant << sh) : (sh > -24 ? (mant >> (-sh)) : 0ull);
+}
+
+// phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then op.finish(row, sum).
+template <class Op>
+__global__ void __launch_bounds__(PB_THREADS)
+pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
+                     const uint16_t *__restrict__ V, const float *__restrict__ vals,
+                     double *__restrict__ partial, unsigned *__restrict__ errflag, Op op) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
+  __shared__ double s_red[PB_WAVES];
+  const unsigned bn = 1u << log_bin;
+  const unsigned b = blockIdx.x;
+  for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
+  __syncthreads();
+  const unsigned lane = gdn_lane();
+  const unsigned w = threadIdx.x >> 6;
+  const eoff_t q0 = bin_ptr[b] >> 2, q1 = bin_ptr[b + 1] >> 2;  // units of 4 edges
+  const pb_f32x4 *X4 = reinterpret_cast<const pb_f32x4 *>(vals);
+  const pb_u16x4 *V4 = reinterpret_cast<const pb_u16x4 *>(V);
+  unsigned bad = 0u;
+  constexpr int UNR = 4;
+  for (eoff_t q = q0 + threadIdx.x; q < q1; q += UNR * PB_THREADS) {
+    pb_f32x4 xs[UNR];
+    pb_u16x4 vs[UNR];
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t qq = q + (eoff_t)r * PB_THREADS;
+      if (qq < q1) {
+        xs[r] = __builtin_nontemporal_load(X4 + qq);
+        vs[r] = __builtin_nontemporal_load(V4 + qq);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t qq = q + (eoff_t)r * PB_THREADS;
+      if (qq < q1) {
+        atomicAdd(&s_acc[vs[r].x], pb_to_fixed(xs[r].x, bad));
+        atomicAdd(&s_acc[vs[r].y], pb_to_fixed(xs[r].y, bad));
+        atomicAdd(&s_acc[vs[r].z], pb_to_fixed(xs[r].z, bad));
+        atomicAdd(&s_acc[vs[r].w], pb_to_fixed(xs[r].w, bad));
+      }
+    }
+  }
+  __syncthreads();
+  double dsum = 0.0;
+  const size_t row0 = (size_t)b << log_bin;
+  for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
+    const size_t row = row0 + i;
+    if (row < (size_t)m_local) {
+      const unsigned long long a = s_acc[i];
+      if (a >> 63) bad = 1u;
+      // u64 -> float with one rounding, then the exact power-of-two scale
+      const float sum = ldexpf((float)a, -PB_FIX_SHIFT);
+      dsum += op.finish((int32_t)row, sum);
+    }
+  }
+  if (bad) *errflag = 1u;
+  dsum = gdn_wave_sum(dsum);
+  if (lane == 0) s_red[w] = dsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < PB_WAVES; i++) t += s_red[i];
+    partial[b] = t;
+  }
+}
+#endif  // __HIPCC__

@@ -9,10 +9,17 @@
 // new = base + d*sum (no FMA contraction), error accumulated in double (omp_base.cc:22).
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "gdn_mergepath.hpp"
+#include "gdn_pb.hpp"
 
 struct gdn_pr_plan {
-  MpPlan mp;
+  int layout = GDN_LAYOUT_CSR;
+  MpPlan mp;  // GDN_LAYOUT_CSR
+  PbPlan pb;  // GDN_LAYOUT_PB
+  int32_t m_local = 0;
+  uint64_t nnz = 0;
   const int32_t *out_degree = nullptr;  // device, m_local
   int32_t m_global = 0;
   int32_t row_base = 0;
@@ -44,19 +51,54 @@ pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ 
 
 extern "C" {
 
+// slice sizes: as large as LDS allows on big graphs, but keep >= ~1024 workgroups per phase
+static int pb_pick_log(int64_t n, int max_log) {
+  int lg = 10;
+  while (lg < max_log && ((int64_t)1 << (lg + 10)) < n) lg++;
+  return lg;
+}
+
 int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
-                       int32_t row_base, gdn_pr_plan **plan) {
+                       int32_t row_base, int32_t layout, gdn_pr_plan **plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
   *plan = nullptr;
   GDN_REQUIRE(in_csr != nullptr && d_out_degree != nullptr, "in_csr / d_out_degree");
   GDN_REQUIRE(m_global >= in_csr->m && row_base >= 0 && row_base + in_csr->m <= m_global, "row range");
+  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_AUTO, "layout");
+  if (layout == GDN_LAYOUT_AUTO) {
+    const char *env = getenv("GDN_PR_LAYOUT");
+    if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
+    else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
+    else layout = in_csr->nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
+  }
   gdn_pr_plan *p = new gdn_pr_plan();
+  p->layout = layout;
   p->out_degree = d_out_degree;
   p->m_global = m_global;
   p->row_base = row_base;
-  int st = mp_plan_build(p->mp, in_csr, 0);
+  p->m_local = in_csr->m;
+  p->nnz = in_csr->nnz;
+  int st;
+  if (layout == GDN_LAYOUT_CSR) {
+    st = mp_plan_build(p->mp, in_csr, 0);
+  } else {
+    st = pb_build(in_csr, m_global, pb_pick_log(m_global, PB_MAX_LOG_CHUNK), pb_pick_log(in_csr->m, PB_MAX_LOG_BIN),
+                  p->pb);
+    if (st == GDN_OK) {
+      const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
+      const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
+      hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<PrOp>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_b);
+      if (e != hipSuccess) {
+        gdn_set_error("hipFuncSetAttribute(dynamic LDS %d/%d): %s", lds_a, lds_b, hipGetErrorString(e));
+        st = GDN_ERR_HIP;
+      }
+    }
+  }
   if (st == GDN_OK && hipDeviceSynchronize() != hipSuccess) {
-    gdn_set_error("gdn_pr_plan_create: tile table kernel failed");
+    gdn_set_error("gdn_pr_plan_create: layout kernels failed: %s", hipGetErrorString(hipGetLastError()));
     st = GDN_ERR_HIP;
   }
   if (st != GDN_OK) {
@@ -74,8 +116,8 @@ int gdn_pr_plan_free(gdn_pr_plan *plan) {
 
 int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contrib, void *stream) {
   GDN_REQUIRE(plan && d_scores && d_contrib, "null argument");
-  hipLaunchKernelGGL(pr_contrib_kernel, dim3(gdn_nblocks((uint64_t)plan->mp.m)), dim3(GDN_BLOCK), 0,
-                     (hipStream_t)stream, d_scores, plan->out_degree, plan->mp.m, d_contrib + plan->row_base);
+  hipLaunchKernelGGL(pr_contrib_kernel, dim3(gdn_nblocks((uint64_t)plan->m_local)), dim3(GDN_BLOCK), 0,
+                     (hipStream_t)stream, d_scores, plan->out_degree, plan->m_local, d_contrib + plan->row_base);
   GDN_HIP(hipGetLastError());
   return GDN_OK;
 }
@@ -91,18 +133,99 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   op.out_degree = plan->out_degree;
   op.base_score = (1.0f - damping) / (float)plan->m_global;
   op.damping = damping;
-  return mp_run(plan->mp, op, d_diff, (hipStream_t)stream);
+  if (plan->layout == GDN_LAYOUT_CSR) return mp_run(plan->mp, op, d_diff, (hipStream_t)stream);
+  // ---- propagation-blocked path: expand (per chunk) then accumulate + fused update (per bin)
+  PbPlan &pb = plan->pb;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
+  const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
+  const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
+  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
+  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
+                     pb.log_chunk, pb.chunk_ptr.p, pb.U.p, pb.G.p, pb.vals.p);
+  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
+                     pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, op);
+  if (timed) {
+    GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
+    pb.ev_used += 3;
+  }
+  if (d_diff) {
+    uint32_t n = pb.nbins;
+    const double *in = pb.partial.p;
+    double *bufs[2] = {pb.red_scratch.p, pb.red_scratch.p + (pb.red_scratch.n / 2)};
+    int which = 0;
+    for (;;) {
+      const uint32_t nb = (n + MP_RED_CHUNK - 1) / MP_RED_CHUNK;
+      double *out = (nb == 1) ? d_diff : bufs[which];
+      hipLaunchKernelGGL(mp_reduce_f64, dim3(nb), dim3(GDN_BLOCK), 0, s, in, n, out);
+      if (nb == 1) break;
+      in = out;
+      n = nb;
+      which ^= 1;
+    }
+  }
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
 }
 
 int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
                             int32_t *launches) {
   GDN_REQUIRE(plan != nullptr, "plan");
-  return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+  if (total_ms) total_ms[0] = total_ms[1] = 0.0;
+  if (plan->layout == GDN_LAYOUT_CSR) return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+  PbPlan &pb = plan->pb;
+  if (reset) {
+    while (pb.ev.size() < (size_t)max_launches * 3) {
+      hipEvent_t e;
+      GDN_HIP(hipEventCreate(&e));
+      pb.ev.push_back(e);
+    }
+    pb.ev_used = 0;
+    pb.timing = max_launches > 0;
+    return GDN_OK;
+  }
+  double a = 0, b = 0;
+  for (size_t i = 0; i + 3 <= pb.ev_used; i += 3) {
+    GDN_HIP(hipEventSynchronize(pb.ev[i + 2]));
+    float ms = 0;
+    GDN_HIP(hipEventElapsedTime(&ms, pb.ev[i], pb.ev[i + 1]));
+    a += ms;
+    GDN_HIP(hipEventElapsedTime(&ms, pb.ev[i + 1], pb.ev[i + 2]));
+    b += ms;
+  }
+  if (total_ms) {
+    total_ms[0] = a;
+    total_ms[1] = b;
+  }
+  if (launches) *launches = (int32_t)(pb.ev_used / 3);
+  pb.timing = false;
+  return GDN_OK;
+}
+
+int gdn_pr_plan_check(gdn_pr_plan *plan) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (plan->layout != GDN_LAYOUT_PB) return GDN_OK;
+  unsigned f = 0;
+  GDN_HIP(hipMemcpy(&f, plan->pb.errflag.p, sizeof(f), hipMemcpyDeviceToHost));
+  if (f) {
+    gdn_set_error("PB layout: a contribution outside [0,1] (or a row sum >= 2) reached the fixed-point accumulator; "
+                  "scores must be a probability vector -- use GDN_LAYOUT_CSR for other inputs");
+    return GDN_ERR_OVERFLOW;
+  }
+  return GDN_OK;
+}
+
+int gdn_pr_plan_layout(const gdn_pr_plan *plan, int32_t *layout, int32_t *log_blk) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (layout) *layout = plan->layout;
+  if (log_blk) *log_blk = plan->layout == GDN_LAYOUT_PB ? plan->pb.log_chunk * 100 + plan->pb.log_bin : 0;
+  return GDN_OK;
 }
 
 uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan) {
   if (!plan) return 0;
-  const uint64_t m = (uint64_t)plan->mp.m, nnz = plan->mp.nnz;
+  const uint64_t m = (uint64_t)plan->m_local, nnz = plan->nnz;
   return 8 * (m + 1) + 4 * nnz + 4 * nnz + 16 * m;
 }
 
@@ -136,7 +259,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     }
     st.h2d_ms = th2d.stop_ms();
     tprep.start();
-    if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, &plan))) break;
+    if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, GDN_LAYOUT_AUTO, &plan))) break;
     st.prep_ms = tprep.stop_ms();
     // timed region == src/pr/base.cu:110-128 (t.Start .. t.Stop around the do/while)
     tsolve.start();
@@ -158,6 +281,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     }
     if (rc) break;
     st.solve_ms = tsolve.stop_ms();
+    if ((rc = gdn_pr_plan_check(plan))) break;
     st.iterations = iter + 1;  // the reference prints iter+1 (omp_base.cc:39)
     st.last_error = diff;
     st.edges_traversed = nnz * (uint64_t)(iter < max_iter ? iter + 1 : max_iter);

@@ -63,6 +63,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
 int gdn_spmv_plan_kernel_time(gdn_spmv_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
                               int32_t *launches) {
   GDN_REQUIRE(plan != nullptr, "plan");
+  if (total_ms) total_ms[0] = total_ms[1] = 0.0;
   return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
 }
 

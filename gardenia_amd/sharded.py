@@ -85,7 +85,7 @@ class HipPageRankBackend:
     """Local shard on one MI355X: torch device tensors + the _dev entry points of the C-ABI."""
 
     def __init__(self, torch, in_csr_handle, out_degree_local, m_global: int, lo: int, hi: int, chunk: int,
-                 world: int, device):
+                 world: int, device, layout: int = -1):
         from . import _cabi
         self.torch, self._cabi, self.L = torch, _cabi, _cabi.lib()
         self.device = device
@@ -97,7 +97,10 @@ class HipPageRankBackend:
         self.diff = torch.zeros(1, dtype=torch.float64, device=device)
         self.plan = C.c_void_p()
         _cabi.check(self.L.gdn_pr_plan_create(in_csr_handle, C.c_void_p(out_degree_local.data_ptr()), m_global, lo,
-                                              C.byref(self.plan)))
+                                              layout, C.byref(self.plan)))
+        lay, lg = C.c_int32(0), C.c_int32(0)
+        _cabi.check(self.L.gdn_pr_plan_layout(self.plan, C.byref(lay), C.byref(lg)))
+        self.layout, self.log_blk = lay.value, lg.value
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -118,6 +121,10 @@ class HipPageRankBackend:
                                                 C.c_void_p(self.contribs[cout].data_ptr()),
                                                 C.c_void_p(self.diff.data_ptr()), float(damping), self._stream()))
 
+    def check(self):
+        """Raise if the PB fixed-point accumulator saw an out-of-range value (blocking)."""
+        self._cabi.check(self.L.gdn_pr_plan_check(self.plan))
+
     def iter_bytes(self) -> int:
         return int(self.L.gdn_pr_iter_bytes(self.plan))
 
@@ -125,9 +132,9 @@ class HipPageRankBackend:
         self._cabi.check(self.L.gdn_pr_plan_kernel_time(self.plan, 1, max_launches, None, None))
 
     def read_kernel_timing(self):
-        tot, n = C.c_double(0), C.c_int32(0)
-        self._cabi.check(self.L.gdn_pr_plan_kernel_time(self.plan, 0, 0, C.byref(tot), C.byref(n)))
-        return tot.value, n.value
+        tot, n = (C.c_double * 2)(0, 0), C.c_int32(0)
+        self._cabi.check(self.L.gdn_pr_plan_kernel_time(self.plan, 0, 0, tot, C.byref(n)))
+        return (tot[0], tot[1]), n.value
 
     def close(self):
         if self.plan:

@@ -139,8 +139,21 @@ typedef struct gdn_pr_plan gdn_pr_plan;
 /* in_csr: IN-CSR of the m_local rows this device owns (global row ids row_base ..
  * row_base+m_local-1; column ids in [0,m_global)).  d_out_degree: m_local entries.
  * Single GPU: row_base = 0, m_global = m_local. */
+/* layout: how the plan stores the edges of its rows.
+ *   GDN_LAYOUT_CSR  merge-path over the caller's CSR (no copy; bitwise reproducible sums)
+ *   GDN_LAYOUT_PB   propagation blocking: edges re-grouped into (source chunk, destination bin)
+ *                   tiles with 16-bit local ids, both slices LDS resident (the reference's
+ *                   precedent: include/prop_blocking.h, src/pr/push_pb.cu; built once per graph,
+ *                   outside the timed loop like segmenting() in src/pr/partition.cu)
+ *   GDN_LAYOUT_AUTO PB for graphs with >= 2^22 edges (env GDN_PR_LAYOUT=csr|pb overrides) */
+enum { GDN_LAYOUT_AUTO = -1, GDN_LAYOUT_CSR = 0, GDN_LAYOUT_PB = 1 };
 int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
-                       int32_t row_base, gdn_pr_plan **plan);
+                       int32_t row_base, int32_t layout, gdn_pr_plan **plan);
+/* log_blk: 0 for CSR; for PB 100*log2(chunk ids) + log2(bin rows) */
+int gdn_pr_plan_layout(const gdn_pr_plan *plan, int32_t *layout, int32_t *log_blk);
+/* PB accumulates in 2^-62 fixed point (contributions must lie in [0,1]): returns
+ * GDN_ERR_OVERFLOW if any launch on this plan saw a value outside that range (blocking) */
+int gdn_pr_plan_check(gdn_pr_plan *plan);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */
 int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contrib, void *stream);
@@ -151,9 +164,10 @@ int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contri
  * change of the local rows (double, deterministic reduction order). */
 int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
                     double *d_diff, float damping, void *stream);
-/* Per-launch HIP-event timing of the dominant kernel (the merge-path tile kernel) on the launch
- * stream.  reset != 0 arms it for up to max_launches launches; reset == 0 waits for the events
- * and reports their summed duration and count (bench.py roofline.achieved). */
+/* Per-launch HIP-event timing of the iteration's kernels on the launch stream.  reset != 0 arms
+ * it for up to max_launches launches; reset == 0 waits for the events and reports summed
+ * durations in total_ms[2] (CSR: [0] = merge-path tile kernel; PB: [0] = expand, [1] =
+ * accumulate) and the launch count (bench.py roofline.achieved). */
 int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
                             int32_t *launches);
 /* algorithmic bytes of one pull iteration on this plan:
