@@ -10,8 +10,10 @@
 //                        dropped (:132-143).
 //   gdn_graph_transpose: reverse graph (csr_graph.h:170-194), rows ascending.
 // The reference builds both serially with vector<vector<int>> and an O(deg^2) erase loop.
+#include <algorithm>
 #include <cstring>
 #include <string.h>
+#include <stdlib.h>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -298,12 +300,12 @@ pb_fill_u16_kernel(uint16_t *p, unsigned long long n, uint16_t v) {
 
 // padded tile sizes in chunk-major (psz_c) and bin-major (psz_b) tile order
 __global__ void __launch_bounds__(GDN_BLOCK)
-pb_tile_sizes_kernel(const eoff_t *__restrict__ tsu, unsigned nchunks, unsigned nbins, uint32_t *__restrict__ psz_c,
-                     uint32_t *__restrict__ psz_b) {
+pb_tile_sizes_kernel(const eoff_t *__restrict__ tsu, unsigned nchunks, unsigned nbins, unsigned pad,
+                     uint32_t *__restrict__ psz_c, uint32_t *__restrict__ psz_b) {
   const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (t >= (unsigned long long)nchunks * nbins) return;
   const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
-  const uint32_t sz = (uint32_t)(((tsu[t + 1] - tsu[t]) + 7) & ~(eoff_t)7);
+  const uint32_t sz = (uint32_t)(((tsu[t + 1] - tsu[t]) + (pad - 1)) & ~(eoff_t)(pad - 1));
   psz_c[t] = sz;
   psz_b[(unsigned long long)b * nchunks + c] = sz;
 }
@@ -338,13 +340,13 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
 // group table: the q-th group of 8 of tile t in chunk-major order -> its group index in bin-major
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, unsigned nchunks, unsigned nbins,
-                 uint32_t *__restrict__ G) {
+                 uint32_t *__restrict__ G, int identity) {
   const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (t >= (unsigned long long)nchunks * nbins) return;
   const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
   const eoff_t gu = pu[t] >> 3, ng = (pu[t + 1] - pu[t]) >> 3;
   const eoff_t gv = pv[(unsigned long long)b * nchunks + c] >> 3;
-  for (eoff_t q = 0; q < ng; q++) G[gu + q] = (uint32_t)(gv + q);
+  for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p) {
@@ -416,8 +418,12 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       hipLaunchKernelGGL(pb_bounds_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk + log_bin, bin_bits,
                          p.nbins, ntiles, tsu.p);
     }
+    // tile runs are padded to 16 edges = whole 64-byte lines of vals, so phase A never leaves a
+    // partially written line to another workgroup (measured 7.9 vs 8.4 ms/iter at pad 8, RMAT-27)
+    unsigned pad = 16;
+    if (const char *e = getenv("GDN_PB_PAD")) pad = atoi(e) == 8 ? 8u : 16u;
     hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, p.nchunks, p.nbins,
-                       psz_c.p, psz_b.p);
+                       pad, psz_c.p, psz_b.p);
     GDN_HIP(hipGetLastError());
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_c.p, pu.p, (size_t)ntiles, 0));
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_b.p, pv.p, (size_t)ntiles, 0));
@@ -440,11 +446,26 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     if (n)
       hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p);
+    // GDN_PB_IDENTITY=1 is a TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
-                       p.G.p);
+                       p.G.p, getenv("GDN_PB_IDENTITY") ? 1 : 0);
     GDN_HIP(hipGetLastError());
     GDN_HIP(hipDeviceSynchronize());
   }  // key buffers freed here
+  {  // largest-first launch order for both phases (hub chunks / bins would otherwise form the tail)
+    std::vector<eoff_t> cp((size_t)p.nchunks + 1), bp((size_t)p.nbins + 1);
+    GDN_HIP(hipMemcpy(cp.data(), p.chunk_ptr.p, cp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+    GDN_HIP(hipMemcpy(bp.data(), p.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> co(p.nchunks), bo(p.nbins);
+    for (unsigned i = 0; i < p.nchunks; i++) co[i] = i;
+    for (unsigned i = 0; i < p.nbins; i++) bo[i] = i;
+    std::stable_sort(co.begin(), co.end(), [&](uint32_t a, uint32_t b) { return cp[a + 1] - cp[a] > cp[b + 1] - cp[b]; });
+    std::stable_sort(bo.begin(), bo.end(), [&](uint32_t a, uint32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
+    GDN_TRY(p.chunk_order.alloc(p.nchunks));
+    GDN_TRY(p.bin_order.alloc(p.nbins));
+    GDN_HIP(hipMemcpy(p.chunk_order.p, co.data(), co.size() * 4, hipMemcpyHostToDevice));
+    GDN_HIP(hipMemcpy(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice));
+  }
   GDN_TRY(p.vals.alloc(p.n_pad + 8));
   GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
   GDN_TRY(p.partial.alloc(p.nbins));

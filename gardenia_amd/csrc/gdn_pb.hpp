@@ -57,6 +57,8 @@ struct PbPlan {
   DevBuf<float> vals;             // bin-major
   DevBuf<eoff_t> chunk_ptr;       // nchunks + 1, element units (multiples of 8)
   DevBuf<eoff_t> bin_ptr;         // nbins + 1, element units (multiples of 8)
+  DevBuf<uint32_t> chunk_order;   // chunks by descending edge count (largest first: no long tail)
+  DevBuf<uint32_t> bin_order;     // bins by descending edge count
   DevBuf<double> partial;         // nbins
   DevBuf<double> red_scratch;
   DevBuf<unsigned> errflag;       // 1 word: fixed-point range violation
@@ -79,47 +81,52 @@ typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 // phase A: vals[8*G[g] + i] = x[chunk*CH + U[8*g + i]]
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
-                 const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, float *__restrict__ vals) {
+                 const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
+                 const uint32_t *__restrict__ G, float *__restrict__ vals) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   const unsigned ch = 1u << log_chunk;
-  const unsigned c = blockIdx.x;
+  const unsigned c = chunk_order[blockIdx.x];
   const size_t base = (size_t)c << log_chunk;
-  for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
-    const size_t g = base + i;
-    s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+  if (base + ch <= (size_t)m_global) {  // whole slice in range: 16-byte loads
+    const pb_f32x4 *x4 = reinterpret_cast<const pb_f32x4 *>(x + base);
+    pb_f32x4 *s4 = reinterpret_cast<pb_f32x4 *>(s_x);
+#pragma unroll 4
+    for (unsigned i = threadIdx.x; i < (ch >> 2); i += PB_THREADS) s4[i] = x4[i];
+  } else {
+    for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
+      const size_t g = base + i;
+      s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+    }
   }
   if (threadIdx.x == 0) s_x[ch] = 0.0f;  // zero slot for pad edges
   __syncthreads();
-  const eoff_t g0 = chunk_ptr[c] >> 3, g1 = chunk_ptr[c + 1] >> 3;
-  const pb_u16x8 *U8 = reinterpret_cast<const pb_u16x8 *>(U);
+  // half-groups: lane pair (2i, 2i+1) handles group i; each lane loads 4 source ids (8 B),
+  // gathers 4 values from LDS and stores 16 B, so a wave store covers whole 64-byte lines
+  const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
+  const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
   pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
-  constexpr int UNR = 4;
-  for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
-    pb_u16x8 u[UNR];
+  constexpr int UNR = 8;
+  for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
+    pb_u16x4 u[UNR];
     unsigned d[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
-      if (gg < g1) {
-        u[r] = __builtin_nontemporal_load(U8 + gg);
-        d[r] = __builtin_nontemporal_load(G + gg);
+      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
+      if (hh < h1) {
+        u[r] = __builtin_nontemporal_load(U4 + hh);
+        d[r] = __builtin_nontemporal_load(G + (hh >> 1));
       }
     }
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
-      if (gg < g1) {
-        pb_f32x4 lo, hi;
-        lo.x = s_x[u[r].s0];
-        lo.y = s_x[u[r].s1];
-        lo.z = s_x[u[r].s2];
-        lo.w = s_x[u[r].s3];
-        hi.x = s_x[u[r].s4];
-        hi.y = s_x[u[r].s5];
-        hi.z = s_x[u[r].s6];
-        hi.w = s_x[u[r].s7];
-        X4[2 * (size_t)d[r]] = lo;
-        X4[2 * (size_t)d[r] + 1] = hi;
+      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
+      if (hh < h1) {
+        pb_f32x4 o;
+        o.x = s_x[u[r].x];
+        o.y = s_x[u[r].y];
+        o.z = s_x[u[r].z];
+        o.w = s_x[u[r].w];
+        X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
       }
     }
   }
@@ -143,12 +150,13 @@ __device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad
 template <class Op>
 __global__ void __launch_bounds__(PB_THREADS)
 pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
-                     const uint16_t *__restrict__ V, const float *__restrict__ vals,
-                     double *__restrict__ partial, unsigned *__restrict__ errflag, Op op) {
+                     const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
+                     const float *__restrict__ vals, double *__restrict__ partial, unsigned *__restrict__ errflag,
+                     Op op) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   const unsigned bn = 1u << log_bin;
-  const unsigned b = blockIdx.x;
+  const unsigned b = bin_order[blockIdx.x];
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
   __syncthreads();
   const unsigned lane = gdn_lane();
@@ -173,24 +181,54 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
       if (qq < q1) {
-        atomicAdd(&s_acc[vs[r].x], pb_to_fixed(xs[r].x, bad));
-        atomicAdd(&s_acc[vs[r].y], pb_to_fixed(xs[r].y, bad));
-        atomicAdd(&s_acc[vs[r].z], pb_to_fixed(xs[r].z, bad));
-        atomicAdd(&s_acc[vs[r].w], pb_to_fixed(xs[r].w, bad));
+        // edges of one tile are sorted by destination row: fold equal neighbours in the lane
+        // first (a hub row receives hundreds of consecutive edges per tile)
+        unsigned cur = vs[r].x;
+        unsigned long long a = pb_to_fixed(xs[r].x, bad);
+        unsigned long long f = pb_to_fixed(xs[r].y, bad);
+        if (vs[r].y == cur) a += f;
+        else {
+          atomicAdd(&s_acc[cur], a);
+          cur = vs[r].y;
+          a = f;
+        }
+        f = pb_to_fixed(xs[r].z, bad);
+        if (vs[r].z == cur) a += f;
+        else {
+          atomicAdd(&s_acc[cur], a);
+          cur = vs[r].z;
+          a = f;
+        }
+        f = pb_to_fixed(xs[r].w, bad);
+        if (vs[r].w == cur) a += f;
+        else {
+          atomicAdd(&s_acc[cur], a);
+          cur = vs[r].w;
+          a = f;
+        }
+        atomicAdd(&s_acc[cur], a);
       }
     }
   }
   __syncthreads();
   double dsum = 0.0;
   const size_t row0 = (size_t)b << log_bin;
-  for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
-    const size_t row = row0 + i;
-    if (row < (size_t)m_local) {
+  if (row0 + bn <= (size_t)m_local) {  // full bin: unrolled so the row loads of several steps overlap
+#pragma unroll 8
+    for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
       const unsigned long long a = s_acc[i];
       if (a >> 63) bad = 1u;
       // u64 -> float with one rounding, then the exact power-of-two scale
-      const float sum = ldexpf((float)a, -PB_FIX_SHIFT);
-      dsum += op.finish((int32_t)row, sum);
+      dsum += op.finish((int32_t)(row0 + i), ldexpf((float)a, -PB_FIX_SHIFT));
+    }
+  } else {
+    for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
+      const size_t row = row0 + i;
+      if (row < (size_t)m_local) {
+        const unsigned long long a = s_acc[i];
+        if (a >> 63) bad = 1u;
+        dsum += op.finish((int32_t)row, ldexpf((float)a, -PB_FIX_SHIFT));
+      }
     }
   }
   if (bad) *errflag = 1u;

@@ -82,8 +82,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
-    st = pb_build(in_csr, m_global, pb_pick_log(m_global, PB_MAX_LOG_CHUNK), pb_pick_log(in_csr->m, PB_MAX_LOG_BIN),
-                  p->pb);
+    int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN);
+    if (const char *e = getenv("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
+    if (const char *e = getenv("GDN_PB_LOG_BIN")) lb = atoi(e);
+    st = pb_build(in_csr, m_global, lc, lb, p->pb);
     if (st == GDN_OK) {
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
@@ -142,10 +144,11 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
-                     pb.log_chunk, pb.chunk_ptr.p, pb.U.p, pb.G.p, pb.vals.p);
+                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
-                     pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, op);
+                     pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
+                     pb.errflag.p, op);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

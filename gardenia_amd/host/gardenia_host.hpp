@@ -1,0 +1,113 @@
+// gardenia_host.hpp -- C++ host-side mirror of the reference harness API for the CSR hot path.
+//
+// Same names, argument meaning and in/out conventions as the reference so that a main.cc
+// written like src/<kernel>/main.cc links unchanged against libgardenia_hip.so:
+//   types      include/common.h:35-47,66   (ScoreT/ValueT float, DistT/CompT/IndexT int, MYINFINITY)
+//   Graph      include/csr_graph.h:46-351  (ctor :211-250, accessors :265-306)
+//   XxxSolver  src/bfs/bfs.h:43, src/pr/pr.h:31, src/spmv/spmv.h:29, src/sssp/sssp.h:47,
+//              src/cc/cc.h:28, src/tc/tc.h:7        -> one call into include/gardenia_hip.h
+//   XxxVerifier src/<k>/verifier.cc                  -> serial checkers of the harness (verifiers.cc)
+// Differences on purpose: no exit() inside solvers (errors throw std::runtime_error with
+// gdn_last_error()), the loader sorts+dedupes in O(E log E) instead of the reference's
+// O(deg^2) erase loop (csr_graph.h:132-143), in_rowptr() is never left uninitialised
+// (SURVEY 3.3 warning), and max_degree >= n_vertices does not kill the process (:248).
+#pragma once
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <exception>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "../../include/gardenia_hip.h"
+
+typedef float ScoreT;
+typedef float ValueT;
+typedef int DistT;
+typedef int CompT;
+typedef int IndexT;
+typedef int WeightT;
+typedef int32_t VertexId;
+#define MYINFINITY 1000000000
+#define kDistInf (UINT_MAX / 2)
+#define EPSILON 0.0001
+const float kDamp = 0.85f;
+#define MAX_ITER 100
+
+class VertexSet {  // include/csr_graph.h:13-37 (the slice of it the solvers/verifiers use)
+  const VertexId *ptr;
+  VertexId size_;
+
+ public:
+  VertexSet(const VertexId *p, VertexId s) : ptr(p), size_(s) {}
+  VertexId size() const { return size_; }
+  const VertexId *begin() const { return ptr; }
+  const VertexId *end() const { return ptr + size_; }
+  VertexId get_intersect_num(const VertexSet &other) const;
+};
+
+class Graph {
+  bool directed = false, has_reverse = false;
+  VertexId n_vertices = 0, max_degree = 0;
+  uint64_t n_edges = 0;
+  std::vector<uint64_t> vertices, reverse_vertices;
+  std::vector<VertexId> edges, reverse_edges;
+  bool reverse_is_alias = false;
+  void from_edges(VertexId m, std::vector<std::pair<VertexId, VertexId> > &el);
+  void build_reverse_graph();
+
+ public:
+  Graph(std::string prefix, std::string filetype = "bin", bool symmetrize = false, bool need_reverse = false);
+  Graph(const Graph &) = delete;
+  Graph &operator=(const Graph &) = delete;
+  VertexSet N(VertexId v) const { return VertexSet(edges.data() + vertices[v], (VertexId)(vertices[v + 1] - vertices[v])); }
+  VertexSet out_neigh(VertexId v, VertexId start_offset = 0) const;
+  VertexSet in_neigh(VertexId v) const;
+  VertexId V() const { return n_vertices; }
+  size_t E() const { return n_edges; }
+  size_t size() const { return (size_t)n_vertices; }
+  size_t sizeEdges() const { return n_edges; }
+  VertexId get_degree(VertexId v) const { return (VertexId)(vertices[v + 1] - vertices[v]); }
+  VertexId out_degree(VertexId v) const { return get_degree(v); }
+  uint64_t edge_begin(VertexId v) const { return vertices[v]; }
+  uint64_t edge_end(VertexId v) const { return vertices[v + 1]; }
+  VertexId get_max_degree() const { return max_degree; }
+  bool is_directed() const { return directed; }
+  bool has_reverse_graph() const { return has_reverse; }
+  uint64_t *out_rowptr() { return vertices.data(); }
+  VertexId *out_colidx() { return edges.data(); }
+  uint64_t *in_rowptr() { return reverse_is_alias ? vertices.data() : reverse_vertices.data(); }
+  VertexId *in_colidx() { return reverse_is_alias ? edges.data() : reverse_edges.data(); }
+  void orientation();  // src/common/graph.cc:67-113 (host copy, used by the TC verifier only)
+  void write_bin(const std::string &prefix) const;  // the format of csr_graph.h:219-230 (no writer upstream)
+};
+
+// ---- solvers: each is ONE call through the C-ABI (solvers.cc)
+void BFSSolver(Graph &g, int source, DistT *dist);
+void PRSolver(Graph &g, ScoreT *scores);
+void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y);
+void SSSPSolver(Graph &g, int source, DistT *weight, DistT *dist, int delta);
+void CCSolver(Graph &g, CompT *comp);
+void TCSolver(Graph &g, uint64_t &total);  // g symmetric: orientation is applied on the device
+
+// ---- verifiers (verifiers.cc): print Correct / Wrong like the reference and also return it
+bool BFSVerifier(Graph &g, int source, DistT *dist);
+bool PRVerifier(Graph &g, ScoreT *scores, double target_error);
+bool SpmvVerifier(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y0, ValueT *test_y);
+bool SSSPVerifier(Graph &g, int source, DistT *weight, DistT *dist);
+bool CCVerifier(Graph &g, CompT *comp);
+bool TCVerifier(Graph &g, uint64_t test_total);  // g symmetric; orients a host copy
+
+// Solver failures are exceptions, not exit() (cutil_subset.h:4-12 exits): the mains report and
+// return 3 so that buffered output (graph statistics) is still flushed.
+inline int gardenia_guarded_main(int (*f)(int, char **), int argc, char **argv) {
+  try {
+    return f(argc, argv);
+  } catch (const std::exception &e) {
+    std::cout.flush();
+    fflush(stdout);
+    fprintf(stderr, "error: %s\n", e.what());
+    return 3;
+  }
+}

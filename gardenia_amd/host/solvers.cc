@@ -1,0 +1,65 @@
+// solvers.cc -- the reference's XxxSolver(Graph&, ...) signatures, each ONE call into the C-ABI.
+// Prints the lines the reference solvers print ("\titerations = %d.", "\truntime [..] = %f ms.")
+// so outputs stay diff-able (SURVEY 5 metrics/logging).  No CPU fallback: failures throw.
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+
+#include "gardenia_host.hpp"
+
+static void must(int status, const char *what) {
+  if (status != GDN_OK) throw std::runtime_error(std::string(what) + ": " + gdn_last_error());
+}
+
+void BFSSolver(Graph &g, int source, DistT *dist) {  // src/bfs/bfs.h:43
+  gdn_stats st;
+  const bool rev = g.has_reverse_graph();
+  must(gdn_bfs(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), rev ? g.in_rowptr() : nullptr,
+               rev ? g.in_colidx() : nullptr, source, dist, &st), "BFSSolver");
+  printf("\titerations = %d.\n", st.iterations);
+  printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
+  printf("\tthroughput = %f GTEPS (%llu edges)\n", st.edges_traversed / (st.solve_ms * 1e-3) / 1e9,
+         (unsigned long long)st.edges_traversed);
+}
+
+void PRSolver(Graph &g, ScoreT *scores) {  // src/pr/pr.h:31
+  std::vector<int32_t> deg(g.V());
+  for (VertexId v = 0; v < g.V(); v++) deg[v] = g.get_degree(v);
+  gdn_stats st;
+  must(gdn_pr(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), deg.data(), scores, kDamp, EPSILON, MAX_ITER, &st), "PRSolver");
+  printf(" %2d    %lf\n", st.iterations, st.last_error);
+  printf("\titerations = %d.\n", st.iterations);
+  printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
+}
+
+void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y) {  // src/spmv/spmv.h:29
+  gdn_stats st;
+  must(gdn_spmv(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), Ax, x, y, &st), "SpmvSolver");
+  const double t = st.solve_ms;
+  const double bytes = 8.0 * (g.V() + 1) + 12.0 * g.E() + 8.0 * g.V();  // SURVEY 8d byte model
+  printf("\truntime [hip_gfx950] = %.4f ms ( %5.2f GFLOP/s %5.1f GB/s)\n", t, t > 0 ? 2.0 * g.E() / t / 1e6 : 0.0,
+         t > 0 ? bytes / t / 1e6 : 0.0);
+}
+
+void SSSPSolver(Graph &g, int source, DistT *weight, DistT *dist, int delta) {  // src/sssp/sssp.h:47
+  gdn_stats st;
+  must(gdn_sssp(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), weight, source, delta, dist, &st), "SSSPSolver");
+  printf("\titerations = %d.\n", st.iterations);
+  printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
+}
+
+void CCSolver(Graph &g, CompT *comp) {  // src/cc/cc.h:28
+  gdn_stats st;
+  const bool dir = g.is_directed();
+  must(gdn_cc(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), dir ? g.in_rowptr() : nullptr, dir ? g.in_colidx() : nullptr,
+              comp, &st), "CCSolver");
+  printf("iterations = %d\n", st.iterations);
+  printf("runtime [hip_gfx950] = %f seconds\n", st.solve_ms * 1e-3);
+}
+
+void TCSolver(Graph &g, uint64_t &total) {  // src/tc/tc.h:7
+  gdn_stats st;
+  must(gdn_tc(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), /*oriented=*/0, &total, &st), "TCSolver");
+  printf("runtime [hip_gfx950] = %f sec (orientation %f sec)\n", st.solve_ms * 1e-3, st.prep_ms * 1e-3);
+  printf("throughput = %f billion Traversed Edges Per Second (TEPS)\n", st.edges_traversed / (st.solve_ms * 1e-3) / 1e9);
+}

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes of tools/profile_r01.sh into profiles/:
+  * <tag>_kernel_stats.{csv,md}   from --kernel-trace --stats
+  * pr_traffic.json               HBM bytes per PageRank iteration from the FETCH_SIZE / WRITE_SIZE
+                                  passes (KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md
+                                  "HBM": it reports 1/2 of the bytes of wide coalesced reads)
+bench.py copies hbm_bytes_per_launch into roofline.traffic when scale/n_gpus match."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01_pb"
+out = os.path.join(ROOT, "profiles")
+
+
+def counters(pat):
+    f = glob.glob(os.path.join(ROOT, pat))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+    return agg
+
+
+stats = glob.glob(os.path.join(ROOT, "gpurun_out/prof_pb_trace/runc/*_kernel_stats.csv"))[0]
+shutil.copyfile(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu  (RMAT-27, PB layout)\n\n")
+    f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
+    for r in rows[:18]:
+        f.write(f"| `{r['Name'].split('(')[0][:80]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | "
+                f"{float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |\n")
+fetch = counters("gpurun_out/prof_pb_fetch/runc/*_counter_collection.csv")
+write = counters("gpurun_out/prof_pb_write/runc/*_counter_collection.csv")
+kern = {}
+total = 0.0
+for k in ("pb_expand_kernel", "void pb_accumulate_kernel<PrOp>"):
+    fk = sum(fetch[k]) / len(fetch[k]) * 1024.0
+    wk = sum(write[k]) / len(write[k]) * 1024.0
+    kern[k] = {"FETCH_SIZE_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "WRITE_SIZE_bytes": wk,
+               "hbm_bytes": 2 * fk + wk, "dispatches": len(fetch[k])}
+    total += 2 * fk + wk
+bench = json.load(open(os.path.join(ROOT, "gpurun_out/prof_pb_bench.json")))
+res = {"scale": 27, "n_gpus": 1, "layout": bench["config"]["layout"], "hbm_bytes_per_launch": total,
+       "note": "one launch = one PageRank iteration = pb_expand_kernel + pb_accumulate_kernel<PrOp>; "
+               "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md, WRITE_SIZE (KB) as is; separate --pmc passes",
+       "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"], "kernels": kern,
+       "kernel_ms_under_rocprof": bench["roofline"]["kernel_ms"]}
+json.dump(res, open(os.path.join(out, "pr_traffic.json"), "w"), indent=1)
+shutil.copyfile(os.path.join(ROOT, "gpurun_out/prof_pb_bench.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+print(json.dumps(res, indent=1))
+print(open(os.path.join(out, f"{tag}_kernel_stats.md")).read())
