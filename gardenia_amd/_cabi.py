@@ -52,6 +52,10 @@ PROTOTYPES = {
     "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
     "gdn_cc": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
+    "gdn_dev_alloc": (C.c_int, [_u64, _pp]),
+    "gdn_dev_free": (C.c_int, [_vp]),
+    "gdn_dev_upload": (C.c_int, [_vp, _vp, _u64]),
+    "gdn_dev_download": (C.c_int, [_vp, _vp, _u64]),
     "gdn_graph_upload": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
     "gdn_graph_wrap_dev": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
     "gdn_graph_free": (C.c_int, [_vp]),
@@ -75,6 +79,9 @@ PROTOTYPES = {
     "gdn_spmv_plan_kernel_time": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "gdn_spmv_bytes": (_u64, [_vp]),
     "gdn_bfs_dev": (C.c_int, [_vp, _vp, _i32, _vp, _st]),
+    "gdn_bfs_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),
+    "gdn_bfs_plan_free": (C.c_int, [_vp]),
+    "gdn_bfs_run": (C.c_int, [_vp, _i32, _vp, _st]),
     "gdn_sssp_dev": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_cc_dev": (C.c_int, [_vp, _vp, _vp, _st]),
     "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),

@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "gdn_expand.hpp"
+#include "gdn_pb.hpp"
 
 struct BfsCounters {  // device, zeroed per level by the host-side memset
   unsigned next_count;
@@ -185,45 +186,219 @@ int gdn_reached_edges(const gdn_graph *g, const int32_t *d_dist, int32_t unreach
   return GDN_OK;
 }
 
-extern "C" {
+// ------------------------------------------------------------------------------------------
+// Dense level = one propagation-blocked sweep over ALL in-edges (gdn_pb.hpp layout of the
+// in-CSR, 1 bit per edge instead of a value).  It replaces the bottom-up step for the big
+// levels: bfs_bu_kernel spends 21 ms per RMAT-27 level on divergent probes of the 16 MiB
+// frontier bitmap (profiles/r01_*), the sweep streams 2 B/edge twice (~2 ms) whatever the
+// frontier is.
+//   phase A (per source chunk): frontier bits of the chunk -> LDS; for every group of 8 edges
+//           one byte = the 8 frontier bits of their sources, stored at the group's bin-major place
+//   phase B (per destination bin): visited bits of the bin -> LDS; for every non-zero byte load the
+//           8 destination ids and OR the unvisited ones into the bin's new-frontier bits (LDS);
+//           epilogue writes depth / visited / next frontier for the bin (coalesced by row).
+// ------------------------------------------------------------------------------------------
+typedef unsigned short bfs_u16x8 __attribute__((ext_vector_type(8)));
 
-int gdn_bfs_dev(const gdn_graph *g, const gdn_graph *gin, int32_t source, int32_t *d_dist, gdn_stats *stats) {
-  GDN_REQUIRE(g != nullptr && d_dist != nullptr, "graph / d_dist");
-  GDN_REQUIRE(source >= 0 && source < g->m, "source out of range");
-  GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
-  const int32_t m = g->m;
-  const unsigned nwords = ((unsigned)m + 31u) / 32u;
-  const unsigned nwords_pad = (nwords + 63u) & ~63u;  // bottom-up waves write whole 2-word groups
-  gdn_stats st;
-  memset(&st, 0, sizeof(st));
-  HostTimer tprep, tsolve;
-  tprep.start();
+__global__ void __launch_bounds__(PB_THREADS)
+bfs_pb_expand_kernel(const unsigned *__restrict__ front, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
+                     const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
+                     const uint32_t *__restrict__ G, unsigned char *__restrict__ ebits) {
+  __shared__ unsigned s_f[(1 << 15) / 32 + 1];
+  const unsigned words = 1u << (log_chunk - 5);
+  const unsigned c = chunk_order[blockIdx.x];
+  for (unsigned i = threadIdx.x; i < words; i += PB_THREADS) s_f[i] = front[(size_t)c * words + i];
+  if (threadIdx.x == 0) s_f[words] = 0u;  // pad edges carry U == chunk size -> bit 0 of this word
+  __syncthreads();
+  const eoff_t g0 = chunk_ptr[c] >> 3, g1 = chunk_ptr[c + 1] >> 3;
+  const bfs_u16x8 *U8 = reinterpret_cast<const bfs_u16x8 *>(U);
+  constexpr int UNR = 4;
+  for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
+    bfs_u16x8 u[UNR];
+    unsigned d[UNR];
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        u[r] = __builtin_nontemporal_load(U8 + gg);
+        d[r] = __builtin_nontemporal_load(G + gg);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        unsigned byte = 0;
+#define BFS_BIT(e, i) byte |= ((s_f[(unsigned)(e) >> 5] >> ((unsigned)(e)&31u)) & 1u) << (i)
+        BFS_BIT(u[r].s0, 0);
+        BFS_BIT(u[r].s1, 1);
+        BFS_BIT(u[r].s2, 2);
+        BFS_BIT(u[r].s3, 3);
+        BFS_BIT(u[r].s4, 4);
+        BFS_BIT(u[r].s5, 5);
+        BFS_BIT(u[r].s6, 6);
+        BFS_BIT(u[r].s7, 7);
+#undef BFS_BIT
+        ebits[d[r]] = (unsigned char)byte;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PB_THREADS)
+bfs_pb_accumulate_kernel(int32_t m, int log_bin, const eoff_t *__restrict__ bin_ptr,
+                         const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
+                         const unsigned char *__restrict__ ebits, unsigned *__restrict__ visited,
+                         unsigned *__restrict__ next_front, int32_t *__restrict__ depth, int32_t next_level,
+                         const eoff_t *__restrict__ out_rowptr, BfsCounters *cnt) {
+  __shared__ unsigned s_vis[(1 << 15) / 32];
+  __shared__ unsigned s_new[(1 << 15) / 32];
+  __shared__ unsigned long long s_red[2 * PB_WAVES];
+  const unsigned words = 1u << (log_bin - 5);
+  const unsigned b = bin_order[blockIdx.x];
+  const size_t w0 = (size_t)b * words;
+  for (unsigned i = threadIdx.x; i < words; i += PB_THREADS) {
+    s_vis[i] = visited[w0 + i];
+    s_new[i] = 0u;
+  }
+  __syncthreads();
+  const eoff_t g0 = bin_ptr[b] >> 3, g1 = bin_ptr[b + 1] >> 3;
+  const bfs_u16x8 *V8 = reinterpret_cast<const bfs_u16x8 *>(V);
+  constexpr int UNR = 4;
+  for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
+    unsigned by[UNR];
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      by[r] = (gg < g1) ? (unsigned)__builtin_nontemporal_load(ebits + gg) : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      if (by[r]) {
+        const bfs_u16x8 v = __builtin_nontemporal_load(V8 + g + (eoff_t)r * PB_THREADS);
+#define BFS_HIT(e, i)                                                               \
+  if ((by[r] >> (i)) & 1u) {                                                        \
+    const unsigned bit = 1u << ((unsigned)(e)&31u);                                 \
+    if (!(s_vis[(unsigned)(e) >> 5] & bit)) atomicOr(&s_new[(unsigned)(e) >> 5], bit); \
+  }
+        BFS_HIT(v.s0, 0)
+        BFS_HIT(v.s1, 1)
+        BFS_HIT(v.s2, 2)
+        BFS_HIT(v.s3, 3)
+        BFS_HIT(v.s4, 4)
+        BFS_HIT(v.s5, 5)
+        BFS_HIT(v.s6, 6)
+        BFS_HIT(v.s7, 7)
+#undef BFS_HIT
+      }
+    }
+  }
+  __syncthreads();
+  unsigned long long awake = 0, scout = 0;
+  for (unsigned i = threadIdx.x; i < words; i += PB_THREADS) {
+    unsigned nb = s_new[i];
+    next_front[w0 + i] = nb;
+    if (nb) {
+      visited[w0 + i] = s_vis[i] | nb;
+      const size_t row0 = (w0 + i) * 32;
+      while (nb) {
+        const int k = __ffs((int)nb) - 1;
+        nb &= nb - 1u;
+        const size_t row = row0 + (size_t)k;
+        if (row < (size_t)m) {
+          depth[row] = next_level;
+          awake++;
+          scout += out_rowptr[row + 1] - out_rowptr[row];
+        }
+      }
+    }
+  }
+  awake = gdn_wave_sum(awake);
+  scout = gdn_wave_sum(scout);
+  const unsigned w = threadIdx.x >> 6;
+  if (gdn_lane() == 0) {
+    s_red[w] = awake;
+    s_red[PB_WAVES + w] = scout;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, sc = 0;
+    for (int i = 0; i < PB_WAVES; i++) {
+      a += s_red[i];
+      sc += s_red[PB_WAVES + i];
+    }
+    if (a) {
+      atomicAdd(&cnt->awake, a);
+      atomicAdd(&cnt->scout, sc);
+    }
+  }
+}
+
+struct gdn_bfs_plan {
+  const gdn_graph *g = nullptr, *gin = nullptr;
+  bool dense = false;
+  PbPlan pb;  // layout of the in-CSR (no vals)
+  DevBuf<unsigned char> ebits;
   DevBuf<unsigned> visited, front, next;
   DevBuf<vid_t> q0, q1;
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
-  const unsigned qcap = (unsigned)m;
-  const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
-  const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-  GDN_TRY(visited.alloc(nwords_pad));
-  GDN_TRY(q0.alloc(qcap));
-  GDN_TRY(q1.alloc(qcap));
-  GDN_TRY(bigitems.alloc(bigcap));
-  GDN_TRY(cnt.alloc(1));
-  if (gin) {
-    GDN_TRY(front.alloc(nwords_pad));
-    GDN_TRY(next.alloc(nwords_pad));
-  }
-  st.prep_ms = tprep.stop_ms();
+  unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
+  double prep_ms = 0;
+};
 
+static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *gin, bool dense) {
+  HostTimer t;
+  t.start();
+  p.g = g;
+  p.gin = gin;
+  const int32_t m = g->m;
+  p.nwords = ((unsigned)m + 31u) / 32u;
+  p.nwords_pad = (p.nwords + 63u) & ~63u;
+  if (dense && gin) {
+    // 32768-id chunks / 32768-row bins: bit slices are tiny, so take the largest tiles u16 ids allow
+    int lg = 10;
+    while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
+    GDN_TRY(pb_build(gin, m, lg, lg, p.pb, /*alloc_vals=*/false));
+    const unsigned wpad = (unsigned)((((uint64_t)(p.pb.nchunks > p.pb.nbins ? p.pb.nchunks : p.pb.nbins)) << lg) / 32u);
+    if (wpad > p.nwords_pad) p.nwords_pad = wpad;
+    GDN_TRY(p.ebits.alloc((p.pb.n_pad >> 3) + 8));
+    GDN_HIP(hipMemset(p.ebits.p, 0, (p.pb.n_pad >> 3) + 8));
+    p.dense = true;
+  }
+  p.qcap = (unsigned)m;
+  const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+  p.bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+  GDN_TRY(p.visited.alloc(p.nwords_pad));
+  GDN_TRY(p.q0.alloc(p.qcap));
+  GDN_TRY(p.q1.alloc(p.qcap));
+  GDN_TRY(p.bigitems.alloc(p.bigcap));
+  GDN_TRY(p.cnt.alloc(1));
+  if (gin) {
+    GDN_TRY(p.front.alloc(p.nwords_pad));
+    GDN_TRY(p.next.alloc(p.nwords_pad));
+  }
+  GDN_HIP(hipDeviceSynchronize());
+  p.prep_ms = t.stop_ms();
+  return GDN_OK;
+}
+
+static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *stats) {
+  const gdn_graph *g = p.g, *gin = p.gin;
+  const int32_t m = g->m;
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  st.prep_ms = p.prep_ms;
+  HostTimer tsolve;
   // ---- timed region == omp_beamer.cc:128-148 plus the depth initialisation
   tsolve.start();
   GDN_TRY(gdn_fill_i32(d_dist, GDN_MYINFINITY, (size_t)m, 0));
-  GDN_HIP(hipMemsetAsync(visited.p, 0, (size_t)nwords_pad * 4, 0));
-  hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, 0, source, d_dist, visited.p, q0.p);
+  GDN_HIP(hipMemsetAsync(p.visited.p, 0, (size_t)p.nwords_pad * 4, 0));
+  hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, 0, source, d_dist, p.visited.p, p.q0.p);
 
-  const int alpha = 15, beta = 18;
-  vid_t *qin = q0.p, *qout = q1.p;
+  const int alpha = 15, beta = 18;   // omp_beamer.cc:111
+  const int alpha_dense = 32;        // a dense sweep costs about nnz/32 top-down edge visits
+  vid_t *qin = p.q0.p, *qout = p.q1.p;
   unsigned nf = 1;
   int64_t edges_to_check = (int64_t)g->nnz;
   eoff_t srow[2];
@@ -232,55 +407,88 @@ int gdn_bfs_dev(const gdn_graph *g, const gdn_graph *gin, int32_t source, int32_
   int32_t level = 0;  // depth of the vertices in the current frontier
   int iter = 0;
   BfsCounters h;
+  memset(&h, 0, sizeof(h));
   ExpBigList big;
-  big.items = bigitems.p;
-  big.capacity = bigcap;
+  big.items = p.bigitems.p;
+  big.capacity = p.bigcap;
   while (nf > 0) {
-    if (gin != nullptr && scout_count > edges_to_check / alpha) {
+    if (p.dense && scout_count > (int64_t)(g->nnz / alpha_dense)) {
+      // ---- dense phase: propagation-blocked sweeps while the frontier stays heavy
+      GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
+      hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
+      unsigned *fr = p.front.p, *nx = p.next.p;
+      int64_t awake = 0;
+      do {
+        ++iter;
+        GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+        hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
+                           p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
+        hipLaunchKernelGGL(bfs_pb_accumulate_kernel, dim3(p.pb.nbins), dim3(PB_THREADS), 0, 0, m, p.pb.log_bin,
+                           p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_dist, level + 1,
+                           g->rowptr, p.cnt.p);
+        GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+        awake = (int64_t)h.awake;
+        scout_count = (int64_t)h.scout;
+        unsigned *t = fr;
+        fr = nx;
+        nx = t;
+        level++;
+      } while (awake > 0 && scout_count > (int64_t)(g->nnz / alpha_dense));
+      if (awake == 0) {
+        nf = 0;
+        break;
+      }
+      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
+                         p.cnt.p, p.qcap);
+      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      nf = h.next_count;
+      edges_to_check = 0;  // from here on only the top-down tail is left
+    } else if (!p.dense && gin != nullptr && scout_count > edges_to_check / alpha) {
       // ---- bottom-up phase (omp_beamer.cc:130-141)
-      GDN_HIP(hipMemsetAsync(front.p, 0, (size_t)nwords_pad * 4, 0));
-      hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, front.p);
+      GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
+      hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
       int64_t awake = (int64_t)nf, old_awake;
-      unsigned *fr = front.p, *nx = next.p;
+      unsigned *fr = p.front.p, *nx = p.next.p;
       do {
         ++iter;
         old_awake = awake;
-        GDN_HIP(hipMemsetAsync(cnt.p, 0, sizeof(BfsCounters), 0));
-        hipLaunchKernelGGL(bfs_bu_kernel, dim3(gdn_nblocks((uint64_t)nwords_pad * 32)), dim3(GDN_BLOCK), 0, 0,
-                           gin->rowptr, gin->colidx, m, fr, nx, visited.p, d_dist, level + 1, cnt.p);
-        GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+        GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+        hipLaunchKernelGGL(bfs_bu_kernel, dim3(gdn_nblocks((uint64_t)p.nwords_pad * 32)), dim3(GDN_BLOCK), 0, 0,
+                           gin->rowptr, gin->colidx, m, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
+        GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
         awake = (int64_t)h.awake;
         unsigned *t = fr;
         fr = nx;
         nx = t;
         level++;
       } while (awake >= old_awake || awake > m / beta);
-      GDN_HIP(hipMemsetAsync(cnt.p, 0, sizeof(BfsCounters), 0));
-      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(nwords)), dim3(GDN_BLOCK), 0, 0, fr, nwords, qin,
-                         cnt.p, qcap);
-      GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
+                         p.cnt.p, p.qcap);
+      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
       scout_count = 1;
     } else {
       // ---- top-down step (omp_beamer.cc:143-146)
       ++iter;
       edges_to_check -= scout_count;
-      GDN_HIP(hipMemsetAsync(cnt.p, 0, sizeof(BfsCounters), 0));
+      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
       BfsTdVis vis;
       vis.rowptr = g->rowptr;
       vis.colidx = g->colidx;
-      vis.visited = visited.p;
+      vis.visited = p.visited.p;
       vis.depth = d_dist;
       vis.outq = qout;
-      vis.cnt = cnt.p;
-      vis.cap = qcap;
+      vis.cnt = p.cnt.p;
+      vis.cap = p.qcap;
       vis.next_level = level + 1;
       vis.scout_local = 0;
-      big.count = &cnt.p->big_count;
-      big.overflow = &cnt.p->overflow;
+      big.count = &p.cnt.p->big_count;
+      big.overflow = &p.cnt.p->overflow;
       hipLaunchKernelGGL(bfs_td_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nf, big, vis);
       hipLaunchKernelGGL(bfs_td_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
-      GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;
       vid_t *t = qin;
@@ -301,6 +509,43 @@ int gdn_bfs_dev(const gdn_graph *g, const gdn_graph *gin, int32_t source, int32_
   st.edges_traversed = te;
   if (stats) *stats = st;
   return GDN_OK;
+}
+
+extern "C" {
+
+int gdn_bfs_plan_create(const gdn_graph *g, const gdn_graph *gin, int32_t dense, gdn_bfs_plan **plan) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  *plan = nullptr;
+  GDN_REQUIRE(g != nullptr, "graph");
+  GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
+  gdn_bfs_plan *p = new gdn_bfs_plan();
+  const int rc = bfs_plan_init(*p, g, gin, dense != 0);
+  if (rc != GDN_OK) {
+    delete p;
+    return rc;
+  }
+  *plan = p;
+  return GDN_OK;
+}
+
+int gdn_bfs_plan_free(gdn_bfs_plan *plan) {
+  delete plan;
+  return GDN_OK;
+}
+
+int gdn_bfs_run(gdn_bfs_plan *plan, int32_t source, int32_t *d_dist, gdn_stats *stats) {
+  GDN_REQUIRE(plan != nullptr && d_dist != nullptr, "plan / d_dist");
+  GDN_REQUIRE(source >= 0 && source < plan->g->m, "source out of range");
+  return bfs_run(*plan, source, d_dist, stats);
+}
+
+int gdn_bfs_dev(const gdn_graph *g, const gdn_graph *gin, int32_t source, int32_t *d_dist, gdn_stats *stats) {
+  GDN_REQUIRE(g != nullptr && d_dist != nullptr, "graph / d_dist");
+  GDN_REQUIRE(source >= 0 && source < g->m, "source out of range");
+  GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
+  gdn_bfs_plan p;
+  GDN_TRY(bfs_plan_init(p, g, gin, /*dense=*/false));
+  return bfs_run(p, source, d_dist, stats);
 }
 
 // Host API: one call == BFSSolver(g, source, dist) (src/bfs/main.cc:22).

@@ -349,9 +349,9 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, u
   for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
 
-int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p) {
-  GDN_REQUIRE(log_chunk >= 8 && log_chunk <= PB_MAX_LOG_CHUNK, "log_chunk");
-  GDN_REQUIRE(log_bin >= 8 && log_bin <= PB_MAX_LOG_BIN, "log_bin");
+int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals) {
+  GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");  // u16 local ids + one pad value
+  GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
   const int32_t m = g->m;
   const unsigned long long n = g->nnz;
   p.m_local = m;
@@ -466,8 +466,10 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_HIP(hipMemcpy(p.chunk_order.p, co.data(), co.size() * 4, hipMemcpyHostToDevice));
     GDN_HIP(hipMemcpy(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice));
   }
-  GDN_TRY(p.vals.alloc(p.n_pad + 8));
-  GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
+  if (alloc_vals) {
+    GDN_TRY(p.vals.alloc(p.n_pad + 8));
+    GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
+  }
   GDN_TRY(p.partial.alloc(p.nbins));
   GDN_TRY(p.red_scratch.alloc(2 * ((size_t)p.nbins / 4096 + 2)));
   GDN_HIP(hipDeviceSynchronize());

@@ -153,6 +153,31 @@ int gdn_set_device(int device) {
   return GDN_OK;
 }
 
+int gdn_dev_alloc(uint64_t bytes, void **d_ptr) {
+  GDN_REQUIRE(d_ptr != nullptr, "d_ptr");
+  *d_ptr = nullptr;
+  GDN_TRY(gdn_require_device());
+  GDN_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+  return GDN_OK;
+}
+
+int gdn_dev_free(void *d_ptr) {
+  if (d_ptr) GDN_HIP(hipFree(d_ptr));
+  return GDN_OK;
+}
+
+int gdn_dev_upload(void *d_dst, const void *h_src, uint64_t bytes) {
+  GDN_REQUIRE(d_dst && h_src, "null pointer");
+  GDN_HIP(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return GDN_OK;
+}
+
+int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes) {
+  GDN_REQUIRE(h_dst && d_src, "null pointer");
+  GDN_HIP(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return GDN_OK;
+}
+
 int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
                      gdn_graph **out) {
   GDN_REQUIRE(out != nullptr, "out");

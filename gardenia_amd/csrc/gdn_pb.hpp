@@ -71,7 +71,8 @@ struct PbPlan {
 };
 
 // implemented in gdn_build.hip (uses the radix sort)
-int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p);
+// alloc_vals = false: only the static layout (U, V, G, pointers, orders) -- BFS keeps 1 bit per edge
+int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true);
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));

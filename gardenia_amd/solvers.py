@@ -128,3 +128,36 @@ def CCSolver(g: Graph, comp: np.ndarray) -> dict:
     st = _cabi.GdnStats()
     _cabi.check(_cabi.lib().gdn_cc(g.V(), g.E(), _p(rp), _p(ci), _p(irp), _p(ici), _p(comp), C.byref(st)))
     return st.as_dict()
+
+
+class ResidentBFS:
+    """Many BFS runs on one resident graph (gdn_bfs_plan_*): upload once, search from any source.
+    dense=True also builds the propagation-blocked in-edge layout used for the heavy levels."""
+
+    def __init__(self, g: Graph, dense: bool = True):
+        L = _cabi.lib()
+        self.L, self.m = L, g.V()
+        self.h_out, self.h_in, self.plan, self.d_dist = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(rp), _p(ci), C.byref(self.h_out)))
+        hin = None
+        if g.has_reverse_graph():
+            irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+            _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.h_in)))
+            hin = self.h_in
+        _cabi.check(L.gdn_bfs_plan_create(self.h_out, hin, 1 if (dense and hin is not None) else 0, C.byref(self.plan)))
+        _cabi.check(L.gdn_dev_alloc(4 * g.V(), C.byref(self.d_dist)))
+
+    def run(self, source: int):
+        st = _cabi.GdnStats()
+        _cabi.check(self.L.gdn_bfs_run(self.plan, source, self.d_dist, C.byref(st)))
+        dist = np.empty(self.m, np.int32)
+        _cabi.check(self.L.gdn_dev_download(_p(dist), self.d_dist, 4 * self.m))
+        return dist, st.as_dict()
+
+    def close(self):
+        self.L.gdn_bfs_plan_free(self.plan)
+        self.L.gdn_dev_free(self.d_dist)
+        self.L.gdn_graph_free(self.h_out)
+        if self.h_in:
+            self.L.gdn_graph_free(self.h_in)

@@ -101,6 +101,12 @@ int gdn_tc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colid
 int gdn_cc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
            const uint64_t *in_rowptr, const int32_t *in_colidx, int32_t *comp, gdn_stats *stats);
 
+/* Device buffers for callers of the _dev API that do not bring their own allocator (blocking). */
+int gdn_dev_alloc(uint64_t bytes, void **d_ptr);
+int gdn_dev_free(void *d_ptr);
+int gdn_dev_upload(void *d_dst, const void *h_src, uint64_t bytes);
+int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes);
+
 /* ------------------------------------------------------------------------------------------
  * Resident graphs (the reference re-uploads per Solver call: src/bfs/linear_base.cu:42-49).
  * ---------------------------------------------------------------------------------------- */
@@ -189,6 +195,15 @@ uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan);
  * src/bfs/linear_base.cu:73). */
 int gdn_bfs_dev(const gdn_graph *out_csr, const gdn_graph *in_csr /*nullable*/, int32_t source,
                 int32_t *d_dist, gdn_stats *stats);
+/* Reusable BFS state for many searches on one resident graph.  dense != 0 (needs in_csr) also
+ * builds the propagation-blocked layout of the in-CSR once, so that heavy levels run as one
+ * streaming sweep over all in-edges instead of a bottom-up step (built outside the timed search,
+ * like the reverse graph the reference builds in its Graph constructor, csr_graph.h:236-240). */
+typedef struct gdn_bfs_plan gdn_bfs_plan;
+int gdn_bfs_plan_create(const gdn_graph *out_csr, const gdn_graph *in_csr /*nullable*/, int32_t dense,
+                        gdn_bfs_plan **plan);
+int gdn_bfs_plan_free(gdn_bfs_plan *plan);
+int gdn_bfs_run(gdn_bfs_plan *plan, int32_t source, int32_t *d_dist, gdn_stats *stats);
 int gdn_sssp_dev(const gdn_graph *csr, const int32_t *d_weight, int32_t source, int32_t delta,
                  int32_t *d_dist, gdn_stats *stats);
 int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,

@@ -45,6 +45,22 @@ def test_bfs_vs_oracle_rmat(orc, scale, ef, seed):
         assert st["edges_traversed"] == int(g.degrees()[reached].astype(np.int64).sum())
 
 
+@pytest.mark.parametrize("scale,ef,seed", [(12, 16, 4), (16, 16, 5), (19, 16, 6), (17, 64, 7)])
+def test_bfs_resident_dense_levels(orc, scale, ef, seed):
+    """gdn_bfs_plan_*: heavy levels run as propagation-blocked sweeps over all in-edges."""
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    bfs = solvers.ResidentBFS(G, dense=True)
+    deg = g.degrees()
+    sources = [graphio.first_nonisolated(g), int(np.argmax(deg)), int(np.nonzero(deg)[0][-1])]
+    for s in sources:
+        dist, st = bfs.run(s)
+        want = orc.bfs_serial(g, s)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+        assert st["edges_traversed"] == int(deg[want != solvers.MYINFINITY].astype(np.int64).sum())
+    bfs.close()
+
+
 def test_bfs_star_and_chain(orc):
     # a hub with 20000 out-neighbours (big-row path) feeding a chain (many tiny levels)
     n = 20001 + 300
