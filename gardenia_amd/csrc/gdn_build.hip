@@ -322,7 +322,8 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int log_chunk, int log_bin,
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
-                  uint16_t *__restrict__ V) {
+                  uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
+                  const float *__restrict__ ev_in, float *__restrict__ ev_out) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -332,8 +333,21 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     const unsigned long long b = cb & bmask, c = cb >> bin_bits;
     const unsigned long long t = c * nbins + b;
     const unsigned long long off = i - tsu[t];
-    U[pu[t] + off] = (uint16_t)((unsigned)k & ((1u << log_chunk) - 1u));
-    V[pv[b * nchunks + c] + off] = (uint16_t)((unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u));
+    const unsigned ul = (unsigned)k & ((1u << log_chunk) - 1u);
+    const unsigned vl = (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
+    U[pu[t] + off] = (uint16_t)ul;
+    V[pv[b * nchunks + c] + off] = (uint16_t)vl;
+    if (ev_in) {  // value of this edge: find the column in its (ascending) CSR row
+      const unsigned long long row = (b << log_bin) + vl;
+      const vid_t col = (vid_t)((c << log_chunk) + ul);
+      eoff_t lo = rowptr[row], hi = rowptr[row + 1];
+      while (lo < hi) {
+        const eoff_t mid = lo + ((hi - lo) >> 1);
+        if (colidx[mid] < col) lo = mid + 1;
+        else hi = mid;
+      }
+      ev_out[pu[t] + off] = ev_in[lo];
+    }
   }
 }
 
@@ -349,7 +363,8 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, u
   for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
 
-int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals) {
+int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
+             const float *edge_vals_in, DevBuf<float> *edge_vals_out) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
   const int32_t m = g->m;
@@ -443,9 +458,16 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p,
                        n_pad + 8, (uint16_t)(1u << log_chunk));
     GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + 8) * sizeof(uint16_t), 0));
+    float *ev_out = nullptr;
+    if (edge_vals_in && edge_vals_out) {
+      GDN_TRY(edge_vals_out->alloc(n_pad + 8));
+      GDN_HIP(hipMemsetAsync(edge_vals_out->p, 0, (n_pad + 8) * sizeof(float), 0));
+      ev_out = edge_vals_out->p;
+    }
     if (n)
       hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
-                         p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p);
+                         p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
+                         ev_out ? edge_vals_in : nullptr, ev_out);
     // GDN_PB_IDENTITY=1 is a TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
                        p.G.p, getenv("GDN_PB_IDENTITY") ? 1 : 0);

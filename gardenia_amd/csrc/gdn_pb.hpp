@@ -72,7 +72,9 @@ struct PbPlan {
 
 // implemented in gdn_build.hip (uses the radix sort)
 // alloc_vals = false: only the static layout (U, V, G, pointers, orders) -- BFS keeps 1 bit per edge
-int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true);
+// edge_vals_in (nullable, CSR order) -> *edge_vals_out in chunk-major order, pads = 0 (SpMV's Ax)
+int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true,
+             const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr);
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
@@ -133,6 +135,55 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   }
 }
 
+// phase A with a per-edge factor (SpMV): vals[8*G[g] + i] = A[8*g + i] * x[chunk*CH + U[8*g + i]]
+static __global__ void __launch_bounds__(PB_THREADS)
+pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk,
+                        const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
+                        const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, const float *__restrict__ A,
+                        float *__restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];
+  const unsigned ch = 1u << log_chunk;
+  const unsigned c = chunk_order[blockIdx.x];
+  const size_t base = (size_t)c << log_chunk;
+  for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
+    const size_t g = base + i;
+    s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+  }
+  if (threadIdx.x == 0) s_x[ch] = 0.0f;
+  __syncthreads();
+  const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
+  const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
+  const pb_f32x4 *A4 = reinterpret_cast<const pb_f32x4 *>(A);
+  pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
+  constexpr int UNR = 4;
+  for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
+    pb_u16x4 u[UNR];
+    pb_f32x4 a[UNR];
+    unsigned d[UNR];
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
+      if (hh < h1) {
+        u[r] = __builtin_nontemporal_load(U4 + hh);
+        a[r] = __builtin_nontemporal_load(A4 + hh);
+        d[r] = __builtin_nontemporal_load(G + (hh >> 1));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
+      if (hh < h1) {
+        pb_f32x4 o;
+        o.x = __fmul_rn(s_x[u[r].x], a[r].x);
+        o.y = __fmul_rn(s_x[u[r].y], a[r].y);
+        o.z = __fmul_rn(s_x[u[r].z], a[r].z);
+        o.w = __fmul_rn(s_x[u[r].w], a[r].w);
+        X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
+      }
+    }
+  }
+}
+
 // float in [0,1] -> 2^-62 fixed point (truncating); flags anything else
 __device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad) {
   const unsigned bits = __float_as_uint(v);
@@ -148,6 +199,16 @@ __device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad
 }
 
 // phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then op.finish(row, sum).
+// signed value * 2^shift -> two's complement fixed point (SpMV); |v * 2^shift| must stay < 2^62
+__device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float scale, unsigned &bad) {
+  const float t = v * scale;  // exact: scale is a power of two
+  if (!(fabsf(t) < 4.611686018427388e18f)) {  // also catches nan / inf
+    bad = 1u;
+    return 0ull;
+  }
+  return (unsigned long long)(long long)t;
+}
+
 template <class Op>
 __global__ void __launch_bounds__(PB_THREADS)
 pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
@@ -185,22 +246,22 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         // edges of one tile are sorted by destination row: fold equal neighbours in the lane
         // first (a hub row receives hundreds of consecutive edges per tile)
         unsigned cur = vs[r].x;
-        unsigned long long a = pb_to_fixed(xs[r].x, bad);
-        unsigned long long f = pb_to_fixed(xs[r].y, bad);
+        unsigned long long a = op.to_fixed(xs[r].x, bad);
+        unsigned long long f = op.to_fixed(xs[r].y, bad);
         if (vs[r].y == cur) a += f;
         else {
           atomicAdd(&s_acc[cur], a);
           cur = vs[r].y;
           a = f;
         }
-        f = pb_to_fixed(xs[r].z, bad);
+        f = op.to_fixed(xs[r].z, bad);
         if (vs[r].z == cur) a += f;
         else {
           atomicAdd(&s_acc[cur], a);
           cur = vs[r].z;
           a = f;
         }
-        f = pb_to_fixed(xs[r].w, bad);
+        f = op.to_fixed(xs[r].w, bad);
         if (vs[r].w == cur) a += f;
         else {
           atomicAdd(&s_acc[cur], a);
@@ -217,18 +278,14 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   if (row0 + bn <= (size_t)m_local) {  // full bin: unrolled so the row loads of several steps overlap
 #pragma unroll 8
     for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
-      const unsigned long long a = s_acc[i];
-      if (a >> 63) bad = 1u;
-      // u64 -> float with one rounding, then the exact power-of-two scale
-      dsum += op.finish((int32_t)(row0 + i), ldexpf((float)a, -PB_FIX_SHIFT));
+      // fixed -> float with one rounding, then the exact power-of-two scale
+      dsum += op.finish((int32_t)(row0 + i), op.from_fixed(s_acc[i], bad));
     }
   } else {
     for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
       const size_t row = row0 + i;
       if (row < (size_t)m_local) {
-        const unsigned long long a = s_acc[i];
-        if (a >> 63) bad = 1u;
-        dsum += op.finish((int32_t)row, ldexpf((float)a, -PB_FIX_SHIFT));
+        dsum += op.finish((int32_t)row, op.from_fixed(s_acc[i], bad));
       }
     }
   }

@@ -33,6 +33,12 @@ struct PrOp {
   float base_score;
   float damping;
   __device__ __forceinline__ float load(uint64_t, vid_t col) const { return contrib_in[col]; }
+  // PB layout: unsigned 2^-62 fixed point (gdn_pb.hpp)
+  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const { return pb_to_fixed(v, bad); }
+  __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &bad) const {
+    if (a >> 63) bad = 1u;
+    return ldexpf((float)a, -PB_FIX_SHIFT);
+  }
   __device__ __forceinline__ double finish(int32_t row, float sum) const {
     const float old_score = scores[row];
     const float new_score = __fadd_rn(base_score, __fmul_rn(damping, sum));

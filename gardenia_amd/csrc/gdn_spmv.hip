@@ -7,10 +7,20 @@
 // the rows of (Ap, Aj); products are rounded before the add like the reference's x86 build.
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "gdn_mergepath.hpp"
+#include "gdn_pb.hpp"
 
 struct gdn_spmv_plan {
-  MpPlan mp;
+  int layout = GDN_LAYOUT_CSR;
+  int32_t m = 0;
+  uint64_t nnz = 0;
+  MpPlan mp;            // GDN_LAYOUT_CSR
+  PbPlan pb;            // GDN_LAYOUT_PB
+  DevBuf<float> Axp;    // PB: Ax in chunk-major tile order (pads 0)
+  DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] max row length
+  DevBuf<float> scale;  // PB: [0] = 2^shift, [1] = 2^-shift (per call)
 };
 
 struct SpmvOp {
@@ -24,18 +34,112 @@ struct SpmvOp {
     y[row] = __fadd_rn(y[row], sum);
     return 0.0;
   }
+  // PB layout: signed fixed point with a per-call power-of-two scale (gdn_pb.hpp)
+  const float *__restrict__ scale;
+  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const {
+    return pb_to_fixed_signed(v, scale[0], bad);
+  }
+  __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &) const {
+    return __fmul_rn((float)(long long)a, scale[1]);
+  }
 };
+
+// max |v| over an array, as float bits (non-negative floats order like unsigned integers)
+__global__ void __launch_bounds__(GDN_BLOCK)
+spmv_absmax_kernel(const float *__restrict__ v, size_t n, unsigned *__restrict__ out) {
+  unsigned mx = 0;
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const unsigned b = __float_as_uint(v[i]) & 0x7FFFFFFFu;
+    mx = b > mx ? b : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if (gdn_lane() == 0 && mx) atomicMax(out, mx);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+spmv_maxdeg_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned *__restrict__ out) {
+  unsigned mx = 0;
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const eoff_t d = rowptr[i + 1] - rowptr[i];
+    const unsigned b = d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d;
+    mx = b > mx ? b : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if (gdn_lane() == 0 && mx) atomicMax(out, mx);
+}
+
+// scale = 2^shift with max|Ax| * max|x| * maxdeg * 2^shift < 2^61  (no host round trip)
+__global__ void spmv_scale_kernel(const unsigned *__restrict__ mx, float *__restrict__ scale) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float a = __uint_as_float(mx[0]), x = __uint_as_float(mx[1]);
+  const float bound = a * x * (float)(mx[2] ? mx[2] : 1u);
+  int e = 0;
+  if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &e);  // bound < 2^e
+  int shift = 61 - e;
+  if (shift > 120) shift = 120;
+  if (shift < -120) shift = -120;
+  scale[0] = ldexpf(1.0f, shift);
+  scale[1] = ldexpf(1.0f, -shift);
+}
 
 extern "C" {
 
-int gdn_spmv_plan_create(const gdn_graph *csr, gdn_spmv_plan **plan) {
+static int spmv_pick_log(int64_t n, int max_log) {
+  int lg = 10;
+  while (lg < max_log && ((int64_t)1 << (lg + 10)) < n) lg++;
+  return lg;
+}
+
+int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax, int32_t layout, gdn_spmv_plan **plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
   *plan = nullptr;
   GDN_REQUIRE(csr != nullptr, "csr");
+  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_AUTO, "layout");
+  if (layout == GDN_LAYOUT_AUTO) {
+    const char *env = getenv("GDN_SPMV_LAYOUT");
+    if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
+    else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
+    else layout = (d_Ax != nullptr && csr->nnz >= (1ull << 22)) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
+  }
+  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || d_Ax != nullptr, "the PB layout stores Ax inside the plan: pass d_Ax");
   gdn_spmv_plan *p = new gdn_spmv_plan();
-  int st = mp_plan_build(p->mp, csr, 0);
+  p->layout = layout;
+  p->m = csr->m;
+  p->nnz = csr->nnz;
+  int st;
+  if (layout == GDN_LAYOUT_CSR) {
+    st = mp_plan_build(p->mp, csr, 0);
+  } else {
+    st = pb_build(csr, csr->m, spmv_pick_log(csr->m, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
+                  true, d_Ax, &p->Axp);
+    if (st == GDN_OK) st = p->mx.alloc(4);
+    if (st == GDN_OK) st = p->scale.alloc(2);
+    if (st == GDN_OK) {
+      (void)hipMemset(p->mx.p, 0, 16);
+      if (csr->nnz)
+        hipLaunchKernelGGL(spmv_absmax_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_Ax, (size_t)csr->nnz, p->mx.p);
+      hipLaunchKernelGGL(spmv_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->m, p->mx.p + 2);
+      const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
+      const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
+      hipError_t e = hipFuncSetAttribute((const void *)pb_expand_scaled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<SpmvOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+      if (e != hipSuccess) {
+        gdn_set_error("hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+        st = GDN_ERR_HIP;
+      }
+    }
+  }
   if (st == GDN_OK && hipDeviceSynchronize() != hipSuccess) {
-    gdn_set_error("gdn_spmv_plan_create: tile table kernel failed");
+    gdn_set_error("gdn_spmv_plan_create: layout kernels failed: %s", hipGetErrorString(hipGetLastError()));
     st = GDN_ERR_HIP;
   }
   if (st != GDN_OK) {
@@ -52,25 +156,92 @@ int gdn_spmv_plan_free(gdn_spmv_plan *plan) {
 }
 
 int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream) {
-  GDN_REQUIRE(plan && d_Ax && d_x && d_y, "null argument");
+  GDN_REQUIRE(plan && d_x && d_y, "null argument");
   SpmvOp op;
   op.Ax = d_Ax;
   op.x = d_x;
   op.y = d_y;
-  return mp_run(plan->mp, op, nullptr, (hipStream_t)stream);
+  op.scale = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (plan->layout == GDN_LAYOUT_CSR) {
+    GDN_REQUIRE(d_Ax != nullptr, "d_Ax");
+    return mp_run(plan->mp, op, nullptr, s);
+  }
+  // ---- propagation-blocked path (Ax lives in the plan in tile order; d_Ax is not read)
+  PbPlan &pb = plan->pb;
+  GDN_HIP(hipMemsetAsync(plan->mx.p + 1, 0, sizeof(unsigned), s));
+  hipLaunchKernelGGL(spmv_absmax_kernel, dim3(1024), dim3(GDN_BLOCK), 0, s, d_x, (size_t)plan->m, plan->mx.p + 1);
+  hipLaunchKernelGGL(spmv_scale_kernel, dim3(1), dim3(64), 0, s, plan->mx.p, plan->scale.p);
+  op.scale = plan->scale.p;
+  const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
+  const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
+  const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
+  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
+  hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
+                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p);
+  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
+                     pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
+                     pb.errflag.p, op);
+  if (timed) {
+    GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
+    pb.ev_used += 3;
+  }
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
 }
 
 int gdn_spmv_plan_kernel_time(gdn_spmv_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,
                               int32_t *launches) {
   GDN_REQUIRE(plan != nullptr, "plan");
   if (total_ms) total_ms[0] = total_ms[1] = 0.0;
-  return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+  if (plan->layout == GDN_LAYOUT_CSR) return mp_plan_timing(plan->mp, reset, max_launches, total_ms, launches);
+  PbPlan &pb = plan->pb;
+  if (reset) {
+    while (pb.ev.size() < (size_t)max_launches * 3) {
+      hipEvent_t e;
+      GDN_HIP(hipEventCreate(&e));
+      pb.ev.push_back(e);
+    }
+    pb.ev_used = 0;
+    pb.timing = max_launches > 0;
+    return GDN_OK;
+  }
+  double a = 0, b = 0;
+  for (size_t i = 0; i + 3 <= pb.ev_used; i += 3) {
+    GDN_HIP(hipEventSynchronize(pb.ev[i + 2]));
+    float ms = 0;
+    GDN_HIP(hipEventElapsedTime(&ms, pb.ev[i], pb.ev[i + 1]));
+    a += ms;
+    GDN_HIP(hipEventElapsedTime(&ms, pb.ev[i + 1], pb.ev[i + 2]));
+    b += ms;
+  }
+  if (total_ms) {
+    total_ms[0] = a;
+    total_ms[1] = b;
+  }
+  if (launches) *launches = (int32_t)(pb.ev_used / 3);
+  pb.timing = false;
+  return GDN_OK;
+}
+
+// PB layout: GDN_ERR_OVERFLOW if a product left the fixed-point range (non-finite inputs)
+int gdn_spmv_plan_check(gdn_spmv_plan *plan) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (plan->layout != GDN_LAYOUT_PB) return GDN_OK;
+  unsigned f = 0;
+  GDN_HIP(hipMemcpy(&f, plan->pb.errflag.p, sizeof(f), hipMemcpyDeviceToHost));
+  if (f) {
+    gdn_set_error("PB SpMV: a product overflowed the fixed-point accumulator (non-finite Ax or x?)");
+    return GDN_ERR_OVERFLOW;
+  }
+  return GDN_OK;
 }
 
 // 8(m+1) + 4 nnz [Aj] + 4 nnz [Ax] + 4 nnz [x gather] + 8 m [y r+w]
 uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan) {
   if (!plan) return 0;
-  const uint64_t m = (uint64_t)plan->mp.m, nnz = plan->mp.nnz;
+  const uint64_t m = (uint64_t)plan->m, nnz = plan->nnz;
   return 8 * (m + 1) + 12 * nnz + 8 * m;
 }
 
@@ -99,7 +270,7 @@ int gdn_spmv(int32_t m, uint64_t nnz, const uint64_t *Ap, const int32_t *Aj, con
     }
     st.h2d_ms = th2d.stop_ms();
     tprep.start();
-    if ((rc = gdn_spmv_plan_create(g, &plan))) break;
+    if ((rc = gdn_spmv_plan_create(g, nullptr, GDN_LAYOUT_CSR, &plan))) break;  // one multiply: no layout build
     st.prep_ms = tprep.stop_ms();
     tsolve.start();  // src/spmv/warp.cu:100-104: one timed launch
     if ((rc = gdn_spmv_dev(plan, d_Ax.p, d_x.p, d_y.p, nullptr))) break;

@@ -9,9 +9,9 @@
 //   keep[k] = deg[dst] > deg[src] || (deg equal && dst > src)        (graph.cc:80-81)
 //   pos     = exclusive_scan(keep)                                    (order preserving)
 //   dag.colidx[pos[k]] = colidx[k];  dag.rowptr[u] = pos[rowptr[u]]
-// Counting: one wavefront per source vertex u; for each v in N+(u) the 64 lanes stride over
-// N+(v) and binary-search N+(u) (which stays L1/L2 hot across all v); uint64 count reduced per
-// wave then one atomicAdd per workgroup.  The count is exact (integer sum).
+// Counting: one wavefront per source vertex u with N+(u) staged in LDS; the neighbour lists of 64
+// out-neighbours at a time are walked lane-packed (gdn_expand.hpp) and looked up by binary search in
+// LDS; uint64 count reduced per wave then one atomicAdd per workgroup.  Exact (integer sum).
 #include <string.h>
 
 #include "gdn_expand.hpp"
@@ -67,41 +67,89 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
   if (v <= (unsigned)m) out[v] = pos[rowptr[v]];
 }
 
-__global__ void __launch_bounds__(GDN_BLOCK)
-tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
-                unsigned long long *__restrict__ total) {
-  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
-  const unsigned lane = gdn_lane();
-  const unsigned nwaves = gridDim.x * GDN_WAVES_PER_BLOCK;
-  unsigned long long count = 0;
-  for (unsigned u = blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); u < (unsigned)m; u += nwaves) {
-    const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
-    const int du = (int)(ue - ub);
-    if (du < 2) continue;  // the last out-neighbour in id/degree order closes no triangle alone
-    const vid_t *nu = colidx + ub;
-    for (eoff_t i = ub; i < ue; i++) {
-      const vid_t v = colidx[i];
-      const eoff_t vb = rowptr[v], ve = rowptr[v + 1];
-      for (eoff_t k0 = vb; k0 < ve; k0 += 64) {
-        const eoff_t k = k0 + lane;
-        if (k < ve) {
-          const vid_t w = colidx[k];
-          int lo = 0, hi = du - 1;
-          while (lo <= hi) {
-            const int mid = (lo + hi) >> 1;
-            const vid_t x = nu[mid];
-            if (x == w) {
-              count++;
-              break;
-            }
-            if (x < w) lo = mid + 1;
-            else hi = mid - 1;
-          }
+// Counting.  One wavefront per source vertex u.  N+(u) is staged in LDS (TC_CAP ids per wave);
+// the out-neighbours v of u are taken 64 at a time, one per lane, and THEIR neighbour lists are
+// walked through gdn_expand_wave, so the 64 lanes always hold 64 distinct (v, w) pairs no matter how
+// short the lists are; every w is looked up in N+(u) by binary search in LDS (global memory when
+// N+(u) does not fit).  With the degree orientation every list is O(sqrt(nnz)) long.
+#define TC_CAP 2048
+
+struct TcCountVis {
+  const vid_t *__restrict__ colidx;
+  const vid_t *nu;  // N+(u): LDS copy or the global list
+  int du;
+  unsigned long long count;
+  __device__ __forceinline__ void begin_big(vid_t) {}
+  __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
+    if (valid) {
+      const vid_t w = colidx[k];
+      int lo = 0, hi = du - 1;
+      while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const vid_t x = nu[mid];
+        if (x == w) {
+          count++;
+          break;
         }
+        if (x < w) lo = mid + 1;
+        else hi = mid - 1;
       }
     }
   }
-  count = gdn_block_sum(count, s_red);
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
+                unsigned *__restrict__ next_vertex, unsigned long long *__restrict__ total) {
+  __shared__ vid_t s_nu[GDN_WAVES_PER_BLOCK][TC_CAP];
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  const unsigned lane = gdn_lane();
+  const unsigned w = threadIdx.x >> 6;
+  TcCountVis vis;
+  vis.colidx = colidx;
+  vis.count = 0;
+  ExpBigList nobig;
+  nobig.items = nullptr;
+  nobig.count = nullptr;
+  nobig.capacity = 0;
+  nobig.overflow = nullptr;
+  for (;;) {
+    // dynamic vertex assignment: 16 consecutive vertices per grab (one atomic per 16 rows)
+    unsigned u0 = 0;
+    if (lane == 0) u0 = atomicAdd(next_vertex, 16u);
+    u0 = __shfl(u0, 0, 64);
+    if (u0 >= (unsigned)m) break;
+    const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
+    for (unsigned u = u0; u < u1; u++) {
+      const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
+      const int du = (int)(ue - ub);
+      if (du < 2) continue;  // a single out-neighbour closes no triangle
+      vis.du = du;
+      if (du <= TC_CAP) {
+        for (int i = lane; i < du; i += 64) s_nu[w][i] = colidx[ub + i];
+        vis.nu = s_nu[w];
+      } else {
+        vis.nu = colidx + ub;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (eoff_t i0 = ub; i0 < ue; i0 += 64) {
+        const eoff_t i = i0 + lane;
+        eoff_t vb = 0, ve = 0;
+        vid_t v = 0;
+        if (i < ue) {
+          v = vis.nu == s_nu[w] ? s_nu[w][i - ub] : colidx[i];
+          vb = rowptr[v];
+          ve = rowptr[v + 1];
+        }
+        gdn_expand_wave(vb, ve, v, nobig, vis, s_scan[w]);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  unsigned long long count = gdn_block_sum(vis.count, s_red);
   if (threadIdx.x == 0 && count) atomicAdd(total, count);
 }
 
@@ -185,15 +233,16 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
     GDN_TRY(tc_orient(g, &own));
     dag = own;
   }
-  DevBuf<unsigned long long> d_total;
-  int rc = d_total.alloc(1);
-  if (rc == GDN_OK && hipMemset(d_total.p, 0, 8) != hipSuccess) rc = GDN_ERR_HIP;
+  DevBuf<unsigned long long> d_total;  // [0] = triangle count, [1] = work-distribution cursor
+  int rc = d_total.alloc(2);
+  if (rc == GDN_OK && hipMemset(d_total.p, 0, 16) != hipSuccess) rc = GDN_ERR_HIP;
   st.prep_ms = tprep.stop_ms();
   if (rc == GDN_OK) {
     tsolve.start();  // src/tc/gpu_base.cu:52-58
-    unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK);
-    if (nb > 65536) nb = 65536;  // gpu_base.cu:39
-    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, d_total.p);
+    unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK * 16);
+    if (nb > 256 * 4) nb = 256 * 4;  // persistent: 4 workgroups per CU pulling vertex batches
+    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m,
+                       (unsigned *)(d_total.p + 1), d_total.p);
     unsigned long long h = 0;
     if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
       gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));

@@ -161,3 +161,37 @@ class ResidentBFS:
         self.L.gdn_graph_free(self.h_out)
         if self.h_in:
             self.L.gdn_graph_free(self.h_in)
+
+
+class ResidentSpMV:
+    """y += A x with the matrix resident (gdn_spmv_plan_*).  layout: 0 CSR merge-path, 1 PB."""
+
+    def __init__(self, g: Graph, Ax: np.ndarray, layout: int = _cabi.GDN_LAYOUT_PB):
+        L = _cabi.lib()
+        self.L, self.m, self.nnz = L, g.V(), g.E()
+        self.h, self.plan = C.c_void_p(), C.c_void_p()
+        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.h)))
+        self.d_Ax, self.d_x, self.d_y = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        Ax = _arr(Ax, np.float32)
+        _cabi.check(L.gdn_dev_alloc(4 * max(self.nnz, 1), C.byref(self.d_Ax)))
+        _cabi.check(L.gdn_dev_alloc(4 * self.m, C.byref(self.d_x)))
+        _cabi.check(L.gdn_dev_alloc(4 * self.m, C.byref(self.d_y)))
+        if self.nnz:
+            _cabi.check(L.gdn_dev_upload(self.d_Ax, _p(Ax), 4 * self.nnz))
+        _cabi.check(L.gdn_spmv_plan_create(self.h, self.d_Ax, layout, C.byref(self.plan)))
+
+    def multiply(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        x, y = _arr(x, np.float32), np.array(y, dtype=np.float32)
+        _cabi.check(self.L.gdn_dev_upload(self.d_x, _p(x), 4 * self.m))
+        _cabi.check(self.L.gdn_dev_upload(self.d_y, _p(y), 4 * self.m))
+        _cabi.check(self.L.gdn_spmv_dev(self.plan, self.d_Ax, self.d_x, self.d_y, None))
+        _cabi.check(self.L.gdn_dev_download(_p(y), self.d_y, 4 * self.m))
+        _cabi.check(self.L.gdn_spmv_plan_check(self.plan))
+        return y
+
+    def close(self):
+        self.L.gdn_spmv_plan_free(self.plan)
+        for d in (self.d_Ax, self.d_x, self.d_y):
+            self.L.gdn_dev_free(d)
+        self.L.gdn_graph_free(self.h)

@@ -182,7 +182,12 @@ uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan);
 
 /* _dev API -- SpMV */
 typedef struct gdn_spmv_plan gdn_spmv_plan;
-int gdn_spmv_plan_create(const gdn_graph *csr, gdn_spmv_plan **plan);
+/* layout as for PageRank.  GDN_LAYOUT_PB keeps Ax inside the plan in tile order (pass d_Ax here; the
+ * d_Ax argument of gdn_spmv_dev is then ignored) and accumulates in signed fixed point whose
+ * power-of-two scale is derived per call from max|Ax|*max|x|*max row length on the device. */
+int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax /*nullable for CSR*/, int32_t layout,
+                         gdn_spmv_plan **plan);
+int gdn_spmv_plan_check(gdn_spmv_plan *plan);
 int gdn_spmv_plan_free(gdn_spmv_plan *plan);
 /* y[v] += SUM Ax[k]*x[Aj[k]]   (src/spmv/base.cu:13, warp.cu:26, vector.cu:27 superseded) */
 int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream);

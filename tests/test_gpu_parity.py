@@ -216,6 +216,29 @@ def test_spmv_vs_oracle_rmat(orc, scale, ef, seed):
     assert np.array_equal(y2, y1 * np.float32(2))
 
 
+@pytest.mark.parametrize("layout", [0, 1])
+@pytest.mark.parametrize("scale,ef,seed,signed", [(13, 16, 14, False), (17, 16, 15, True), (15, 64, 16, True)])
+def test_spmv_resident_layouts(orc, layout, scale, ef, seed, signed):
+    """gdn_spmv_plan_*: CSR merge-path and the propagation-blocked layout (signed fixed-point sums)."""
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    gi = graphio.transpose(g)
+    rng = np.random.default_rng(seed)
+    Ax, x = rng.random(gi.nnz, dtype=np.float32), rng.random(gi.m, dtype=np.float32)
+    if signed:
+        Ax, x = Ax * np.float32(200) - np.float32(100), x - np.float32(0.5)
+    y0 = rng.random(gi.m, dtype=np.float32)
+    sp = solvers.ResidentSpMV(solvers.Graph(csr=g, in_csr=gi), Ax, layout)
+    for xx in (x, x * np.float32(1e-3), np.zeros_like(x)):
+        want = orc.spmv(gi, Ax, xx, y0)
+        got = sp.multiply(xx, y0)
+        # sums of signed terms cancel: compare against the scale of the row, like SpmvVerifier
+        # (maximum_relative_error, src/spmv/spmv_util.h:16-29) but at the north-star 1e-4
+        absrow = orc.spmv(gi, np.abs(Ax), np.abs(xx), np.abs(y0))
+        assert np.all(np.abs(got - want) <= REL_TOL * absrow + 1e-30)
+        assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps) or signed
+    sp.close()
+
+
 # ------------------------------------------------------------------ SSSP
 @pytest.mark.parametrize("case", ["test_bc_unit", "chesapeake_unit", "rmat10_unit", "rmat10_w255"])
 @pytest.mark.parametrize("delta", [1, 7, 1 << 20])

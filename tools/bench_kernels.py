@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Per-kernel measurements for the remaining BASELINE.json configs (device-built R-MAT stand-ins:
+soc-LiveJournal1 / com-Orkut are not in the repo and there is no network).
+
+  config 2  PageRank pull      RMAT-22 x16 (LJ-sized: 4.2 M vertices, 65 M edges), solve to eps=1e-4
+  config 3  SpMV fp32          RMAT-25 x16, Ax/x ~ U(0,1) and the constants of src/spmv/main.cc
+  config 4  Triangle counting  RMAT-21 x16 symmetrized (Orkut stand-in), device orientation
+  +         BFS, SSSP (unit and U[1,255] weights), CC on RMAT-24 x16
+
+Every number is measured with the graph resident (the reference's Timer boundary); algorithmic bytes
+follow SURVEY 8(d).  Prints one JSON object; tools/ is measurement scaffolding, not product code.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from gardenia_amd import _cabi, graphio
+
+L = _cabi.lib()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(0)
+HBM = 8000.0
+
+
+def info(h):
+    m, nnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(h, C.byref(m), C.byref(nnz), None, None))
+    return m.value, nnz.value
+
+
+def build(scale, ef=16, want_out=True, want_in=True):
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(scale, ef, graphio.K_RAND_SEED, 1, C.byref(go) if want_out else None,
+                                 C.byref(gi) if want_in else None))
+    return go, gi
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def first_sources(out_deg, n=3):
+    return torch.nonzero(out_deg[:1 << 16] > 0)[:n].flatten().tolist()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pr-scale", type=int, default=22)
+    ap.add_argument("--spmv-scale", type=int, default=25)
+    ap.add_argument("--tc-scale", type=int, default=21)
+    ap.add_argument("--trav-scale", type=int, default=24)
+    args = ap.parse_args()
+    res = {}
+
+    # ---------------- PageRank to convergence (config 2 stand-in)
+    go, gi = build(args.pr_scale)
+    m, nnz = info(gi)
+    deg = torch.empty(m, dtype=torch.int32, device=dev)
+    _cabi.check(L.gdn_graph_degrees_dev(go, ptr(deg), None))
+    for layout, name in ((0, "csr"), (1, "pb")):
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_pr_plan_create(gi, ptr(deg), m, 0, layout, C.byref(plan)))
+        scores = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+        c = [torch.zeros(m, dtype=torch.float32, device=dev) for _ in range(2)]
+        diff = torch.zeros(1, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _cabi.check(L.gdn_pr_contrib_dev(plan, ptr(scores), ptr(c[0]), None))
+        it = 0
+        for it in range(100):
+            _cabi.check(L.gdn_pr_pull_dev(plan, ptr(c[it & 1]), ptr(scores), ptr(c[(it + 1) & 1]), ptr(diff), 0.85, None))
+            if float(diff.item()) < 1e-4:
+                break
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        b = int(L.gdn_pr_iter_bytes(plan))
+        res[f"pr_rmat{args.pr_scale}_{name}"] = {
+            "vertices": m, "edges": nnz, "iterations": it + 1, "solve_ms": dt * 1e3, "ms_per_iter": dt * 1e3 / (it + 1),
+            "gteps": nnz * (it + 1) / dt / 1e9, "algorithmic_GBps": b * (it + 1) / dt / 1e9,
+            "roofline_frac": b * (it + 1) / dt / 1e9 / HBM}
+        L.gdn_pr_plan_free(plan)
+    L.gdn_graph_free(go)
+    L.gdn_graph_free(gi)
+    del deg, scores, c
+
+    # ---------------- SpMV (config 3)
+    go, gi = build(args.spmv_scale, want_out=False)
+    m, nnz = info(gi)
+    for layout, lname in ((0, "csr"), (1, "pb")):
+      for label, mk in (("const_0.2_0.3", lambda n, v: torch.full((n,), v, dtype=torch.float32, device=dev)),
+                        ("uniform01", lambda n, v: torch.rand(n, dtype=torch.float32, device=dev))):
+        Ax, x, y = mk(nnz, 0.2), mk(m, 0.3), torch.zeros(m, dtype=torch.float32, device=dev)
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_spmv_plan_create(gi, ptr(Ax), layout, C.byref(plan)))
+        b = int(L.gdn_spmv_bytes(plan))
+        for _ in range(2):
+            _cabi.check(L.gdn_spmv_dev(plan, ptr(Ax), ptr(x), ptr(y), None))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 10
+        for _ in range(reps):
+            _cabi.check(L.gdn_spmv_dev(plan, ptr(Ax), ptr(x), ptr(y), None))
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        _cabi.check(L.gdn_spmv_plan_check(plan))
+        L.gdn_spmv_plan_free(plan)
+        res[f"spmv_rmat{args.spmv_scale}_{lname}_{label}"] = {
+            "vertices": m, "nnz": nnz, "ms": dt * 1e3, "gflops": 2 * nnz / dt / 1e9, "algorithmic_GBps": b / dt / 1e9,
+            "roofline_frac": b / dt / 1e9 / HBM, "algorithmic_bytes": b}
+        del Ax, x, y
+    L.gdn_graph_free(gi)
+
+    # ---------------- BFS / SSSP / CC on one traversal graph
+    go, gi = build(args.trav_scale)
+    m, nnz = info(go)
+    deg = torch.empty(m, dtype=torch.int32, device=dev)
+    _cabi.check(L.gdn_graph_degrees_dev(go, ptr(deg), None))
+    srcs = first_sources(deg)
+    dist = torch.empty(m, dtype=torch.int32, device=dev)
+    bplan = C.c_void_p()
+    _cabi.check(L.gdn_bfs_plan_create(go, gi, 1, C.byref(bplan)))
+    best = None
+    for s in srcs:
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_bfs_run(bplan, int(s), ptr(dist), C.byref(st)))
+        r = {"source": int(s), "ms": st.solve_ms, "levels": st.iterations, "edges_traversed": st.edges_traversed,
+             "gteps": st.edges_traversed / st.solve_ms / 1e6}
+        if best is None or r["gteps"] > best["gteps"]:
+            best = r
+    res[f"bfs_rmat{args.trav_scale}"] = best
+    L.gdn_bfs_plan_free(bplan)
+    for wname, w in (("unit", torch.ones(nnz, dtype=torch.int32, device=dev)),
+                     ("u1_255", torch.randint(1, 256, (nnz,), dtype=torch.int32, device=dev))):
+        for delta in ((1,) if wname == "unit" else (16, 64)):
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_sssp_dev(go, ptr(w), int(srcs[0]), delta, ptr(dist), C.byref(st)))
+            res[f"sssp_rmat{args.trav_scale}_{wname}_delta{delta}"] = {
+                "ms": st.solve_ms, "phases": st.iterations, "edges_traversed": st.edges_traversed,
+                "gteps": st.edges_traversed / st.solve_ms / 1e6}
+    del w
+    L.gdn_graph_free(gi)
+    # CC on the symmetrized graph: build it by transposing and merging on the host side is too slow; use
+    # the directed out-CSR (hooking is symmetric in (u,v), weakly connected components)
+    comp = torch.empty(m, dtype=torch.int32, device=dev)
+    st = _cabi.GdnStats()
+    _cabi.check(L.gdn_cc_dev(go, None, ptr(comp), C.byref(st)))
+    ncomp = int((comp == torch.arange(m, dtype=torch.int32, device=dev)).sum().item())
+    bytes_round = 8 * (m + 1) + 8 * nnz + 8 * m
+    res[f"cc_rmat{args.trav_scale}"] = {"ms": st.solve_ms, "rounds": st.iterations, "components": ncomp,
+                                        "algorithmic_GBps": bytes_round * st.iterations / st.solve_ms / 1e6,
+                                        "gteps": nnz * st.iterations / st.solve_ms / 1e6}
+    L.gdn_graph_free(go)
+    del comp, dist, deg
+
+    # ---------------- TC (config 4 stand-in): symmetrize on the host with numpy at this scale
+    g = graphio.symmetrize(graphio.rmat_graph(args.tc_scale, 16))
+    h = C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, g.rowptr.ctypes.data_as(C.c_void_p), g.colidx.ctypes.data_as(C.c_void_p),
+                                   C.byref(h)))
+    total = C.c_uint64(0)
+    st = _cabi.GdnStats()
+    _cabi.check(L.gdn_tc_dev(h, 0, C.byref(total), C.byref(st)))
+    res[f"tc_rmat{args.tc_scale}_sym"] = {"vertices": g.m, "sym_edges": g.nnz, "dag_edges": st.edges_traversed,
+                                          "triangles": int(total.value), "count_ms": st.solve_ms,
+                                          "orient_ms": st.prep_ms, "gteps_dag": st.edges_traversed / st.solve_ms / 1e6}
+    L.gdn_graph_free(h)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
