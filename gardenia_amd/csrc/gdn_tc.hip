@@ -72,17 +72,34 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 // walked through gdn_expand_wave, so the 64 lanes always hold 64 distinct (v, w) pairs no matter how
 // short the lists are; every w is looked up in N+(u) by binary search in LDS (global memory when
 // N+(u) does not fit).  With the degree orientation every list is O(sqrt(nnz)) long.
-#define TC_CAP 2048
+#define TC_CAP 2048            // ids of N+(u) kept in LDS per wave
+#define TC_HASH (2 * TC_CAP)   // open-addressing slots per wave (load factor <= 0.5)
+#define TC_EMPTY (-1)
+
+__device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - 12); }
 
 struct TcCountVis {
   const vid_t *__restrict__ colidx;
-  const vid_t *nu;  // N+(u): LDS copy or the global list
+  const vid_t *nu;    // N+(u) in global memory (fallback for lists longer than TC_CAP)
+  const vid_t *table; // LDS hash set of N+(u), or nullptr
   int du;
   unsigned long long count;
   __device__ __forceinline__ void begin_big(vid_t) {}
   __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
-    if (valid) {
-      const vid_t w = colidx[k];
+    if (!valid) return;
+    const vid_t w = colidx[k];
+    if (table) {  // expected ~1.3 probes
+      unsigned h = tc_hash(w);
+      for (;;) {
+        const vid_t x = table[h];
+        if (x == w) {
+          count++;
+          break;
+        }
+        if (x == TC_EMPTY) break;
+        h = (h + 1) & (TC_HASH - 1);
+      }
+    } else {
       int lo = 0, hi = du - 1;
       while (lo <= hi) {
         const int mid = (lo + hi) >> 1;
@@ -101,7 +118,7 @@ struct TcCountVis {
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
                 unsigned *__restrict__ next_vertex, unsigned long long *__restrict__ total) {
-  __shared__ vid_t s_nu[GDN_WAVES_PER_BLOCK][TC_CAP];
+  __shared__ vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
@@ -114,6 +131,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
   nobig.count = nullptr;
   nobig.capacity = 0;
   nobig.overflow = nullptr;
+  for (int i = lane; i < TC_HASH; i += 64) s_tab[w][i] = TC_EMPTY;
   for (;;) {
     // dynamic vertex assignment: 16 consecutive vertices per grab (one atomic per 16 rows)
     unsigned u0 = 0;
@@ -126,11 +144,15 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       const int du = (int)(ue - ub);
       if (du < 2) continue;  // a single out-neighbour closes no triangle
       vis.du = du;
-      if (du <= TC_CAP) {
-        for (int i = lane; i < du; i += 64) s_nu[w][i] = colidx[ub + i];
-        vis.nu = s_nu[w];
-      } else {
-        vis.nu = colidx + ub;
+      vis.nu = colidx + ub;
+      const bool hashed = du <= TC_CAP;
+      vis.table = hashed ? s_tab[w] : nullptr;
+      if (hashed) {  // build the hash set of N+(u): integer LDS CAS, linear probing
+        for (int i = lane; i < du; i += 64) {
+          const vid_t x = colidx[ub + i];
+          unsigned h = tc_hash(x);
+          while (atomicCAS(&s_tab[w][h], TC_EMPTY, x) != TC_EMPTY) h = (h + 1) & (TC_HASH - 1);
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -140,13 +162,26 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
         eoff_t vb = 0, ve = 0;
         vid_t v = 0;
         if (i < ue) {
-          v = vis.nu == s_nu[w] ? s_nu[w][i - ub] : colidx[i];
+          v = colidx[i];
           vb = rowptr[v];
           ve = rowptr[v + 1];
         }
         gdn_expand_wave(vb, ve, v, nobig, vis, s_scan[w]);
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      if (hashed) {  // clear only the slots that were used
+        for (int i = lane; i < du; i += 64) {
+          const vid_t x = colidx[ub + i];
+          unsigned h = tc_hash(x);
+          while (s_tab[w][h] != x) h = (h + 1) & (TC_HASH - 1);
+          s_tab[w][h] = TC_EMPTY;
+        }
+        // (the search above walks past emptied slots: every key is still present until ITS lane
+        // clears it, so all du keys are found and the table is empty again afterwards)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
     }
   }
   unsigned long long count = gdn_block_sum(vis.count, s_red);

@@ -39,6 +39,7 @@ class ShardedPageRank:
         self.rank, self.world, self.dist = rank, world, dist
         self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
         self.damping = damping
+        self._inplace = True
         self.cur = 0  # index of the contrib buffer holding the current iteration's input
         self.iterations = 0
 
@@ -51,7 +52,13 @@ class ShardedPageRank:
         if self.world > 1:
             full = self.be.contrib_full(which)
             mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
-            self.dist.all_gather_into_tensor(full, mine)
+            if self._inplace:
+                try:  # in-place all-gather: each rank's slice already sits at its place in `full`
+                    self.dist.all_gather_into_tensor(full, mine)
+                    return
+                except (RuntimeError, ValueError):
+                    self._inplace = False  # a backend that rejects aliasing: gather from a copy
+            self.dist.all_gather_into_tensor(full, mine.clone())
 
     def step(self):
         """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
