@@ -230,14 +230,18 @@ transpose_keys_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, Key
 struct PbKeyVis {
   const vid_t *__restrict__ colidx;
   unsigned long long *__restrict__ keys;
+  const eoff_t *__restrict__ cs;  // compact source index of every global id (nullptr = identity)
+  const eoff_t *__restrict__ cd;  // compact row index of every local row (nullptr = identity)
   int log_chunk, log_bin;
   int bin_bits;
   int32_t v;
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
-    const unsigned row = (unsigned)__shfl(v, owner, 64);
+    unsigned row = (unsigned)__shfl(v, owner, 64);
     if (valid) {
-      const unsigned col = (unsigned)colidx[k];
+      unsigned col = (unsigned)colidx[k];
+      if (cs) col = (unsigned)cs[col];
+      if (cd) row = (unsigned)cd[row];
       const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
       const unsigned long long vl = row & ((1u << log_bin) - 1u), ul = col & ((1u << log_chunk) - 1u);
       keys[k] = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | (vl << log_chunk) | ul;
@@ -262,6 +266,56 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 pb_keys_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PbKeyVis vis) {
   vis.v = 0;
   gdn_expand_big_items(rowptr, big, vis);
+}
+
+// ---- vertex compaction helpers
+struct PbMarkVis {
+  const vid_t *__restrict__ colidx;
+  uint32_t *__restrict__ mark;
+  __device__ __forceinline__ void begin_big(vid_t) {}
+  __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
+    if (valid) mark[colidx[k]] = 1u;  // benign race: everybody stores 1
+  }
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_mark_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, PbMarkVis vis, uint32_t *__restrict__ dflag) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+    dflag[v] = e > b ? 1u : 0u;
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_mark_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PbMarkVis vis) {
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
+// activity bitmap + original id of the first active vertex of every slice
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_slices_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cidx, unsigned n, int log_slice,
+                 unsigned nslices, uint32_t *__restrict__ bits, uint32_t *__restrict__ lo) {
+  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;  // one 32-id word per thread
+  if (w > ((n + 31u) >> 5)) return;
+  unsigned word = 0;
+  for (unsigned i = 0; i < 32; i++) {
+    const unsigned id = (w << 5) + i;
+    if (id < n && flag[id]) {
+      word |= 1u << i;
+      const eoff_t c = cidx[id];
+      if ((c & ((1ull << log_slice) - 1ull)) == 0 && (c >> log_slice) > 0) lo[c >> log_slice] = id;
+    }
+  }
+  if (w < ((n + 31u) >> 5)) bits[w] = word;
+  if (w == 0) {
+    lo[0] = 0;  // slice 0 also owns the inactive ids in front of its first active one
+    lo[nslices] = n;
+  }
 }
 
 // tsu[t] = index of the first sorted key whose tile id (chunk*nbins + bin) is >= t
@@ -323,7 +377,7 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
                   uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
-                  const float *__restrict__ ev_in, float *__restrict__ ev_out) {
+                  const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -336,7 +390,7 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     const unsigned ul = (unsigned)k & ((1u << log_chunk) - 1u);
     const unsigned vl = (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
     U[pu[t] + off] = (uint16_t)ul;
-    V[pv[b * nchunks + c] + off] = (uint16_t)vl;
+    V[pv[b * nchunks + c] + off] = randv ? (uint16_t)((i * 2654435761ull >> 7) & ((1u << log_bin) - 1u)) : (uint16_t)vl;
     if (ev_in) {  // value of this edge: find the column in its (ascending) CSR row
       const unsigned long long row = (b << log_bin) + vl;
       const vid_t col = (vid_t)((c << log_chunk) + ul);
@@ -364,9 +418,10 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, u
 }
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
-             const float *edge_vals_in, DevBuf<float> *edge_vals_out) {
+             const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
+  GDN_REQUIRE(!(compact && edge_vals_in), "edge values are not supported on a compacted layout");
   const int32_t m = g->m;
   const unsigned long long n = g->nnz;
   p.m_local = m;
@@ -374,8 +429,66 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   p.nnz = n;
   p.log_chunk = log_chunk;
   p.log_bin = log_bin;
-  p.nchunks = (unsigned)(((uint64_t)m_global + (1u << log_chunk) - 1) >> log_chunk);
-  p.nbins = (unsigned)(((uint64_t)m + (1u << log_bin) - 1) >> log_bin);
+  p.compact = compact;
+  uint64_t n_src = (uint64_t)m_global, n_dst = (uint64_t)m;
+  DevBuf<eoff_t> cs, cd;  // compact index of every source id / row (exclusive scans of the flags)
+  if (compact) {
+    DevBuf<uint32_t> sflag, dflag;
+    DevBuf<unsigned long long> bigitems;
+    DevBuf<unsigned> cnt;
+    const uint64_t bigcap64 = n / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+    const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+    GDN_TRY(sflag.alloc((size_t)m_global));
+    GDN_TRY(dflag.alloc((size_t)m));
+    GDN_TRY(cs.alloc((size_t)m_global + 1));
+    GDN_TRY(cd.alloc((size_t)m + 1));
+    GDN_TRY(bigitems.alloc(bigcap));
+    GDN_TRY(cnt.alloc(2));
+    GDN_HIP(hipMemset(cnt.p, 0, 8));
+    GDN_HIP(hipMemset(sflag.p, 0, (size_t)m_global * 4));
+    ExpBigList big;
+    big.items = bigitems.p;
+    big.capacity = bigcap;
+    big.count = cnt.p;
+    big.overflow = cnt.p + 1;
+    PbMarkVis mv;
+    mv.colidx = g->colidx;
+    mv.mark = sflag.p;
+    hipLaunchKernelGGL(pb_mark_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, mv, dflag.p);
+    hipLaunchKernelGGL(pb_mark_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, mv);
+    GDN_HIP(hipGetLastError());
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64(sflag.p, cs.p, (size_t)m_global, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64(dflag.p, cd.p, (size_t)m, 0));
+    eoff_t tot[2];
+    GDN_HIP(hipMemcpy(&tot[0], cs.p + m_global, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    GDN_HIP(hipMemcpy(&tot[1], cd.p + m, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    unsigned ovf[2];
+    GDN_HIP(hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost));
+    if (ovf[1]) {
+      gdn_set_error("pb_build: device worklist overflow");
+      return GDN_ERR_OVERFLOW;
+    }
+    n_src = tot[0];
+    n_dst = tot[1];
+    const unsigned nch = (unsigned)((n_src + (1u << log_chunk) - 1) >> log_chunk), nbn = (unsigned)((n_dst + (1u << log_bin) - 1) >> log_bin);
+    const unsigned nchunks = nch ? nch : 1u, nbins = nbn ? nbn : 1u;
+    GDN_TRY(p.src_bits.alloc(((size_t)m_global + 31) / 32 + 1));
+    GDN_TRY(p.dst_bits.alloc(((size_t)m + 31) / 32 + 1));
+    GDN_TRY(p.chunk_lo.alloc((size_t)nchunks + 1));
+    GDN_TRY(p.bin_lo.alloc((size_t)nbins + 1));
+    GDN_HIP(hipMemset(p.chunk_lo.p, 0, ((size_t)nchunks + 1) * 4));
+    GDN_HIP(hipMemset(p.bin_lo.p, 0, ((size_t)nbins + 1) * 4));
+    hipLaunchKernelGGL(pb_slices_kernel, dim3(gdn_nblocks(((uint64_t)m_global + 31) / 32 + 1)), dim3(GDN_BLOCK), 0, 0,
+                       sflag.p, cs.p, (unsigned)m_global, log_chunk, nchunks, p.src_bits.p, p.chunk_lo.p);
+    hipLaunchKernelGGL(pb_slices_kernel, dim3(gdn_nblocks(((uint64_t)m + 31) / 32 + 1)), dim3(GDN_BLOCK), 0, 0, dflag.p,
+                       cd.p, (unsigned)m, log_bin, nbins, p.dst_bits.p, p.bin_lo.p);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipDeviceSynchronize());
+  }
+  p.nchunks = (unsigned)((n_src + (1u << log_chunk) - 1) >> log_chunk);
+  p.nbins = (unsigned)((n_dst + (1u << log_bin) - 1) >> log_bin);
+  if (p.nchunks == 0) p.nchunks = 1;
+  if (p.nbins == 0) p.nbins = 1;
   const int bin_bits = bits_for((int32_t)p.nbins);
   const int chunk_bits = bits_for((int32_t)p.nchunks);
   const unsigned long long ntiles = (unsigned long long)p.nchunks * p.nbins;
@@ -410,6 +523,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     PbKeyVis vis;
     vis.colidx = g->colidx;
     vis.keys = ka.p;
+    vis.cs = compact ? cs.p : nullptr;
+    vis.cd = compact ? cd.p : nullptr;
     vis.log_chunk = log_chunk;
     vis.log_bin = log_bin;
     vis.bin_bits = bin_bits;
@@ -424,6 +539,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       return GDN_ERR_OVERFLOW;
     }
     bigitems.release();
+    cs.release();
+    cd.release();
     const unsigned long long *sorted = nullptr;
     GDN_TRY(sort_keys(ka, kb, n, (unsigned)(chunk_bits + bin_bits + log_chunk + log_bin), &sorted));
     if (n == 0) {
@@ -467,7 +584,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     if (n)
       hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
-                         ev_out ? edge_vals_in : nullptr, ev_out);
+                         ev_out ? edge_vals_in : nullptr, ev_out,
+                         getenv("GDN_PB_TEST_RANDV") ? 1 : 0);  // TIMING-ONLY experiment: uniform row ids
     // GDN_PB_IDENTITY=1 is a TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
                        p.G.p, getenv("GDN_PB_IDENTITY") ? 1 : 0);

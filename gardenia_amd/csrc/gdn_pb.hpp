@@ -62,6 +62,12 @@ struct PbPlan {
   DevBuf<double> partial;         // nbins
   DevBuf<double> red_scratch;
   DevBuf<unsigned> errflag;       // 1 word: fixed-point range violation
+  // vertex compaction (PageRank): chunks / bins are cut over the ACTIVE sources (referenced by an
+  // edge) and ACTIVE rows (in-degree > 0) only -- on RMAT-27 half of the vertices are neither, so
+  // tiles get 4x longer.  Bitmaps over the original ids + the original id range of every slice.
+  bool compact = false;
+  DevBuf<uint32_t> src_bits, dst_bits;   // ceil(m_global/32), ceil(m_local/32) words
+  DevBuf<uint32_t> chunk_lo, bin_lo;     // nchunks + 1 / nbins + 1 original ids
   bool timing = false;
   std::vector<hipEvent_t> ev;  // triples: start, after A, after B
   size_t ev_used = 0;
@@ -74,23 +80,137 @@ struct PbPlan {
 // alloc_vals = false: only the static layout (U, V, G, pointers, orders) -- BFS keeps 1 bit per edge
 // edge_vals_in (nullable, CSR order) -> *edge_vals_out in chunk-major order, pads = 0 (SpMV's Ax)
 int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true,
-             const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr);
+             const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr, bool compact = false);
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short pb_u16x4 __attribute__((ext_vector_type(4)));
 typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 
+// exclusive scan over the PB_THREADS threads of a workgroup; scratch = PB_WAVES + 1 unsigned
+__device__ __forceinline__ unsigned pb_block_excl_scan(unsigned v, unsigned *scratch, unsigned *total) {
+  const unsigned incl = gdn_wave_incl_scan(v);
+  const unsigned w = threadIdx.x >> 6;
+  __syncthreads();
+  if (gdn_lane() == 63) scratch[w] = incl;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < PB_WAVES; i++) {
+    const unsigned x = scratch[i];
+    if ((unsigned)i < w) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+// Walk the original ids [lo,hi) of a compacted slice in tiles of 32*PB_THREADS ids.  For every tile
+// s_bits[w] / s_pref[w] (PB_THREADS words each) hold the activity word and the compact index of its
+// first active id; fn(id, k) is called for every ACTIVE id (k = index inside the slice) and
+// fn_inactive(id) for the others, ids visited in coalesced order.
+template <class FA, class FI>
+__device__ __forceinline__ void pb_walk_slice(const uint32_t *__restrict__ bits, unsigned lo, unsigned hi,
+                                              unsigned *s_bits, unsigned *s_pref, unsigned *s_scr, FA fn, FI fn_inactive) {
+  unsigned running = 0;
+  const unsigned w_begin = lo >> 5, w_end = (hi + 31u) >> 5;
+  for (unsigned wb = w_begin; wb < w_end; wb += PB_THREADS) {
+    const unsigned w = wb + threadIdx.x;
+    unsigned b = (w < w_end) ? bits[w] : 0u;
+    if (w == w_begin && (lo & 31u)) b &= ~0u << (lo & 31u);
+    if (w + 1 == w_end && (hi & 31u)) b &= ~0u >> (32u - (hi & 31u));
+    unsigned total;
+    const unsigned ex = pb_block_excl_scan((unsigned)__popc(b), s_scr, &total);
+    s_bits[threadIdx.x] = b;
+    s_pref[threadIdx.x] = running + ex;
+    __syncthreads();
+    const unsigned id0 = wb << 5;
+#pragma unroll 4
+    for (unsigned j = 0; j < 32; j++) {
+      const unsigned off = j * PB_THREADS + threadIdx.x;
+      const unsigned id = id0 + off;
+      if (id >= lo && id < hi) {
+        const unsigned bw = s_bits[off >> 5];
+        const unsigned bit = 1u << (off & 31u);
+        if (bw & bit) fn(id, s_pref[off >> 5] + (unsigned)__popc(bw & (bit - 1u)));
+        else fn_inactive(id);
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+// Epilogue walk over the original rows [lo,hi) of a bin with software prefetch: per step every thread
+// gathers the row state of EPI rows (op.pre: independent loads in flight together), then finishes
+// them (op.fin: compute + stores).  bits == nullptr: plain bin (row r <-> accumulator r - lo).
+#define PB_EPI 8
+template <class Op, class SumOf>
+__device__ __forceinline__ double pb_epilogue(const uint32_t *__restrict__ bits, unsigned lo, unsigned hi,
+                                              unsigned *s_bits, unsigned *s_pref, unsigned *s_scr, const Op &op,
+                                              SumOf sum_of) {
+  double dsum = 0.0;
+  unsigned running = 0;
+  const unsigned w_begin = lo >> 5, w_end = (hi + 31u) >> 5;
+  for (unsigned wb = w_begin; wb < w_end; wb += PB_THREADS) {
+    const unsigned w = wb + threadIdx.x;
+    unsigned b = 0u;
+    if (w < w_end) b = bits ? bits[w] : ~0u;
+    if (w == w_begin && (lo & 31u)) b &= ~0u << (lo & 31u);
+    if (w + 1 == w_end && (hi & 31u)) b &= ~0u >> (32u - (hi & 31u));
+    unsigned total;
+    const unsigned ex = pb_block_excl_scan((unsigned)__popc(b), s_scr, &total);
+    s_bits[threadIdx.x] = b;
+    s_pref[threadIdx.x] = running + ex;
+    __syncthreads();
+    const unsigned id0 = wb << 5;
+    for (unsigned j0 = 0; j0 < 32; j0 += PB_EPI) {
+      typename Op::Pre pre[PB_EPI];
+      float sum[PB_EPI];
+      bool ok[PB_EPI];
+#pragma unroll
+      for (int j = 0; j < PB_EPI; j++) {
+        const unsigned off = (j0 + j) * PB_THREADS + threadIdx.x;
+        const unsigned id = id0 + off;
+        ok[j] = id >= lo && id < hi;
+        sum[j] = 0.0f;
+        if (ok[j]) {
+          const unsigned bw = s_bits[off >> 5];
+          const unsigned bit = 1u << (off & 31u);
+          if (bw & bit) sum[j] = sum_of(s_pref[off >> 5] + (unsigned)__popc(bw & (bit - 1u)));
+          pre[j] = op.pre((int32_t)id);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < PB_EPI; j++) {
+        const unsigned id = id0 + (j0 + j) * PB_THREADS + threadIdx.x;
+        if (ok[j]) dsum += op.fin((int32_t)id, sum[j], pre[j]);
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+  return dsum;
+}
+
 // phase A: vals[8*G[g] + i] = x[chunk*CH + U[8*g + i]]
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
                  const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
-                 const uint32_t *__restrict__ G, float *__restrict__ vals) {
+                 const uint32_t *__restrict__ G, float *__restrict__ vals, const uint32_t *__restrict__ src_bits,
+                 const uint32_t *__restrict__ chunk_lo, unsigned split) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
+  __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
-  const unsigned c = chunk_order[blockIdx.x];
+  // `split` workgroups share one chunk (same LDS slice, consecutive parts of its edge range): more,
+  // smaller work units so that the last round of workgroups does not leave most CUs idle
+  const unsigned c = chunk_order[blockIdx.x / split];
+  const unsigned part = blockIdx.x % split;
   const size_t base = (size_t)c << log_chunk;
-  if (base + ch <= (size_t)m_global) {  // whole slice in range: 16-byte loads
+  if (src_bits) {  // compacted slice: the chunk's active sources, gathered from their original id range
+    pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
+                  [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
+  } else if (base + ch <= (size_t)m_global) {  // whole slice in range: 16-byte loads
     const pb_f32x4 *x4 = reinterpret_cast<const pb_f32x4 *>(x + base);
     pb_f32x4 *s4 = reinterpret_cast<pb_f32x4 *>(s_x);
 #pragma unroll 4
@@ -105,7 +225,10 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   __syncthreads();
   // half-groups: lane pair (2i, 2i+1) handles group i; each lane loads 4 source ids (8 B),
   // gathers 4 values from LDS and stores 16 B, so a wave store covers whole 64-byte lines
-  const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
+  const eoff_t hc0 = chunk_ptr[c] >> 2, hc1 = chunk_ptr[c + 1] >> 2;
+  const eoff_t hlen = (hc1 - hc0 + split - 1) / split;
+  const eoff_t h0 = hc0 + (eoff_t)part * hlen;
+  const eoff_t h1 = (h0 + hlen < hc1) ? h0 + hlen : hc1;
   const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
   pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
   constexpr int UNR = 8;
@@ -214,9 +337,11 @@ __global__ void __launch_bounds__(PB_THREADS)
 pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
                      const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
                      const float *__restrict__ vals, double *__restrict__ partial, unsigned *__restrict__ errflag,
-                     Op op) {
+                     const uint32_t *__restrict__ dst_bits, const uint32_t *__restrict__ bin_lo, Op op,
+                     int dbg = 0) {  // dbg: timing-only experiments (bit0 no LDS atomics, bit1 no epilogue)
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
+  __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order[blockIdx.x];
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
@@ -228,9 +353,12 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const pb_u16x4 *V4 = reinterpret_cast<const pb_u16x4 *>(V);
   unsigned bad = 0u;
   constexpr int UNR = 4;
-  for (eoff_t q = q0 + threadIdx.x; q < q1; q += UNR * PB_THREADS) {
-    pb_f32x4 xs[UNR];
-    pb_u16x4 vs[UNR];
+  const eoff_t STEP = (eoff_t)UNR * PB_THREADS;
+  pb_f32x4 xs[UNR], nx[UNR];
+  pb_u16x4 vs[UNR], nv[UNR];
+  // software pipeline: the loads of step i+1 are in flight while step i is folded into LDS
+  {
+    const eoff_t q = q0 + threadIdx.x;
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
@@ -239,12 +367,26 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         vs[r] = __builtin_nontemporal_load(V4 + qq);
       }
     }
+  }
+  for (eoff_t q = q0 + threadIdx.x; q < q1; q += STEP) {
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const eoff_t qq = q + STEP + (eoff_t)r * PB_THREADS;
+      if (qq < q1) {
+        nx[r] = __builtin_nontemporal_load(X4 + qq);
+        nv[r] = __builtin_nontemporal_load(V4 + qq);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
       if (qq < q1) {
         // edges of one tile are sorted by destination row: fold equal neighbours in the lane
         // first (a hub row receives hundreds of consecutive edges per tile)
+        if (dbg & 1) {
+          bad |= (unsigned)(xs[r].x + xs[r].y + xs[r].z + xs[r].w == 123.456f) + (unsigned)(vs[r].x + vs[r].w == 77777u);
+          continue;
+        }
         unsigned cur = vs[r].x;
         unsigned long long a = op.to_fixed(xs[r].x, bad);
         unsigned long long f = op.to_fixed(xs[r].y, bad);
@@ -271,23 +413,21 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         atomicAdd(&s_acc[cur], a);
       }
     }
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      xs[r] = nx[r];
+      vs[r] = nv[r];
+    }
   }
   __syncthreads();
   double dsum = 0.0;
-  const size_t row0 = (size_t)b << log_bin;
-  if (row0 + bn <= (size_t)m_local) {  // full bin: unrolled so the row loads of several steps overlap
-#pragma unroll 8
-    for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
-      // fixed -> float with one rounding, then the exact power-of-two scale
-      dsum += op.finish((int32_t)(row0 + i), op.from_fixed(s_acc[i], bad));
-    }
-  } else {
-    for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
-      const size_t row = row0 + i;
-      if (row < (size_t)m_local) {
-        dsum += op.finish((int32_t)row, op.from_fixed(s_acc[i], bad));
-      }
-    }
+  if (!(dbg & 2)) {
+    // compacted bin: its original row range (rows without in-edges get sum 0); plain bin: its 2^log_bin rows
+    const size_t row0 = (size_t)b << log_bin;
+    const unsigned lo = dst_bits ? bin_lo[b] : (unsigned)row0;
+    const unsigned hi = dst_bits ? bin_lo[b + 1] : (unsigned)((row0 + bn < (size_t)m_local) ? row0 + bn : (size_t)m_local);
+    dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
+                       [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
   }
   if (bad) *errflag = 1u;
   dsum = gdn_wave_sum(dsum);

@@ -39,13 +39,18 @@ struct PrOp {
     if (a >> 63) bad = 1u;
     return ldexpf((float)a, -PB_FIX_SHIFT);
   }
-  __device__ __forceinline__ double finish(int32_t row, float sum) const {
-    const float old_score = scores[row];
+  struct Pre {
+    float old_score;
+    int32_t deg;
+  };
+  __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{scores[row], out_degree[row]}; }
+  __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
     const float new_score = __fadd_rn(base_score, __fmul_rn(damping, sum));
     scores[row] = new_score;
-    contrib_out[row] = __fdiv_rn(new_score, (float)out_degree[row]);
-    return (double)fabsf(__fsub_rn(new_score, old_score));
+    contrib_out[row] = __fdiv_rn(new_score, (float)p.deg);
+    return (double)fabsf(__fsub_rn(new_score, p.old_score));
   }
+  __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
 };
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -91,7 +96,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN);
     if (const char *e = getenv("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
     if (const char *e = getenv("GDN_PB_LOG_BIN")) lb = atoi(e);
-    st = pb_build(in_csr, m_global, lc, lb, p->pb);
+    // vertex compaction on by default (GDN_PB_COMPACT=0 switches it off for A/B measurements)
+    const char *ce = getenv("GDN_PB_COMPACT");
+    st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, !(ce && ce[0] == '0'));
     if (st == GDN_OK) {
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
@@ -149,12 +156,20 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
-  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
-                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p);
+  static unsigned split = 0;
+  if (split == 0) {
+    const char *e = getenv("GDN_PB_SPLIT");
+    split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
+    if (split < 1 || split > 64) split = 1;
+  }
+  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
+                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
+                     pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
-                     pb.errflag.p, op);
+                     pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
+                     getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

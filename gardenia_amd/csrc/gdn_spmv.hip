@@ -30,10 +30,15 @@ struct SpmvOp {
   __device__ __forceinline__ float load(uint64_t j, vid_t col) const {
     return __fmul_rn(x[col], __builtin_nontemporal_load(Ax + j));
   }
-  __device__ __forceinline__ double finish(int32_t row, float sum) const {
-    y[row] = __fadd_rn(y[row], sum);
+  struct Pre {
+    float y;
+  };
+  __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{y[row]}; }
+  __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
+    y[row] = __fadd_rn(p.y, sum);
     return 0.0;
   }
+  __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
   // PB layout: signed fixed point with a per-call power-of-two scale (gdn_pb.hpp)
   const float *__restrict__ scale;
   __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const {
@@ -182,7 +187,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
-                     pb.errflag.p, op);
+                     pb.errflag.p, nullptr, nullptr, op);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

@@ -80,6 +80,28 @@ __global__ void __launch_bounds__(T) accumB(const uint16_t *__restrict__ V, cons
   if (racc == 1.2345f || s_acc[threadIdx.x] == 77) out[0] = racc;
 }
 
+// ceilings: write-only and copy streams, 16 B per lane
+__global__ void __launch_bounds__(T) write_only(f32x4 *__restrict__ out, size_t n4) {
+  size_t i = (size_t)blockIdx.x * T * 8 + threadIdx.x;
+  f32x4 v = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+  for (int k = 0; k < 8; k++) { size_t j = i + (size_t)k * T; if (j < n4) out[j] = v; }
+}
+__global__ void __launch_bounds__(T) write_only_nt(f32x4 *__restrict__ out, size_t n4) {
+  size_t i = (size_t)blockIdx.x * T * 8 + threadIdx.x;
+  f32x4 v = {1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+  for (int k = 0; k < 8; k++) { size_t j = i + (size_t)k * T; if (j < n4) __builtin_nontemporal_store(v, out + j); }
+}
+__global__ void __launch_bounds__(T) copy16(const f32x4 *__restrict__ in, f32x4 *__restrict__ out, size_t n4) {
+  size_t i = (size_t)blockIdx.x * T * 8 + threadIdx.x;
+  f32x4 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) { size_t j = i + (size_t)k * T; if (j < n4) v[k] = __builtin_nontemporal_load(in + j); }
+#pragma unroll
+  for (int k = 0; k < 8; k++) { size_t j = i + (size_t)k * T; if (j < n4) out[j] = v[k]; }
+}
+
 template <class F> float timeit(F f) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
@@ -114,6 +136,18 @@ int main() {
       RUNA(3, "plain (temporal) loads");
       RUNA(4, "no LDS, no G: pure 2B-read/4B-write stream");
     }
+  }
+  {
+    const size_t n4 = n / 4;  // 8.6 GB
+    const unsigned nb = (unsigned)((n4 + T * 8 - 1) / (T * 8));
+    float ms = timeit([&] { write_only<<<nb, T>>>((f32x4 *)vals, n4); });
+    printf("W write-only 16 B/lane (plain)                         %7.3f ms  %6.2f TB/s\n", ms, n * 4.0 / ms / 1e9);
+    ms = timeit([&] { write_only_nt<<<nb, T>>>((f32x4 *)vals, n4); });
+    printf("W write-only 16 B/lane (nontemporal)                   %7.3f ms  %6.2f TB/s\n", ms, n * 4.0 / ms / 1e9);
+    const size_t h4 = n4 / 2;
+    const unsigned nb2 = (unsigned)((h4 + T * 8 - 1) / (T * 8));
+    ms = timeit([&] { copy16<<<nb2, T>>>((const f32x4 *)vals, (f32x4 *)vals + h4, h4); });
+    printf("C copy 4.3 GB -> 4.3 GB                                %7.3f ms  %6.2f TB/s (read+write)\n", ms, n * 4.0 / ms / 1e9);
   }
   RUNB(3, "full: u64 LDS atomics + fixed conversion");
   RUNB(1, "u64 LDS atomics, no conversion");
