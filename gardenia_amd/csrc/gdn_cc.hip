@@ -1,4 +1,13 @@
-// gdn_cc.hip -- connected components: Shiloach-Vishkin hooking + pointer jumping.
+// gdn_cc.hip -- connected components: Afforest (when the reverse graph is given) or
+// Shiloach-Vishkin hooking + pointer jumping.
+//
+// Afforest (src/cc/omp_afforest.cc:37-83, CUDA src/cc/afforest.cu:32-88): two neighbour-sampling
+// rounds link every vertex with its r-th neighbour (2m links instead of nnz), a sample of 1024 labels
+// finds the giant component c, and only vertices OUTSIDE c walk their remaining out- and in-edges.
+// On R-MAT graphs that skips almost every edge.  link() is a CAS loop that always points the higher
+// root at the lower one, so the final label of a vertex is the minimum vertex id of its component --
+// the same labels as the SV fixpoint -- whatever the sample is.  Label reads inside link() are
+// agent-scope atomic loads: the 8 XCD L2s are not coherent for plain loads within one launch.
 //
 // Reference path: CCSolver (src/cc/cc.h:28).  OpenMP src/cc/omp_base.cc:6-50 (hook :24-37,
 // shortcut :38-43, repeat while changed); CUDA src/cc/base.cu:8 hook (thread per vertex, racy
@@ -10,6 +19,8 @@
 // symmetric in (u,v) like omp_base.cc:27-36, so the out-CSR alone yields weakly connected
 // components; in_csr is accepted for API parity and unused by this variant.
 #include <string.h>
+
+#include <algorithm>
 
 #include "gdn_expand.hpp"
 
@@ -85,6 +96,81 @@ __global__ void __launch_bounds__(GDN_BLOCK) cc_shortcut_kernel(int32_t *__restr
   comp[v] = c;
 }
 
+// ------------------------------------------------------------------------------------------
+// Afforest
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t cc_ld(const int32_t *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void cc_link(int32_t u, int32_t v, int32_t *comp) {  // omp_afforest.cc:12-25
+  int32_t p1 = cc_ld(comp + u), p2 = cc_ld(comp + v);
+  while (p1 != p2) {
+    const int32_t high = p1 > p2 ? p1 : p2;
+    const int32_t low = p1 + (p2 - high);
+    const int32_t p_high = cc_ld(comp + high);
+    if (p_high == low) break;
+    if (p_high == high && atomicCAS(comp + high, high, low) == high) break;
+    p1 = cc_ld(comp + cc_ld(comp + high));
+    p2 = cc_ld(comp + low);
+  }
+}
+
+// sampling round r: link v with its r-th out-neighbour (omp_afforest.cc:40-46)
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_sample_link_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int r,
+                      int32_t *__restrict__ comp) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v >= (unsigned)m) return;
+  const eoff_t b = rowptr[v], e = rowptr[v + 1];
+  if (b + (eoff_t)r < e) cc_link((int32_t)v, colidx[b + r], comp);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_sample_labels_kernel(const int32_t *__restrict__ comp, int32_t m, int32_t *__restrict__ out, int n) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= (unsigned)n) return;
+  unsigned long long z = (i + 1) * 0x9E3779B97F4A7C15ull;
+  z ^= z >> 29;
+  z *= 0xBF58476D1CE4E5B9ull;
+  z ^= z >> 32;
+  out[i] = comp[z % (unsigned long long)m];
+}
+
+struct CcLinkVis {
+  const vid_t *__restrict__ colidx;
+  int32_t *__restrict__ comp;
+  int32_t v;  // per-lane source vertex
+  __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t src = __shfl(v, owner, 64);
+    if (valid) cc_link(src, colidx[k], comp);
+  }
+};
+
+// remaining edges of the vertices outside the giant component c (omp_afforest.cc:56-76);
+// skip = neighbours already used by the sampling rounds (out-CSR) or 0 (in-CSR)
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_finish_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int32_t c, int skip, ExpBigList big, CcLinkVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  if (v < (unsigned)m && vis.comp[v] != c) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+    b = (b + (eoff_t)skip < e) ? b + skip : e;
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+// big rows: the chunk work item does not know the skip; re-linking 2 sampled neighbours is harmless
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_finish_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, CcLinkVis vis) {
+  vis.v = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK) cc_init_kernel(int32_t *__restrict__ comp, int32_t m) {
   const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (v < (unsigned)m) comp[v] = (int32_t)v;
@@ -92,9 +178,14 @@ __global__ void __launch_bounds__(GDN_BLOCK) cc_init_kernel(int32_t *__restrict_
 
 extern "C" {
 
+static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_stats *stats);
+
 int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_stats *stats) {
   GDN_REQUIRE(g != nullptr && d_comp != nullptr, "graph / d_comp");
-  (void)gin;
+  GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
+  // With the reverse graph (or the graph itself for a symmetric one) every edge can be seen from
+  // both ends: Afforest.  Without it only the symmetric SV hook is safe on a directed graph.
+  if (gin != nullptr) return cc_afforest(g, gin, d_comp, stats);
   const int32_t m = g->m;
   gdn_stats st;
   memset(&st, 0, sizeof(st));
@@ -144,17 +235,104 @@ int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_st
   return GDN_OK;
 }
 
+}  // extern "C"
+
+static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_stats *stats) {
+  const int32_t m = g->m;
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  HostTimer tprep, tsolve;
+  tprep.start();
+  DevBuf<unsigned long long> bigitems;
+  DevBuf<CcCounters> cnt;
+  DevBuf<int32_t> d_sample;
+  const int nsample = 1024;  // src/cc/verifier.cc:13 SampleFrequentElement(num_samples = 1024)
+  const uint64_t nn = g->nnz > gin->nnz ? g->nnz : gin->nnz;
+  const uint64_t bigcap64 = nn / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+  const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+  GDN_TRY(bigitems.alloc(bigcap));
+  GDN_TRY(cnt.alloc(1));
+  GDN_TRY(d_sample.alloc(nsample));
+  st.prep_ms = tprep.stop_ms();
+
+  tsolve.start();
+  const dim3 grid_m(gdn_nblocks((uint64_t)m)), blk(GDN_BLOCK);
+  hipLaunchKernelGGL(cc_init_kernel, grid_m, blk, 0, 0, d_comp, m);
+  const int neighbor_rounds = 2;  // omp_afforest.cc:37
+  for (int r = 0; r < neighbor_rounds; r++) {
+    hipLaunchKernelGGL(cc_sample_link_kernel, grid_m, blk, 0, 0, g->rowptr, g->colidx, m, r, d_comp);
+    hipLaunchKernelGGL(cc_shortcut_kernel, grid_m, blk, 0, 0, d_comp, m);
+  }
+  // most frequent label of the sample = the giant intermediate component
+  hipLaunchKernelGGL(cc_sample_labels_kernel, dim3(gdn_nblocks(nsample)), blk, 0, 0, d_comp, m, d_sample.p, nsample);
+  int32_t h_sample[1024];
+  GDN_HIP(hipMemcpy(h_sample, d_sample.p, sizeof(h_sample), hipMemcpyDeviceToHost));
+  std::sort(h_sample, h_sample + nsample);
+  int32_t c = h_sample[0];
+  int best = 0;
+  for (int i = 0; i < nsample;) {
+    int j = i;
+    while (j < nsample && h_sample[j] == h_sample[i]) j++;
+    if (j - i > best) {
+      best = j - i;
+      c = h_sample[i];
+    }
+    i = j;
+  }
+  GDN_HIP(hipMemsetAsync(cnt.p, 0, sizeof(CcCounters), 0));
+  ExpBigList big;
+  big.items = bigitems.p;
+  big.capacity = bigcap;
+  big.count = &cnt.p->big_count;
+  big.overflow = &cnt.p->overflow;
+  CcLinkVis vis;
+  vis.comp = d_comp;
+  vis.v = 0;
+  vis.colidx = g->colidx;
+  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, c, neighbor_rounds, big, vis);
+  hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, vis);
+  if (gin != g) {  // directed: the in-edges too (omp_afforest.cc:72-74)
+    GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
+    vis.colidx = gin->colidx;
+    hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, gin->rowptr, m, c, 0, big, vis);
+    hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, gin->rowptr, big, vis);
+  }
+  hipLaunchKernelGGL(cc_shortcut_kernel, grid_m, blk, 0, 0, d_comp, m);
+  CcCounters h;
+  GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (h.overflow) {
+    gdn_set_error("gdn_cc: device worklist overflow");
+    return GDN_ERR_OVERFLOW;
+  }
+  GDN_HIP(hipGetLastError());
+  st.solve_ms = tsolve.stop_ms();
+  st.iterations = neighbor_rounds + 1;
+  st.edges_traversed = g->nnz;
+  if (stats) *stats = st;
+  return GDN_OK;
+}
+
+extern "C" {
+
 // Host API: one call == CCSolver(g, comp) (src/cc/main.cc:16).
 int gdn_cc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx, const uint64_t *in_rowptr,
            const int32_t *in_colidx, int32_t *comp, gdn_stats *stats) {
   GDN_REQUIRE(m > 0 && rowptr && comp, "null argument");
-  (void)in_rowptr;
-  (void)in_colidx;
   GDN_TRY(gdn_require_device());
   HostTimer th2d;
   th2d.start();
-  gdn_graph *g = nullptr;
+  gdn_graph *g = nullptr, *gi = nullptr;
   GDN_TRY(gdn_graph_upload(m, nnz, rowptr, colidx, &g));
+  if (in_rowptr && in_colidx) {
+    if (in_rowptr == rowptr && in_colidx == colidx) gi = g;  // symmetric graph (csr_graph.h:241-245)
+    else {
+      const int rc0 = gdn_graph_upload(m, nnz, in_rowptr, in_colidx, &gi);
+      if (rc0 != GDN_OK) {
+        gdn_graph_free(g);
+        return rc0;
+      }
+    }
+  }
   DevBuf<int32_t> d_comp;
   gdn_stats st;
   memset(&st, 0, sizeof(st));
@@ -162,13 +340,14 @@ int gdn_cc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colid
   do {
     if ((rc = d_comp.alloc(m))) break;
     const double h2d = th2d.stop_ms();
-    if ((rc = gdn_cc_dev(g, nullptr, d_comp.p, &st))) break;
+    if ((rc = gdn_cc_dev(g, gi, d_comp.p, &st))) break;
     st.h2d_ms = h2d;
     if (hipMemcpy(comp, d_comp.p, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) {
       gdn_set_error("gdn_cc: download failed");
       rc = GDN_ERR_HIP;
     }
   } while (0);
+  if (gi && gi != g) gdn_graph_free(gi);
   gdn_graph_free(g);
   if (stats) *stats = st;
   return rc;

@@ -50,8 +50,9 @@ void SSSPSolver(Graph &g, int source, DistT *weight, DistT *dist, int delta) {  
 
 void CCSolver(Graph &g, CompT *comp) {  // src/cc/cc.h:28
   gdn_stats st;
-  const bool dir = g.is_directed();
-  must(gdn_cc(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), dir ? g.in_rowptr() : nullptr, dir ? g.in_colidx() : nullptr,
+  // reverse graph for directed inputs, the graph itself for symmetrized ones (in_rowptr() aliases)
+  const bool rev = g.has_reverse_graph();
+  must(gdn_cc(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), rev ? g.in_rowptr() : nullptr, rev ? g.in_colidx() : nullptr,
               comp, &st), "CCSolver");
   printf("iterations = %d\n", st.iterations);
   printf("runtime [hip_gfx950] = %f seconds\n", st.solve_ms * 1e-3);

@@ -123,8 +123,11 @@ def CCSolver(g: Graph, comp: np.ndarray) -> dict:
     assert comp.dtype == np.int32 and comp.flags.c_contiguous
     rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
     irp = ici = None
-    if g.has_reverse_graph() and g.is_directed():
-        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    if g.has_reverse_graph():  # directed: the reverse graph; symmetrized: the graph itself (alias)
+        if g.is_directed():
+            irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+        else:
+            irp, ici = rp, ci
     st = _cabi.GdnStats()
     _cabi.check(_cabi.lib().gdn_cc(g.V(), g.E(), _p(rp), _p(ci), _p(irp), _p(ici), _p(comp), C.byref(st)))
     return st.as_dict()
@@ -194,4 +197,94 @@ class ResidentSpMV:
         self.L.gdn_spmv_plan_free(self.plan)
         for d in (self.d_Ax, self.d_x, self.d_y):
             self.L.gdn_dev_free(d)
+        self.L.gdn_graph_free(self.h)
+
+
+class ResidentPageRankShards:
+    """The sharded PageRank data path of gardenia_amd.sharded on ONE device: `world` vertex-range
+    shards of the same graph, each with its own plan (row_base, m_local < m_global), the all-gather
+    emulated by device copies.  Exercises exactly the C-ABI calls a multi-GPU run makes."""
+
+    def __init__(self, g: Graph, world: int, layout: int = _cabi.GDN_LAYOUT_AUTO):
+        from .sharded import vertex_range
+        L = _cabi.lib()
+        self.L, self.m, self.world = L, g.V(), world
+        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+        self.h = C.c_void_p()
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.h)))
+        deg = _arr(g.out_degrees(), np.int32)
+        self.ranks = []
+        self.chunk = vertex_range(0, world, self.m)[2]
+        nfull = self.chunk * world
+        for r in range(world):
+            lo, hi, _ = vertex_range(r, world, self.m)
+            sh, plan = C.c_void_p(), C.c_void_p()
+            if hi > lo:
+                _cabi.check(L.gdn_graph_slice_rows(self.h, lo, hi, C.byref(sh)))
+            d_deg, d_scores, d_diff = C.c_void_p(), C.c_void_p(), C.c_void_p()
+            d_c = [C.c_void_p(), C.c_void_p()]
+            n = max(hi - lo, 1)
+            _cabi.check(L.gdn_dev_alloc(4 * n, C.byref(d_deg)))
+            _cabi.check(L.gdn_dev_alloc(4 * n, C.byref(d_scores)))
+            _cabi.check(L.gdn_dev_alloc(8, C.byref(d_diff)))
+            for k in range(2):
+                _cabi.check(L.gdn_dev_alloc(4 * nfull, C.byref(d_c[k])))
+                _cabi.check(L.gdn_dev_upload(d_c[k], _p(np.zeros(nfull, np.float32)), 4 * nfull))
+            if hi > lo:
+                _cabi.check(L.gdn_dev_upload(d_deg, _p(np.ascontiguousarray(deg[lo:hi])), 4 * (hi - lo)))
+                init = np.full(hi - lo, np.float32(1.0) / np.float32(self.m), np.float32)
+                _cabi.check(L.gdn_dev_upload(d_scores, _p(init), 4 * (hi - lo)))
+                _cabi.check(L.gdn_pr_plan_create(sh, d_deg, self.m, lo, layout, C.byref(plan)))
+            self.ranks.append(dict(lo=lo, hi=hi, sh=sh, plan=plan, deg=d_deg, scores=d_scores, diff=d_diff, c=d_c))
+
+    def _allgather(self, which):
+        # every rank's slice [lo,hi) of buffer `which` -> the same slice of every other rank's buffer
+        for src in self.ranks:
+            n = src["hi"] - src["lo"]
+            if n <= 0:
+                continue
+            tmp = np.empty(n, np.float32)
+            off = 4 * src["lo"]
+            _cabi.check(self.L.gdn_dev_download(_p(tmp), C.c_void_p(src["c"][which].value + off), 4 * n))
+            for dst in self.ranks:
+                if dst is not src:
+                    _cabi.check(self.L.gdn_dev_upload(C.c_void_p(dst["c"][which].value + off), _p(tmp), 4 * n))
+
+    def solve(self, epsilon=EPSILON, max_iter=MAX_ITER, damping=0.85):
+        L = self.L
+        for r in self.ranks:
+            if r["plan"]:
+                _cabi.check(L.gdn_pr_contrib_dev(r["plan"], r["scores"], r["c"][0], None))
+        self._allgather(0)
+        cur, it, err = 0, 0, 0.0
+        for it in range(max_iter):
+            err = 0.0
+            for r in self.ranks:
+                if r["plan"]:
+                    _cabi.check(L.gdn_pr_pull_dev(r["plan"], r["c"][cur], r["scores"], r["c"][cur ^ 1], r["diff"],
+                                                  float(damping), None))
+                    d = np.zeros(1, np.float64)
+                    _cabi.check(L.gdn_dev_download(_p(d), r["diff"], 8))
+                    err += float(d[0])
+            self._allgather(cur ^ 1)
+            cur ^= 1
+            if err < epsilon:
+                break
+        scores = np.empty(self.m, np.float32)
+        for r in self.ranks:
+            if r["plan"]:
+                _cabi.check(L.gdn_pr_plan_check(r["plan"]))
+                part = np.empty(r["hi"] - r["lo"], np.float32)
+                _cabi.check(L.gdn_dev_download(_p(part), r["scores"], 4 * len(part)))
+                scores[r["lo"]:r["hi"]] = part
+        return scores, it + 1, err
+
+    def close(self):
+        for r in self.ranks:
+            if r["plan"]:
+                self.L.gdn_pr_plan_free(r["plan"])
+            if r["sh"]:
+                self.L.gdn_graph_free(r["sh"])
+            for d in (r["deg"], r["scores"], r["diff"], r["c"][0], r["c"][1]):
+                self.L.gdn_dev_free(d)
         self.L.gdn_graph_free(self.h)

@@ -115,6 +115,27 @@ def test_pr_vs_oracle_rmat(orc, scale, ef, seed, pr_layout):
     assert orc.pr_verify_error(g, scores) < 1e-4  # PRVerifier criterion, src/pr/verifier.cc:53
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_pr_sharded_data_path_on_one_device(orc, world, layout):
+    """Every C-ABI call of the multi-GPU path (row slices, plans with row_base and m_local < m_global,
+    contrib slices at their global place) on one device, all-gather emulated by copies: the result must
+    equal the single-plan solve."""
+    g = graphio.rmat_graph(15, 16, seed=31)
+    m = g.m - 5  # not divisible by the world size
+    src, dst = graphio.csr_to_coo(g)
+    keep = (src < m) & (dst < m)
+    g = graphio.build_csr(m, src[keep], dst[keep])
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    sh = solvers.ResidentPageRankShards(solvers.Graph(csr=g, in_csr=gi), world, layout)
+    scores, it2, err = sh.solve()
+    sh.close()
+    assert it2 == it
+    np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+    assert abs(err - trace[-1]) < 1e-6
+
+
 def test_pr_is_bitwise_reproducible(monkeypatch):
     monkeypatch.setenv("GDN_PR_LAYOUT", "csr")  # the merge-path layout is the reproducible one
     g = graphio.rmat_graph(15, 16, seed=9)
@@ -276,14 +297,38 @@ def test_cc_golden(orc, case):
 
 
 @pytest.mark.parametrize("scale,ef,seed", [(14, 4, 31), (16, 16, 32), (18, 2, 33)])
-def test_cc_vs_oracle_rmat(orc, scale, ef, seed):
-    g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
+@pytest.mark.parametrize("variant", ["afforest_sym", "afforest_directed", "sv_no_reverse"])
+def test_cc_vs_oracle_rmat(orc, scale, ef, seed, variant):
+    d = graphio.rmat_graph(scale, ef, seed=seed)
+    gs = graphio.symmetrize(d)
+    want, _ = orc.cc_sv(gs)  # weakly connected components, min-id labels
+    if variant == "afforest_sym":      # symmetric graph, reverse = alias  -> Afforest
+        G, g = solvers.Graph(csr=gs, symmetrize=True), gs
+    elif variant == "afforest_directed":  # directed graph + reverse graph -> Afforest over out- and in-edges
+        G, g = solvers.Graph(csr=d, need_reverse=True), d
+    else:                               # directed graph, no reverse     -> symmetric SV hook
+        G, g = solvers.Graph(csr=d), d
+    comp = np.arange(g.m, dtype=np.int32)
+    solvers.CCSolver(G, comp)
+    assert np.array_equal(comp, want)
+    # min-id property
+    assert np.all(comp <= np.arange(g.m)) and np.all(comp[comp] == comp)
+
+
+def test_cc_many_small_components(orc):
+    """No giant component: Afforest's sampled label covers almost nothing, every edge is walked."""
+    n, k = 60000, 6  # 10000 cycles of 6 vertices + a long path
+    base = np.arange(0, n, k)
+    src = np.concatenate([base + i for i in range(k)])
+    dst = np.concatenate([base + (i + 1) % k for i in range(k)])
+    path = np.arange(n, n + 3000)
+    src = np.concatenate([src, path[:-1]])
+    dst = np.concatenate([dst, path[1:]])
+    g = graphio.symmetrize(graphio.build_csr(n + 3000, src, dst))
     want, _ = orc.cc_sv(g)
     comp = np.arange(g.m, dtype=np.int32)
     solvers.CCSolver(solvers.Graph(csr=g, symmetrize=True), comp)
     assert np.array_equal(comp, want)
-    # min-id property
-    assert np.all(comp <= np.arange(g.m)) and np.all(comp[comp] == comp)
 
 
 # ------------------------------------------------------------------ TC
