@@ -84,6 +84,9 @@ PROTOTYPES = {
     "gdn_bfs_plan_free": (C.c_int, [_vp]),
     "gdn_bfs_run": (C.c_int, [_vp, _i32, _vp, _st]),
     "gdn_sssp_dev": (C.c_int, [_vp, _vp, _i32, _i32, _vp, _st]),
+    "gdn_sssp_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),
+    "gdn_sssp_plan_free": (C.c_int, [_vp]),
+    "gdn_sssp_run": (C.c_int, [_vp, _i32, _i32, _vp, _st]),
     "gdn_cc_dev": (C.c_int, [_vp, _vp, _vp, _st]),
     "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),
 }

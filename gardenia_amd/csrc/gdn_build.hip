@@ -234,12 +234,18 @@ struct PbKeyVis {
   const eoff_t *__restrict__ cd;  // compact row index of every local row (nullptr = identity)
   int log_chunk, log_bin;
   int bin_bits;
+  int transposed;  // the CSR's rows are the SOURCES (out-CSR): swap the roles
   int32_t v;
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     unsigned row = (unsigned)__shfl(v, owner, 64);
     if (valid) {
       unsigned col = (unsigned)colidx[k];
+      if (transposed) {
+        const unsigned t = row;
+        row = col;
+        col = t;
+      }
       if (cs) col = (unsigned)cs[col];
       if (cd) row = (unsigned)cd[row];
       const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
@@ -377,7 +383,7 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
                   uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
-                  const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv) {
+                  const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv, int transposed) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -392,8 +398,13 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     U[pu[t] + off] = (uint16_t)ul;
     V[pv[b * nchunks + c] + off] = randv ? (uint16_t)((i * 2654435761ull >> 7) & ((1u << log_bin) - 1u)) : (uint16_t)vl;
     if (ev_in) {  // value of this edge: find the column in its (ascending) CSR row
-      const unsigned long long row = (b << log_bin) + vl;
-      const vid_t col = (vid_t)((c << log_chunk) + ul);
+      unsigned long long row = (b << log_bin) + vl;  // destination
+      vid_t col = (vid_t)((c << log_chunk) + ul);    // source
+      if (transposed) {                               // out-CSR: row = source, column = destination
+        const unsigned long long t = row;
+        row = (unsigned long long)col;
+        col = (vid_t)t;
+      }
       eoff_t lo = rowptr[row], hi = rowptr[row + 1];
       while (lo < hi) {
         const eoff_t mid = lo + ((hi - lo) >> 1);
@@ -418,19 +429,22 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, u
 }
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
-             const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact) {
+             const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
   GDN_REQUIRE(!(compact && edge_vals_in), "edge values are not supported on a compacted layout");
+  GDN_REQUIRE(!(compact && rows_are_sources), "compaction is not supported on an out-CSR");
   const int32_t m = g->m;
   const unsigned long long n = g->nnz;
-  p.m_local = m;
-  p.m_global = m_global;
+  // normal: rows = destinations (m), columns = sources (m_global).  out-CSR: rows = sources (m),
+  // columns = destinations (m_global)
+  p.m_local = rows_are_sources ? m_global : m;
+  p.m_global = rows_are_sources ? m : m_global;
   p.nnz = n;
   p.log_chunk = log_chunk;
   p.log_bin = log_bin;
   p.compact = compact;
-  uint64_t n_src = (uint64_t)m_global, n_dst = (uint64_t)m;
+  uint64_t n_src = (uint64_t)p.m_global, n_dst = (uint64_t)p.m_local;
   DevBuf<eoff_t> cs, cd;  // compact index of every source id / row (exclusive scans of the flags)
   if (compact) {
     DevBuf<uint32_t> sflag, dflag;
@@ -528,6 +542,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     vis.log_chunk = log_chunk;
     vis.log_bin = log_bin;
     vis.bin_bits = bin_bits;
+    vis.transposed = rows_are_sources ? 1 : 0;
     vis.v = 0;
     hipLaunchKernelGGL(pb_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
     hipLaunchKernelGGL(pb_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
@@ -585,7 +600,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
                          ev_out ? edge_vals_in : nullptr, ev_out,
-                         getenv("GDN_PB_TEST_RANDV") ? 1 : 0);  // TIMING-ONLY experiment: uniform row ids
+                         getenv("GDN_PB_TEST_RANDV") ? 1 : 0,  // TIMING-ONLY experiment: uniform row ids
+                         rows_are_sources ? 1 : 0);
     // GDN_PB_IDENTITY=1 is a TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
                        p.G.p, getenv("GDN_PB_IDENTITY") ? 1 : 0);

@@ -80,7 +80,8 @@ struct PbPlan {
 // alloc_vals = false: only the static layout (U, V, G, pointers, orders) -- BFS keeps 1 bit per edge
 // edge_vals_in (nullable, CSR order) -> *edge_vals_out in chunk-major order, pads = 0 (SpMV's Ax)
 int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true,
-             const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr, bool compact = false);
+             const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr, bool compact = false,
+             bool rows_are_sources = false);  // true: `in_csr` is an OUT-CSR (row = source, col = destination)
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));

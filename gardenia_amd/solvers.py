@@ -288,3 +288,34 @@ class ResidentPageRankShards:
             for d in (r["deg"], r["scores"], r["diff"], r["c"][0], r["c"][1]):
                 self.L.gdn_dev_free(d)
         self.L.gdn_graph_free(self.h)
+
+
+class ResidentSSSP:
+    """Many SSSP runs on one resident weighted graph (gdn_sssp_plan_*); dense=True adds the
+    propagation-blocked Bellman-Ford sweeps for heavy frontiers."""
+
+    def __init__(self, g: Graph, weight: np.ndarray, dense: bool = True):
+        L = _cabi.lib()
+        self.L, self.m = L, g.V()
+        self.h, self.plan, self.d_w, self.d_dist = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+        w = _arr(weight, np.int32)
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(rp), _p(ci), C.byref(self.h)))
+        _cabi.check(L.gdn_dev_alloc(4 * max(g.E(), 1), C.byref(self.d_w)))
+        if g.E():
+            _cabi.check(L.gdn_dev_upload(self.d_w, _p(w), 4 * g.E()))
+        _cabi.check(L.gdn_dev_alloc(4 * g.V(), C.byref(self.d_dist)))
+        _cabi.check(L.gdn_sssp_plan_create(self.h, self.d_w, 1 if dense else 0, C.byref(self.plan)))
+
+    def run(self, source: int, delta: int = 1):
+        st = _cabi.GdnStats()
+        _cabi.check(self.L.gdn_sssp_run(self.plan, source, delta, self.d_dist, C.byref(st)))
+        dist = np.empty(self.m, np.int32)
+        _cabi.check(self.L.gdn_dev_download(_p(dist), self.d_dist, 4 * self.m))
+        return dist, st.as_dict()
+
+    def close(self):
+        self.L.gdn_sssp_plan_free(self.plan)
+        self.L.gdn_dev_free(self.d_w)
+        self.L.gdn_dev_free(self.d_dist)
+        self.L.gdn_graph_free(self.h)

@@ -211,6 +211,14 @@ int gdn_bfs_plan_free(gdn_bfs_plan *plan);
 int gdn_bfs_run(gdn_bfs_plan *plan, int32_t source, int32_t *d_dist, gdn_stats *stats);
 int gdn_sssp_dev(const gdn_graph *csr, const int32_t *d_weight, int32_t source, int32_t delta,
                  int32_t *d_dist, gdn_stats *stats);
+/* Reusable SSSP state (graph + weights resident).  dense != 0 also builds the propagation-blocked
+ * layout of the out-CSR with the weights in tile order: while the frontier is heavy the solver runs
+ * Bellman-Ford sweeps over all edges (LDS min-reduction per destination bin) instead of worklist
+ * passes, then finishes with a worklist.  Distances are the exact shortest distances either way. */
+typedef struct gdn_sssp_plan gdn_sssp_plan;
+int gdn_sssp_plan_create(const gdn_graph *csr, const int32_t *d_weight, int32_t dense, gdn_sssp_plan **plan);
+int gdn_sssp_plan_free(gdn_sssp_plan *plan);
+int gdn_sssp_run(gdn_sssp_plan *plan, int32_t source, int32_t delta, int32_t *d_dist, gdn_stats *stats);
 int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,
                gdn_stats *stats);
 int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stats *stats);

@@ -283,6 +283,21 @@ def test_sssp_vs_oracle_rmat(orc, scale, ef, seed, delta):
     assert np.array_equal(dist, want)
 
 
+@pytest.mark.parametrize("scale,ef,seed,wmax", [(12, 16, 24, 1), (16, 16, 25, 255), (18, 16, 26, 1), (17, 32, 27, 1000)])
+def test_sssp_resident_dense_sweeps(orc, scale, ef, seed, wmax):
+    """gdn_sssp_plan_*: heavy frontiers are relaxed by Bellman-Ford sweeps on the PB layout."""
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    rng = np.random.default_rng(seed)
+    wt = rng.integers(1, wmax + 1, size=g.nnz).astype(np.int32)
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    deg = g.degrees()
+    for s, delta in ((graphio.first_nonisolated(g), 1), (int(np.argmax(deg)), max(1, wmax // 4))):
+        want = orc.sssp_dijkstra(g, wt, s)
+        dist, st = sp.run(s, delta)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+    sp.close()
+
+
 # ------------------------------------------------------------------ CC
 @pytest.mark.parametrize("case", ["test_cc_sym", "chesapeake_sym", "rmat10_sym", "rmat10_dir"])
 def test_cc_golden(orc, case):

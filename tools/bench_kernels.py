@@ -139,12 +139,20 @@ def main():
     L.gdn_bfs_plan_free(bplan)
     for wname, w in (("unit", torch.ones(nnz, dtype=torch.int32, device=dev)),
                      ("u1_255", torch.randint(1, 256, (nnz,), dtype=torch.int32, device=dev))):
+        splan = C.c_void_p()
+        _cabi.check(L.gdn_sssp_plan_create(go, ptr(w), 1, C.byref(splan)))
         for delta in ((1,) if wname == "unit" else (16, 64)):
             st = _cabi.GdnStats()
             _cabi.check(L.gdn_sssp_dev(go, ptr(w), int(srcs[0]), delta, ptr(dist), C.byref(st)))
-            res[f"sssp_rmat{args.trav_scale}_{wname}_delta{delta}"] = {
+            res[f"sssp_rmat{args.trav_scale}_{wname}_delta{delta}_worklist"] = {
                 "ms": st.solve_ms, "phases": st.iterations, "edges_traversed": st.edges_traversed,
                 "gteps": st.edges_traversed / st.solve_ms / 1e6}
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_sssp_run(splan, int(srcs[0]), delta, ptr(dist), C.byref(st)))
+            res[f"sssp_rmat{args.trav_scale}_{wname}_delta{delta}_plan_dense"] = {
+                "ms": st.solve_ms, "phases": st.iterations, "edges_traversed": st.edges_traversed,
+                "gteps": st.edges_traversed / st.solve_ms / 1e6}
+        L.gdn_sssp_plan_free(splan)
     del w
     # CC = weakly connected components of the directed graph: SV (out-CSR only, symmetric hook) and
     # Afforest (out- and in-CSR)
