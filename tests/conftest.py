@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+try:  # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's): load it FIRST so that
+    import torch  # noqa: F401  libgardenia_hip.so binds to the same HIP runtime instance in this process
+except Exception:  # pragma: no cover
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -1,0 +1,150 @@
+"""Full-size checks (BASELINE.json sizes: R-MAT scale 27, 2.1 G edges) through size-independent
+properties -- the oracle cannot run at this size inside a test:
+
+  PageRank  both layouts (CSR merge-path, propagation-blocked) agree to 1e-4 after the same number of
+            iterations; rank mass obeys  sum(new) = (1-d) + d * sum(old over vertices with out-edges);
+            the L1 change reported by the kernel equals sum|new-old| recomputed with torch
+  BFS       the resident dense-sweep plan and the plan-less Beamer search give identical depths; every
+            edge (u,v) with u reached has depth[v] <= depth[u]+1; every reached v != source has
+            depth >= 1; TEPS numerator = sum of out-degrees of the reached vertices
+  SSSP      unit weights: distances == BFS depths (R-MAT scale 25)
+  graph     the device generator's CSR has ascending, duplicate-free, self-loop-free rows
+
+Needs ~120 GB of HBM; everything stays on the device (torch is only used for the checks)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SCALE = 27
+
+
+@pytest.fixture(scope="module")
+def big():
+    torch = pytest.importorskip("torch")
+    from gardenia_amd import _cabi, graphio
+    L = _cabi.lib()
+    dev = torch.device("cuda", 0)
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(SCALE, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+    m, nnz = C.c_int32(), C.c_uint64()
+    rp, ci = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), C.byref(rp), C.byref(ci)))
+    deg = torch.empty(m.value, dtype=torch.int32, device=dev)
+    _cabi.check(L.gdn_graph_degrees_dev(go, C.c_void_p(deg.data_ptr()), None))
+    yield dict(torch=torch, L=L, cabi=_cabi, dev=dev, go=go, gi=gi, m=m.value, nnz=nnz.value, deg=deg,
+               out_rowptr=rp.value, out_colidx=ci.value)
+    L.gdn_graph_free(go)
+    L.gdn_graph_free(gi)
+
+
+def _view(torch, ptr, n, dtype, dev):
+    """torch tensor over device memory owned by libgardenia_hip (no copy)."""
+    itemsize = torch.empty(0, dtype=dtype).element_size()
+    class _Holder:  # __cuda_array_interface__ carrier
+        pass
+    h = _Holder()
+    typestr = {torch.int64: "<i8", torch.int32: "<i4", torch.float32: "<f4"}[dtype]
+    h.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+    return torch.as_tensor(h, device=dev)
+
+
+def test_generated_graph_is_clean(big):
+    torch, m, nnz = big["torch"], big["m"], big["nnz"]
+    assert m == 1 << SCALE and 2_000_000_000 < nnz < 2_147_483_648
+    rp = _view(torch, big["out_rowptr"], m + 1, torch.int64, big["dev"])
+    ci = _view(torch, big["out_colidx"], nnz, torch.int32, big["dev"])
+    assert int(rp[0]) == 0 and int(rp[-1]) == nnz and bool((rp[1:] >= rp[:-1]).all())
+    # sample 4M edges: strictly ascending inside a row (=> no duplicates), no self loops
+    idx = torch.randint(1, nnz, (1 << 22,), device=big["dev"])
+    row = torch.searchsorted(rp, idx, right=True) - 1
+    same_row = rp[row] <= idx - 1
+    assert bool((ci[idx][same_row] > ci[idx - 1][same_row]).all())
+    assert bool((ci[idx].to(torch.int64) != row).all())
+
+
+def test_pagerank_layouts_agree_and_conserve_mass(big):
+    torch, L, cabi, dev, m = big["torch"], big["L"], big["cabi"], big["dev"], big["m"]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    results = {}
+    for layout in (0, 1):
+        plan = C.c_void_p()
+        cabi.check(L.gdn_pr_plan_create(big["gi"], p(big["deg"]), m, 0, layout, C.byref(plan)))
+        scores = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+        c = [torch.zeros(m, dtype=torch.float32, device=dev) for _ in range(2)]
+        diff = torch.zeros(1, dtype=torch.float64, device=dev)
+        cabi.check(L.gdn_pr_contrib_dev(plan, p(scores), p(c[0]), None))
+        for it in range(3):
+            old = scores.clone()
+            cabi.check(L.gdn_pr_pull_dev(plan, p(c[it & 1]), p(scores), p(c[(it + 1) & 1]), p(diff), 0.85, None))
+            torch.cuda.synchronize()
+            has_out = big["deg"] > 0
+            want_mass = 0.15 + 0.85 * float(old[has_out].double().sum())
+            got_mass = float(scores.double().sum())
+            assert abs(got_mass - want_mass) < 2e-6, (layout, it, got_mass, want_mass)
+            l1 = float((scores - old).abs().double().sum())
+            assert abs(l1 - float(diff.item())) < 1e-6 * max(l1, 1e-9) + 1e-12
+        cabi.check(L.gdn_pr_plan_check(plan))
+        L.gdn_pr_plan_free(plan)
+        results[layout] = scores
+    a, b = results[0], results[1]
+    rel = ((a - b).abs() / b).max()
+    assert float(rel) < 1e-4
+
+
+def test_bfs_plans_agree_and_depths_are_consistent(big):
+    torch, L, cabi, dev, m, nnz = big["torch"], big["L"], big["cabi"], big["dev"], big["m"], big["nnz"]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    src = int(torch.nonzero(big["deg"][:1 << 16] > 0)[0])
+    d1 = torch.empty(m, dtype=torch.int32, device=dev)
+    d2 = torch.empty(m, dtype=torch.int32, device=dev)
+    st1, st2 = cabi.GdnStats(), cabi.GdnStats()
+    cabi.check(L.gdn_bfs_dev(big["go"], big["gi"], src, p(d1), C.byref(st1)))  # Beamer top-down/bottom-up
+    plan = C.c_void_p()
+    cabi.check(L.gdn_bfs_plan_create(big["go"], big["gi"], 1, C.byref(plan)))
+    cabi.check(L.gdn_bfs_run(plan, src, p(d2), C.byref(st2)))                   # top-down + dense sweeps
+    L.gdn_bfs_plan_free(plan)
+    assert bool((d1 == d2).all())
+    INF = 1000000000
+    reached = d2 != INF
+    assert int(d2[src]) == 0 and int((d2[reached] == 0).sum()) == 1
+    assert st2.edges_traversed == int(big["deg"][reached].to(torch.int64).sum()) == st1.edges_traversed
+    # edge property on 64M sampled edges: depth[v] <= depth[u] + 1 whenever u is reached
+    rp = _view(torch, big["out_rowptr"], m + 1, torch.int64, dev)
+    ci = _view(torch, big["out_colidx"], nnz, torch.int32, dev)
+    idx = torch.randint(0, nnz, (1 << 26,), device=dev)
+    u = torch.searchsorted(rp, idx, right=True) - 1
+    du, dv = d2[u].to(torch.int64), d2[ci[idx].to(torch.int64)].to(torch.int64)
+    ok = (du == INF) | (dv <= du + 1)
+    assert bool(ok.all())
+
+
+def test_sssp_unit_weights_equal_bfs_depths():
+    torch = pytest.importorskip("torch")
+    from gardenia_amd import _cabi, graphio
+    L = _cabi.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(25, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+    m, nnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), None, None))
+    m, nnz = m.value, nnz.value
+    deg = torch.empty(m, dtype=torch.int32, device=dev)
+    _cabi.check(L.gdn_graph_degrees_dev(go, p(deg), None))
+    src = int(torch.nonzero(deg[:1 << 16] > 0)[0])
+    w = torch.ones(nnz, dtype=torch.int32, device=dev)
+    dist = torch.empty(m, dtype=torch.int32, device=dev)
+    depth = torch.empty(m, dtype=torch.int32, device=dev)
+    plan = C.c_void_p()
+    _cabi.check(L.gdn_sssp_plan_create(go, p(w), 1, C.byref(plan)))
+    st = _cabi.GdnStats()
+    _cabi.check(L.gdn_sssp_run(plan, src, 1, p(dist), C.byref(st)))
+    L.gdn_sssp_plan_free(plan)
+    _cabi.check(L.gdn_bfs_dev(go, gi, src, p(depth), C.byref(st)))
+    depth = torch.where(depth == 1000000000, torch.full_like(depth, 2147483647), depth)
+    assert bool((dist == depth).all())
+    L.gdn_graph_free(go)
+    L.gdn_graph_free(gi)
