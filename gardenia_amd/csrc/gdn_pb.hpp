@@ -199,7 +199,7 @@ static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
                  const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
                  const uint32_t *__restrict__ G, float *__restrict__ vals, const uint32_t *__restrict__ src_bits,
-                 const uint32_t *__restrict__ chunk_lo, unsigned split) {
+                 const uint32_t *__restrict__ chunk_lo, unsigned split, int nt_store = 0) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
@@ -253,7 +253,8 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
         o.y = s_x[u[r].y];
         o.z = s_x[u[r].z];
         o.w = s_x[u[r].w];
-        X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
+        if (nt_store) __builtin_nontemporal_store(o, X4 + 2 * (size_t)d[r] + (size_t)(hh & 1));
+        else X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
       }
     }
   }

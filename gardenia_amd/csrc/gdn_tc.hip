@@ -72,11 +72,11 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 // walked through gdn_expand_wave, so the 64 lanes always hold 64 distinct (v, w) pairs no matter how
 // short the lists are; every w is looked up in N+(u) by binary search in LDS (global memory when
 // N+(u) does not fit).  With the degree orientation every list is O(sqrt(nnz)) long.
-#define TC_CAP 2048            // ids of N+(u) kept in LDS per wave
+#define TC_CAP 1024            // ids of N+(u) kept in LDS per wave (8 KB hash set -> 5 workgroups per CU)
 #define TC_HASH (2 * TC_CAP)   // open-addressing slots per wave (load factor <= 0.5)
 #define TC_EMPTY (-1)
 
-__device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - 12); }
+__device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - 11); }
 
 struct TcCountVis {
   const vid_t *__restrict__ colidx;
@@ -275,7 +275,7 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
   if (rc == GDN_OK) {
     tsolve.start();  // src/tc/gpu_base.cu:52-58
     unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK * 16);
-    if (nb > 256 * 4) nb = 256 * 4;  // persistent: 4 workgroups per CU pulling vertex batches
+    if (nb > 256 * 5) nb = 256 * 5;  // persistent: 5 workgroups per CU pulling vertex batches
     hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m,
                        (unsigned *)(d_total.p + 1), d_total.p);
     unsigned long long h = 0;
