@@ -14,6 +14,7 @@
 // only cause a redundant atomic, never a wrong depth; next-frontier compaction is one
 // atomicAdd per wavefront (gdn_wl_push).  Depths are exact: every vertex is claimed once, in
 // the level in which it is first reached.
+#include <stdlib.h>
 #include <string.h>
 
 #include "gdn_expand.hpp"
@@ -397,7 +398,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, 0, source, d_dist, p.visited.p, p.q0.p);
 
   const int alpha = 15, beta = 18;   // omp_beamer.cc:111
-  const int alpha_dense = 32;        // a dense sweep costs about nnz/32 top-down edge visits
+  int alpha_dense = 32;              // a dense sweep costs about nnz/32 top-down edge visits
+  if (const char *e = getenv("GDN_BFS_ALPHA_DENSE")) alpha_dense = atoi(e) > 0 ? atoi(e) : 32;  // tuning knob
   vid_t *qin = p.q0.p, *qout = p.q1.p;
   unsigned nf = 1;
   int64_t edges_to_check = (int64_t)g->nnz;
@@ -411,6 +413,16 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   ExpBigList big;
   big.items = p.bigitems.p;
   big.capacity = p.bigcap;
+  const bool trace = getenv("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
+  HostTimer tl;
+  auto lap = [&](const char *what, long long a, long long b) {
+    if (trace) fprintf(stderr, "[bfs] level %d %-10s nf/awake=%lld scout=%lld  %.3f ms\n", level, what, a, b, tl.stop_ms());
+    if (trace) tl.start();
+  };
+  if (trace) {
+    (void)hipDeviceSynchronize();
+    tl.start();
+  }
   while (nf > 0) {
     if (p.dense && scout_count > (int64_t)(g->nnz / alpha_dense)) {
       // ---- dense phase: propagation-blocked sweeps while the frontier stays heavy
@@ -433,6 +445,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         fr = nx;
         nx = t;
         level++;
+        lap("dense", awake, scout_count);
       } while (awake > 0 && scout_count > (int64_t)(g->nnz / alpha_dense));
       if (awake == 0) {
         nf = 0;
@@ -443,6 +456,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                          p.cnt.p, p.qcap);
       GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
+      lap("bitmap2q", nf, 0);
       edges_to_check = 0;  // from here on only the top-down tail is left
     } else if (!p.dense && gin != nullptr && scout_count > edges_to_check / alpha) {
       // ---- bottom-up phase (omp_beamer.cc:130-141)
@@ -495,6 +509,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       qin = qout;
       qout = t;
       level++;
+      lap("top-down", nf, scout_count);
     }
     if (h.overflow) {
       gdn_set_error("gdn_bfs: device worklist overflow");

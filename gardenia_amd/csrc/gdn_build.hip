@@ -378,6 +378,23 @@ pb_ptrs_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uns
   if (i <= nbins) bin_ptr[i] = pv[(unsigned long long)i * nchunks];
 }
 
+// slice starts are moved to aligned positions: every tile of chunk c (bin b) shifts by du[c] (dv[b])
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_shift_kernel(eoff_t *__restrict__ pu, eoff_t *__restrict__ pv, const eoff_t *__restrict__ du,
+                const eoff_t *__restrict__ dv, unsigned nchunks, unsigned nbins) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (t >= (unsigned long long)nchunks * nbins) return;
+  pu[t] += du[t / nbins];
+  pv[t] += dv[t / nchunks];
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_fill_u32_kernel(uint32_t *p, unsigned long long n, uint32_t v) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) p[i] = v;
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int log_chunk, int log_bin,
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
@@ -418,12 +435,12 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
 
 // group table: the q-th group of 8 of tile t in chunk-major order -> its group index in bin-major
 __global__ void __launch_bounds__(GDN_BLOCK)
-pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, unsigned nchunks, unsigned nbins,
-                 uint32_t *__restrict__ G, int identity) {
+pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, const uint32_t *__restrict__ psz_c,
+                 unsigned nchunks, unsigned nbins, uint32_t *__restrict__ G, int identity) {
   const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (t >= (unsigned long long)nchunks * nbins) return;
   const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
-  const eoff_t gu = pu[t] >> 3, ng = (pu[t + 1] - pu[t]) >> 3;
+  const eoff_t gu = pu[t] >> 3, ng = psz_c[t] >> 3;
   const eoff_t gv = pv[(unsigned long long)b * nchunks + c] >> 3;
   for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
@@ -508,6 +525,17 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   const unsigned long long ntiles = (unsigned long long)p.nchunks * p.nbins;
   const unsigned long long gb = (n + GDN_BLOCK - 1) / GDN_BLOCK;
   const unsigned grid_n = (unsigned)(gb > 262144ull ? 262144ull : (gb ? gb : 1));
+  // The long-lived streamed arrays are allocated FIRST, at an upper bound of the padded size, before
+  // the multi-GB sort temporaries come and go: allocated afterwards they land in whatever fragments
+  // the temporaries left behind (experiment GDN_PB_EARLY_ALLOC)
+  const uint64_t n_pad_bound = ((n + 15) & ~15ull) + 16ull * (ntiles < n ? ntiles : n) + 64;
+  const bool early = false;  // measured: no effect (7.18 vs 7.23 ms), kept off
+  if (early) {
+    GDN_TRY(p.U.alloc(n_pad_bound));
+    GDN_TRY(p.V.alloc(n_pad_bound));
+    GDN_TRY(p.G.alloc((n_pad_bound >> 3) + 1));
+    if (alloc_vals) GDN_TRY(p.vals.alloc(n_pad_bound));
+  }
   DevBuf<eoff_t> tsu, pu, pv;
   DevBuf<uint32_t> psz_c, psz_b;
   GDN_TRY(tsu.alloc(ntiles + 1));
@@ -574,18 +602,55 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_HIP(hipGetLastError());
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_c.p, pu.p, (size_t)ntiles, 0));
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_b.p, pv.p, (size_t)ntiles, 0));
+    hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(p.nchunks > p.nbins ? p.nchunks : p.nbins) + 1)),
+                       dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins, p.chunk_ptr.p, p.bin_ptr.p);
+    GDN_HIP(hipGetLastError());
+    // Every chunk's range in U/G and every bin's range in V/vals starts on an aligned boundary: streams that
+    // begin at arbitrary offsets run 10-20 % slower on this memory system (measured: phase A 3.70 -> 2.98 ms,
+    // phase B stream 2.26 -> 2.05 ms on RMAT-27 with 16384-edge alignment, profiles/pb_ablation_r01.txt).
+    // The gap behind a slice belongs to the slice: U = pad id, G = the dump group, V = 0, scratch = neutral.
     eoff_t n_pad = 0;
-    GDN_HIP(hipMemcpy(&n_pad, pu.p + ntiles, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    {
+      std::vector<eoff_t> cs((size_t)p.nchunks + 1), bs((size_t)p.nbins + 1), du(p.nchunks), dv(p.nbins);
+      GDN_HIP(hipMemcpy(cs.data(), p.chunk_ptr.p, cs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+      GDN_HIP(hipMemcpy(bs.data(), p.bin_ptr.p, bs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+      auto pick_align = [](eoff_t total, unsigned parts) {
+        eoff_t a = 16;
+        while (a < 16384 && a * 32 <= total / (parts ? parts : 1)) a <<= 1;  // keep the gaps below ~3 % of a slice
+        return a;
+      };
+      const eoff_t al_c = pick_align(cs[p.nchunks], p.nchunks), al_b = pick_align(bs[p.nbins], p.nbins);
+      std::vector<eoff_t> ca((size_t)p.nchunks + 1, 0), ba((size_t)p.nbins + 1, 0);
+      for (unsigned c = 0; c < p.nchunks; c++) {
+        du[c] = ca[c] - cs[c];
+        ca[c + 1] = (ca[c] + (cs[c + 1] - cs[c]) + al_c - 1) & ~(al_c - 1);
+      }
+      for (unsigned b = 0; b < p.nbins; b++) {
+        dv[b] = ba[b] - bs[b];
+        ba[b + 1] = (ba[b] + (bs[b + 1] - bs[b]) + al_b - 1) & ~(al_b - 1);
+      }
+      n_pad = ca[p.nchunks] > ba[p.nbins] ? ca[p.nchunks] : ba[p.nbins];
+      DevBuf<eoff_t> d_du, d_dv;
+      GDN_TRY(d_du.alloc(p.nchunks));
+      GDN_TRY(d_dv.alloc(p.nbins));
+      GDN_HIP(hipMemcpy(d_du.p, du.data(), du.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+      GDN_HIP(hipMemcpy(d_dv.p, dv.data(), dv.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(pb_shift_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, d_du.p, d_dv.p,
+                         p.nchunks, p.nbins);
+      GDN_HIP(hipMemcpy(p.chunk_ptr.p, ca.data(), ca.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+      GDN_HIP(hipMemcpy(p.bin_ptr.p, ba.data(), ba.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+      GDN_HIP(hipDeviceSynchronize());
+    }
     p.n_pad = n_pad;
-    if ((n_pad >> 3) > 0xFFFFFFFFull) {
+    if ((n_pad >> 3) + 1 > 0xFFFFFFFFull) {
       gdn_set_error("pb_build: more than 2^35 padded edges");
       return GDN_ERR_INVALID;
     }
-    hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(p.nchunks > p.nbins ? p.nchunks : p.nbins) + 1)),
-                       dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins, p.chunk_ptr.p, p.bin_ptr.p);
-    GDN_TRY(p.U.alloc(n_pad + 8));
-    GDN_TRY(p.V.alloc(n_pad + 8));
-    GDN_TRY(p.G.alloc((n_pad >> 3) + 1));
+    if (!early) {
+      GDN_TRY(p.U.alloc(n_pad + 8));
+      GDN_TRY(p.V.alloc(n_pad + 8));
+      GDN_TRY(p.G.alloc((n_pad >> 3) + 1));
+    }
     const unsigned long long fb = (n_pad + 8 + GDN_BLOCK - 1) / GDN_BLOCK;
     hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p,
                        n_pad + 8, (uint16_t)(1u << log_chunk));
@@ -600,11 +665,24 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
                          ev_out ? edge_vals_in : nullptr, ev_out,
+#ifdef GDN_EXPERIMENTS
                          getenv("GDN_PB_TEST_RANDV") ? 1 : 0,  // TIMING-ONLY experiment: uniform row ids
+#else
+                         0,
+#endif
                          rows_are_sources ? 1 : 0);
-    // GDN_PB_IDENTITY=1 is a TIMING-ONLY experiment (sequential phase-A stores, wrong results)
-    hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, p.nchunks, p.nbins,
-                       p.G.p, getenv("GDN_PB_IDENTITY") ? 1 : 0);
+    int identity_g = 0;
+#ifdef GDN_EXPERIMENTS  // GDN_PB_IDENTITY=1: TIMING-ONLY experiment (sequential phase-A stores, wrong results)
+    identity_g = getenv("GDN_PB_IDENTITY") ? 1 : 0;
+#endif
+    {  // groups in the alignment gaps store their (neutral) values into the dump group behind the arrays
+      const unsigned long long ng = (n_pad >> 3) + 1;
+      const unsigned long long fbg = (ng + GDN_BLOCK - 1) / GDN_BLOCK;
+      hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fbg > 262144ull ? 262144ull : fbg)), dim3(GDN_BLOCK), 0, 0,
+                         p.G.p, ng, (uint32_t)(n_pad >> 3));
+    }
+    hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, psz_c.p, p.nchunks,
+                       p.nbins, p.G.p, identity_g);
     GDN_HIP(hipGetLastError());
     GDN_HIP(hipDeviceSynchronize());
   }  // key buffers freed here
@@ -612,6 +690,16 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     std::vector<eoff_t> cp((size_t)p.nchunks + 1), bp((size_t)p.nbins + 1);
     GDN_HIP(hipMemcpy(cp.data(), p.chunk_ptr.p, cp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
     GDN_HIP(hipMemcpy(bp.data(), p.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+#ifdef GDN_EXPERIMENTS  // GDN_PB_UNIFORM=1: TIMING-ONLY, equal-sized chunk / bin ranges (wrong results)
+    if (getenv("GDN_PB_UNIFORM")) {
+      const eoff_t al = atoi(getenv("GDN_PB_UNIFORM")) > 1 ? (eoff_t)atoi(getenv("GDN_PB_UNIFORM")) - 1 : 15;
+      for (unsigned i = 0; i <= p.nchunks; i++) cp[i] = ((p.n_pad / p.nchunks) * i) & ~al;
+      for (unsigned i = 0; i <= p.nbins; i++) bp[i] = ((p.n_pad / p.nbins) * i) & ~al;
+      cp[p.nchunks] = bp[p.nbins] = p.n_pad;
+      GDN_HIP(hipMemcpy(p.chunk_ptr.p, cp.data(), cp.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+      GDN_HIP(hipMemcpy(p.bin_ptr.p, bp.data(), bp.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+    }
+#endif
     std::vector<uint32_t> co(p.nchunks), bo(p.nbins);
     for (unsigned i = 0; i < p.nchunks; i++) co[i] = i;
     for (unsigned i = 0; i < p.nbins; i++) bo[i] = i;
@@ -623,7 +711,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_HIP(hipMemcpy(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice));
   }
   if (alloc_vals) {
-    GDN_TRY(p.vals.alloc(p.n_pad + 8));
+    if (!early) GDN_TRY(p.vals.alloc(p.n_pad + 8));
     GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
   }
   GDN_TRY(p.partial.alloc(p.nbins));

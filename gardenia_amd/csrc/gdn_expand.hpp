@@ -22,8 +22,8 @@
 #pragma once
 #include "gdn_common.hpp"
 
-#define EXP_BIG 4096     // rows at least this long go to the big-row list
-#define EXP_CHUNK 2048   // edges per big-row work item
+#define EXP_BIG 512      // rows at least this long go to the big-row list (a small frontier of medium rows would otherwise sit on a handful of waves)
+#define EXP_CHUNK 256    // edges per big-row work item
 
 struct ExpBigList {
   unsigned long long *items;  // (chunk << 32) | vertex

@@ -350,6 +350,8 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
                      /*compact=*/false, /*rows_are_sources=*/true));
     GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
+    // slots in the alignment gaps of the layout are never written by phase A: keep them neutral
+    GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), GDN_DIST_INF, (size_t)p.pb.n_pad + 8, 0));
     p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lg) / 32u);
     GDN_TRY(p.improved.alloc(p.nwords + 64));
     const int lds = (int)((sizeof(unsigned) << lg) + 16);

@@ -117,6 +117,13 @@ int main() {
   CK(hipMalloc(&U, n * 2)); CK(hipMalloc(&V, n * 2)); CK(hipMalloc(&G, n / 8 * 4)); CK(hipMalloc(&vals, n * 4));
   CK(hipMalloc(&x, nblk * 32768 * 4)); CK(hipMalloc(&out, 64));
   CK(hipMemset(x, 0, nblk * 32768 * 4)); CK(hipMemset(vals, 0, n * 4));
+  const bool random_data = getenv("PB_PROBE_RANDOM") != nullptr;  // zero-filled vs random payloads
+  if (random_data) {
+    fill_u16<<<8192, 256>>>((uint16_t *)x, nblk * 32768 * 2, 0x3F7F);   // random small positive floats (bit patterns)
+    fill_u16<<<8192, 256>>>((uint16_t *)vals, n * 2, 0x3F7F);
+    CK(hipDeviceSynchronize());
+  }
+  printf("payload: %s\n", random_data ? "random" : "zeros");
   fill_u16<<<8192, 256>>>(U, n, 32767); fill_u16<<<8192, 256>>>(V, n, 16383); CK(hipDeviceSynchronize());
   const int ldsA = 32768 * 4 + 16, ldsB = 16384 * 8;
 #define RUNA(FL, name) { auto k = expandA<FL>; CK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, ldsA)); \

@@ -1,4 +1,2 @@
-mkdir -p gpurun_out
 run() { echo "== $*"; env "$@" timeout 300 python bench.py --no-cpu --no-bfs --layout pb --steps 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['roofline']['kernel_ms_parts'])"; }
-run GDN_PB_SPLIT=1
-run GDN_PB_NT_STORE=1
+run GDN_X=0

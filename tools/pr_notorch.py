@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""PageRank iteration timing through the C-ABI only (no torch in the process): checks that the numbers of
+bench.py do not depend on which HIP runtime copy the process loaded (torch bundles its own)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gardenia_amd import _cabi, graphio
+
+L = _cabi.lib()
+scale = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+go, gi = C.c_void_p(), C.c_void_p()
+_cabi.check(L.gdn_rmat_build(scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+m, nnz = C.c_int32(), C.c_uint64()
+_cabi.check(L.gdn_graph_info(gi, C.byref(m), C.byref(nnz), None, None))
+m, nnz = m.value, nnz.value
+
+
+def alloc(nbytes):
+    p = C.c_void_p()
+    _cabi.check(L.gdn_dev_alloc(nbytes, C.byref(p)))
+    return p
+
+
+deg, scores, c0, c1, diff = alloc(4 * m), alloc(4 * m), alloc(4 * m), alloc(4 * m), alloc(8)
+_cabi.check(L.gdn_graph_degrees_dev(go, deg, None))
+L.gdn_graph_free(go)
+import numpy as np
+init = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+_cabi.check(L.gdn_dev_upload(scores, init.ctypes.data_as(C.c_void_p), 4 * m))
+plan = C.c_void_p()
+_cabi.check(L.gdn_pr_plan_create(gi, deg, m, 0, 1, C.byref(plan)))
+_cabi.check(L.gdn_pr_contrib_dev(plan, scores, c0, None))
+bufs = [c0, c1]
+for it in range(3):
+    _cabi.check(L.gdn_pr_pull_dev(plan, bufs[it & 1], scores, bufs[(it + 1) & 1], diff, 0.85, None))
+steps = 10
+_cabi.check(L.gdn_pr_plan_kernel_time(plan, 1, steps, None, None))
+for it in range(3, 3 + steps):
+    _cabi.check(L.gdn_pr_pull_dev(plan, bufs[it & 1], scores, bufs[(it + 1) & 1], diff, 0.85, None))
+tot, n = (C.c_double * 2)(0, 0), C.c_int32(0)
+_cabi.check(L.gdn_pr_plan_kernel_time(plan, 0, 0, tot, C.byref(n)))
+print("no-torch process: scale", scale, "A %.3f ms  B %.3f ms  sum %.3f ms" % (tot[0] / n.value, tot[1] / n.value, (tot[0] + tot[1]) / n.value))
