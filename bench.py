@@ -42,6 +42,9 @@ def main():
     ap.add_argument("--edge-factor", type=int, default=16)
     ap.add_argument("--layout", choices=["auto", "csr", "pb"], default="auto",
                     help="edge layout of the PageRank plan (include/gardenia_hip.h GDN_LAYOUT_*)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the collectives go through gloo, so the N>1 code path "
+                         "can be exercised on a 1-GPU box (numbers are meaningless)")
     ap.add_argument("--no-bfs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -60,12 +63,17 @@ def main():
         log(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: gardenia_amd has no CPU fallback")
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     L = _cabi.lib()
     _cabi.check(L.gdn_set_device(local_rank))
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.share_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- synthetic input: R-MAT(scale, edge_factor), cleaned like the reference loader
     t0 = time.time()
