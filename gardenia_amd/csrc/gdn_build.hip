@@ -433,21 +433,26 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
   }
 }
 
-// group table: the q-th group of 8 of tile t in chunk-major order -> its group index in bin-major
+// group table: the q-th group of 2^log_group edges of tile t in chunk-major order -> its group index in bin-major
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, const uint32_t *__restrict__ psz_c,
-                 unsigned nchunks, unsigned nbins, uint32_t *__restrict__ G, int identity) {
+                 unsigned nchunks, unsigned nbins, uint32_t *__restrict__ G, int identity, int log_group) {
   const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (t >= (unsigned long long)nchunks * nbins) return;
   const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
-  const eoff_t gu = pu[t] >> 3, ng = psz_c[t] >> 3;
-  const eoff_t gv = pv[(unsigned long long)b * nchunks + c] >> 3;
+  const eoff_t gu = pu[t] >> log_group, ng = psz_c[t] >> log_group;
+  const eoff_t gv = pv[(unsigned long long)b * nchunks + c] >> log_group;
   for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
-             const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources) {
-  GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");  // u16 local ids + one pad value
+             const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
+             int log_group) {
+  GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
+  GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
+              "pad / log_group");
+  p.log_group = log_group;
+  const unsigned grp = 1u << log_group;  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
   GDN_REQUIRE(!(compact && edge_vals_in), "edge values are not supported on a compacted layout");
   GDN_REQUIRE(!(compact && rows_are_sources), "compaction is not supported on an out-CSR");
@@ -533,7 +538,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   if (early) {
     GDN_TRY(p.U.alloc(n_pad_bound));
     GDN_TRY(p.V.alloc(n_pad_bound));
-    GDN_TRY(p.G.alloc((n_pad_bound >> 3) + 1));
+    GDN_TRY(p.G.alloc((n_pad_bound >> log_group) + 1));
     if (alloc_vals) GDN_TRY(p.vals.alloc(n_pad_bound));
   }
   DevBuf<eoff_t> tsu, pu, pv;
@@ -595,8 +600,6 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     }
     // tile runs are padded to 16 edges = whole 64-byte lines of vals, so phase A never leaves a
     // partially written line to another workgroup (measured 7.9 vs 8.4 ms/iter at pad 8, RMAT-27)
-    unsigned pad = 16;
-    if (const char *e = getenv("GDN_PB_PAD")) pad = atoi(e) == 8 ? 8u : 16u;
     hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, p.nchunks, p.nbins,
                        pad, psz_c.p, psz_b.p);
     GDN_HIP(hipGetLastError());
@@ -642,23 +645,23 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       GDN_HIP(hipDeviceSynchronize());
     }
     p.n_pad = n_pad;
-    if ((n_pad >> 3) + 1 > 0xFFFFFFFFull) {
+    if ((n_pad >> log_group) + 1 > 0xFFFFFFFFull) {
       gdn_set_error("pb_build: more than 2^35 padded edges");
       return GDN_ERR_INVALID;
     }
     if (!early) {
-      GDN_TRY(p.U.alloc(n_pad + 8));
-      GDN_TRY(p.V.alloc(n_pad + 8));
-      GDN_TRY(p.G.alloc((n_pad >> 3) + 1));
+      GDN_TRY(p.U.alloc(n_pad + grp));
+      GDN_TRY(p.V.alloc(n_pad + grp));
+      GDN_TRY(p.G.alloc((n_pad >> log_group) + 1));
     }
-    const unsigned long long fb = (n_pad + 8 + GDN_BLOCK - 1) / GDN_BLOCK;
+    const unsigned long long fb = (n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
     hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p,
-                       n_pad + 8, (uint16_t)(1u << log_chunk));
-    GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + 8) * sizeof(uint16_t), 0));
+                       n_pad + grp, (uint16_t)(1u << log_chunk));
+    GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + grp) * sizeof(uint16_t), 0));
     float *ev_out = nullptr;
     if (edge_vals_in && edge_vals_out) {
-      GDN_TRY(edge_vals_out->alloc(n_pad + 8));
-      GDN_HIP(hipMemsetAsync(edge_vals_out->p, 0, (n_pad + 8) * sizeof(float), 0));
+      GDN_TRY(edge_vals_out->alloc(n_pad + grp));
+      GDN_HIP(hipMemsetAsync(edge_vals_out->p, 0, (n_pad + grp) * sizeof(float), 0));
       ev_out = edge_vals_out->p;
     }
     if (n)
@@ -676,13 +679,13 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     identity_g = getenv("GDN_PB_IDENTITY") ? 1 : 0;
 #endif
     {  // groups in the alignment gaps store their (neutral) values into the dump group behind the arrays
-      const unsigned long long ng = (n_pad >> 3) + 1;
+      const unsigned long long ng = (n_pad >> log_group) + 1;
       const unsigned long long fbg = (ng + GDN_BLOCK - 1) / GDN_BLOCK;
       hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fbg > 262144ull ? 262144ull : fbg)), dim3(GDN_BLOCK), 0, 0,
-                         p.G.p, ng, (uint32_t)(n_pad >> 3));
+                         p.G.p, ng, (uint32_t)(n_pad >> log_group));
     }
     hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu.p, pv.p, psz_c.p, p.nchunks,
-                       p.nbins, p.G.p, identity_g);
+                       p.nbins, p.G.p, identity_g, log_group);
     GDN_HIP(hipGetLastError());
     GDN_HIP(hipDeviceSynchronize());
   }  // key buffers freed here
@@ -711,8 +714,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_HIP(hipMemcpy(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice));
   }
   if (alloc_vals) {
-    if (!early) GDN_TRY(p.vals.alloc(p.n_pad + 8));
-    GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + 8) * sizeof(float)));
+    if (!early) GDN_TRY(p.vals.alloc(p.n_pad + grp));
+    GDN_HIP(hipMemset(p.vals.p, 0, (p.n_pad + grp) * sizeof(float)));
   }
   GDN_TRY(p.partial.alloc(p.nbins));
   GDN_TRY(p.red_scratch.alloc(2 * ((size_t)p.nbins / 4096 + 2)));

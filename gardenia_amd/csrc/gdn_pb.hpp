@@ -49,10 +49,11 @@ struct PbPlan {
   int32_t m_global = 0;  // source ids
   uint64_t nnz = 0;
   int log_chunk = 0, log_bin = 0;
+  int log_group = 3;              // edges per entry of G = 2^log_group (tiles are padded to a multiple of it)
   uint32_t nchunks = 0, nbins = 0;
-  uint64_t n_pad = 0;             // padded edge count (multiple of 8) = length of U, V, vals
+  uint64_t n_pad = 0;             // padded edge count (multiple of the group size) = length of U, V, vals
   DevBuf<uint16_t> U;             // chunk-major
-  DevBuf<uint32_t> G;             // n_pad / 8
+  DevBuf<uint32_t> G;             // n_pad >> log_group (+ 1 dump group)
   DevBuf<uint16_t> V;             // bin-major
   DevBuf<float> vals;             // bin-major
   DevBuf<eoff_t> chunk_ptr;       // nchunks + 1, element units (multiples of 8)
@@ -81,12 +82,15 @@ struct PbPlan {
 // edge_vals_in (nullable, CSR order) -> *edge_vals_out in chunk-major order, pads = 0 (SpMV's Ax)
 int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals = true,
              const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr, bool compact = false,
-             bool rows_are_sources = false);  // true: `in_csr` is an OUT-CSR (row = source, col = destination)
+             bool rows_are_sources = false,  // true: `in_csr` is an OUT-CSR (row = source, col = destination)
+             unsigned pad = 16,              // every tile is padded to a multiple of `pad` edges (power of two <= 128)
+             int log_group = 3);             // 2^log_group <= pad edges share one entry of G
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short pb_u16x4 __attribute__((ext_vector_type(4)));
 typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
+typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
 
 // exclusive scan over the PB_THREADS threads of a workgroup; scratch = PB_WAVES + 1 unsigned
 __device__ __forceinline__ unsigned pb_block_excl_scan(unsigned v, unsigned *scratch, unsigned *total) {
@@ -194,12 +198,133 @@ __device__ __forceinline__ double pb_epilogue(const uint32_t *__restrict__ bits,
   return dsum;
 }
 
+// 16-byte form of pb_walk_slice for phase A's prologue: s_x[k] = x[id] for the ACTIVE ids of [lo,hi).
+// A tile is 32*PB_THREADS ids = 8*PB_THREADS groups of 4 ids; every thread issues the loads of its 8
+// groups back to back (one HBM round trip per tile instead of eight), then squeezes them into LDS
+// through the activity nibble.  x must be 16-byte aligned; ids beyond m_global are never active.
+__device__ __forceinline__ void pb_load_slice4(const float *__restrict__ x, int32_t m_global,
+                                               const uint32_t *__restrict__ bits, unsigned lo, unsigned hi, float *s_x,
+                                               unsigned *s_bits, unsigned *s_pref, unsigned *s_scr) {
+  unsigned running = 0;
+  const unsigned w_begin = lo >> 5, w_end = (hi + 31u) >> 5;
+  const pb_f32x4 *x4 = reinterpret_cast<const pb_f32x4 *>(x);
+  for (unsigned wb = w_begin; wb < w_end; wb += PB_THREADS) {
+    const unsigned w = wb + threadIdx.x;
+    unsigned b = (w < w_end) ? bits[w] : 0u;
+    if (w == w_begin && (lo & 31u)) b &= ~0u << (lo & 31u);
+    if (w + 1 == w_end && (hi & 31u)) b &= ~0u >> (32u - (hi & 31u));
+    unsigned total;
+    const unsigned ex = pb_block_excl_scan((unsigned)__popc(b), s_scr, &total);
+    s_bits[threadIdx.x] = b;
+    s_pref[threadIdx.x] = running + ex;
+    __syncthreads();
+    const unsigned g0 = wb << 3;  // first group of 4 ids of this tile
+    pb_f32x4 v[8];
+    unsigned nib[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const unsigned g = (unsigned)j * PB_THREADS + threadIdx.x;
+      nib[j] = (s_bits[g >> 3] >> ((g & 7u) * 4u)) & 15u;
+      if (nib[j]) {
+        const size_t id = ((size_t)g0 + g) << 2;
+        if (id + 3 < (size_t)m_global) v[j] = __builtin_nontemporal_load(x4 + g0 + g);
+        else {
+          v[j].x = x[id];  // an active id is < m_global; the rest of the group may not be
+          v[j].y = id + 1 < (size_t)m_global ? x[id + 1] : 0.0f;
+          v[j].z = id + 2 < (size_t)m_global ? x[id + 2] : 0.0f;
+          v[j].w = 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (nib[j]) {
+        const unsigned g = (unsigned)j * PB_THREADS + threadIdx.x;
+        const unsigned sh = (g & 7u) * 4u;
+        unsigned k = s_pref[g >> 3] + (unsigned)__popc(s_bits[g >> 3] & ((1u << sh) - 1u));
+        if (nib[j] & 1u) s_x[k++] = v[j].x;
+        if (nib[j] & 2u) s_x[k++] = v[j].y;
+        if (nib[j] & 4u) s_x[k++] = v[j].z;
+        if (nib[j] & 8u) s_x[k] = v[j].w;
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+}
+
+// 16-byte form of pb_epilogue (Op::vec_ok: every row array of the op is 16-byte aligned): a thread owns
+// groups of 4 consecutive rows, prefetches the row state of PB_EPI4 groups with 16-byte loads
+// (op.pre4), then finishes them with 16-byte stores (op.fin4).  Groups cut by lo / hi take the scalar
+// path of op.pre / op.fin.
+#define PB_EPI4 4
+template <class Op, class SumOf>
+__device__ __forceinline__ double pb_epilogue4(const uint32_t *__restrict__ bits, unsigned lo, unsigned hi,
+                                               unsigned *s_bits, unsigned *s_pref, unsigned *s_scr, const Op &op,
+                                               SumOf sum_of) {
+  double dsum = 0.0;
+  unsigned running = 0;
+  const unsigned w_begin = lo >> 5, w_end = (hi + 31u) >> 5;
+  for (unsigned wb = w_begin; wb < w_end; wb += PB_THREADS) {
+    const unsigned w = wb + threadIdx.x;
+    unsigned b = 0u;
+    if (w < w_end) b = bits ? bits[w] : ~0u;
+    if (w == w_begin && (lo & 31u)) b &= ~0u << (lo & 31u);
+    if (w + 1 == w_end && (hi & 31u)) b &= ~0u >> (32u - (hi & 31u));
+    unsigned total;
+    const unsigned ex = pb_block_excl_scan((unsigned)__popc(b), s_scr, &total);
+    s_bits[threadIdx.x] = b;
+    s_pref[threadIdx.x] = running + ex;
+    __syncthreads();
+    const unsigned id0 = wb << 5;
+    const unsigned tile_hi = (w_end - wb < PB_THREADS ? w_end - wb : PB_THREADS) << 5;  // ids of this tile that can be in range
+    for (unsigned j0 = 0; j0 < 8; j0 += PB_EPI4) {
+      if (((j0 * PB_THREADS) << 2) >= tile_hi) break;  // uniform: the rest of the tile is past hi
+      typename Op::Pre4 pre[PB_EPI4];
+      int kind[PB_EPI4];  // 0 nothing, 1 whole group, 2 cut group
+#pragma unroll
+      for (int j = 0; j < PB_EPI4; j++) {
+        const unsigned id = id0 + ((((unsigned)(j0 + j)) * PB_THREADS + threadIdx.x) << 2);
+        kind[j] = (id >= lo && id + 3 < hi && id + 3 > id) ? 1 : ((id + 3 >= lo && id < hi) ? 2 : 0);
+        if (kind[j] == 1) pre[j] = op.pre4((int32_t)id);
+      }
+#pragma unroll
+      for (int j = 0; j < PB_EPI4; j++) {
+        if (!kind[j]) continue;
+        const unsigned g = ((unsigned)(j0 + j)) * PB_THREADS + threadIdx.x;
+        const unsigned id = id0 + (g << 2);
+        const unsigned sh = (g & 7u) * 4u;
+        const unsigned bw = s_bits[g >> 3];
+        const unsigned nb = (bw >> sh) & 15u;
+        unsigned k = s_pref[g >> 3] + (unsigned)__popc(bw & ((1u << sh) - 1u));
+        float sum[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          sum[c] = 0.0f;
+          if (nb & (1u << c)) sum[c] = sum_of(k++);
+        }
+        if (kind[j] == 1) dsum += op.fin4((int32_t)id, sum, pre[j]);
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const unsigned r = id + (unsigned)c;
+            if (r >= lo && r < hi) dsum += op.fin((int32_t)r, sum[c], op.pre((int32_t)r));
+          }
+        }
+      }
+    }
+    running += total;
+    __syncthreads();
+  }
+  return dsum;
+}
+
 // phase A: vals[8*G[g] + i] = x[chunk*CH + U[8*g + i]]
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
                  const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
                  const uint32_t *__restrict__ G, float *__restrict__ vals, const uint32_t *__restrict__ src_bits,
-                 const uint32_t *__restrict__ chunk_lo, unsigned split, int nt_store = 0) {
+                 const uint32_t *__restrict__ chunk_lo, unsigned split, int log_group, int nt_store = 0) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
@@ -209,8 +334,11 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   const unsigned part = blockIdx.x % split;
   const size_t base = (size_t)c << log_chunk;
   if (src_bits) {  // compacted slice: the chunk's active sources, gathered from their original id range
-    pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
-                  [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && !(nt_store & 2))
+      pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
+    else
+      pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
+                    [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
   } else if (base + ch <= (size_t)m_global) {  // whole slice in range: 16-byte loads
     const pb_f32x4 *x4 = reinterpret_cast<const pb_f32x4 *>(x + base);
     pb_f32x4 *s4 = reinterpret_cast<pb_f32x4 *>(s_x);
@@ -233,6 +361,8 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
   pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
   constexpr int UNR = 8;
+  const int lq = log_group - 2;  // a lane owns a quad of 4 edges; 2^lq lanes share one entry of G
+  const unsigned qmask = (1u << lq) - 1u;
   for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
     pb_u16x4 u[UNR];
     unsigned d[UNR];
@@ -241,7 +371,7 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
       const eoff_t hh = h + (eoff_t)r * PB_THREADS;
       if (hh < h1) {
         u[r] = __builtin_nontemporal_load(U4 + hh);
-        d[r] = __builtin_nontemporal_load(G + (hh >> 1));
+        d[r] = __builtin_nontemporal_load(G + (hh >> lq));
       }
     }
 #pragma unroll
@@ -253,8 +383,9 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
         o.y = s_x[u[r].y];
         o.z = s_x[u[r].z];
         o.w = s_x[u[r].w];
-        if (nt_store) __builtin_nontemporal_store(o, X4 + 2 * (size_t)d[r] + (size_t)(hh & 1));
-        else X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
+        pb_f32x4 *dst = X4 + (((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask);
+        if (nt_store & 1) __builtin_nontemporal_store(o, dst);
+        else *dst = o;
       }
     }
   }
@@ -265,7 +396,7 @@ static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk,
                         const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
                         const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, const float *__restrict__ A,
-                        float *__restrict__ vals) {
+                        float *__restrict__ vals, int log_group) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   const unsigned ch = 1u << log_chunk;
   const unsigned c = chunk_order[blockIdx.x];
@@ -281,6 +412,8 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
   const pb_f32x4 *A4 = reinterpret_cast<const pb_f32x4 *>(A);
   pb_f32x4 *X4 = reinterpret_cast<pb_f32x4 *>(vals);
   constexpr int UNR = 4;
+  const int lq = log_group - 2;
+  const unsigned qmask = (1u << lq) - 1u;
   for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
     pb_u16x4 u[UNR];
     pb_f32x4 a[UNR];
@@ -291,7 +424,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
       if (hh < h1) {
         u[r] = __builtin_nontemporal_load(U4 + hh);
         a[r] = __builtin_nontemporal_load(A4 + hh);
-        d[r] = __builtin_nontemporal_load(G + (hh >> 1));
+        d[r] = __builtin_nontemporal_load(G + (hh >> lq));
       }
     }
 #pragma unroll
@@ -303,7 +436,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
         o.y = __fmul_rn(s_x[u[r].y], a[r].y);
         o.z = __fmul_rn(s_x[u[r].z], a[r].z);
         o.w = __fmul_rn(s_x[u[r].w], a[r].w);
-        X4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
+        X4[(((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask)] = o;
       }
     }
   }
@@ -428,8 +561,12 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const size_t row0 = (size_t)b << log_bin;
     const unsigned lo = dst_bits ? bin_lo[b] : (unsigned)row0;
     const unsigned hi = dst_bits ? bin_lo[b + 1] : (unsigned)((row0 + bn < (size_t)m_local) ? row0 + bn : (size_t)m_local);
-    dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
-                       [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
+    if (op.vec_ok && !(dbg & 4))
+      dsum = pb_epilogue4(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
+                          [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
+    else
+      dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
+                         [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
   }
   if (bad) *errflag = 1u;
   dsum = gdn_wave_sum(dsum);

@@ -51,6 +51,29 @@ struct PrOp {
     return (double)fabsf(__fsub_rn(new_score, p.old_score));
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
+  // 16-byte row accesses of the PB epilogue (pb_epilogue4); vec_ok = all three row arrays 16-byte aligned
+  bool vec_ok;
+  struct Pre4 {
+    pb_f32x4 old_score;
+    pb_i32x4 deg;
+  };
+  __device__ __forceinline__ Pre4 pre4(int32_t row) const {
+    return Pre4{*reinterpret_cast<const pb_f32x4 *>(scores + row), *reinterpret_cast<const pb_i32x4 *>(out_degree + row)};
+  }
+  __device__ __forceinline__ double fin4(int32_t row, const float (&sum)[4], const Pre4 &p) const {
+    pb_f32x4 ns, nc;
+    double d = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const float new_score = __fadd_rn(base_score, __fmul_rn(damping, sum[c]));
+      ns[c] = new_score;
+      nc[c] = __fdiv_rn(new_score, (float)p.deg[c]);
+      d += (double)fabsf(__fsub_rn(new_score, p.old_score[c]));
+    }
+    *reinterpret_cast<pb_f32x4 *>(scores + row) = ns;
+    *reinterpret_cast<pb_f32x4 *>(contrib_out + row) = nc;
+    return d;
+  }
 };
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -98,7 +121,13 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (const char *e = getenv("GDN_PB_LOG_BIN")) lb = atoi(e);
     // vertex compaction on by default (GDN_PB_COMPACT=0 switches it off for A/B measurements)
     const char *ce = getenv("GDN_PB_COMPACT");
-    st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, !(ce && ce[0] == '0'));
+    // tiles padded to 32 edges = whole 128-byte lines of vals (a line shared by two tiles is written by two
+    // workgroups at different times: measured 3.9 -> 3.0 ms for phase A on RMAT-27), one G entry per 32 edges
+    unsigned pad = 32;
+    int lg = 5;
+    if (const char *e = getenv("GDN_PB_PAD")) pad = (unsigned)atoi(e);
+    if (const char *e = getenv("GDN_PB_LOG_GROUP")) lg = atoi(e);
+    st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, !(ce && ce[0] == '0'), false, pad, lg);
     if (st == GDN_OK) {
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
@@ -148,6 +177,8 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   op.out_degree = plan->out_degree;
   op.base_score = (1.0f - damping) / (float)plan->m_global;
   op.damping = damping;
+  op.vec_ok = ((reinterpret_cast<uintptr_t>(op.scores) | reinterpret_cast<uintptr_t>(op.contrib_out) |
+                reinterpret_cast<uintptr_t>(op.out_degree)) & 15u) == 0;
   if (plan->layout == GDN_LAYOUT_CSR) return mp_run(plan->mp, op, d_diff, (hipStream_t)stream);
   // ---- propagation-blocked path: expand (per chunk) then accumulate + fused update (per bin)
   PbPlan &pb = plan->pb;
@@ -164,16 +195,13 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   }
   hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
-                     pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, 0);
+                     pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
+                     getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
                      pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
-#ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: TIMING-ONLY ablations (bit0 no LDS atomics, bit1 no epilogue), wrong results
                      getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0
-#else
-                     0
-#endif
   );
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));

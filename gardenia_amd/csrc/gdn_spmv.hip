@@ -39,6 +39,18 @@ struct SpmvOp {
     return 0.0;
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
+  bool vec_ok;  // y 16-byte aligned: pb_epilogue4
+  struct Pre4 {
+    pb_f32x4 y;
+  };
+  __device__ __forceinline__ Pre4 pre4(int32_t row) const { return Pre4{*reinterpret_cast<const pb_f32x4 *>(y + row)}; }
+  __device__ __forceinline__ double fin4(int32_t row, const float (&sum)[4], const Pre4 &p) const {
+    pb_f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; c++) o[c] = __fadd_rn(p.y[c], sum[c]);
+    *reinterpret_cast<pb_f32x4 *>(y + row) = o;
+    return 0.0;
+  }
   // PB layout: signed fixed point with a per-call power-of-two scale (gdn_pb.hpp)
   const float *__restrict__ scale;
   __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const {
@@ -124,7 +136,7 @@ int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax, int32_t layout
     st = mp_plan_build(p->mp, csr, 0);
   } else {
     st = pb_build(csr, csr->m, spmv_pick_log(csr->m, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
-                  true, d_Ax, &p->Axp);
+                  true, d_Ax, &p->Axp, false, false, /*pad=*/32, /*log_group=*/5);
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
     if (st == GDN_OK) {
@@ -167,6 +179,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   op.x = d_x;
   op.y = d_y;
   op.scale = nullptr;
+  op.vec_ok = (reinterpret_cast<uintptr_t>(d_y) & 15u) == 0;
   hipStream_t s = (hipStream_t)stream;
   if (plan->layout == GDN_LAYOUT_CSR) {
     GDN_REQUIRE(d_Ax != nullptr, "d_Ax");
@@ -183,7 +196,8 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
-                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p);
+                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
+                     pb.log_group);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,

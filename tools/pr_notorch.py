@@ -41,4 +41,10 @@ for it in range(3, 3 + steps):
     _cabi.check(L.gdn_pr_pull_dev(plan, bufs[it & 1], scores, bufs[(it + 1) & 1], diff, 0.85, None))
 tot, n = (C.c_double * 2)(0, 0), C.c_int32(0)
 _cabi.check(L.gdn_pr_plan_kernel_time(plan, 0, 0, tot, C.byref(n)))
+out = np.empty(m, np.float32)
+_cabi.check(L.gdn_dev_download(out.ctypes.data_as(C.c_void_p), scores, 4 * m))
+dd = np.empty(1, np.float64)
+_cabi.check(L.gdn_dev_download(dd.ctypes.data_as(C.c_void_p), diff, 8))
+import zlib
+print("check: sum %.9f diff %.12e crc %08x" % (float(out.astype(np.float64).sum()), dd[0], zlib.crc32(out.tobytes())))
 print("no-torch process: scale", scale, "A %.3f ms  B %.3f ms  sum %.3f ms" % (tot[0] / n.value, tot[1] / n.value, (tot[0] + tot[1]) / n.value))
