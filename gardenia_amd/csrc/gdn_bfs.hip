@@ -265,31 +265,36 @@ bfs_pb_accumulate_kernel(int32_t m, int log_bin, const eoff_t *__restrict__ bin_
   __syncthreads();
   const eoff_t g0 = bin_ptr[b] >> 3, g1 = bin_ptr[b + 1] >> 3;
   const bfs_u16x8 *V8 = reinterpret_cast<const bfs_u16x8 *>(V);
-  constexpr int UNR = 4;
+  // two dependent loads per group (edge byte, then the 8 row ids of a non-zero byte): all byte loads of a
+  // step are issued first, then all row-id loads, so a wave keeps UNR of each in flight
+  constexpr int UNR = 8;
   for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
     unsigned by[UNR];
+    bfs_u16x8 v[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t gg = g + (eoff_t)r * PB_THREADS;
       by[r] = (gg < g1) ? (unsigned)__builtin_nontemporal_load(ebits + gg) : 0u;
     }
 #pragma unroll
+    for (int r = 0; r < UNR; r++)
+      if (by[r]) v[r] = __builtin_nontemporal_load(V8 + g + (eoff_t)r * PB_THREADS);
+#pragma unroll
     for (int r = 0; r < UNR; r++) {
       if (by[r]) {
-        const bfs_u16x8 v = __builtin_nontemporal_load(V8 + g + (eoff_t)r * PB_THREADS);
 #define BFS_HIT(e, i)                                                               \
   if ((by[r] >> (i)) & 1u) {                                                        \
     const unsigned bit = 1u << ((unsigned)(e)&31u);                                 \
     if (!(s_vis[(unsigned)(e) >> 5] & bit)) atomicOr(&s_new[(unsigned)(e) >> 5], bit); \
   }
-        BFS_HIT(v.s0, 0)
-        BFS_HIT(v.s1, 1)
-        BFS_HIT(v.s2, 2)
-        BFS_HIT(v.s3, 3)
-        BFS_HIT(v.s4, 4)
-        BFS_HIT(v.s5, 5)
-        BFS_HIT(v.s6, 6)
-        BFS_HIT(v.s7, 7)
+        BFS_HIT(v[r].s0, 0)
+        BFS_HIT(v[r].s1, 1)
+        BFS_HIT(v[r].s2, 2)
+        BFS_HIT(v[r].s3, 3)
+        BFS_HIT(v[r].s4, 4)
+        BFS_HIT(v[r].s5, 5)
+        BFS_HIT(v[r].s6, 6)
+        BFS_HIT(v[r].s7, 7)
 #undef BFS_HIT
       }
     }

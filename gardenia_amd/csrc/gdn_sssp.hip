@@ -13,6 +13,7 @@
 //   * neighbour expansion = gdn_expand.hpp (hub rows chunked across the grid).
 // Distances are exact (integer min is order independent): identical to Dijkstra
 // (src/sssp/verifier.cc:8-39).
+#include <stdlib.h>
 #include <string.h>
 
 #include "gdn_expand.hpp"
@@ -348,7 +349,8 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
     GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
-                     /*compact=*/false, /*rows_are_sources=*/true));
+                     /*compact=*/false, /*rows_are_sources=*/true,
+                     /*pad=*/getenv("GDN_SSSP_PAD") ? (unsigned)atoi(getenv("GDN_SSSP_PAD")) : 32u, /*log_group=*/3));
     GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
     // slots in the alignment gaps of the layout are never written by phase A: keep them neutral
     GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), GDN_DIST_INF, (size_t)p.pb.n_pad + 8, 0));
