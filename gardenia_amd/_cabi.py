@@ -62,7 +62,9 @@ PROTOTYPES = {
     "gdn_graph_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64), _pp, _pp]),
     "gdn_graph_degrees_dev": (C.c_int, [_vp, _vp, _vp]),
     "gdn_graph_transpose": (C.c_int, [_vp, _pp]),
+    "gdn_graph_symmetrize": (C.c_int, [_vp, _pp]),
     "gdn_graph_slice_rows": (C.c_int, [_vp, _i32, _i32, _pp]),
+    "gdn_graph_from_edges": (C.c_int, [_i32, _u64, _vp, _vp, _i32, _pp]),
     "gdn_graph_download": (C.c_int, [_vp, _vp, _vp]),
     "gdn_rmat_build": (C.c_int, [_i32, _i32, _u64, _i32, _pp, _pp]),
     "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pp]),

@@ -197,10 +197,15 @@ struct KeyVis {
   const vid_t *__restrict__ colidx;
   unsigned long long *__restrict__ keys;
   int32_t v;
+  unsigned long long *__restrict__ fwd = nullptr;  // optional second array: the untransposed key (row<<32 | col)
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     const unsigned src = (unsigned)__shfl(v, owner, 64);
-    if (valid) keys[k] = ((unsigned long long)(unsigned)colidx[k] << 32) | src;
+    if (valid) {
+      const unsigned col = (unsigned)colidx[k];
+      keys[k] = ((unsigned long long)col << 32) | src;
+      if (fwd) fwd[k] = ((unsigned long long)src << 32) | col;
+    }
   }
 };
 
@@ -759,6 +764,98 @@ int gdn_graph_transpose(const gdn_graph *g, gdn_graph **out) {
   }
   bigitems.release();
   return csr_from_keys(ka, kb, g->nnz, m, bits_for(m), out);
+}
+
+// (src,dst) pairs -> sort keys; symmetrize doubles them.  bad[0] is set when an id is outside [0,m)
+__global__ void __launch_bounds__(GDN_BLOCK)
+edge_keys_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ dst, unsigned long long n, int32_t m,
+                 int symmetrize, unsigned long long *__restrict__ keys, unsigned *__restrict__ bad) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) {
+    const int32_t a = src[i], b = dst[i];
+    if (a < 0 || a >= m || b < 0 || b >= m) {
+      *bad = 1u;
+      keys[i] = 0ull;  // (0,0) is a self loop: dropped
+      if (symmetrize) keys[n + i] = 0ull;
+      continue;
+    }
+    keys[i] = ((unsigned long long)(unsigned)a << 32) | (unsigned)b;
+    if (symmetrize) keys[n + i] = ((unsigned long long)(unsigned)b << 32) | (unsigned)a;
+  }
+}
+
+int gdn_graph_from_edges(int32_t m, uint64_t n_edges, const int32_t *src, const int32_t *dst, int32_t symmetrize,
+                         gdn_graph **out) {
+  GDN_REQUIRE(out != nullptr, "out");
+  *out = nullptr;
+  GDN_REQUIRE(m > 0, "m");
+  GDN_REQUIRE(n_edges == 0 || (src != nullptr && dst != nullptr), "src / dst");
+  GDN_TRY(gdn_require_device());
+  const unsigned long long n = n_edges, nk = symmetrize ? 2 * n : n;
+  DevBuf<unsigned long long> ka, kb;
+  DevBuf<unsigned> bad;
+  GDN_TRY(ka.alloc(nk));
+  GDN_TRY(kb.alloc(nk));
+  GDN_TRY(bad.alloc(1));
+  GDN_HIP(hipMemset(bad.p, 0, sizeof(unsigned)));
+  if (n) {
+    DevBuf<int32_t> ds, dd;
+    GDN_TRY(ds.alloc(n));
+    GDN_TRY(dd.alloc(n));
+    GDN_HIP(hipMemcpy(ds.p, src, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    GDN_HIP(hipMemcpy(dd.p, dst, n * sizeof(int32_t), hipMemcpyHostToDevice));
+    const unsigned long long nb64 = (n + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(edge_keys_kernel, dim3((unsigned)(nb64 > 262144ull ? 262144ull : nb64)), dim3(GDN_BLOCK), 0, 0, ds.p,
+                       dd.p, n, m, symmetrize ? 1 : 0, ka.p, bad.p);
+    GDN_HIP(hipGetLastError());
+    unsigned h = 0;
+    GDN_HIP(hipMemcpy(&h, bad.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (h) {
+      gdn_set_error("gdn_graph_from_edges: a vertex id lies outside [0,%d)", m);
+      return GDN_ERR_INVALID;
+    }
+  }
+  return csr_from_keys(ka, kb, nk, m, bits_for(m), out);
+}
+
+// undirected closure of a resident graph: every edge in both directions, duplicates dropped (what the
+// reference loader does with symmetrize = true, csr_graph.h:112-115 + fill_data)
+int gdn_graph_symmetrize(const gdn_graph *g, gdn_graph **out) {
+  GDN_REQUIRE(g != nullptr && out != nullptr, "graph / out");
+  *out = nullptr;
+  const int32_t m = g->m;
+  DevBuf<unsigned long long> ka, kb, bigitems;
+  DevBuf<unsigned> cnt;
+  const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+  const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+  GDN_TRY(ka.alloc(2 * g->nnz));
+  GDN_TRY(kb.alloc(2 * g->nnz));
+  GDN_TRY(bigitems.alloc(bigcap));
+  GDN_TRY(cnt.alloc(2));
+  GDN_HIP(hipMemset(cnt.p, 0, 8));
+  ExpBigList big;
+  big.items = bigitems.p;
+  big.capacity = bigcap;
+  big.count = cnt.p;
+  big.overflow = cnt.p + 1;
+  KeyVis vis;
+  vis.colidx = g->colidx;
+  vis.keys = ka.p;
+  vis.fwd = ka.p + g->nnz;
+  vis.v = 0;
+  hipLaunchKernelGGL(transpose_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big,
+                     vis);
+  hipLaunchKernelGGL(transpose_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+  GDN_HIP(hipGetLastError());
+  unsigned h[2];
+  GDN_HIP(hipMemcpy(h, cnt.p, 8, hipMemcpyDeviceToHost));
+  if (h[1]) {
+    gdn_set_error("gdn_graph_symmetrize: device worklist overflow");
+    return GDN_ERR_OVERFLOW;
+  }
+  bigitems.release();
+  return csr_from_keys(ka, kb, 2 * g->nnz, m, bits_for(m), out);
 }
 
 int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute, gdn_graph **out_csr,

@@ -78,42 +78,135 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 
 __device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - 11); }
 
-struct TcCountVis {
-  const vid_t *__restrict__ colidx;
-  const vid_t *nu;    // N+(u) in global memory (fallback for lists longer than TC_CAP)
-  const vid_t *table; // LDS hash set of N+(u), or nullptr
+// membership of w in N+(u): LDS hash set (expected ~1.3 probes) or binary search in global memory
+struct TcSet {
+  const vid_t *table;  // LDS hash set of N+(u), or nullptr
+  const vid_t *nu;     // N+(u) in global memory (lists longer than TC_CAP)
   int du;
-  unsigned long long count;
-  __device__ __forceinline__ void begin_big(vid_t) {}
-  __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
-    if (!valid) return;
-    const vid_t w = colidx[k];
-    if (table) {  // expected ~1.3 probes
-      unsigned h = tc_hash(w);
-      for (;;) {
-        const vid_t x = table[h];
-        if (x == w) {
-          count++;
-          break;
-        }
-        if (x == TC_EMPTY) break;
-        h = (h + 1) & (TC_HASH - 1);
-      }
-    } else {
-      int lo = 0, hi = du - 1;
-      while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const vid_t x = nu[mid];
-        if (x == w) {
-          count++;
-          break;
-        }
-        if (x < w) lo = mid + 1;
-        else hi = mid - 1;
-      }
+  __device__ __forceinline__ unsigned slow(vid_t w, unsigned h) const {  // continue a probe sequence that collided
+    for (;;) {
+      h = (h + 1) & (TC_HASH - 1);
+      const vid_t x = table[h];
+      if (x == w) return 1u;
+      if (x == TC_EMPTY) return 0u;
     }
   }
+  __device__ __forceinline__ unsigned search(vid_t w) const {
+    int lo = 0, hi = du - 1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      const vid_t x = nu[mid];
+      if (x == w) return 1u;
+      if (x < w) lo = mid + 1;
+      else hi = mid - 1;
+    }
+    return 0u;
+  }
+  // TC_UNR candidates at once: the first probes are independent LDS reads (in flight together)
+  template <int N>
+  __device__ __forceinline__ unsigned count(const vid_t (&w)[N], const bool (&valid)[N]) const {
+    unsigned c = 0;
+    if (table) {
+      unsigned h[N];
+      vid_t x[N];
+#pragma unroll
+      for (int r = 0; r < N; r++) {
+        h[r] = tc_hash(w[r]);
+        x[r] = table[h[r]];
+      }
+#pragma unroll
+      for (int r = 0; r < N; r++) {
+        if (!valid[r]) continue;
+        if (x[r] == w[r]) c++;
+        else if (x[r] != TC_EMPTY) c += slow(w[r], h[r]);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < N; r++)
+        if (valid[r]) c += search(w[r]);
+    }
+    return c;
+  }
 };
+
+#define TC_UNR 4  // neighbour-list elements per lane in flight (the kernel is latency bound: 67 % of its wave cycles
+                  // were spent in s_waitcnt with one element per lane, profiles/r01_tc_pmc.md)
+
+// Walk the out-neighbour lists [vb,ve) held one per lane (vb == ve for idle lanes) and count the elements that
+// are in `set`.  Lists of >= 64 elements are walked by the whole wave, shorter ones are packed (wave prefix sum of
+// the lengths, owner of a packed position by binary search over the prefix sums in LDS) -- the scheme of
+// gdn_expand.hpp with TC_UNR independent positions per lane, so TC_UNR global loads and LDS probes overlap.
+__device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restrict__ colidx, eoff_t vb, eoff_t ve,
+                                                            const TcSet &set, unsigned *s_scan) {
+  const unsigned lane = gdn_lane();
+  unsigned long long count = 0;
+  unsigned deg = (unsigned)(ve - vb);
+  {  // lists of a wave's width or more: one list at a time, 64 * TC_UNR consecutive elements per step
+    unsigned long long mask = __ballot(deg >= 64u);
+    while (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      mask &= mask - 1ull;
+      const eoff_t bb = __shfl(vb, leader, 64);
+      const eoff_t ee = __shfl(ve, leader, 64);
+      for (eoff_t k0 = bb; k0 < ee; k0 += 64 * TC_UNR) {
+        vid_t w[TC_UNR];
+        bool valid[TC_UNR];
+#pragma unroll
+        for (int r = 0; r < TC_UNR; r++) {
+          const eoff_t k = k0 + (eoff_t)(64 * r) + lane;
+          valid[r] = k < ee;
+          w[r] = valid[r] ? colidx[k] : 0;
+        }
+        count += set.count(w, valid);
+      }
+    }
+    if (deg >= 64u) deg = 0;
+  }
+  {  // short lists, packed
+    const unsigned incl = gdn_wave_incl_scan(deg);
+    const unsigned total = __shfl(incl, 63, 64);
+    if (total) {
+      s_scan[lane] = incl - deg;  // exclusive prefix
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      for (unsigned base = 0; base < total; base += 64 * TC_UNR) {
+        unsigned idx[TC_UNR];
+        int lo[TC_UNR], hi[TC_UNR];
+        bool valid[TC_UNR];
+#pragma unroll
+        for (int r = 0; r < TC_UNR; r++) {
+          idx[r] = base + 64u * (unsigned)r + lane;
+          valid[r] = idx[r] < total;
+          lo[r] = 0;
+          hi[r] = 63;
+        }
+        // owner = LAST lane whose exclusive prefix is <= idx (empty lists share a prefix with their successor)
+#pragma unroll
+        for (int st = 0; st < 6; st++) {
+#pragma unroll
+          for (int r = 0; r < TC_UNR; r++) {
+            const int mid = (lo[r] + hi[r] + 1) >> 1;
+            if (s_scan[mid] <= idx[r]) lo[r] = mid;
+            else hi[r] = mid - 1;
+          }
+        }
+        vid_t w[TC_UNR];
+#pragma unroll
+        for (int r = 0; r < TC_UNR; r++) {
+          const int owner = valid[r] ? lo[r] : (int)lane;
+          const eoff_t ob = __shfl(vb, owner, 64);
+          const unsigned oex = s_scan[owner];
+          w[r] = valid[r] ? colidx[ob + (idx[r] - oex)] : 0;
+        }
+        count += set.count(w, valid);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  return count;
+}
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
@@ -123,14 +216,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
   const unsigned w = threadIdx.x >> 6;
-  TcCountVis vis;
-  vis.colidx = colidx;
-  vis.count = 0;
-  ExpBigList nobig;
-  nobig.items = nullptr;
-  nobig.count = nullptr;
-  nobig.capacity = 0;
-  nobig.overflow = nullptr;
+  unsigned long long count = 0;
   for (int i = lane; i < TC_HASH; i += 64) s_tab[w][i] = TC_EMPTY;
   for (;;) {
     // dynamic vertex assignment: 16 consecutive vertices per grab (one atomic per 16 rows)
@@ -139,17 +225,24 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     u0 = __shfl(u0, 0, 64);
     if (u0 >= (unsigned)m) break;
     const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
+    // the 17 row offsets of the batch in one load
+    eoff_t rp = 0;
+    if (u0 + lane <= u1) rp = rowptr[u0 + lane];
     for (unsigned u = u0; u < u1; u++) {
-      const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
+      const eoff_t ub = __shfl(rp, (int)(u - u0), 64), ue = __shfl(rp, (int)(u - u0) + 1, 64);
       const int du = (int)(ue - ub);
       if (du < 2) continue;  // a single out-neighbour closes no triangle
-      vis.du = du;
-      vis.nu = colidx + ub;
+      TcSet set;
+      set.du = du;
+      set.nu = colidx + ub;
       const bool hashed = du <= TC_CAP;
-      vis.table = hashed ? s_tab[w] : nullptr;
+      set.table = hashed ? s_tab[w] : nullptr;
+      // the first 64 out-neighbours: loaded once, used for the hash build, the list walk and the clean-up
+      vid_t v0 = 0;
+      if (lane < (unsigned)du) v0 = colidx[ub + lane];
       if (hashed) {  // build the hash set of N+(u): integer LDS CAS, linear probing
         for (int i = lane; i < du; i += 64) {
-          const vid_t x = colidx[ub + i];
+          const vid_t x = i < 64 ? v0 : colidx[ub + i];
           unsigned h = tc_hash(x);
           while (atomicCAS(&s_tab[w][h], TC_EMPTY, x) != TC_EMPTY) h = (h + 1) & (TC_HASH - 1);
         }
@@ -160,19 +253,18 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       for (eoff_t i0 = ub; i0 < ue; i0 += 64) {
         const eoff_t i = i0 + lane;
         eoff_t vb = 0, ve = 0;
-        vid_t v = 0;
         if (i < ue) {
-          v = colidx[i];
+          const vid_t v = i0 == ub ? v0 : colidx[i];
           vb = rowptr[v];
           ve = rowptr[v + 1];
         }
-        gdn_expand_wave(vb, ve, v, nobig, vis, s_scan[w]);
+        count += tc_walk_lists(colidx, vb, ve, set, s_scan[w]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (hashed) {  // clear only the slots that were used
         for (int i = lane; i < du; i += 64) {
-          const vid_t x = colidx[ub + i];
+          const vid_t x = i < 64 ? v0 : colidx[ub + i];
           unsigned h = tc_hash(x);
           while (s_tab[w][h] != x) h = (h + 1) & (TC_HASH - 1);
           s_tab[w][h] = TC_EMPTY;
@@ -184,7 +276,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       }
     }
   }
-  unsigned long long count = gdn_block_sum(vis.count, s_red);
+  count = gdn_block_sum(count, s_red);
   if (threadIdx.x == 0 && count) atomicAdd(total, count);
 }
 

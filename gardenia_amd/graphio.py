@@ -74,6 +74,31 @@ def build_csr(m: int, src: np.ndarray, dst: np.ndarray, dedupe: bool = True,
     return CSR(m, rowptr, d)
 
 
+def build_csr_device(m: int, src: np.ndarray, dst: np.ndarray, symmetrize_: bool = False) -> CSR:
+    """The same clean-up as build_csr (+ optional symmetrization) done on the device through
+    gdn_graph_from_edges: one radix sort instead of the reference's per-row sort + erase loop
+    (csr_graph.h:122-143).  Needs a HIP device (no CPU fallback)."""
+    import ctypes as C
+    from . import _cabi
+    L = _cabi.lib()
+    s32 = np.ascontiguousarray(src, dtype=np.int32)
+    d32 = np.ascontiguousarray(dst, dtype=np.int32)
+    if s32.shape != d32.shape:
+        raise ValueError("src and dst must have the same length")
+    h = C.c_void_p()
+    _cabi.check(L.gdn_graph_from_edges(m, s32.size, s32.ctypes.data_as(C.c_void_p), d32.ctypes.data_as(C.c_void_p),
+                                       1 if symmetrize_ else 0, C.byref(h)))
+    try:
+        mm, nnz = C.c_int32(), C.c_uint64()
+        _cabi.check(L.gdn_graph_info(h, C.byref(mm), C.byref(nnz), None, None))
+        rowptr = np.empty(m + 1, np.uint64)
+        colidx = np.empty(nnz.value, np.int32)
+        _cabi.check(L.gdn_graph_download(h, rowptr.ctypes.data_as(C.c_void_p), colidx.ctypes.data_as(C.c_void_p)))
+    finally:
+        L.gdn_graph_free(h)
+    return CSR(m, rowptr, colidx)
+
+
 def csr_to_coo(g: CSR) -> Tuple[np.ndarray, np.ndarray]:
     src = np.repeat(np.arange(g.m, dtype=np.int64), np.diff(g.rowptr.astype(np.int64)))
     return src, g.colidx.astype(np.int64)

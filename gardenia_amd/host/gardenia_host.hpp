@@ -54,11 +54,14 @@ class Graph {
   std::vector<uint64_t> vertices, reverse_vertices;
   std::vector<VertexId> edges, reverse_edges;
   bool reverse_is_alias = false;
-  void from_edges(VertexId m, std::vector<std::pair<VertexId, VertexId> > &el);
+  void from_edges(VertexId m, std::vector<VertexId> &src, std::vector<VertexId> &dst, bool symmetrize);
+  void from_edges_device(VertexId m, std::vector<VertexId> &src, std::vector<VertexId> &dst, bool symmetrize);
   void build_reverse_graph();
 
  public:
-  Graph(std::string prefix, std::string filetype = "bin", bool symmetrize = false, bool need_reverse = false);
+  // device_ingest: build the CSR of an .mtx input on the GPU (gdn_graph_from_edges) instead of on the host
+  Graph(std::string prefix, std::string filetype = "bin", bool symmetrize = false, bool need_reverse = false,
+        bool device_ingest = false);
   Graph(const Graph &) = delete;
   Graph &operator=(const Graph &) = delete;
   VertexSet N(VertexId v) const { return VertexSet(edges.data() + vertices[v], (VertexId)(vertices[v + 1] - vertices[v])); }
@@ -82,6 +85,11 @@ class Graph {
   void orientation();  // src/common/graph.cc:67-113 (host copy, used by the TC verifier only)
   void write_bin(const std::string &prefix) const;  // the format of csr_graph.h:219-230 (no writer upstream)
 };
+
+// Parallel .mtx edge reader (graph.cc): the text is cut into one piece per thread at line boundaries and parsed
+// with a hand-written integer scanner; semantics of csr_graph.h:74-120 (1-based ids, '%' banner lines, '#' and
+// blank lines skipped, a third column ignored, self loops dropped).  Returns the header's vertex count.
+VertexId read_mtx_edges(const std::string &fname, std::vector<VertexId> &src, std::vector<VertexId> &dst);
 
 // ---- solvers: each is ONE call through the C-ABI (solvers.cc)
 void BFSSolver(Graph &g, int source, DistT *dist);

@@ -124,9 +124,18 @@ int gdn_graph_info(const gdn_graph *g, int32_t *m, uint64_t *nnz, const uint64_t
 int gdn_graph_degrees_dev(const gdn_graph *g, int32_t *d_degree, void *stream);
 /* reverse graph, csr_graph.h:170-194 build_reverse_graph (rows ascending) */
 int gdn_graph_transpose(const gdn_graph *g, gdn_graph **out);
+/* undirected closure: every edge in both directions, duplicates dropped, rows ascending (the loader's
+ * symmetrize = true, csr_graph.h:112-115) */
+int gdn_graph_symmetrize(const gdn_graph *g, gdn_graph **out);
 /* rows [row_lo,row_hi) as an independent graph (column ids stay global): the vertex-range
  * shard one GPU holds in the multi-GPU PageRank/SpMV path */
 int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn_graph **out);
+/* Device ingest: edge list (host arrays, 0-based ids) -> resident CSR with the clean-up of the reference
+ * loader (include/csr_graph.h:108 self loops dropped, :127 rows sorted ascending, :132-143 duplicates
+ * dropped; symmetrize != 0 also inserts every reverse edge, :112-115).  One radix sort on the device
+ * replaces the per-row std::sort + O(deg^2) erase loop.  Ids outside [0,m) are an error. */
+int gdn_graph_from_edges(int32_t m, uint64_t n_edges, const int32_t *src, const int32_t *dst, int32_t symmetrize,
+                         gdn_graph **out);
 /* download to caller-provided host arrays ((m+1) x u64, nnz x i32) */
 int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx);
 
