@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgardenia_hip.so")
+# GARDENIA_HIP_LIB: another build of the same library (tools/ A/B measurements of compile-time variants)
+LIB_PATH = os.environ.get("GARDENIA_HIP_LIB") or os.path.join(_HERE, "lib", "libgardenia_hip.so")
 
 GDN_OK = 0
 GDN_ERR_INVALID = -1

@@ -72,17 +72,19 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 // walked through gdn_expand_wave, so the 64 lanes always hold 64 distinct (v, w) pairs no matter how
 // short the lists are; every w is looked up in N+(u) by binary search in LDS (global memory when
 // N+(u) does not fit).  With the degree orientation every list is O(sqrt(nnz)) long.
-#define TC_CAP 1024            // ids of N+(u) kept in LDS per wave (8 KB hash set -> 5 workgroups per CU)
+#ifndef TC_CAP
+#define TC_CAP 1024            // ids of N+(u) staged in LDS per pass and wave (8 KB hash set -> 4 workgroups per CU)
+#endif
 #define TC_HASH (2 * TC_CAP)   // open-addressing slots per wave (load factor <= 0.5)
 #define TC_EMPTY (-1)
 
-__device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - 11); }
+#define TC_HASH_BITS (TC_CAP == 1024 ? 11 : TC_CAP == 512 ? 10 : TC_CAP == 256 ? 9 : 8)
+static_assert((1 << TC_HASH_BITS) == TC_HASH, "TC_CAP must be 128, 256, 512 or 1024");
+__device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - TC_HASH_BITS); }
 
-// membership of w in N+(u): LDS hash set (expected ~1.3 probes) or binary search in global memory
+// membership of w in the staged part of N+(u): LDS hash set, expected ~1.3 probes
 struct TcSet {
-  const vid_t *table;  // LDS hash set of N+(u), or nullptr
-  const vid_t *nu;     // N+(u) in global memory (lists longer than TC_CAP)
-  int du;
+  const vid_t *table;
   __device__ __forceinline__ unsigned slow(vid_t w, unsigned h) const {  // continue a probe sequence that collided
     for (;;) {
       h = (h + 1) & (TC_HASH - 1);
@@ -91,53 +93,43 @@ struct TcSet {
       if (x == TC_EMPTY) return 0u;
     }
   }
-  __device__ __forceinline__ unsigned search(vid_t w) const {
-    int lo = 0, hi = du - 1;
-    while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
-      const vid_t x = nu[mid];
-      if (x == w) return 1u;
-      if (x < w) lo = mid + 1;
-      else hi = mid - 1;
-    }
-    return 0u;
-  }
-  // TC_UNR candidates at once: the first probes are independent LDS reads (in flight together)
+  // N candidates at once: the first probes are independent LDS reads (in flight together)
   template <int N>
   __device__ __forceinline__ unsigned count(const vid_t (&w)[N], const bool (&valid)[N]) const {
     unsigned c = 0;
-    if (table) {
-      unsigned h[N];
-      vid_t x[N];
+    unsigned h[N];
+    vid_t x[N];
 #pragma unroll
-      for (int r = 0; r < N; r++) {
-        h[r] = tc_hash(w[r]);
-        x[r] = table[h[r]];
-      }
+    for (int r = 0; r < N; r++) {
+      h[r] = tc_hash(w[r]);
+      x[r] = table[h[r]];
+    }
 #pragma unroll
-      for (int r = 0; r < N; r++) {
-        if (!valid[r]) continue;
-        if (x[r] == w[r]) c++;
-        else if (x[r] != TC_EMPTY) c += slow(w[r], h[r]);
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < N; r++)
-        if (valid[r]) c += search(w[r]);
+    for (int r = 0; r < N; r++) {
+      if (!valid[r]) continue;
+      if (x[r] == w[r]) c++;
+      else if (x[r] != TC_EMPTY) c += slow(w[r], h[r]);
     }
     return c;
   }
 };
 
-#define TC_UNR 4  // neighbour-list elements per lane in flight (the kernel is latency bound: 67 % of its wave cycles
-                  // were spent in s_waitcnt with one element per lane, profiles/r01_tc_pmc.md)
+// neighbour-list elements per lane in flight: the kernel is latency bound (67 % of its wave cycles were spent in
+// s_waitcnt with one element per lane, profiles/r01_tc_pmc.md)
+#ifndef TC_UNR
+#define TC_UNR 8
+#endif
+#ifndef TC_WAVES_PER_EU
+#define TC_WAVES_PER_EU 4  // LDS allows 4 workgroups per CU; measured: 8 waves/SIMD with 4 KB sets is slower
+#endif
 
 // Walk the out-neighbour lists [vb,ve) held one per lane (vb == ve for idle lanes) and count the elements that
 // are in `set`.  Lists of >= 64 elements are walked by the whole wave, shorter ones are packed (wave prefix sum of
-// the lengths, owner of a packed position by binary search over the prefix sums in LDS) -- the scheme of
-// gdn_expand.hpp with TC_UNR independent positions per lane, so TC_UNR global loads and LDS probes overlap.
+// the lengths; the owner of a packed position comes from start markers dropped into LDS instead of the 6-step
+// binary search of gdn_expand.hpp: the kernel was VALU bound on that search) with TC_UNR independent positions
+// per lane, so TC_UNR global loads and LDS probes overlap.
 __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restrict__ colidx, eoff_t vb, eoff_t ve,
-                                                            const TcSet &set, unsigned *s_scan) {
+                                                            const TcSet &set, unsigned char *s_own) {
   const unsigned lane = gdn_lane();
   unsigned long long count = 0;
   unsigned deg = (unsigned)(ve - vb);
@@ -162,41 +154,47 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
     }
     if (deg >= 64u) deg = 0;
   }
-  {  // short lists, packed
+  {  // shorter lists, packed
     const unsigned incl = gdn_wave_incl_scan(deg);
     const unsigned total = __shfl(incl, 63, 64);
     if (total) {
-      s_scan[lane] = incl - deg;  // exclusive prefix
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned excl = incl - deg;
+      int carry = 0;  // owner of the last packed position handled so far (uniform)
       for (unsigned base = 0; base < total; base += 64 * TC_UNR) {
         unsigned idx[TC_UNR];
-        int lo[TC_UNR], hi[TC_UNR];
+        int own[TC_UNR];
         bool valid[TC_UNR];
+        // owner of a packed position WITHOUT a search: every non-empty list drops its lane id at the position
+        // where it starts (positions are distinct), a position's owner is the nearest marker at or before it
+        const unsigned mypos = excl - base;  // wraps for lists that started before this step
+        const bool starts_here = deg > 0u && mypos < 64u * TC_UNR;
+        if (starts_here) s_own[mypos] = (unsigned char)(lane + 1u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned mark[TC_UNR];
+#pragma unroll
+        for (int r = 0; r < TC_UNR; r++) mark[r] = s_own[64 * r + lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (starts_here) s_own[mypos] = 0;
 #pragma unroll
         for (int r = 0; r < TC_UNR; r++) {
           idx[r] = base + 64u * (unsigned)r + lane;
           valid[r] = idx[r] < total;
-          lo[r] = 0;
-          hi[r] = 63;
-        }
-        // owner = LAST lane whose exclusive prefix is <= idx (empty lists share a prefix with their successor)
-#pragma unroll
-        for (int st = 0; st < 6; st++) {
-#pragma unroll
-          for (int r = 0; r < TC_UNR; r++) {
-            const int mid = (lo[r] + hi[r] + 1) >> 1;
-            if (s_scan[mid] <= idx[r]) lo[r] = mid;
-            else hi[r] = mid - 1;
-          }
+          const unsigned long long starts = __ballot(mark[r] != 0u);
+          const unsigned long long upto = starts & (gdn_lanemask_lt() | (1ull << lane));
+          const int from = 63 - __clzll((long long)upto);  // lane of the nearest marker (garbage when upto == 0)
+          const int fetched = (int)__shfl(mark[r], from & 63, 64) - 1;
+          own[r] = upto ? fetched : carry;
+          carry = __shfl(own[r], 63, 64);
         }
         vid_t w[TC_UNR];
 #pragma unroll
         for (int r = 0; r < TC_UNR; r++) {
-          const int owner = valid[r] ? lo[r] : (int)lane;
+          const int owner = valid[r] ? own[r] : (int)lane;
           const eoff_t ob = __shfl(vb, owner, 64);
-          const unsigned oex = s_scan[owner];
+          const unsigned oex = __shfl(excl, owner, 64);
           w[r] = valid[r] ? colidx[ob + (idx[r] - oex)] : 0;
         }
         count += set.count(w, valid);
@@ -208,72 +206,123 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
   return count;
 }
 
+// One wave: count the triangles closed by the out-neighbours v = colidx[vlo..vhi) of the row [ub,ue) (vlo..vhi is
+// the whole row for a light row, a slice of it for a heavy one).  N+(u) is staged in the wave's LDS hash set TC_CAP
+// ids at a time (one pass for all but a few hub rows; every pass walks all the lists of the slice).
+__device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
+                                                           eoff_t ub, eoff_t ue, eoff_t vlo, eoff_t vhi, vid_t *s_tab,
+                                                           unsigned char *s_own) {
+  const unsigned lane = gdn_lane();
+  const int du = (int)(ue - ub);
+  unsigned long long count = 0;
+  TcSet set;
+  set.table = s_tab;
+  for (int c0 = 0; c0 < du; c0 += TC_CAP) {
+    const int cn = du - c0 < TC_CAP ? du - c0 : TC_CAP;
+    const eoff_t cb = ub + (eoff_t)c0;
+    vid_t x0 = 0;  // the first 64 ids of the pass: loaded once for the hash build and the clean-up
+    if (lane < (unsigned)cn) x0 = colidx[cb + lane];
+    for (int i = lane; i < cn; i += 64) {  // build: integer LDS CAS, linear probing
+      const vid_t x = i < 64 ? x0 : colidx[cb + i];
+      unsigned h = tc_hash(x);
+      while (atomicCAS(&s_tab[h], TC_EMPTY, x) != TC_EMPTY) h = (h + 1) & (TC_HASH - 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (eoff_t i0 = vlo; i0 < vhi; i0 += 64) {
+      const eoff_t i = i0 + lane;
+      eoff_t vb = 0, ve = 0;
+      if (i < vhi) {
+        const vid_t v = i0 == cb ? x0 : colidx[i];
+        vb = rowptr[v];
+        ve = rowptr[v + 1];
+      }
+      count += tc_walk_lists(colidx, vb, ve, set, s_own);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < cn; i += 64) {  // clear only the slots that were used
+      const vid_t x = i < 64 ? x0 : colidx[cb + i];
+      unsigned h = tc_hash(x);
+      while (s_tab[h] != x) h = (h + 1) & (TC_HASH - 1);
+      s_tab[h] = TC_EMPTY;
+    }
+    // (the search above walks past emptied slots: every key is still present until ITS lane
+    // clears it, so all keys are found and the table is empty again afterwards)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  return count;
+}
+
+// Rows with more than TC_LIGHT out-neighbours are cut into work items of TC_SLICE neighbours: the work of a row
+// grows with du * (length of its neighbours' lists), and on a skewed graph a third of all list elements belongs to
+// a few thousand hub rows -- one wave per row left the kernel waiting for them (profiles/r01_tc_pmc.md).
+#define TC_LIGHT 64
+#define TC_SLICE 256
+
 __global__ void __launch_bounds__(GDN_BLOCK)
+tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ items,
+                      unsigned capacity, unsigned *__restrict__ n_items, unsigned *__restrict__ overflow) {
+  const unsigned u = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t du = 0;
+  if (u < (unsigned)m) du = rowptr[u + 1] - rowptr[u];
+  const unsigned n = du > TC_LIGHT ? (unsigned)((du + TC_SLICE - 1) / TC_SLICE) : 0u;
+  // wave-aggregated reservation: one atomic per wave
+  const unsigned incl = gdn_wave_incl_scan(n);
+  const unsigned tot = __shfl(incl, 63, 64);
+  if (tot == 0) return;
+  unsigned base = 0;
+  if (gdn_lane() == 63) base = atomicAdd(n_items, tot);
+  base = __shfl(base, 63, 64) + incl - n;
+  for (unsigned c = 0; c < n; c++) {
+    if (base + c < capacity) items[base + c] = ((unsigned long long)c << 32) | u;
+    else *overflow = 1u;
+  }
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK, TC_WAVES_PER_EU)
 tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
-                unsigned *__restrict__ next_vertex, unsigned long long *__restrict__ total) {
+                const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
+                unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
+                unsigned long long *__restrict__ total) {
   __shared__ vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
-  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
   const unsigned w = threadIdx.x >> 6;
   unsigned long long count = 0;
   for (int i = lane; i < TC_HASH; i += 64) s_tab[w][i] = TC_EMPTY;
+  for (int i = lane; i < 64 * TC_UNR; i += 64) s_own[w][i] = 0;
+  // ---- heavy rows first (they are the long work items): one (row, slice) item per grab
+  const unsigned n_items = *n_items_p;
   for (;;) {
-    // dynamic vertex assignment: 16 consecutive vertices per grab (one atomic per 16 rows)
+    unsigned it = 0;
+    if (lane == 0) it = atomicAdd(&cursors[0], 1u);
+    it = __shfl(it, 0, 64);
+    if (it >= n_items) break;
+    const unsigned long long item = items[it];
+    const unsigned u = (unsigned)(item & 0xFFFFFFFFull), c = (unsigned)(item >> 32);
+    const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
+    const eoff_t vlo = ub + (eoff_t)c * TC_SLICE;
+    const eoff_t vhi = vlo + TC_SLICE < ue ? vlo + TC_SLICE : ue;
+    count += tc_row_slice(rowptr, colidx, ub, ue, vlo, vhi, s_tab[w], s_own[w]);
+  }
+  // ---- light rows: 16 consecutive vertices per grab (one atomic per 16 rows)
+  for (;;) {
     unsigned u0 = 0;
-    if (lane == 0) u0 = atomicAdd(next_vertex, 16u);
+    if (lane == 0) u0 = atomicAdd(&cursors[1], 16u);
     u0 = __shfl(u0, 0, 64);
     if (u0 >= (unsigned)m) break;
     const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
-    // the 17 row offsets of the batch in one load
-    eoff_t rp = 0;
+    eoff_t rp = 0;  // the 17 row offsets of the batch in one load
     if (u0 + lane <= u1) rp = rowptr[u0 + lane];
     for (unsigned u = u0; u < u1; u++) {
       const eoff_t ub = __shfl(rp, (int)(u - u0), 64), ue = __shfl(rp, (int)(u - u0) + 1, 64);
-      const int du = (int)(ue - ub);
-      if (du < 2) continue;  // a single out-neighbour closes no triangle
-      TcSet set;
-      set.du = du;
-      set.nu = colidx + ub;
-      const bool hashed = du <= TC_CAP;
-      set.table = hashed ? s_tab[w] : nullptr;
-      // the first 64 out-neighbours: loaded once, used for the hash build, the list walk and the clean-up
-      vid_t v0 = 0;
-      if (lane < (unsigned)du) v0 = colidx[ub + lane];
-      if (hashed) {  // build the hash set of N+(u): integer LDS CAS, linear probing
-        for (int i = lane; i < du; i += 64) {
-          const vid_t x = i < 64 ? v0 : colidx[ub + i];
-          unsigned h = tc_hash(x);
-          while (atomicCAS(&s_tab[w][h], TC_EMPTY, x) != TC_EMPTY) h = (h + 1) & (TC_HASH - 1);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      for (eoff_t i0 = ub; i0 < ue; i0 += 64) {
-        const eoff_t i = i0 + lane;
-        eoff_t vb = 0, ve = 0;
-        if (i < ue) {
-          const vid_t v = i0 == ub ? v0 : colidx[i];
-          vb = rowptr[v];
-          ve = rowptr[v + 1];
-        }
-        count += tc_walk_lists(colidx, vb, ve, set, s_scan[w]);
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (hashed) {  // clear only the slots that were used
-        for (int i = lane; i < du; i += 64) {
-          const vid_t x = i < 64 ? v0 : colidx[ub + i];
-          unsigned h = tc_hash(x);
-          while (s_tab[w][h] != x) h = (h + 1) & (TC_HASH - 1);
-          s_tab[w][h] = TC_EMPTY;
-        }
-        // (the search above walks past emptied slots: every key is still present until ITS lane
-        // clears it, so all du keys are found and the table is empty again afterwards)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-      }
+      const eoff_t du = ue - ub;
+      if (du < 2 || du > TC_LIGHT) continue;  // a single out-neighbour closes no triangle; heavy rows are done
+      count += tc_row_slice(rowptr, colidx, ub, ue, ub, ue, s_tab[w], s_own[w]);
     }
   }
   count = gdn_block_sum(count, s_red);
@@ -360,20 +409,32 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
     GDN_TRY(tc_orient(g, &own));
     dag = own;
   }
-  DevBuf<unsigned long long> d_total;  // [0] = triangle count, [1] = work-distribution cursor
-  int rc = d_total.alloc(2);
-  if (rc == GDN_OK && hipMemset(d_total.p, 0, 16) != hipSuccess) rc = GDN_ERR_HIP;
+  DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
+  DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
+  const uint64_t cap64 = dag->nnz / TC_LIGHT + 1024;  // a heavy row of du > TC_LIGHT ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT items
+  const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
+  int rc = d_total.alloc(1);
+  if (rc == GDN_OK) rc = d_items.alloc(cap);
+  if (rc == GDN_OK) rc = d_ctl.alloc(4);
+  if (rc == GDN_OK && (hipMemset(d_total.p, 0, 8) != hipSuccess || hipMemset(d_ctl.p, 0, 16) != hipSuccess)) rc = GDN_ERR_HIP;
   st.prep_ms = tprep.stop_ms();
   if (rc == GDN_OK) {
     tsolve.start();  // src/tc/gpu_base.cu:52-58
+    hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks((uint64_t)dag->m)), dim3(GDN_BLOCK), 0, 0, dag->rowptr,
+                       dag->m, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
     unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK * 16);
-    if (nb > 256 * 5) nb = 256 * 5;  // persistent: 5 workgroups per CU pulling vertex batches
-    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m,
-                       (unsigned *)(d_total.p + 1), d_total.p);
+    if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
+    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, d_items.p,
+                       d_ctl.p + 2, d_ctl.p, d_total.p);
     unsigned long long h = 0;
-    if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+    unsigned ctl[4] = {0, 0, 0, 0};
+    if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(ctl, d_ctl.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
       gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));
       rc = GDN_ERR_HIP;
+    } else if (ctl[3]) {
+      gdn_set_error("gdn_tc: heavy-row work list overflow");
+      rc = GDN_ERR_OVERFLOW;
     }
     st.solve_ms = tsolve.stop_ms();
     *total = h;
