@@ -196,12 +196,21 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                      pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
-                     getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0);
+#ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
+                     getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0
+#else
+                     0
+#endif
+  );
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
                      pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
+#ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
                      getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0
+#else
+                     0
+#endif
   );
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
