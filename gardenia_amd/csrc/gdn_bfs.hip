@@ -39,6 +39,7 @@ struct BfsTdVis {
   unsigned cap;
   int32_t next_level;
   unsigned long long scout_local;
+  GdnWlStage stage;  // per-wave LDS strip of discovered vertices (one atomicAdd on next_count per flush)
   __device__ __forceinline__ void begin_big(vid_t) {}
   __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
     bool claim = false;
@@ -56,9 +57,10 @@ struct BfsTdVis {
       depth[dst] = next_level;
       scout_local += rowptr[dst + 1] - rowptr[dst];
     }
-    gdn_wl_push(outq, &cnt->next_count, cap, claim, dst, &cnt->overflow);
+    gdn_wl_push_staged(stage, outq, &cnt->next_count, cap, claim, dst, &cnt->overflow);
   }
   __device__ __forceinline__ void finish() {
+    gdn_wl_flush(stage, outq, &cnt->next_count, cap, &cnt->overflow);
     const unsigned long long s = gdn_wave_sum(scout_local);
     if (gdn_lane() == 0 && s) atomicAdd(&cnt->scout, s);
   }
@@ -68,6 +70,7 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_td_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ inq, unsigned nf, ExpBigList big,
               BfsTdVis vis) {
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
   eoff_t b = 0, e = 0;
   vid_t v = 0;
@@ -77,12 +80,17 @@ bfs_td_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ inq, 
     e = rowptr[v + 1];
   }
   vis.scout_local = 0;
+  vis.stage.strip = s_stage[threadIdx.x >> 6];
+  vis.stage.n = 0;
   gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
   vis.finish();
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_td_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsTdVis vis) {
+  __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  vis.stage.strip = s_stage[threadIdx.x >> 6];
+  vis.stage.n = 0;
   vis.scout_local = 0;
   gdn_expand_big_items(rowptr, big, vis);
   vis.finish();
@@ -130,25 +138,38 @@ bfs_queue_to_bitmap(const vid_t *__restrict__ q, unsigned n, unsigned *__restric
   }
 }
 
+// 8 bitmap words per thread, block scan of the popcounts, ONE atomicAdd per workgroup (a wave-level atomic per 64
+// words made this conversion cost 0.76 ms on RMAT-27: 65 K atomics on one counter at ~12 ns each)
+#define BFS_B2Q_WORDS 8
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_bitmap_to_queue(const unsigned *__restrict__ bits, unsigned nwords, vid_t *__restrict__ q,
                     BfsCounters *cnt, unsigned cap) {
-  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  unsigned word = (w < nwords) ? bits[w] : 0u;
-  const unsigned n = __popc(word);
-  const unsigned incl = gdn_wave_incl_scan(n);
-  const unsigned total = __shfl(incl, 63, 64);
-  if (total == 0) return;
-  unsigned base = 0;
-  if (gdn_lane() == 63) base = atomicAdd(&cnt->next_count, total);
-  base = __shfl(base, 63, 64);
-  unsigned pos = base + incl - n;
-  while (word) {
-    const int b = __ffs((int)word) - 1;
-    word &= word - 1u;
-    if (pos < cap) q[pos] = (vid_t)(w * 32u + (unsigned)b);
-    else cnt->overflow = 1u;
-    pos++;
+  __shared__ unsigned s_scr[GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned s_base;
+  const unsigned w0 = (blockIdx.x * GDN_BLOCK + threadIdx.x) * BFS_B2Q_WORDS;
+  unsigned word[BFS_B2Q_WORDS];
+  unsigned n = 0;
+#pragma unroll
+  for (int j = 0; j < BFS_B2Q_WORDS; j++) {
+    word[j] = (w0 + j < nwords) ? bits[w0 + j] : 0u;
+    n += __popc(word[j]);
+  }
+  unsigned total;
+  const unsigned ex = gdn_block_excl_scan(n, s_scr, &total);
+  if (total == 0) return;  // uniform
+  if (threadIdx.x == 0) s_base = atomicAdd(&cnt->next_count, total);
+  __syncthreads();
+  unsigned pos = s_base + ex;
+#pragma unroll
+  for (int j = 0; j < BFS_B2Q_WORDS; j++) {
+    unsigned wd = word[j];
+    while (wd) {
+      const int b = __ffs((int)wd) - 1;
+      wd &= wd - 1u;
+      if (pos < cap) q[pos] = (vid_t)((w0 + j) * 32u + (unsigned)b);
+      else cnt->overflow = 1u;
+      pos++;
+    }
   }
 }
 
@@ -222,7 +243,7 @@ bfs_pb_expand_kernel(const unsigned *__restrict__ front, int log_chunk, const eo
       const eoff_t gg = g + (eoff_t)r * PB_THREADS;
       if (gg < g1) {
         u[r] = __builtin_nontemporal_load(U8 + gg);
-        d[r] = __builtin_nontemporal_load(G + gg);
+        d[r] = __builtin_nontemporal_load(G + (gg >> 1));  // a lane owns 8 edges = half a G group
       }
     }
 #pragma unroll
@@ -240,7 +261,7 @@ bfs_pb_expand_kernel(const unsigned *__restrict__ front, int log_chunk, const eo
         BFS_BIT(u[r].s6, 6);
         BFS_BIT(u[r].s7, 7);
 #undef BFS_BIT
-        ebits[d[r]] = (unsigned char)byte;
+        ebits[2 * (size_t)d[r] + (size_t)(gg & 1)] = (unsigned char)byte;
       }
     }
   }
@@ -365,7 +386,8 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     // 32768-id chunks / 32768-row bins: bit slices are tiny, so take the largest tiles u16 ids allow
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
-    GDN_TRY(pb_build(gin, m, lg, lg, p.pb, /*alloc_vals=*/false));
+    // tiles padded to 16 edges = 2 bytes of edge bits, one G entry per 16 edges
+    GDN_TRY(pb_build(gin, m, lg, lg, p.pb, /*alloc_vals=*/false, nullptr, nullptr, false, false, /*pad=*/16, /*log_group=*/4));
     const unsigned wpad = (unsigned)((((uint64_t)(p.pb.nchunks > p.pb.nbins ? p.pb.nchunks : p.pb.nbins)) << lg) / 32u);
     if (wpad > p.nwords_pad) p.nwords_pad = wpad;
     GDN_TRY(p.ebits.alloc((p.pb.n_pad >> 3) + 8));
@@ -457,7 +479,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         break;
       }
       GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
-      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
+      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
       GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
@@ -483,7 +505,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         level++;
       } while (awake >= old_awake || awake > m / beta);
       GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
-      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
+      hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
       GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
