@@ -44,6 +44,7 @@ struct SsspVis {
   int32_t thr_hi;
   int32_t pass;
   int32_t du;  // per-lane: distance of this lane's source vertex
+  GdnWlStage near_st, far_st;  // per-wave LDS strips: one atomic on the hot counters per flush, not per wave step
   __device__ __forceinline__ void begin_big(vid_t v) { du = dist[v]; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     const int32_t d_src = __shfl(du, owner, 64);
@@ -64,10 +65,12 @@ struct SsspVis {
         }
       }
     }
-    gdn_wl_push(near_out, &cnt->near_count, cap, push_near, dst, &cnt->overflow);
-    gdn_wl_push(far_out, &cnt->far_count, cap, push_far, dst, &cnt->overflow);
+    gdn_wl_push_staged(near_st, near_out, &cnt->near_count, cap, push_near, dst, &cnt->overflow);
+    gdn_wl_push_staged(far_st, far_out, &cnt->far_count, cap, push_far, dst, &cnt->overflow);
   }
   __device__ __forceinline__ void finish() {
+    gdn_wl_flush(near_st, near_out, &cnt->near_count, cap, &cnt->overflow);
+    gdn_wl_flush(far_st, far_out, &cnt->far_count, cap, &cnt->overflow);
     const unsigned long long s = gdn_wave_sum(near_edges);
     if (gdn_lane() == 0 && s) atomicAdd(&cnt->relaxed, s);
   }
@@ -77,6 +80,10 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ near_in, unsigned n,
                   int32_t thr_lo, ExpBigList big, SsspVis vis) {
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  __shared__ vid_t s_stage[2][GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  vis.near_st.strip = s_stage[0][threadIdx.x >> 6];
+  vis.far_st.strip = s_stage[1][threadIdx.x >> 6];
+  vis.near_st.n = vis.far_st.n = 0;
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
   eoff_t b = 0, e = 0;
   vid_t v = 0;
@@ -97,6 +104,10 @@ sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ n
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_relax_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, SsspVis vis) {
+  __shared__ vid_t s_stage[2][GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  vis.near_st.strip = s_stage[0][threadIdx.x >> 6];
+  vis.far_st.strip = s_stage[1][threadIdx.x >> 6];
+  vis.near_st.n = vis.far_st.n = 0;
   vis.du = 0;
   vis.near_edges = 0;
   gdn_expand_big_items(rowptr, big, vis);
