@@ -162,7 +162,8 @@ def main():
                                "A=.57 B=.19 C=.19, seed 27491095, self loops+duplicates dropped)"
                                % (args.scale, args.edge_factor),
                    "vertices": m, "edges": nnz, "layout": layout_name, "plan_build_s": t_plan,
-                   "partition": "vertex-range x%d, RCCL all-gather of contrib" % world if world > 1 else "single GPU"},
+                   "partition": "vertex-range x%d, RCCL all-gather of contrib pipelined in %d row-range parts behind "
+                                "the pull kernels" % (world, pr.parts) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "mp_tile_kernel<PrOp>" if be.layout == 0 else

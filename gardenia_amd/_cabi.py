@@ -19,6 +19,7 @@ GDN_ERR_HIP = -3
 GDN_ERR_OOM = -4
 GDN_ERR_OVERFLOW = -5
 GDN_LAYOUT_AUTO, GDN_LAYOUT_CSR, GDN_LAYOUT_PB = -1, 0, 1
+GDN_PR_PART_FIRST, GDN_PR_PART_LAST = 1, 2
 
 
 class GdnStats(C.Structure):
@@ -74,6 +75,7 @@ PROTOTYPES = {
     "gdn_pr_plan_free": (C.c_int, [_vp]),
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gdn_pr_pull_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp]),
+    "gdn_pr_pull_rows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp]),
     "gdn_pr_plan_kernel_time": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "gdn_pr_iter_bytes": (_u64, [_vp]),
     "gdn_spmv_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),

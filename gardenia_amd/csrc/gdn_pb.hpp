@@ -70,6 +70,7 @@ struct PbPlan {
   DevBuf<uint32_t> src_bits, dst_bits;   // ceil(m_global/32), ceil(m_local/32) words
   DevBuf<uint32_t> chunk_lo, bin_lo;     // nchunks + 1 / nbins + 1 original ids
   bool timing = false;
+  std::vector<uint32_t> h_bin_lo;  // host copy of bin_lo (compact layouts): first original row of every bin
   std::vector<hipEvent_t> ev;  // triples: start, after A, after B
   size_t ev_used = 0;
   ~PbPlan() {
@@ -473,12 +474,13 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
                      const float *__restrict__ vals, double *__restrict__ partial, unsigned *__restrict__ errflag,
                      const uint32_t *__restrict__ dst_bits, const uint32_t *__restrict__ bin_lo, Op op,
-                     int dbg = 0) {  // dbg: timing-only experiments (bit0 no LDS atomics, bit1 no epilogue)
+                     int dbg = 0,  // dbg: timing-only experiments (bit0 no LDS atomics, bit1 no epilogue)
+                     unsigned bin_begin = 0) {  // bin_order == nullptr: bins bin_begin + blockIdx.x (partial launches)
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned bn = 1u << log_bin;
-  const unsigned b = bin_order[blockIdx.x];
+  const unsigned b = bin_order ? bin_order[blockIdx.x] : bin_begin + blockIdx.x;
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
   __syncthreads();
   const unsigned lane = gdn_lane();

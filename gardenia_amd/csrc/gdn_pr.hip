@@ -128,6 +128,13 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (const char *e = getenv("GDN_PB_PAD")) pad = (unsigned)atoi(e);
     if (const char *e = getenv("GDN_PB_LOG_GROUP")) lg = atoi(e);
     st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, !(ce && ce[0] == '0'), false, pad, lg);
+    if (st == GDN_OK && p->pb.compact) {  // row -> bin lookups of partial launches (gdn_pr_pull_rows_dev)
+      p->pb.h_bin_lo.resize((size_t)p->pb.nbins + 1);
+      if (hipMemcpy(p->pb.h_bin_lo.data(), p->pb.bin_lo.p, p->pb.h_bin_lo.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+        gdn_set_error("gdn_pr_plan_create: bin_lo download failed");
+        st = GDN_ERR_HIP;
+      }
+    }
     if (st == GDN_OK) {
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
@@ -166,10 +173,30 @@ int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contri
   return GDN_OK;
 }
 
-int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
-                    double *d_diff, float damping, void *stream) {
+// first bin whose first row is >= row (bins cover [0, m_local) contiguously, ascending)
+static unsigned pb_first_bin_at(const PbPlan &pb, int64_t row) {
+  if (row <= 0) return 0;
+  if (row >= (int64_t)pb.m_local) return pb.nbins;
+  if (!pb.compact) {
+    const uint64_t b = ((uint64_t)row + (1ull << pb.log_bin) - 1) >> pb.log_bin;
+    return b > pb.nbins ? pb.nbins : (unsigned)b;
+  }
+  unsigned lo = 0, hi = pb.nbins;  // smallest b with h_bin_lo[b] >= row
+  while (lo < hi) {
+    const unsigned mid = (lo + hi) >> 1;
+    if ((int64_t)pb.h_bin_lo[mid] >= row) hi = mid;
+    else lo = mid + 1;
+  }
+  return lo;
+}
+
+int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                         double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
+                         void *stream) {
   GDN_REQUIRE(plan && d_contrib_in && d_scores && d_contrib_out, "null argument");
   GDN_REQUIRE(d_contrib_in != d_contrib_out, "contrib_in and contrib_out must differ (Jacobi)");
+  GDN_REQUIRE(row_begin >= 0 && row_begin <= row_end, "row range");
+  const bool first = (flags & GDN_PR_PART_FIRST) != 0, last = (flags & GDN_PR_PART_LAST) != 0;
   PrOp op;
   op.contrib_in = d_contrib_in;
   op.scores = d_scores;
@@ -179,60 +206,79 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
   op.damping = damping;
   op.vec_ok = ((reinterpret_cast<uintptr_t>(op.scores) | reinterpret_cast<uintptr_t>(op.contrib_out) |
                 reinterpret_cast<uintptr_t>(op.out_degree)) & 15u) == 0;
-  if (plan->layout == GDN_LAYOUT_CSR) return mp_run(plan->mp, op, d_diff, (hipStream_t)stream);
-  // ---- propagation-blocked path: expand (per chunk) then accumulate + fused update (per bin)
+  if (plan->layout == GDN_LAYOUT_CSR) {
+    // the merge-path pass is not cut into parts: the FIRST part runs all rows, later parts are no-ops
+    return first ? mp_run(plan->mp, op, d_diff, (hipStream_t)stream) : GDN_OK;
+  }
+  // ---- propagation-blocked path: expand (per chunk, first part) then accumulate + fused update (per bin)
   PbPlan &pb = plan->pb;
   hipStream_t s = (hipStream_t)stream;
   const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
-  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
-  static unsigned split = 0;
-  if (split == 0) {
-    const char *e = getenv("GDN_PB_SPLIT");
-    split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
-    if (split < 1 || split > 64) split = 1;
-  }
-  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
-                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
-                     pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
+  if (first) {
+    if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
+    static unsigned split = 0;
+    if (split == 0) {
+      const char *e = getenv("GDN_PB_SPLIT");
+      split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
+      if (split < 1 || split > 64) split = 1;
+    }
+    hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
+                       pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
+                       pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
-                     getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0
+                       getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0
 #else
-                     0
+                       0
 #endif
-  );
-  if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
-                     pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
-                     pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
-#ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
-                     getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0
-#else
-                     0
-#endif
-  );
-  if (timed) {
-    GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
-    pb.ev_used += 3;
+    );
+    if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }
-  if (d_diff) {
-    uint32_t n = pb.nbins;
-    const double *in = pb.partial.p;
-    double *bufs[2] = {pb.red_scratch.p, pb.red_scratch.p + (pb.red_scratch.n / 2)};
-    int which = 0;
-    for (;;) {
-      const uint32_t nb = (n + MP_RED_CHUNK - 1) / MP_RED_CHUNK;
-      double *out = (nb == 1) ? d_diff : bufs[which];
-      hipLaunchKernelGGL(mp_reduce_f64, dim3(nb), dim3(GDN_BLOCK), 0, s, in, n, out);
-      if (nb == 1) break;
-      in = out;
-      n = nb;
-      which ^= 1;
+  // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
+  const bool whole = first && last;
+  const unsigned b0 = whole ? 0u : pb_first_bin_at(pb, row_begin);
+  const unsigned b1 = whole ? pb.nbins : (last ? pb.nbins : pb_first_bin_at(pb, row_end));
+  if (b1 > b0)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(b1 - b0), dim3(PB_THREADS), lds_b, s, pb.m_local,
+                       pb.log_bin, pb.bin_ptr.p, whole ? pb.bin_order.p : nullptr, pb.V.p, pb.vals.p, pb.partial.p,
+                       pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
+#ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
+                       getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0,
+#else
+                       0,
+#endif
+                       b0);
+  if (last) {
+    if (timed) {
+      GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
+      pb.ev_used += 3;
+    }
+    if (d_diff) {
+      uint32_t n = pb.nbins;
+      const double *in = pb.partial.p;
+      double *bufs[2] = {pb.red_scratch.p, pb.red_scratch.p + (pb.red_scratch.n / 2)};
+      int which = 0;
+      for (;;) {
+        const uint32_t nb = (n + MP_RED_CHUNK - 1) / MP_RED_CHUNK;
+        double *out = (nb == 1) ? d_diff : bufs[which];
+        hipLaunchKernelGGL(mp_reduce_f64, dim3(nb), dim3(GDN_BLOCK), 0, s, in, n, out);
+        if (nb == 1) break;
+        in = out;
+        n = nb;
+        which ^= 1;
+      }
     }
   }
   GDN_HIP(hipGetLastError());
   return GDN_OK;
+}
+
+int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                    double *d_diff, float damping, void *stream) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  return gdn_pr_pull_rows_dev(plan, d_contrib_in, d_scores, d_contrib_out, d_diff, damping, 0, plan->m_local,
+                              GDN_PR_PART_FIRST | GDN_PR_PART_LAST, stream);
 }
 
 int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launches, double *total_ms,

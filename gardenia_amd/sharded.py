@@ -7,8 +7,14 @@ Per iteration each rank
 
   1. runs the fused pull kernel on its rows: reads the full contrib vector, writes its slice of
      the next contrib vector and its local L1 change          (C-ABI gdn_pr_pull_dev)
-  2. all-gathers the next contrib vector in place               (one RCCL all-gather, m*4 B)
+  2. all-gathers the next contrib vector in place               (RCCL all-gather, m*4 B in all)
   3. all-reduces the 8-byte L1 change                           (convergence test)
+
+Steps 1 and 2 are pipelined: the rank's rows are cut into `parts` row ranges; as soon as the kernel of part j has
+been queued (gdn_pr_pull_rows_dev) its rows are all-gathered asynchronously (RCCL runs on its own stream, ordered
+behind the compute stream at the call), so only the last part's exchange is exposed.  xGMI is point to point: the
+64 MB a rank sends at N = 8 on RMAT-27 take longer than its share of the compute, so an un-overlapped exchange
+would dominate the iteration.
 
 The north star words step 2 as "all-reduce of the rank vector"; the all-gather moves half the
 bytes for the same result (each slice has exactly one writer).  BFS/SSSP stay single-GPU.
@@ -33,8 +39,9 @@ def vertex_range(rank: int, world: int, m: int) -> Tuple[int, int, int]:
 
 class ShardedPageRank:
     def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None,
-                 damping: float = 0.85):
+                 damping: float = 0.85, parts: int = 4):
         self.be = backend
+        self.parts = max(1, int(parts)) if world > 1 and hasattr(backend, "pull_rows") else 1
         self.m = m_global
         self.rank, self.world, self.dist = rank, world, dist
         self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
@@ -60,11 +67,40 @@ class ShardedPageRank:
                     self._inplace = False  # a backend that rejects aliasing: gather from a copy
             self.dist.all_gather_into_tensor(full, mine.clone())
 
+    def part_ranges(self):
+        """Row ranges [r0,r1) (relative to a rank's first row) of the pipeline parts: equal on every rank,
+        multiples of 4 rows (16-byte aligned slices), the last part takes the remainder of the chunk."""
+        seg = -(-self.chunk // self.parts)
+        seg = (seg + 3) & ~3
+        out = []
+        for j in range(self.parts):
+            r0 = min(j * seg, self.chunk)
+            r1 = self.chunk if j == self.parts - 1 else min((j + 1) * seg, self.chunk)
+            if r1 > r0 or j == 0:
+                out.append((r0, r1))
+        return out
+
+    def _gather_rows_async(self, which, r0, r1):
+        """All-gather rows [r0,r1) of every rank's slice (strided in the full vector: a list of views)."""
+        full = self.be.contrib_full(which)
+        outs = [full[r * self.chunk + r0:r * self.chunk + r1] for r in range(self.world)]
+        return self.dist.all_gather(outs, outs[self.rank], async_op=True)
+
     def step(self):
         """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
         nxt = self.cur ^ 1
-        self.be.pull(self.cur, nxt, self.damping)
-        self._gather(nxt)
+        if self.parts <= 1:
+            self.be.pull(self.cur, nxt, self.damping)
+            self._gather(nxt)
+        else:
+            ranges = self.part_ranges()
+            works = []
+            for j, (r0, r1) in enumerate(ranges):
+                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
+                if r1 > r0:
+                    works.append(self._gather_rows_async(nxt, r0, r1))
+            for w in works:
+                w.wait()
         self.cur = nxt
         self.iterations += 1
 
@@ -127,6 +163,16 @@ class HipPageRankBackend:
                                                 C.c_void_p(self.scores.data_ptr()),
                                                 C.c_void_p(self.contribs[cout].data_ptr()),
                                                 C.c_void_p(self.diff.data_ptr()), float(damping), self._stream()))
+
+    def pull_rows(self, cin, cout, damping, r0, r1, first, last):
+        """Rows [r0,r1) of this rank (clipped to its row count) of one iteration: gdn_pr_pull_rows_dev."""
+        flags = (self._cabi.GDN_PR_PART_FIRST if first else 0) | (self._cabi.GDN_PR_PART_LAST if last else 0)
+        r0c, r1c = min(r0, self.m_local), min(r1, self.m_local)
+        self._cabi.check(self.L.gdn_pr_pull_rows_dev(self.plan, C.c_void_p(self.contribs[cin].data_ptr()),
+                                                     C.c_void_p(self.scores.data_ptr()),
+                                                     C.c_void_p(self.contribs[cout].data_ptr()),
+                                                     C.c_void_p(self.diff.data_ptr()), float(damping), r0c, r1c, flags,
+                                                     self._stream()))
 
     def check(self):
         """Raise if the PB fixed-point accumulator saw an out-of-range value (blocking)."""

@@ -205,10 +205,11 @@ class ResidentPageRankShards:
     shards of the same graph, each with its own plan (row_base, m_local < m_global), the all-gather
     emulated by device copies.  Exercises exactly the C-ABI calls a multi-GPU run makes."""
 
-    def __init__(self, g: Graph, world: int, layout: int = _cabi.GDN_LAYOUT_AUTO):
+    def __init__(self, g: Graph, world: int, layout: int = _cabi.GDN_LAYOUT_AUTO, parts: int = 1):
         from .sharded import vertex_range
         L = _cabi.lib()
         self.L, self.m, self.world = L, g.V(), world
+        self.parts = parts  # > 1: every iteration is issued as row-range parts (gdn_pr_pull_rows_dev)
         irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
         self.h = C.c_void_p()
         _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.h)))
@@ -261,8 +262,22 @@ class ResidentPageRankShards:
             err = 0.0
             for r in self.ranks:
                 if r["plan"]:
-                    _cabi.check(L.gdn_pr_pull_dev(r["plan"], r["c"][cur], r["scores"], r["c"][cur ^ 1], r["diff"],
-                                                  float(damping), None))
+                    if self.parts <= 1:
+                        _cabi.check(L.gdn_pr_pull_dev(r["plan"], r["c"][cur], r["scores"], r["c"][cur ^ 1], r["diff"],
+                                                      float(damping), None))
+                    else:  # the same part ranges as sharded.ShardedPageRank.part_ranges()
+                        from .sharded import ShardedPageRank
+
+                        class _B:
+                            pull_rows = None
+                        ranges = ShardedPageRank(_B(), self.m, 0, self.world, None, parts=self.parts).part_ranges()
+                        n = r["hi"] - r["lo"]
+                        for j, (r0, r1) in enumerate(ranges):
+                            flags = (_cabi.GDN_PR_PART_FIRST if j == 0 else 0) | \
+                                    (_cabi.GDN_PR_PART_LAST if j == len(ranges) - 1 else 0)
+                            _cabi.check(L.gdn_pr_pull_rows_dev(r["plan"], r["c"][cur], r["scores"], r["c"][cur ^ 1],
+                                                               r["diff"], float(damping), min(r0, n), min(r1, n), flags,
+                                                               None))
                     d = np.zeros(1, np.float64)
                     _cabi.check(L.gdn_dev_download(_p(d), r["diff"], 8))
                     err += float(d[0])

@@ -179,6 +179,17 @@ int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contri
  * change of the local rows (double, deterministic reduction order). */
 int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
                     double *d_diff, float damping, void *stream);
+/* The same iteration cut into parts by LOCAL row range, so that a multi-GPU driver can send the finished rows of
+ * part j (RCCL all-gather on another stream) while part j+1 is computed.  Parts are issued in ascending row order
+ * on one stream; flags: GDN_PR_PART_FIRST on the first part (it also runs the source-side phase of the whole
+ * iteration), GDN_PR_PART_LAST on the last (it covers every remaining row and reduces the L1 change into d_diff).
+ * After part j has run, scores[v] and contrib_out[row_base+v] are final for every v < row_end of that part (a part
+ * may finish rows beyond its row_end early).  gdn_pr_pull_dev == one part with both flags. */
+#define GDN_PR_PART_FIRST 1
+#define GDN_PR_PART_LAST 2
+int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                         double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
+                         void *stream);
 /* Per-launch HIP-event timing of the iteration's kernels on the launch stream.  reset != 0 arms
  * it for up to max_launches launches; reset == 0 waits for the events and reports summed
  * durations in total_ms[2] (CSR: [0] = merge-path tile kernel; PB: [0] = expand, [1] =

@@ -37,19 +37,27 @@ class NumpyBackend:
             self.contribs[which].numpy()[self.lo:self.hi] = self.scores / self.deg
 
     def pull(self, cin, cout, damping):
+        self.pull_rows(cin, cout, damping, 0, self.hi - self.lo, True, True)
+
+    def pull_rows(self, cin, cout, damping, r0, r1, first, last):
+        """Rows [r0,r1) of this rank only (the contract of gdn_pr_pull_rows_dev: rows below r1 are final
+        afterwards, the L1 change is complete after the last part)."""
+        r0, r1 = min(r0, self.hi - self.lo), min(r1, self.hi - self.lo)
         c = self.contribs[cin].numpy()
         base = np.float32((np.float32(1.0) - np.float32(damping)) / np.float32(self.m))
-        sums = np.zeros(self.hi - self.lo, np.float32)
-        for r in range(self.hi - self.lo):
+        if first:
+            self._acc = 0.0
+        for r in range(r0, r1):
             acc = np.float32(0)
             for e in range(self.rowptr[r], self.rowptr[r + 1]):
                 acc = np.float32(acc + c[self.colidx[e]])
-            sums[r] = acc
-        new = (base + np.float32(damping) * sums).astype(np.float32)
-        self.diff[0] = float(np.abs((new - self.scores).astype(np.float32)).astype(np.float64).sum())
-        self.scores = new
-        with np.errstate(divide="ignore"):
-            self.contribs[cout].numpy()[self.lo:self.hi] = new / self.deg
+            new = np.float32(base + np.float32(damping) * acc)
+            self._acc += float(np.abs(np.float32(new - self.scores[r])))
+            self.scores[r] = new
+            with np.errstate(divide="ignore"):
+                self.contribs[cout].numpy()[self.lo + r] = new / self.deg[r]
+        if last:
+            self.diff[0] = self._acc
 
 
 def main():
@@ -64,7 +72,8 @@ def main():
     gi = graphio.transpose(g)
     lo, hi, chunk = vertex_range(rank, world, m)
     be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world)
-    pr = ShardedPageRank(be, m, rank, world, dist)
+    parts = int(os.environ.get("GDN_TEST_PARTS", "4"))
+    pr = ShardedPageRank(be, m, rank, world, dist, parts=parts)
     it, err = pr.solve()
     np.save(f"{out}.{rank}.npy", be.scores)
     if rank == 0:

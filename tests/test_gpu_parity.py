@@ -136,6 +136,75 @@ def test_pr_sharded_data_path_on_one_device(orc, world, layout):
     assert abs(err - trace[-1]) < 1e-6
 
 
+@pytest.mark.parametrize("world,parts", [(2, 4), (3, 3), (8, 4), (1, 5)])
+def test_pr_row_range_parts_equal_whole_iterations(world, parts):
+    """gdn_pr_pull_rows_dev: an iteration issued as row-range parts (what the multi-GPU pipeline does) gives the
+    same bits as gdn_pr_pull_dev on the propagation-blocked layout (integer accumulation, same bins)."""
+    g = graphio.rmat_graph(16, 16, seed=33)
+    m = g.m - 7
+    src, dst = graphio.csr_to_coo(g)
+    keep = (src < m) & (dst < m)
+    g = graphio.build_csr(m, src[keep], dst[keep])
+    G = solvers.Graph(csr=g, need_reverse=True)
+    res = []
+    for p in (1, parts):
+        sh = solvers.ResidentPageRankShards(G, world, 1, parts=p)
+        res.append(sh.solve())
+        sh.close()
+    assert res[0][1] == res[1][1] and res[0][2] == res[1][2]
+    assert np.array_equal(res[0][0], res[1][0])
+
+
+def test_pr_row_range_part_contract():
+    """After part j every row below its row_end is final in scores and contrib_out (the rows the pipeline sends)."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    g = graphio.rmat_graph(17, 16, seed=34)
+    gi = graphio.transpose(g)
+    m = g.m
+    h, plan = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p),
+                                   C.byref(h)))
+
+    def dev(a):
+        p = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(a.nbytes, C.byref(p)))
+        _cabi.check(L.gdn_dev_upload(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    def host(p, n, dt):
+        a = np.empty(n, dt)
+        _cabi.check(L.gdn_dev_download(a.ctypes.data_as(C.c_void_p), p, a.nbytes))
+        return a
+
+    deg = dev(g.degrees().astype(np.int32))
+    _cabi.check(L.gdn_pr_plan_create(h, deg, m, 0, 1, C.byref(plan)))
+    init = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    zeros = np.zeros(m, np.float32)
+    # reference: one whole iteration
+    sc, c0, c1, diff = dev(init), dev(zeros), dev(zeros), dev(np.zeros(1, np.float64))
+    _cabi.check(L.gdn_pr_contrib_dev(plan, sc, c0, None))
+    _cabi.check(L.gdn_pr_pull_dev(plan, c0, sc, c1, diff, 0.85, None))
+    want_s, want_c, want_d = host(sc, m, np.float32), host(c1, m, np.float32), host(diff, 1, np.float64)[0]
+    # the same iteration in 5 uneven parts
+    sc2, c2 = dev(init), dev(zeros)
+    cuts = [0, 1000, 1004, m // 3, m - 12345, m]
+    for j in range(len(cuts) - 1):
+        flags = (1 if j == 0 else 0) | (2 if j == len(cuts) - 2 else 0)
+        _cabi.check(L.gdn_pr_pull_rows_dev(plan, c0, sc2, c2, diff, 0.85, cuts[j], cuts[j + 1], flags, None))
+        r1 = cuts[j + 1]
+        assert np.array_equal(host(sc2, m, np.float32)[:r1], want_s[:r1]), j
+        got_c = host(c2, m, np.float32)[:r1]
+        assert np.array_equal(got_c, want_c[:r1], equal_nan=True), j
+    assert host(diff, 1, np.float64)[0] == want_d
+    _cabi.check(L.gdn_pr_plan_check(plan))
+    L.gdn_pr_plan_free(plan)
+    L.gdn_graph_free(h)
+    for p in (deg, sc, c0, c1, diff, sc2, c2):
+        L.gdn_dev_free(p)
+
+
 def test_pr_is_bitwise_reproducible(monkeypatch):
     monkeypatch.setenv("GDN_PR_LAYOUT", "csr")  # the merge-path layout is the reproducible one
     g = graphio.rmat_graph(15, 16, seed=9)

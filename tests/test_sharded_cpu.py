@@ -32,15 +32,31 @@ def test_vertex_range_partition():
         assert all(hi - lo <= c for lo, hi, c in ranges) and ranges[0][2] * w >= m
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_pagerank_gloo(orc, tmp_path, world):
+def test_part_ranges_cover_the_chunk_and_agree_across_ranks():
+    from gardenia_amd.sharded import ShardedPageRank
+
+    class B:
+        def pull_rows(self):
+            pass
+    for m, world, parts in [(1000, 2, 4), (1 << 20, 8, 4), (37, 3, 4), (64, 8, 3), (5, 2, 4)]:
+        got = [ShardedPageRank(B(), m, r, world, dist=None, parts=parts).part_ranges() for r in range(world)]
+        assert all(g == got[0] for g in got)
+        chunk = vertex_range(0, world, m)[2]
+        assert got[0][0][0] == 0 and got[0][-1][1] == chunk
+        for (a0, a1), (b0, b1) in zip(got[0], got[0][1:]):
+            assert a1 == b0 and a0 % 4 == 0
+    assert ShardedPageRank(B(), 100, 0, 1, dist=None, parts=4).parts == 1  # a single rank is never cut
+
+
+@pytest.mark.parametrize("world,parts", [(2, 4), (3, 4), (2, 1), (3, 7)])
+def test_sharded_pagerank_gloo(orc, tmp_path, world, parts):
     scale, ef = 8, 8
     out = str(tmp_path / "pr")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"),
                                        str(scale), str(ef), out], env=env))
     for p in procs:
