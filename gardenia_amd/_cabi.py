@@ -79,6 +79,7 @@ PROTOTYPES = {
     "gdn_pr_plan_kernel_time": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "gdn_pr_iter_bytes": (_u64, [_vp]),
     "gdn_spmv_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),
+    "gdn_spmv_plan_create_cols": (C.c_int, [_vp, _vp, _i32, _i32, _pp]),
     "gdn_spmv_plan_check": (C.c_int, [_vp]),
     "gdn_spmv_plan_free": (C.c_int, [_vp]),
     "gdn_spmv_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

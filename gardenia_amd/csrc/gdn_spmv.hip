@@ -14,7 +14,8 @@
 
 struct gdn_spmv_plan {
   int layout = GDN_LAYOUT_CSR;
-  int32_t m = 0;
+  int32_t m = 0;        // rows
+  int32_t n_cols = 0;   // length of x (== m for a whole matrix, the global size for a row shard)
   uint64_t nnz = 0;
   MpPlan mp;            // GDN_LAYOUT_CSR
   PbPlan pb;            // GDN_LAYOUT_PB
@@ -116,9 +117,16 @@ static int spmv_pick_log(int64_t n, int max_log) {
 }
 
 int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax, int32_t layout, gdn_spmv_plan **plan) {
+  GDN_REQUIRE(csr != nullptr, "csr");
+  return gdn_spmv_plan_create_cols(csr, d_Ax, csr->m, layout, plan);
+}
+
+int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n_cols, int32_t layout,
+                              gdn_spmv_plan **plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
   *plan = nullptr;
   GDN_REQUIRE(csr != nullptr, "csr");
+  GDN_REQUIRE(n_cols >= 1, "n_cols");
   GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_AUTO, "layout");
   if (layout == GDN_LAYOUT_AUTO) {
     const char *env = getenv("GDN_SPMV_LAYOUT");
@@ -130,12 +138,13 @@ int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax, int32_t layout
   gdn_spmv_plan *p = new gdn_spmv_plan();
   p->layout = layout;
   p->m = csr->m;
+  p->n_cols = n_cols;
   p->nnz = csr->nnz;
   int st;
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, csr, 0);
   } else {
-    st = pb_build(csr, csr->m, spmv_pick_log(csr->m, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
+    st = pb_build(csr, n_cols, spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
                   true, d_Ax, &p->Axp, false, false, /*pad=*/32, /*log_group=*/5);
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
@@ -188,7 +197,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   // ---- propagation-blocked path (Ax lives in the plan in tile order; d_Ax is not read)
   PbPlan &pb = plan->pb;
   GDN_HIP(hipMemsetAsync(plan->mx.p + 1, 0, sizeof(unsigned), s));
-  hipLaunchKernelGGL(spmv_absmax_kernel, dim3(1024), dim3(GDN_BLOCK), 0, s, d_x, (size_t)plan->m, plan->mx.p + 1);
+  hipLaunchKernelGGL(spmv_absmax_kernel, dim3(1024), dim3(GDN_BLOCK), 0, s, d_x, (size_t)plan->n_cols, plan->mx.p + 1);
   hipLaunchKernelGGL(spmv_scale_kernel, dim3(1), dim3(64), 0, s, plan->mx.p, plan->scale.p);
   op.scale = plan->scale.p;
   const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;

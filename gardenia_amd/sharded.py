@@ -193,3 +193,56 @@ class HipPageRankBackend:
         if self.plan:
             self.L.gdn_pr_plan_free(self.plan)
             self.plan = C.c_void_p()
+
+
+class ShardedSpMV:
+    """y = y + A x with the rows of A split into vertex ranges like ShardedPageRank: every rank holds
+    rows [lo,hi) with global column ids and its slice of x; one all-gather of x (m*4 B) precedes the local multiply,
+    y stays distributed.  Iterated use (power method) repeats exactly this exchange per multiply."""
+
+    def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None):
+        self.be, self.m, self.rank, self.world, self.dist = backend, m_global, rank, world, dist
+        self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
+
+    def gather_x(self):
+        if self.world > 1:
+            full = self.be.x_full()
+            mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
+            try:
+                self.dist.all_gather_into_tensor(full, mine)
+            except (RuntimeError, ValueError):
+                self.dist.all_gather_into_tensor(full, mine.clone())
+
+    def multiply(self):
+        self.gather_x()
+        self.be.multiply()
+
+
+class HipSpMVBackend:
+    """Local row shard on one MI355X: plan over rows [lo,hi) x all columns (gdn_spmv_plan_create_cols)."""
+
+    def __init__(self, torch, shard_handle, Ax_local, m_global: int, lo: int, hi: int, chunk: int, world: int, device,
+                 layout: int = -1):
+        from . import _cabi
+        self.torch, self._cabi, self.L = torch, _cabi, _cabi.lib()
+        self.m_local = hi - lo
+        self.Ax = Ax_local  # float32 device tensor, nnz of the shard, CSR order
+        self.x = torch.zeros(chunk * world, dtype=torch.float32, device=device)
+        self.y = torch.zeros(max(self.m_local, 1), dtype=torch.float32, device=device)
+        self.plan = C.c_void_p()
+        _cabi.check(self.L.gdn_spmv_plan_create_cols(shard_handle, C.c_void_p(Ax_local.data_ptr()), m_global, layout,
+                                                      C.byref(self.plan)))
+
+    def x_full(self):
+        return self.x
+
+    def multiply(self):
+        s = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+        self._cabi.check(self.L.gdn_spmv_dev(self.plan, C.c_void_p(self.Ax.data_ptr()), C.c_void_p(self.x.data_ptr()),
+                                             C.c_void_p(self.y.data_ptr()), s))
+
+    def close(self):
+        if self.plan:
+            self._cabi.check(self.L.gdn_spmv_plan_check(self.plan))
+            self.L.gdn_spmv_plan_free(self.plan)
+            self.plan = C.c_void_p()

@@ -207,6 +207,10 @@ typedef struct gdn_spmv_plan gdn_spmv_plan;
  * power-of-two scale is derived per call from max|Ax|*max|x|*max row length on the device. */
 int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax /*nullable for CSR*/, int32_t layout,
                          gdn_spmv_plan **plan);
+/* the same for a ROW SHARD of a larger matrix: csr holds rows [lo,hi) with global column ids, x has n_cols entries
+ * (the vertex-range shard one GPU multiplies in the multi-GPU path; y has csr->m entries) */
+int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax /*nullable for CSR*/, int32_t n_cols,
+                              int32_t layout, gdn_spmv_plan **plan);
 int gdn_spmv_plan_check(gdn_spmv_plan *plan);
 int gdn_spmv_plan_free(gdn_spmv_plan *plan);
 /* y[v] += SUM Ax[k]*x[Aj[k]]   (src/spmv/base.cu:13, warp.cu:26, vector.cu:27 superseded) */

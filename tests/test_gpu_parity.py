@@ -458,3 +458,57 @@ def test_device_rmat_matches_numpy_generator():
         assert np.array_equal(rp, want_in.rowptr) and np.array_equal(ci, want_in.colidx)
         for h in (go, gi, gt):
             L.gdn_graph_free(h)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("layout", [0, 1])
+def test_spmv_row_shards_on_one_device(orc, world, layout):
+    """gdn_spmv_plan_create_cols: the plan of a vertex-range row shard (global column ids, x of the global
+    length) -- the local multiply of gardenia_amd.sharded.ShardedSpMV -- against the oracle's whole product."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    from gardenia_amd.sharded import vertex_range
+    L = _cabi.lib()
+    g = graphio.rmat_graph(15, 16, seed=41)
+    m = g.m - 3
+    src, dst = graphio.csr_to_coo(g)
+    keep = (src < m) & (dst < m)
+    g = graphio.build_csr(m, src[keep], dst[keep])
+    rng = np.random.default_rng(8)
+    Ax = (rng.random(g.nnz) - 0.5).astype(np.float32)
+    x = (rng.random(m) - 0.5).astype(np.float32)
+    y0 = rng.random(m).astype(np.float32)
+    want = orc.spmv(g, Ax, x, y0)
+
+    def dev(a):
+        p = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(max(a.nbytes, 4), C.byref(p)))
+        if a.nbytes:
+            _cabi.check(L.gdn_dev_upload(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    h = C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, g.nnz, g.rowptr.ctypes.data_as(C.c_void_p), g.colidx.ctypes.data_as(C.c_void_p),
+                                   C.byref(h)))
+    d_x = dev(x)
+    got = np.empty(m, np.float32)
+    for r in range(world):
+        lo, hi, _ = vertex_range(r, world, m)
+        sh, plan = C.c_void_p(), C.c_void_p()
+        _cabi.check(L.gdn_graph_slice_rows(h, lo, hi, C.byref(sh)))
+        e0, e1 = int(g.rowptr[lo]), int(g.rowptr[hi])
+        d_Ax, d_y = dev(np.ascontiguousarray(Ax[e0:e1])), dev(np.ascontiguousarray(y0[lo:hi]))
+        _cabi.check(L.gdn_spmv_plan_create_cols(sh, d_Ax, m, layout, C.byref(plan)))
+        _cabi.check(L.gdn_spmv_dev(plan, d_Ax, d_x, d_y, None))
+        _cabi.check(L.gdn_spmv_plan_check(plan))
+        part = np.empty(hi - lo, np.float32)
+        _cabi.check(L.gdn_dev_download(part.ctypes.data_as(C.c_void_p), d_y, part.nbytes))
+        got[lo:hi] = part
+        L.gdn_spmv_plan_free(plan)
+        L.gdn_graph_free(sh)
+        L.gdn_dev_free(d_Ax)
+        L.gdn_dev_free(d_y)
+    L.gdn_dev_free(d_x)
+    L.gdn_graph_free(h)
+    assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)  # src/spmv/verifier.cc:24
+    np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=1e-6)

@@ -75,3 +75,25 @@ def test_sharded_pagerank_gloo(orc, tmp_path, world, parts):
     assert got.shape == want.shape
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
     assert abs(meta[1] - trace[-1]) < 1e-9
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_spmv_gloo(orc, tmp_path, world):
+    """ShardedSpMV: all-gather of x, local multiply of the row range, y distributed."""
+    out = str(tmp_path / "spmv")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_spmv_worker.py"), out], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    g = graphio.rmat_graph(8, 8, seed=78)
+    rng = np.random.default_rng(5)
+    Ax = rng.random(g.nnz).astype(np.float32)
+    x = rng.random(g.m).astype(np.float32)
+    y0 = rng.random(g.m).astype(np.float32)
+    want = orc.spmv(g, Ax, x, y0)
+    got = np.concatenate([np.load(f"{out}.{r}.npy") for r in range(world)])
+    np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
