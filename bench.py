@@ -107,6 +107,13 @@ def main():
                    1: "propagation-blocked tiles (source chunk of %d ids x destination bin of %d rows, u16 local "
                       "ids, LDS-resident slices, 2^-62 fixed-point LDS accumulation)"
                       % (1 << (be.log_blk // 100), 1 << (be.log_blk % 100))}[be.layout]
+    if be.layout == 1:
+        nh, he = C.c_int32(0), C.c_uint64(0)
+        _cabi.check(L.gdn_pr_plan_hubs(be.plan, C.byref(nh), C.byref(he)))
+        if nh.value:
+            layout_name += "; hub tier: the %d sources with the most out-edges (%.1f %% of this rank's edges) are read by " \
+                           "the accumulate phase as (u16 hub, u16 row) pairs, their values from a per-iteration table" \
+                           % (nh.value, 100.0 * he.value / max(snnz.value, 1))
     pr = ShardedPageRank(be, m, rank, world, dist if world > 1 else None)
     pr.init_contrib()
 

@@ -241,6 +241,15 @@ struct PbKeyVis {
   int bin_bits;
   int transposed;  // the CSR's rows are the SOURCES (out-CSR): swap the roles
   int32_t v;
+  // source classes (PageRank hub tier): only edges whose source has class `want` belong to this layout, the
+  // others get the sentinel key (sorts behind every real key).  src_major: tile order (source, row) instead of
+  // (row, source).  nvalid: per-lane count of the edges that got a real key.
+  const uint8_t *__restrict__ cls = nullptr;
+  int want = 0;
+  int src_major = 0;
+  unsigned long long sentinel = 0;
+  unsigned long long nvalid = 0;
+  unsigned long long *nvalid_out = nullptr;
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     unsigned row = (unsigned)__shfl(v, owner, 64);
@@ -251,12 +260,23 @@ struct PbKeyVis {
         row = col;
         col = t;
       }
+      if (cls && (int)cls[col] != want) {
+        keys[k] = sentinel;
+        return;
+      }
+      nvalid++;
       if (cs) col = (unsigned)cs[col];
       if (cd) row = (unsigned)cd[row];
       const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
       const unsigned long long vl = row & ((1u << log_bin) - 1u), ul = col & ((1u << log_chunk) - 1u);
-      keys[k] = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | (vl << log_chunk) | ul;
+      const unsigned long long in_tile = src_major ? ((ul << log_bin) | vl) : ((vl << log_chunk) | ul);
+      keys[k] = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | in_tile;
     }
+  }
+  __device__ __forceinline__ void finish() {
+    if (!nvalid_out) return;
+    const unsigned long long s = gdn_wave_sum(nvalid);
+    if (gdn_lane() == 0 && s) atomicAdd(nvalid_out, s);
   }
 };
 
@@ -271,21 +291,28 @@ pb_keys_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, PbK
     e = rowptr[v + 1];
   }
   gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+  vis.finish();
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_keys_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PbKeyVis vis) {
   vis.v = 0;
   gdn_expand_big_items(rowptr, big, vis);
+  vis.finish();
 }
 
 // ---- vertex compaction helpers
 struct PbMarkVis {
   const vid_t *__restrict__ colidx;
   uint32_t *__restrict__ mark;
+  const uint8_t *__restrict__ cls = nullptr;  // source classes: only sources of class `want` are marked
+  int want = 0;
   __device__ __forceinline__ void begin_big(vid_t) {}
   __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
-    if (valid) mark[colidx[k]] = 1u;  // benign race: everybody stores 1
+    if (valid) {
+      const vid_t c = colidx[k];
+      if (!cls || (int)cls[c] == want) mark[c] = 1u;  // benign race: everybody stores 1
+    }
   }
 };
 
@@ -405,7 +432,8 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
                   uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
-                  const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv, int transposed) {
+                  const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv, int transposed,
+                  int src_major) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -415,8 +443,8 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     const unsigned long long b = cb & bmask, c = cb >> bin_bits;
     const unsigned long long t = c * nbins + b;
     const unsigned long long off = i - tsu[t];
-    const unsigned ul = (unsigned)k & ((1u << log_chunk) - 1u);
-    const unsigned vl = (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
+    const unsigned ul = src_major ? (unsigned)(k >> log_bin) & ((1u << log_chunk) - 1u) : (unsigned)k & ((1u << log_chunk) - 1u);
+    const unsigned vl = src_major ? (unsigned)k & ((1u << log_bin) - 1u) : (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
     U[pu[t] + off] = (uint16_t)ul;
     V[pv[b * nchunks + c] + off] = randv ? (uint16_t)((i * 2654435761ull >> 7) & ((1u << log_bin) - 1u)) : (uint16_t)vl;
     if (ev_in) {  // value of this edge: find the column in its (ascending) CSR row
@@ -452,8 +480,9 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, c
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
-             int log_group) {
+             int log_group, const uint8_t *src_class, int want_class, bool src_major) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
+  GDN_REQUIRE(!(src_class && (rows_are_sources || edge_vals_in)), "source classes: in-CSR without edge values only");
   GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
               "pad / log_group");
   p.log_group = log_group;
@@ -463,6 +492,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   GDN_REQUIRE(!(compact && rows_are_sources), "compaction is not supported on an out-CSR");
   const int32_t m = g->m;
   const unsigned long long n = g->nnz;
+  unsigned long long n_use = n;  // edges that belong to this layout (< n with a source-class filter)
   // normal: rows = destinations (m), columns = sources (m_global).  out-CSR: rows = sources (m),
   // columns = destinations (m_global)
   p.m_local = rows_are_sources ? m_global : m;
@@ -495,6 +525,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     PbMarkVis mv;
     mv.colidx = g->colidx;
     mv.mark = sflag.p;
+    mv.cls = src_class;
+    mv.want = want_class;
     hipLaunchKernelGGL(pb_mark_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, mv, dflag.p);
     hipLaunchKernelGGL(pb_mark_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, mv);
     GDN_HIP(hipGetLastError());
@@ -558,7 +590,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   GDN_TRY(p.errflag.alloc(1));
   GDN_HIP(hipMemset(p.errflag.p, 0, sizeof(unsigned)));
   {
-    DevBuf<unsigned long long> ka, kb, bigitems;
+    DevBuf<unsigned long long> ka, kb, bigitems, nvalid;
     DevBuf<unsigned> cnt;
     const uint64_t bigcap64 = n / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
@@ -566,12 +598,15 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_TRY(kb.alloc(n));
     GDN_TRY(bigitems.alloc(bigcap));
     GDN_TRY(cnt.alloc(2));
+    GDN_TRY(nvalid.alloc(1));
     GDN_HIP(hipMemset(cnt.p, 0, 8));
+    GDN_HIP(hipMemset(nvalid.p, 0, 8));
     ExpBigList big;
     big.items = bigitems.p;
     big.capacity = bigcap;
     big.count = cnt.p;
     big.overflow = cnt.p + 1;
+    const unsigned key_bits = (unsigned)(chunk_bits + bin_bits + log_chunk + log_bin);
     PbKeyVis vis;
     vis.colidx = g->colidx;
     vis.keys = ka.p;
@@ -582,6 +617,11 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     vis.bin_bits = bin_bits;
     vis.transposed = rows_are_sources ? 1 : 0;
     vis.v = 0;
+    vis.cls = src_class;
+    vis.want = want_class;
+    vis.src_major = src_major ? 1 : 0;
+    vis.sentinel = 1ull << key_bits;
+    vis.nvalid_out = src_class ? nvalid.p : nullptr;
     hipLaunchKernelGGL(pb_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
     hipLaunchKernelGGL(pb_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
     GDN_HIP(hipGetLastError());
@@ -594,13 +634,17 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     bigitems.release();
     cs.release();
     cd.release();
+    if (src_class) {  // the edges of the other class carry the sentinel key: they sort behind the n_use real keys
+      GDN_HIP(hipMemcpy(&n_use, nvalid.p, 8, hipMemcpyDeviceToHost));
+      p.nnz = n_use;
+    }
     const unsigned long long *sorted = nullptr;
-    GDN_TRY(sort_keys(ka, kb, n, (unsigned)(chunk_bits + bin_bits + log_chunk + log_bin), &sorted));
-    if (n == 0) {
+    GDN_TRY(sort_keys(ka, kb, n, key_bits + (src_class ? 1u : 0u), &sorted));
+    if (n_use == 0) {
       hipLaunchKernelGGL(pb_fill_u64_kernel, dim3(gdn_nblocks(ntiles + 1)), dim3(GDN_BLOCK), 0, 0, tsu.p, ntiles + 1,
                          (eoff_t)0);
     } else {
-      hipLaunchKernelGGL(pb_bounds_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk + log_bin, bin_bits,
+      hipLaunchKernelGGL(pb_bounds_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n_use, log_chunk + log_bin, bin_bits,
                          p.nbins, ntiles, tsu.p);
     }
     // tile runs are padded to 16 edges = whole 64-byte lines of vals, so phase A never leaves a
@@ -627,7 +671,9 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
         while (a < 16384 && a * 32 <= total / (parts ? parts : 1)) a <<= 1;  // keep the gaps below ~3 % of a slice
         return a;
       };
-      const eoff_t al_c = pick_align(cs[p.nchunks], p.nchunks), al_b = pick_align(bs[p.nbins], p.nbins);
+      // src_major layouts (one chunk, read by phase B only) keep U and V at the SAME positions: no extra gaps
+      const eoff_t al_c = src_major ? (eoff_t)pad : pick_align(cs[p.nchunks], p.nchunks);
+      const eoff_t al_b = src_major ? (eoff_t)pad : pick_align(bs[p.nbins], p.nbins);
       std::vector<eoff_t> ca((size_t)p.nchunks + 1, 0), ba((size_t)p.nbins + 1, 0);
       for (unsigned c = 0; c < p.nchunks; c++) {
         du[c] = ca[c] - cs[c];
@@ -669,8 +715,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       GDN_HIP(hipMemsetAsync(edge_vals_out->p, 0, (n_pad + grp) * sizeof(float), 0));
       ev_out = edge_vals_out->p;
     }
-    if (n)
-      hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n, log_chunk, log_bin, bin_bits,
+    if (n_use)
+      hipLaunchKernelGGL(pb_scatter_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n_use, log_chunk, log_bin, bin_bits,
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
                          ev_out ? edge_vals_in : nullptr, ev_out,
 #ifdef GDN_EXPERIMENTS
@@ -678,7 +724,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
 #else
                          0,
 #endif
-                         rows_are_sources ? 1 : 0);
+                         rows_are_sources ? 1 : 0, src_major ? 1 : 0);
     int identity_g = 0;
 #ifdef GDN_EXPERIMENTS  // GDN_PB_IDENTITY=1: TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     identity_g = getenv("GDN_PB_IDENTITY") ? 1 : 0;

@@ -85,7 +85,10 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              const float *edge_vals_in = nullptr, DevBuf<float> *edge_vals_out = nullptr, bool compact = false,
              bool rows_are_sources = false,  // true: `in_csr` is an OUT-CSR (row = source, col = destination)
              unsigned pad = 16,              // every tile is padded to a multiple of `pad` edges (power of two <= 128)
-             int log_group = 3);             // 2^log_group <= pad edges share one entry of G
+             int log_group = 3,              // 2^log_group <= pad edges share one entry of G
+             const uint8_t *src_class = nullptr,  // per global source id: only edges whose source has class
+             int want_class = 0,                  //   `want_class` are laid out (PageRank hub tier, gdn_pr.hip)
+             bool src_major = false);             // order inside a tile: (source, row) instead of (row, source)
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
@@ -475,7 +478,11 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const float *__restrict__ vals, double *__restrict__ partial, unsigned *__restrict__ errflag,
                      const uint32_t *__restrict__ dst_bits, const uint32_t *__restrict__ bin_lo, Op op,
                      int dbg = 0,  // dbg: timing-only experiments (bit0 no LDS atomics, bit1 no epilogue)
-                     unsigned bin_begin = 0) {  // bin_order == nullptr: bins bin_begin + blockIdx.x (partial launches)
+                     unsigned bin_begin = 0,  // bin_order == nullptr: bins bin_begin + blockIdx.x (partial launches)
+                     // hub tier (nullable): per bin a second stream of (hub index, row) pairs, sorted by hub, whose
+                     // values are read from the small per-iteration table hub_val instead of travelling through vals
+                     const eoff_t *__restrict__ hub_ptr = nullptr, const uint16_t *__restrict__ hub_U = nullptr,
+                     const uint16_t *__restrict__ hub_V = nullptr, const float *__restrict__ hub_val = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
@@ -554,6 +561,45 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     for (int r = 0; r < UNR; r++) {
       xs[r] = nx[r];
       vs[r] = nv[r];
+    }
+  }
+  if (hub_ptr) {
+    // edges of hub sources: 4 B per edge (u16 hub index + u16 row), the value of a quad's hubs comes from a table
+    // that stays in L2 (one 4-byte gather per distinct hub of the quad: the stream is sorted by hub)
+    const eoff_t h0 = hub_ptr[b] >> 2, h1 = hub_ptr[b + 1] >> 2;
+    const pb_u16x4 *HU = reinterpret_cast<const pb_u16x4 *>(hub_U);
+    const pb_u16x4 *HV = reinterpret_cast<const pb_u16x4 *>(hub_V);
+    constexpr int HUNR = 4;
+    for (eoff_t q = h0 + threadIdx.x; q < h1; q += (eoff_t)HUNR * PB_THREADS) {
+      pb_u16x4 hu[HUNR], hv[HUNR];
+      float f0[HUNR];
+#pragma unroll
+      for (int r = 0; r < HUNR; r++) {
+        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
+        if (qq < h1) {
+          hu[r] = __builtin_nontemporal_load(HU + qq);
+          hv[r] = __builtin_nontemporal_load(HV + qq);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < HUNR; r++) {
+        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
+        if (qq < h1) f0[r] = hub_val[hu[r].x];
+      }
+#pragma unroll
+      for (int r = 0; r < HUNR; r++) {
+        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
+        if (qq < h1) {
+          unsigned long long a = op.to_fixed(f0[r], bad);
+          atomicAdd(&s_acc[hv[r].x], a);
+          if (hu[r].y != hu[r].x) a = op.to_fixed(hub_val[hu[r].y], bad);
+          atomicAdd(&s_acc[hv[r].y], a);
+          if (hu[r].z != hu[r].y) a = op.to_fixed(hub_val[hu[r].z], bad);
+          atomicAdd(&s_acc[hv[r].z], a);
+          if (hu[r].w != hu[r].z) a = op.to_fixed(hub_val[hu[r].w], bad);
+          atomicAdd(&s_acc[hv[r].w], a);
+        }
+      }
     }
   }
   __syncthreads();

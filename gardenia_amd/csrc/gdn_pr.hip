@@ -9,6 +9,9 @@
 // new = base + d*sum (no FMA contraction), error accumulated in double (omp_base.cc:22).
 #include <string.h>
 
+#include <algorithm>
+#include <vector>
+
 #include <stdlib.h>
 
 #include "gdn_mergepath.hpp"
@@ -18,6 +21,13 @@ struct gdn_pr_plan {
   int layout = GDN_LAYOUT_CSR;
   MpPlan mp;  // GDN_LAYOUT_CSR
   PbPlan pb;  // GDN_LAYOUT_PB
+  // hub tier of the PB layout: the edges of the n_hubs sources with the most out-edges live in a second layout
+  // (one source chunk, tiles sorted by hub) that phase B reads directly -- they never pass through vals
+  bool has_hub = false;
+  PbPlan hub;
+  unsigned n_hubs = 0;
+  DevBuf<uint32_t> hub_ids;  // original id of hub k (ascending)
+  DevBuf<float> hub_val;     // PB_HUB_SLOTS values per iteration: contrib of hub k, slot 32768 = 0 for pad edges
   int32_t m_local = 0;
   uint64_t nnz = 0;
   const int32_t *out_degree = nullptr;  // device, m_local
@@ -76,6 +86,136 @@ struct PrOp {
   }
 };
 
+#define PB_HUB_LOG 15
+#define PB_HUB_SLOTS ((1 << PB_HUB_LOG) + 1)
+
+// hub_val[k] = contrib[hub_ids[k]]; the slots behind the hubs (incl. the pad slot 32768) stay 0
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_hub_gather_kernel(const float *__restrict__ contrib, const uint32_t *__restrict__ hub_ids, unsigned n_hubs,
+                     float *__restrict__ hub_val) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < PB_HUB_SLOTS) hub_val[k] = k < n_hubs ? contrib[hub_ids[k]] : 0.0f;
+}
+
+// ---- hub selection: out-edge counts of the sources from a 1/16 sample of the rows (any classification is
+// correct, it only decides which edges take the cheap path), a log2 histogram of them, then the class flags
+#define PB_HUB_SAMPLE_LOG 4
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_hub_sample_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
+                     uint32_t *__restrict__ cnt) {
+  // one wave per sampled row
+  const unsigned wid = (blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  const uint64_t row = (uint64_t)wid << PB_HUB_SAMPLE_LOG;
+  if (row >= (uint64_t)m) return;
+  const eoff_t b = rowptr[row], e = rowptr[row + 1];
+  for (eoff_t k = b + gdn_lane(); k < e; k += 64) atomicAdd(&cnt[colidx[k]], 1u);
+}
+
+// histogram buckets: 4 per octave; bucket(c) = 4*floor(log2 c) + the two bits below the leading one
+#define PB_HUB_BUCKETS 128
+__host__ __device__ static inline unsigned pr_hub_bucket(unsigned c) {
+  unsigned l = 0;
+  while ((c >> l) > 1u) l++;
+  return 4u * l + (l >= 2 ? ((c >> (l - 2)) & 3u) : 0u);
+}
+static inline unsigned pr_hub_bucket_floor(unsigned b) {  // smallest count that falls into bucket b (l >= 2)
+  const unsigned l = b >> 2, f = b & 3u;
+  return l >= 2 ? (4u + f) << (l - 2) : (1u << l);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_hub_hist_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restrict__ hist /*PB_HUB_BUCKETS*/) {
+  __shared__ unsigned s_h[PB_HUB_BUCKETS];
+  if (threadIdx.x < PB_HUB_BUCKETS) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const unsigned c = cnt[i];
+    if (c) atomicAdd(&s_h[pr_hub_bucket(c)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_hub_class_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned thr, uint8_t *__restrict__ cls,
+                    uint32_t *__restrict__ ids, unsigned cap, unsigned *__restrict__ n_ids) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const bool hub = cnt[i] >= thr;
+  cls[i] = hub ? 1 : 0;
+  if (hub) {
+    const unsigned pos = atomicAdd(n_ids, 1u);
+    if (pos < cap) ids[pos] = (uint32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const bool act = v < (unsigned)m && rowptr[v + 1] > rowptr[v];
+  const unsigned long long mask = __ballot(act);
+  if (gdn_lane() == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
+}
+
+// picks the hub sources of `in_csr` (at most 2^15, each with >= PB_HUB_MIN_PER_BIN expected edges per bin);
+// cls gets one byte per source id, hub_ids the ascending ids.  n_hubs == 0: no hub tier.
+#define PB_HUB_MIN_PER_BIN 2
+static int pr_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                        unsigned *n_hubs) {
+  *n_hubs = 0;
+  DevBuf<uint32_t> cnt;
+  DevBuf<unsigned> hist;
+  DevBuf<unsigned long long> nrows;
+  GDN_TRY(cnt.alloc((size_t)m_global));
+  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1));
+  GDN_TRY(nrows.alloc(1));
+  GDN_HIP(hipMemset(cnt.p, 0, (size_t)m_global * 4));
+  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1) * 4));
+  GDN_HIP(hipMemset(nrows.p, 0, 8));
+  const uint64_t sampled = ((uint64_t)g->m + (1u << PB_HUB_SAMPLE_LOG) - 1) >> PB_HUB_SAMPLE_LOG;
+  hipLaunchKernelGGL(pr_hub_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx,
+                     g->m, cnt.p);
+  hipLaunchKernelGGL(pr_hub_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, cnt.p, (size_t)m_global, hist.p);
+  hipLaunchKernelGGL(pr_count_rows_kernel, dim3(gdn_nblocks((uint64_t)g->m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->m,
+                     nrows.p);
+  GDN_HIP(hipGetLastError());
+  unsigned h[PB_HUB_BUCKETS];
+  unsigned long long active_rows = 0;
+  GDN_HIP(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&active_rows, nrows.p, 8, hipMemcpyDeviceToHost));
+  const uint64_t nbins = ((active_rows + (1ull << log_bin) - 1) >> log_bin) + 1;
+  // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
+  uint64_t per_bin = PB_HUB_MIN_PER_BIN;
+  if (const char *e = getenv("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
+  uint64_t want = (nbins * per_bin) >> PB_HUB_SAMPLE_LOG;
+  if (want < 4) want = 4;
+  if (want > 0x40000000ull) return GDN_OK;
+  unsigned bk = pr_hub_bucket((unsigned)want);
+  if (pr_hub_bucket_floor(bk) < want) bk++;
+  for (;; bk++) {  // threshold = floor of bucket bk; raise it until at most 2^15 sources qualify
+    if (bk >= PB_HUB_BUCKETS) return GDN_OK;
+    uint64_t above = 0;
+    for (unsigned j = bk; j < PB_HUB_BUCKETS; j++) above += h[j];
+    if (above == 0) return GDN_OK;
+    if (above <= (1u << PB_HUB_LOG)) break;
+  }
+  const unsigned thr = pr_hub_bucket_floor(bk);
+  GDN_TRY(cls.alloc((size_t)m_global));
+  GDN_TRY(hub_ids.alloc(1u << PB_HUB_LOG));
+  hipLaunchKernelGGL(pr_hub_class_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, cnt.p,
+                     (size_t)m_global, thr, cls.p, hub_ids.p, 1u << PB_HUB_LOG, hist.p + PB_HUB_BUCKETS);
+  GDN_HIP(hipGetLastError());
+  unsigned n = 0;
+  GDN_HIP(hipMemcpy(&n, hist.p + PB_HUB_BUCKETS, 4, hipMemcpyDeviceToHost));
+  if (n == 0 || n > (1u << PB_HUB_LOG)) return GDN_OK;  // (cannot exceed: the histogram counted them)
+  std::vector<uint32_t> ids(n);
+  GDN_HIP(hipMemcpy(ids.data(), hub_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::sort(ids.begin(), ids.end());  // hub k = k-th marked source in id order = its compact index in the hub layout
+  GDN_HIP(hipMemcpy(hub_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  *n_hubs = n;
+  return GDN_OK;
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ out_degree, int32_t m,
                   float *__restrict__ contrib) {
@@ -127,7 +267,29 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int lg = 5;
     if (const char *e = getenv("GDN_PB_PAD")) pad = (unsigned)atoi(e);
     if (const char *e = getenv("GDN_PB_LOG_GROUP")) lg = atoi(e);
-    st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, !(ce && ce[0] == '0'), false, pad, lg);
+    const bool compact = !(ce && ce[0] == '0');
+    DevBuf<uint8_t> cls;
+    const char *he = getenv("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
+    st = GDN_OK;
+    if (compact && in_csr->nnz >= (1ull << 24) && !(he && he[0] == '0'))
+      st = pr_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
+    if (st == GDN_OK)
+      st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
+                    p->n_hubs ? cls.p : nullptr, 0, false);
+    if (st == GDN_OK && p->n_hubs) {
+      st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true);
+      if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
+        gdn_set_error("gdn_pr_plan_create: hub layout does not line up with the main layout (%u chunks, %u vs %u bins)",
+                      p->hub.nchunks, p->hub.nbins, p->pb.nbins);
+        st = GDN_ERR_INVALID;
+      }
+      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS);
+      if (st == GDN_OK) {
+        // the single chunk makes chunk-major == bin-major: U and V of the hub layout share one order
+        p->hub.G.release();
+        p->has_hub = true;
+      }
+    }
     if (st == GDN_OK && p->pb.compact) {  // row -> bin lookups of partial launches (gdn_pr_pull_rows_dev)
       p->pb.h_bin_lo.resize((size_t)p->pb.nbins + 1);
       if (hipMemcpy(p->pb.h_bin_lo.data(), p->pb.bin_lo.p, p->pb.h_bin_lo.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) {
@@ -233,6 +395,9 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        0
 #endif
     );
+    if (plan->has_hub)
+      hipLaunchKernelGGL(pr_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
+                         plan->hub_ids.p, plan->n_hubs, plan->hub_val.p);
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }
   // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
@@ -248,7 +413,8 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
 #else
                        0,
 #endif
-                       b0);
+                       b0, plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
+                       plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr);
   if (last) {
     if (timed) {
       GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
@@ -332,6 +498,13 @@ int gdn_pr_plan_layout(const gdn_pr_plan *plan, int32_t *layout, int32_t *log_bl
   GDN_REQUIRE(plan != nullptr, "plan");
   if (layout) *layout = plan->layout;
   if (log_blk) *log_blk = plan->layout == GDN_LAYOUT_PB ? plan->pb.log_chunk * 100 + plan->pb.log_bin : 0;
+  return GDN_OK;
+}
+
+int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edges) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (n_hubs) *n_hubs = plan->has_hub ? (int32_t)plan->n_hubs : 0;
+  if (hub_edges) *hub_edges = plan->has_hub ? plan->hub.nnz : 0;
   return GDN_OK;
 }
 

@@ -168,6 +168,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
 int gdn_pr_plan_layout(const gdn_pr_plan *plan, int32_t *layout, int32_t *log_blk);
 /* PB accumulates in 2^-62 fixed point (contributions must lie in [0,1]): returns
  * GDN_ERR_OVERFLOW if any launch on this plan saw a value outside that range (blocking) */
+/* hub tier of the PB layout (0 / 0 when the plan has none): number of hub sources and of the edges that leave them */
+int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edges);
 int gdn_pr_plan_check(gdn_pr_plan *plan);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */

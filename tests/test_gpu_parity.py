@@ -205,6 +205,62 @@ def test_pr_row_range_part_contract():
         L.gdn_dev_free(p)
 
 
+def test_pr_hub_tier_is_bitwise_neutral(monkeypatch):
+    """PB layout with the hub tier (edges of the highest-degree sources bypass the per-edge value stream) against the
+    same layout without it: integer accumulation makes the two bit-identical; and the tier really is in use."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    g = graphio.rmat_graph(20, 24, seed=35)  # > 2^24 edges: the tier is only built for large graphs
+    gi = graphio.transpose(g)
+    m = g.m
+    h = C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p),
+                                   C.byref(h)))
+
+    def dev(a):
+        p = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(a.nbytes, C.byref(p)))
+        _cabi.check(L.gdn_dev_upload(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    deg = dev(g.degrees().astype(np.int32))
+    out = []
+    for hubs in ("0", "1"):
+        monkeypatch.setenv("GDN_PB_HUBS", hubs)
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_pr_plan_create(h, deg, m, 0, 1, C.byref(plan)))
+        nh, he = C.c_int32(0), C.c_uint64(0)
+        _cabi.check(L.gdn_pr_plan_hubs(plan, C.byref(nh), C.byref(he)))
+        if hubs == "0":
+            assert nh.value == 0 and he.value == 0
+        else:
+            assert 0 < nh.value <= 32768 and 0 < he.value < gi.nnz
+            hub_edges = he.value
+        sc = dev(np.full(m, np.float32(1.0) / np.float32(m), np.float32))
+        c = [dev(np.zeros(m, np.float32)), dev(np.zeros(m, np.float32))]
+        diff = dev(np.zeros(1, np.float64))
+        _cabi.check(L.gdn_pr_contrib_dev(plan, sc, c[0], None))
+        diffs = []
+        for it in range(4):
+            _cabi.check(L.gdn_pr_pull_dev(plan, c[it & 1], sc, c[(it + 1) & 1], diff, 0.85, None))
+            d = np.empty(1, np.float64)
+            _cabi.check(L.gdn_dev_download(d.ctypes.data_as(C.c_void_p), diff, 8))
+            diffs.append(d[0])
+        _cabi.check(L.gdn_pr_plan_check(plan))
+        s = np.empty(m, np.float32)
+        _cabi.check(L.gdn_dev_download(s.ctypes.data_as(C.c_void_p), sc, 4 * m))
+        out.append((s, diffs))
+        L.gdn_pr_plan_free(plan)
+        for p in (sc, c[0], c[1], diff):
+            L.gdn_dev_free(p)
+    L.gdn_dev_free(deg)
+    L.gdn_graph_free(h)
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+    # the hubs are the top sources: their share of the edges is far above their share of the vertices
+    assert hub_edges > gi.nnz // 50
+
+
 def test_pr_is_bitwise_reproducible(monkeypatch):
     monkeypatch.setenv("GDN_PR_LAYOUT", "csr")  # the merge-path layout is the reproducible one
     g = graphio.rmat_graph(15, 16, seed=9)

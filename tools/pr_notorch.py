@@ -31,6 +31,9 @@ init = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
 _cabi.check(L.gdn_dev_upload(scores, init.ctypes.data_as(C.c_void_p), 4 * m))
 plan = C.c_void_p()
 _cabi.check(L.gdn_pr_plan_create(gi, deg, m, 0, 1, C.byref(plan)))
+nh, he = C.c_int32(0), C.c_uint64(0)
+_cabi.check(L.gdn_pr_plan_hubs(plan, C.byref(nh), C.byref(he)))
+print("hub tier: %d hubs, %d edges (%.1f %% of %d)" % (nh.value, he.value, 100.0 * he.value / max(nnz, 1), nnz))
 _cabi.check(L.gdn_pr_contrib_dev(plan, scores, c0, None))
 bufs = [c0, c1]
 for it in range(3):
