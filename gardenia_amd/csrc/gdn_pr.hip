@@ -271,7 +271,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     DevBuf<uint8_t> cls;
     const char *he = getenv("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
     st = GDN_OK;
-    if (compact && in_csr->nnz >= (1ull << 24) && !(he && he[0] == '0'))
+    uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
+    if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
       st = pr_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,

@@ -205,6 +205,32 @@ def test_pr_row_range_part_contract():
         L.gdn_dev_free(p)
 
 
+@pytest.mark.parametrize("world,parts", [(1, 1), (2, 4), (3, 2)])
+def test_pr_hub_tier_on_row_shards(orc, monkeypatch, world, parts):
+    """Hub tier + vertex-range shards (m_local < m_global, row_base) + row-range parts: the multi-GPU configuration of
+    bench.py at a size the oracle solves; the tier is forced on for small shards."""
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1000")
+    monkeypatch.setenv("GDN_PB_HUB_MIN", "1")
+    g = graphio.rmat_graph(16, 16, seed=36)
+    m = g.m - 11
+    src, dst = graphio.csr_to_coo(g)
+    keep = (src < m) & (dst < m)
+    g = graphio.build_csr(m, src[keep], dst[keep])
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    sh = solvers.ResidentPageRankShards(solvers.Graph(csr=g, in_csr=gi), world, 1, parts=parts)
+    import ctypes as C
+    from gardenia_amd import _cabi
+    nh = C.c_int32(0)
+    _cabi.check(_cabi.lib().gdn_pr_plan_hubs(sh.ranks[0]["plan"], C.byref(nh), None))
+    assert nh.value > 0, "the hub tier was not built"
+    scores, it2, err = sh.solve()
+    sh.close()
+    assert it2 == it
+    np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+    assert abs(err - trace[-1]) < 1e-6
+
+
 def test_pr_hub_tier_is_bitwise_neutral(monkeypatch):
     """PB layout with the hub tier (edges of the highest-degree sources bypass the per-edge value stream) against the
     same layout without it: integer accumulation makes the two bit-identical; and the tier really is in use."""
