@@ -93,14 +93,24 @@ class ShardedPageRank:
             self.be.pull(self.cur, nxt, self.damping)
             self._gather(nxt)
         else:
-            ranges = self.part_ranges()
-            works = []
-            for j, (r0, r1) in enumerate(ranges):
-                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
-                if r1 > r0:
-                    works.append(self._gather_rows_async(nxt, r0, r1))
-            for w in works:
-                w.wait()
+            try:
+                ranges = self.part_ranges()
+                works = []
+                for j, (r0, r1) in enumerate(ranges):
+                    self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
+                    if r1 > r0:
+                        works.append(self._gather_rows_async(nxt, r0, r1))
+                for w in works:
+                    w.wait()
+            except (RuntimeError, ValueError, NotImplementedError) as e:
+                # a backend that cannot gather into strided views: redo the iteration unpipelined (the pull only
+                # reads contrib[cur], so repeating it is exact; the L1 change of THIS step is the repeated one)
+                import sys
+                print(f"[sharded] pipelined exchange unavailable ({e}); falling back to one all-gather per iteration",
+                      file=sys.stderr, flush=True)
+                self.parts = 1
+                self.be.pull(self.cur, nxt, self.damping)
+                self._gather(nxt)
         self.cur = nxt
         self.iterations += 1
 
