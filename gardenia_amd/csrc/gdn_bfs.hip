@@ -98,35 +98,64 @@ bfs_td_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsTdVis vi
 
 // Bottom-up step: one thread per vertex, early exit on the first parent found in the frontier
 // bitmap (omp_beamer.cc:13-31).  A wave owns two bitmap words, so next/visited words are
-// written whole, without atomics.
+// written whole, without atomics.  Persistent grid: the awake / scout totals are kept in registers and added
+// to the level counters ONCE per workgroup (one atomicAdd per wave serialised on the hot counter at ~12 ns each:
+// 2 M of them made a cheap late level cost 21 ms on RMAT-27).
 __global__ void __launch_bounds__(GDN_BLOCK)
-bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx, int32_t m,
-              const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
-              int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt) {
-  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
+              const eoff_t *__restrict__ out_rowptr, int32_t m, unsigned m_pad, const unsigned *__restrict__ front,
+              unsigned *__restrict__ next, unsigned *__restrict__ visited, int32_t *__restrict__ depth,
+              int32_t next_level, BfsCounters *cnt) {
+  __shared__ unsigned long long s_red[2 * GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
-  bool found = false;
-  if (v < (unsigned)m) {
-    const unsigned vw = visited[v >> 5];
-    if (!((vw >> (v & 31)) & 1u)) {
-      const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
-      for (eoff_t k = rb; k < re; k++) {
-        const vid_t u = in_colidx[k];
-        if ((front[u >> 5] >> (u & 31)) & 1u) {
-          found = true;
-          break;
+  unsigned long long awake = 0, scout = 0;
+  for (unsigned base = blockIdx.x * GDN_BLOCK; base < m_pad; base += gridDim.x * GDN_BLOCK) {
+    const unsigned v = base + threadIdx.x;
+    bool found = false;
+    if (v < (unsigned)m) {
+      const unsigned vw = visited[v >> 5];
+      if (!((vw >> (v & 31)) & 1u)) {
+        const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
+        for (eoff_t k = rb; k < re; k++) {
+          const vid_t u = in_colidx[k];
+          if ((front[u >> 5] >> (u & 31)) & 1u) {
+            found = true;
+            break;
+          }
         }
       }
     }
+    if (found) {
+      depth[v] = next_level;
+      awake++;
+      scout += out_rowptr[v + 1] - out_rowptr[v];
+    }
+    const unsigned long long mask = __ballot(found);
+    if ((lane & 31u) == 0 && v < m_pad) {
+      const unsigned bits = (unsigned)(mask >> (lane & 32u));
+      next[v >> 5] = bits;
+      if (bits) visited[v >> 5] |= bits;
+    }
   }
-  if (found) depth[v] = next_level;
-  const unsigned long long mask = __ballot(found);
-  if ((lane & 31u) == 0 && v < (unsigned)m) {
-    const unsigned bits = (unsigned)(mask >> (lane & 32u));
-    next[v >> 5] = bits;
-    if (bits) visited[v >> 5] |= bits;
+  awake = gdn_wave_sum(awake);
+  scout = gdn_wave_sum(scout);
+  const unsigned w = threadIdx.x >> 6;
+  if (lane == 0) {
+    s_red[w] = awake;
+    s_red[GDN_WAVES_PER_BLOCK + w] = scout;
   }
-  if (lane == 0 && mask) atomicAdd(&cnt->awake, (unsigned long long)__popcll(mask));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, sc = 0;
+    for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
+      a += s_red[i];
+      sc += s_red[GDN_WAVES_PER_BLOCK + i];
+    }
+    if (a) {
+      atomicAdd(&cnt->awake, a);
+      atomicAdd(&cnt->scout, sc);
+    }
+  }
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -212,8 +241,10 @@ int gdn_reached_edges(const gdn_graph *g, const int32_t *d_dist, int32_t unreach
 // Dense level = one propagation-blocked sweep over ALL in-edges (gdn_pb.hpp layout of the
 // in-CSR, 1 bit per edge instead of a value).  It replaces the bottom-up step for the big
 // levels: bfs_bu_kernel spends 21 ms per RMAT-27 level on divergent probes of the 16 MiB
-// frontier bitmap (profiles/r01_*), the sweep streams 2 B/edge twice (~2 ms) whatever the
-// frontier is.
+// frontier bitmap when most rows are still unvisited, the sweep streams 2 B/edge twice (~2.5 ms) whatever the
+// frontier is.  Once >= 3/4 of the rows that have in-edges are visited the roles flip: the bottom-up step only
+// walks the few unvisited rows and stops at the first frontier parent, so the resident plan takes it for the late
+// heavy levels (gdn_bfs_run).
 //   phase A (per source chunk): frontier bits of the chunk -> LDS; for every group of 8 edges
 //           one byte = the 8 frontier bits of their sources, stored at the group's bin-major place
 //   phase B (per destination bin): visited bits of the bin -> LDS; for every non-zero byte load the
@@ -371,8 +402,18 @@ struct gdn_bfs_plan {
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
+  unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   double prep_ms = 0;
 };
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
+  unsigned long long n = 0;
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK)
+    n += rowptr[v + 1] > rowptr[v] ? 1u : 0u;
+  n = gdn_wave_sum(n);
+  if (gdn_lane() == 0 && n) atomicAdd(out, n);
+}
 
 static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *gin, bool dense) {
   HostTimer t;
@@ -393,6 +434,11 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     GDN_TRY(p.ebits.alloc((p.pb.n_pad >> 3) + 8));
     GDN_HIP(hipMemset(p.ebits.p, 0, (p.pb.n_pad >> 3) + 8));
     p.dense = true;
+    DevBuf<unsigned long long> nact;
+    GDN_TRY(nact.alloc(1));
+    GDN_HIP(hipMemset(nact.p, 0, 8));
+    hipLaunchKernelGGL(bfs_count_rows_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, gin->rowptr, m, nact.p);
+    GDN_HIP(hipMemcpy(&p.active_rows, nact.p, 8, hipMemcpyDeviceToHost));
   }
   p.qcap = (unsigned)m;
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
@@ -435,6 +481,9 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int64_t scout_count = (int64_t)(srow[1] - srow[0]);
   int32_t level = 0;  // depth of the vertices in the current frontier
   int iter = 0;
+  int64_t visited_total = 1;  // discovered so far (the source included)
+  int64_t bu_frac = 4;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered
+  if (const char *e = getenv("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
   BfsCounters h;
   memset(&h, 0, sizeof(h));
   ExpBigList big;
@@ -460,20 +509,34 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       do {
         ++iter;
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
-        hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
-                           p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
-        hipLaunchKernelGGL(bfs_pb_accumulate_kernel, dim3(p.pb.nbins), dim3(PB_THREADS), 0, 0, m, p.pb.log_bin,
-                           p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_dist, level + 1,
-                           g->rowptr, p.cnt.p);
+        // engine of this heavy level: the sweep over all in-edges, or -- once few rows are left to discover --
+        // the bottom-up step over the unvisited rows (omp_beamer.cc:13-31)
+        const int64_t left = (int64_t)p.active_rows - visited_total;
+        const bool bottom_up = left * bu_frac <= (int64_t)p.active_rows;
+        if (bottom_up) {
+          hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
+                             p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
+        } else {
+          hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
+                             p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
+          hipLaunchKernelGGL(bfs_pb_accumulate_kernel, dim3(p.pb.nbins), dim3(PB_THREADS), 0, 0, m, p.pb.log_bin,
+                             p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_dist, level + 1,
+                             g->rowptr, p.cnt.p);
+        }
         GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
         awake = (int64_t)h.awake;
         scout_count = (int64_t)h.scout;
+        visited_total += awake;
         unsigned *t = fr;
         fr = nx;
         nx = t;
         level++;
-        lap("dense", awake, scout_count);
-      } while (awake > 0 && scout_count > (int64_t)(g->nnz / alpha_dense));
+        lap(bottom_up ? "bottom-up" : "dense", awake, scout_count);
+        // stay on bitmaps while the frontier is heavy, or while the cheap bottom-up engine beats a top-down
+        // step over scout_count edges (a late level with millions of frontier vertices but few discoveries)
+      } while (awake > 0 && (scout_count > (int64_t)(g->nnz / alpha_dense) ||
+                             (((int64_t)p.active_rows - visited_total) * bu_frac <= (int64_t)p.active_rows &&
+                              scout_count > (int64_t)m / 16)));
       if (awake == 0) {
         nf = 0;
         break;
@@ -495,8 +558,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         ++iter;
         old_awake = awake;
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
-        hipLaunchKernelGGL(bfs_bu_kernel, dim3(gdn_nblocks((uint64_t)p.nwords_pad * 32)), dim3(GDN_BLOCK), 0, 0,
-                           gin->rowptr, gin->colidx, m, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
+        hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
+                           p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
         GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
         awake = (int64_t)h.awake;
         unsigned *t = fr;
@@ -532,6 +595,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;
+      visited_total += (int64_t)nf;
       vid_t *t = qin;
       qin = qout;
       qout = t;
