@@ -590,8 +590,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       vis.scout_local = 0;
       big.count = &p.cnt.p->big_count;
       big.overflow = &p.cnt.p->overflow;
+      // a small frontier of long rows: hand every row of a wave's width or more to the persistent item kernel
+      // (rows of 64..511 edges walked one after the other by the few waves of such a level cost 0.35 ms on RMAT-27)
+      big.min_deg = ((uint64_t)nf < 65536u && (uint64_t)nf + (uint64_t)scout_count / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
+                        ? 64u : (unsigned)EXP_BIG;
       hipLaunchKernelGGL(bfs_td_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nf, big, vis);
-      hipLaunchKernelGGL(bfs_td_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+      hipLaunchKernelGGL(bfs_td_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
       GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;

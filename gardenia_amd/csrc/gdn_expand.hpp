@@ -30,6 +30,8 @@ struct ExpBigList {
   unsigned *count;
   unsigned capacity;
   unsigned *overflow;
+  unsigned min_deg = EXP_BIG;  // rows at least this long become work items (>= 64; lower it for SMALL vertex lists,
+                               // whose medium rows would otherwise be walked one at a time by a handful of waves)
 };
 
 #ifdef __HIPCC__
@@ -44,7 +46,7 @@ __device__ __forceinline__ void gdn_expand_wave(eoff_t b, eoff_t e, vid_t v, Exp
 
   // ---- tier 1: big rows -> chunk work items
   if (big.items != nullptr) {
-    const bool is_big = deg >= EXP_BIG;
+    const bool is_big = deg >= big.min_deg;
     const unsigned nchunks = is_big ? (unsigned)((e - b + EXP_CHUNK - 1) / EXP_CHUNK) : 0u;
     const unsigned incl = gdn_wave_incl_scan(nchunks);
     const unsigned total = __shfl(incl, 63, 64);
@@ -53,9 +55,19 @@ __device__ __forceinline__ void gdn_expand_wave(eoff_t b, eoff_t e, vid_t v, Exp
       if (lane == 63) base = atomicAdd(big.count, total);
       base = __shfl(base, 63, 64);
       const unsigned mine = base + incl - nchunks;
-      for (unsigned c = 0; c < nchunks; c++) {
-        if (mine + c < big.capacity) big.items[mine + c] = ((unsigned long long)c << 32) | (unsigned)v;
-        else *big.overflow = 1u;
+      // the whole wave writes the items of one big row at a time: a hub of 10^6 edges is thousands of items, and
+      // one lane writing them alone held a 456-vertex BFS level for 0.35 ms
+      unsigned long long bigmask = __ballot(nchunks > 0u);
+      while (bigmask) {
+        const int leader = __ffsll((long long)bigmask) - 1;
+        bigmask &= bigmask - 1ull;
+        const unsigned n = __shfl(nchunks, leader, 64);
+        const unsigned first = __shfl(mine, leader, 64);
+        const unsigned vv = (unsigned)__shfl(v, leader, 64);
+        for (unsigned c = lane; c < n; c += 64) {
+          if (first + c < big.capacity) big.items[first + c] = ((unsigned long long)c << 32) | vv;
+          else *big.overflow = 1u;
+        }
       }
     }
     if (is_big) deg = 0;
