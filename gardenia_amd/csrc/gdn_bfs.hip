@@ -354,15 +354,19 @@ bfs_pb_accumulate_kernel(int32_t m, int log_bin, const eoff_t *__restrict__ bin_
   __syncthreads();
   unsigned long long awake = 0, scout = 0;
   for (unsigned i = threadIdx.x; i < words; i += PB_THREADS) {
-    unsigned nb = s_new[i];
+    const unsigned nb = s_new[i];
     next_front[w0 + i] = nb;
-    if (nb) {
-      visited[w0 + i] = s_vis[i] | nb;
-      const size_t row0 = (w0 + i) * 32;
-      while (nb) {
-        const int k = __ffs((int)nb) - 1;
-        nb &= nb - 1u;
-        const size_t row = row0 + (size_t)k;
+    if (nb) visited[w0 + i] = s_vis[i] | nb;
+  }
+  // one lane per ROW (a wave covers two bitmap words): the depth stores and row-offset loads of the discovered rows
+  // are consecutive across the lanes (a heavy level discovers a third of all rows)
+  {
+    const unsigned lane = gdn_lane(), wv = threadIdx.x >> 6;
+    for (unsigned i0 = wv * 2u; i0 < words; i0 += 2u * PB_WAVES) {
+      const unsigned i = i0 + (lane >> 5);
+      const unsigned nb = i < words ? s_new[i] : 0u;
+      if ((nb >> (lane & 31u)) & 1u) {
+        const size_t row = ((size_t)w0 + i) * 32 + (lane & 31u);
         if (row < (size_t)m) {
           depth[row] = next_level;
           awake++;
