@@ -393,11 +393,12 @@ pb_fill_u16_kernel(uint16_t *p, unsigned long long n, uint16_t v) {
 // padded tile sizes in chunk-major (psz_c) and bin-major (psz_b) tile order
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_tile_sizes_kernel(const eoff_t *__restrict__ tsu, unsigned nchunks, unsigned nbins, unsigned pad,
-                     uint32_t *__restrict__ psz_c, uint32_t *__restrict__ psz_b) {
+                     uint32_t *__restrict__ psz_c, uint32_t *__restrict__ psz_b, const eoff_t *__restrict__ ds) {
   const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (t >= (unsigned long long)nchunks * nbins) return;
   const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
-  const uint32_t sz = (uint32_t)(((tsu[t + 1] - tsu[t]) + (pad - 1)) & ~(eoff_t)(pad - 1));
+  const eoff_t fill = ds ? ds[tsu[t + 1]] - ds[tsu[t]] : 0;  // filler edges of the delta-coded row stream
+  const uint32_t sz = (uint32_t)(((tsu[t + 1] - tsu[t]) + fill + (pad - 1)) & ~(eoff_t)(pad - 1));
   psz_c[t] = sz;
   psz_b[(unsigned long long)b * nchunks + c] = sz;
 }
@@ -427,13 +428,73 @@ pb_fill_u32_kernel(uint32_t *p, unsigned long long n, uint32_t v) {
   for (; i < n; i += stride) p[i] = v;
 }
 
+// ---- 8-bit delta coding of the row stream V (PbPlan::v8): inside a tile the edges are sorted by row, so the row of
+// an edge is stored as its distance to the previous edge of the same 32-edge group (+ one u16 base per group).
+// nd[i] = filler edges (source = the pad id, value 0) in front of sorted key i so that no distance exceeds 255.
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_gap_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int log_chunk, int log_bin,
+              uint32_t *__restrict__ nd) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) {
+    uint32_t f = 0;
+    if (i > 0) {
+      const unsigned long long k = keys[i], kp = keys[i - 1];
+      if ((k >> (log_chunk + log_bin)) == (kp >> (log_chunk + log_bin))) {
+        const unsigned r = (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
+        const unsigned rp = (unsigned)(kp >> log_chunk) & ((1u << log_bin) - 1u);
+        const unsigned gap = r - rp;
+        if (gap > 255u) f = (gap - 1u) / 255u;
+      }
+    }
+    nd[i] = f;
+  }
+}
+
+// pads behind the edges of a tile repeat its last row (distance 0) instead of row 0
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_pad_rows_kernel(const eoff_t *__restrict__ tsu, const eoff_t *__restrict__ ds, const eoff_t *__restrict__ pv,
+                   const uint32_t *__restrict__ psz_b, unsigned nchunks, unsigned nbins, uint16_t *__restrict__ V) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (t >= (unsigned long long)nchunks * nbins) return;
+  const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
+  const eoff_t cnt = (tsu[t + 1] - tsu[t]) + (ds[tsu[t + 1]] - ds[tsu[t]]);
+  if (cnt == 0) return;
+  const unsigned long long tb = (unsigned long long)b * nchunks + c;
+  const eoff_t base = pv[tb];
+  const uint16_t last = V[base + cnt - 1];
+  for (eoff_t j = cnt; j < (eoff_t)psz_b[tb]; j++) V[base + j] = last;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_encode_rows_kernel(const uint16_t *__restrict__ V, unsigned long long n, uint8_t *__restrict__ Vd,
+                      uint16_t *__restrict__ Vb, unsigned *__restrict__ bad) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) {
+    const unsigned v = V[i];
+    unsigned d = 0;
+    if (i & 31ull) {
+      const unsigned vp = V[i - 1];
+      d = v - vp;
+      if (v < vp || d > 255u) {
+        *bad = 1u;
+        d = 0;
+      }
+    } else {
+      Vb[i >> 5] = (uint16_t)v;
+    }
+    Vd[i] = (uint8_t)d;
+  }
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, int log_chunk, int log_bin,
                   int bin_bits, unsigned nchunks, unsigned nbins, const eoff_t *__restrict__ tsu,
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
                   uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
                   const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv, int transposed,
-                  int src_major) {
+                  int src_major, const uint32_t *__restrict__ nd, const eoff_t *__restrict__ ds) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -442,7 +503,16 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     const unsigned long long cb = k >> (log_chunk + log_bin);
     const unsigned long long b = cb & bmask, c = cb >> bin_bits;
     const unsigned long long t = c * nbins + b;
-    const unsigned long long off = i - tsu[t];
+    unsigned long long off = i - tsu[t];
+    if (ds) {  // delta-coded rows: nd[i] fillers sit in front of this edge, 255 rows apart behind the previous edge
+      const unsigned f = nd[i];
+      off += (ds[i] - ds[tsu[t]]) + f;
+      if (f) {
+        const unsigned rp = (unsigned)(keys[i - 1] >> log_chunk) & ((1u << log_bin) - 1u);
+        for (unsigned j = 0; j < f; j++)  // U keeps the pad id (value 0) from the fill
+          V[pv[b * nchunks + c] + off - f + j] = (uint16_t)(rp + 255u * (j + 1u));
+      }
+    }
     const unsigned ul = src_major ? (unsigned)(k >> log_bin) & ((1u << log_chunk) - 1u) : (unsigned)k & ((1u << log_chunk) - 1u);
     const unsigned vl = src_major ? (unsigned)k & ((1u << log_bin) - 1u) : (unsigned)(k >> log_chunk) & ((1u << log_bin) - 1u);
     U[pu[t] + off] = (uint16_t)ul;
@@ -480,8 +550,9 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, c
 
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
-             int log_group, const uint8_t *src_class, int want_class, bool src_major) {
+             int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
+  GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
   GDN_REQUIRE(!(src_class && (rows_are_sources || edge_vals_in)), "source classes: in-CSR without edge values only");
   GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
               "pad / log_group");
@@ -649,8 +720,18 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     }
     // tile runs are padded to 16 edges = whole 64-byte lines of vals, so phase A never leaves a
     // partially written line to another workgroup (measured 7.9 vs 8.4 ms/iter at pad 8, RMAT-27)
+    DevBuf<uint32_t> nd;  // delta-coded rows: fillers in front of every sorted key, and their exclusive scan
+    DevBuf<eoff_t> ds;
+    if (v_delta) {
+      GDN_TRY(nd.alloc(n_use + 1));
+      GDN_TRY(ds.alloc(n_use + 2));
+      if (n_use)
+        hipLaunchKernelGGL(pb_gap_kernel, dim3(grid_n), dim3(GDN_BLOCK), 0, 0, sorted, n_use, log_chunk, log_bin, nd.p);
+      GDN_HIP(hipGetLastError());
+      GDN_TRY(gdn_exclusive_scan_u32_to_u64(nd.p, ds.p, (size_t)n_use, 0));
+    }
     hipLaunchKernelGGL(pb_tile_sizes_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, p.nchunks, p.nbins,
-                       pad, psz_c.p, psz_b.p);
+                       pad, psz_c.p, psz_b.p, v_delta ? ds.p : nullptr);
     GDN_HIP(hipGetLastError());
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_c.p, pu.p, (size_t)ntiles, 0));
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(psz_b.p, pv.p, (size_t)ntiles, 0));
@@ -696,6 +777,14 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       GDN_HIP(hipDeviceSynchronize());
     }
     p.n_pad = n_pad;
+    if (getenv("GDN_PB_TRACE")) {
+      eoff_t fill = 0;
+      if (v_delta) (void)hipMemcpy(&fill, ds.p + n_use, sizeof(eoff_t), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[pb_build] edges %llu fillers %llu padded %llu (%.3f x) chunks %u bins %u pad %u group %u%s%s\n",
+              (unsigned long long)n_use, (unsigned long long)fill, (unsigned long long)n_pad,
+              n_use ? (double)n_pad / (double)n_use : 0.0, p.nchunks, p.nbins, pad, grp, v_delta ? " v8" : "",
+              src_major ? " src-major" : "");
+    }
     if ((n_pad >> log_group) + 1 > 0xFFFFFFFFull) {
       gdn_set_error("pb_build: more than 2^35 padded edges");
       return GDN_ERR_INVALID;
@@ -724,7 +813,25 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
 #else
                          0,
 #endif
-                         rows_are_sources ? 1 : 0, src_major ? 1 : 0);
+                         rows_are_sources ? 1 : 0, src_major ? 1 : 0, v_delta ? nd.p : nullptr, v_delta ? ds.p : nullptr);
+    if (v_delta) {  // pads repeat the tile's last row, then V (u16) -> one byte per edge + one u16 base per 32 edges
+      hipLaunchKernelGGL(pb_pad_rows_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, ds.p, pv.p, psz_b.p,
+                         p.nchunks, p.nbins, p.V.p);
+      GDN_TRY(p.Vd.alloc(n_pad + grp));
+      GDN_TRY(p.Vb.alloc((n_pad >> 5) + 2));
+      const unsigned long long eb = (n_pad + GDN_BLOCK - 1) / GDN_BLOCK;
+      hipLaunchKernelGGL(pb_encode_rows_kernel, dim3((unsigned)(eb > 262144ull ? 262144ull : (eb ? eb : 1))), dim3(GDN_BLOCK),
+                         0, 0, p.V.p, n_pad, p.Vd.p, p.Vb.p, p.errflag.p);
+      GDN_HIP(hipGetLastError());
+      unsigned bad = 0;
+      GDN_HIP(hipMemcpy(&bad, p.errflag.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+      if (bad) {
+        gdn_set_error("pb_build: a row distance of the delta-coded layout does not fit 8 bits (internal error)");
+        return GDN_ERR_INVALID;
+      }
+      p.V.release();
+      p.v8 = true;
+    }
     int identity_g = 0;
 #ifdef GDN_EXPERIMENTS  // GDN_PB_IDENTITY=1: TIMING-ONLY experiment (sequential phase-A stores, wrong results)
     identity_g = getenv("GDN_PB_IDENTITY") ? 1 : 0;

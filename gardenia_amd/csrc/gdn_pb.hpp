@@ -54,7 +54,12 @@ struct PbPlan {
   uint64_t n_pad = 0;             // padded edge count (multiple of the group size) = length of U, V, vals
   DevBuf<uint16_t> U;             // chunk-major
   DevBuf<uint32_t> G;             // n_pad >> log_group (+ 1 dump group)
-  DevBuf<uint16_t> V;             // bin-major
+  DevBuf<uint16_t> V;             // bin-major (released when v8)
+  // v8: the row of an edge = Vb[its 32-edge group] + the sum of the Vd bytes of the group up to and including it
+  // (edges of a tile are sorted by row; filler edges with value 0 keep every distance <= 255): 1.06 B/edge, not 2
+  bool v8 = false;
+  DevBuf<uint8_t> Vd;             // bin-major, one byte per padded edge
+  DevBuf<uint16_t> Vb;            // one base row per 32 padded edges
   DevBuf<float> vals;             // bin-major
   DevBuf<eoff_t> chunk_ptr;       // nchunks + 1, element units (multiples of 8)
   DevBuf<eoff_t> bin_ptr;         // nbins + 1, element units (multiples of 8)
@@ -88,7 +93,8 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              int log_group = 3,              // 2^log_group <= pad edges share one entry of G
              const uint8_t *src_class = nullptr,  // per global source id: only edges whose source has class
              int want_class = 0,                  //   `want_class` are laid out (PageRank hub tier, gdn_pr.hip)
-             bool src_major = false);             // order inside a tile: (source, row) instead of (row, source)
+             bool src_major = false,              // order inside a tile: (source, row) instead of (row, source)
+             bool v_delta = false);               // rows as 8-bit distances (Vd, Vb) instead of u16 (V): see PbPlan::v8
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
@@ -482,7 +488,9 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      // hub tier (nullable): per bin a second stream of (hub index, row) pairs, sorted by hub, whose
                      // values are read from the small per-iteration table hub_val instead of travelling through vals
                      const eoff_t *__restrict__ hub_ptr = nullptr, const uint16_t *__restrict__ hub_U = nullptr,
-                     const uint16_t *__restrict__ hub_V = nullptr, const float *__restrict__ hub_val = nullptr) {
+                     const uint16_t *__restrict__ hub_V = nullptr, const float *__restrict__ hub_val = nullptr,
+                     // delta-coded rows (PbPlan::v8, nullable): V is then not read
+                     const uint8_t *__restrict__ Vd = nullptr, const uint16_t *__restrict__ Vb = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
@@ -500,26 +508,57 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const eoff_t STEP = (eoff_t)UNR * PB_THREADS;
   pb_f32x4 xs[UNR], nx[UNR];
   pb_u16x4 vs[UNR], nv[UNR];
+  // the 4 rows of quad qq.  Delta-coded stream: 4 distance bytes per quad + the base of its 32-edge group; the 8
+  // lanes of a group (bin ranges are whole groups, so a group is valid or not as a whole) scan their quad sums.
+  // Called by whole 8-lane groups.
+  const uint32_t *Vd4 = reinterpret_cast<const uint32_t *>(Vd);
+  auto load_rows = [&](eoff_t qq, bool ok) -> pb_u16x4 {
+    pb_u16x4 o = {0, 0, 0, 0};
+    if (!Vd) {
+      if (ok) o = __builtin_nontemporal_load(V4 + qq);
+      return o;
+    }
+    unsigned d = 0, base = 0;
+    if (ok) {
+      d = __builtin_nontemporal_load(Vd4 + qq);
+      base = __builtin_nontemporal_load(Vb + (qq >> 3));
+    }
+    const unsigned d0 = d & 255u, d1 = (d >> 8) & 255u, d2 = (d >> 16) & 255u, d3 = d >> 24;
+    const unsigned tot = d0 + d1 + d2 + d3;
+    unsigned incl = tot;
+    const unsigned l8 = lane & 7u;
+    // DPP row_shr:k (0x110 + k) stays in the VALU; a lane with l8 >= k reads a lane of its own group
+    unsigned t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xf, 0xf, true);
+    if (l8 >= 1u) incl += t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xf, 0xf, true);
+    if (l8 >= 2u) incl += t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xf, 0xf, true);
+    if (l8 >= 4u) incl += t;
+    const unsigned r0 = base + incl - tot + d0;
+    o.x = (unsigned short)r0;
+    o.y = (unsigned short)(r0 + d1);
+    o.z = (unsigned short)(r0 + d1 + d2);
+    o.w = (unsigned short)(r0 + d1 + d2 + d3);
+    return o;
+  };
   // software pipeline: the loads of step i+1 are in flight while step i is folded into LDS
   {
     const eoff_t q = q0 + threadIdx.x;
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-      if (qq < q1) {
-        xs[r] = __builtin_nontemporal_load(X4 + qq);
-        vs[r] = __builtin_nontemporal_load(V4 + qq);
-      }
+      if (qq < q1) xs[r] = __builtin_nontemporal_load(X4 + qq);
+      vs[r] = load_rows(qq, qq < q1);
     }
   }
+  // (q0 and q1 are multiples of 8 quads, so the 8 lanes of a group leave this loop together: the lane-group
+  // shuffles of load_rows never read a lane that has left)
   for (eoff_t q = q0 + threadIdx.x; q < q1; q += STEP) {
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + STEP + (eoff_t)r * PB_THREADS;
-      if (qq < q1) {
-        nx[r] = __builtin_nontemporal_load(X4 + qq);
-        nv[r] = __builtin_nontemporal_load(V4 + qq);
-      }
+      if (qq < q1) nx[r] = __builtin_nontemporal_load(X4 + qq);
+      nv[r] = load_rows(qq, qq < q1);
     }
 #pragma unroll
     for (int r = 0; r < UNR; r++) {

@@ -268,6 +268,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (const char *e = getenv("GDN_PB_PAD")) pad = (unsigned)atoi(e);
     if (const char *e = getenv("GDN_PB_LOG_GROUP")) lg = atoi(e);
     const bool compact = !(ce && ce[0] == '0');
+    // 8-bit delta-coded rows (PbPlan::v8) are OFF by default: they save 0.94 B/edge of phase B's reads but the decode
+    // (3 DPP steps + unpack per quad) cost more than that on RMAT-27 (B 3.0 -> 3.5 ms); GDN_PB_V8=1 builds them
+    const char *ve = getenv("GDN_PB_V8");
+    const bool v_delta = pad >= 32 && ve && ve[0] == '1';
     DevBuf<uint8_t> cls;
     const char *he = getenv("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
     st = GDN_OK;
@@ -277,7 +281,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       st = pr_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
-                    p->n_hubs ? cls.p : nullptr, 0, false);
+                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta);
     if (st == GDN_OK && p->n_hubs) {
       st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
@@ -416,7 +420,8 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        0,
 #endif
                        b0, plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
-                       plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr);
+                       plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr,
+                       pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr);
   if (last) {
     if (timed) {
       GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));

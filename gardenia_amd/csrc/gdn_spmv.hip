@@ -145,7 +145,8 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     st = mp_plan_build(p->mp, csr, 0);
   } else {
     st = pb_build(csr, n_cols, spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
-                  true, d_Ax, &p->Axp, false, false, /*pad=*/32, /*log_group=*/5);
+                  true, d_Ax, &p->Axp, false, false, /*pad=*/32, /*log_group=*/5, nullptr, 0, false,
+                  /*v_delta=*/getenv("GDN_PB_V8") && getenv("GDN_PB_V8")[0] == '1');  // off by default, see gdn_pr.hip
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
     if (st == GDN_OK) {
@@ -210,7 +211,8 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
-                     pb.errflag.p, nullptr, nullptr, op);
+                     pb.errflag.p, nullptr, nullptr, op, 0, 0u, nullptr, nullptr, nullptr, nullptr, pb.v8 ? pb.Vd.p : nullptr,
+                     pb.v8 ? pb.Vb.p : nullptr);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

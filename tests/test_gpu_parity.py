@@ -231,6 +231,52 @@ def test_pr_hub_tier_on_row_shards(orc, monkeypatch, world, parts):
     assert abs(err - trace[-1]) < 1e-6
 
 
+@pytest.mark.parametrize("layout_env", [{"GDN_PB_V8": "1"}, {"GDN_PB_V8": "1", "GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1"}])
+def test_pr_delta_coded_rows_are_bitwise_neutral(orc, monkeypatch, layout_env):
+    """Optional 8-bit delta coding of the row stream (PbPlan::v8, off by default because its decode costs more than
+    the bytes it saves): filler edges keep every distance <= 255; the result equals the u16 layout bit for bit.
+    The graph has long empty row ranges, so fillers are really needed."""
+    rng = np.random.default_rng(12)
+    m = 1 << 16
+    # sparse rows: ~2 edges per 1000 rows inside a bin -> distances far above 255, plus a few dense rows
+    src = rng.integers(0, m, 6000)
+    dst = rng.integers(0, m, 6000)
+    src = np.concatenate([src, rng.integers(0, m, 20000)])
+    dst = np.concatenate([dst, np.repeat(rng.integers(0, m, 20), 1000)])
+    g = graphio.build_csr(m, src, dst)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    ref = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    st0 = solvers.PRSolver(G, ref)
+    for k, v in layout_env.items():
+        monkeypatch.setenv(k, v)
+    got = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    st1 = solvers.PRSolver(G, got)
+    assert st0["iterations"] == st1["iterations"]
+    assert np.array_equal(ref, got)
+    want, it, _ = orc.pr(graphio.transpose(g), g.degrees())
+    assert it == st1["iterations"]
+    np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=0)
+
+
+def test_spmv_delta_coded_rows(orc, monkeypatch):
+    g = graphio.rmat_graph(15, 8, seed=13)
+    rng = np.random.default_rng(3)
+    Ax = (rng.random(g.nnz) - 0.5).astype(np.float32)
+    x = (rng.random(g.m) - 0.5).astype(np.float32)
+    y0 = rng.random(g.m).astype(np.float32)
+    G = solvers.Graph(csr=g, in_csr=g)
+    want = orc.spmv(g, Ax, x, y0)
+    ys = []
+    for v8 in ("0", "1"):
+        monkeypatch.setenv("GDN_PB_V8", v8)
+        sp = solvers.ResidentSpMV(G, Ax, layout=1)
+        ys.append(sp.multiply(x, y0))
+        sp.close()
+    assert np.array_equal(ys[0], ys[1])
+    np.testing.assert_allclose(ys[1], want, rtol=REL_TOL, atol=1e-6)
+
+
 def test_pr_hub_tier_is_bitwise_neutral(monkeypatch):
     """PB layout with the hub tier (edges of the highest-degree sources bypass the per-edge value stream) against the
     same layout without it: integer accumulation makes the two bit-identical; and the tier really is in use."""
