@@ -505,23 +505,28 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const pb_u16x4 *V4 = reinterpret_cast<const pb_u16x4 *>(V);
   unsigned bad = 0u;
   constexpr int UNR = 4;
-  const eoff_t STEP = (eoff_t)UNR * PB_THREADS;
   pb_f32x4 xs[UNR], nx[UNR];
   pb_u16x4 vs[UNR], nv[UNR];
-  // the 4 rows of quad qq.  Delta-coded stream: 4 distance bytes per quad + the base of its 32-edge group; the 8
-  // lanes of a group (bin ranges are whole groups, so a group is valid or not as a whole) scan their quad sums.
-  // Called by whole 8-lane groups.
-  const uint32_t *Vd4 = reinterpret_cast<const uint32_t *>(Vd);
-  auto load_rows = [&](eoff_t qq, bool ok) -> pb_u16x4 {
+  // The bin's range as 32-bit quad indices behind wave-uniform base pointers (scalar base + 32-bit lane offset
+  // addressing instead of 64-bit pointer arithmetic per load), and the steps in which every lane has work run
+  // without bounds predicates: phase B has no spare issue slots (one 1024-thread workgroup per CU).
+  const unsigned nq = (unsigned)(q1 - q0);
+  const pb_f32x4 *Xq = X4 + q0;
+  const pb_u16x4 *Vq = V4 + q0;
+  const uint32_t *Dq = reinterpret_cast<const uint32_t *>(Vd) + q0;  // delta-coded rows: 4 distance bytes per quad
+  const uint16_t *Bq = Vb + (q0 >> 3);                                //   + the base row of every 32-edge group
+  // the 4 rows of quad i.  Delta-coded stream: the 8 lanes of a group (bin ranges are whole groups, so a group is
+  // valid or not as a whole) scan their quad sums.  Called by whole 8-lane groups.
+  auto load_rows = [&](unsigned i, bool ok) -> pb_u16x4 {
     pb_u16x4 o = {0, 0, 0, 0};
     if (!Vd) {
-      if (ok) o = __builtin_nontemporal_load(V4 + qq);
+      if (ok) o = __builtin_nontemporal_load(Vq + i);
       return o;
     }
     unsigned d = 0, base = 0;
     if (ok) {
-      d = __builtin_nontemporal_load(Vd4 + qq);
-      base = __builtin_nontemporal_load(Vb + (qq >> 3));
+      d = __builtin_nontemporal_load(Dq + i);
+      base = __builtin_nontemporal_load(Bq + (i >> 3));
     }
     const unsigned d0 = d & 255u, d1 = (d >> 8) & 255u, d2 = (d >> 16) & 255u, d3 = d >> 24;
     const unsigned tot = d0 + d1 + d2 + d3;
@@ -541,66 +546,79 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     o.w = (unsigned short)(r0 + d1 + d2 + d3);
     return o;
   };
-  // software pipeline: the loads of step i+1 are in flight while step i is folded into LDS
-  {
-    const eoff_t q = q0 + threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-      if (qq < q1) xs[r] = __builtin_nontemporal_load(X4 + qq);
-      vs[r] = load_rows(qq, qq < q1);
+  // edges of one tile are sorted by destination row: fold equal neighbours in the lane first (a hub row receives
+  // hundreds of consecutive edges per tile)
+  auto fold = [&](const pb_f32x4 &x, const pb_u16x4 &v) {
+    if (dbg & 1) {
+      bad |= (unsigned)(x.x + x.y + x.z + x.w == 123.456f) + (unsigned)(v.x + v.w == 77777u);
+      return;
     }
-  }
-  // (q0 and q1 are multiples of 8 quads, so the 8 lanes of a group leave this loop together: the lane-group
-  // shuffles of load_rows never read a lane that has left)
-  for (eoff_t q = q0 + threadIdx.x; q < q1; q += STEP) {
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const eoff_t qq = q + STEP + (eoff_t)r * PB_THREADS;
-      if (qq < q1) nx[r] = __builtin_nontemporal_load(X4 + qq);
-      nv[r] = load_rows(qq, qq < q1);
+    unsigned cur = v.x;
+    unsigned long long a = op.to_fixed(x.x, bad);
+    unsigned long long f = op.to_fixed(x.y, bad);
+    if (v.y == cur) a += f;
+    else {
+      atomicAdd(&s_acc[cur], a);
+      cur = v.y;
+      a = f;
     }
+    f = op.to_fixed(x.z, bad);
+    if (v.z == cur) a += f;
+    else {
+      atomicAdd(&s_acc[cur], a);
+      cur = v.z;
+      a = f;
+    }
+    f = op.to_fixed(x.w, bad);
+    if (v.w == cur) a += f;
+    else {
+      atomicAdd(&s_acc[cur], a);
+      cur = v.w;
+      a = f;
+    }
+    atomicAdd(&s_acc[cur], a);
+  };
+  constexpr unsigned STEPU = (unsigned)UNR * PB_THREADS;
+  unsigned sb = 0;  // first quad of the current step (wave-uniform)
+  if (nq >= STEPU) {
+    // software pipeline over the full steps: the loads of step k+1 are in flight while step k is folded into LDS
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-      if (qq < q1) {
-        // edges of one tile are sorted by destination row: fold equal neighbours in the lane
-        // first (a hub row receives hundreds of consecutive edges per tile)
-        if (dbg & 1) {
-          bad |= (unsigned)(xs[r].x + xs[r].y + xs[r].z + xs[r].w == 123.456f) + (unsigned)(vs[r].x + vs[r].w == 77777u);
-          continue;
-        }
-        unsigned cur = vs[r].x;
-        unsigned long long a = op.to_fixed(xs[r].x, bad);
-        unsigned long long f = op.to_fixed(xs[r].y, bad);
-        if (vs[r].y == cur) a += f;
-        else {
-          atomicAdd(&s_acc[cur], a);
-          cur = vs[r].y;
-          a = f;
-        }
-        f = op.to_fixed(xs[r].z, bad);
-        if (vs[r].z == cur) a += f;
-        else {
-          atomicAdd(&s_acc[cur], a);
-          cur = vs[r].z;
-          a = f;
-        }
-        f = op.to_fixed(xs[r].w, bad);
-        if (vs[r].w == cur) a += f;
-        else {
-          atomicAdd(&s_acc[cur], a);
-          cur = vs[r].w;
-          a = f;
-        }
-        atomicAdd(&s_acc[cur], a);
+      const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
+      xs[r] = __builtin_nontemporal_load(Xq + i);
+      vs[r] = load_rows(i, true);
+    }
+    for (; sb + 2u * STEPU <= nq; sb += STEPU) {
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const unsigned i = sb + STEPU + threadIdx.x + (unsigned)r * PB_THREADS;
+        nx[r] = __builtin_nontemporal_load(Xq + i);
+        nv[r] = load_rows(i, true);
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; r++) fold(xs[r], vs[r]);
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        xs[r] = nx[r];
+        vs[r] = nv[r];
       }
     }
 #pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      xs[r] = nx[r];
-      vs[r] = nv[r];
-    }
+    for (int r = 0; r < UNR; r++) fold(xs[r], vs[r]);
+    sb += STEPU;
+  }
+  // the last, partial step (q0 and q1 are multiples of 8 quads, so the 8 lanes of a group are valid together)
+#pragma unroll
+  for (int r = 0; r < UNR; r++) {
+    const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
+    const bool ok = i < nq;
+    if (ok) xs[r] = __builtin_nontemporal_load(Xq + i);
+    vs[r] = load_rows(i, ok);
+  }
+#pragma unroll
+  for (int r = 0; r < UNR; r++) {
+    const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
+    if (i < nq) fold(xs[r], vs[r]);
   }
   if (hub_ptr) {
     // edges of hub sources: 4 B per edge (u16 hub index + u16 row), the value of a quad's hubs comes from a table
