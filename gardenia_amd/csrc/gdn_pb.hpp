@@ -621,40 +621,40 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     if (i < nq) fold(xs[r], vs[r]);
   }
   if (hub_ptr) {
-    // edges of hub sources: 4 B per edge (u16 hub index + u16 row), the value of a quad's hubs comes from a table
-    // that stays in L2 (one 4-byte gather per distinct hub of the quad: the stream is sorted by hub)
-    const eoff_t h0 = hub_ptr[b] >> 2, h1 = hub_ptr[b + 1] >> 2;
-    const pb_u16x4 *HU = reinterpret_cast<const pb_u16x4 *>(hub_U);
-    const pb_u16x4 *HV = reinterpret_cast<const pb_u16x4 *>(hub_V);
-    constexpr int HUNR = 4;
-    for (eoff_t q = h0 + threadIdx.x; q < h1; q += (eoff_t)HUNR * PB_THREADS) {
-      pb_u16x4 hu[HUNR], hv[HUNR];
+    // edges of hub sources: 4 B per edge (u16 hub index + u16 row), 8 edges per lane and step with 16-byte loads;
+    // the values come from a table that stays in L2: one 4-byte gather per DISTINCT hub of the lane's run (the
+    // stream is sorted by hub, so a run of 8 edges holds 1-4 hubs)
+    const unsigned nh = (unsigned)((hub_ptr[b + 1] - hub_ptr[b]) >> 3);  // octets (bin ranges are multiples of 16)
+    const pb_u16x8 *HU = reinterpret_cast<const pb_u16x8 *>(hub_U) + (hub_ptr[b] >> 3);
+    const pb_u16x8 *HV = reinterpret_cast<const pb_u16x8 *>(hub_V) + (hub_ptr[b] >> 3);
+    constexpr int HUNR = 2;
+    for (unsigned o0 = threadIdx.x; o0 < nh; o0 += (unsigned)HUNR * PB_THREADS) {
+      pb_u16x8 hu[HUNR], hv[HUNR];
       float f0[HUNR];
 #pragma unroll
       for (int r = 0; r < HUNR; r++) {
-        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-        if (qq < h1) {
-          hu[r] = __builtin_nontemporal_load(HU + qq);
-          hv[r] = __builtin_nontemporal_load(HV + qq);
+        const unsigned o = o0 + (unsigned)r * PB_THREADS;
+        if (o < nh) {
+          hu[r] = __builtin_nontemporal_load(HU + o);
+          hv[r] = __builtin_nontemporal_load(HV + o);
         }
       }
 #pragma unroll
       for (int r = 0; r < HUNR; r++) {
-        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-        if (qq < h1) f0[r] = hub_val[hu[r].x];
+        const unsigned o = o0 + (unsigned)r * PB_THREADS;
+        if (o < nh) f0[r] = hub_val[hu[r][0]];
       }
 #pragma unroll
       for (int r = 0; r < HUNR; r++) {
-        const eoff_t qq = q + (eoff_t)r * PB_THREADS;
-        if (qq < h1) {
+        const unsigned o = o0 + (unsigned)r * PB_THREADS;
+        if (o < nh) {
           unsigned long long a = op.to_fixed(f0[r], bad);
-          atomicAdd(&s_acc[hv[r].x], a);
-          if (hu[r].y != hu[r].x) a = op.to_fixed(hub_val[hu[r].y], bad);
-          atomicAdd(&s_acc[hv[r].y], a);
-          if (hu[r].z != hu[r].y) a = op.to_fixed(hub_val[hu[r].z], bad);
-          atomicAdd(&s_acc[hv[r].z], a);
-          if (hu[r].w != hu[r].z) a = op.to_fixed(hub_val[hu[r].w], bad);
-          atomicAdd(&s_acc[hv[r].w], a);
+          atomicAdd(&s_acc[hv[r][0]], a);
+#pragma unroll
+          for (int k = 1; k < 8; k++) {
+            if (hu[r][k] != hu[r][k - 1]) a = op.to_fixed(hub_val[hu[r][k]], bad);
+            atomicAdd(&s_acc[hv[r][k]], a);
+          }
         }
       }
     }
