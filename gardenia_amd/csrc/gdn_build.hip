@@ -334,6 +334,16 @@ pb_mark_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PbMarkVis 
   gdn_expand_big_items(rowptr, big, vis);
 }
 
+// compact index i -> (i / per) * 2^lg + i % per: `per` vertices per slice, slices still 2^lg apart
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_respace_kernel(eoff_t *__restrict__ cidx, size_t n, uint64_t per, int lg) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) {
+    const eoff_t c = cidx[i];
+    cidx[i] = ((c / per) << lg) + (c % per);
+  }
+}
+
 // activity bitmap + original id of the first active vertex of every slice
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_slices_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cidx, unsigned n, int log_slice,
@@ -614,6 +624,39 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     }
     n_src = tot[0];
     n_dst = tot[1];
+    {
+      // Whole rounds: a full-size slice (128 KB of LDS) means one workgroup per CU, so a phase takes
+      // ceil(slices / CUs) rounds of about equal length -- 1585 chunks on 256 CUs are 6.2 rounds of work in the
+      // time of 7.  Spread the active vertices over rounds * CUs slices instead (fewer than 2^log slots used per
+      // slice; the compact index keeps its power-of-two slice stride so every shift below stays valid).
+      int ncu = 0;
+      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || ncu <= 0) ncu = 256;
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      const char *be = getenv("GDN_PB_BALANCE");  // 0 switches it off (A/B measurements)
+      const bool on = !(be && be[0] == '0');
+      auto per_slice = [&](uint64_t n_act, int lg, int lg_full) -> uint64_t {
+        const uint64_t cap = 1ull << lg;
+        const uint64_t ns = (n_act + cap - 1) >> lg;
+        if (!on || lg != lg_full || ns <= (uint64_t)ncu) return cap;
+        const uint64_t rounds = (ns + (uint64_t)ncu - 1) / (uint64_t)ncu;
+        uint64_t per = (n_act + rounds * ncu - 1) / (rounds * ncu);
+        per = (per + 3) & ~3ull;
+        return per < cap ? per : cap;
+      };
+      const uint64_t per_c = per_slice(n_src, log_chunk, PB_MAX_LOG_CHUNK), per_b = per_slice(n_dst, log_bin, PB_MAX_LOG_BIN);
+      if (per_c < (1ull << log_chunk)) {
+        hipLaunchKernelGGL(pb_respace_kernel, dim3(gdn_nblocks((uint64_t)m_global + 1)), dim3(GDN_BLOCK), 0, 0, cs.p,
+                           (size_t)m_global + 1, per_c, log_chunk);
+        n_src = ((n_src + per_c - 1) / per_c) << log_chunk;
+      }
+      if (per_b < (1ull << log_bin)) {
+        hipLaunchKernelGGL(pb_respace_kernel, dim3(gdn_nblocks((uint64_t)m + 1)), dim3(GDN_BLOCK), 0, 0, cd.p, (size_t)m + 1,
+                           per_b, log_bin);
+        n_dst = ((n_dst + per_b - 1) / per_b) << log_bin;
+      }
+      GDN_HIP(hipGetLastError());
+    }
     const unsigned nch = (unsigned)((n_src + (1u << log_chunk) - 1) >> log_chunk), nbn = (unsigned)((n_dst + (1u << log_bin) - 1) >> log_bin);
     const unsigned nchunks = nch ? nch : 1u, nbins = nbn ? nbn : 1u;
     GDN_TRY(p.src_bits.alloc(((size_t)m_global + 31) / 32 + 1));
