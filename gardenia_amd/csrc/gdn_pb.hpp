@@ -469,17 +469,26 @@ __device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad
   return ok ? r : 0ull;
 }
 
-// phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then op.finish(row, sum).
-// signed value * 2^shift -> two's complement fixed point (SpMV); |v * 2^shift| must stay < 2^62
+// signed value * 2^shift -> two's complement fixed point (SpMV); |v * 2^shift| must stay < 2^62.  Branch-free form
+// of (long long)(v * scale) (truncation toward zero): mantissa at bits 39..62, one clamped right shift, conditional
+// negation -- the compiler's float -> int64 conversion is a long divergent sequence, and phase B pays it per edge.
 __device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float scale, unsigned &bad) {
   const float t = v * scale;  // exact: scale is a power of two
-  if (!(fabsf(t) < 4.611686018427388e18f)) {  // also catches nan / inf
-    bad = 1u;
-    return 0ull;
-  }
-  return (unsigned long long)(long long)t;
+  const unsigned bits = __float_as_uint(t);
+  const unsigned mag_bits = bits & 0x7FFFFFFFu;
+  const bool ok = mag_bits < 0x5E800000u;  // |t| < 2^62 (also rejects inf / nan)
+  bad |= ok ? 0u : 1u;
+  const unsigned e = mag_bits >> 23;
+  const unsigned mant = (mag_bits & 0x7FFFFFu) | 0x800000u;
+  const unsigned long long m62 = (unsigned long long)(mant << 7) << 32;  // mant * 2^39
+  unsigned sh = 189u - e;  // |t| = mant * 2^(e - 150) = m62 >> (189 - e); e <= 188 when ok
+  sh = sh > 63u ? 63u : sh;
+  const unsigned long long mag = m62 >> sh;
+  const unsigned long long r = (bits >> 31) ? (0ull - mag) : mag;
+  return ok ? r : 0ull;
 }
 
+// phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then the fused epilogue of the rows (op).
 template <class Op>
 __global__ void __launch_bounds__(PB_THREADS)
 pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
