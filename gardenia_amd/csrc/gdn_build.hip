@@ -344,6 +344,13 @@ pb_respace_kernel(eoff_t *__restrict__ cidx, size_t n, uint64_t per, int lg) {
   }
 }
 
+// inverse of the compact index over the active vertices
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_inverse_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cidx, size_t n, uint32_t *__restrict__ inv) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n && flag[i]) inv[cidx[i]] = (uint32_t)i;
+}
+
 // activity bitmap + original id of the first active vertex of every slice
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_slices_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cidx, unsigned n, int log_slice,
@@ -504,7 +511,8 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
                   const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
                   uint16_t *__restrict__ V, const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
                   const float *__restrict__ ev_in, float *__restrict__ ev_out, int randv, int transposed,
-                  int src_major, const uint32_t *__restrict__ nd, const eoff_t *__restrict__ ds) {
+                  int src_major, const uint32_t *__restrict__ nd, const eoff_t *__restrict__ ds,
+                  const uint32_t *__restrict__ inv_s, const uint32_t *__restrict__ inv_d) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   const unsigned long long bmask = (1ull << bin_bits) - 1ull;
@@ -530,6 +538,10 @@ pb_scatter_kernel(const unsigned long long *__restrict__ keys, unsigned long lon
     if (ev_in) {  // value of this edge: find the column in its (ascending) CSR row
       unsigned long long row = (b << log_bin) + vl;  // destination
       vid_t col = (vid_t)((c << log_chunk) + ul);    // source
+      if (inv_s) {  // compacted layout: back to the original ids
+        row = inv_d[row];
+        col = (vid_t)inv_s[(size_t)col];
+      }
       if (transposed) {                               // out-CSR: row = source, column = destination
         const unsigned long long t = row;
         row = (unsigned long long)col;
@@ -558,18 +570,137 @@ pb_groups_kernel(const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, c
   for (eoff_t q = 0; q < ng; q++) G[gu + q] = identity ? (uint32_t)(gu + q) : (uint32_t)(gv + q);
 }
 
+// ---- hub selection: out-edge counts of the sources from a 1/16 sample of the rows (any classification is
+// correct, it only decides which edges take the cheap path), a log2 histogram of them, then the class flags
+#define PB_HUB_SAMPLE_LOG 4
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hub_sample_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
+                     uint32_t *__restrict__ cnt) {
+  // one wave per sampled row
+  const unsigned wid = (blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  const uint64_t row = (uint64_t)wid << PB_HUB_SAMPLE_LOG;
+  if (row >= (uint64_t)m) return;
+  const eoff_t b = rowptr[row], e = rowptr[row + 1];
+  for (eoff_t k = b + gdn_lane(); k < e; k += 64) atomicAdd(&cnt[colidx[k]], 1u);
+}
+
+// histogram buckets: 4 per octave; bucket(c) = 4*floor(log2 c) + the two bits below the leading one
+#define PB_HUB_BUCKETS 128
+__host__ __device__ static inline unsigned pb_hub_bucket(unsigned c) {
+  unsigned l = 0;
+  while ((c >> l) > 1u) l++;
+  return 4u * l + (l >= 2 ? ((c >> (l - 2)) & 3u) : 0u);
+}
+static inline unsigned pb_hub_bucket_floor(unsigned b) {  // smallest count that falls into bucket b (l >= 2)
+  const unsigned l = b >> 2, f = b & 3u;
+  return l >= 2 ? (4u + f) << (l - 2) : (1u << l);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hub_hist_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restrict__ hist /*PB_HUB_BUCKETS*/) {
+  __shared__ unsigned s_h[PB_HUB_BUCKETS];
+  if (threadIdx.x < PB_HUB_BUCKETS) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const unsigned c = cnt[i];
+    if (c) atomicAdd(&s_h[pb_hub_bucket(c)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hub_class_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned thr, uint8_t *__restrict__ cls,
+                    uint32_t *__restrict__ ids, unsigned cap, unsigned *__restrict__ n_ids) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const bool hub = cnt[i] >= thr;
+  cls[i] = hub ? 1 : 0;
+  if (hub) {
+    const unsigned pos = atomicAdd(n_ids, 1u);
+    if (pos < cap) ids[pos] = (uint32_t)i;
+  }
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const bool act = v < (unsigned)m && rowptr[v + 1] > rowptr[v];
+  const unsigned long long mask = __ballot(act);
+  if (gdn_lane() == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
+}
+
+// picks the hub sources of `in_csr` (at most 2^15, each with >= PB_HUB_MIN_PER_BIN expected edges per bin);
+// cls gets one byte per source id, hub_ids the ascending ids.  n_hubs == 0: no hub tier.
+#define PB_HUB_MIN_PER_BIN 2
+int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                        unsigned *n_hubs) {
+  *n_hubs = 0;
+  DevBuf<uint32_t> cnt;
+  DevBuf<unsigned> hist;
+  DevBuf<unsigned long long> nrows;
+  GDN_TRY(cnt.alloc((size_t)m_global));
+  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1));
+  GDN_TRY(nrows.alloc(1));
+  GDN_HIP(hipMemset(cnt.p, 0, (size_t)m_global * 4));
+  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1) * 4));
+  GDN_HIP(hipMemset(nrows.p, 0, 8));
+  const uint64_t sampled = ((uint64_t)g->m + (1u << PB_HUB_SAMPLE_LOG) - 1) >> PB_HUB_SAMPLE_LOG;
+  hipLaunchKernelGGL(pb_hub_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx,
+                     g->m, cnt.p);
+  hipLaunchKernelGGL(pb_hub_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, cnt.p, (size_t)m_global, hist.p);
+  hipLaunchKernelGGL(pb_count_rows_kernel, dim3(gdn_nblocks((uint64_t)g->m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->m,
+                     nrows.p);
+  GDN_HIP(hipGetLastError());
+  unsigned h[PB_HUB_BUCKETS];
+  unsigned long long active_rows = 0;
+  GDN_HIP(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&active_rows, nrows.p, 8, hipMemcpyDeviceToHost));
+  const uint64_t nbins = ((active_rows + (1ull << log_bin) - 1) >> log_bin) + 1;
+  // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
+  uint64_t per_bin = PB_HUB_MIN_PER_BIN;
+  if (const char *e = getenv("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
+  uint64_t want = (nbins * per_bin) >> PB_HUB_SAMPLE_LOG;
+  if (want < 4) want = 4;
+  if (want > 0x40000000ull) return GDN_OK;
+  unsigned bk = pb_hub_bucket((unsigned)want);
+  if (pb_hub_bucket_floor(bk) < want) bk++;
+  for (;; bk++) {  // threshold = floor of bucket bk; raise it until at most 2^15 sources qualify
+    if (bk >= PB_HUB_BUCKETS) return GDN_OK;
+    uint64_t above = 0;
+    for (unsigned j = bk; j < PB_HUB_BUCKETS; j++) above += h[j];
+    if (above == 0) return GDN_OK;
+    if (above <= (1u << PB_HUB_LOG)) break;
+  }
+  const unsigned thr = pb_hub_bucket_floor(bk);
+  GDN_TRY(cls.alloc((size_t)m_global));
+  GDN_TRY(hub_ids.alloc(1u << PB_HUB_LOG));
+  hipLaunchKernelGGL(pb_hub_class_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, cnt.p,
+                     (size_t)m_global, thr, cls.p, hub_ids.p, 1u << PB_HUB_LOG, hist.p + PB_HUB_BUCKETS);
+  GDN_HIP(hipGetLastError());
+  unsigned n = 0;
+  GDN_HIP(hipMemcpy(&n, hist.p + PB_HUB_BUCKETS, 4, hipMemcpyDeviceToHost));
+  if (n == 0 || n > (1u << PB_HUB_LOG)) return GDN_OK;  // (cannot exceed: the histogram counted them)
+  std::vector<uint32_t> ids(n);
+  GDN_HIP(hipMemcpy(ids.data(), hub_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::sort(ids.begin(), ids.end());  // hub k = k-th marked source in id order = its compact index in the hub layout
+  GDN_HIP(hipMemcpy(hub_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  *n_hubs = n;
+  return GDN_OK;
+}
+
+
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
              int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
   GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
-  GDN_REQUIRE(!(src_class && (rows_are_sources || edge_vals_in)), "source classes: in-CSR without edge values only");
+  GDN_REQUIRE(!(src_class && rows_are_sources), "source classes: in-CSR only");
   GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
               "pad / log_group");
   p.log_group = log_group;
   const unsigned grp = 1u << log_group;  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
-  GDN_REQUIRE(!(compact && edge_vals_in), "edge values are not supported on a compacted layout");
   GDN_REQUIRE(!(compact && rows_are_sources), "compaction is not supported on an out-CSR");
   const int32_t m = g->m;
   const unsigned long long n = g->nnz;
@@ -584,6 +715,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   p.compact = compact;
   uint64_t n_src = (uint64_t)p.m_global, n_dst = (uint64_t)p.m_local;
   DevBuf<eoff_t> cs, cd;  // compact index of every source id / row (exclusive scans of the flags)
+  DevBuf<uint32_t> inv_s, inv_d;  // compact index -> original id (only built to look edge values up again)
   if (compact) {
     DevBuf<uint32_t> sflag, dflag;
     DevBuf<unsigned long long> bigitems;
@@ -669,6 +801,14 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
                        sflag.p, cs.p, (unsigned)m_global, log_chunk, nchunks, p.src_bits.p, p.chunk_lo.p);
     hipLaunchKernelGGL(pb_slices_kernel, dim3(gdn_nblocks(((uint64_t)m + 31) / 32 + 1)), dim3(GDN_BLOCK), 0, 0, dflag.p,
                        cd.p, (unsigned)m, log_bin, nbins, p.dst_bits.p, p.bin_lo.p);
+    if (edge_vals_in) {
+      GDN_TRY(inv_s.alloc((size_t)nchunks << log_chunk));
+      GDN_TRY(inv_d.alloc((size_t)nbins << log_bin));
+      hipLaunchKernelGGL(pb_inverse_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, sflag.p, cs.p,
+                         (size_t)m_global, inv_s.p);
+      hipLaunchKernelGGL(pb_inverse_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, dflag.p, cd.p, (size_t)m,
+                         inv_d.p);
+    }
     GDN_HIP(hipGetLastError());
     GDN_HIP(hipDeviceSynchronize());
   }
@@ -856,7 +996,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
 #else
                          0,
 #endif
-                         rows_are_sources ? 1 : 0, src_major ? 1 : 0, v_delta ? nd.p : nullptr, v_delta ? ds.p : nullptr);
+                         rows_are_sources ? 1 : 0, src_major ? 1 : 0, v_delta ? nd.p : nullptr, v_delta ? ds.p : nullptr,
+                         (compact && ev_out) ? inv_s.p : nullptr, (compact && ev_out) ? inv_d.p : nullptr);
     if (v_delta) {  // pads repeat the tile's last row, then V (u16) -> one byte per edge + one u16 base per 32 edges
       hipLaunchKernelGGL(pb_pad_rows_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, tsu.p, ds.p, pv.p, psz_b.p,
                          p.nchunks, p.nbins, p.V.p);

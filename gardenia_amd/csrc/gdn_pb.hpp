@@ -96,11 +96,30 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              bool src_major = false,              // order inside a tile: (source, row) instead of (row, source)
              bool v_delta = false);               // rows as 8-bit distances (Vd, Vb) instead of u16 (V): see PbPlan::v8
 
+// Hub tier (gdn_pr.hip, gdn_spmv.hip): the edges of the <= 2^15 sources with the most out-edges live in a second layout
+// (one source chunk, tiles sorted by hub) that phase B reads directly; their source values come from a
+// PB_HUB_SLOTS-entry table refreshed per multiply (slot 2^15 = 0 for pad edges).
+#define PB_HUB_LOG 15
+#define PB_HUB_SLOTS ((1 << PB_HUB_LOG) + 1)
+// picks the hub sources of `in_csr` (gdn_build.hip): cls gets one byte per source id, hub_ids the ascending ids;
+// *n_hubs == 0: no hub tier
+int pb_pick_hubs(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                 unsigned *n_hubs);
+
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short pb_u16x4 __attribute__((ext_vector_type(4)));
 typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
+
+// hub_val[k] = x[hub_ids[k]] (PageRank: contrib, SpMV: x); the slots behind the hubs (incl. the pad slot 32768) stay 0
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_hub_gather_kernel(const float *__restrict__ contrib, const uint32_t *__restrict__ hub_ids, unsigned n_hubs,
+                     float *__restrict__ hub_val) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < PB_HUB_SLOTS) hub_val[k] = k < n_hubs ? contrib[hub_ids[k]] : 0.0f;
+}
+
 
 // exclusive scan over the PB_THREADS threads of a workgroup; scratch = PB_WAVES + 1 unsigned
 __device__ __forceinline__ unsigned pb_block_excl_scan(unsigned v, unsigned *scratch, unsigned *total) {
@@ -406,14 +425,24 @@ static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk,
                         const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
                         const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, const float *__restrict__ A,
-                        float *__restrict__ vals, int log_group) {
+                        float *__restrict__ vals, int log_group, const uint32_t *__restrict__ src_bits = nullptr,
+                        const uint32_t *__restrict__ chunk_lo = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
+  __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
   const unsigned c = chunk_order[blockIdx.x];
   const size_t base = (size_t)c << log_chunk;
-  for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
-    const size_t g = base + i;
-    s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+  if (src_bits) {  // compacted slice: the chunk's active columns, gathered from their original id range
+    if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0)
+      pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
+    else
+      pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
+                    [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
+  } else {
+    for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
+      const size_t g = base + i;
+      s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
+    }
   }
   if (threadIdx.x == 0) s_x[ch] = 0.0f;
   __syncthreads();
@@ -502,7 +531,9 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const eoff_t *__restrict__ hub_ptr = nullptr, const uint16_t *__restrict__ hub_U = nullptr,
                      const uint16_t *__restrict__ hub_V = nullptr, const float *__restrict__ hub_val = nullptr,
                      // delta-coded rows (PbPlan::v8, nullable): V is then not read
-                     const uint8_t *__restrict__ Vd = nullptr, const uint16_t *__restrict__ Vb = nullptr) {
+                     const uint8_t *__restrict__ Vd = nullptr, const uint16_t *__restrict__ Vb = nullptr,
+                     // per-edge factor of the hub stream (SpMV's Ax in hub order, nullable): value = hub_val * hub_A
+                     const float *__restrict__ hub_A = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
@@ -642,6 +673,24 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       for (int r = 0; r < HUNR; r++) {
         const unsigned o = o0 + (unsigned)r * PB_THREADS;
         if (o < nh) f0[r] = hub_val[hu[r][0]];
+      }
+      if (hub_A) {  // every edge has its own factor: product rounded like the main path (phase A), then converted
+        const pb_f32x4 *HA = reinterpret_cast<const pb_f32x4 *>(hub_A) + 2 * (hub_ptr[b] >> 3);
+#pragma unroll
+        for (int r = 0; r < HUNR; r++) {
+          const unsigned o = o0 + (unsigned)r * PB_THREADS;
+          if (o < nh) {
+            const pb_f32x4 a0 = __builtin_nontemporal_load(HA + 2 * (size_t)o), a1 = __builtin_nontemporal_load(HA + 2 * (size_t)o + 1);
+            const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float xv = f0[r];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+              if (k > 0 && hu[r][k] != hu[r][k - 1]) xv = hub_val[hu[r][k]];
+              atomicAdd(&s_acc[hv[r][k]], op.to_fixed(__fmul_rn(xv, av[k]), bad));
+            }
+          }
+        }
+        continue;
       }
 #pragma unroll
       for (int r = 0; r < HUNR; r++) {

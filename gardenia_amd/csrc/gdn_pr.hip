@@ -86,136 +86,6 @@ struct PrOp {
   }
 };
 
-#define PB_HUB_LOG 15
-#define PB_HUB_SLOTS ((1 << PB_HUB_LOG) + 1)
-
-// hub_val[k] = contrib[hub_ids[k]]; the slots behind the hubs (incl. the pad slot 32768) stay 0
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_hub_gather_kernel(const float *__restrict__ contrib, const uint32_t *__restrict__ hub_ids, unsigned n_hubs,
-                     float *__restrict__ hub_val) {
-  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (k < PB_HUB_SLOTS) hub_val[k] = k < n_hubs ? contrib[hub_ids[k]] : 0.0f;
-}
-
-// ---- hub selection: out-edge counts of the sources from a 1/16 sample of the rows (any classification is
-// correct, it only decides which edges take the cheap path), a log2 histogram of them, then the class flags
-#define PB_HUB_SAMPLE_LOG 4
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_hub_sample_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
-                     uint32_t *__restrict__ cnt) {
-  // one wave per sampled row
-  const unsigned wid = (blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
-  const uint64_t row = (uint64_t)wid << PB_HUB_SAMPLE_LOG;
-  if (row >= (uint64_t)m) return;
-  const eoff_t b = rowptr[row], e = rowptr[row + 1];
-  for (eoff_t k = b + gdn_lane(); k < e; k += 64) atomicAdd(&cnt[colidx[k]], 1u);
-}
-
-// histogram buckets: 4 per octave; bucket(c) = 4*floor(log2 c) + the two bits below the leading one
-#define PB_HUB_BUCKETS 128
-__host__ __device__ static inline unsigned pr_hub_bucket(unsigned c) {
-  unsigned l = 0;
-  while ((c >> l) > 1u) l++;
-  return 4u * l + (l >= 2 ? ((c >> (l - 2)) & 3u) : 0u);
-}
-static inline unsigned pr_hub_bucket_floor(unsigned b) {  // smallest count that falls into bucket b (l >= 2)
-  const unsigned l = b >> 2, f = b & 3u;
-  return l >= 2 ? (4u + f) << (l - 2) : (1u << l);
-}
-
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_hub_hist_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restrict__ hist /*PB_HUB_BUCKETS*/) {
-  __shared__ unsigned s_h[PB_HUB_BUCKETS];
-  if (threadIdx.x < PB_HUB_BUCKETS) s_h[threadIdx.x] = 0;
-  __syncthreads();
-  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
-    const unsigned c = cnt[i];
-    if (c) atomicAdd(&s_h[pr_hub_bucket(c)], 1u);
-  }
-  __syncthreads();
-  if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
-}
-
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_hub_class_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned thr, uint8_t *__restrict__ cls,
-                    uint32_t *__restrict__ ids, unsigned cap, unsigned *__restrict__ n_ids) {
-  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  const bool hub = cnt[i] >= thr;
-  cls[i] = hub ? 1 : 0;
-  if (hub) {
-    const unsigned pos = atomicAdd(n_ids, 1u);
-    if (pos < cap) ids[pos] = (uint32_t)i;
-  }
-}
-
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
-  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  const bool act = v < (unsigned)m && rowptr[v + 1] > rowptr[v];
-  const unsigned long long mask = __ballot(act);
-  if (gdn_lane() == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
-}
-
-// picks the hub sources of `in_csr` (at most 2^15, each with >= PB_HUB_MIN_PER_BIN expected edges per bin);
-// cls gets one byte per source id, hub_ids the ascending ids.  n_hubs == 0: no hub tier.
-#define PB_HUB_MIN_PER_BIN 2
-static int pr_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
-                        unsigned *n_hubs) {
-  *n_hubs = 0;
-  DevBuf<uint32_t> cnt;
-  DevBuf<unsigned> hist;
-  DevBuf<unsigned long long> nrows;
-  GDN_TRY(cnt.alloc((size_t)m_global));
-  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1));
-  GDN_TRY(nrows.alloc(1));
-  GDN_HIP(hipMemset(cnt.p, 0, (size_t)m_global * 4));
-  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1) * 4));
-  GDN_HIP(hipMemset(nrows.p, 0, 8));
-  const uint64_t sampled = ((uint64_t)g->m + (1u << PB_HUB_SAMPLE_LOG) - 1) >> PB_HUB_SAMPLE_LOG;
-  hipLaunchKernelGGL(pr_hub_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx,
-                     g->m, cnt.p);
-  hipLaunchKernelGGL(pr_hub_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, cnt.p, (size_t)m_global, hist.p);
-  hipLaunchKernelGGL(pr_count_rows_kernel, dim3(gdn_nblocks((uint64_t)g->m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->m,
-                     nrows.p);
-  GDN_HIP(hipGetLastError());
-  unsigned h[PB_HUB_BUCKETS];
-  unsigned long long active_rows = 0;
-  GDN_HIP(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
-  GDN_HIP(hipMemcpy(&active_rows, nrows.p, 8, hipMemcpyDeviceToHost));
-  const uint64_t nbins = ((active_rows + (1ull << log_bin) - 1) >> log_bin) + 1;
-  // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
-  uint64_t per_bin = PB_HUB_MIN_PER_BIN;
-  if (const char *e = getenv("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
-  uint64_t want = (nbins * per_bin) >> PB_HUB_SAMPLE_LOG;
-  if (want < 4) want = 4;
-  if (want > 0x40000000ull) return GDN_OK;
-  unsigned bk = pr_hub_bucket((unsigned)want);
-  if (pr_hub_bucket_floor(bk) < want) bk++;
-  for (;; bk++) {  // threshold = floor of bucket bk; raise it until at most 2^15 sources qualify
-    if (bk >= PB_HUB_BUCKETS) return GDN_OK;
-    uint64_t above = 0;
-    for (unsigned j = bk; j < PB_HUB_BUCKETS; j++) above += h[j];
-    if (above == 0) return GDN_OK;
-    if (above <= (1u << PB_HUB_LOG)) break;
-  }
-  const unsigned thr = pr_hub_bucket_floor(bk);
-  GDN_TRY(cls.alloc((size_t)m_global));
-  GDN_TRY(hub_ids.alloc(1u << PB_HUB_LOG));
-  hipLaunchKernelGGL(pr_hub_class_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, cnt.p,
-                     (size_t)m_global, thr, cls.p, hub_ids.p, 1u << PB_HUB_LOG, hist.p + PB_HUB_BUCKETS);
-  GDN_HIP(hipGetLastError());
-  unsigned n = 0;
-  GDN_HIP(hipMemcpy(&n, hist.p + PB_HUB_BUCKETS, 4, hipMemcpyDeviceToHost));
-  if (n == 0 || n > (1u << PB_HUB_LOG)) return GDN_OK;  // (cannot exceed: the histogram counted them)
-  std::vector<uint32_t> ids(n);
-  GDN_HIP(hipMemcpy(ids.data(), hub_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  std::sort(ids.begin(), ids.end());  // hub k = k-th marked source in id order = its compact index in the hub layout
-  GDN_HIP(hipMemcpy(hub_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  *n_hubs = n;
-  return GDN_OK;
-}
-
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ out_degree, int32_t m,
                   float *__restrict__ contrib) {
@@ -278,7 +148,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
     if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
-      st = pr_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
+      st = pb_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
                     p->n_hubs ? cls.p : nullptr, 0, false, v_delta);
@@ -402,7 +272,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
 #endif
     );
     if (plan->has_hub)
-      hipLaunchKernelGGL(pr_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
+      hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
                          plan->hub_ids.p, plan->n_hubs, plan->hub_val.p);
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }

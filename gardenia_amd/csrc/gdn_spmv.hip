@@ -20,6 +20,13 @@ struct gdn_spmv_plan {
   MpPlan mp;            // GDN_LAYOUT_CSR
   PbPlan pb;            // GDN_LAYOUT_PB
   DevBuf<float> Axp;    // PB: Ax in chunk-major tile order (pads 0)
+  // hub tier (gdn_pb.hpp): the edges of the highest-degree columns skip the per-edge value stream
+  bool has_hub = false;
+  PbPlan hub;
+  unsigned n_hubs = 0;
+  DevBuf<uint32_t> hub_ids;
+  DevBuf<float> hub_val;  // x of the hub columns, refreshed per multiply
+  DevBuf<float> hub_Ax;   // Ax of the hub edges in hub-layout order (pads 0)
   DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] max row length
   DevBuf<float> scale;  // PB: [0] = 2^shift, [1] = 2^-shift (per call)
 };
@@ -144,9 +151,32 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, csr, 0);
   } else {
-    st = pb_build(csr, n_cols, spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK), spmv_pick_log(csr->m, PB_MAX_LOG_BIN), p->pb,
-                  true, d_Ax, &p->Axp, false, false, /*pad=*/32, /*log_group=*/5, nullptr, 0, false,
-                  /*v_delta=*/getenv("GDN_PB_V8") && getenv("GDN_PB_V8")[0] == '1');  // off by default, see gdn_pr.hip
+    // compacted like PageRank's layout (columns that occur / rows that have entries), rows of whole 128-byte lines;
+    // GDN_PB_COMPACT=0 / GDN_PB_HUBS=0 switch the two refinements off (A/B measurements)
+    const int lc = spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK), lb = spmv_pick_log(csr->m, PB_MAX_LOG_BIN);
+    const char *ce = getenv("GDN_PB_COMPACT"), *he = getenv("GDN_PB_HUBS"), *ve = getenv("GDN_PB_V8");
+    const bool compact = !(ce && ce[0] == '0');
+    const bool v_delta = ve && ve[0] == '1';  // off by default, see gdn_pr.hip
+    uint64_t hub_min_nnz = 1ull << 24;
+    if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    DevBuf<uint8_t> cls;
+    st = GDN_OK;
+    if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0')) st = pb_pick_hubs(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs);
+    if (st == GDN_OK)
+      st = pb_build(csr, n_cols, lc, lb, p->pb, true, d_Ax, &p->Axp, compact, false, /*pad=*/32, /*log_group=*/5,
+                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta);
+    if (st == GDN_OK && p->n_hubs) {
+      st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true);
+      if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
+        gdn_set_error("gdn_spmv_plan_create: hub layout does not line up with the main layout");
+        st = GDN_ERR_INVALID;
+      }
+      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS);
+      if (st == GDN_OK) {
+        p->hub.G.release();
+        p->has_hub = true;
+      }
+    }
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
     if (st == GDN_OK) {
@@ -207,12 +237,17 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
-                     pb.log_group);
+                     pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr);
+  if (plan->has_hub)
+    hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_x, plan->hub_ids.p,
+                       plan->n_hubs, plan->hub_val.p);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
-                     pb.errflag.p, nullptr, nullptr, op, 0, 0u, nullptr, nullptr, nullptr, nullptr, pb.v8 ? pb.Vd.p : nullptr,
-                     pb.v8 ? pb.Vb.p : nullptr);
+                     pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op, 0, 0u,
+                     plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
+                     plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr,
+                     pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, plan->has_hub ? plan->hub_Ax.p : nullptr);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

@@ -259,6 +259,37 @@ def test_pr_delta_coded_rows_are_bitwise_neutral(orc, monkeypatch, layout_env):
     np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=0)
 
 
+@pytest.mark.parametrize("env", [{}, {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1"},
+                                 {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1", "GDN_PB_V8": "1"},
+                                 {"GDN_PB_COMPACT": "0"}])
+def test_spmv_pb_layout_variants(orc, monkeypatch, env):
+    """SpMV on the propagation-blocked layout: compacted (default), with the hub tier forced on at this size (hub edges
+    multiply x[hub] by their own Ax inside phase B), with delta-coded rows, and uncompacted -- all against the oracle,
+    and bit-identical to each other (integer accumulation)."""
+    g = graphio.rmat_graph(16, 16, seed=14)
+    rng = np.random.default_rng(4)
+    Ax = (rng.random(g.nnz) - 0.5).astype(np.float32)
+    x = (rng.random(g.m) - 0.5).astype(np.float32)
+    y0 = rng.random(g.m).astype(np.float32)
+    G = solvers.Graph(csr=g, in_csr=g)
+    want = orc.spmv(g, Ax, x, y0)
+    monkeypatch.setenv("GDN_PB_HUBS", "0")
+    sp = solvers.ResidentSpMV(G, Ax, layout=1)
+    ref = sp.multiply(x, y0)
+    sp.close()
+    monkeypatch.delenv("GDN_PB_HUBS")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    sp = solvers.ResidentSpMV(G, Ax, layout=1)
+    got = sp.multiply(x, y0)
+    got2 = sp.multiply(x, got)  # a second multiply on the same plan: y accumulates
+    sp.close()
+    assert np.array_equal(got, ref)
+    np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=1e-6)
+    np.testing.assert_allclose(got2, orc.spmv(g, Ax, x, want), rtol=REL_TOL, atol=1e-5)
+    assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)
+
+
 def test_spmv_delta_coded_rows(orc, monkeypatch):
     g = graphio.rmat_graph(15, 8, seed=13)
     rng = np.random.default_rng(3)
