@@ -308,6 +308,33 @@ def test_spmv_delta_coded_rows(orc, monkeypatch):
     np.testing.assert_allclose(ys[1], want, rtol=REL_TOL, atol=1e-6)
 
 
+@pytest.mark.parametrize("shape", ["star_out", "star_in", "two_hubs_only", "empty_rows"])
+def test_pr_hub_tier_degenerate_graphs(orc, monkeypatch, shape):
+    """Corner cases of the two-layout plan: every edge leaves a hub (the main layout is EMPTY), every edge enters one
+    row, no edges at all in most bins."""
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    monkeypatch.setenv("GDN_PB_HUB_MIN", "1")
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    m = 40000
+    if shape == "star_out":  # vertex 0 -> everybody
+        src, dst = np.zeros(m - 1, np.int64), np.arange(1, m)
+    elif shape == "star_in":  # everybody -> vertex 0
+        src, dst = np.arange(1, m), np.zeros(m - 1, np.int64)
+    elif shape == "two_hubs_only":  # two sources own all edges, scattered rows
+        rng = np.random.default_rng(1)
+        dst = rng.permutation(m)[:5000]
+        src = np.where(np.arange(5000) % 2 == 0, 7, 31000)
+    else:  # a few edges between ids far apart
+        src, dst = np.array([5, 39999, 20000]), np.array([39999, 5, 1])
+    g = graphio.build_csr(m, src, dst)
+    gi = graphio.transpose(g)
+    want, it, _ = orc.pr(gi, g.degrees())
+    got = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    st = solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), got)
+    assert st["iterations"] == it
+    np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=0)
+
+
 def test_pr_hub_tier_is_bitwise_neutral(monkeypatch):
     """PB layout with the hub tier (edges of the highest-degree sources bypass the per-edge value stream) against the
     same layout without it: integer accumulation makes the two bit-identical; and the tier really is in use."""
