@@ -1,4 +1,5 @@
-// gdn_pb.hpp -- propagation-blocked row reduction with LDS-resident slices (PageRank pull).
+// gdn_pb.hpp -- propagation-blocked row reduction with LDS-resident slices (PageRank pull, SpMV; layout also
+// used by the dense BFS / SSSP sweeps).
 //
 // Why: on MI355X a divergent 4-byte gather costs a vector-memory issue slot per cache line;
 // tools/gather_probe measures 54 G gathers/s out of a 512 MiB table and ~200 G/s even when the
@@ -9,24 +10,26 @@
 // (include/segmenting.h, include/prop_blocking.h, src/pr/push_pb.cu, src/pr/partition.cu);
 // this is the CDNA4 form of it, built around the 160 KB LDS instead of a cache:
 //
-//   edges are grouped into TILES (source chunk c, destination bin b): chunk = 2^log_chunk
-//   consecutive source ids (fp32 slice = 128 KB of LDS), bin = 2^log_bin consecutive
-//   destination rows (u64 accumulators = 128 KB of LDS).  Every tile is padded to a multiple
-//   of 8 edges.  Static data per (padded) edge:
+//   edges are grouped into TILES (source chunk c, destination bin b): chunk = up to 2^log_chunk
+//   source ids (fp32 slice = 128 KB of LDS), bin = up to 2^log_bin destination rows (u64
+//   accumulators = 128 KB of LDS); with `compact` the slices are cut over the vertices that occur
+//   at all and spread over whole rounds of 256 workgroups.  Every tile is padded to `pad` edges
+//   (PageRank / SpMV: 32 = whole 128-byte lines of vals).  Static data per (padded) edge:
 //     U[e]  u16  source id within its chunk, CHUNK-major order (pad = chunk size -> a 0.0 slot)
-//     V[e'] u16  destination row within its bin, BIN-major order (pad = 0)
-//     G[e/8] u32 for each group of 8 edges in chunk-major order: its group index in bin-major
+//     V[e'] u16  destination row within its bin, BIN-major order (optionally 8-bit deltas: v8)
+//     G[e >> log_group] u32 per group of edges in chunk-major order: its group index in bin-major
 //   Per iteration:
-//   phase A (pb_expand_kernel, one workgroup per chunk): contrib[chunk] -> LDS (coalesced);
-//       one flat sweep over the chunk's groups: 16-byte U load, 8 LDS gathers, two 16-byte
-//       stores into the bin-major vals array at G[g].
+//   phase A (pb_expand_kernel, one workgroup per chunk): x[chunk] -> LDS (coalesced, squeezed
+//       through the activity bitmap); one flat sweep over the chunk's edges: 8-byte U load per lane,
+//       4 LDS gathers, one 16-byte store into the bin-major vals array at G[group].
 //   phase B (pb_accumulate_kernel, one workgroup per bin): ONE contiguous range of vals/V per
 //       bin streamed with 16-/8-byte loads; each value is converted to 2^-62 fixed point and
 //       added with ds_add_u64 (integer LDS atomics are 14x faster than float ones here, and
 //       integer addition is associative, so the sums are BITWISE REPRODUCIBLE); then the fused
-//       epilogue of the pull iteration over the bin's rows (coalesced).
-//   HBM traffic per edge ~ (2 + 0.5 + 4) + (4 + 2) = 12.5 B x 1.05 (padding), all streamed; no
-//   vector-memory gather or scatter is left on the path.
+//       epilogue of the rows (coalesced, 16-byte accesses).  Edges of HUB sources (second layout,
+//       sorted by hub) are read here directly as (hub, row) pairs, their value from a small table.
+//   HBM traffic per main-layout edge ~ (2 + 0.125 + 4) + (4 + 2) = 12.1 B, per hub edge 4 B, all
+//   streamed; no vector-memory gather or scatter is left on the per-edge path.
 //
 // Fixed point: PageRank contributions lie in [0,1] and every row sum is <= the total rank mass
 // <= 1 (no dangling redistribution in the reference, src/pr/omp_base.cc), so sum*2^62 fits a
