@@ -246,6 +246,8 @@ struct PbKeyVis {
   // (row, source).  nvalid: per-lane count of the edges that got a real key.
   const uint8_t *__restrict__ cls = nullptr;
   int want = 0;
+  const uint8_t *__restrict__ dcls = nullptr;  // row classes (original row ids), same convention as cls
+  int dwant = 0;
   int src_major = 0;
   unsigned long long sentinel = 0;
   unsigned long long nvalid = 0;
@@ -260,7 +262,7 @@ struct PbKeyVis {
         row = col;
         col = t;
       }
-      if (cls && (int)cls[col] != want) {
+      if ((cls && (int)cls[col] != want) || (dcls && (int)dcls[row] != dwant)) {
         keys[k] = sentinel;
         return;
       }
@@ -317,14 +319,17 @@ struct PbMarkVis {
 };
 
 __global__ void __launch_bounds__(GDN_BLOCK)
-pb_mark_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, PbMarkVis vis, uint32_t *__restrict__ dflag) {
+pb_mark_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, PbMarkVis vis, uint32_t *__restrict__ dflag,
+               const uint8_t *__restrict__ dcls, int dwant, int rows_of_class_only) {
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
   const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
   eoff_t b = 0, e = 0;
   if (v < (unsigned)m) {
     b = rowptr[v];
     e = rowptr[v + 1];
-    dflag[v] = e > b ? 1u : 0u;
+    // rows_of_class_only: the row slices hold the rows of class dwant only (hub-row layout); otherwise every row
+    // with entries, whatever its class (the bins of the main and hub-source layouts must be the same)
+    dflag[v] = (e > b && (!rows_of_class_only || (int)dcls[v] == dwant)) ? 1u : 0u;
   }
   gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
 }
@@ -690,9 +695,92 @@ int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8
 }
 
 
+// ---- hub ROWS (PageRank): the rows with the most in-edges, at most max_rows of them and each with >= min_deg
+// in-edges; dcls gets one byte per row, row_ids the ascending ids.  Degrees are exact (row offsets).
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hubrow_hist_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned *__restrict__ hist) {
+  __shared__ unsigned s_h[PB_HUB_BUCKETS];
+  if (threadIdx.x < PB_HUB_BUCKETS) s_h[threadIdx.x] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const eoff_t d = rowptr[i + 1] - rowptr[i];
+    if (d) atomicAdd(&s_h[pb_hub_bucket(d > 0xFFFFFFFFull ? 0xFFFFFFFFu : (unsigned)d)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hubrow_class_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned thr, uint8_t *__restrict__ dcls,
+                       uint32_t *__restrict__ ids, unsigned cap, unsigned *__restrict__ n_ids) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= (size_t)m) return;
+  const bool hub = rowptr[i + 1] - rowptr[i] >= (eoff_t)thr;
+  dcls[i] = hub ? 1 : 0;
+  if (hub) {
+    const unsigned pos = atomicAdd(n_ids, 1u);
+    if (pos < cap) ids[pos] = (uint32_t)i;
+  }
+}
+
+int pb_pick_hub_rows(const gdn_graph *g, unsigned max_rows, uint64_t min_deg, DevBuf<uint8_t> &dcls, DevBuf<uint32_t> &row_ids,
+                     unsigned *n_rows) {
+  *n_rows = 0;
+  if (max_rows == 0) return GDN_OK;
+  DevBuf<unsigned> hist;
+  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1));
+  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1) * 4));
+  hipLaunchKernelGGL(pb_hubrow_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->m, hist.p);
+  GDN_HIP(hipGetLastError());
+  unsigned h[PB_HUB_BUCKETS];
+  GDN_HIP(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
+  if (min_deg < 4) min_deg = 4;
+  if (min_deg > 0x40000000ull) return GDN_OK;
+  unsigned bk = pb_hub_bucket((unsigned)min_deg);
+  if (pb_hub_bucket_floor(bk) < min_deg) bk++;
+  for (;; bk++) {
+    if (bk >= PB_HUB_BUCKETS) return GDN_OK;
+    uint64_t above = 0;
+    for (unsigned j = bk; j < PB_HUB_BUCKETS; j++) above += h[j];
+    if (above == 0) return GDN_OK;
+    if (above <= max_rows) break;
+  }
+  GDN_TRY(dcls.alloc((size_t)g->m));
+  GDN_TRY(row_ids.alloc(max_rows));
+  hipLaunchKernelGGL(pb_hubrow_class_kernel, dim3(gdn_nblocks((uint64_t)g->m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->m,
+                     pb_hub_bucket_floor(bk), dcls.p, row_ids.p, max_rows, hist.p + PB_HUB_BUCKETS);
+  GDN_HIP(hipGetLastError());
+  unsigned n = 0;
+  GDN_HIP(hipMemcpy(&n, hist.p + PB_HUB_BUCKETS, 4, hipMemcpyDeviceToHost));
+  if (n == 0 || n > max_rows) return GDN_OK;
+  std::vector<uint32_t> ids(n);
+  GDN_HIP(hipMemcpy(ids.data(), row_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+  std::sort(ids.begin(), ids.end());  // hub row k = k-th marked row in id order = its compact row index in the hub-row layout
+  GDN_HIP(hipMemcpy(row_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+  *n_rows = n;
+  return GDN_OK;
+}
+
+// slots used per slice when n_act active vertices are spread over whole rounds of workgroups (see pb_build)
+uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full) {
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (ncu <= 0) ncu = 256;
+  const char *be = getenv("GDN_PB_BALANCE");  // 0 switches the spreading off (A/B measurements)
+  const bool on = !(be && be[0] == '0');
+  const uint64_t cap = 1ull << lg;
+  const uint64_t ns = (n_act + cap - 1) >> lg;
+  if (!on || lg != lg_full || ns <= (uint64_t)ncu) return cap;
+  const uint64_t rounds = (ns + (uint64_t)ncu - 1) / (uint64_t)ncu;
+  uint64_t per = (n_act + rounds * ncu - 1) / (rounds * ncu);
+  per = (per + 3) & ~3ull;
+  return per < cap ? per : cap;
+}
+
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
-             int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta) {
+             int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta,
+             const uint8_t *dst_class, int want_dst, bool rows_of_class_only, bool no_gaps) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
   GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
   GDN_REQUIRE(!(src_class && rows_are_sources), "source classes: in-CSR only");
@@ -713,6 +801,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   p.log_chunk = log_chunk;
   p.log_bin = log_bin;
   p.compact = compact;
+  p.chunk_slots = 1u << log_chunk;
   uint64_t n_src = (uint64_t)p.m_global, n_dst = (uint64_t)p.m_local;
   DevBuf<eoff_t> cs, cd;  // compact index of every source id / row (exclusive scans of the flags)
   DevBuf<uint32_t> inv_s, inv_d;  // compact index -> original id (only built to look edge values up again)
@@ -740,7 +829,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     mv.mark = sflag.p;
     mv.cls = src_class;
     mv.want = want_class;
-    hipLaunchKernelGGL(pb_mark_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, mv, dflag.p);
+    hipLaunchKernelGGL(pb_mark_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, mv, dflag.p,
+                       dst_class, want_dst, (dst_class && rows_of_class_only) ? 1 : 0);
     hipLaunchKernelGGL(pb_mark_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, mv);
     GDN_HIP(hipGetLastError());
     GDN_TRY(gdn_exclusive_scan_u32_to_u64(sflag.p, cs.p, (size_t)m_global, 0));
@@ -761,22 +851,9 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       // ceil(slices / CUs) rounds of about equal length -- 1585 chunks on 256 CUs are 6.2 rounds of work in the
       // time of 7.  Spread the active vertices over rounds * CUs slices instead (fewer than 2^log slots used per
       // slice; the compact index keeps its power-of-two slice stride so every shift below stays valid).
-      int ncu = 0;
-      if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0) != hipSuccess || ncu <= 0) ncu = 256;
-      int dev = 0;
-      if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-      const char *be = getenv("GDN_PB_BALANCE");  // 0 switches it off (A/B measurements)
-      const bool on = !(be && be[0] == '0');
-      auto per_slice = [&](uint64_t n_act, int lg, int lg_full) -> uint64_t {
-        const uint64_t cap = 1ull << lg;
-        const uint64_t ns = (n_act + cap - 1) >> lg;
-        if (!on || lg != lg_full || ns <= (uint64_t)ncu) return cap;
-        const uint64_t rounds = (ns + (uint64_t)ncu - 1) / (uint64_t)ncu;
-        uint64_t per = (n_act + rounds * ncu - 1) / (rounds * ncu);
-        per = (per + 3) & ~3ull;
-        return per < cap ? per : cap;
-      };
-      const uint64_t per_c = per_slice(n_src, log_chunk, PB_MAX_LOG_CHUNK), per_b = per_slice(n_dst, log_bin, PB_MAX_LOG_BIN);
+      const uint64_t per_c = pb_slots_per_slice(n_src, log_chunk, PB_MAX_LOG_CHUNK);
+      const uint64_t per_b = pb_slots_per_slice(n_dst, log_bin, PB_MAX_LOG_BIN);
+      p.chunk_slots = (unsigned)per_c;
       if (per_c < (1ull << log_chunk)) {
         hipLaunchKernelGGL(pb_respace_kernel, dim3(gdn_nblocks((uint64_t)m_global + 1)), dim3(GDN_BLOCK), 0, 0, cs.p,
                            (size_t)m_global + 1, per_c, log_chunk);
@@ -873,9 +950,11 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     vis.v = 0;
     vis.cls = src_class;
     vis.want = want_class;
+    vis.dcls = dst_class;
+    vis.dwant = want_dst;
     vis.src_major = src_major ? 1 : 0;
     vis.sentinel = 1ull << key_bits;
-    vis.nvalid_out = src_class ? nvalid.p : nullptr;
+    vis.nvalid_out = (src_class || dst_class) ? nvalid.p : nullptr;
     hipLaunchKernelGGL(pb_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
     hipLaunchKernelGGL(pb_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
     GDN_HIP(hipGetLastError());
@@ -888,12 +967,12 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     bigitems.release();
     cs.release();
     cd.release();
-    if (src_class) {  // the edges of the other class carry the sentinel key: they sort behind the n_use real keys
+    if (src_class || dst_class) {  // the edges of the other classes carry the sentinel key: they sort behind the n_use real keys
       GDN_HIP(hipMemcpy(&n_use, nvalid.p, 8, hipMemcpyDeviceToHost));
       p.nnz = n_use;
     }
     const unsigned long long *sorted = nullptr;
-    GDN_TRY(sort_keys(ka, kb, n, key_bits + (src_class ? 1u : 0u), &sorted));
+    GDN_TRY(sort_keys(ka, kb, n, key_bits + ((src_class || dst_class) ? 1u : 0u), &sorted));
     if (n_use == 0) {
       hipLaunchKernelGGL(pb_fill_u64_kernel, dim3(gdn_nblocks(ntiles + 1)), dim3(GDN_BLOCK), 0, 0, tsu.p, ntiles + 1,
                          (eoff_t)0);
@@ -936,8 +1015,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
         return a;
       };
       // src_major layouts (one chunk, read by phase B only) keep U and V at the SAME positions: no extra gaps
-      const eoff_t al_c = src_major ? (eoff_t)pad : pick_align(cs[p.nchunks], p.nchunks);
-      const eoff_t al_b = src_major ? (eoff_t)pad : pick_align(bs[p.nbins], p.nbins);
+      const eoff_t al_c = (src_major || no_gaps) ? (eoff_t)pad : pick_align(cs[p.nchunks], p.nchunks);
+      const eoff_t al_b = (src_major || no_gaps) ? (eoff_t)pad : pick_align(bs[p.nbins], p.nbins);
       std::vector<eoff_t> ca((size_t)p.nchunks + 1, 0), ba((size_t)p.nbins + 1, 0);
       for (unsigned c = 0; c < p.nchunks; c++) {
         du[c] = ca[c] - cs[c];
@@ -979,7 +1058,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     }
     const unsigned long long fb = (n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
     hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p,
-                       n_pad + grp, (uint16_t)(1u << log_chunk));
+                       n_pad + grp, (uint16_t)p.chunk_slots);  // pad edges read the zero slot behind the slice
     GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + grp) * sizeof(uint16_t), 0));
     float *ev_out = nullptr;
     if (edge_vals_in && edge_vals_out) {

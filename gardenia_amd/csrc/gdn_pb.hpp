@@ -52,6 +52,7 @@ struct PbPlan {
   int32_t m_global = 0;  // source ids
   uint64_t nnz = 0;
   int log_chunk = 0, log_bin = 0;
+  unsigned chunk_slots = 0;       // source slots used per chunk (<= 2^log_chunk) = the id of the zero slot pad edges read
   int log_group = 3;              // edges per entry of G = 2^log_group (tiles are padded to a multiple of it)
   uint32_t nchunks = 0, nbins = 0;
   uint64_t n_pad = 0;             // padded edge count (multiple of the group size) = length of U, V, vals
@@ -97,7 +98,12 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              const uint8_t *src_class = nullptr,  // per global source id: only edges whose source has class
              int want_class = 0,                  //   `want_class` are laid out (PageRank hub tier, gdn_pr.hip)
              bool src_major = false,              // order inside a tile: (source, row) instead of (row, source)
-             bool v_delta = false);               // rows as 8-bit distances (Vd, Vb) instead of u16 (V): see PbPlan::v8
+             bool v_delta = false,                // rows as 8-bit distances (Vd, Vb) instead of u16 (V): see PbPlan::v8
+             const uint8_t *dst_class = nullptr,  // per row: only edges whose row has class `want_dst` are laid out
+             int want_dst = 0,
+             bool rows_of_class_only = false,     // the row slices hold the rows of that class only (hub-row layout)
+             bool no_gaps = false);               // slice starts padded to `pad` only: with ONE bin (or chunk) U and V
+                                                  // then sit at the same positions
 
 // Hub tier (gdn_pr.hip, gdn_spmv.hip): the edges of the <= 2^15 sources with the most out-edges live in a second layout
 // (one source chunk, tiles sorted by hub) that phase B reads directly; their source values come from a
@@ -108,6 +114,11 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
 // *n_hubs == 0: no hub tier
 int pb_pick_hubs(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
                  unsigned *n_hubs);
+
+// the rows with the most in-edges (gdn_build.hip): at most max_rows rows with >= min_deg in-edges each
+uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full);  // vertices per slice after round balancing
+int pb_pick_hub_rows(const gdn_graph *in_csr, unsigned max_rows, uint64_t min_deg, DevBuf<uint8_t> &dcls,
+                     DevBuf<uint32_t> &row_ids, unsigned *n_rows);
 
 #ifdef __HIPCC__
 typedef unsigned short pb_u16x8 __attribute__((ext_vector_type(8)));
@@ -351,12 +362,36 @@ __device__ __forceinline__ double pb_epilogue4(const uint32_t *__restrict__ bits
   return dsum;
 }
 
-// phase A: vals[8*G[g] + i] = x[chunk*CH + U[8*g + i]]
+// float in [0,1] -> 2^-62 fixed point (truncating); flags anything else.  Branch-free: the 24-bit mantissa is
+// placed at bits 39..62 (the image of 1.0) and shifted right by 127 - exponent, clamped to 63 (a 64-bit shift only
+// looks at 6 bits) -- the same bits as "mant << (e - 88) or mant >> (88 - e)", in a dozen instructions instead of
+// five nested exec-mask regions per value (phase B spent 57 % of its time issuing VALU work, most of it here).
+__device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad) {
+  const unsigned bits = __float_as_uint(v);
+  const bool ok = bits <= 0x3F800000u;  // +0 .. 1.0; negative, > 1, inf and nan have larger bit patterns
+  bad |= ok ? 0u : 1u;
+  const unsigned e = bits >> 23;  // biased exponent (<= 127 when ok)
+  const unsigned mant = (bits & 0x7FFFFFu) | 0x800000u;
+  const unsigned long long m62 = (unsigned long long)(mant << 7) << 32;  // mant * 2^39
+  unsigned sh = 127u - e;
+  sh = sh > 63u ? 63u : sh;  // zero / denormal / tiny: everything is shifted out (m62 < 2^63)
+  const unsigned long long r = m62 >> sh;
+  return ok ? r : 0ull;
+}
+
+// phase A: vals[group(G[g]) + i] = x[chunk*CH + U[...]]
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
                  const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
                  const uint32_t *__restrict__ G, float *__restrict__ vals, const uint32_t *__restrict__ src_bits,
-                 const uint32_t *__restrict__ chunk_lo, unsigned split, int log_group, int nt_store = 0) {
+                 const uint32_t *__restrict__ chunk_lo, unsigned split, int log_group, int nt_store = 0,
+                 // hub-ROW tier (nullable): the chunk's edges into the hr_n highest in-degree rows are not written to
+                 // vals; their values are added up here, in hr_n u64 accumulators behind the slice, and ONE partial sum
+                 // per (chunk, hub row) goes to hr_partial[chunk * hr_n + row] (integer sums: exact, order independent)
+                 const eoff_t *__restrict__ hr_ptr = nullptr, const uint16_t *__restrict__ hr_U = nullptr,
+                 const uint16_t *__restrict__ hr_R = nullptr, unsigned hr_n = 0,
+                 unsigned long long *__restrict__ hr_partial = nullptr, unsigned *__restrict__ errflag = nullptr,
+                 unsigned pad_slot = 0) {  // PbPlan::chunk_slots (0 = 2^log_chunk)
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
@@ -382,7 +417,8 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
       s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
     }
   }
-  if (threadIdx.x == 0) s_x[ch] = 0.0f;  // zero slot for pad edges
+  const unsigned zslot = pad_slot ? pad_slot : ch;
+  if (threadIdx.x == 0) s_x[zslot] = 0.0f;  // zero slot for pad edges
   __syncthreads();
   // half-groups: lane pair (2i, 2i+1) handles group i; each lane loads 4 source ids (8 B),
   // gathers 4 values from LDS and stores 16 B, so a wave store covers whole 64-byte lines
@@ -421,6 +457,72 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
       }
     }
   }
+  if (hr_ptr && part == 0) {
+    unsigned long long *s_hr = reinterpret_cast<unsigned long long *>(s_x + zslot + 4);  // 16 bytes behind the zero slot
+    for (unsigned i = threadIdx.x; i < hr_n; i += PB_THREADS) s_hr[i] = 0ull;
+    __syncthreads();
+    const unsigned nq = (unsigned)((hr_ptr[c + 1] - hr_ptr[c]) >> 2);
+    const pb_u16x4 *HU = reinterpret_cast<const pb_u16x4 *>(hr_U) + (hr_ptr[c] >> 2);
+    const pb_u16x4 *HR = reinterpret_cast<const pb_u16x4 *>(hr_R) + (hr_ptr[c] >> 2);
+    unsigned bad = 0u;
+    // every thread folds ONE contiguous block of the (row-sorted) edge list: a hub row owns hundreds of consecutive
+    // edges per chunk, and one atomic per lane and quad made its accumulator the bottleneck (phase A 2.2 -> 2.9 ms);
+    // a block of ~20 quads turns that into one atomic per thread and run
+    const unsigned blk = (nq + PB_THREADS - 1) / PB_THREADS;
+    const unsigned qb = threadIdx.x * blk, qe = qb + blk < nq ? qb + blk : nq;
+    unsigned cur = 0xFFFFFFFFu;
+    unsigned long long acc = 0ull;
+    constexpr int HRB = 8;  // quads loaded ahead of the fold
+    for (unsigned q = qb; q < qe; q += HRB) {
+      pb_u16x4 u[HRB], v[HRB];
+#pragma unroll
+      for (int j = 0; j < HRB; j++)
+        if (q + j < qe) {
+          u[j] = HU[q + j];
+          v[j] = HR[q + j];
+        }
+#pragma unroll
+      for (int j = 0; j < HRB; j++) {
+        if (q + j < qe) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const unsigned row = v[j][k];
+            const unsigned long long f = pb_to_fixed(s_x[u[j][k]], bad);
+            if (row == cur) acc += f;
+            else {
+              if (cur != 0xFFFFFFFFu) atomicAdd(&s_hr[cur], acc);
+              cur = row;
+              acc = f;
+            }
+          }
+        }
+      }
+    }
+    if (cur != 0xFFFFFFFFu) atomicAdd(&s_hr[cur], acc);
+    if (bad) *errflag = 1u;
+    __syncthreads();
+    for (unsigned i = threadIdx.x; i < hr_n; i += PB_THREADS) hr_partial[(size_t)c * hr_n + i] = s_hr[i];
+  }
+}
+
+// hub-row totals: total[r] = SUM over chunks of partial[c * n + r].  64 rows x 16 chunk lanes per workgroup (a thread
+// per row walking all chunks alone is one long chain of dependent-latency loads: 0.5 ms for 1792 chunks)
+static __global__ void __launch_bounds__(PB_THREADS)
+pb_hubrow_reduce_kernel(const unsigned long long *__restrict__ partial, unsigned nchunks, unsigned n,
+                        unsigned long long *__restrict__ total) {
+  __shared__ unsigned long long s_part[16][64];
+  const unsigned rl = threadIdx.x & 63u, cl = threadIdx.x >> 6;
+  const unsigned r = blockIdx.x * 64u + rl;
+  unsigned long long t = 0;
+  if (r < n)
+    for (unsigned c = cl; c < nchunks; c += 16u) t += partial[(size_t)c * n + r];
+  s_part[cl][rl] = t;
+  __syncthreads();
+  if (cl == 0 && r < n) {
+#pragma unroll
+    for (int j = 1; j < 16; j++) t += s_part[j][rl];
+    total[r] = t;
+  }
 }
 
 // phase A with a per-edge factor (SpMV): vals[8*G[g] + i] = A[8*g + i] * x[chunk*CH + U[8*g + i]]
@@ -429,7 +531,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
                         const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
                         const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, const float *__restrict__ A,
                         float *__restrict__ vals, int log_group, const uint32_t *__restrict__ src_bits = nullptr,
-                        const uint32_t *__restrict__ chunk_lo = nullptr) {
+                        const uint32_t *__restrict__ chunk_lo = nullptr, unsigned pad_slot = 0) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
@@ -447,7 +549,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
       s_x[i] = (g < (size_t)m_global) ? x[g] : 0.0f;
     }
   }
-  if (threadIdx.x == 0) s_x[ch] = 0.0f;
+  if (threadIdx.x == 0) s_x[pad_slot ? pad_slot : ch] = 0.0f;
   __syncthreads();
   const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
   const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
@@ -482,23 +584,6 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
       }
     }
   }
-}
-
-// float in [0,1] -> 2^-62 fixed point (truncating); flags anything else.  Branch-free: the 24-bit mantissa is
-// placed at bits 39..62 (the image of 1.0) and shifted right by 127 - exponent, clamped to 63 (a 64-bit shift only
-// looks at 6 bits) -- the same bits as "mant << (e - 88) or mant >> (88 - e)", in a dozen instructions instead of
-// five nested exec-mask regions per value (phase B spent 57 % of its time issuing VALU work, most of it here).
-__device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad) {
-  const unsigned bits = __float_as_uint(v);
-  const bool ok = bits <= 0x3F800000u;  // +0 .. 1.0; negative, > 1, inf and nan have larger bit patterns
-  bad |= ok ? 0u : 1u;
-  const unsigned e = bits >> 23;  // biased exponent (<= 127 when ok)
-  const unsigned mant = (bits & 0x7FFFFFu) | 0x800000u;
-  const unsigned long long m62 = (unsigned long long)(mant << 7) << 32;  // mant * 2^39
-  unsigned sh = 127u - e;
-  sh = sh > 63u ? 63u : sh;  // zero / denormal / tiny: everything is shifted out (m62 < 2^63)
-  const unsigned long long r = m62 >> sh;
-  return ok ? r : 0ull;
 }
 
 // signed value * 2^shift -> two's complement fixed point (SpMV); |v * 2^shift| must stay < 2^62.  Branch-free form
@@ -536,7 +621,11 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      // delta-coded rows (PbPlan::v8, nullable): V is then not read
                      const uint8_t *__restrict__ Vd = nullptr, const uint16_t *__restrict__ Vb = nullptr,
                      // per-edge factor of the hub stream (SpMV's Ax in hub order, nullable): value = hub_val * hub_A
-                     const float *__restrict__ hub_A = nullptr) {
+                     const float *__restrict__ hub_A = nullptr,
+                     // hub-ROW tier (nullable): rows hrb_vl[hrb_ptr[b] .. hrb_ptr[b+1]) of this bin start from the
+                     // totals phase A already summed (pb_expand_kernel), not from zero
+                     const unsigned *__restrict__ hrb_ptr = nullptr, const uint16_t *__restrict__ hrb_vl = nullptr,
+                     const unsigned long long *__restrict__ hr_total = nullptr) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
@@ -544,6 +633,10 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const unsigned b = bin_order ? bin_order[blockIdx.x] : bin_begin + blockIdx.x;
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
   __syncthreads();
+  if (hrb_ptr) {
+    for (unsigned i = hrb_ptr[b] + threadIdx.x; i < hrb_ptr[b + 1]; i += PB_THREADS) s_acc[hrb_vl[i]] = hr_total[i];
+    __syncthreads();
+  }
   const unsigned lane = gdn_lane();
   const unsigned w = threadIdx.x >> 6;
   const eoff_t q0 = bin_ptr[b] >> 2, q1 = bin_ptr[b + 1] >> 2;  // units of 4 edges

@@ -28,6 +28,16 @@ struct gdn_pr_plan {
   unsigned n_hubs = 0;
   DevBuf<uint32_t> hub_ids;  // original id of hub k (ascending)
   DevBuf<float> hub_val;     // PB_HUB_SLOTS values per iteration: contrib of hub k, slot 32768 = 0 for pad edges
+  // hub-ROW tier: the edges into the n_hr rows with the most in-edges (from non-hub sources) are summed by phase A in
+  // LDS behind the chunk's slice; one partial sum per (chunk, hub row) replaces one value per edge
+  bool has_hr = false;
+  PbPlan hr;                              // chunks as in `pb`, ONE bin over the hub rows; U and V share one order
+  unsigned n_hr = 0;
+  DevBuf<uint32_t> hr_ids;                // original row of hub row k (ascending)
+  DevBuf<unsigned long long> hr_partial;  // nchunks x n_hr
+  DevBuf<unsigned long long> hr_total;    // n_hr, per iteration
+  DevBuf<unsigned> hrb_ptr;               // nbins + 1: hub rows of every bin (they are sorted by id = by bin)
+  DevBuf<uint16_t> hrb_vl;                // n_hr: row index inside its bin
   int32_t m_local = 0;
   uint64_t nnz = 0;
   const int32_t *out_degree = nullptr;  // device, m_local
@@ -85,6 +95,40 @@ struct PrOp {
     return d;
   }
 };
+
+// bin and in-bin index of every hub row in the compacted main layout (bin_lo = first original row of a bin,
+// dst_bits = rows that have entries)
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_hubrow_locate_kernel(const uint32_t *__restrict__ ids, unsigned n, const uint32_t *__restrict__ bin_lo, unsigned nbins,
+                        const uint32_t *__restrict__ dst_bits, unsigned *__restrict__ bin_of, uint16_t *__restrict__ vl) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k >= n) return;
+  const unsigned r = ids[k];
+  unsigned lo = 0, hi = nbins;  // last bin with bin_lo <= r
+  while (hi - lo > 1) {
+    const unsigned mid = (lo + hi) >> 1;
+    if (bin_lo[mid] <= r) lo = mid;
+    else hi = mid;
+  }
+  unsigned rank = 0;  // active rows of the bin in front of r
+  const unsigned b0 = bin_lo[lo];
+  for (unsigned w = b0 >> 5; w <= (r >> 5); w++) {
+    unsigned bits = dst_bits[w];
+    if (w == (b0 >> 5)) bits &= ~0u << (b0 & 31u);
+    if (w == (r >> 5)) bits &= (1u << (r & 31u)) - 1u;
+    rank += (unsigned)__popc(bits);
+  }
+  bin_of[k] = lo;
+  vl[k] = (uint16_t)rank;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_count_sources_kernel(const int32_t *__restrict__ deg, int32_t m, unsigned long long *__restrict__ out) {
+  unsigned long long n = 0;
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK) n += deg[v] > 0;
+  n = gdn_wave_sum(n);
+  if (gdn_lane() == 0 && n) atomicAdd(out, n);
+}
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ out_degree, int32_t m,
@@ -149,9 +193,77 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
       st = pb_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
+    // hub rows: as many as phase A's LDS can hold accumulators for behind the slice (the slice size is known when
+    // this plan covers the whole graph: sources = vertices with out-edges; a row shard takes the safe bound)
+    DevBuf<uint8_t> dcls;
+    const char *re = getenv("GDN_PB_HUB_ROWS");  // 0 switches the hub-row tier off (A/B measurements)
+    const unsigned lds_static = 8704;             // s_bits + s_pref + s_scr of pb_expand_kernel, rounded up
+    unsigned slots_assumed = 1u << lc;
+    if (st == GDN_OK && compact && lc == PB_MAX_LOG_CHUNK && in_csr->nnz >= hub_min_nnz && !(re && re[0] == '0')) {
+      if (in_csr->m == m_global) {
+        DevBuf<unsigned long long> nsrc;
+        unsigned long long h_nsrc = 0;
+        if ((st = nsrc.alloc(1)) == GDN_OK) {
+          (void)hipMemset(nsrc.p, 0, 8);
+          hipLaunchKernelGGL(pr_count_sources_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_out_degree, in_csr->m, nsrc.p);
+          if (hipMemcpy(&h_nsrc, nsrc.p, 8, hipMemcpyDeviceToHost) != hipSuccess) st = GDN_ERR_HIP;
+          if (h_nsrc > p->n_hubs) slots_assumed = (unsigned)pb_slots_per_slice(h_nsrc - p->n_hubs, lc, PB_MAX_LOG_CHUNK);
+        }
+      }
+      const long long room = 163840ll - 4ll * ((long long)slots_assumed + 4) - (long long)lds_static;
+      unsigned max_rows = room > 0 ? (unsigned)(room / 8) : 0u;
+      if (max_rows > 4096u) max_rows = 4096u;
+      // a hub row should collect a couple of edges per chunk on average
+      const uint64_t nchunks_est = ((uint64_t)m_global >> lc) + 1;
+      if (st == GDN_OK) st = pb_pick_hub_rows(in_csr, max_rows, 2 * nchunks_est, dcls, p->hr_ids, &p->n_hr);
+    }
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
-                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta);
+                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0);
+    if (st == GDN_OK && p->n_hr &&
+        4ull * (p->pb.chunk_slots + 4ull) + 8ull * p->n_hr + lds_static > 163840ull) {
+      // cannot happen with out_degree == the column counts of in_csr (the slice size was derived from it)
+      gdn_set_error("gdn_pr_plan_create: out_degree does not match the columns of in_csr (slice of %u sources, %u hub rows)",
+                    p->pb.chunk_slots, p->n_hr);
+      st = GDN_ERR_INVALID;
+    }
+    if (st == GDN_OK && p->n_hr) {
+      // same chunks as the main layout (the source marks ignore the row class), one bin over the hub rows
+      st = pb_build(in_csr, m_global, lc, 12, p->hr, false, nullptr, nullptr, true, false, 16, 4, p->n_hubs ? cls.p : nullptr, 0,
+                    false, false, dcls.p, 1, /*rows_of_class_only=*/true, /*no_gaps=*/true);
+      if (st == GDN_OK && (p->hr.nbins != 1 || p->hr.nchunks != p->pb.nchunks || p->hr.chunk_slots != p->pb.chunk_slots)) {
+        gdn_set_error("gdn_pr_plan_create: hub-row layout does not line up with the main layout (%u bins, %u vs %u chunks)",
+                      p->hr.nbins, p->hr.nchunks, p->pb.nchunks);
+        st = GDN_ERR_INVALID;
+      }
+      if (st == GDN_OK) st = p->hr_partial.alloc((size_t)p->pb.nchunks * p->n_hr);
+      if (st == GDN_OK) st = p->hr_total.alloc(p->n_hr);
+      if (st == GDN_OK) st = p->hrb_ptr.alloc((size_t)p->pb.nbins + 1);
+      if (st == GDN_OK) st = p->hrb_vl.alloc(p->n_hr);
+      if (st == GDN_OK) {
+        DevBuf<unsigned> bin_of;
+        st = bin_of.alloc(p->n_hr);
+        if (st == GDN_OK) {
+          hipLaunchKernelGGL(pr_hubrow_locate_kernel, dim3(gdn_nblocks(p->n_hr)), dim3(GDN_BLOCK), 0, 0, p->hr_ids.p, p->n_hr,
+                             p->pb.bin_lo.p, p->pb.nbins, p->pb.dst_bits.p, bin_of.p, p->hrb_vl.p);
+          std::vector<unsigned> hb(p->n_hr), ptr((size_t)p->pb.nbins + 1, 0u);
+          if (hipMemcpy(hb.data(), bin_of.p, (size_t)p->n_hr * 4, hipMemcpyDeviceToHost) != hipSuccess) st = GDN_ERR_HIP;
+          for (unsigned k = 0; k < p->n_hr && st == GDN_OK; k++) {
+            if (hb[k] >= p->pb.nbins || (k && hb[k] < hb[k - 1])) {
+              gdn_set_error("gdn_pr_plan_create: hub rows are not ordered by bin");
+              st = GDN_ERR_INVALID;
+            } else ptr[hb[k] + 1]++;
+          }
+          for (unsigned b = 0; b < p->pb.nbins; b++) ptr[b + 1] += ptr[b];
+          if (st == GDN_OK &&
+              hipMemcpy(p->hrb_ptr.p, ptr.data(), ptr.size() * 4, hipMemcpyHostToDevice) != hipSuccess) st = GDN_ERR_HIP;
+        }
+      }
+      if (st == GDN_OK) {
+        p->hr.G.release();
+        p->has_hr = true;
+      }
+    }
     if (st == GDN_OK && p->n_hubs) {
       st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
@@ -174,7 +286,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       }
     }
     if (st == GDN_OK) {
-      const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
+      const int lds_a = (int)(sizeof(float) * (p->pb.chunk_slots + 4) + (p->has_hr ? 8 * p->n_hr : 0));
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
       hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
       if (e == hipSuccess)
@@ -251,7 +363,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   // ---- propagation-blocked path: expand (per chunk, first part) then accumulate + fused update (per bin)
   PbPlan &pb = plan->pb;
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
+  const size_t lds_a = sizeof(float) * (pb.chunk_slots + 4) + (plan->has_hr ? 8 * (size_t)plan->n_hr : 0);
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (first) {
@@ -266,11 +378,16 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                        pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
-                       getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0
+                       getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0,
 #else
-                       0
+                       0,
 #endif
-    );
+                       plan->has_hr ? plan->hr.chunk_ptr.p : nullptr, plan->has_hr ? plan->hr.U.p : nullptr,
+                       plan->has_hr ? plan->hr.V.p : nullptr, plan->has_hr ? plan->n_hr : 0u,
+                       plan->has_hr ? plan->hr_partial.p : nullptr, pb.errflag.p, pb.chunk_slots);
+    if (plan->has_hr)
+      hipLaunchKernelGGL(pb_hubrow_reduce_kernel, dim3((plan->n_hr + 63u) / 64u), dim3(PB_THREADS), 0, s, plan->hr_partial.p,
+                         pb.nchunks, plan->n_hr, plan->hr_total.p);
     if (plan->has_hub)
       hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
                          plan->hub_ids.p, plan->n_hubs, plan->hub_val.p);
@@ -291,7 +408,9 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
 #endif
                        b0, plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
                        plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr,
-                       pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr);
+                       pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, nullptr,
+                       plan->has_hr ? plan->hrb_ptr.p : nullptr, plan->has_hr ? plan->hrb_vl.p : nullptr,
+                       plan->has_hr ? plan->hr_total.p : nullptr);
   if (last) {
     if (timed) {
       GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));

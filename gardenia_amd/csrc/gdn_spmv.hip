@@ -237,7 +237,8 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
-                     pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr);
+                     pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr,
+                     pb.chunk_slots);
   if (plan->has_hub)
     hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_x, plan->hub_ids.p,
                        plan->n_hubs, plan->hub_val.p);

@@ -205,6 +205,28 @@ def test_pr_row_range_part_contract():
         L.gdn_dev_free(p)
 
 
+@pytest.mark.parametrize("world,parts", [(1, 1), (2, 3)])
+def test_pr_hub_row_tier(orc, monkeypatch, world, parts):
+    """Hub-ROW tier (phase A sums the edges into the highest in-degree rows in LDS, one partial per chunk and row):
+    only built with full-size chunks, so the chunk size is forced here; bit-identical to the plan without it."""
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1000")
+    monkeypatch.setenv("GDN_PB_HUB_MIN", "1")
+    monkeypatch.setenv("GDN_PB_LOG_CHUNK", "15")
+    g = graphio.rmat_graph(17, 16, seed=37)
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    res = []
+    for rows in ("0", "1"):
+        monkeypatch.setenv("GDN_PB_HUB_ROWS", rows)
+        sh = solvers.ResidentPageRankShards(G, world, 1, parts=parts)
+        res.append(sh.solve())
+        sh.close()
+    assert res[0][1] == res[1][1] == it
+    assert np.array_equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[1][0], want, rtol=REL_TOL, atol=0)
+
+
 @pytest.mark.parametrize("world,parts", [(1, 1), (2, 4), (3, 2)])
 def test_pr_hub_tier_on_row_shards(orc, monkeypatch, world, parts):
     """Hub tier + vertex-range shards (m_local < m_global, row_base) + row-range parts: the multi-GPU configuration of
