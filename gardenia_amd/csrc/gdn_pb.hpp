@@ -46,6 +46,7 @@
 #define PB_MAX_LOG_CHUNK 15  // 32768 floats = 128 KB of LDS
 #define PB_MAX_LOG_BIN 14    // 16384 u64    = 128 KB of LDS
 #define PB_FIX_SHIFT 62
+#define PB_HR_THREADS 128    // threads of phase A that fold the hub-row edges while the others sweep
 
 struct PbPlan {
   int32_t m_local = 0;   // destination rows
@@ -419,7 +420,15 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   }
   const unsigned zslot = pad_slot ? pad_slot : ch;
   if (threadIdx.x == 0) s_x[zslot] = 0.0f;  // zero slot for pad edges
+  unsigned long long *s_hr = reinterpret_cast<unsigned long long *>(s_x + zslot + 4);  // 16 bytes behind the zero slot
+  // hub-row tier: PB_HR_THREADS threads (two waves) fold the hub-row edge list while the others run the main sweep --
+  // the fold is a chain of short dependent steps (latency), the sweep is throughput, and both only READ the slice
+  const bool with_hr = hr_ptr != nullptr && part == 0;
+  if (with_hr)
+    for (unsigned i = threadIdx.x; i < hr_n; i += PB_THREADS) s_hr[i] = 0ull;
   __syncthreads();
+  const unsigned t0 = with_hr ? PB_HR_THREADS : 0u;      // first thread of the main sweep
+  const unsigned nthr = PB_THREADS - t0;                  // its thread count
   // half-groups: lane pair (2i, 2i+1) handles group i; each lane loads 4 source ids (8 B),
   // gathers 4 values from LDS and stores 16 B, so a wave store covers whole 64-byte lines
   const eoff_t hc0 = chunk_ptr[c] >> 2, hc1 = chunk_ptr[c + 1] >> 2;
@@ -431,36 +440,34 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   constexpr int UNR = 8;
   const int lq = log_group - 2;  // a lane owns a quad of 4 edges; 2^lq lanes share one entry of G
   const unsigned qmask = (1u << lq) - 1u;
-  for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
-    pb_u16x4 u[UNR];
-    unsigned d[UNR];
+  if (threadIdx.x >= t0) {
+    for (eoff_t h = h0 + (threadIdx.x - t0); h < h1; h += (eoff_t)UNR * nthr) {
+      pb_u16x4 u[UNR];
+      unsigned d[UNR];
 #pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
-      if (hh < h1) {
-        u[r] = __builtin_nontemporal_load(U4 + hh);
-        d[r] = __builtin_nontemporal_load(G + (hh >> lq));
+      for (int r = 0; r < UNR; r++) {
+        const eoff_t hh = h + (eoff_t)r * nthr;
+        if (hh < h1) {
+          u[r] = __builtin_nontemporal_load(U4 + hh);
+          d[r] = __builtin_nontemporal_load(G + (hh >> lq));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const eoff_t hh = h + (eoff_t)r * nthr;
+        if (hh < h1) {
+          pb_f32x4 o;
+          o.x = s_x[u[r].x];
+          o.y = s_x[u[r].y];
+          o.z = s_x[u[r].z];
+          o.w = s_x[u[r].w];
+          pb_f32x4 *dst = X4 + (((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask);
+          if (nt_store & 1) __builtin_nontemporal_store(o, dst);
+          else *dst = o;
+        }
       }
     }
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
-      if (hh < h1) {
-        pb_f32x4 o;
-        o.x = s_x[u[r].x];
-        o.y = s_x[u[r].y];
-        o.z = s_x[u[r].z];
-        o.w = s_x[u[r].w];
-        pb_f32x4 *dst = X4 + (((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask);
-        if (nt_store & 1) __builtin_nontemporal_store(o, dst);
-        else *dst = o;
-      }
-    }
-  }
-  if (hr_ptr && part == 0) {
-    unsigned long long *s_hr = reinterpret_cast<unsigned long long *>(s_x + zslot + 4);  // 16 bytes behind the zero slot
-    for (unsigned i = threadIdx.x; i < hr_n; i += PB_THREADS) s_hr[i] = 0ull;
-    __syncthreads();
+  } else {
     const unsigned nq = (unsigned)((hr_ptr[c + 1] - hr_ptr[c]) >> 2);
     const pb_u16x4 *HU = reinterpret_cast<const pb_u16x4 *>(hr_U) + (hr_ptr[c] >> 2);
     const pb_u16x4 *HR = reinterpret_cast<const pb_u16x4 *>(hr_R) + (hr_ptr[c] >> 2);
@@ -468,8 +475,8 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
     // every thread folds ONE contiguous block of the (row-sorted) edge list: a hub row owns hundreds of consecutive
     // edges per chunk, and one atomic per lane and quad made its accumulator the bottleneck (phase A 2.2 -> 2.9 ms);
     // a block of ~20 quads turns that into one atomic per thread and run
-    const unsigned blk = (nq + PB_THREADS - 1) / PB_THREADS;
-    const unsigned qb = threadIdx.x * blk, qe = qb + blk < nq ? qb + blk : nq;
+    const unsigned blk = (nq + PB_HR_THREADS - 1) / PB_HR_THREADS;
+    const unsigned qb = threadIdx.x * blk < nq ? threadIdx.x * blk : nq, qe = qb + blk < nq ? qb + blk : nq;
     unsigned cur = 0xFFFFFFFFu;
     unsigned long long acc = 0ull;
     constexpr int HRB = 8;  // quads loaded ahead of the fold
@@ -500,6 +507,8 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
     }
     if (cur != 0xFFFFFFFFu) atomicAdd(&s_hr[cur], acc);
     if (bad) *errflag = 1u;
+  }
+  if (with_hr) {
     __syncthreads();
     for (unsigned i = threadIdx.x; i < hr_n; i += PB_THREADS) hr_partial[(size_t)c * hr_n + i] = s_hr[i];
   }

@@ -196,10 +196,12 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     // hub rows: as many as phase A's LDS can hold accumulators for behind the slice (the slice size is known when
     // this plan covers the whole graph: sources = vertices with out-edges; a row shard takes the safe bound)
     DevBuf<uint8_t> dcls;
-    const char *re = getenv("GDN_PB_HUB_ROWS");  // 0 switches the hub-row tier off (A/B measurements)
+    // OFF by default (GDN_PB_HUB_ROWS=1 builds it): it takes 1.1 GB out of an iteration (phase B -0.2 ms) but phase A
+    // pays the same back -- any wave of a CU that folds instead of streaming lowers the CU's bytes in flight
+    const char *re = getenv("GDN_PB_HUB_ROWS");
     const unsigned lds_static = 8704;             // s_bits + s_pref + s_scr of pb_expand_kernel, rounded up
     unsigned slots_assumed = 1u << lc;
-    if (st == GDN_OK && compact && lc == PB_MAX_LOG_CHUNK && in_csr->nnz >= hub_min_nnz && !(re && re[0] == '0')) {
+    if (st == GDN_OK && compact && lc == PB_MAX_LOG_CHUNK && in_csr->nnz >= hub_min_nnz && re && re[0] == '1') {
       if (in_csr->m == m_global) {
         DevBuf<unsigned long long> nsrc;
         unsigned long long h_nsrc = 0;

@@ -207,8 +207,9 @@ def test_pr_row_range_part_contract():
 
 @pytest.mark.parametrize("world,parts", [(1, 1), (2, 3)])
 def test_pr_hub_row_tier(orc, monkeypatch, world, parts):
-    """Hub-ROW tier (phase A sums the edges into the highest in-degree rows in LDS, one partial per chunk and row):
-    only built with full-size chunks, so the chunk size is forced here; bit-identical to the plan without it."""
+    """Hub-ROW tier (phase A sums the edges into the highest in-degree rows in LDS, one partial per chunk and row;
+    optional, GDN_PB_HUB_ROWS=1): only built with full-size chunks, so the chunk size is forced here; bit-identical to
+    the plan without it."""
     monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1000")
     monkeypatch.setenv("GDN_PB_HUB_MIN", "1")
     monkeypatch.setenv("GDN_PB_LOG_CHUNK", "15")
