@@ -72,6 +72,7 @@ PROTOTYPES = {
     "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pp]),
     "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
+    "gdn_pr_plan_mid": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_pr_plan_check": (C.c_int, [_vp]),
     "gdn_pr_plan_free": (C.c_int, [_vp]),
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),

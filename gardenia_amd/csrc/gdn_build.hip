@@ -614,16 +614,27 @@ pb_hub_hist_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restr
   if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 
+// class of every source from its sampled count: 1 = hub (>= thr[0]), 1 + t = mid tier t (thr[t] <= count < thr[t-1]),
+// 0 = main layout; the ids of every class are collected (unordered) in ids[class - 1]
+struct PbTierArgs {
+  unsigned thr[1 + PB_MAX_MID];
+  uint32_t *ids[1 + PB_MAX_MID];
+  unsigned cap[1 + PB_MAX_MID];
+  int ntiers;  // classes in use (hub class included)
+};
 __global__ void __launch_bounds__(GDN_BLOCK)
-pb_hub_class_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned thr, uint8_t *__restrict__ cls,
-                    uint32_t *__restrict__ ids, unsigned cap, unsigned *__restrict__ n_ids) {
+pb_tier_class_kernel(const uint32_t *__restrict__ cnt, size_t n, PbTierArgs a, uint8_t *__restrict__ cls,
+                     unsigned *__restrict__ n_ids /*1 + PB_MAX_MID*/) {
   const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (i >= n) return;
-  const bool hub = cnt[i] >= thr;
-  cls[i] = hub ? 1 : 0;
-  if (hub) {
-    const unsigned pos = atomicAdd(n_ids, 1u);
-    if (pos < cap) ids[pos] = (uint32_t)i;
+  const unsigned c = cnt[i];
+  int k = 0;
+  for (int t = a.ntiers - 1; t >= 0; t--)
+    if (c >= a.thr[t]) k = t + 1;
+  cls[i] = (uint8_t)k;
+  if (k) {
+    const unsigned pos = atomicAdd(&n_ids[k - 1], 1u);
+    if (pos < a.cap[k - 1]) a.ids[k - 1][pos] = (uint32_t)i;
   }
 }
 
@@ -635,20 +646,24 @@ pb_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long
   if (gdn_lane() == 0 && mask) atomicAdd(out, (unsigned long long)__popcll(mask));
 }
 
-// picks the hub sources of `in_csr` (at most 2^15, each with >= PB_HUB_MIN_PER_BIN expected edges per bin);
-// cls gets one byte per source id, hub_ids the ascending ids.  n_hubs == 0: no hub tier.
+// picks the hub sources of `in_csr` (at most 2^15, each with >= PB_HUB_MIN_PER_BIN expected edges per bin) and, below
+// them, up to max_mid MID tiers (each at most PB_MID_MAX sources, >= PB_MID_MIN_PER_BIN16 / 16 expected edges per bin).
+// cls gets one byte per source id (0 main, 1 hub, 2.. mid tiers), hub_ids / mid_ids[t] the ascending ids.
 #define PB_HUB_MIN_PER_BIN 2
-int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
-                        unsigned *n_hubs) {
+#define PB_MID_MIN_PER_BIN16 4
+int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid) {
   *n_hubs = 0;
+  if (max_mid > PB_MAX_MID) max_mid = PB_MAX_MID;
+  for (int t = 0; t < max_mid; t++) n_mid[t] = 0;
   DevBuf<uint32_t> cnt;
   DevBuf<unsigned> hist;
   DevBuf<unsigned long long> nrows;
   GDN_TRY(cnt.alloc((size_t)m_global));
-  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1));
+  GDN_TRY(hist.alloc(PB_HUB_BUCKETS + 1 + PB_MAX_MID));
   GDN_TRY(nrows.alloc(1));
   GDN_HIP(hipMemset(cnt.p, 0, (size_t)m_global * 4));
-  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1) * 4));
+  GDN_HIP(hipMemset(hist.p, 0, (PB_HUB_BUCKETS + 1 + PB_MAX_MID) * 4));
   GDN_HIP(hipMemset(nrows.p, 0, 8));
   const uint64_t sampled = ((uint64_t)g->m + (1u << PB_HUB_SAMPLE_LOG) - 1) >> PB_HUB_SAMPLE_LOG;
   hipLaunchKernelGGL(pb_hub_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx,
@@ -665,32 +680,120 @@ int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8
   // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
   uint64_t per_bin = PB_HUB_MIN_PER_BIN;
   if (const char *e = getenv("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
-  uint64_t want = (nbins * per_bin) >> PB_HUB_SAMPLE_LOG;
-  if (want < 4) want = 4;
-  if (want > 0x40000000ull) return GDN_OK;
-  unsigned bk = pb_hub_bucket((unsigned)want);
-  if (pb_hub_bucket_floor(bk) < want) bk++;
-  for (;; bk++) {  // threshold = floor of bucket bk; raise it until at most 2^15 sources qualify
-    if (bk >= PB_HUB_BUCKETS) return GDN_OK;
-    uint64_t above = 0;
-    for (unsigned j = bk; j < PB_HUB_BUCKETS; j++) above += h[j];
-    if (above == 0) return GDN_OK;
-    if (above <= (1u << PB_HUB_LOG)) break;
+  // smallest bucket >= the bucket of `want` whose sources, up to (not including) bucket `top`, number at most `cap`;
+  // PB_HUB_BUCKETS = none
+  auto pick = [&](uint64_t want, unsigned top, uint64_t cap) -> unsigned {
+    if (want < 4) want = 4;
+    if (want > 0x40000000ull) return PB_HUB_BUCKETS;
+    unsigned bk = pb_hub_bucket((unsigned)want);
+    if (pb_hub_bucket_floor(bk) < want) bk++;
+    for (; bk < top; bk++) {
+      uint64_t above = 0;
+      for (unsigned j = bk; j < top; j++) above += h[j];
+      if (above == 0) return PB_HUB_BUCKETS;
+      if (above <= cap) return bk;
+    }
+    return PB_HUB_BUCKETS;
+  };
+  PbTierArgs ta;
+  memset(&ta, 0, sizeof(ta));
+  // tier 0 = hubs (the slot keeps an unreachable threshold when no source qualifies, so the classes keep their numbers)
+  const unsigned bk0 = pick((nbins * per_bin) >> PB_HUB_SAMPLE_LOG, PB_HUB_BUCKETS, 1u << PB_HUB_LOG);
+  ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
+  ta.cap[0] = 1u << PB_HUB_LOG;
+  ta.ntiers = 1;
+  uint64_t mid16 = PB_MID_MIN_PER_BIN16;
+  if (const char *e = getenv("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
+  unsigned top = bk0 < PB_HUB_BUCKETS ? bk0 : PB_HUB_BUCKETS;
+  for (int t = 0; t < max_mid; t++) {
+    const unsigned bk = pick((nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4), top, PB_MID_MAX);
+    if (bk >= top) break;
+    ta.thr[1 + t] = pb_hub_bucket_floor(bk);
+    ta.cap[1 + t] = PB_MID_MAX;
+    ta.ntiers = 2 + t;
+    top = bk;
   }
-  const unsigned thr = pb_hub_bucket_floor(bk);
+  if (bk0 >= PB_HUB_BUCKETS && ta.ntiers == 1) return GDN_OK;
   GDN_TRY(cls.alloc((size_t)m_global));
   GDN_TRY(hub_ids.alloc(1u << PB_HUB_LOG));
-  hipLaunchKernelGGL(pb_hub_class_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, cnt.p,
-                     (size_t)m_global, thr, cls.p, hub_ids.p, 1u << PB_HUB_LOG, hist.p + PB_HUB_BUCKETS);
+  ta.ids[0] = hub_ids.p;
+  for (int t = 1; t < ta.ntiers; t++) {
+    GDN_TRY(mid_ids[t - 1].alloc(PB_MID_MAX));
+    ta.ids[t] = mid_ids[t - 1].p;
+  }
+  hipLaunchKernelGGL(pb_tier_class_kernel, dim3(gdn_nblocks((uint64_t)m_global)), dim3(GDN_BLOCK), 0, 0, cnt.p,
+                     (size_t)m_global, ta, cls.p, hist.p + PB_HUB_BUCKETS);
   GDN_HIP(hipGetLastError());
-  unsigned n = 0;
-  GDN_HIP(hipMemcpy(&n, hist.p + PB_HUB_BUCKETS, 4, hipMemcpyDeviceToHost));
-  if (n == 0 || n > (1u << PB_HUB_LOG)) return GDN_OK;  // (cannot exceed: the histogram counted them)
-  std::vector<uint32_t> ids(n);
-  GDN_HIP(hipMemcpy(ids.data(), hub_ids.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-  std::sort(ids.begin(), ids.end());  // hub k = k-th marked source in id order = its compact index in the hub layout
-  GDN_HIP(hipMemcpy(hub_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-  *n_hubs = n;
+  unsigned n[1 + PB_MAX_MID];
+  GDN_HIP(hipMemcpy(n, hist.p + PB_HUB_BUCKETS, sizeof(n), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> ids;
+  for (int t = 0; t < ta.ntiers; t++) {
+    if (n[t] == 0) continue;
+    if (n[t] > ta.cap[t]) {  // cannot happen: the histogram counted them
+      gdn_set_error("pb_pick_tiers: tier %d holds %u sources (cap %u)", t, n[t], ta.cap[t]);
+      return GDN_ERR_INVALID;
+    }
+    // source k of a tier = the k-th source of its class in id order = its compact index in the tier's layout
+    ids.resize(n[t]);
+    GDN_HIP(hipMemcpy(ids.data(), ta.ids[t], (size_t)n[t] * 4, hipMemcpyDeviceToHost));
+    std::sort(ids.begin(), ids.end());
+    GDN_HIP(hipMemcpy(ta.ids[t], ids.data(), (size_t)n[t] * 4, hipMemcpyHostToDevice));
+    if (t == 0) *n_hubs = n[0];
+    else n_mid[t - 1] = n[t];
+  }
+  if (getenv("GDN_PB_TRACE")) {
+    fprintf(stderr, "[pb_pick_tiers] bins %llu: hubs %u (sampled count >= %u)", (unsigned long long)nbins, n[0], ta.thr[0]);
+    for (int t = 1; t < ta.ntiers; t++) fprintf(stderr, ", mid %d: %u (>= %u)", t, n[t], ta.thr[t]);
+    fprintf(stderr, "\n");
+  }
+  return GDN_OK;
+}
+
+int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                 unsigned *n_hubs) {
+  return pb_pick_tiers(g, m_global, log_bin, cls, hub_ids, n_hubs, 0, nullptr, nullptr);
+}
+
+// ---- mid tiers: the layout pb_build made for the sources of one mid class (chunks of 2^15 sources, tiles sorted by
+// (source, row)) becomes ONE bin-major stream of 32-bit records (source index in the tier << 14 | row in the bin);
+// pad records point at the tier's zero slot.  U, V and G are not needed afterwards.
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_mid_records_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, const uint32_t *__restrict__ G,
+                      const eoff_t *__restrict__ chunk_ptr, unsigned nchunks, unsigned long long ngroups, int log_group,
+                      int log_chunk, unsigned pad_id, unsigned zslot, uint32_t *__restrict__ rec) {
+  const unsigned long long g = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (g >= ngroups) return;
+  const uint32_t dst = G[g];
+  if ((unsigned long long)dst >= ngroups) return;  // a group of an alignment gap (dump group)
+  const eoff_t e0 = (eoff_t)g << log_group;
+  unsigned c = 0;
+  while (c + 1 < nchunks && chunk_ptr[c + 1] <= e0) c++;
+  const unsigned grp = 1u << log_group;
+  for (unsigned i = 0; i < grp; i++) {
+    const unsigned u = U[e0 + i];
+    const unsigned k = (u == pad_id) ? zslot : ((c << log_chunk) + u);
+    rec[((size_t)dst << log_group) + i] = (k << PB_MID_ROW_BITS) | (unsigned)V[((size_t)dst << log_group) + i];
+  }
+}
+
+int pb_mid_finish(PbPlan &p, unsigned n_src, DevBuf<uint32_t> &rec) {
+  GDN_REQUIRE(p.log_bin <= PB_MID_ROW_BITS && n_src <= PB_MID_MAX, "mid tier: row / source index width");
+  GDN_REQUIRE(((size_t)p.nchunks << p.log_chunk) >= n_src && p.chunk_slots == (1u << p.log_chunk), "mid tier: chunks");
+  const unsigned grp = 1u << p.log_group;
+  GDN_TRY(rec.alloc(p.n_pad + grp));
+  const unsigned long long ngroups = p.n_pad >> p.log_group;
+  const unsigned zrec = n_src << PB_MID_ROW_BITS;
+  const unsigned long long fb = (p.n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
+  hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, rec.p,
+                     p.n_pad + grp, zrec);
+  if (ngroups)
+    hipLaunchKernelGGL(pb_mid_records_kernel, dim3(gdn_nblocks(ngroups)), dim3(GDN_BLOCK), 0, 0, p.U.p, p.V.p, p.G.p,
+                       p.chunk_ptr.p, p.nchunks, ngroups, p.log_group, p.log_chunk, p.chunk_slots, n_src, rec.p);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipDeviceSynchronize());
+  p.U.release();
+  p.V.release();
+  p.G.release();
   return GDN_OK;
 }
 

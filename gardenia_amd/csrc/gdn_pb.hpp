@@ -116,6 +116,30 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
 int pb_pick_hubs(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
                  unsigned *n_hubs);
 
+// Mid tiers (gdn_pr.hip): below the hubs, the sources that still own a fraction of an edge per average bin (R-MAT: the
+// next two degree levels, a third of all edges).  Their edges do not pass through phase A / vals either: phase B reads
+// them per bin as ONE stream of 32-bit records (source index in the tier << 14 | row in the bin), sorted by source, one
+// record per lane, and fetches the value from the tier's table (<= 1 MB, refreshed per iteration, L2 resident).  Sorted
+// by source and one record per lane, the 64 gathers of a wave instruction fall into a handful of consecutive cache
+// lines: a near-coalesced load, not a divergent gather.  4 B/edge of HBM traffic instead of 12.1.
+#define PB_MAX_MID 2
+#define PB_MID_ROW_BITS 14
+#define PB_MID_MAX ((1u << (32 - PB_MID_ROW_BITS)) - 1u)  // sources per tier; index PB_MID_MAX can be the zero slot
+#define PB_MAX_REC_TIERS (1 + PB_MAX_MID)  // record streams of phase B: PageRank's hubs + the mid tiers
+struct PbMidArgs {  // kernel argument of phase B
+  const eoff_t *ptr[PB_MAX_REC_TIERS];     // nbins + 1 record offsets per tier (multiples of 16)
+  const uint32_t *rec[PB_MAX_REC_TIERS];
+  const float *val[PB_MAX_REC_TIERS];      // n + 1 values (slot n = 0 for pad records)
+  unsigned zrec[PB_MAX_REC_TIERS];         // the pad record: n << PB_MID_ROW_BITS
+  int n = 0;
+  int variant = 0;  // measurement knob (GDN_EXPERIMENTS builds)
+};
+int pb_pick_tiers(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
+                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid);
+// turns the layout pb_build made for one mid class (log_chunk 15, src_major, same bins as the main layout) into the
+// bin-major record stream; releases U, V and G of the layout
+int pb_mid_finish(PbPlan &layout, unsigned n_src, DevBuf<uint32_t> &rec);
+
 // the rows with the most in-edges (gdn_build.hip): at most max_rows rows with >= min_deg in-edges each
 uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full);  // vertices per slice after round balancing
 int pb_pick_hub_rows(const gdn_graph *in_csr, unsigned max_rows, uint64_t min_deg, DevBuf<uint8_t> &dcls,
@@ -128,6 +152,13 @@ typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
 
 // hub_val[k] = x[hub_ids[k]] (PageRank: contrib, SpMV: x); the slots behind the hubs (incl. the pad slot 32768) stay 0
+// table of a mid tier: val[k] = x[ids[k]], val[n] = 0
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_mid_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, float *__restrict__ val) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k <= n) val[k] = k < n ? x[ids[k]] : 0.0f;
+}
+
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pb_hub_gather_kernel(const float *__restrict__ contrib, const uint32_t *__restrict__ hub_ids, unsigned n_hubs,
                      float *__restrict__ hub_val) {
@@ -634,7 +665,9 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      // hub-ROW tier (nullable): rows hrb_vl[hrb_ptr[b] .. hrb_ptr[b+1]) of this bin start from the
                      // totals phase A already summed (pb_expand_kernel), not from zero
                      const unsigned *__restrict__ hrb_ptr = nullptr, const uint16_t *__restrict__ hrb_vl = nullptr,
-                     const unsigned long long *__restrict__ hr_total = nullptr) {
+                     const unsigned long long *__restrict__ hr_total = nullptr,
+                     // mid tiers: per bin one stream of (source index, row) records per tier, values from the tier's table
+                     PbMidArgs mid = PbMidArgs()) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
@@ -715,7 +748,8 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   };
   constexpr unsigned STEPU = (unsigned)UNR * PB_THREADS;
   unsigned sb = 0;  // first quad of the current step (wave-uniform)
-  if (nq >= STEPU) {
+  if (dbg & 32) sb = nq;  // timing-only ablation: no main stream
+  else if (nq >= STEPU) {
     // software pipeline over the full steps: the loads of step k+1 are in flight while step k is folded into LDS
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
@@ -755,7 +789,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
     if (i < nq) fold(xs[r], vs[r]);
   }
-  if (hub_ptr) {
+  if (hub_ptr && !(dbg & 16)) {
     // edges of hub sources: 4 B per edge (u16 hub index + u16 row), 8 edges per lane and step with 16-byte loads;
     // the values come from a table that stays in L2: one 4-byte gather per DISTINCT hub of the lane's run (the
     // stream is sorted by hub, so a run of 8 edges holds 1-4 hubs)
@@ -810,6 +844,74 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
           }
         }
       }
+    }
+  }
+  for (int t = 0; t < ((dbg & 8) ? 0 : mid.n); t++) {
+    // record streams, sorted by source: a lane owns 4 consecutive records per 16-byte load, MU loads per step, and the
+    // loads of step k+1 are in flight while the values of step k are fetched from the tier's table and added (as much
+    // in flight per CU as the main stream keeps).  Sorted by source, the table reads of one wave instruction fall
+    // into a few consecutive lines: near-coalesced L2 hits, not a divergent gather.
+    typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
+    const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
+    const float *__restrict__ T = mid.val[t];
+    const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
+    const unsigned z = mid.zrec[t];
+    constexpr unsigned RMASK = (1u << PB_MID_ROW_BITS) - 1u;
+    if (mid.variant >= 1) {  // the first form: one record per lane and load, no pipelining
+      const uint32_t *__restrict__ R = mid.rec[t] + mid.ptr[t][b];
+      const unsigned nr = nr4 << 2;
+      constexpr int MUNR = 8;
+      for (unsigned i0 = threadIdx.x; i0 < nr; i0 += (unsigned)MUNR * PB_THREADS) {
+        uint32_t rc[MUNR];
+        float f[MUNR];
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) {
+          const unsigned i = i0 + (unsigned)r * PB_THREADS;
+          rc[r] = z;
+          if (i < nr) rc[r] = __builtin_nontemporal_load(R + i);
+        }
+        // variants >= 2: TIMING-ONLY ablations (wrong results): 2 no table read, 3 no LDS atomics, 4 every table read
+        // of a wave in one line
+#pragma unroll
+        for (int r = 0; r < MUNR; r++)
+          f[r] = mid.variant == 2 ? 1e-9f : T[mid.variant == 4 ? ((rc[r] >> PB_MID_ROW_BITS) & 31u) : (rc[r] >> PB_MID_ROW_BITS)];
+        if (mid.variant == 3) {
+#pragma unroll
+          for (int r = 0; r < MUNR; r++) bad |= (unsigned)(f[r] == 123.456f) + (unsigned)((rc[r] & RMASK) == 77777u);
+        } else {
+#pragma unroll
+          for (int r = 0; r < MUNR; r++) atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
+        }
+      }
+      continue;
+    }
+    constexpr int MU = 4;
+    constexpr unsigned MSTEP = (unsigned)MU * PB_THREADS;
+    pb_u32x4 cur[MU], nxt[MU];
+#pragma unroll
+    for (int r = 0; r < MU; r++) {
+      const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
+      cur[r] = pb_u32x4{z, z, z, z};
+      if (i < nr4) cur[r] = __builtin_nontemporal_load(R4 + i);
+    }
+    for (unsigned s0 = 0; s0 < nr4; s0 += MSTEP) {
+#pragma unroll
+      for (int r = 0; r < MU; r++) {
+        const unsigned i = s0 + MSTEP + threadIdx.x + (unsigned)r * PB_THREADS;
+        nxt[r] = pb_u32x4{z, z, z, z};
+        if (i < nr4) nxt[r] = __builtin_nontemporal_load(R4 + i);
+      }
+      float f[MU][4];
+#pragma unroll
+      for (int r = 0; r < MU; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) f[r][k] = T[cur[r][k] >> PB_MID_ROW_BITS];
+#pragma unroll
+      for (int r = 0; r < MU; r++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) atomicAdd(&s_acc[cur[r][k] & RMASK], op.to_fixed(f[r][k], bad));
+#pragma unroll
+      for (int r = 0; r < MU; r++) cur[r] = nxt[r];
     }
   }
   __syncthreads();

@@ -27,7 +27,17 @@ struct gdn_pr_plan {
   PbPlan hub;
   unsigned n_hubs = 0;
   DevBuf<uint32_t> hub_ids;  // original id of hub k (ascending)
-  DevBuf<float> hub_val;     // PB_HUB_SLOTS values per iteration: contrib of hub k, slot 32768 = 0 for pad edges
+  DevBuf<float> hub_val;     // PB_HUB_SLOTS values per iteration: contrib of hub k, slots >= n_hubs = 0 for pad edges
+  DevBuf<uint32_t> hub_rec;  // the hub layout as bin-major (hub index << 14 | row) records (pb_mid_finish)
+  // mid tiers (gdn_pb.hpp): the next degree levels below the hubs, read by phase B as 32-bit (source, row) records
+  int n_mid_tiers = 0;
+  struct MidTier {
+    PbPlan layout;           // only bin_ptr is kept (pb_mid_finish)
+    unsigned n = 0;          // sources
+    DevBuf<uint32_t> ids;    // original id of source k (ascending)
+    DevBuf<uint32_t> rec;    // bin-major records
+    DevBuf<float> val;       // n + 1 values per iteration
+  } mid[PB_MAX_MID];
   // hub-ROW tier: the edges into the n_hr rows with the most in-edges (from non-hub sources) are summed by phase A in
   // LDS behind the chunk's slice; one partial sum per (chunk, hub row) replaces one value per edge
   bool has_hr = false;
@@ -191,8 +201,14 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     st = GDN_OK;
     uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
     if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    const char *me = getenv("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    int max_mid = me ? atoi(me) : PB_MAX_MID;
+    if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
+    DevBuf<uint32_t> mid_ids[PB_MAX_MID];
+    unsigned n_mid[PB_MAX_MID] = {0, 0};
     if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
-      st = pb_pick_hubs(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs);
+      st = pb_pick_tiers(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
+    const bool any_class = p->n_hubs || n_mid[0];
     // hub rows: as many as phase A's LDS can hold accumulators for behind the slice (the slice size is known when
     // this plan covers the whole graph: sources = vertices with out-edges; a row shard takes the safe bound)
     DevBuf<uint8_t> dcls;
@@ -221,7 +237,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     }
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
-                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0);
+                    any_class ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0);
     if (st == GDN_OK && p->n_hr &&
         4ull * (p->pb.chunk_slots + 4ull) + 8ull * p->n_hr + lds_static > 163840ull) {
       // cannot happen with out_degree == the column counts of in_csr (the slice size was derived from it)
@@ -231,7 +247,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     }
     if (st == GDN_OK && p->n_hr) {
       // same chunks as the main layout (the source marks ignore the row class), one bin over the hub rows
-      st = pb_build(in_csr, m_global, lc, 12, p->hr, false, nullptr, nullptr, true, false, 16, 4, p->n_hubs ? cls.p : nullptr, 0,
+      st = pb_build(in_csr, m_global, lc, 12, p->hr, false, nullptr, nullptr, true, false, 16, 4, any_class ? cls.p : nullptr, 0,
                     false, false, dcls.p, 1, /*rows_of_class_only=*/true, /*no_gaps=*/true);
       if (st == GDN_OK && (p->hr.nbins != 1 || p->hr.nchunks != p->pb.nchunks || p->hr.chunk_slots != p->pb.chunk_slots)) {
         gdn_set_error("gdn_pr_plan_create: hub-row layout does not line up with the main layout (%u bins, %u vs %u chunks)",
@@ -274,10 +290,27 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
         st = GDN_ERR_INVALID;
       }
       if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS);
+      // read by phase B as one record stream like the mid tiers (U, V and G of the layout are released)
+      if (st == GDN_OK) st = pb_mid_finish(p->hub, p->n_hubs, p->hub_rec);
+      if (st == GDN_OK) p->has_hub = true;
+    }
+    for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
+      gdn_pr_plan::MidTier &mt = p->mid[t];
+      st = pb_build(in_csr, m_global, 15, lb, mt.layout, false, nullptr, nullptr, true, false, 16, 4, cls.p, 2 + t, true);
+      if (st == GDN_OK && mt.layout.nbins != p->pb.nbins) {
+        gdn_set_error("gdn_pr_plan_create: mid layout %d does not line up with the main layout (%u vs %u bins)", t,
+                      mt.layout.nbins, p->pb.nbins);
+        st = GDN_ERR_INVALID;
+      }
+      if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec);
+      if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 1);
       if (st == GDN_OK) {
-        // the single chunk makes chunk-major == bin-major: U and V of the hub layout share one order
-        p->hub.G.release();
-        p->has_hub = true;
+        mt.n = n_mid[t];
+        mt.ids.p = mid_ids[t].p;  // take the buffer over
+        mt.ids.n = mid_ids[t].n;
+        mid_ids[t].p = nullptr;
+        mid_ids[t].n = 0;
+        p->n_mid_tiers = t + 1;
       }
     }
     if (st == GDN_OK && p->pb.compact) {  // row -> bin lookups of partial launches (gdn_pr_pull_rows_dev)
@@ -393,8 +426,27 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     if (plan->has_hub)
       hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
                          plan->hub_ids.p, plan->n_hubs, plan->hub_val.p);
+    for (int t = 0; t < plan->n_mid_tiers; t++)
+      hipLaunchKernelGGL(pb_mid_gather_kernel, dim3(gdn_nblocks((uint64_t)plan->mid[t].n + 1)), dim3(GDN_BLOCK), 0, s,
+                         d_contrib_in, plan->mid[t].ids.p, plan->mid[t].n, plan->mid[t].val.p);
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }
+  PbMidArgs mid;
+  if (plan->has_hub) {
+    mid.ptr[mid.n] = plan->hub.bin_ptr.p;
+    mid.rec[mid.n] = plan->hub_rec.p;
+    mid.val[mid.n] = plan->hub_val.p;
+    mid.zrec[mid.n++] = plan->n_hubs << PB_MID_ROW_BITS;
+  }
+  for (int t = 0; t < plan->n_mid_tiers; t++) {
+    mid.ptr[mid.n] = plan->mid[t].layout.bin_ptr.p;
+    mid.rec[mid.n] = plan->mid[t].rec.p;
+    mid.val[mid.n] = plan->mid[t].val.p;
+    mid.zrec[mid.n++] = plan->mid[t].n << PB_MID_ROW_BITS;
+  }
+#ifdef GDN_EXPERIMENTS
+  if (const char *e = getenv("GDN_PB_MIDVAR")) mid.variant = atoi(e);
+#endif
   // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
   const bool whole = first && last;
   const unsigned b0 = whole ? 0u : pb_first_bin_at(pb, row_begin);
@@ -408,11 +460,10 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
 #else
                        0,
 #endif
-                       b0, plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
-                       plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr,
+                       b0, nullptr, nullptr, nullptr, nullptr,
                        pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, nullptr,
                        plan->has_hr ? plan->hrb_ptr.p : nullptr, plan->has_hr ? plan->hrb_vl.p : nullptr,
-                       plan->has_hr ? plan->hr_total.p : nullptr);
+                       plan->has_hr ? plan->hr_total.p : nullptr, mid);
   if (last) {
     if (timed) {
       GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
@@ -503,6 +554,20 @@ int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edg
   GDN_REQUIRE(plan != nullptr, "plan");
   if (n_hubs) *n_hubs = plan->has_hub ? (int32_t)plan->n_hubs : 0;
   if (hub_edges) *hub_edges = plan->has_hub ? plan->hub.nnz : 0;
+  return GDN_OK;
+}
+
+int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  int32_t ns = 0;
+  uint64_t ne = 0;
+  for (int t = 0; t < plan->n_mid_tiers; t++) {
+    ns += (int32_t)plan->mid[t].n;
+    ne += plan->mid[t].layout.nnz;
+  }
+  if (n_tiers) *n_tiers = plan->n_mid_tiers;
+  if (n_sources) *n_sources = ns;
+  if (n_edges) *n_edges = ne;
   return GDN_OK;
 }
 

@@ -170,6 +170,9 @@ int gdn_pr_plan_layout(const gdn_pr_plan *plan, int32_t *layout, int32_t *log_bl
  * GDN_ERR_OVERFLOW if any launch on this plan saw a value outside that range (blocking) */
 /* hub tier of the PB layout (0 / 0 when the plan has none): number of hub sources and of the edges that leave them */
 int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edges);
+/* mid tiers of the PB layout (the degree levels below the hubs, read by phase B as 32-bit (source, row) records):
+ * number of tiers, their sources and their edges (0 / 0 / 0 when the plan has none) */
+int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges);
 int gdn_pr_plan_check(gdn_pr_plan *plan);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */

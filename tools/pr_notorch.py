@@ -34,6 +34,9 @@ _cabi.check(L.gdn_pr_plan_create(gi, deg, m, 0, 1, C.byref(plan)))
 nh, he = C.c_int32(0), C.c_uint64(0)
 _cabi.check(L.gdn_pr_plan_hubs(plan, C.byref(nh), C.byref(he)))
 print("hub tier: %d hubs, %d edges (%.1f %% of %d)" % (nh.value, he.value, 100.0 * he.value / max(nnz, 1), nnz))
+mt, ms, me = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+_cabi.check(L.gdn_pr_plan_mid(plan, C.byref(mt), C.byref(ms), C.byref(me)))
+print("mid tiers: %d, %d sources, %d edges (%.1f %%)" % (mt.value, ms.value, me.value, 100.0 * me.value / max(nnz, 1)))
 _cabi.check(L.gdn_pr_contrib_dev(plan, scores, c0, None))
 bufs = [c0, c1]
 for it in range(3):
