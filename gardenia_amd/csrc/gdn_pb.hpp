@@ -131,8 +131,14 @@ struct PbMidArgs {  // kernel argument of phase B
   const uint32_t *rec[PB_MAX_REC_TIERS];
   const float *val[PB_MAX_REC_TIERS];      // n + 1 values (slot n = 0 for pad records)
   unsigned zrec[PB_MAX_REC_TIERS];         // the pad record: n << PB_MID_ROW_BITS
+  int form[PB_MAX_REC_TIERS];              // 0 record per lane, 1 four records per lane + table window (val: n + 4 slots)
   int n = 0;
-  int variant = 0;  // measurement knob (GDN_EXPERIMENTS builds)
+};
+struct PbTierRefresh {  // kernel argument of phase A (PageRank): the tier tables are refreshed by the same launch
+  const uint32_t *ids[PB_MAX_REC_TIERS];  // original id of source k
+  float *val[PB_MAX_REC_TIERS];           // slots[t] entries: the code of x[ids[k]] for k < n[t], 0 behind
+  unsigned n[PB_MAX_REC_TIERS], slots[PB_MAX_REC_TIERS];
+  int ntiers = 0;
 };
 int pb_pick_tiers(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
                   unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid);
@@ -152,11 +158,16 @@ typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
 
 // hub_val[k] = x[hub_ids[k]] (PageRank: contrib, SpMV: x); the slots behind the hubs (incl. the pad slot 32768) stay 0
-// table of a mid tier: val[k] = x[ids[k]], val[n] = 0
+__device__ __forceinline__ uint32_t pb_encode(float v, unsigned &bad);
+// table of a record tier (PageRank): val[k] = pb_encode(x[ids[k]]) for k < n, 0 (= the code of 0.0) up to n_slots
 static __global__ void __launch_bounds__(GDN_BLOCK)
-pb_mid_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, float *__restrict__ val) {
+pb_tier_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
+                      float *__restrict__ val, unsigned *__restrict__ errflag) {
   const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (k <= n) val[k] = k < n ? x[ids[k]] : 0.0f;
+  if (k >= n_slots) return;
+  unsigned bad = 0u;
+  val[k] = k < n ? __uint_as_float(pb_encode(x[ids[k]], bad)) : 0.0f;
+  if (bad) *errflag = 1u;
 }
 
 static __global__ void __launch_bounds__(GDN_BLOCK)
@@ -190,7 +201,7 @@ __device__ __forceinline__ unsigned pb_block_excl_scan(unsigned v, unsigned *scr
 // first active id; fn(id, k) is called for every ACTIVE id (k = index inside the slice) and
 // fn_inactive(id) for the others, ids visited in coalesced order.
 template <class FA, class FI>
-__device__ __forceinline__ void pb_walk_slice(const uint32_t *__restrict__ bits, unsigned lo, unsigned hi,
+__device__ __forceinline__ unsigned pb_walk_slice(const uint32_t *__restrict__ bits, unsigned lo, unsigned hi,
                                               unsigned *s_bits, unsigned *s_pref, unsigned *s_scr, FA fn, FI fn_inactive) {
   unsigned running = 0;
   const unsigned w_begin = lo >> 5, w_end = (hi + 31u) >> 5;
@@ -219,6 +230,7 @@ __device__ __forceinline__ void pb_walk_slice(const uint32_t *__restrict__ bits,
     running += total;
     __syncthreads();
   }
+  return running;  // active ids of the slice (the same in every thread)
 }
 
 // Epilogue walk over the original rows [lo,hi) of a bin with software prefetch: per step every thread
@@ -277,7 +289,7 @@ __device__ __forceinline__ double pb_epilogue(const uint32_t *__restrict__ bits,
 // A tile is 32*PB_THREADS ids = 8*PB_THREADS groups of 4 ids; every thread issues the loads of its 8
 // groups back to back (one HBM round trip per tile instead of eight), then squeezes them into LDS
 // through the activity nibble.  x must be 16-byte aligned; ids beyond m_global are never active.
-__device__ __forceinline__ void pb_load_slice4(const float *__restrict__ x, int32_t m_global,
+__device__ __forceinline__ unsigned pb_load_slice4(const float *__restrict__ x, int32_t m_global,
                                                const uint32_t *__restrict__ bits, unsigned lo, unsigned hi, float *s_x,
                                                unsigned *s_bits, unsigned *s_pref, unsigned *s_scr) {
   unsigned running = 0;
@@ -326,6 +338,7 @@ __device__ __forceinline__ void pb_load_slice4(const float *__restrict__ x, int3
     running += total;
     __syncthreads();
   }
+  return running;
 }
 
 // 16-byte form of pb_epilogue (Op::vec_ok: every row array of the op is 16-byte aligned): a thread owns
@@ -411,6 +424,22 @@ __device__ __forceinline__ unsigned long long pb_to_fixed(float v, unsigned &bad
   return ok ? r : 0ull;
 }
 
+// The same conversion cut in two (PageRank): pb_encode runs ONCE PER SOURCE (phase A's slice, the tier tables) and
+// leaves the value as (shift + 1) << 24 | 24-bit mantissa -- the same information as the fp32 -- and pb_decode, which
+// phase B runs once PER EDGE, is two 32-bit shifts and one 64-bit shift: pb_decode(pb_encode(v)) == pb_to_fixed(v)
+// bit for bit.  Phase B is bound by its per-edge VALU work, not by memory.
+__device__ __forceinline__ uint32_t pb_encode(float v, unsigned &bad) {
+  const unsigned bits = __float_as_uint(v);
+  const bool ok = bits <= 0x3F800000u;
+  bad |= ok ? 0u : 1u;
+  const unsigned sh = 127u - (bits >> 23);  // wraps for e > 127, which is !ok
+  const unsigned mant = (bits & 0x7FFFFFu) | 0x800000u;
+  return (ok && sh < 63u) ? (((sh + 1u) << 24) | mant) : 0u;  // shifts >= 63 leave nothing of a 24-bit mantissa
+}
+__device__ __forceinline__ unsigned long long pb_decode(uint32_t enc) {
+  return ((unsigned long long)(enc << 8) << 32) >> (enc >> 24);  // mantissa * 2^40 >> (shift + 1)
+}
+
 // phase A: vals[group(G[g]) + i] = x[chunk*CH + U[...]]
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
@@ -423,8 +452,19 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
                  const eoff_t *__restrict__ hr_ptr = nullptr, const uint16_t *__restrict__ hr_U = nullptr,
                  const uint16_t *__restrict__ hr_R = nullptr, unsigned hr_n = 0,
                  unsigned long long *__restrict__ hr_partial = nullptr, unsigned *__restrict__ errflag = nullptr,
-                 unsigned pad_slot = 0) {  // PbPlan::chunk_slots (0 = 2^log_chunk)
+                 unsigned pad_slot = 0,  // PbPlan::chunk_slots (0 = 2^log_chunk)
+                 PbTierRefresh tiers = PbTierRefresh()) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
+  // every workgroup first refreshes its share of the tier tables phase B reads (a few hundred entries: three tiny
+  // launches between A and B otherwise)
+  for (int t = 0; t < tiers.ntiers; t++) {
+    const unsigned per = (tiers.slots[t] + gridDim.x - 1) / gridDim.x;
+    const unsigned k0 = blockIdx.x * per, k1 = k0 + per < tiers.slots[t] ? k0 + per : tiers.slots[t];
+    unsigned bad_t = 0u;
+    for (unsigned k = k0 + threadIdx.x; k < k1; k += PB_THREADS)
+      tiers.val[t][k] = k < tiers.n[t] ? __uint_as_float(pb_encode(x[tiers.ids[t][k]], bad_t)) : 0.0f;
+    if (bad_t && errflag) *errflag = 1u;
+  }
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
   // `split` workgroups share one chunk (same LDS slice, consecutive parts of its edge range): more,
@@ -432,12 +472,13 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   const unsigned c = chunk_order[blockIdx.x / split];
   const unsigned part = blockIdx.x % split;
   const size_t base = (size_t)c << log_chunk;
+  unsigned n_slots = ch;  // slots of the slice that hold a source value
   if (src_bits) {  // compacted slice: the chunk's active sources, gathered from their original id range
     if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0 && !(nt_store & 2))
-      pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
+      n_slots = pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
     else
-      pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
-                    [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
+      n_slots = pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
+                              [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
   } else if (base + ch <= (size_t)m_global) {  // whole slice in range: 16-byte loads
     const pb_f32x4 *x4 = reinterpret_cast<const pb_f32x4 *>(x + base);
     pb_f32x4 *s4 = reinterpret_cast<pb_f32x4 *>(s_x);
@@ -450,6 +491,15 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
     }
   }
   const unsigned zslot = pad_slot ? pad_slot : ch;
+  // the slice becomes fixed-point codes (pb_encode): the float -> fixed conversion is paid per source here, not per
+  // edge in phase B; the code of 0.0 is 0, so the zero slot and the bits that travel through vals stay what they were
+  __syncthreads();
+  {
+    unsigned bad_a = 0u;
+    uint32_t *s_u = reinterpret_cast<uint32_t *>(s_x);
+    for (unsigned i = threadIdx.x; i < n_slots; i += PB_THREADS) s_u[i] = pb_encode(s_x[i], bad_a);
+    if (bad_a && errflag) *errflag = 1u;
+  }
   if (threadIdx.x == 0) s_x[zslot] = 0.0f;  // zero slot for pad edges
   unsigned long long *s_hr = reinterpret_cast<unsigned long long *>(s_x + zslot + 4);  // 16 bytes behind the zero slot
   // hub-row tier: PB_HR_THREADS threads (two waves) fold the hub-row edge list while the others run the main sweep --
@@ -525,7 +575,7 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const unsigned row = v[j][k];
-            const unsigned long long f = pb_to_fixed(s_x[u[j][k]], bad);
+            const unsigned long long f = pb_decode(__float_as_uint(s_x[u[j][k]]));
             if (row == cur) acc += f;
             else {
               if (cur != 0xFFFFFFFFu) atomicAdd(&s_hr[cur], acc);
@@ -847,21 +897,53 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     }
   }
   for (int t = 0; t < ((dbg & 8) ? 0 : mid.n); t++) {
-    // record streams, sorted by source: a lane owns 4 consecutive records per 16-byte load, MU loads per step, and the
-    // loads of step k+1 are in flight while the values of step k are fetched from the tier's table and added (as much
-    // in flight per CU as the main stream keeps).  Sorted by source, the table reads of one wave instruction fall
-    // into a few consecutive lines: near-coalesced L2 hits, not a divergent gather.
-    typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
-    const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
+    // record streams, sorted by source.  Two forms (PbMidArgs::form):
+    //  0  one record per lane and load (mid tiers): the 64 table reads of a wave instruction fall into a few
+    //     consecutive lines -- near-coalesced L2 hits, not a divergent gather
+    //  1  four consecutive records per lane (hubs: several records per source and bin): ONE 16-byte read of the table
+    //     window [k0, k0 + 4) behind the lane's first source serves the four of them; a record further away (rare)
+    //     falls back to its own read.  A per-lane table read costs vector-memory issue time whatever it hits, and
+    //     this form needs a quarter of them.
     const float *__restrict__ T = mid.val[t];
-    const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
     const unsigned z = mid.zrec[t];
     constexpr unsigned RMASK = (1u << PB_MID_ROW_BITS) - 1u;
-    if (mid.variant >= 1) {  // the first form: one record per lane and load, no pipelining
+    if (mid.form[t] == 0) {
       const uint32_t *__restrict__ R = mid.rec[t] + mid.ptr[t][b];
-      const unsigned nr = nr4 << 2;
-      constexpr int MUNR = 8;
-      for (unsigned i0 = threadIdx.x; i0 < nr; i0 += (unsigned)MUNR * PB_THREADS) {
+      const unsigned nr = (unsigned)(mid.ptr[t][b + 1] - mid.ptr[t][b]);
+#ifndef PB_REC_MUNR
+#define PB_REC_MUNR 8
+#endif
+#ifndef PB_REC_PIPE
+#define PB_REC_PIPE 0
+#endif
+      constexpr int MUNR = PB_REC_MUNR;
+      constexpr unsigned RSTEP = (unsigned)MUNR * PB_THREADS;
+#if PB_REC_PIPE
+      // the loads of step k+1 are in flight while the values of step k are fetched from the table and added
+      uint32_t rc[MUNR], nx[MUNR];
+#pragma unroll
+      for (int r = 0; r < MUNR; r++) {
+        const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
+        rc[r] = z;
+        if (i < nr) rc[r] = __builtin_nontemporal_load(R + i);
+      }
+      for (unsigned s0 = 0; s0 < nr; s0 += RSTEP) {
+        float f[MUNR];
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) {
+          const unsigned i = s0 + RSTEP + threadIdx.x + (unsigned)r * PB_THREADS;
+          nx[r] = z;
+          if (i < nr) nx[r] = __builtin_nontemporal_load(R + i);
+        }
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) f[r] = T[rc[r] >> PB_MID_ROW_BITS];
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) rc[r] = nx[r];
+      }
+#else
+      for (unsigned i0 = threadIdx.x; i0 < nr; i0 += RSTEP) {
         uint32_t rc[MUNR];
         float f[MUNR];
 #pragma unroll
@@ -870,48 +952,47 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
           rc[r] = z;
           if (i < nr) rc[r] = __builtin_nontemporal_load(R + i);
         }
-        // variants >= 2: TIMING-ONLY ablations (wrong results): 2 no table read, 3 no LDS atomics, 4 every table read
-        // of a wave in one line
+#ifndef PB_REC_ABL  // TIMING-ONLY ablations (wrong results): 1 no table read, 2 no LDS atomics, 3 neither
+#define PB_REC_ABL 0
+#endif
 #pragma unroll
-        for (int r = 0; r < MUNR; r++)
-          f[r] = mid.variant == 2 ? 1e-9f : T[mid.variant == 4 ? ((rc[r] >> PB_MID_ROW_BITS) & 31u) : (rc[r] >> PB_MID_ROW_BITS)];
-        if (mid.variant == 3) {
+        for (int r = 0; r < MUNR; r++) f[r] = (PB_REC_ABL & 1) ? __uint_as_float(rc[r] | 0x1000000u) : T[rc[r] >> PB_MID_ROW_BITS];
 #pragma unroll
-          for (int r = 0; r < MUNR; r++) bad |= (unsigned)(f[r] == 123.456f) + (unsigned)((rc[r] & RMASK) == 77777u);
-        } else {
-#pragma unroll
-          for (int r = 0; r < MUNR; r++) atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
+        for (int r = 0; r < MUNR; r++) {
+          if (PB_REC_ABL & 2) bad |= (unsigned)(f[r] == 123.456f) + (unsigned)((rc[r] & RMASK) == 77777u);
+          else atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
         }
       }
+#endif
       continue;
     }
+    typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
+    typedef float pb_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned window
+    const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
+    const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
     constexpr int MU = 4;
-    constexpr unsigned MSTEP = (unsigned)MU * PB_THREADS;
-    pb_u32x4 cur[MU], nxt[MU];
-#pragma unroll
-    for (int r = 0; r < MU; r++) {
-      const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
-      cur[r] = pb_u32x4{z, z, z, z};
-      if (i < nr4) cur[r] = __builtin_nontemporal_load(R4 + i);
-    }
-    for (unsigned s0 = 0; s0 < nr4; s0 += MSTEP) {
+    for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)MU * PB_THREADS) {
+      pb_u32x4 rc[MU];
+      pb_f32x4 w[MU];
 #pragma unroll
       for (int r = 0; r < MU; r++) {
-        const unsigned i = s0 + MSTEP + threadIdx.x + (unsigned)r * PB_THREADS;
-        nxt[r] = pb_u32x4{z, z, z, z};
-        if (i < nr4) nxt[r] = __builtin_nontemporal_load(R4 + i);
+        const unsigned i = i0 + (unsigned)r * PB_THREADS;
+        rc[r] = pb_u32x4{z, z, z, z};
+        if (i < nr4) rc[r] = __builtin_nontemporal_load(R4 + i);
       }
-      float f[MU][4];
 #pragma unroll
-      for (int r = 0; r < MU; r++)
+      for (int r = 0; r < MU; r++) w[r] = *reinterpret_cast<const pb_f32x4_a4 *>(T + (rc[r].x >> PB_MID_ROW_BITS));
 #pragma unroll
-        for (int k = 0; k < 4; k++) f[r][k] = T[cur[r][k] >> PB_MID_ROW_BITS];
+      for (int r = 0; r < MU; r++) {
+        const unsigned k0 = rc[r].x >> PB_MID_ROW_BITS;
 #pragma unroll
-      for (int r = 0; r < MU; r++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) atomicAdd(&s_acc[cur[r][k] & RMASK], op.to_fixed(f[r][k], bad));
-#pragma unroll
-      for (int r = 0; r < MU; r++) cur[r] = nxt[r];
+        for (int j = 0; j < 4; j++) {
+          const unsigned d = (rc[r][j] >> PB_MID_ROW_BITS) - k0;
+          float f = d == 0 ? w[r].x : (d == 1 ? w[r].y : (d == 2 ? w[r].z : w[r].w));
+          if (d > 3u) f = T[rc[r][j] >> PB_MID_ROW_BITS];  // also a source in FRONT of k0 (never in a sorted stream)
+          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(f, bad));
+        }
+      }
     }
   }
   __syncthreads();

@@ -63,8 +63,9 @@ struct PrOp {
   float base_score;
   float damping;
   __device__ __forceinline__ float load(uint64_t, vid_t col) const { return contrib_in[col]; }
-  // PB layout: unsigned 2^-62 fixed point (gdn_pb.hpp)
-  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const { return pb_to_fixed(v, bad); }
+  // PB layout: unsigned 2^-62 fixed point (gdn_pb.hpp).  What phase B reads (vals, the tier tables) are the CODES
+  // pb_encode made of the contributions, once per source: per edge only the decode is left
+  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &) const { return pb_decode(__float_as_uint(v)); }
   __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &bad) const {
     if (a >> 63) bad = 1u;
     return ldexpf((float)a, -PB_FIX_SHIFT);
@@ -289,7 +290,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
                       p->hub.nchunks, p->hub.nbins, p->pb.nbins);
         st = GDN_ERR_INVALID;
       }
-      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS);
+      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS + 3);  // + the window behind the last slot
       // read by phase B as one record stream like the mid tiers (U, V and G of the layout are released)
       if (st == GDN_OK) st = pb_mid_finish(p->hub, p->n_hubs, p->hub_rec);
       if (st == GDN_OK) p->has_hub = true;
@@ -303,7 +304,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
         st = GDN_ERR_INVALID;
       }
       if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec);
-      if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 1);
+      if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
       if (st == GDN_OK) {
         mt.n = n_mid[t];
         mt.ids.p = mid_ids[t].p;  // take the buffer over
@@ -311,6 +312,46 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
         mid_ids[t].p = nullptr;
         mid_ids[t].n = 0;
         p->n_mid_tiers = t + 1;
+      }
+    }
+    if (st == GDN_OK && (p->has_hub || p->n_mid_tiers)) {
+      // launch order of phase B: largest first by ALL the bytes of a bin (main stream 6 B/edge, records 4 B, 16 B per row
+      // of its original range), not by its main stream alone
+      const unsigned nb = p->pb.nbins;
+      std::vector<eoff_t> bp((size_t)nb + 1), tp((size_t)nb + 1);
+      std::vector<uint32_t> blo((size_t)nb + 1, 0u);
+      std::vector<double> work(nb, 0.0);
+      auto get = [&](const DevBuf<eoff_t> &d, std::vector<eoff_t> &h) {
+        return hipMemcpy(h.data(), d.p, h.size() * sizeof(eoff_t), hipMemcpyDeviceToHost) == hipSuccess;
+      };
+      bool ok = get(p->pb.bin_ptr, bp);
+      for (unsigned b = 0; ok && b < nb; b++) work[b] = 6.0 * (double)(bp[b + 1] - bp[b]);
+      if (ok && p->pb.compact) {
+        ok = hipMemcpy(blo.data(), p->pb.bin_lo.p, blo.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        for (unsigned b = 0; ok && b < nb; b++) work[b] += 16.0 * (double)(blo[b + 1] - blo[b]);
+      }
+      if (ok && p->has_hub) {
+        ok = get(p->hub.bin_ptr, tp);
+        for (unsigned b = 0; ok && b < nb; b++) work[b] += 4.0 * (double)(tp[b + 1] - tp[b]);
+      }
+      for (int t = 0; ok && t < p->n_mid_tiers; t++) {
+        ok = get(p->mid[t].layout.bin_ptr, tp);
+        for (unsigned b = 0; ok && b < nb; b++) work[b] += 4.0 * (double)(tp[b + 1] - tp[b]);
+      }
+      std::vector<uint32_t> bo(nb);
+      for (unsigned b = 0; b < nb; b++) bo[b] = b;
+      std::stable_sort(bo.begin(), bo.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
+      if (!ok || hipMemcpy(p->pb.bin_order.p, bo.data(), (size_t)nb * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        gdn_set_error("gdn_pr_plan_create: bin order update failed");
+        st = GDN_ERR_HIP;
+      }
+      if (getenv("GDN_PB_TRACE") && ok && nb) {
+        double mx = 0, sum = 0;
+        for (unsigned b = 0; b < nb; b++) {
+          sum += work[b];
+          if (work[b] > mx) mx = work[b];
+        }
+        fprintf(stderr, "[gdn_pr_plan] bins %u: %.1f MB each on average, largest %.1f MB\n", nb, sum / nb / 1e6, mx / 1e6);
       }
     }
     if (st == GDN_OK && p->pb.compact) {  // row -> bin lookups of partial launches (gdn_pr_pull_rows_dev)
@@ -409,6 +450,19 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
       split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
       if (split < 1 || split > 64) split = 1;
     }
+    PbTierRefresh tr;
+    if (plan->has_hub) {
+      tr.ids[tr.ntiers] = plan->hub_ids.p;
+      tr.val[tr.ntiers] = plan->hub_val.p;
+      tr.n[tr.ntiers] = plan->n_hubs;
+      tr.slots[tr.ntiers++] = (unsigned)PB_HUB_SLOTS + 3u;
+    }
+    for (int t = 0; t < plan->n_mid_tiers; t++) {
+      tr.ids[tr.ntiers] = plan->mid[t].ids.p;
+      tr.val[tr.ntiers] = plan->mid[t].val.p;
+      tr.n[tr.ntiers] = plan->mid[t].n;
+      tr.slots[tr.ntiers++] = plan->mid[t].n + 4u;
+    }
     hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
                        pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                        pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
@@ -419,16 +473,10 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
 #endif
                        plan->has_hr ? plan->hr.chunk_ptr.p : nullptr, plan->has_hr ? plan->hr.U.p : nullptr,
                        plan->has_hr ? plan->hr.V.p : nullptr, plan->has_hr ? plan->n_hr : 0u,
-                       plan->has_hr ? plan->hr_partial.p : nullptr, pb.errflag.p, pb.chunk_slots);
+                       plan->has_hr ? plan->hr_partial.p : nullptr, pb.errflag.p, pb.chunk_slots, tr);
     if (plan->has_hr)
       hipLaunchKernelGGL(pb_hubrow_reduce_kernel, dim3((plan->n_hr + 63u) / 64u), dim3(PB_THREADS), 0, s, plan->hr_partial.p,
                          pb.nchunks, plan->n_hr, plan->hr_total.p);
-    if (plan->has_hub)
-      hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_contrib_in,
-                         plan->hub_ids.p, plan->n_hubs, plan->hub_val.p);
-    for (int t = 0; t < plan->n_mid_tiers; t++)
-      hipLaunchKernelGGL(pb_mid_gather_kernel, dim3(gdn_nblocks((uint64_t)plan->mid[t].n + 1)), dim3(GDN_BLOCK), 0, s,
-                         d_contrib_in, plan->mid[t].ids.p, plan->mid[t].n, plan->mid[t].val.p);
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }
   PbMidArgs mid;
@@ -436,16 +484,19 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     mid.ptr[mid.n] = plan->hub.bin_ptr.p;
     mid.rec[mid.n] = plan->hub_rec.p;
     mid.val[mid.n] = plan->hub_val.p;
-    mid.zrec[mid.n++] = plan->n_hubs << PB_MID_ROW_BITS;
+    mid.zrec[mid.n] = plan->n_hubs << PB_MID_ROW_BITS;
+    mid.form[mid.n++] = 1;
   }
   for (int t = 0; t < plan->n_mid_tiers; t++) {
     mid.ptr[mid.n] = plan->mid[t].layout.bin_ptr.p;
     mid.rec[mid.n] = plan->mid[t].rec.p;
     mid.val[mid.n] = plan->mid[t].val.p;
-    mid.zrec[mid.n++] = plan->mid[t].n << PB_MID_ROW_BITS;
+    mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
+    mid.form[mid.n++] = 0;
   }
-#ifdef GDN_EXPERIMENTS
-  if (const char *e = getenv("GDN_PB_MIDVAR")) mid.variant = atoi(e);
+#ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)
+  if (const char *e = getenv("GDN_PB_MIDVAR"))
+    for (int t = 0; t < mid.n; t++) mid.form[t] = (atoi(e) >> t) & 1;
 #endif
   // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
   const bool whole = first && last;
