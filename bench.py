@@ -110,10 +110,14 @@ def main():
     if be.layout == 1:
         nh, he = C.c_int32(0), C.c_uint64(0)
         _cabi.check(L.gdn_pr_plan_hubs(be.plan, C.byref(nh), C.byref(he)))
-        if nh.value:
-            layout_name += "; hub tier: the %d sources with the most out-edges (%.1f %% of this rank's edges) are read by " \
-                           "the accumulate phase as (u16 hub, u16 row) pairs, their values from a per-iteration table" \
-                           % (nh.value, 100.0 * he.value / max(snnz.value, 1))
+        mt, ms_, me = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+        _cabi.check(L.gdn_pr_plan_mid(be.plan, C.byref(mt), C.byref(ms_), C.byref(me)))
+        if nh.value or mt.value:
+            layout_name += "; record tiers: the %d hub sources (%.1f %% of this rank's edges) and %d mid-tier sources " \
+                           "(%.1f %%) bypass the expand phase -- the accumulate phase reads their edges as 32-bit " \
+                           "(source, row) records sorted by source, values from per-iteration tables of fixed-point codes" \
+                           % (nh.value, 100.0 * he.value / max(snnz.value, 1), ms_.value,
+                              100.0 * me.value / max(snnz.value, 1))
     pr = ShardedPageRank(be, m, rank, world, dist if world > 1 else None)
     pr.init_contrib()
 
