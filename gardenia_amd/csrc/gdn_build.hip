@@ -760,7 +760,8 @@ int pb_pick_hubs(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8
 __global__ void __launch_bounds__(GDN_BLOCK)
 pb_mid_records_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict__ V, const uint32_t *__restrict__ G,
                       const eoff_t *__restrict__ chunk_ptr, unsigned nchunks, unsigned long long ngroups, int log_group,
-                      int log_chunk, unsigned pad_id, unsigned zslot, uint32_t *__restrict__ rec) {
+                      int log_chunk, unsigned pad_id, unsigned zslot, uint32_t *__restrict__ rec,
+                      const float *__restrict__ ev_in, float *__restrict__ ev_out) {
   const unsigned long long g = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (g >= ngroups) return;
   const uint32_t dst = G[g];
@@ -773,10 +774,11 @@ pb_mid_records_kernel(const uint16_t *__restrict__ U, const uint16_t *__restrict
     const unsigned u = U[e0 + i];
     const unsigned k = (u == pad_id) ? zslot : ((c << log_chunk) + u);
     rec[((size_t)dst << log_group) + i] = (k << PB_MID_ROW_BITS) | (unsigned)V[((size_t)dst << log_group) + i];
+    if (ev_in) ev_out[((size_t)dst << log_group) + i] = ev_in[e0 + i];
   }
 }
 
-int pb_mid_finish(PbPlan &p, unsigned n_src, DevBuf<uint32_t> &rec) {
+int pb_mid_finish(PbPlan &p, unsigned n_src, DevBuf<uint32_t> &rec, DevBuf<float> *ev) {
   GDN_REQUIRE(p.log_bin <= PB_MID_ROW_BITS && n_src <= PB_MID_MAX, "mid tier: row / source index width");
   GDN_REQUIRE(((size_t)p.nchunks << p.log_chunk) >= n_src && p.chunk_slots == (1u << p.log_chunk), "mid tier: chunks");
   const unsigned grp = 1u << p.log_group;
@@ -786,11 +788,24 @@ int pb_mid_finish(PbPlan &p, unsigned n_src, DevBuf<uint32_t> &rec) {
   const unsigned long long fb = (p.n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
   hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, rec.p,
                      p.n_pad + grp, zrec);
+  DevBuf<float> ev_b;  // the per-edge values in record (bin-major) order
+  if (ev) {
+    GDN_TRY(ev_b.alloc(p.n_pad + grp));
+    GDN_HIP(hipMemset(ev_b.p, 0, (p.n_pad + grp) * sizeof(float)));
+  }
   if (ngroups)
     hipLaunchKernelGGL(pb_mid_records_kernel, dim3(gdn_nblocks(ngroups)), dim3(GDN_BLOCK), 0, 0, p.U.p, p.V.p, p.G.p,
-                       p.chunk_ptr.p, p.nchunks, ngroups, p.log_group, p.log_chunk, p.chunk_slots, n_src, rec.p);
+                       p.chunk_ptr.p, p.nchunks, ngroups, p.log_group, p.log_chunk, p.chunk_slots, n_src, rec.p,
+                       ev ? ev->p : nullptr, ev ? ev_b.p : nullptr);
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());
+  if (ev) {
+    ev->release();
+    ev->p = ev_b.p;
+    ev->n = ev_b.n;
+    ev_b.p = nullptr;
+    ev_b.n = 0;
+  }
   p.U.release();
   p.V.release();
   p.G.release();
@@ -861,6 +876,37 @@ int pb_pick_hub_rows(const gdn_graph *g, unsigned max_rows, uint64_t min_deg, De
   std::sort(ids.begin(), ids.end());  // hub row k = k-th marked row in id order = its compact row index in the hub-row layout
   GDN_HIP(hipMemcpy(row_ids.p, ids.data(), (size_t)n * 4, hipMemcpyHostToDevice));
   *n_rows = n;
+  return GDN_OK;
+}
+
+int pb_order_bins_by_work(PbPlan &main, int n_tiers, const eoff_t *const *tier_bin_ptr, double main_bytes_per_edge,
+                          double rec_bytes, double row_bytes) {
+  const unsigned nb = main.nbins;
+  std::vector<eoff_t> bp((size_t)nb + 1);
+  std::vector<uint32_t> blo((size_t)nb + 1, 0u);
+  std::vector<double> work(nb, 0.0);
+  GDN_HIP(hipMemcpy(bp.data(), main.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  for (unsigned b = 0; b < nb; b++) work[b] = main_bytes_per_edge * (double)(bp[b + 1] - bp[b]);
+  if (main.compact) {
+    GDN_HIP(hipMemcpy(blo.data(), main.bin_lo.p, blo.size() * 4, hipMemcpyDeviceToHost));
+    for (unsigned b = 0; b < nb; b++) work[b] += row_bytes * (double)(blo[b + 1] - blo[b]);
+  }
+  for (int t = 0; t < n_tiers; t++) {
+    GDN_HIP(hipMemcpy(bp.data(), tier_bin_ptr[t], bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+    for (unsigned b = 0; b < nb; b++) work[b] += rec_bytes * (double)(bp[b + 1] - bp[b]);
+  }
+  std::vector<uint32_t> bo(nb);
+  for (unsigned b = 0; b < nb; b++) bo[b] = b;
+  std::stable_sort(bo.begin(), bo.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
+  GDN_HIP(hipMemcpy(main.bin_order.p, bo.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
+  if (getenv("GDN_PB_TRACE") && nb) {
+    double mx = 0, sum = 0;
+    for (unsigned b = 0; b < nb; b++) {
+      sum += work[b];
+      if (work[b] > mx) mx = work[b];
+    }
+    fprintf(stderr, "[pb_order_bins] bins %u: %.1f MB each on average, largest %.1f MB\n", nb, sum / nb / 1e6, mx / 1e6);
+  }
   return GDN_OK;
 }
 

@@ -132,6 +132,7 @@ struct PbMidArgs {  // kernel argument of phase B
   const float *val[PB_MAX_REC_TIERS];      // n + 1 values (slot n = 0 for pad records)
   unsigned zrec[PB_MAX_REC_TIERS];         // the pad record: n << PB_MID_ROW_BITS
   int form[PB_MAX_REC_TIERS];              // 0 record per lane, 1 four records per lane + table window (val: n + 4 slots)
+  const float *A[PB_MAX_REC_TIERS];        // nullable: per-record factor (SpMV's Ax in record order): value = table * A
   int n = 0;
 };
 struct PbTierRefresh {  // kernel argument of phase A (PageRank): the tier tables are refreshed by the same launch
@@ -144,7 +145,12 @@ int pb_pick_tiers(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf
                   unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid);
 // turns the layout pb_build made for one mid class (log_chunk 15, src_major, same bins as the main layout) into the
 // bin-major record stream; releases U, V and G of the layout
-int pb_mid_finish(PbPlan &layout, unsigned n_src, DevBuf<uint32_t> &rec);
+// ev (nullable): the layout's per-edge values (pb_build's edge_vals_out, chunk-major) are moved into record order
+int pb_mid_finish(PbPlan &layout, unsigned n_src, DevBuf<uint32_t> &rec, DevBuf<float> *ev = nullptr);
+// launch order of phase B: largest first by ALL the bytes of a bin -- main stream, the record streams of the tiers
+// (tier_bin_ptr[t]: device array of nbins + 1 record offsets), the rows of its original range
+int pb_order_bins_by_work(PbPlan &main, int n_tiers, const eoff_t *const *tier_bin_ptr, double main_bytes_per_edge,
+                          double rec_bytes, double row_bytes);
 
 // the rows with the most in-edges (gdn_build.hip): at most max_rows rows with >= min_deg in-edges each
 uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full);  // vertices per slice after round balancing
@@ -168,6 +174,14 @@ pb_tier_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ 
   unsigned bad = 0u;
   val[k] = k < n ? __uint_as_float(pb_encode(x[ids[k]], bad)) : 0.0f;
   if (bad) *errflag = 1u;
+}
+
+// plain-float table of a record tier (SpMV): val[k] = x[ids[k]] for k < n, 0 up to n_slots
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
+                          float *__restrict__ val) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < n_slots) val[k] = k < n ? x[ids[k]] : 0.0f;
 }
 
 static __global__ void __launch_bounds__(GDN_BLOCK)
@@ -905,80 +919,53 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     //     falls back to its own read.  A per-lane table read costs vector-memory issue time whatever it hits, and
     //     this form needs a quarter of them.
     const float *__restrict__ T = mid.val[t];
+    const float *__restrict__ FA = mid.A[t] ? mid.A[t] + mid.ptr[t][b] : nullptr;  // per-record factors
     const unsigned z = mid.zrec[t];
     constexpr unsigned RMASK = (1u << PB_MID_ROW_BITS) - 1u;
     if (mid.form[t] == 0) {
       const uint32_t *__restrict__ R = mid.rec[t] + mid.ptr[t][b];
       const unsigned nr = (unsigned)(mid.ptr[t][b + 1] - mid.ptr[t][b]);
-#ifndef PB_REC_MUNR
-#define PB_REC_MUNR 8
-#endif
-#ifndef PB_REC_PIPE
-#define PB_REC_PIPE 0
-#endif
-      constexpr int MUNR = PB_REC_MUNR;
+      constexpr int MUNR = 8;
       constexpr unsigned RSTEP = (unsigned)MUNR * PB_THREADS;
-#if PB_REC_PIPE
-      // the loads of step k+1 are in flight while the values of step k are fetched from the table and added
-      uint32_t rc[MUNR], nx[MUNR];
-#pragma unroll
-      for (int r = 0; r < MUNR; r++) {
-        const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
-        rc[r] = z;
-        if (i < nr) rc[r] = __builtin_nontemporal_load(R + i);
-      }
-      for (unsigned s0 = 0; s0 < nr; s0 += RSTEP) {
-        float f[MUNR];
-#pragma unroll
-        for (int r = 0; r < MUNR; r++) {
-          const unsigned i = s0 + RSTEP + threadIdx.x + (unsigned)r * PB_THREADS;
-          nx[r] = z;
-          if (i < nr) nx[r] = __builtin_nontemporal_load(R + i);
-        }
-#pragma unroll
-        for (int r = 0; r < MUNR; r++) f[r] = T[rc[r] >> PB_MID_ROW_BITS];
-#pragma unroll
-        for (int r = 0; r < MUNR; r++) atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
-#pragma unroll
-        for (int r = 0; r < MUNR; r++) rc[r] = nx[r];
-      }
-#else
       for (unsigned i0 = threadIdx.x; i0 < nr; i0 += RSTEP) {
         uint32_t rc[MUNR];
-        float f[MUNR];
+        float f[MUNR], a[MUNR];
 #pragma unroll
         for (int r = 0; r < MUNR; r++) {
           const unsigned i = i0 + (unsigned)r * PB_THREADS;
           rc[r] = z;
-          if (i < nr) rc[r] = __builtin_nontemporal_load(R + i);
+          a[r] = 0.0f;
+          if (i < nr) {
+            rc[r] = __builtin_nontemporal_load(R + i);
+            if (FA) a[r] = __builtin_nontemporal_load(FA + i);
+          }
         }
-#ifndef PB_REC_ABL  // TIMING-ONLY ablations (wrong results): 1 no table read, 2 no LDS atomics, 3 neither
-#define PB_REC_ABL 0
-#endif
 #pragma unroll
-        for (int r = 0; r < MUNR; r++) f[r] = (PB_REC_ABL & 1) ? __uint_as_float(rc[r] | 0x1000000u) : T[rc[r] >> PB_MID_ROW_BITS];
+        for (int r = 0; r < MUNR; r++) f[r] = T[rc[r] >> PB_MID_ROW_BITS];
 #pragma unroll
-        for (int r = 0; r < MUNR; r++) {
-          if (PB_REC_ABL & 2) bad |= (unsigned)(f[r] == 123.456f) + (unsigned)((rc[r] & RMASK) == 77777u);
-          else atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(f[r], bad));
-        }
+        for (int r = 0; r < MUNR; r++)
+          atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(FA ? __fmul_rn(f[r], a[r]) : f[r], bad));
       }
-#endif
       continue;
     }
     typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
     typedef float pb_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned window
     const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
+    const pb_f32x4 *__restrict__ FA4 = reinterpret_cast<const pb_f32x4 *>(FA);
     const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
     constexpr int MU = 4;
     for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)MU * PB_THREADS) {
       pb_u32x4 rc[MU];
-      pb_f32x4 w[MU];
+      pb_f32x4 w[MU], a[MU];
 #pragma unroll
       for (int r = 0; r < MU; r++) {
         const unsigned i = i0 + (unsigned)r * PB_THREADS;
         rc[r] = pb_u32x4{z, z, z, z};
-        if (i < nr4) rc[r] = __builtin_nontemporal_load(R4 + i);
+        a[r] = pb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < nr4) {
+          rc[r] = __builtin_nontemporal_load(R4 + i);
+          if (FA4) a[r] = __builtin_nontemporal_load(FA4 + i);
+        }
       }
 #pragma unroll
       for (int r = 0; r < MU; r++) w[r] = *reinterpret_cast<const pb_f32x4_a4 *>(T + (rc[r].x >> PB_MID_ROW_BITS));
@@ -990,7 +977,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
           const unsigned d = (rc[r][j] >> PB_MID_ROW_BITS) - k0;
           float f = d == 0 ? w[r].x : (d == 1 ? w[r].y : (d == 2 ? w[r].z : w[r].w));
           if (d > 3u) f = T[rc[r][j] >> PB_MID_ROW_BITS];  // also a source in FRONT of k0 (never in a sorted stream)
-          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(f, bad));
+          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(FA4 ? __fmul_rn(f, a[r][j]) : f, bad));
         }
       }
     }

@@ -315,44 +315,12 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       }
     }
     if (st == GDN_OK && (p->has_hub || p->n_mid_tiers)) {
-      // launch order of phase B: largest first by ALL the bytes of a bin (main stream 6 B/edge, records 4 B, 16 B per row
-      // of its original range), not by its main stream alone
-      const unsigned nb = p->pb.nbins;
-      std::vector<eoff_t> bp((size_t)nb + 1), tp((size_t)nb + 1);
-      std::vector<uint32_t> blo((size_t)nb + 1, 0u);
-      std::vector<double> work(nb, 0.0);
-      auto get = [&](const DevBuf<eoff_t> &d, std::vector<eoff_t> &h) {
-        return hipMemcpy(h.data(), d.p, h.size() * sizeof(eoff_t), hipMemcpyDeviceToHost) == hipSuccess;
-      };
-      bool ok = get(p->pb.bin_ptr, bp);
-      for (unsigned b = 0; ok && b < nb; b++) work[b] = 6.0 * (double)(bp[b + 1] - bp[b]);
-      if (ok && p->pb.compact) {
-        ok = hipMemcpy(blo.data(), p->pb.bin_lo.p, blo.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
-        for (unsigned b = 0; ok && b < nb; b++) work[b] += 16.0 * (double)(blo[b + 1] - blo[b]);
-      }
-      if (ok && p->has_hub) {
-        ok = get(p->hub.bin_ptr, tp);
-        for (unsigned b = 0; ok && b < nb; b++) work[b] += 4.0 * (double)(tp[b + 1] - tp[b]);
-      }
-      for (int t = 0; ok && t < p->n_mid_tiers; t++) {
-        ok = get(p->mid[t].layout.bin_ptr, tp);
-        for (unsigned b = 0; ok && b < nb; b++) work[b] += 4.0 * (double)(tp[b + 1] - tp[b]);
-      }
-      std::vector<uint32_t> bo(nb);
-      for (unsigned b = 0; b < nb; b++) bo[b] = b;
-      std::stable_sort(bo.begin(), bo.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
-      if (!ok || hipMemcpy(p->pb.bin_order.p, bo.data(), (size_t)nb * 4, hipMemcpyHostToDevice) != hipSuccess) {
-        gdn_set_error("gdn_pr_plan_create: bin order update failed");
-        st = GDN_ERR_HIP;
-      }
-      if (getenv("GDN_PB_TRACE") && ok && nb) {
-        double mx = 0, sum = 0;
-        for (unsigned b = 0; b < nb; b++) {
-          sum += work[b];
-          if (work[b] > mx) mx = work[b];
-        }
-        fprintf(stderr, "[gdn_pr_plan] bins %u: %.1f MB each on average, largest %.1f MB\n", nb, sum / nb / 1e6, mx / 1e6);
-      }
+      // launch order of phase B by all the bytes of a bin: main stream 6 B/edge, records 4 B, 16 B per row
+      const eoff_t *tp[PB_MAX_REC_TIERS];
+      int nt = 0;
+      if (p->has_hub) tp[nt++] = p->hub.bin_ptr.p;
+      for (int t = 0; t < p->n_mid_tiers; t++) tp[nt++] = p->mid[t].layout.bin_ptr.p;
+      st = pb_order_bins_by_work(p->pb, nt, tp, 6.0, 4.0, 16.0);
     }
     if (st == GDN_OK && p->pb.compact) {  // row -> bin lookups of partial launches (gdn_pr_pull_rows_dev)
       p->pb.h_bin_lo.resize((size_t)p->pb.nbins + 1);
@@ -450,7 +418,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
       split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
       if (split < 1 || split > 64) split = 1;
     }
-    PbTierRefresh tr;
+    PbTierRefresh tr = PbTierRefresh();
     if (plan->has_hub) {
       tr.ids[tr.ntiers] = plan->hub_ids.p;
       tr.val[tr.ntiers] = plan->hub_val.p;
@@ -479,12 +447,13 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                          pb.nchunks, plan->n_hr, plan->hr_total.p);
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   }
-  PbMidArgs mid;
+  PbMidArgs mid = PbMidArgs();
   if (plan->has_hub) {
     mid.ptr[mid.n] = plan->hub.bin_ptr.p;
     mid.rec[mid.n] = plan->hub_rec.p;
     mid.val[mid.n] = plan->hub_val.p;
     mid.zrec[mid.n] = plan->n_hubs << PB_MID_ROW_BITS;
+    mid.A[mid.n] = nullptr;
     mid.form[mid.n++] = 1;
   }
   for (int t = 0; t < plan->n_mid_tiers; t++) {
@@ -492,6 +461,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     mid.rec[mid.n] = plan->mid[t].rec.p;
     mid.val[mid.n] = plan->mid[t].val.p;
     mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
+    mid.A[mid.n] = nullptr;
     mid.form[mid.n++] = 0;
   }
 #ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)

@@ -26,7 +26,16 @@ struct gdn_spmv_plan {
   unsigned n_hubs = 0;
   DevBuf<uint32_t> hub_ids;
   DevBuf<float> hub_val;  // x of the hub columns, refreshed per multiply
-  DevBuf<float> hub_Ax;   // Ax of the hub edges in hub-layout order (pads 0)
+  DevBuf<float> hub_Ax;   // Ax of the hub edges in record order (pads 0)
+  DevBuf<uint32_t> hub_rec;  // the hub layout as bin-major (hub index << 14 | row) records
+  // mid tiers (gdn_pb.hpp): the next degree levels below the hubs, read by phase B as (record, Ax) pairs = 8 B/edge
+  int n_mid_tiers = 0;
+  struct MidTier {
+    PbPlan layout;  // only bin_ptr is kept
+    unsigned n = 0;
+    DevBuf<uint32_t> ids, rec;
+    DevBuf<float> val, Ax;
+  } mid[PB_MAX_MID];
   DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] max row length
   DevBuf<float> scale;  // PB: [0] = 2^shift, [1] = 2^-shift (per call)
 };
@@ -161,21 +170,51 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     DevBuf<uint8_t> cls;
     st = GDN_OK;
-    if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0')) st = pb_pick_hubs(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs);
+    const char *me = getenv("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    int max_mid = me ? atoi(me) : PB_MAX_MID;
+    if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
+    DevBuf<uint32_t> mid_ids[PB_MAX_MID];
+    unsigned n_mid[PB_MAX_MID] = {0, 0};
+    if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
+      st = pb_pick_tiers(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
     if (st == GDN_OK)
       st = pb_build(csr, n_cols, lc, lb, p->pb, true, d_Ax, &p->Axp, compact, false, /*pad=*/32, /*log_group=*/5,
-                    p->n_hubs ? cls.p : nullptr, 0, false, v_delta);
+                    (p->n_hubs || n_mid[0]) ? cls.p : nullptr, 0, false, v_delta);
     if (st == GDN_OK && p->n_hubs) {
       st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
         gdn_set_error("gdn_spmv_plan_create: hub layout does not line up with the main layout");
         st = GDN_ERR_INVALID;
       }
-      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS);
-      if (st == GDN_OK) {
-        p->hub.G.release();
-        p->has_hub = true;
+      if (st == GDN_OK) st = p->hub_val.alloc(PB_HUB_SLOTS + 3);  // + the window behind the last slot
+      if (st == GDN_OK) st = pb_mid_finish(p->hub, p->n_hubs, p->hub_rec, &p->hub_Ax);
+      if (st == GDN_OK) p->has_hub = true;
+    }
+    for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
+      gdn_spmv_plan::MidTier &mt = p->mid[t];
+      st = pb_build(csr, n_cols, 15, lb, mt.layout, false, d_Ax, &mt.Ax, true, false, 16, 4, cls.p, 2 + t, true);
+      if (st == GDN_OK && mt.layout.nbins != p->pb.nbins) {
+        gdn_set_error("gdn_spmv_plan_create: mid layout %d does not line up with the main layout", t);
+        st = GDN_ERR_INVALID;
       }
+      if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec, &mt.Ax);
+      if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
+      if (st == GDN_OK) {
+        mt.n = n_mid[t];
+        mt.ids.p = mid_ids[t].p;  // take the buffer over
+        mt.ids.n = mid_ids[t].n;
+        mid_ids[t].p = nullptr;
+        mid_ids[t].n = 0;
+        p->n_mid_tiers = t + 1;
+      }
+    }
+    if (st == GDN_OK && (p->has_hub || p->n_mid_tiers)) {
+      // launch order of phase B by all the bytes of a bin: main stream 6 B/edge, records 8 B, 8 B per row
+      const eoff_t *tp[PB_MAX_REC_TIERS];
+      int nt = 0;
+      if (p->has_hub) tp[nt++] = p->hub.bin_ptr.p;
+      for (int t = 0; t < p->n_mid_tiers; t++) tp[nt++] = p->mid[t].layout.bin_ptr.p;
+      st = pb_order_bins_by_work(p->pb, nt, tp, 6.0, 8.0, 8.0);
     }
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
@@ -239,16 +278,33 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
                      pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr,
                      pb.chunk_slots);
-  if (plan->has_hub)
-    hipLaunchKernelGGL(pb_hub_gather_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS)), dim3(GDN_BLOCK), 0, s, d_x, plan->hub_ids.p,
-                       plan->n_hubs, plan->hub_val.p);
+  PbMidArgs mid = PbMidArgs();
+  if (plan->has_hub) {
+    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS + 3)), dim3(GDN_BLOCK), 0, s, d_x,
+                       plan->hub_ids.p, plan->n_hubs, (unsigned)PB_HUB_SLOTS + 3u, plan->hub_val.p);
+    mid.ptr[mid.n] = plan->hub.bin_ptr.p;
+    mid.rec[mid.n] = plan->hub_rec.p;
+    mid.val[mid.n] = plan->hub_val.p;
+    mid.A[mid.n] = plan->hub_Ax.p;
+    mid.zrec[mid.n] = plan->n_hubs << PB_MID_ROW_BITS;
+    mid.form[mid.n++] = 1;
+  }
+  for (int t = 0; t < plan->n_mid_tiers; t++) {
+    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(gdn_nblocks((uint64_t)plan->mid[t].n + 4)), dim3(GDN_BLOCK), 0, s,
+                       d_x, plan->mid[t].ids.p, plan->mid[t].n, plan->mid[t].n + 4u, plan->mid[t].val.p);
+    mid.ptr[mid.n] = plan->mid[t].layout.bin_ptr.p;
+    mid.rec[mid.n] = plan->mid[t].rec.p;
+    mid.val[mid.n] = plan->mid[t].val.p;
+    mid.A[mid.n] = plan->mid[t].Ax.p;
+    mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
+    mid.form[mid.n++] = 0;
+  }
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
                      pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op, 0, 0u,
-                     plan->has_hub ? plan->hub.bin_ptr.p : nullptr, plan->has_hub ? plan->hub.U.p : nullptr,
-                     plan->has_hub ? plan->hub.V.p : nullptr, plan->has_hub ? plan->hub_val.p : nullptr,
-                     pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, plan->has_hub ? plan->hub_Ax.p : nullptr);
+                     nullptr, nullptr, nullptr, nullptr, pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, nullptr,
+                     nullptr, nullptr, nullptr, mid);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;
