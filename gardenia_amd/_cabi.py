@@ -83,6 +83,7 @@ PROTOTYPES = {
     "gdn_spmv_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),
     "gdn_spmv_plan_create_cols": (C.c_int, [_vp, _vp, _i32, _i32, _pp]),
     "gdn_spmv_plan_check": (C.c_int, [_vp]),
+    "gdn_spmv_plan_tiers": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_spmv_plan_free": (C.c_int, [_vp]),
     "gdn_spmv_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "gdn_spmv_plan_kernel_time": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),

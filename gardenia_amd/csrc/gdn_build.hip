@@ -705,8 +705,10 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
   uint64_t mid16 = PB_MID_MIN_PER_BIN16;
   if (const char *e = getenv("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
   unsigned top = bk0 < PB_HUB_BUCKETS ? bk0 : PB_HUB_BUCKETS;
+  uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
+  if (const char *e = getenv("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
   for (int t = 0; t < max_mid; t++) {
-    const unsigned bk = pick((nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4), top, PB_MID_MAX);
+    const unsigned bk = pick((nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4), top, mid_cap);
     if (bk >= top) break;
     ta.thr[1 + t] = pb_hub_bucket_floor(bk);
     ta.cap[1 + t] = PB_MID_MAX;

@@ -347,6 +347,16 @@ int gdn_spmv_plan_kernel_time(gdn_spmv_plan *plan, int32_t reset, int32_t max_la
   return GDN_OK;
 }
 
+int gdn_spmv_plan_tiers(const gdn_spmv_plan *plan, int32_t *n_hubs, int32_t *n_mid_tiers, uint64_t *tier_edges) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  uint64_t ne = plan->has_hub ? plan->hub.nnz : 0;
+  for (int t = 0; t < plan->n_mid_tiers; t++) ne += plan->mid[t].layout.nnz;
+  if (n_hubs) *n_hubs = plan->has_hub ? (int32_t)plan->n_hubs : 0;
+  if (n_mid_tiers) *n_mid_tiers = plan->n_mid_tiers;
+  if (tier_edges) *tier_edges = ne;
+  return GDN_OK;
+}
+
 // PB layout: GDN_ERR_OVERFLOW if a product left the fixed-point range (non-finite inputs)
 int gdn_spmv_plan_check(gdn_spmv_plan *plan) {
   GDN_REQUIRE(plan != nullptr, "plan");

@@ -217,6 +217,9 @@ int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax /*nullable for 
 int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax /*nullable for CSR*/, int32_t n_cols,
                               int32_t layout, gdn_spmv_plan **plan);
 int gdn_spmv_plan_check(gdn_spmv_plan *plan);
+/* record tiers of the PB layout (hub and mid-tier columns whose nonzeros phase B reads directly as (record, Ax) pairs):
+ * hub columns, number of mid tiers, nonzeros in all tiers (0 / 0 / 0 when the plan has none) */
+int gdn_spmv_plan_tiers(const gdn_spmv_plan *plan, int32_t *n_hubs, int32_t *n_mid_tiers, uint64_t *tier_edges);
 int gdn_spmv_plan_free(gdn_spmv_plan *plan);
 /* y[v] += SUM Ax[k]*x[Aj[k]]   (src/spmv/base.cu:13, warp.cu:26, vector.cu:27 superseded) */
 int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream);

@@ -254,6 +254,64 @@ def test_pr_hub_tier_on_row_shards(orc, monkeypatch, world, parts):
     assert abs(err - trace[-1]) < 1e-6
 
 
+TIER_ENV = {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "64", "GDN_PB_MID_CAP": "1500"}
+
+
+@pytest.mark.parametrize("world,parts", [(1, 1), (2, 3)])
+def test_pr_mid_tiers_are_bitwise_neutral(orc, monkeypatch, world, parts):
+    """Record tiers of the PB layout (hubs + two mid tiers: their edges skip phase A and are read by phase B as 32-bit
+    (source, row) records, values from per-iteration tables of fixed-point codes), forced on at a size the oracle
+    solves (GDN_PB_MID_CAP bounds a tier's sources so that two tiers form): bit-identical to the plan without mid
+    tiers and to the plan without any tier, on whole graphs and on row shards issued in parts."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    g = graphio.rmat_graph(17, 16, seed=41)
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    for k, v in TIER_ENV.items():
+        monkeypatch.setenv(k, v)
+    res = []
+    for hubs, mid in (("0", "0"), ("1", "0"), ("1", "2")):
+        monkeypatch.setenv("GDN_PB_HUBS", hubs)
+        monkeypatch.setenv("GDN_PB_MID", mid)
+        sh = solvers.ResidentPageRankShards(G, world, 1, parts=parts)
+        nh, nt, ns, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+        _cabi.check(_cabi.lib().gdn_pr_plan_hubs(sh.ranks[0]["plan"], C.byref(nh), None))
+        _cabi.check(_cabi.lib().gdn_pr_plan_mid(sh.ranks[0]["plan"], C.byref(nt), C.byref(ns), C.byref(ne)))
+        if hubs == "0":
+            assert nh.value == 0 and nt.value == 0
+        elif mid == "0":
+            assert nh.value > 0 and nt.value == 0 and ne.value == 0
+        else:
+            assert nh.value > 0 and nt.value == 2 and ns.value > 1500 and ne.value > 0, (nh.value, nt.value, ns.value)
+        scores, it2, err = sh.solve()
+        sh.close()
+        res.append((scores, it2, err))
+    assert res[0][1] == res[1][1] == res[2][1] == it
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], res[2][0])
+    assert res[0][2] == res[1][2] == res[2][2]
+    np.testing.assert_allclose(res[2][0], want, rtol=REL_TOL, atol=0)
+    assert abs(res[2][2] - trace[-1]) < 1e-6
+
+
+def test_pr_pb_rejects_out_of_range_scores(monkeypatch):
+    """The fixed-point codes are made once per source (phase A's slice, the tier tables): a contribution outside [0,1]
+    must still raise GDN_ERR_OVERFLOW, whichever tier its source sits in."""
+    for k, v in TIER_ENV.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    g = graphio.rmat_graph(15, 16, seed=5)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    deg = g.degrees()
+    for victim in (int(np.argmax(deg)), int(np.flatnonzero(deg == 1)[0])):  # a hub source, a main-layout source
+        scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        scores[victim] = np.float32(3.0) * max(int(deg[victim]), 1)  # contribution 3.0
+        with pytest.raises(Exception) as ei:
+            solvers.PRSolver(G, scores)
+        assert "fixed-point" in str(ei.value) or "OVERFLOW" in str(ei.value).upper(), str(ei.value)
+
+
 @pytest.mark.parametrize("layout_env", [{"GDN_PB_V8": "1"}, {"GDN_PB_V8": "1", "GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1"}])
 def test_pr_delta_coded_rows_are_bitwise_neutral(orc, monkeypatch, layout_env):
     """Optional 8-bit delta coding of the row stream (PbPlan::v8, off by default because its decode costs more than
@@ -284,7 +342,7 @@ def test_pr_delta_coded_rows_are_bitwise_neutral(orc, monkeypatch, layout_env):
 
 @pytest.mark.parametrize("env", [{}, {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1"},
                                  {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1", "GDN_PB_V8": "1"},
-                                 {"GDN_PB_COMPACT": "0"}])
+                                 {"GDN_PB_COMPACT": "0"}, TIER_ENV])
 def test_spmv_pb_layout_variants(orc, monkeypatch, env):
     """SpMV on the propagation-blocked layout: compacted (default), with the hub tier forced on at this size (hub edges
     multiply x[hub] by their own Ax inside phase B), with delta-coded rows, and uncompacted -- all against the oracle,
@@ -304,6 +362,12 @@ def test_spmv_pb_layout_variants(orc, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sp = solvers.ResidentSpMV(G, Ax, layout=1)
+    if env is TIER_ENV:  # hubs + two mid tiers really are in use
+        import ctypes as C
+        from gardenia_amd import _cabi
+        nh, nt, ne = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+        _cabi.check(_cabi.lib().gdn_spmv_plan_tiers(sp.plan, C.byref(nh), C.byref(nt), C.byref(ne)))
+        assert nh.value > 0 and nt.value == 2 and 0 < ne.value < g.nnz, (nh.value, nt.value, ne.value)
     got = sp.multiply(x, y0)
     got2 = sp.multiply(x, got)  # a second multiply on the same plan: y accumulates
     sp.close()
