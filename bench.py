@@ -45,6 +45,9 @@ def main():
     ap.add_argument("--share-device", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the collectives go through gloo, so the N>1 code path "
                          "can be exercised on a 1-GPU box (numbers are meaningless)")
+    ap.add_argument("--exchange", choices=["auto", "dense", "compact"], default="auto",
+                    help="N > 1: contributions exchanged per iteration -- every row (dense) or only the rows with "
+                         "out-edges (compact = auto)")
     ap.add_argument("--no-bfs", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
@@ -118,7 +121,7 @@ def main():
                            "(source, row) records sorted by source, values from per-iteration tables of fixed-point codes" \
                            % (nh.value, 100.0 * he.value / max(snnz.value, 1), ms_.value,
                               100.0 * me.value / max(snnz.value, 1))
-    pr = ShardedPageRank(be, m, rank, world, dist if world > 1 else None)
+    pr = ShardedPageRank(be, m, rank, world, dist if world > 1 else None, exchange=args.exchange)
     pr.init_contrib()
 
     def barrier():
@@ -173,8 +176,9 @@ def main():
                                "A=.57 B=.19 C=.19, seed 27491095, self loops+duplicates dropped)"
                                % (args.scale, args.edge_factor),
                    "vertices": m, "edges": nnz, "layout": layout_name, "plan_build_s": t_plan,
-                   "partition": "vertex-range x%d, RCCL all-gather of contrib pipelined in %d row-range parts behind "
-                                "the pull kernels" % (world, pr.parts) if world > 1 else "single GPU"},
+                   "partition": "vertex-range x%d, RCCL all-gather of contrib (%s exchange, %.0f MB received per rank "
+                                "and iteration) pipelined in %d row-range parts behind the pull kernels"
+                                % (world, pr.exchange, pr.exchanged_bytes() / 1e6, pr.parts) if world > 1 else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": "mp_tile_kernel<PrOp>" if be.layout == 0 else

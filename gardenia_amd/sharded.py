@@ -10,6 +10,13 @@ Per iteration each rank
   2. all-gathers the next contrib vector in place               (RCCL all-gather, m*4 B in all)
   3. all-reduces the 8-byte L1 change                           (convergence test)
 
+Compact exchange (`exchange="compact"`, the default): only the contributions of vertices WITH out-edges are ever read by
+anybody (39 % of RMAT-27's vertices), so a rank sends just those -- gathered into a dense send buffer, all-gathered,
+scattered to their places in the full vector (index lists exchanged once at setup) -- 2.6x fewer bytes over xGMI.  xGMI is
+point to point: a pair of GPUs shares ONE link (~77 GB/s per direction), so the dense exchange (N = 2: 256 MB over one link,
+N = 8: 64 MB to each of 7 peers) takes longer than a rank's share of the compute at every N; the scatter costs 0.33 ms for
+all of RMAT-27's 52 M active entries (measured, tools/scatter_probe.py), less the rank's own share.
+
 Steps 1 and 2 are pipelined: the rank's rows are cut into `parts` row ranges; as soon as the kernel of part j has
 been queued (gdn_pr_pull_rows_dev) its rows are all-gathered asynchronously (RCCL runs on its own stream, ordered
 behind the compute stream at the call), so only the last part's exchange is exposed.  xGMI is point to point: the
@@ -39,7 +46,7 @@ def vertex_range(rank: int, world: int, m: int) -> Tuple[int, int, int]:
 
 class ShardedPageRank:
     def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None,
-                 damping: float = 0.85, parts: int = 4):
+                 damping: float = 0.85, parts: int = 4, exchange: str = "auto"):
         self.be = backend
         self.parts = max(1, int(parts)) if world > 1 and hasattr(backend, "pull_rows") else 1
         self.m = m_global
@@ -49,6 +56,49 @@ class ShardedPageRank:
         self._inplace = True
         self.cur = 0  # index of the contrib buffer holding the current iteration's input
         self.iterations = 0
+        self.n_full = self.chunk * world
+        # exchange: "dense" = every row's contribution, "compact" = only rows with out-edges (see the module docstring)
+        self.exchange = "dense"
+        self._cx = None
+        if world > 1 and hasattr(backend, "active_sources") and exchange in ("compact", "auto"):
+            try:
+                self._setup_compact()
+                self.exchange = "compact"
+            except (RuntimeError, ValueError, NotImplementedError) as e:
+                import sys
+                print(f"[sharded] compact exchange unavailable ({e}); using the dense all-gather", file=sys.stderr, flush=True)
+                self._cx = None
+
+    def _setup_compact(self):
+        """Index lists of the compact exchange, one set per pipeline part: `my` = positions (in the full vector) of this
+        rank's rows with out-edges inside the part, padded to the largest count over the ranks with the dummy slot
+        n_full; `all` = the same lists of every rank, in all-gather order."""
+        import torch
+        full = self.be.contrib_full(0)
+        if full.numel() < self.n_full + 1:
+            raise ValueError("the contrib buffers have no dummy slot behind chunk * world entries")
+        act = self.be.active_sources()
+        ml = self.hi - self.lo
+        cx = []
+        for (r0, r1) in (self.part_ranges() if self.parts > 1 else [(0, self.chunk)]):
+            a0, a1 = min(r0, ml), min(r1, ml)
+            idx = torch.nonzero(act[a0:a1]).flatten().to(torch.int64) + a0
+            n = int(idx.numel())
+            cap_t = torch.tensor([n], dtype=torch.int64, device=full.device)
+            self.dist.all_reduce(cap_t, op=self.dist.ReduceOp.MAX)
+            cap = max(int(cap_t.item()), 1)
+            my = torch.full((cap,), self.n_full, dtype=torch.int64, device=full.device)
+            my[:n] = idx + self.rank * self.chunk
+            allg = torch.empty(self.world * cap, dtype=torch.int64, device=full.device)
+            self.dist.all_gather_into_tensor(allg, my)
+            cx.append({"my": my, "all": allg, "recv": torch.empty(self.world * cap, dtype=full.dtype, device=full.device)})
+        self._cx = cx
+
+    def exchanged_bytes(self) -> int:
+        """Bytes one rank receives per iteration (incl. its own slice)."""
+        if self._cx is None:
+            return 4 * self.n_full
+        return sum(4 * int(c["recv"].numel()) for c in self._cx)
 
     def init_contrib(self):
         """contrib = score/out_degree for the local rows, then gather (src/pr/base.cu:14)."""
@@ -57,7 +107,7 @@ class ShardedPageRank:
 
     def _gather(self, which):
         if self.world > 1:
-            full = self.be.contrib_full(which)
+            full = self.be.contrib_full(which)[:self.n_full]
             mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
             if self._inplace:
                 try:  # in-place all-gather: each rank's slice already sits at its place in `full`
@@ -86,10 +136,33 @@ class ShardedPageRank:
         outs = [full[r * self.chunk + r0:r * self.chunk + r1] for r in range(self.world)]
         return self.dist.all_gather(outs, outs[self.rank], async_op=True)
 
+    def _step_compact(self, nxt):
+        full = self.be.contrib_full(nxt)
+        ranges = self.part_ranges() if self.parts > 1 else [(0, self.chunk)]
+        works = []
+        for j, (r0, r1) in enumerate(ranges):
+            if self.parts > 1:
+                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
+            else:
+                self.be.pull(self.cur, nxt, self.damping)
+            cx = self._cx[j]
+            send = full.index_select(0, cx["my"])  # pad entries read the dummy slot
+            works.append((self.dist.all_gather_into_tensor(cx["recv"], send, async_op=True), send, cx))
+        for w, _send, cx in works:
+            w.wait()
+            cap = cx["my"].numel()
+            a, b = self.rank * cap, (self.rank + 1) * cap  # this rank's own entries are already in place
+            if a > 0:
+                full.index_copy_(0, cx["all"][:a], cx["recv"][:a])  # pad entries land in the dummy slot
+            if b < cx["all"].numel():
+                full.index_copy_(0, cx["all"][b:], cx["recv"][b:])
+
     def step(self):
         """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
         nxt = self.cur ^ 1
-        if self.parts <= 1:
+        if self._cx is not None:
+            self._step_compact(nxt)
+        elif self.parts <= 1:
             self.be.pull(self.cur, nxt, self.damping)
             self._gather(nxt)
         else:
@@ -145,7 +218,8 @@ class HipPageRankBackend:
         self.m_local = hi - lo
         self.out_degree = out_degree_local  # int32 device tensor, m_local
         n_full = chunk * world
-        self.contribs = [torch.zeros(n_full, dtype=torch.float32, device=device) for _ in range(2)]
+        # + 4 entries behind the vector: [n_full] is the dummy slot of the compact exchange (16-byte alignment kept)
+        self.contribs = [torch.zeros(n_full + 4, dtype=torch.float32, device=device) for _ in range(2)]
         self.scores = torch.full((max(self.m_local, 1),), 1.0 / m_global, dtype=torch.float32, device=device)
         self.diff = torch.zeros(1, dtype=torch.float64, device=device)
         self.plan = C.c_void_p()
@@ -160,6 +234,10 @@ class HipPageRankBackend:
 
     def contrib_full(self, which):
         return self.contribs[which]
+
+    def active_sources(self):
+        """Rows of this rank whose contribution anybody reads: the vertices with out-edges."""
+        return self.out_degree > 0
 
     def diff_tensor(self):
         return self.diff

@@ -22,12 +22,15 @@ class NumpyBackend:
         self.rowptr = g_in.rowptr[lo:hi + 1].astype(np.int64)
         self.colidx = g_in.colidx
         self.deg = out_degree[lo:hi].astype(np.float32)
-        self.contribs = [torch.zeros(chunk * world, dtype=torch.float32) for _ in range(2)]
+        self.contribs = [torch.zeros(chunk * world + 4, dtype=torch.float32) for _ in range(2)]  # + the dummy slot
         self.scores = np.full(hi - lo, np.float32(1.0) / np.float32(m), np.float32)
         self.diff = torch.zeros(1, dtype=torch.float64)
 
     def contrib_full(self, which):
         return self.contribs[which]
+
+    def active_sources(self):
+        return torch.from_numpy(self.deg > 0)
 
     def diff_tensor(self):
         return self.diff
@@ -73,7 +76,10 @@ def main():
     lo, hi, chunk = vertex_range(rank, world, m)
     be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world)
     parts = int(os.environ.get("GDN_TEST_PARTS", "4"))
-    pr = ShardedPageRank(be, m, rank, world, dist, parts=parts)
+    pr = ShardedPageRank(be, m, rank, world, dist, parts=parts, exchange=os.environ.get("GDN_TEST_EXCHANGE", "auto"))
+    assert pr.exchange == os.environ.get("GDN_TEST_EXCHANGE", "dense"), pr.exchange
+    if pr.exchange == "compact":
+        assert pr.exchanged_bytes() < 4 * chunk * world
     it, err = pr.solve()
     np.save(f"{out}.{rank}.npy", be.scores)
     if rank == 0:

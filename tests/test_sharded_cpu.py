@@ -48,15 +48,16 @@ def test_part_ranges_cover_the_chunk_and_agree_across_ranks():
     assert ShardedPageRank(B(), 100, 0, 1, dist=None, parts=4).parts == 1  # a single rank is never cut
 
 
-@pytest.mark.parametrize("world,parts", [(2, 4), (3, 4), (2, 1), (3, 7)])
-def test_sharded_pagerank_gloo(orc, tmp_path, world, parts):
+@pytest.mark.parametrize("world,parts,exchange", [(2, 4, "dense"), (3, 4, "dense"), (2, 1, "dense"), (3, 7, "dense"),
+                                                  (2, 4, "compact"), (3, 3, "compact"), (2, 1, "compact")])
+def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange):
     scale, ef = 8, 8
     out = str(tmp_path / "pr")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts))
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts), GDN_TEST_EXCHANGE=exchange)
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"),
                                        str(scale), str(ef), out], env=env))
     for p in procs:
