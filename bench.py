@@ -110,6 +110,9 @@ def main():
                    1: "propagation-blocked tiles (source chunk of %d ids x destination bin of %d rows, u16 local "
                       "ids, LDS-resident slices, 2^-62 fixed-point LDS accumulation)"
                       % (1 << (be.log_blk // 100), 1 << (be.log_blk % 100))}[be.layout]
+    if be.layout == 1 and be.squished:
+        layout_name += "; vertex space of the %d live vertices (%.1f %% of |V|: the others have no edge, keep the base " \
+                       "score and are written once at export)" % (be.m_state, 100.0 * be.m_state / m)
     if be.layout == 1:
         nh, he = C.c_int32(0), C.c_uint64(0)
         _cabi.check(L.gdn_pr_plan_hubs(be.plan, C.byref(nh), C.byref(he)))

@@ -18,7 +18,7 @@ GDN_ERR_NO_DEVICE = -2
 GDN_ERR_HIP = -3
 GDN_ERR_OOM = -4
 GDN_ERR_OVERFLOW = -5
-GDN_LAYOUT_AUTO, GDN_LAYOUT_CSR, GDN_LAYOUT_PB = -1, 0, 1
+GDN_LAYOUT_AUTO, GDN_LAYOUT_CSR, GDN_LAYOUT_PB, GDN_LAYOUT_PB_SQUISHED = -1, 0, 1, 2
 GDN_PR_PART_FIRST, GDN_PR_PART_LAST = 1, 2
 
 
@@ -73,6 +73,10 @@ PROTOTYPES = {
     "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_pr_plan_mid": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
+    "gdn_pr_plan_state_size": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "gdn_pr_import_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
+    "gdn_pr_import_diff": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "gdn_pr_export_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
     "gdn_pr_plan_check": (C.c_int, [_vp]),
     "gdn_pr_plan_free": (C.c_int, [_vp]),
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),

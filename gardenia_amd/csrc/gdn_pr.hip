@@ -53,6 +53,19 @@ struct gdn_pr_plan {
   const int32_t *out_degree = nullptr;  // device, m_local
   int32_t m_global = 0;
   int32_t row_base = 0;
+  int32_t m_base = 0;  // vertex count of the base score (1 - d) / m: the ORIGINAL m of a squished plan
+  // GDN_LAYOUT_PB_SQUISHED: the plan works in a vertex space WITHOUT the vertices that have neither in- nor out-edges
+  // (state index k <-> original id sq_ids[k], ascending).  Such a vertex keeps the constant base score and nobody reads
+  // its contribution, so the per-vertex arrays of an iteration (scores, contrib, degrees) shrink to the m_state live
+  // vertices; gdn_pr_import_dev / gdn_pr_export_dev convert at the boundary of a solve.
+  bool squished = false;
+  int32_t m_orig = 0;
+  DevBuf<uint32_t> sq_ids;    // m_state
+  DevBuf<uint32_t> sq_bits;   // ceil(m_orig / 32): live vertices
+  DevBuf<int32_t> sq_deg;     // out-degrees in state order
+  DevBuf<eoff_t> sq_rowptr;   // the relabelled in-CSR (kept while the plan lives only for the CSR of state rows)
+  DevBuf<vid_t> sq_colidx;
+  DevBuf<double> sq_diff;     // 1 double: L1 change of the dead vertices at the last import
 };
 
 struct PrOp {
@@ -148,6 +161,70 @@ pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ 
   if (v < m) contrib[v] = __fdiv_rn(scores[v], (float)out_degree[v]);
 }
 
+// ---- squished vertex space
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_live_flags_kernel(const eoff_t *__restrict__ rowptr, const int32_t *__restrict__ deg, int32_t m, uint32_t *__restrict__ flag) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (size_t)m) flag[v] = (rowptr[v + 1] > rowptr[v] || deg[v] > 0) ? 1u : 0u;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_squish_vertices_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cmap, const eoff_t *__restrict__ rowptr,
+                          const int32_t *__restrict__ deg, int32_t m, uint64_t nnz, uint32_t m_state, uint32_t *__restrict__ ids,
+                          int32_t *__restrict__ deg_c, eoff_t *__restrict__ rowptr_c, uint32_t *__restrict__ bits) {
+  const size_t w = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;  // one 32-id word per thread
+  if (w * 32 >= (size_t)m) return;
+  unsigned word = 0;
+  for (unsigned i = 0; i < 32; i++) {
+    const size_t v = w * 32 + i;
+    if (v < (size_t)m && flag[v]) {
+      word |= 1u << i;
+      const eoff_t k = cmap[v];
+      ids[k] = (uint32_t)v;
+      deg_c[k] = deg[v];
+      rowptr_c[k] = rowptr[v];
+    }
+  }
+  bits[w] = word;
+  if (w == 0) rowptr_c[m_state] = nnz;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_squish_cols_kernel(const vid_t *__restrict__ colidx, const eoff_t *__restrict__ cmap, uint64_t nnz, vid_t *__restrict__ out) {
+  size_t e = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
+  for (; e < nnz; e += stride) out[e] = (vid_t)cmap[colidx[e]];
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_gather_state_kernel(const float *__restrict__ src, const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ dst) {
+  const size_t k = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < n) dst[k] = src[ids[k]];
+}
+
+// export: the dead vertices get the base score, the live ones their state value
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_export_dead_kernel(const uint32_t *__restrict__ bits, int32_t m, float base, float *__restrict__ scores) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (size_t)m && !((bits[v >> 5] >> (v & 31u)) & 1u)) scores[v] = base;
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_export_live_kernel(const float *__restrict__ state, const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ scores) {
+  const size_t k = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < n) scores[ids[k]] = state[k];
+}
+
+// SUM over the dead vertices of |base - scores[v]| (their L1 change in the iteration that follows an import)
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_dead_diff_kernel(const float *__restrict__ scores, const uint32_t *__restrict__ bits, int32_t m, float base,
+                    double *__restrict__ out) {
+  double acc = 0.0;
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK)
+    if (!((bits[v >> 5] >> (v & 31u)) & 1u)) acc += (double)fabsf(__fsub_rn(base, scores[v]));
+  acc = gdn_wave_sum(acc);
+  if (gdn_lane() == 0 && acc != 0.0) atomicAdd(out, acc);
+}
+
 extern "C" {
 
 // slice sizes: as large as LDS allows on big graphs, but keep >= ~1024 workgroups per phase
@@ -163,7 +240,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   *plan = nullptr;
   GDN_REQUIRE(in_csr != nullptr && d_out_degree != nullptr, "in_csr / d_out_degree");
   GDN_REQUIRE(m_global >= in_csr->m && row_base >= 0 && row_base + in_csr->m <= m_global, "row range");
-  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_AUTO, "layout");
+  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_PB_SQUISHED ||
+              layout == GDN_LAYOUT_AUTO, "layout");
+  GDN_REQUIRE(layout != GDN_LAYOUT_PB_SQUISHED || (row_base == 0 && in_csr->m == m_global),
+              "GDN_LAYOUT_PB_SQUISHED: whole graphs only (row_base 0, m_local == m_global)");
   if (layout == GDN_LAYOUT_AUTO) {
     const char *env = getenv("GDN_PR_LAYOUT");
     if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
@@ -174,10 +254,62 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   p->layout = layout;
   p->out_degree = d_out_degree;
   p->m_global = m_global;
+  p->m_base = m_global;
+  p->m_orig = m_global;
   p->row_base = row_base;
   p->m_local = in_csr->m;
   p->nnz = in_csr->nnz;
   int st;
+  gdn_graph sq_graph;  // the relabelled in-CSR of a squished plan (arrays owned by the plan)
+  if (layout == GDN_LAYOUT_PB_SQUISHED) {
+    layout = p->layout = GDN_LAYOUT_PB;
+    const int32_t m = in_csr->m;
+    DevBuf<uint32_t> flag;
+    DevBuf<eoff_t> cmap;
+    st = flag.alloc((size_t)m);
+    if (st == GDN_OK) st = cmap.alloc((size_t)m + 1);
+    if (st == GDN_OK) {
+      hipLaunchKernelGGL(pr_live_flags_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, in_csr->rowptr,
+                         d_out_degree, m, flag.p);
+      st = gdn_exclusive_scan_u32_to_u64(flag.p, cmap.p, (size_t)m, 0);
+    }
+    eoff_t n_live = 0;
+    if (st == GDN_OK && hipMemcpy(&n_live, cmap.p + m, sizeof(eoff_t), hipMemcpyDeviceToHost) != hipSuccess) st = GDN_ERR_HIP;
+    if (st == GDN_OK && n_live > 0 && n_live < (eoff_t)m) {
+      const uint32_t ms = (uint32_t)n_live;
+      if ((st = p->sq_ids.alloc(ms)) == GDN_OK && (st = p->sq_deg.alloc(ms)) == GDN_OK &&
+          (st = p->sq_rowptr.alloc((size_t)ms + 1)) == GDN_OK && (st = p->sq_bits.alloc(((size_t)m + 31) / 32 + 1)) == GDN_OK &&
+          (st = p->sq_colidx.alloc((size_t)in_csr->nnz)) == GDN_OK && (st = p->sq_diff.alloc(1)) == GDN_OK) {
+        (void)hipMemset(p->sq_diff.p, 0, sizeof(double));
+        hipLaunchKernelGGL(pr_squish_vertices_kernel, dim3(gdn_nblocks(((uint64_t)m + 31) / 32)), dim3(GDN_BLOCK), 0, 0, flag.p,
+                           cmap.p, in_csr->rowptr, d_out_degree, m, in_csr->nnz, ms, p->sq_ids.p, p->sq_deg.p, p->sq_rowptr.p,
+                           p->sq_bits.p);
+        if (in_csr->nnz)
+          hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, in_csr->colidx, cmap.p, in_csr->nnz,
+                             p->sq_colidx.p);
+        if (hipDeviceSynchronize() != hipSuccess) {
+          gdn_set_error("gdn_pr_plan_create: squish kernels failed: %s", hipGetErrorString(hipGetLastError()));
+          st = GDN_ERR_HIP;
+        }
+        sq_graph.m = (int32_t)ms;
+        sq_graph.nnz = in_csr->nnz;
+        sq_graph.rowptr = p->sq_rowptr.p;
+        sq_graph.colidx = p->sq_colidx.p;
+        sq_graph.owned = false;
+        in_csr = &sq_graph;
+        d_out_degree = p->sq_deg.p;
+        m_global = (int32_t)ms;
+        p->squished = true;
+        p->out_degree = p->sq_deg.p;
+        p->m_global = m_global;
+        p->m_local = m_global;
+      }
+    }
+    if (st != GDN_OK) {
+      delete p;
+      return st;
+    }
+  }
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
@@ -350,7 +482,55 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     delete p;
     return st;
   }
+  if (p->squished) {  // the PB layouts hold every edge: the relabelled CSR is not read again
+    p->sq_colidx.release();
+    p->sq_rowptr.release();
+  }
   *plan = p;
+  return GDN_OK;
+}
+
+int gdn_pr_plan_state_size(const gdn_pr_plan *plan, int32_t *m_state) {
+  GDN_REQUIRE(plan != nullptr && m_state != nullptr, "null argument");
+  *m_state = plan->m_local;
+  return GDN_OK;
+}
+
+int gdn_pr_import_dev(gdn_pr_plan *plan, const float *d_scores, float *d_state, float damping, void *stream) {
+  GDN_REQUIRE(plan && d_scores && d_state, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (!plan->squished) {
+    if (d_state != d_scores) GDN_HIP(hipMemcpyAsync(d_state, d_scores, (size_t)plan->m_local * 4, hipMemcpyDeviceToDevice, s));
+    return GDN_OK;
+  }
+  const uint32_t n = (uint32_t)plan->m_local;
+  hipLaunchKernelGGL(pr_gather_state_kernel, dim3(gdn_nblocks(n)), dim3(GDN_BLOCK), 0, s, d_scores, plan->sq_ids.p, n, d_state);
+  GDN_HIP(hipMemsetAsync(plan->sq_diff.p, 0, sizeof(double), s));
+  hipLaunchKernelGGL(pr_dead_diff_kernel, dim3(2048), dim3(GDN_BLOCK), 0, s, d_scores, plan->sq_bits.p, plan->m_orig,
+                     (1.0f - damping) / (float)plan->m_base, plan->sq_diff.p);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+int gdn_pr_import_diff(gdn_pr_plan *plan, double *dead_diff) {
+  GDN_REQUIRE(plan && dead_diff, "null argument");
+  *dead_diff = 0.0;
+  if (plan->squished) GDN_HIP(hipMemcpy(dead_diff, plan->sq_diff.p, sizeof(double), hipMemcpyDeviceToHost));
+  return GDN_OK;
+}
+
+int gdn_pr_export_dev(gdn_pr_plan *plan, const float *d_state, float *d_scores, float damping, void *stream) {
+  GDN_REQUIRE(plan && d_scores && d_state, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  if (!plan->squished) {
+    if (d_state != d_scores) GDN_HIP(hipMemcpyAsync(d_scores, d_state, (size_t)plan->m_local * 4, hipMemcpyDeviceToDevice, s));
+    return GDN_OK;
+  }
+  const uint32_t n = (uint32_t)plan->m_local;
+  hipLaunchKernelGGL(pr_export_dead_kernel, dim3(gdn_nblocks((uint64_t)plan->m_orig)), dim3(GDN_BLOCK), 0, s, plan->sq_bits.p,
+                     plan->m_orig, (1.0f - damping) / (float)plan->m_base, d_scores);
+  hipLaunchKernelGGL(pr_export_live_kernel, dim3(gdn_nblocks(n)), dim3(GDN_BLOCK), 0, s, d_state, plan->sq_ids.p, n, d_scores);
+  GDN_HIP(hipGetLastError());
   return GDN_OK;
 }
 
@@ -396,7 +576,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   op.scores = d_scores;
   op.contrib_out = d_contrib_out + plan->row_base;
   op.out_degree = plan->out_degree;
-  op.base_score = (1.0f - damping) / (float)plan->m_global;
+  op.base_score = (1.0f - damping) / (float)plan->m_base;
   op.damping = damping;
   op.vec_ok = ((reinterpret_cast<uintptr_t>(op.scores) | reinterpret_cast<uintptr_t>(op.contrib_out) |
                 reinterpret_cast<uintptr_t>(op.out_degree)) & 15u) == 0;
@@ -594,7 +774,8 @@ int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_source
 
 uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan) {
   if (!plan) return 0;
-  const uint64_t m = (uint64_t)plan->m_local, nnz = plan->nnz;
+  // SURVEY 8d's definition on the graph the caller handed over (a squished plan still solves all m_orig vertices)
+  const uint64_t m = (uint64_t)(plan->squished ? plan->m_orig : plan->m_local), nnz = plan->nnz;
   return 8 * (m + 1) + 4 * nnz + 4 * nnz + 16 * m;
 }
 
@@ -612,14 +793,12 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
   gdn_graph *g = nullptr;
   GDN_TRY(gdn_graph_upload(m, nnz, in_rowptr, in_colidx, &g));
   DevBuf<int32_t> d_deg;
-  DevBuf<float> d_scores, d_c0, d_c1;
+  DevBuf<float> d_scores, d_state, d_c0, d_c1;
   DevBuf<double> d_diff;
   int rc = GDN_OK;
   gdn_pr_plan *plan = nullptr;
   do {
-    if ((rc = d_deg.alloc(m)) || (rc = d_scores.alloc(m)) || (rc = d_c0.alloc(m)) || (rc = d_c1.alloc(m)) ||
-        (rc = d_diff.alloc(1)))
-      break;
+    if ((rc = d_deg.alloc(m)) || (rc = d_scores.alloc(m)) || (rc = d_diff.alloc(1))) break;
     if (hipMemcpy(d_deg.p, out_degree, (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_scores.p, scores, (size_t)m * 4, hipMemcpyHostToDevice) != hipSuccess) {
       gdn_set_error("gdn_pr: upload failed");
@@ -628,27 +807,47 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     }
     st.h2d_ms = th2d.stop_ms();
     tprep.start();
-    if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, GDN_LAYOUT_AUTO, &plan))) break;
+    // the PB layout works on the live vertices only (GDN_LAYOUT_PB_SQUISHED; GDN_PR_SQUISH=0: the caller's vertex space)
+    int32_t layout = GDN_LAYOUT_AUTO;
+    {
+      const char *env = getenv("GDN_PR_LAYOUT"), *sq = getenv("GDN_PR_SQUISH");
+      const bool pb = (env && env[0] == 'p') || (!(env && env[0] == 'c') && nnz >= (1ull << 22));
+      if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
+    }
+    if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, layout, &plan))) break;
+    int32_t ms = m;
+    if ((rc = gdn_pr_plan_state_size(plan, &ms))) break;
+    if ((rc = d_state.alloc(ms)) || (rc = d_c0.alloc(ms)) || (rc = d_c1.alloc(ms))) break;
     st.prep_ms = tprep.stop_ms();
     // timed region == src/pr/base.cu:110-128 (t.Start .. t.Stop around the do/while)
     tsolve.start();
-    if ((rc = gdn_pr_contrib_dev(plan, d_scores.p, d_c0.p, nullptr))) break;
+    if ((rc = gdn_pr_import_dev(plan, d_scores.p, d_state.p, damping, nullptr))) break;
+    double dead_diff = 0;
+    if ((rc = gdn_pr_import_diff(plan, &dead_diff))) break;
+    if ((rc = gdn_pr_contrib_dev(plan, d_state.p, d_c0.p, nullptr))) break;
     float *cin = d_c0.p, *cout = d_c1.p;
     int iter = 0;
     double diff = 0;
     for (iter = 0; iter < max_iter; iter++) {
-      if ((rc = gdn_pr_pull_dev(plan, cin, d_scores.p, cout, d_diff.p, damping, nullptr))) break;
+      if ((rc = gdn_pr_pull_dev(plan, cin, d_state.p, cout, d_diff.p, damping, nullptr))) break;
       if (hipMemcpy(&diff, d_diff.p, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
         gdn_set_error("gdn_pr: diff readback failed: %s", hipGetErrorString(hipGetLastError()));
         rc = GDN_ERR_HIP;
         break;
       }
+      if (iter == 0) diff += dead_diff;  // the vertices outside the state move to the base score in the first iteration
       float *tmp = cin;
       cin = cout;
       cout = tmp;
       if (diff < epsilon) break;  // omp_base.cc:36
     }
     if (rc) break;
+    if ((rc = gdn_pr_export_dev(plan, d_state.p, d_scores.p, damping, nullptr))) break;
+    if (hipDeviceSynchronize() != hipSuccess) {
+      gdn_set_error("gdn_pr: export failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = GDN_ERR_HIP;
+      break;
+    }
     st.solve_ms = tsolve.stop_ms();
     if ((rc = gdn_pr_plan_check(plan))) break;
     st.iterations = iter + 1;  // the reference prints iter+1 (omp_base.cc:39)

@@ -217,17 +217,38 @@ class HipPageRankBackend:
         self.device = device
         self.m_local = hi - lo
         self.out_degree = out_degree_local  # int32 device tensor, m_local
+        self.m_global = m_global
         n_full = chunk * world
-        # + 4 entries behind the vector: [n_full] is the dummy slot of the compact exchange (16-byte alignment kept)
-        self.contribs = [torch.zeros(n_full + 4, dtype=torch.float32, device=device) for _ in range(2)]
-        self.scores = torch.full((max(self.m_local, 1),), 1.0 / m_global, dtype=torch.float32, device=device)
         self.diff = torch.zeros(1, dtype=torch.float64, device=device)
         self.plan = C.c_void_p()
+        # a single rank that holds the whole graph works on the LIVE vertices only (GDN_LAYOUT_PB_SQUISHED: vertices without
+        # any edge keep the base score and are left out of the per-iteration state; GDN_PR_SQUISH=0 keeps them in)
+        import os
+        if world == 1 and layout in (_cabi.GDN_LAYOUT_AUTO, _cabi.GDN_LAYOUT_PB) and os.environ.get("GDN_PR_SQUISH", "1") != "0":
+            nnz = C.c_uint64(0)
+            _cabi.check(self.L.gdn_graph_info(in_csr_handle, None, C.byref(nnz), None, None))
+            env = os.environ.get("GDN_PR_LAYOUT", "")
+            if layout == _cabi.GDN_LAYOUT_PB or env[:1] == "p" or (env[:1] != "c" and nnz.value >= (1 << 22)):
+                layout = _cabi.GDN_LAYOUT_PB_SQUISHED
         _cabi.check(self.L.gdn_pr_plan_create(in_csr_handle, C.c_void_p(out_degree_local.data_ptr()), m_global, lo,
                                               layout, C.byref(self.plan)))
-        lay, lg = C.c_int32(0), C.c_int32(0)
+        lay, lg, ms = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         _cabi.check(self.L.gdn_pr_plan_layout(self.plan, C.byref(lay), C.byref(lg)))
-        self.layout, self.log_blk = lay.value, lg.value
+        _cabi.check(self.L.gdn_pr_plan_state_size(self.plan, C.byref(ms)))
+        self.layout, self.log_blk, self.m_state = lay.value, lg.value, ms.value
+        self.squished = world == 1 and self.m_state != self.m_local
+        n_vec = self.m_state if self.squished else n_full
+        # + 4 entries behind the vector: [n_full] is the dummy slot of the compact exchange (16-byte alignment kept)
+        self.contribs = [torch.zeros(n_vec + 4, dtype=torch.float32, device=device) for _ in range(2)]
+        full = torch.full((max(self.m_local, 1),), 1.0 / m_global, dtype=torch.float32, device=device)
+        if self.squished:
+            self.scores = torch.empty(max(self.m_state, 1), dtype=torch.float32, device=device)
+            _cabi.check(self.L.gdn_pr_import_dev(self.plan, C.c_void_p(full.data_ptr()), C.c_void_p(self.scores.data_ptr()),
+                                                 0.85, self._stream()))
+            torch.cuda.synchronize()
+            del full
+        else:
+            self.scores = full
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -261,6 +282,15 @@ class HipPageRankBackend:
                                                      C.c_void_p(self.contribs[cout].data_ptr()),
                                                      C.c_void_p(self.diff.data_ptr()), float(damping), r0c, r1c, flags,
                                                      self._stream()))
+
+    def export_scores(self, damping: float = 0.85):
+        """The rank's scores in the caller's vertex order (m_local entries)."""
+        if not self.squished:
+            return self.scores
+        out = self.torch.empty(self.m_local, dtype=self.torch.float32, device=self.device)
+        self._cabi.check(self.L.gdn_pr_export_dev(self.plan, C.c_void_p(self.scores.data_ptr()), C.c_void_p(out.data_ptr()),
+                                                  float(damping), self._stream()))
+        return out
 
     def check(self):
         """Raise if the PB fixed-point accumulator saw an out-of-range value (blocking)."""

@@ -160,8 +160,15 @@ typedef struct gdn_pr_plan gdn_pr_plan;
  *                   tiles with 16-bit local ids, both slices LDS resident (the reference's
  *                   precedent: include/prop_blocking.h, src/pr/push_pb.cu; built once per graph,
  *                   outside the timed loop like segmenting() in src/pr/partition.cu)
- *   GDN_LAYOUT_AUTO PB for graphs with >= 2^22 edges (env GDN_PR_LAYOUT=csr|pb overrides) */
-enum { GDN_LAYOUT_AUTO = -1, GDN_LAYOUT_CSR = 0, GDN_LAYOUT_PB = 1 };
+ *   GDN_LAYOUT_AUTO PB for graphs with >= 2^22 edges (env GDN_PR_LAYOUT=csr|pb overrides)
+ *   GDN_LAYOUT_PB_SQUISHED (whole graphs only; never picked by AUTO)  the PB layout in a vertex space WITHOUT the
+ *                   vertices that have neither in- nor out-edges (53 % of RMAT-27): such a vertex keeps the constant
+ *                   base score and nobody reads its contribution, so the per-vertex STATE arrays of an iteration
+ *                   (d_scores, d_contrib_in/out of the calls below) have gdn_pr_plan_state_size() entries, state
+ *                   index k <-> the k-th live vertex in id order; gdn_pr_import_dev / gdn_pr_export_dev convert
+ *                   between the caller's m-entry score vector and the state at the boundary of a solve.  Same bits
+ *                   as GDN_LAYOUT_PB for every vertex. */
+enum { GDN_LAYOUT_AUTO = -1, GDN_LAYOUT_CSR = 0, GDN_LAYOUT_PB = 1, GDN_LAYOUT_PB_SQUISHED = 2 };
 int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
                        int32_t row_base, int32_t layout, gdn_pr_plan **plan);
 /* log_blk: 0 for CSR; for PB 100*log2(chunk ids) + log2(bin rows) */
@@ -175,6 +182,16 @@ int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edg
 int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges);
 int gdn_pr_plan_check(gdn_pr_plan *plan);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
+/* entries of the per-vertex state arrays (scores, contrib) the iteration calls of this plan work on: m_local, or the
+ * live vertices of a GDN_LAYOUT_PB_SQUISHED plan */
+int gdn_pr_plan_state_size(const gdn_pr_plan *plan, int32_t *m_state);
+/* caller's score vector (m entries) -> state (a copy for plans in the caller's vertex space); also records the L1
+ * change the vertices outside the state contribute to the FIRST iteration after the import (they move to the base
+ * score (1 - damping) / m): gdn_pr_import_diff returns it (blocking; 0 for plans in the caller's vertex space) */
+int gdn_pr_import_dev(gdn_pr_plan *plan, const float *d_scores, float *d_state, float damping, void *stream);
+int gdn_pr_import_diff(gdn_pr_plan *plan, double *dead_diff);
+/* state -> caller's score vector: live vertices from the state, the others get the base score */
+int gdn_pr_export_dev(gdn_pr_plan *plan, const float *d_state, float *d_scores, float damping, void *stream);
 /* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */
 int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contrib, void *stream);
 /* one fused pull iteration (src/pr/base.cu:19 pull_step + :37 l1norm + next :14 contrib):

@@ -295,6 +295,86 @@ def test_pr_mid_tiers_are_bitwise_neutral(orc, monkeypatch, world, parts):
     assert abs(res[2][2] - trace[-1]) < 1e-6
 
 
+@pytest.mark.parametrize("tiers", [False, True])
+def test_pr_squished_vertex_space_is_bitwise_neutral(orc, monkeypatch, tiers):
+    """GDN_LAYOUT_PB_SQUISHED: the plan's per-iteration state leaves out the vertices without any edge (they keep the base
+    score).  Host API with and without it: same bits, same iteration count, same last error; and arbitrary (non-uniform)
+    start scores, so that the L1 change of the left-out vertices in the first iteration matters."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    if tiers:
+        for k, v in TIER_ENV.items():
+            monkeypatch.setenv(k, v)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    g = graphio.rmat_graph(17, 4, seed=52)  # sparse: more than half of the vertices have no edge at all
+    gi = graphio.transpose(g)
+    G = solvers.Graph(csr=g, in_csr=gi)
+    live = (g.degrees() > 0) | (gi.degrees() > 0)
+    assert 0.2 < live.mean() < 0.8
+    want, it, trace = orc.pr(gi, g.degrees())
+    res = []
+    for sq in ("0", "1"):
+        monkeypatch.setenv("GDN_PR_SQUISH", sq)
+        scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(G, scores)
+        res.append((scores, st))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1]["iterations"] == res[1][1]["iterations"] == it
+    assert abs(res[0][1]["last_error"] - res[1][1]["last_error"]) < 1e-12
+    np.testing.assert_allclose(res[1][0], want, rtol=REL_TOL, atol=0)
+    # resident calls with non-uniform start scores: first-iteration L1 change incl. the left-out vertices
+    L = _cabi.lib()
+    h = C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(g.m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p),
+                                   C.byref(h)))
+
+    def dev(a):
+        p = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(max(a.nbytes, 4), C.byref(p)))
+        _cabi.check(L.gdn_dev_upload(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    rng = np.random.default_rng(3)
+    start = rng.random(g.m).astype(np.float32)
+    start /= np.float32(start.sum())
+    deg = dev(g.degrees().astype(np.int32))
+    outs = []
+    for layout in (_cabi.GDN_LAYOUT_PB, _cabi.GDN_LAYOUT_PB_SQUISHED):
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_pr_plan_create(h, deg, g.m, 0, layout, C.byref(plan)))
+        ms = C.c_int32(0)
+        _cabi.check(L.gdn_pr_plan_state_size(plan, C.byref(ms)))
+        assert ms.value == (g.m if layout == _cabi.GDN_LAYOUT_PB else int(live.sum()))
+        full = dev(start)
+        state = dev(np.zeros(ms.value, np.float32))
+        c = [dev(np.zeros(ms.value, np.float32)), dev(np.zeros(ms.value, np.float32))]
+        diff = dev(np.zeros(1, np.float64))
+        _cabi.check(L.gdn_pr_import_dev(plan, full, state, 0.85, None))
+        dead = C.c_double(0)
+        _cabi.check(L.gdn_pr_import_diff(plan, C.byref(dead)))
+        _cabi.check(L.gdn_pr_contrib_dev(plan, state, c[0], None))
+        diffs = []
+        for k in range(3):
+            _cabi.check(L.gdn_pr_pull_dev(plan, c[k & 1], state, c[(k + 1) & 1], diff, 0.85, None))
+            d = np.empty(1, np.float64)
+            _cabi.check(L.gdn_dev_download(d.ctypes.data_as(C.c_void_p), diff, 8))
+            diffs.append(d[0] + (dead.value if k == 0 else 0.0))
+        _cabi.check(L.gdn_pr_export_dev(plan, state, full, 0.85, None))
+        got = np.empty(g.m, np.float32)
+        _cabi.check(L.gdn_dev_download(got.ctypes.data_as(C.c_void_p), full, 4 * g.m))
+        _cabi.check(L.gdn_pr_plan_check(plan))
+        outs.append((got, diffs))
+        L.gdn_pr_plan_free(plan)
+        for p_ in (full, state, c[0], c[1], diff):
+            L.gdn_dev_free(p_)
+    L.gdn_dev_free(deg)
+    L.gdn_graph_free(h)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], rtol=1e-12, atol=0)
+    base = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(g.m))
+    assert np.all(outs[1][0][~live] == base)
+
+
 def test_pr_pb_rejects_out_of_range_scores(monkeypatch):
     """The fixed-point codes are made once per source (phase A's slice, the tier tables): a contribution outside [0,1]
     must still raise GDN_ERR_OVERFLOW, whichever tier its source sits in."""

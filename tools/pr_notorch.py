@@ -10,6 +10,7 @@ from gardenia_amd import _cabi, graphio
 
 L = _cabi.lib()
 scale = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+layout = int(sys.argv[2]) if len(sys.argv) > 2 else 1  # 1 = GDN_LAYOUT_PB, 2 = GDN_LAYOUT_PB_SQUISHED, 0 = CSR
 go, gi = C.c_void_p(), C.c_void_p()
 _cabi.check(L.gdn_rmat_build(scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
 m, nnz = C.c_int32(), C.c_uint64()
@@ -23,14 +24,21 @@ def alloc(nbytes):
     return p
 
 
-deg, scores, c0, c1, diff = alloc(4 * m), alloc(4 * m), alloc(4 * m), alloc(4 * m), alloc(8)
+deg, scores, diff = alloc(4 * m), alloc(4 * m), alloc(8)
 _cabi.check(L.gdn_graph_degrees_dev(go, deg, None))
 L.gdn_graph_free(go)
 import numpy as np
 init = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
 _cabi.check(L.gdn_dev_upload(scores, init.ctypes.data_as(C.c_void_p), 4 * m))
 plan = C.c_void_p()
-_cabi.check(L.gdn_pr_plan_create(gi, deg, m, 0, 1, C.byref(plan)))
+_cabi.check(L.gdn_pr_plan_create(gi, deg, m, 0, layout, C.byref(plan)))
+ms_ = C.c_int32(0)
+_cabi.check(L.gdn_pr_plan_state_size(plan, C.byref(ms_)))
+ms_ = ms_.value
+print("layout %d: state of %d entries (%.1f %% of %d vertices)" % (layout, ms_, 100.0 * ms_ / m, m))
+state, c0, c1 = alloc(4 * ms_), alloc(4 * ms_), alloc(4 * ms_)
+_cabi.check(L.gdn_pr_import_dev(plan, scores, state, 0.85, None))
+orig_scores, scores = scores, state  # the iteration calls work on the state
 nh, he = C.c_int32(0), C.c_uint64(0)
 _cabi.check(L.gdn_pr_plan_hubs(plan, C.byref(nh), C.byref(he)))
 print("hub tier: %d hubs, %d edges (%.1f %% of %d)" % (nh.value, he.value, 100.0 * he.value / max(nnz, 1), nnz))
@@ -57,7 +65,8 @@ for batch in range(3):  # three batches of 10 timed iterations; the fastest batc
     if batch == 0:
         first = cur
 out = np.empty(m, np.float32)
-_cabi.check(L.gdn_dev_download(out.ctypes.data_as(C.c_void_p), scores, 4 * m))
+_cabi.check(L.gdn_pr_export_dev(plan, scores, orig_scores, 0.85, None))
+_cabi.check(L.gdn_dev_download(out.ctypes.data_as(C.c_void_p), orig_scores, 4 * m))
 dd = np.empty(1, np.float64)
 _cabi.check(L.gdn_dev_download(dd.ctypes.data_as(C.c_void_p), diff, 8))
 import zlib
