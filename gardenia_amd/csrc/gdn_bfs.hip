@@ -105,7 +105,10 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
               const eoff_t *__restrict__ out_rowptr, int32_t m, unsigned m_pad, const unsigned *__restrict__ front,
               unsigned *__restrict__ next, unsigned *__restrict__ visited, int32_t *__restrict__ depth,
-              int32_t next_level, BfsCounters *cnt) {
+              int32_t next_level, BfsCounters *cnt,
+              // nullable: bitmap of the rows WITHOUT in-edges (never discoverable): skipped without touching their row
+              // offsets -- 61 % of RMAT-27's rows, 16 B of in_rowptr each otherwise
+              const unsigned *__restrict__ noin = nullptr) {
   __shared__ unsigned long long s_red[2 * GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
   unsigned long long awake = 0, scout = 0;
@@ -113,7 +116,7 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
     const unsigned v = base + threadIdx.x;
     bool found = false;
     if (v < (unsigned)m) {
-      const unsigned vw = visited[v >> 5];
+      const unsigned vw = visited[v >> 5] | (noin ? noin[v >> 5] : 0u);
       if (!((vw >> (v & 31)) & 1u)) {
         const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
         for (eoff_t k = rb; k < re; k++) {
@@ -407,8 +410,21 @@ struct gdn_bfs_plan {
   DevBuf<BfsCounters> cnt;
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
+  DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
   double prep_ms = 0;
 };
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_noin_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned nwords, unsigned *__restrict__ noin) {
+  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (w >= nwords) return;
+  unsigned word = 0;
+  for (unsigned i = 0; i < 32; i++) {
+    const size_t v = (size_t)w * 32 + i;
+    if (v >= (size_t)m || rowptr[v + 1] == rowptr[v]) word |= 1u << i;
+  }
+  noin[w] = word;
+}
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
@@ -455,6 +471,9 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
   if (gin) {
     GDN_TRY(p.front.alloc(p.nwords_pad));
     GDN_TRY(p.next.alloc(p.nwords_pad));
+    GDN_TRY(p.noin.alloc(p.nwords_pad));
+    hipLaunchKernelGGL(bfs_noin_kernel, dim3(gdn_nblocks(p.nwords_pad)), dim3(GDN_BLOCK), 0, 0, gin->rowptr, m, p.nwords_pad,
+                       p.noin.p);
   }
   GDN_HIP(hipDeviceSynchronize());
   p.prep_ms = t.stop_ms();
@@ -488,6 +507,11 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int64_t visited_total = 1;  // discovered so far (the source included)
   int64_t bu_frac = 4;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered
   if (const char *e = getenv("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
+  // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
+  // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
+  // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
+  int64_t bu_stay = 256;
+  if (const char *e = getenv("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
   BfsCounters h;
   memset(&h, 0, sizeof(h));
   ExpBigList big;
@@ -519,7 +543,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         const bool bottom_up = left * bu_frac <= (int64_t)p.active_rows;
         if (bottom_up) {
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
-                             p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
+                             p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
         } else {
           hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
                              p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
@@ -540,7 +564,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         // step over scout_count edges (a late level with millions of frontier vertices but few discoveries)
       } while (awake > 0 && (scout_count > (int64_t)(g->nnz / alpha_dense) ||
                              (((int64_t)p.active_rows - visited_total) * bu_frac <= (int64_t)p.active_rows &&
-                              scout_count > (int64_t)m / 16)));
+                              scout_count > (int64_t)m / bu_stay)));
       if (awake == 0) {
         nf = 0;
         break;
@@ -563,7 +587,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         old_awake = awake;
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
         hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
-                           p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p);
+                           p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
         GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
         awake = (int64_t)h.awake;
         unsigned *t = fr;
