@@ -161,7 +161,16 @@ class ShardedPageRank:
         """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
         nxt = self.cur ^ 1
         if self._cx is not None:
-            self._step_compact(nxt)
+            try:
+                self._step_compact(nxt)
+            except (RuntimeError, ValueError, NotImplementedError) as e:
+                # a backend that rejects one of the collectives: redo the iteration with the dense exchange (the pull
+                # only reads contrib[cur], so repeating it is exact)
+                import sys
+                print(f"[sharded] compact exchange failed ({e}); falling back to the dense all-gather", file=sys.stderr, flush=True)
+                self._cx = None
+                self.exchange = "dense"
+                return self.step()
         elif self.parts <= 1:
             self.be.pull(self.cur, nxt, self.damping)
             self._gather(nxt)
