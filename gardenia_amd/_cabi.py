@@ -77,6 +77,13 @@ PROTOTYPES = {
     "gdn_pr_import_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
     "gdn_pr_import_diff": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "gdn_pr_export_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
+    "gdn_pr_squish_create": (C.c_int, [_vp, _vp, _pp]),
+    "gdn_pr_squish_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), _pp, _pp]),
+    "gdn_pr_squish_import_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, C.POINTER(C.c_double), _vp]),
+    "gdn_pr_squish_export_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
+    "gdn_pr_squish_free": (C.c_int, [_vp]),
+    "gdn_pr_squish_degrees_dev": (C.c_int, [_vp, _vp, _vp]),
+    "gdn_pr_plan_set_base": (C.c_int, [_vp, _i32]),
     "gdn_pr_plan_check": (C.c_int, [_vp]),
     "gdn_pr_plan_free": (C.c_int, [_vp]),
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),

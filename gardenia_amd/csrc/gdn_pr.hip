@@ -490,6 +490,119 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   return GDN_OK;
 }
 
+// ---- the same relabelling as an object of its own: a multi-GPU driver squishes the whole graph once, cuts the
+// relabelled in-CSR into vertex ranges (gdn_graph_slice_rows) and builds ordinary plans on the shards
+struct gdn_pr_squish {
+  int32_t m_orig = 0, m_state = 0;
+  gdn_graph graph;            // relabelled in-CSR (arrays below)
+  DevBuf<uint32_t> ids, bits;
+  DevBuf<int32_t> deg;
+  DevBuf<eoff_t> rowptr;
+  DevBuf<vid_t> colidx;
+  DevBuf<double> diff;
+};
+
+int gdn_pr_squish_create(const gdn_graph *in_csr, const int32_t *d_out_degree, gdn_pr_squish **out) {
+  GDN_REQUIRE(in_csr && d_out_degree && out, "null argument");
+  *out = nullptr;
+  const int32_t m = in_csr->m;
+  DevBuf<uint32_t> flag;
+  DevBuf<eoff_t> cmap;
+  GDN_TRY(flag.alloc((size_t)m));
+  GDN_TRY(cmap.alloc((size_t)m + 1));
+  hipLaunchKernelGGL(pr_live_flags_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, in_csr->rowptr, d_out_degree, m,
+                     flag.p);
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(flag.p, cmap.p, (size_t)m, 0));
+  eoff_t n_live = 0;
+  GDN_HIP(hipMemcpy(&n_live, cmap.p + m, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  gdn_pr_squish *q = new gdn_pr_squish();
+  q->m_orig = m;
+  q->m_state = (int32_t)n_live;
+  const uint32_t ms = (uint32_t)n_live;
+  int st;
+  if ((st = q->ids.alloc(ms)) == GDN_OK && (st = q->deg.alloc(ms)) == GDN_OK && (st = q->rowptr.alloc((size_t)ms + 1)) == GDN_OK &&
+      (st = q->bits.alloc(((size_t)m + 31) / 32 + 1)) == GDN_OK && (st = q->colidx.alloc((size_t)in_csr->nnz)) == GDN_OK &&
+      (st = q->diff.alloc(1)) == GDN_OK) {
+    (void)hipMemset(q->diff.p, 0, sizeof(double));
+    hipLaunchKernelGGL(pr_squish_vertices_kernel, dim3(gdn_nblocks(((uint64_t)m + 31) / 32)), dim3(GDN_BLOCK), 0, 0, flag.p, cmap.p,
+                       in_csr->rowptr, d_out_degree, m, in_csr->nnz, ms, q->ids.p, q->deg.p, q->rowptr.p, q->bits.p);
+    if (in_csr->nnz)
+      hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, in_csr->colidx, cmap.p, in_csr->nnz, q->colidx.p);
+    if (hipDeviceSynchronize() != hipSuccess) {
+      gdn_set_error("gdn_pr_squish_create: kernels failed: %s", hipGetErrorString(hipGetLastError()));
+      st = GDN_ERR_HIP;
+    }
+  }
+  if (st != GDN_OK) {
+    delete q;
+    return st;
+  }
+  q->graph.m = q->m_state;
+  q->graph.nnz = in_csr->nnz;
+  q->graph.rowptr = q->rowptr.p;
+  q->graph.colidx = q->colidx.p;
+  q->graph.owned = false;
+  *out = q;
+  return GDN_OK;
+}
+
+int gdn_pr_squish_free(gdn_pr_squish *sq) {
+  delete sq;
+  return GDN_OK;
+}
+
+int gdn_pr_squish_info(const gdn_pr_squish *sq, int32_t *m_orig, int32_t *m_state, const gdn_graph **graph,
+                       const int32_t **d_degrees) {
+  GDN_REQUIRE(sq != nullptr, "squish");
+  if (m_orig) *m_orig = sq->m_orig;
+  if (m_state) *m_state = sq->m_state;
+  if (graph) *graph = &sq->graph;
+  if (d_degrees) *d_degrees = sq->deg.p;
+  return GDN_OK;
+}
+
+int gdn_pr_squish_degrees_dev(const gdn_pr_squish *sq, int32_t *d_degrees, void *stream) {
+  GDN_REQUIRE(sq && d_degrees, "null argument");
+  GDN_HIP(hipMemcpyAsync(d_degrees, sq->deg.p, (size_t)sq->m_state * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return GDN_OK;
+}
+
+int gdn_pr_squish_import_dev(gdn_pr_squish *sq, const float *d_scores, float *d_state, float damping, double *dead_diff,
+                             void *stream) {
+  GDN_REQUIRE(sq && d_scores && d_state, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  const uint32_t n = (uint32_t)sq->m_state;
+  hipLaunchKernelGGL(pr_gather_state_kernel, dim3(gdn_nblocks(n)), dim3(GDN_BLOCK), 0, s, d_scores, sq->ids.p, n, d_state);
+  if (dead_diff) {  // blocking: the L1 change of the dead vertices in the first iteration after the import
+    GDN_HIP(hipMemsetAsync(sq->diff.p, 0, sizeof(double), s));
+    hipLaunchKernelGGL(pr_dead_diff_kernel, dim3(2048), dim3(GDN_BLOCK), 0, s, d_scores, sq->bits.p, sq->m_orig,
+                       (1.0f - damping) / (float)sq->m_orig, sq->diff.p);
+    GDN_HIP(hipStreamSynchronize(s));
+    GDN_HIP(hipMemcpy(dead_diff, sq->diff.p, sizeof(double), hipMemcpyDeviceToHost));
+  }
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+int gdn_pr_squish_export_dev(gdn_pr_squish *sq, const float *d_state, float *d_scores, float damping, void *stream) {
+  GDN_REQUIRE(sq && d_scores && d_state, "null argument");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pr_export_dead_kernel, dim3(gdn_nblocks((uint64_t)sq->m_orig)), dim3(GDN_BLOCK), 0, s, sq->bits.p, sq->m_orig,
+                     (1.0f - damping) / (float)sq->m_orig, d_scores);
+  hipLaunchKernelGGL(pr_export_live_kernel, dim3(gdn_nblocks((uint64_t)sq->m_state)), dim3(GDN_BLOCK), 0, s, d_state, sq->ids.p,
+                     (uint32_t)sq->m_state, d_scores);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+// plans built on (shards of) a squished graph: the base score is (1 - d) / m of the ORIGINAL vertex count
+int gdn_pr_plan_set_base(gdn_pr_plan *plan, int32_t m_base) {
+  GDN_REQUIRE(plan != nullptr && m_base >= plan->m_global, "m_base");
+  plan->m_base = m_base;
+  if (!plan->squished) plan->m_orig = m_base;  // gdn_pr_iter_bytes counts the caller's vertices
+  return GDN_OK;
+}
+
 int gdn_pr_plan_state_size(const gdn_pr_plan *plan, int32_t *m_state) {
   GDN_REQUIRE(plan != nullptr && m_state != nullptr, "null argument");
   *m_state = plan->m_local;

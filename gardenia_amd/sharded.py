@@ -220,7 +220,9 @@ class HipPageRankBackend:
     """Local shard on one MI355X: torch device tensors + the _dev entry points of the C-ABI."""
 
     def __init__(self, torch, in_csr_handle, out_degree_local, m_global: int, lo: int, hi: int, chunk: int,
-                 world: int, device, layout: int = -1):
+                 world: int, device, layout: int = -1, m_base: int = 0):
+        """m_base > 0: the shard belongs to a squished graph of m_global live vertices (gdn_pr_squish_*) whose original
+        vertex count m_base sets the base score and the start scores."""
         from . import _cabi
         self.torch, self._cabi, self.L = torch, _cabi, _cabi.lib()
         self.device = device
@@ -241,6 +243,8 @@ class HipPageRankBackend:
                 layout = _cabi.GDN_LAYOUT_PB_SQUISHED
         _cabi.check(self.L.gdn_pr_plan_create(in_csr_handle, C.c_void_p(out_degree_local.data_ptr()), m_global, lo,
                                               layout, C.byref(self.plan)))
+        if m_base:
+            _cabi.check(self.L.gdn_pr_plan_set_base(self.plan, int(m_base)))
         lay, lg, ms = C.c_int32(0), C.c_int32(0), C.c_int32(0)
         _cabi.check(self.L.gdn_pr_plan_layout(self.plan, C.byref(lay), C.byref(lg)))
         _cabi.check(self.L.gdn_pr_plan_state_size(self.plan, C.byref(ms)))
@@ -249,7 +253,7 @@ class HipPageRankBackend:
         n_vec = self.m_state if self.squished else n_full
         # + 4 entries behind the vector: [n_full] is the dummy slot of the compact exchange (16-byte alignment kept)
         self.contribs = [torch.zeros(n_vec + 4, dtype=torch.float32, device=device) for _ in range(2)]
-        full = torch.full((max(self.m_local, 1),), 1.0 / m_global, dtype=torch.float32, device=device)
+        full = torch.full((max(self.m_local, 1),), 1.0 / (m_base or m_global), dtype=torch.float32, device=device)
         if self.squished:
             self.scores = torch.empty(max(self.m_state, 1), dtype=torch.float32, device=device)
             _cabi.check(self.L.gdn_pr_import_dev(self.plan, C.c_void_p(full.data_ptr()), C.c_void_p(self.scores.data_ptr()),

@@ -192,6 +192,21 @@ int gdn_pr_import_dev(gdn_pr_plan *plan, const float *d_scores, float *d_state, 
 int gdn_pr_import_diff(gdn_pr_plan *plan, double *dead_diff);
 /* state -> caller's score vector: live vertices from the state, the others get the base score */
 int gdn_pr_export_dev(gdn_pr_plan *plan, const float *d_state, float *d_scores, float damping, void *stream);
+/* The same relabelling as an object of its own, for drivers that shard the graph (bench.py --gpus N): squish the whole
+ * in-CSR once, cut `graph` (relabelled in-CSR, m_state rows, owned by the object) into vertex ranges with
+ * gdn_graph_slice_rows, build ordinary plans on the shards (d_degrees: out-degrees in state order) and tell them the
+ * original vertex count with gdn_pr_plan_set_base (base score (1 - d) / m).  import: caller's m-entry scores -> state;
+ * dead_diff (nullable, makes the call blocking) = L1 change of the vertices outside the state in the first iteration. */
+typedef struct gdn_pr_squish gdn_pr_squish;
+int gdn_pr_squish_create(const gdn_graph *in_csr, const int32_t *d_out_degree, gdn_pr_squish **sq);
+int gdn_pr_squish_info(const gdn_pr_squish *sq, int32_t *m_orig, int32_t *m_state, const gdn_graph **graph,
+                       const int32_t **d_degrees);
+int gdn_pr_squish_degrees_dev(const gdn_pr_squish *sq, int32_t *d_degrees /* m_state */, void *stream);
+int gdn_pr_squish_import_dev(gdn_pr_squish *sq, const float *d_scores, float *d_state, float damping, double *dead_diff,
+                             void *stream);
+int gdn_pr_squish_export_dev(gdn_pr_squish *sq, const float *d_state, float *d_scores, float damping, void *stream);
+int gdn_pr_squish_free(gdn_pr_squish *sq);
+int gdn_pr_plan_set_base(gdn_pr_plan *plan, int32_t m_base);
 /* contrib[row_base+v] = scores[v]/out_degree[v]  (src/pr/base.cu:14 contrib) */
 int gdn_pr_contrib_dev(gdn_pr_plan *plan, const float *d_scores, float *d_contrib, void *stream);
 /* one fused pull iteration (src/pr/base.cu:19 pull_step + :37 l1norm + next :14 contrib):

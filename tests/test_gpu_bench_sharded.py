@@ -33,10 +33,11 @@ def _bench(extra, launcher=None):
 def test_bench_two_ranks_on_one_device_match_single():
     single = _bench([])
     res = {}
-    for ex in ("dense", "compact"):
+    for ex, extra in (("dense", []), ("compact", []), ("compact", ["--no-squish"]), ("dense", ["--no-squish"])):
         launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", str(_free_port())]
-        res[ex] = _bench(["--gpus", "2", "--share-device", "--exchange", ex], launcher)
-        assert res[ex]["n_gpus"] == 2 and ex + " exchange" in res[ex]["config"]["partition"]
-        assert res[ex]["pr_last_l1_change"] == single["pr_last_l1_change"]
+        r = res[ex + " ".join(extra)] = _bench(["--gpus", "2", "--share-device", "--exchange", ex] + extra, launcher)
+        assert r["n_gpus"] == 2 and ex + " exchange" in r["config"]["partition"]
+        assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == (not extra)
+        assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     assert "roofline" in single and single["roofline"]["frac"] > 0
