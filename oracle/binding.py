@@ -26,7 +26,7 @@ def build(force: bool = False) -> str:
     if force or not os.path.exists(_LIB_PATH) or (
             os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "gardenia_oracle.cc"))):
         subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
-    if os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(REF_DIR, "ref_tc")):
+    if os.path.isdir("/root/reference/src") and not os.path.exists(os.path.join(REF_DIR, "ref_bc")):
         subprocess.check_call(["make", "-s", "-C", _HERE, "ref"])
     return _LIB_PATH
 
@@ -76,6 +76,10 @@ def lib():
         L.orc_cc_verify.restype = C.c_int
         L.orc_sample_frequent_element.argtypes = [C.c_int32, _i32p, C.c_int64]
         L.orc_sample_frequent_element.restype = C.c_int32
+        L.orc_bc.argtypes = [C.c_int32, _u64p, _i32p, C.c_int32, _f32p, C.c_void_p, C.c_void_p]
+        L.orc_bc.restype = C.c_int
+        L.orc_bc_verify.argtypes = [C.c_int32, _u64p, _i32p, C.c_int32, _f32p]
+        L.orc_bc_verify.restype = C.c_int
         L.orc_tc_orient.argtypes = [C.c_int32, _u64p, _i32p, _u64p, C.c_void_p]
         L.orc_tc_orient.restype = C.c_uint64
         L.orc_tc.argtypes = [C.c_int32, _u64p, _i32p]
@@ -210,3 +214,19 @@ def tc_orient(g):
 def tc(g_dag) -> int:
     rp, ci = _g(g_dag)
     return int(lib().orc_tc(g_dag.m, rp, ci))
+
+
+def bc(g, source, scores=None):
+    """src/bc/omp_base.cc BCSolver from one source: returns (scores, levels, depths, path_counts)."""
+    sc = np.zeros(g.m, np.float32) if scores is None else np.array(scores, dtype=np.float32)
+    depths = np.empty(g.m, np.int32)
+    pcs = np.empty(g.m, np.int32)
+    lv = lib().orc_bc(g.m, np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32), int(source), sc,
+                      depths.ctypes.data_as(C.c_void_p), pcs.ctypes.data_as(C.c_void_p))
+    return sc, lv, depths, pcs
+
+
+def bc_verify(g, source, scores) -> bool:
+    """src/bc/verifier.cc criterion (abs 1e-4 + rel 1e-4 against a serial Brandes)."""
+    return bool(lib().orc_bc_verify(g.m, np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32),
+                                    int(source), np.ascontiguousarray(scores, np.float32)))

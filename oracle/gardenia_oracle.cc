@@ -646,4 +646,88 @@ uint64_t orc_tc(int32_t m, const eoff_t *rowptr, const vid_t *colidx) {
   return counter;
 }
 
+
+// ---------------------------------------------------------------------------------
+// Betweenness centrality, one source
+// ---------------------------------------------------------------------------------
+
+// Brandes from ONE source like src/bc/omp_base.cc:55-105 (num_iters = 1): forward BFS with int path counts
+// (PBFS :16-53: a neighbour found at depth+1 receives the path count of its parent), then the dependencies from the
+// deepest level back (:78-93: delta_src = SUM over successors of pc[src]/pc[dst] * (1 + delta[dst]), float, in CSR
+// order), scores[src] += delta_src, finally every score divided by the largest (:95-101).  scores is in/out like
+// src/bc/main.cc:21 (the caller zero-fills).  depths_out (nullable, m ints, -1 = unreached) and
+// path_counts_out (nullable) expose the forward phase for tests.  Returns the number of BFS levels.
+// The forward phase here is level-synchronous and serial per level, so path counts come out in the same (wrapping
+// int) arithmetic as the reference's atomics; the per-source sums keep the reference's CSR order.
+int orc_bc(int32_t m, const eoff_t *rowptr, const vid_t *colidx, int32_t source, float *scores, int32_t *depths_out,
+           int32_t *path_counts_out) {
+  std::vector<int32_t> depths((size_t)m, -1), order;
+  std::vector<uint32_t> pc((size_t)m, 0u);  // the reference adds ints; unsigned keeps the wrap defined
+  std::vector<size_t> level_ptr;
+  order.reserve((size_t)m);
+  depths[source] = 0;
+  pc[source] = 1;
+  order.push_back(source);
+  level_ptr.push_back(0);
+  size_t head = 0;
+  int depth = 0;
+  while (head < order.size()) {
+    const size_t tail = order.size();
+    level_ptr.push_back(tail);
+    depth++;
+    for (size_t i = head; i < tail; i++) {
+      const vid_t src = order[i];
+      for (eoff_t k = rowptr[src]; k < rowptr[src + 1]; k++) {
+        const vid_t dst = colidx[k];
+        if (depths[dst] == -1) {
+          depths[dst] = depth;
+          order.push_back(dst);
+        }
+        if (depths[dst] == depth) pc[dst] += pc[src];
+      }
+    }
+    head = tail;
+  }
+  // level_ptr = {0, end of level 0, end of level 1, ...}; the last entry repeats the end (empty level)
+  std::vector<float> deltas((size_t)m, 0.0f);
+  const int nlev = (int)level_ptr.size() - 1;  // levels 0 .. nlev-1 (the last one may be empty)
+  for (int d = nlev - 1; d >= 0; d--) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long long i = (long long)level_ptr[d]; i < (long long)level_ptr[d + 1]; i++) {
+      const vid_t src = order[(size_t)i];
+      float delta_src = 0.0f;
+      for (eoff_t k = rowptr[src]; k < rowptr[src + 1]; k++) {
+        const vid_t dst = colidx[k];
+        if (depths[dst] == depths[src] + 1)
+          delta_src += static_cast<float>((int32_t)pc[src]) / static_cast<float>((int32_t)pc[dst]) * (1 + deltas[dst]);
+      }
+      deltas[src] = delta_src;
+      scores[src] += delta_src;
+    }
+  }
+  float biggest = 0.0f;
+  for (int32_t n = 0; n < m; n++) biggest = std::max(biggest, scores[n]);
+  for (int32_t n = 0; n < m; n++) scores[n] = scores[n] / biggest;
+  if (depths_out) memcpy(depths_out, depths.data(), (size_t)m * 4);
+  if (path_counts_out) memcpy(path_counts_out, pc.data(), (size_t)m * 4);
+  int levels = 0;
+  for (int d = 0; d < nlev; d++)
+    if (level_ptr[d + 1] > level_ptr[d]) levels = d + 1;
+  return levels;
+}
+
+// Verifier criterion of src/bc/verifier.cc:17-44,128-132: serial Brandes (orc_bc IS serial in its forward phase and
+// sums in the same order as the verifier's :107-119), then |a - b| <= 1e-4 * (|a| + |b|) + 1e-4 for every vertex.
+// Returns 1 = "Correct", 0 = "POSSIBLE FAILURE".
+int orc_bc_verify(int32_t m, const eoff_t *rowptr, const vid_t *colidx, int32_t source, const float *scores_to_test) {
+  std::vector<float> want((size_t)m, 0.0f);
+  orc_bc(m, rowptr, colidx, source, want.data(), nullptr, nullptr);
+  for (int32_t i = 0; i < m; i++) {
+    const double a = scores_to_test[i], b = want[i];
+    if (std::isnan(a) != std::isnan(b)) return 0;
+    if (std::isnan(a)) continue;  // 0/0 on both sides (no vertex has a dependency)
+    if (fabs(a - b) > 1e-4 * (fabs(a) + fabs(b)) + 1e-4) return 0;
+  }
+  return 1;
+}
 }  // extern "C"

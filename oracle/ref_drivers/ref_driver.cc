@@ -33,8 +33,10 @@
 #include "cc.h"
 #elif defined(K_TC)
 #include "tc.h"
+#elif defined(K_BC)
+#include "bc.h"
 #else
-#error "define one of K_BFS K_PR K_SPMV K_SSSP K_CC K_TC"
+#error "define one of K_BFS K_PR K_SPMV K_SSSP K_CC K_TC K_BC"
 #endif
 
 template <typename T>
@@ -135,6 +137,17 @@ int main(int argc, char **argv) {
   if (argc > 8 && std::string(argv[8]) != "-") wt = slurp<DistT>(argv[8], nnz);
   auto d = slurp<DistT>(io, (size_t)m);
   SSSPVerifier(g, source, wt.data(), d.data());
+#elif defined(K_BC)
+  int source = argc > 7 ? atoi(argv[7]) : 0;
+  if (mode == "solve") {
+    std::vector<ScoreT> scores(m, 0);  // src/bc/main.cc:21
+    BCSolver(g, source, &scores[0]);
+    dump(io + ".scores", scores.data(), (size_t)m);
+    BCVerifier(g, source, 1, &scores[0]);  // src/bc/main.cc:23
+  } else {
+    auto s = slurp<ScoreT>(io, (size_t)m);
+    BCVerifier(g, source, 1, s.data());
+  }
 #elif defined(K_CC)
   if (mode == "solve") {
     std::vector<CompT> comp(m);

@@ -92,6 +92,23 @@ def main():
     def binp(name):
         return ("bin", os.path.join(tmp, name))
 
+    # ---- BC (reference solver = omp_base from ONE source, src/bc/main.cc; its verifier's verdict recorded) ----
+    for case, (ft, px), sym, source in [
+            ("test_bc_dir", mtx("test_bc"), 0, 0), ("test_bc_sym", mtx("test_bc"), 1, 0),
+            ("chesapeake_sym", mtx("chesapeake"), 1, 0), ("4_dir", mtx("4"), 0, 0),
+            ("rmat10_dir", binp("rmat10"), 0, graphio.first_nonisolated(rm10)),
+            ("rmat12_dir", binp("rmat12"), 0, graphio.first_nonisolated(rm12))]:
+        out = os.path.join(tmp, "bc_" + case)
+        so = run([os.path.join(REFBIN, "ref_bc"), "solve", ft, px, str(sym), "0", out, str(source)])
+        d = graph_arrays(out, False)
+        np.savez_compressed(os.path.join(HERE, f"bc_{case}.npz"), source=source, scores=load(out, "scores", np.float32),
+                            verdict=verdict(so), symmetrize=sym, **d)
+        assert verdict(so) == "Correct", so
+    if len(sys.argv) > 1 and sys.argv[1] == "bc":  # only the BC vectors (the others are already committed)
+        shutil.rmtree(tmp)
+        print("BC golden vectors written to", HERE)
+        return
+
     # ---- BFS (reference solver = omp_beamer, needs the reverse graph) ----
     for case, (ft, px), sym, rev, source in [
             ("test_bc_dir", mtx("test_bc"), 0, 1, 0), ("test_bc_sym", mtx("test_bc"), 1, 0, 0),
