@@ -53,6 +53,8 @@ PROTOTYPES = {
     "gdn_spmv": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
+    "gdn_bc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, _vp, C.POINTER(GdnStats)]),
+    "gdn_bc_dev": (C.c_int, [_vp, _i32, _vp, C.POINTER(GdnStats)]),
     "gdn_cc": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_dev_alloc": (C.c_int, [_u64, _pp]),
     "gdn_dev_free": (C.c_int, [_vp]),

@@ -98,6 +98,7 @@ void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y);
 void SSSPSolver(Graph &g, int source, DistT *weight, DistT *dist, int delta);
 void CCSolver(Graph &g, CompT *comp);
 void TCSolver(Graph &g, uint64_t &total);  // g symmetric: orientation is applied on the device
+void BCSolver(Graph &g, int source, ScoreT *scores);  // src/bc/bc.h:37
 
 // ---- verifiers (verifiers.cc): print Correct / Wrong like the reference and also return it
 bool BFSVerifier(Graph &g, int source, DistT *dist);
@@ -106,6 +107,7 @@ bool SpmvVerifier(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y0, Value
 bool SSSPVerifier(Graph &g, int source, DistT *weight, DistT *dist);
 bool CCVerifier(Graph &g, CompT *comp);
 bool TCVerifier(Graph &g, uint64_t test_total);  // g symmetric; orients a host copy
+bool BCVerifier(Graph &g, int source, int num_iters, ScoreT *scores_to_test);  // src/bc/verifier.cc:69
 
 // Solver failures are exceptions, not exit() (cutil_subset.h:4-12 exits): the mains report and
 // return 3 so that buffered output (graph statistics) is still flushed.

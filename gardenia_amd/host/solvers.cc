@@ -64,3 +64,10 @@ void TCSolver(Graph &g, uint64_t &total) {  // src/tc/tc.h:7
   printf("runtime [hip_gfx950] = %f sec (orientation %f sec)\n", st.solve_ms * 1e-3, st.prep_ms * 1e-3);
   printf("throughput = %f billion Traversed Edges Per Second (TEPS)\n", st.edges_traversed / (st.solve_ms * 1e-3) / 1e9);
 }
+
+void BCSolver(Graph &g, int source, ScoreT *scores) {  // src/bc/bc.h:37
+  gdn_stats st;
+  must(gdn_bc(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), source, scores, &st), "BCSolver");
+  printf("\titerations = %d.\n", st.iterations);
+  printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
+}

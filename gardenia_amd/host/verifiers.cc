@@ -143,3 +143,63 @@ bool TCVerifier(Graph &g, uint64_t test_total) {
   printf("total %llu test_total %llu\n", (unsigned long long)total, (unsigned long long)test_total);
   return total == test_total;
 }
+
+// src/bc/verifier.cc:69-146: serial Brandes from the same source (depths and int path counts by a queue BFS, the
+// dependencies from the deepest level back with the successors regenerated from the depths), scores normalised to the
+// largest, then |a - b| <= 1e-4 * (|a| + |b|) + 1e-4 per vertex (:24-30); a NaN on both sides (0/0: nothing lies between)
+// counts as equal.
+bool BCVerifier(Graph &g, int source, int num_iters, ScoreT *scores_to_test) {
+  printf("Verifying...\n");
+  const VertexId m = g.V();
+  std::vector<ScoreT> scores(m, 0);
+  int max_depth = 0;
+  for (int iter = 0; iter < num_iters; iter++) {
+    std::vector<int> depths(m, -1), path_counts(m, 0);
+    std::vector<VertexId> to_visit;
+    to_visit.reserve(m);
+    depths[source] = 0;
+    path_counts[source] = 1;
+    to_visit.push_back(source);
+    for (size_t it = 0; it < to_visit.size(); it++) {
+      const VertexId src = to_visit[it];
+      for (VertexId dst : g.N(src)) {
+        if (depths[dst] == -1) {
+          depths[dst] = depths[src] + 1;
+          to_visit.push_back(dst);
+        }
+        if (depths[dst] == depths[src] + 1) path_counts[dst] = (int)((unsigned)path_counts[dst] + (unsigned)path_counts[src]);
+      }
+    }
+    std::vector<std::vector<VertexId>> at_depth;
+    for (VertexId n = 0; n < m; n++)
+      if (depths[n] != -1) {
+        if (depths[n] >= (int)at_depth.size()) at_depth.resize(depths[n] + 1);
+        at_depth[depths[n]].push_back(n);
+      }
+    max_depth = (int)at_depth.size();
+    std::vector<ScoreT> deltas(m, 0);
+    for (int d = max_depth - 1; d >= 0; d--)
+      for (VertexId src : at_depth[d]) {
+        ScoreT delta_src = 0;
+        for (VertexId dst : g.N(src))
+          if (depths[dst] == depths[src] + 1)
+            delta_src += static_cast<ScoreT>(path_counts[src]) / static_cast<ScoreT>(path_counts[dst]) * (1 + deltas[dst]);
+        deltas[src] = delta_src;
+        scores[src] += delta_src;
+      }
+  }
+  ScoreT biggest = 0;
+  for (VertexId n = 0; n < m; n++) biggest = scores[n] > biggest ? scores[n] : biggest;
+  for (VertexId n = 0; n < m; n++) scores[n] = scores[n] / biggest;
+  printf("\titerations = %d.\n", max_depth);
+  printf("\tmax_score = %.6f.\n", biggest);
+  bool ok = true;
+  for (VertexId n = 0; n < m && ok; n++) {
+    const double a = scores_to_test[n], b = scores[n];
+    if ((a != a) != (b != b)) ok = false;
+    else if (a == a && std::fabs(a - b) > 1e-4 * (std::fabs(a) + std::fabs(b)) + 1e-4) ok = false;
+    if (!ok) printf("score_test[%d] (%f) != score[%d] (%f)\n", (int)n, scores_to_test[n], (int)n, scores[n]);
+  }
+  printf(ok ? "Correct\n" : "POSSIBLE FAILURE\n");
+  return ok;
+}

@@ -89,6 +89,15 @@ def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_
     return st.as_dict()
 
 
+def BCSolver(g: Graph, source: int, scores: np.ndarray) -> dict:
+    """src/bc/bc.h:37.  scores: float32[m], zero-filled by the caller (src/bc/main.cc:21); one source."""
+    assert scores.dtype == np.float32 and scores.flags.c_contiguous
+    rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_bc(g.V(), g.E(), _p(rp), _p(ci), int(source), _p(scores), C.byref(st)))
+    return st.as_dict()
+
+
 def SpmvSolver(g: Graph, Ax: np.ndarray, x: np.ndarray, y: np.ndarray) -> dict:
     """src/spmv/spmv.h:29.  y += A x over the rows of (in_rowptr, in_colidx)."""
     assert y.dtype == np.float32 and y.flags.c_contiguous

@@ -94,6 +94,13 @@ int gdn_sssp(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *col
 int gdn_tc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx, int32_t oriented,
            uint64_t *total, gdn_stats *stats);
 
+/* Betweenness centrality from ONE source == BCSolver(g, source, scores) of src/bc/bc.h:37 (src/bc/main.cc:22;
+ * SURVEY 8f rank 4): Brandes' forward BFS with 32-bit path counts + backward dependency sweep, scores[v] += delta[v],
+ * then every score divided by the largest (all 0/0 = NaN when nothing lies between, like the reference).
+ * scores: m floats, in/out (the reference main zero-fills).  stats.iterations = BFS levels. */
+int gdn_bc(int32_t m, uint64_t nnz, const uint64_t *out_rowptr, const int32_t *out_colidx, int32_t source, float *scores,
+           gdn_stats *stats);
+
 /* replaces CCSolver(Graph&, CompT* comp): src/cc/cc.h:28; caller src/cc/main.cc:16.
  * comp: in = i (main.cc:15), out = component label = minimum vertex id of the (weakly)
  * connected component (fixpoint of src/cc/omp_base.cc:24-43).  in_* nullable (directed
@@ -264,6 +271,8 @@ uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan);
  * src/bfs/linear_base.cu:73). */
 int gdn_bfs_dev(const gdn_graph *out_csr, const gdn_graph *in_csr /*nullable*/, int32_t source,
                 int32_t *d_dist, gdn_stats *stats);
+/* resident graph, device score vector (in/out) */
+int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *stats);
 /* Reusable BFS state for many searches on one resident graph.  dense != 0 (needs in_csr) also
  * builds the propagation-blocked layout of the in-CSR once, so that heavy levels run as one
  * streaming sweep over all in-edges instead of a bottom-up step (built outside the timed search,

@@ -865,3 +865,64 @@ def test_spmv_row_shards_on_one_device(orc, world, layout):
     L.gdn_graph_free(h)
     assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)  # src/spmv/verifier.cc:24
     np.testing.assert_allclose(got, want, rtol=REL_TOL, atol=1e-6)
+
+
+# ------------------------------------------------------------------ BC
+BC_ATOL = BC_RTOL = 1e-4  # the reference verifier's criterion (src/bc/verifier.cc:22-23)
+
+
+def _bc_close(got, want):
+    nan = np.isnan(want)
+    assert np.array_equal(np.isnan(got), nan)
+    g, w = got[~nan].astype(np.float64), want[~nan].astype(np.float64)
+    assert np.all(np.abs(g - w) <= BC_RTOL * (np.abs(g) + np.abs(w)) + BC_ATOL)
+
+
+@pytest.mark.parametrize("case", ["test_bc_dir", "test_bc_sym", "chesapeake_sym", "4_dir", "rmat10_dir", "rmat12_dir"])
+def test_bc_golden(orc, case):
+    """Scores the reference itself produced (src/bc/omp_base.cc through oracle/_ref/ref_bc): within the reference
+    verifier's tolerance everywhere, and bit for bit on the graphs whose rows all have fewer than 32 out-edges (longer
+    rows are summed by a wave in a fixed tree, not in CSR order)."""
+    d = golden("bc_" + case)
+    g = solvers.Graph(csr=csr_from(d))
+    scores = np.zeros(g.V(), np.float32)
+    st = solvers.BCSolver(g, int(d["source"]), scores)
+    _bc_close(scores, d["scores"])
+    if int(csr_from(d).degrees().max()) < 32:  # every row summed by one lane in CSR order: the reference's bits
+        assert np.array_equal(scores, d["scores"], equal_nan=True)
+    assert st["iterations"] == orc.bc(csr_from(d), int(d["source"]))[1]
+    assert orc.bc_verify(csr_from(d), int(d["source"]), scores)
+
+
+@pytest.mark.parametrize("scale,ef,seed,sym", [(14, 16, 1, False), (16, 16, 2, False), (15, 8, 3, True), (18, 16, 4, False)])
+def test_bc_vs_oracle_rmat(orc, scale, ef, seed, sym):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    if sym:
+        g = graphio.symmetrize(g)
+    s = graphio.first_nonisolated(g)
+    want, levels, depths, pcs = orc.bc(g, s)
+    scores = np.zeros(g.m, np.float32)
+    st = solvers.BCSolver(solvers.Graph(csr=g), s, scores)
+    assert st["iterations"] == levels
+    _bc_close(scores, want)
+    assert scores.max() == 1.0 and np.all(scores[depths == -1] == 0.0)
+    assert st["edges_traversed"] == 2 * int(g.degrees()[depths >= 0].astype(np.int64).sum())
+
+
+def test_bc_accumulates_into_scores_and_handles_hubs(orc):
+    """scores is in/out (scores[v] += delta[v] before the normalisation, src/bc/omp_base.cc:91); a star with 10 000
+    leaves and a second layer exercises the workgroup-per-row path of the backward sweep (rows >= 4096 edges)."""
+    n_leaf, n_far = 10000, 300
+    src = np.concatenate([np.zeros(n_leaf, np.int64), np.arange(1, n_far + 1), np.arange(1, n_far + 1)])
+    dst = np.concatenate([np.arange(1, n_leaf + 1), n_leaf + 1 + np.arange(n_far), n_leaf + 1 + (np.arange(n_far) + 1) % n_far])
+    g = graphio.build_csr(n_leaf + 1 + n_far, src, dst)
+    start = np.random.default_rng(2).random(g.m).astype(np.float32)
+    want, _, _, _ = orc.bc(g, 0, scores=start)
+    got = start.copy()
+    solvers.BCSolver(solvers.Graph(csr=g), 0, got)
+    _bc_close(got, want)
+    # an isolated source: nothing is reached, every score is 0/0 like in the reference
+    g2 = graphio.build_csr(5, np.array([1, 2]), np.array([2, 3]))
+    sc = np.zeros(5, np.float32)
+    solvers.BCSolver(solvers.Graph(csr=g2), 0, sc)
+    assert np.isnan(sc).all() and np.isnan(orc.bc(g2, 0)[0]).all()

@@ -21,7 +21,7 @@ def run(exe, *args):
 
 
 def test_mains_exist_and_load_graphs_like_the_reference():
-    for k in ("bfs", "pr", "spmv", "sssp", "cc", "tc"):
+    for k in ("bfs", "pr", "spmv", "sssp", "cc", "tc", "bc"):
         assert os.path.exists(os.path.join(BIN, k + "_hip")), "run __graft_entry__.build()"
     rc, out = run("bfs_hip", "mtx", os.path.join(G, "test_bc"), 1, 0, 0)
     assert "|V| 7 |E| 26" in out  # BASELINE.md known answer
@@ -40,14 +40,17 @@ def test_mains_print_correct(tmp_path):
              ("spmv_hip", ["mtx", os.path.join(G, "test_bc"), 0, 1]),
              ("sssp_hip", ["mtx", os.path.join(G, "test_bc"), 0, 0, 0, 1]),
              ("cc_hip", ["mtx", os.path.join(G, "test_cc"), 1, 0]),
-             ("tc_hip", ["mtx", os.path.join(G, "chesapeake")])]
+             ("tc_hip", ["mtx", os.path.join(G, "chesapeake")]),
+             ("bc_hip", ["mtx", os.path.join(G, "test_bc"), 1, 0, 0]),
+             ("bc_hip", ["mtx", os.path.join(G, "chesapeake"), 1, 0, 0])]
     g = graphio.rmat_graph(14, 16, seed=5)
     graphio.write_bin(str(tmp_path / "rm"), g)
     graphio.write_bin(str(tmp_path / "rms"), graphio.symmetrize(g))
     s = graphio.first_nonisolated(g)
     cases += [("bfs_hip", ["bin", tmp_path / "rm", 0, 1, s]), ("pr_hip", ["bin", tmp_path / "rm", 0]),
               ("sssp_hip", ["bin", tmp_path / "rm", 0, 0, s, 2]), ("cc_hip", ["bin", tmp_path / "rms", 1, 0]),
-              ("tc_hip", [tmp_path / "rms"]), ("spmv_hip", ["bin", tmp_path / "rm", 0, 1])]
+              ("tc_hip", [tmp_path / "rms"]), ("spmv_hip", ["bin", tmp_path / "rm", 0, 1]),
+              ("bc_hip", ["bin", tmp_path / "rm", 0, 0, s]), ("bc_hip", ["bin", tmp_path / "rms", 1, 0, s])]
     for exe, args in cases:
         rc, out = run(exe, *args)
         assert rc == 0 and "Correct" in out, (exe, args, out[-600:])
