@@ -111,11 +111,28 @@ __device__ __forceinline__ float bc_term(float pcs, int32_t pcd, float delta_dst
   return __fmul_rn(__fdiv_rn(pcs, (float)pcd), __fadd_rn(1.0f, delta_dst));
 }
 
-// backward step of one level: delta[src] = SUM over successors, scores[src] += delta[src]
+// What the backward sweep reads of a successor, in ONE 16-byte record (one divergent access per edge instead of three):
+// x = depth, y = path count, z = bits of delta, w unused
+typedef int bc_i32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_pack_kernel(const int32_t *__restrict__ depth, const int32_t *__restrict__ pc, int32_t m, bc_i32x4 *__restrict__ rec) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (size_t)m) rec[v] = bc_i32x4{depth[v], pc[v], 0, 0};
+}
+
+__device__ __forceinline__ float bc_edge_term(const bc_i32x4 *__restrict__ rec, vid_t dst, int32_t next_level, float pcs) {
+  const bc_i32x4 r = rec[dst];
+  return r.x == next_level ? bc_term(pcs, r.y, __int_as_float(r.z)) : 0.0f;
+}
+
+// backward step of one level: delta[src] = SUM over successors, scores[src] += delta[src].  A term of a non-successor
+// is +0.0f, which leaves every partial sum unchanged (the sums are never -0.0f), so the loops carry no branch.
+#define BC_UNR 4
 __global__ void __launch_bounds__(GDN_BLOCK)
 bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ level, unsigned nf,
-               const int32_t *__restrict__ depth, const int32_t *__restrict__ pc, float *__restrict__ delta,
-               float *__restrict__ scores, int32_t next_level, vid_t *__restrict__ big_rows, BcCounters *cnt, unsigned cap) {
+               bc_i32x4 *__restrict__ rec, float *__restrict__ scores, int32_t next_level, vid_t *__restrict__ big_rows,
+               BcCounters *cnt, unsigned cap) {
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned lane = gdn_lane();
   eoff_t b = 0, e = 0;
@@ -125,14 +142,15 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
     v = level[i];
     b = rowptr[v];
     e = rowptr[v + 1];
-    pcs = (float)pc[v];
+    pcs = (float)rec[v].y;
   }
   const eoff_t deg = e - b;
   float acc = 0.0f;
   // rows for the workgroup kernel
   const bool is_big = deg >= BC_BLOCK_ROW;
   gdn_wl_push(big_rows, &cnt->big_count, cap, is_big, v, &cnt->overflow);
-  // medium rows: the whole wave, one row at a time; lane l sums edges l, l + 64, ... then a fixed shuffle tree
+  // medium rows: the whole wave, one row at a time; lane l sums edges l, l + 64, ... (BC_UNR of them in flight), then a
+  // fixed shuffle tree
   unsigned long long mask = __ballot(deg >= BC_WAVE_ROW && !is_big);
   while (mask) {
     const int leader = __ffsll((long long)mask) - 1;
@@ -140,42 +158,62 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
     const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
     const float ps = __shfl(pcs, leader, 64);
     float part = 0.0f;
-    for (eoff_t k = bb + lane; k < ee; k += 64) {
-      const vid_t dst = colidx[k];
-      if (depth[dst] == next_level) part = __fadd_rn(part, bc_term(ps, pc[dst], delta[dst]));
+    for (eoff_t k0 = bb + lane; k0 < ee; k0 += 64 * BC_UNR) {
+      vid_t dst[BC_UNR];
+      float t[BC_UNR];
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + 64 * r < ee ? colidx[k0 + 64 * r] : -1;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
     if ((int)lane == leader) acc = part;
   }
-  // short rows: one lane, CSR order, the reference's arithmetic
+  // short rows: one lane, CSR order, the reference's arithmetic (the loads of BC_UNR edges in flight, added in order)
   if (i < nf && deg < BC_WAVE_ROW) {
-    for (eoff_t k = b; k < e; k++) {
-      const vid_t dst = colidx[k];
-      if (depth[dst] == next_level) acc = __fadd_rn(acc, bc_term(pcs, pc[dst], delta[dst]));
+    for (eoff_t k0 = b; k0 < e; k0 += BC_UNR) {
+      vid_t dst[BC_UNR];
+      float t[BC_UNR];
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + r < e ? colidx[k0 + r] : -1;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) acc = __fadd_rn(acc, t[r]);
     }
   }
   if (i < nf && !is_big) {
-    delta[v] = acc;
+    rec[v].z = __float_as_int(acc);
     scores[v] = __fadd_rn(scores[v], acc);
   }
 }
 
-__global__ void __launch_bounds__(GDN_BLOCK)
+// rows from BC_BLOCK_ROW edges on: one 1024-thread workgroup each, BC_UNR edges per thread in flight
+#define BC_BIG_THREADS 1024
+__global__ void __launch_bounds__(BC_BIG_THREADS)
 bc_back_big_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ big_rows,
-                   const BcCounters *__restrict__ cnt, const int32_t *__restrict__ depth, const int32_t *__restrict__ pc,
-                   float *__restrict__ delta, float *__restrict__ scores, int32_t next_level, unsigned cap) {
-  __shared__ float s_red[GDN_WAVES_PER_BLOCK];
+                   const BcCounters *__restrict__ cnt, bc_i32x4 *__restrict__ rec, float *__restrict__ scores, int32_t next_level,
+                   unsigned cap) {
+  __shared__ float s_red[BC_BIG_THREADS / 64];
   unsigned n = cnt->big_count;
   if (n > cap) n = cap;
-  for (unsigned r = blockIdx.x; r < n; r += gridDim.x) {
-    const vid_t v = big_rows[r];
+  for (unsigned r0 = blockIdx.x; r0 < n; r0 += gridDim.x) {
+    const vid_t v = big_rows[r0];
     const eoff_t b = rowptr[v], e = rowptr[v + 1];
-    const float pcs = (float)pc[v];
+    const float pcs = (float)rec[v].y;
     float part = 0.0f;
-    for (eoff_t k = b + threadIdx.x; k < e; k += GDN_BLOCK) {
-      const vid_t dst = colidx[k];
-      if (depth[dst] == next_level) part = __fadd_rn(part, bc_term(pcs, pc[dst], delta[dst]));
+    for (eoff_t k0 = b + threadIdx.x; k0 < e; k0 += (eoff_t)BC_BIG_THREADS * BC_UNR) {
+      vid_t dst[BC_UNR];
+      float t[BC_UNR];
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + (eoff_t)BC_BIG_THREADS * r < e ? colidx[k0 + (eoff_t)BC_BIG_THREADS * r] : -1;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
@@ -184,8 +222,8 @@ bc_back_big_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.0f;
-      for (int w = 0; w < GDN_WAVES_PER_BLOCK; w++) t = __fadd_rn(t, s_red[w]);
-      delta[v] = t;
+      for (int w = 0; w < BC_BIG_THREADS / 64; w++) t = __fadd_rn(t, s_red[w]);
+      rec[v].z = __float_as_int(t);
       scores[v] = __fadd_rn(scores[v], t);
     }
   }
@@ -220,7 +258,7 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   gdn_stats st;
   memset(&st, 0, sizeof(st));
   DevBuf<int32_t> depth, pc;
-  DevBuf<float> delta;
+  DevBuf<bc_i32x4> rec;
   DevBuf<vid_t> order, big_rows;
   DevBuf<unsigned long long> bigitems;
   DevBuf<BcCounters> cnt;
@@ -230,7 +268,7 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   const unsigned rowcap = (unsigned)(g->nnz / BC_BLOCK_ROW + 16);
   GDN_TRY(depth.alloc((size_t)m));
   GDN_TRY(pc.alloc((size_t)m));
-  GDN_TRY(delta.alloc((size_t)m));
+  GDN_TRY(rec.alloc((size_t)m));
   GDN_TRY(order.alloc((size_t)m));
   GDN_TRY(big_rows.alloc(rowcap));
   GDN_TRY(bigitems.alloc(bigcap));
@@ -241,7 +279,6 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   tsolve.start();
   GDN_TRY(gdn_fill_i32(depth.p, -1, (size_t)m, 0));
   GDN_HIP(hipMemsetAsync(pc.p, 0, (size_t)m * 4, 0));
-  GDN_HIP(hipMemsetAsync(delta.p, 0, (size_t)m * 4, 0));
   GDN_HIP(hipMemsetAsync(mx.p, 0, 4, 0));
   hipLaunchKernelGGL(bc_seed_kernel, dim3(1), dim3(64), 0, 0, source, depth.p, pc.p, order.p, cnt.p);
   // forward: level d = order[lp[d] .. lp[d+1])
@@ -279,12 +316,13 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   }
   const int32_t nlev = (int32_t)lp.size() - 2;  // non-empty levels 0 .. nlev-1
   // backward: the deepest level has no successors (its deltas stay 0, like the reference's first sweep)
+  hipLaunchKernelGGL(bc_pack_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, depth.p, pc.p, m, rec.p);
   for (int32_t d = nlev - 2; d >= 0; d--) {
     const unsigned l0 = lp[(size_t)d], nf = lp[(size_t)d + 1] - l0;
     hipLaunchKernelGGL(bc_back_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, order.p + l0, nf,
-                       depth.p, pc.p, delta.p, d_scores, d + 1, big_rows.p, cnt.p, rowcap);
-    hipLaunchKernelGGL(bc_back_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, big_rows.p, cnt.p, depth.p,
-                       pc.p, delta.p, d_scores, d + 1, rowcap);
+                       rec.p, d_scores, d + 1, big_rows.p, cnt.p, rowcap);
+    hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, big_rows.p, cnt.p, rec.p,
+                       d_scores, d + 1, rowcap);
     GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
   }
   hipLaunchKernelGGL(bc_max_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_scores, m, mx.p);
