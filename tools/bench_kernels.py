@@ -163,6 +163,20 @@ def main():
         ncomp = int((comp == torch.arange(m, dtype=torch.int32, device=dev)).sum().item())
         res[f"cc_rmat{args.trav_scale}_{name}"] = {"ms": st.solve_ms, "rounds": st.iterations, "components": ncomp,
                                                     "gteps": nnz / st.solve_ms / 1e6}
+    # BC from one source.  Byte model per reached edge: forward 4 (colidx) + 4 (depth probe) + 8 (path
+    # count read-modify-write), backward 4 (colidx) + 16 (successor record); + 40 B per reached vertex
+    sc = torch.zeros(m, dtype=torch.float32, device=dev)
+    st = _cabi.GdnStats()
+    _cabi.check(L.gdn_bc_dev(go, int(srcs[0]), ptr(sc), C.byref(st)))
+    sc.zero_()
+    st = _cabi.GdnStats()
+    _cabi.check(L.gdn_bc_dev(go, int(srcs[0]), ptr(sc), C.byref(st)))
+    reached_edges = st.edges_traversed // 2
+    bc_bytes = 36 * reached_edges + 40 * int((sc == sc).sum().item())
+    res[f"bc_rmat{args.trav_scale}"] = {"source": int(srcs[0]), "ms": st.solve_ms, "levels": st.iterations,
+                                        "edge_visits": st.edges_traversed, "gteps": st.edges_traversed / st.solve_ms / 1e6,
+                                        "model_GBps": bc_bytes / st.solve_ms / 1e6, "roofline_frac": bc_bytes / st.solve_ms / 1e6 / HBM}
+    del sc
     L.gdn_graph_free(gi)
     L.gdn_graph_free(go)
     del comp, dist, deg
