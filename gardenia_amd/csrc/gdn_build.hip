@@ -931,7 +931,7 @@ uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full) {
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
              int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta,
-             const uint8_t *dst_class, int want_dst, bool rows_of_class_only, bool no_gaps) {
+             const uint8_t *dst_class, int want_dst, bool rows_of_class_only, bool no_gaps, int bin_balance_log) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
   GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
   GDN_REQUIRE(!(src_class && rows_are_sources), "source classes: in-CSR only");
@@ -1003,7 +1003,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       // time of 7.  Spread the active vertices over rounds * CUs slices instead (fewer than 2^log slots used per
       // slice; the compact index keeps its power-of-two slice stride so every shift below stays valid).
       const uint64_t per_c = pb_slots_per_slice(n_src, log_chunk, PB_MAX_LOG_CHUNK);
-      const uint64_t per_b = pb_slots_per_slice(n_dst, log_bin, PB_MAX_LOG_BIN);
+      const uint64_t per_b = pb_slots_per_slice(n_dst, log_bin, bin_balance_log);
       p.chunk_slots = (unsigned)per_c;
       if (per_c < (1ull << log_chunk)) {
         hipLaunchKernelGGL(pb_respace_kernel, dim3(gdn_nblocks((uint64_t)m_global + 1)), dim3(GDN_BLOCK), 0, 0, cs.p,

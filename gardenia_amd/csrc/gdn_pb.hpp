@@ -103,8 +103,9 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              const uint8_t *dst_class = nullptr,  // per row: only edges whose row has class `want_dst` are laid out
              int want_dst = 0,
              bool rows_of_class_only = false,     // the row slices hold the rows of that class only (hub-row layout)
-             bool no_gaps = false);               // slice starts padded to `pad` only: with ONE bin (or chunk) U and V
+             bool no_gaps = false,                // slice starts padded to `pad` only: with ONE bin (or chunk) U and V
                                                   // then sit at the same positions
+             int bin_balance_log = PB_MAX_LOG_BIN);  // bins of this size are spread over whole rounds of workgroups
 
 // Hub tier (gdn_pr.hip, gdn_spmv.hip): the edges of the <= 2^15 sources with the most out-edges live in a second layout
 // (one source chunk, tiles sorted by hub) that phase B reads directly; their source values come from a
