@@ -55,6 +55,9 @@ PROTOTYPES = {
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
     "gdn_bc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, _vp, C.POINTER(GdnStats)]),
     "gdn_bc_dev": (C.c_int, [_vp, _i32, _vp, C.POINTER(GdnStats)]),
+    "gdn_bc_plan_create": (C.c_int, [_vp, _vp, _pp]),
+    "gdn_bc_run": (C.c_int, [_vp, _i32, _vp, C.POINTER(GdnStats)]),
+    "gdn_bc_plan_free": (C.c_int, [_vp]),
     "gdn_cc": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_dev_alloc": (C.c_int, [_u64, _pp]),
     "gdn_dev_free": (C.c_int, [_vp]),

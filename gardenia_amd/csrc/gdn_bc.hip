@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "gdn_expand.hpp"
+#include "gdn_pb.hpp"
 
 #define BC_WAVE_ROW 32     // rows at least this long: whole wave
 #define BC_BLOCK_ROW 4096  // rows at least this long: one workgroup each (second launch)
@@ -249,7 +250,516 @@ bc_normalize_kernel(float *__restrict__ scores, int32_t m, const unsigned *__res
 
 int gdn_reached_edges(const gdn_graph *g, const int32_t *d_dist, int32_t unreached, uint64_t *out);
 
+extern "C" int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *stats);
+
+// ------------------------------------------------------------------------------------------
+// Resident plan (gdn_bc_plan_*): depths from the BFS plan (direction-optimising + dense sweeps, gdn_bfs.hip), and the
+// two HEAVY levels of an R-MAT-like graph -- 1.5 G random atomics forward, 1.5 G record gathers backward in the path
+// above -- as PROPAGATION-BLOCKED sweeps on the PageRank layout machinery (gdn_pb.hpp):
+//   forward  level d -> d+1: pc[v] = SUM over in-neighbours u at depth d of pc[u]   (in-CSR layout, RAW 32-bit values,
+//            integer LDS accumulation: the low 32 bits of the sum = the reference's wrapping int arithmetic, exact)
+//   backward level d: delta[u] = pc[u] * SUM over out-neighbours v at depth d+1 of (1 + delta[v]) / pc[v]
+//            (out-CSR layout; the values are scaled by a power of two into [0, 2^-21] so that a row sum stays below 1,
+//            encoded like PageRank's contributions and accumulated in 2^-62 fixed point: deterministic, but rounded
+//            differently from the reference's sequential fp32 sum -- inside its verifier's tolerance, not bit-equal)
+// Light levels run vertex-parallel over all vertices with a depth filter (no per-level queues are kept).
+// ------------------------------------------------------------------------------------------
+#define BC_MAX_LEVELS 64
+
+struct BcPcOp {  // epilogue of the forward sweep: rows at depth next_level take the summed path count
+  const int32_t *__restrict__ depth;
+  int32_t *__restrict__ pc;
+  int32_t next_level;
+  bool vec_ok;
+  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &) const { return (unsigned long long)__float_as_uint(v); }
+  __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &) const { return __uint_as_float((unsigned)a); }
+  struct Pre {
+    int32_t d;
+  };
+  __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{depth[row]}; }
+  __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
+    if (p.d == next_level) pc[row] = (int32_t)__float_as_uint(sum);
+    return 0.0;
+  }
+  struct Pre4 {
+    int32_t d;
+  };
+  __device__ __forceinline__ Pre4 pre4(int32_t) const { return Pre4{0}; }
+  __device__ __forceinline__ double fin4(int32_t, const float (&)[4], const Pre4 &) const { return 0.0; }
+};
+
+struct BcBackOp {  // epilogue of the backward sweep: rows at depth `level` get delta = pc * sum * unscale
+  bc_i32x4 *__restrict__ rec;
+  float *__restrict__ scores;
+  int32_t level;
+  float unscale;
+  bool vec_ok;
+  __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &) const { return pb_decode(__float_as_uint(v)); }
+  __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &bad) const {
+    if (a >> 63) bad = 1u;
+    return ldexpf((float)a, -PB_FIX_SHIFT);
+  }
+  struct Pre {
+    bc_i32x4 r;
+  };
+  __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{rec[row]}; }
+  __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
+    if (p.r.x == level) {
+      const float dl = __fmul_rn((float)p.r.y, __fmul_rn(sum, unscale));
+      rec[row].z = __float_as_int(dl);
+      scores[row] = __fadd_rn(scores[row], dl);
+    }
+    return 0.0;
+  }
+  struct Pre4 {
+    int32_t d;
+  };
+  __device__ __forceinline__ Pre4 pre4(int32_t) const { return Pre4{0}; }
+  __device__ __forceinline__ double fin4(int32_t, const float (&)[4], const Pre4 &) const { return 0.0; }
+};
+
+struct BcLevelStats {
+  unsigned long long edges[BC_MAX_LEVELS];  // out-edges of the vertices of a level
+  unsigned long long count[BC_MAX_LEVELS];
+  unsigned deep;                            // a vertex at depth >= BC_MAX_LEVELS exists
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_level_stats_kernel(const int32_t *__restrict__ depth, const eoff_t *__restrict__ rowptr, int32_t m, int32_t unreached,
+                      BcLevelStats *__restrict__ out) {
+  __shared__ unsigned long long s_e[BC_MAX_LEVELS], s_c[BC_MAX_LEVELS];
+  if (threadIdx.x < BC_MAX_LEVELS) s_e[threadIdx.x] = s_c[threadIdx.x] = 0ull;
+  __syncthreads();
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK) {
+    const int32_t d = depth[v];
+    if (d == unreached) continue;
+    if (d >= BC_MAX_LEVELS) {
+      out->deep = 1u;
+      continue;
+    }
+    atomicAdd(&s_e[d], rowptr[v + 1] - rowptr[v]);
+    atomicAdd(&s_c[d], 1ull);
+  }
+  __syncthreads();
+  if (threadIdx.x < BC_MAX_LEVELS && s_c[threadIdx.x]) {
+    atomicAdd(&out->edges[threadIdx.x], s_e[threadIdx.x]);
+    atomicAdd(&out->count[threadIdx.x], s_c[threadIdx.x]);
+  }
+}
+
+// light forward level: every vertex at depth `level` pushes its path count along its out-edges to the vertices one deeper
+struct BcPushVis {
+  const vid_t *__restrict__ colidx;
+  const int32_t *__restrict__ depth;
+  int32_t *__restrict__ pc;
+  int32_t next_level;
+  int32_t pc_src;
+  int big;
+  __device__ __forceinline__ void begin_big(vid_t v) {
+    big = 1;
+    pc_src = pc[v];
+  }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t ps = big ? pc_src : __shfl(pc_src, owner, 64);
+    if (valid) {
+      const vid_t dst = __builtin_nontemporal_load(colidx + k);
+      if (depth[dst] == next_level) atomicAdd(&pc[dst], ps);
+    }
+  }
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_push_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int32_t level, ExpBigList big, BcPushVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.pc_src = 0;
+  vis.big = 0;
+  if (v < (unsigned)m && vis.depth[v] == level) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+    vis.pc_src = vis.pc[v];
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_push_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BcPushVis vis) {
+  vis.big = 1;
+  vis.pc_src = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
+// x of the forward sweep: the path count (raw bits) of the vertices at depth `level`, 0 elsewhere
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_x_fwd_kernel(const int32_t *__restrict__ depth, const int32_t *__restrict__ pc, int32_t m, int32_t level, float *__restrict__ x) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (size_t)m) x[v] = depth[v] == level ? __int_as_float(pc[v]) : 0.0f;
+}
+
+// backward sweep: w[v] = (1 + delta[v]) / pc[v] of the vertices at depth next_level; first its maximum, then x = w * scale
+__device__ __forceinline__ float bc_w(const bc_i32x4 r) { return __fdiv_rn(__fadd_rn(1.0f, __int_as_float(r.z)), (float)r.y); }
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_w_max_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level, unsigned *__restrict__ out) {
+  float mx = 0.0f;
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK) {
+    const bc_i32x4 r = rec[v];
+    if (r.x == next_level) {
+      const float w = bc_w(r);
+      if (w > mx && w < 3.0e38f) mx = w;  // inf / nan (a wrapped path count of 0) do not take part in the sweep
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  if (gdn_lane() == 0 && mx > 0.0f) atomicMax(out, __float_as_uint(mx));
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_x_back_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level, float scale, float *__restrict__ x,
+                 unsigned *__restrict__ odd) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v >= (size_t)m) return;
+  const bc_i32x4 r = rec[v];
+  float xv = 0.0f;
+  if (r.x == next_level) {
+    const float w = bc_w(r);
+    if (w >= 0.0f && w < 3.0e38f) xv = __fmul_rn(w, scale);
+    else *odd = 1u;  // a non-finite term: this level falls back to the gather path (same arithmetic as the reference)
+  }
+  x[v] = xv;
+}
+
+// light backward level, vertex-parallel: the rows at depth `level` (see bc_back_kernel for the row classes)
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int32_t level,
+                   bc_i32x4 *__restrict__ rec, float *__restrict__ scores, vid_t *__restrict__ big_rows, BcCounters *cnt,
+                   unsigned cap) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned lane = gdn_lane();
+  const int32_t next_level = level + 1;
+  eoff_t b = 0, e = 0;
+  float pcs = 0.0f;
+  bool mine = false;
+  if (i < (unsigned)m) {
+    const bc_i32x4 r = rec[i];
+    if (r.x == level) {
+      mine = true;
+      b = rowptr[i];
+      e = rowptr[i + 1];
+      pcs = (float)r.y;
+    }
+  }
+  const vid_t v = (vid_t)i;
+  const eoff_t deg = e - b;
+  float acc = 0.0f;
+  const bool is_big = deg >= BC_BLOCK_ROW;
+  gdn_wl_push(big_rows, &cnt->big_count, cap, is_big, v, &cnt->overflow);
+  unsigned long long mask = __ballot(deg >= BC_WAVE_ROW && !is_big);
+  while (mask) {
+    const int leader = __ffsll((long long)mask) - 1;
+    mask &= mask - 1ull;
+    const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
+    const float ps = __shfl(pcs, leader, 64);
+    float part = 0.0f;
+    for (eoff_t k0 = bb + lane; k0 < ee; k0 += 64 * BC_UNR) {
+      vid_t dst[BC_UNR];
+      float t[BC_UNR];
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + 64 * r < ee ? colidx[k0 + 64 * r] : -1;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
+    if ((int)lane == leader) acc = part;
+  }
+  if (mine && deg < BC_WAVE_ROW) {
+    for (eoff_t k0 = b; k0 < e; k0 += BC_UNR) {
+      vid_t dst[BC_UNR];
+      float t[BC_UNR];
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + r < e ? colidx[k0 + r] : -1;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
+#pragma unroll
+      for (int r = 0; r < BC_UNR; r++) acc = __fadd_rn(acc, t[r]);
+    }
+  }
+  if (mine && !is_big) {
+    rec[v].z = __float_as_int(acc);
+    scores[v] = __fadd_rn(scores[v], acc);
+  }
+}
+
+struct gdn_bc_plan {
+  const gdn_graph *g = nullptr;
+  gdn_graph *gin_own = nullptr;  // transposed here when the caller has no in-CSR
+  const gdn_graph *gin = nullptr;
+  gdn_bfs_plan *bfs = nullptr;
+  PbPlan fwd, back;              // layouts of the in-CSR / the out-CSR
+  DevBuf<int32_t> depth, pc;
+  DevBuf<bc_i32x4> rec;
+  DevBuf<float> x;
+  DevBuf<vid_t> big_rows;
+  DevBuf<unsigned long long> bigitems;
+  DevBuf<BcCounters> cnt;
+  DevBuf<BcLevelStats> lstats;
+  DevBuf<unsigned> mx;  // [0] max bits, [1] odd flag
+  unsigned bigcap = 0, rowcap = 0;
+  uint64_t max_deg = 1;
+  double prep_ms = 0;
+  ~gdn_bc_plan() {
+    if (bfs) gdn_bfs_plan_free(bfs);
+    if (gin_own) gdn_graph_free(gin_own);
+  }
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_maxdeg_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ out) {
+  unsigned long long mx = 0;
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const unsigned long long d = rowptr[i + 1] - rowptr[i];
+    mx = d > mx ? d : mx;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if (gdn_lane() == 0 && mx) atomicMax(out, mx);
+}
+
+static int bc_pb_sweep_fwd(gdn_bc_plan &p, int32_t level) {
+  PbPlan &pb = p.fwd;
+  const int32_t m = p.g->m;
+  hipLaunchKernelGGL(bc_x_fwd_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, p.depth.p, p.pc.p, m, level, p.x.p);
+  const size_t lds_a = sizeof(float) * (pb.chunk_slots + 4);
+  const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
+  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
+                     pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p, pb.src_bits.p, pb.chunk_lo.p, 1u, pb.log_group, /*raw*/ 8,
+                     nullptr, nullptr, nullptr, 0u, nullptr, pb.errflag.p, pb.chunk_slots);
+  BcPcOp op;
+  op.depth = p.depth.p;
+  op.pc = p.pc.p;
+  op.next_level = level + 1;
+  op.vec_ok = false;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<BcPcOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, 0, pb.m_local,
+                     pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, pb.dst_bits.p,
+                     pb.bin_lo.p, op);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
+// returns GDN_OK and *done = false when the level holds a non-finite term (the caller takes the gather path)
+static int bc_pb_sweep_back(gdn_bc_plan &p, int32_t level, float *d_scores, bool *done) {
+  PbPlan &pb = p.back;
+  const int32_t m = p.g->m;
+  *done = false;
+  GDN_HIP(hipMemsetAsync(p.mx.p, 0, 8, 0));
+  hipLaunchKernelGGL(bc_w_max_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p.rec.p, m, level + 1, p.mx.p);
+  unsigned h[2];
+  GDN_HIP(hipMemcpy(h, p.mx.p, 8, hipMemcpyDeviceToHost));
+  float wmax;
+  memcpy(&wmax, &h[0], 4);
+  if (!(wmax > 0.0f)) {  // no successor carries anything: every delta of the level is 0
+    *done = true;
+    return GDN_OK;
+  }
+  // scale = 2^-k with wmax * max_deg * 2^-k < 1: a row sum stays inside the unsigned 2^-62 fixed point
+  int e1 = 0, e2 = 0;
+  (void)frexpf(wmax, &e1);                 // wmax < 2^e1
+  (void)frexp((double)p.max_deg, &e2);     // max_deg < 2^e2
+  const int k = e1 + e2;
+  const float scale = ldexpf(1.0f, -k), unscale = ldexpf(1.0f, k);
+  hipLaunchKernelGGL(bc_x_back_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, p.rec.p, m, level + 1, scale, p.x.p,
+                     p.mx.p + 1);
+  GDN_HIP(hipMemcpy(h, p.mx.p, 8, hipMemcpyDeviceToHost));
+  if (h[1]) return GDN_OK;  // inf / nan among the terms: not for the fixed-point sweep
+  const size_t lds_a = sizeof(float) * (pb.chunk_slots + 4);
+  const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
+  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
+                     pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p, pb.src_bits.p, pb.chunk_lo.p, 1u, pb.log_group, 0, nullptr,
+                     nullptr, nullptr, 0u, nullptr, pb.errflag.p, pb.chunk_slots);
+  BcBackOp op;
+  op.rec = p.rec.p;
+  op.scores = d_scores;
+  op.level = level;
+  op.unscale = unscale;
+  op.vec_ok = false;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<BcBackOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, 0, pb.m_local,
+                     pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, pb.dst_bits.p,
+                     pb.bin_lo.p, op);
+  GDN_HIP(hipGetLastError());
+  *done = true;
+  return GDN_OK;
+}
+
 extern "C" {
+
+int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **plan) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  *plan = nullptr;
+  GDN_REQUIRE(g != nullptr, "graph");
+  GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
+  HostTimer t;
+  t.start();
+  gdn_bc_plan *p = new gdn_bc_plan();
+  p->g = g;
+  int st = GDN_OK;
+  do {
+    if (!gin) {
+      if ((st = gdn_graph_transpose(g, &p->gin_own))) break;
+      gin = p->gin_own;
+    }
+    p->gin = gin;
+    const int32_t m = g->m;
+    if ((st = gdn_bfs_plan_create(g, gin, 1, &p->bfs))) break;
+    int lc = 10, lb = 10;
+    while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 10)) < (int64_t)m) lc++;
+    while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 10)) < (int64_t)m) lb++;
+    // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
+    if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5))) break;
+    if ((st = pb_build(g, m, lc, lb, p->back, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5))) break;
+    const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+    p->bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+    p->rowcap = (unsigned)(g->nnz / BC_BLOCK_ROW + 16);
+    if ((st = p->depth.alloc((size_t)m)) || (st = p->pc.alloc((size_t)m)) || (st = p->rec.alloc((size_t)m)) ||
+        (st = p->x.alloc((size_t)m + 4)) || (st = p->big_rows.alloc(p->rowcap)) || (st = p->bigitems.alloc(p->bigcap)) ||
+        (st = p->cnt.alloc(1)) || (st = p->lstats.alloc(1)) || (st = p->mx.alloc(2)))
+      break;
+    DevBuf<unsigned long long> md;
+    if ((st = md.alloc(1))) break;
+    (void)hipMemset(md.p, 0, 8);
+    hipLaunchKernelGGL(bc_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, md.p);
+    unsigned long long h_md = 1;
+    if (hipMemcpy(&h_md, md.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      gdn_set_error("gdn_bc_plan_create: max degree readback failed");
+      st = GDN_ERR_HIP;
+      break;
+    }
+    p->max_deg = h_md ? h_md : 1;
+    const int lds_a = (int)(sizeof(float) * ((p->fwd.chunk_slots > p->back.chunk_slots ? p->fwd.chunk_slots : p->back.chunk_slots) + 4));
+    const int lds_b = (int)(sizeof(unsigned long long) << lb);
+    hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<BcPcOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<BcBackOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
+    if (e != hipSuccess) {
+      gdn_set_error("gdn_bc_plan_create: hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+      st = GDN_ERR_HIP;
+      break;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) {
+      gdn_set_error("gdn_bc_plan_create: %s", hipGetErrorString(hipGetLastError()));
+      st = GDN_ERR_HIP;
+    }
+  } while (0);
+  if (st != GDN_OK) {
+    delete p;
+    return st;
+  }
+  p->prep_ms = t.stop_ms();
+  *plan = p;
+  return GDN_OK;
+}
+
+int gdn_bc_plan_free(gdn_bc_plan *plan) {
+  delete plan;
+  return GDN_OK;
+}
+
+int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *stats) {
+  GDN_REQUIRE(plan != nullptr && d_scores != nullptr, "plan / d_scores");
+  gdn_bc_plan &p = *plan;
+  const gdn_graph *g = p.g;
+  const int32_t m = g->m;
+  GDN_REQUIRE(source >= 0 && source < m, "source out of range");
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  st.prep_ms = p.prep_ms;
+  HostTimer tsolve;
+  tsolve.start();
+  // depths: the BFS plan (unreached = MYINFINITY = 1e9, which no level equals)
+  gdn_stats bst;
+  GDN_TRY(gdn_bfs_run(p.bfs, source, p.depth.p, &bst));
+  GDN_HIP(hipMemsetAsync(p.lstats.p, 0, sizeof(BcLevelStats), 0));
+  hipLaunchKernelGGL(bc_level_stats_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p.depth.p, g->rowptr, m, (int32_t)1000000000, p.lstats.p);
+  BcLevelStats ls;
+  GDN_HIP(hipMemcpy(&ls, p.lstats.p, sizeof(ls), hipMemcpyDeviceToHost));
+  if (ls.deep) {  // a deep, thin graph: nothing is heavy there -- the queue-based path
+    return gdn_bc_dev(g, source, d_scores, stats);
+  }
+  int32_t nlev = 0;
+  for (int d = 0; d < BC_MAX_LEVELS; d++)
+    if (ls.count[d]) nlev = d + 1;
+  const uint64_t heavy = g->nnz / 16 + 1;
+  GDN_HIP(hipMemsetAsync(p.pc.p, 0, (size_t)m * 4, 0));
+  GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BcCounters), 0));
+  GDN_HIP(hipMemsetAsync(p.mx.p, 0, 8, 0));
+  {
+    const int32_t one = 1;
+    GDN_HIP(hipMemcpyAsync(p.pc.p + source, &one, 4, hipMemcpyHostToDevice, 0));
+  }
+  ExpBigList big;
+  big.items = p.bigitems.p;
+  big.capacity = p.bigcap;
+  big.count = &p.cnt.p->big_count;
+  big.overflow = &p.cnt.p->overflow;
+  // ---- forward: path counts level by level
+  for (int32_t d = 0; d + 1 < nlev; d++) {
+    if (ls.edges[d] >= heavy) {
+      GDN_TRY(bc_pb_sweep_fwd(p, d));
+    } else {
+      BcPushVis vis;
+      vis.colidx = g->colidx;
+      vis.depth = p.depth.p;
+      vis.pc = p.pc.p;
+      vis.next_level = d + 1;
+      vis.pc_src = 0;
+      vis.big = 0;
+      hipLaunchKernelGGL(bc_push_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, d, big, vis);
+      hipLaunchKernelGGL(bc_push_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+      GDN_HIP(hipMemsetAsync(&p.cnt.p->big_count, 0, sizeof(unsigned), 0));
+    }
+  }
+  // ---- backward
+  hipLaunchKernelGGL(bc_pack_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, p.depth.p, p.pc.p, m, p.rec.p);
+  for (int32_t d = nlev - 2; d >= 0; d--) {
+    bool done = false;
+    if (ls.edges[d] >= heavy) GDN_TRY(bc_pb_sweep_back(p, d, d_scores, &done));
+    if (!done) {
+      hipLaunchKernelGGL(bc_back_all_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, m, d,
+                         p.rec.p, d_scores, p.big_rows.p, p.cnt.p, p.rowcap);
+      hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, p.big_rows.p, p.cnt.p,
+                         p.rec.p, d_scores, d + 1, p.rowcap);
+      GDN_HIP(hipMemsetAsync(&p.cnt.p->big_count, 0, sizeof(unsigned), 0));
+    }
+  }
+  GDN_HIP(hipMemsetAsync(p.mx.p, 0, 4, 0));
+  hipLaunchKernelGGL(bc_max_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_scores, m, p.mx.p);
+  hipLaunchKernelGGL(bc_normalize_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, d_scores, m, p.mx.p);
+  GDN_HIP(hipGetLastError());
+  BcCounters h;
+  GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+  unsigned ef[2] = {0, 0};
+  GDN_HIP(hipMemcpy(&ef[0], p.fwd.errflag.p, 4, hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&ef[1], p.back.errflag.p, 4, hipMemcpyDeviceToHost));
+  if (h.overflow || ef[0] || ef[1]) {
+    gdn_set_error("gdn_bc_run: %s", h.overflow ? "device worklist overflow" : "a term left the fixed-point range of the blocked sweep");
+    return GDN_ERR_OVERFLOW;
+  }
+  st.solve_ms = tsolve.stop_ms();
+  st.iterations = nlev;
+  uint64_t te = 0;
+  for (int d = 0; d < nlev; d++) te += ls.edges[d];
+  st.edges_traversed = 2 * te;
+  if (stats) *stats = st;
+  return GDN_OK;
+}
 
 int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *stats) {
   GDN_REQUIRE(g != nullptr && d_scores != nullptr, "graph / d_scores");

@@ -509,7 +509,7 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
   // the slice becomes fixed-point codes (pb_encode): the float -> fixed conversion is paid per source here, not per
   // edge in phase B; the code of 0.0 is 0, so the zero slot and the bits that travel through vals stay what they were
   __syncthreads();
-  {
+  if (!(nt_store & 8)) {  // bit 3: RAW slice -- the 32-bit words of x travel as they are (integer sweeps, gdn_bc.hip)
     unsigned bad_a = 0u;
     uint32_t *s_u = reinterpret_cast<uint32_t *>(s_x);
     for (unsigned i = threadIdx.x; i < n_slots; i += PB_THREADS) s_u[i] = pb_encode(s_x[i], bad_a);

@@ -209,6 +209,39 @@ class ResidentSpMV:
         self.L.gdn_graph_free(self.h)
 
 
+class ResidentBC:
+    """Betweenness centrality from many sources on one resident graph (gdn_bc_plan_*: BFS plan + propagation-blocked
+    heavy levels)."""
+
+    def __init__(self, g: Graph, with_reverse: bool = True):
+        L = _cabi.lib()
+        self.L, self.m = L, g.V()
+        self.h, self.hi, self.plan = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        rp, ci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(rp), _p(ci), C.byref(self.h)))
+        if with_reverse:
+            irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+            _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.hi)))
+        _cabi.check(L.gdn_bc_plan_create(self.h, self.hi if with_reverse else None, C.byref(self.plan)))
+        self.d_scores = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(4 * self.m, C.byref(self.d_scores)))
+
+    def run(self, source: int, scores: np.ndarray) -> dict:
+        assert scores.dtype == np.float32 and scores.flags.c_contiguous
+        _cabi.check(self.L.gdn_dev_upload(self.d_scores, _p(scores), 4 * self.m))
+        st = _cabi.GdnStats()
+        _cabi.check(self.L.gdn_bc_run(self.plan, int(source), self.d_scores, C.byref(st)))
+        _cabi.check(self.L.gdn_dev_download(_p(scores), self.d_scores, 4 * self.m))
+        return st.as_dict()
+
+    def close(self):
+        self.L.gdn_bc_plan_free(self.plan)
+        self.L.gdn_dev_free(self.d_scores)
+        if self.hi:
+            self.L.gdn_graph_free(self.hi)
+        self.L.gdn_graph_free(self.h)
+
+
 class ResidentPageRankShards:
     """The sharded PageRank data path of gardenia_amd.sharded on ONE device: `world` vertex-range
     shards of the same graph, each with its own plan (row_base, m_local < m_global), the all-gather

@@ -273,6 +273,14 @@ int gdn_bfs_dev(const gdn_graph *out_csr, const gdn_graph *in_csr /*nullable*/, 
                 int32_t *d_dist, gdn_stats *stats);
 /* resident graph, device score vector (in/out) */
 int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *stats);
+/* Resident plan for many sources on one graph: depths from the BFS plan, and the heavy levels of both phases as
+ * propagation-blocked sweeps (forward: exact integer path counts on a layout of the in-CSR; backward: the dependencies in
+ * 2^-62 fixed point on a layout of the out-CSR -- deterministic, inside the reference verifier's tolerance, not bit-equal to
+ * its sequential fp32 sums on those levels).  gin: the in-CSR (nullable: transposed here).  d_scores in/out like gdn_bc_dev. */
+typedef struct gdn_bc_plan gdn_bc_plan;
+int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **plan);
+int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *stats);
+int gdn_bc_plan_free(gdn_bc_plan *plan);
 /* Reusable BFS state for many searches on one resident graph.  dense != 0 (needs in_csr) also
  * builds the propagation-blocked layout of the in-CSR once, so that heavy levels run as one
  * streaming sweep over all in-edges instead of a bottom-up step (built outside the timed search,

@@ -926,3 +926,30 @@ def test_bc_accumulates_into_scores_and_handles_hubs(orc):
     sc = np.zeros(5, np.float32)
     solvers.BCSolver(solvers.Graph(csr=g2), 0, sc)
     assert np.isnan(sc).all() and np.isnan(orc.bc(g2, 0)[0]).all()
+
+
+@pytest.mark.parametrize("scale,ef,seed,sym,with_reverse", [(16, 16, 2, False, True), (15, 8, 3, True, False), (18, 16, 4, False, True)])
+def test_bc_plan_vs_oracle_rmat(orc, scale, ef, seed, sym, with_reverse):
+    """gdn_bc_plan_*: depths from the BFS plan, heavy levels as propagation-blocked sweeps (on R-MAT graphs of this size
+    the levels 2..3 are heavy: more than 1/16 of the edges).  Against the oracle within the reference verifier's
+    tolerance, several sources on one plan, the same level count, NaN-free where the oracle is."""
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    if sym:
+        g = graphio.symmetrize(g)
+    G = solvers.Graph(csr=g, in_csr=g if sym else graphio.transpose(g))
+    bc = solvers.ResidentBC(G, with_reverse=with_reverse)
+    deg = g.degrees()
+    sources = [graphio.first_nonisolated(g), int(np.argmax(deg)), int(np.flatnonzero(deg > 0)[-1])]
+    for s in sources:
+        want, levels, depths, pcs = orc.bc(g, s)
+        scores = np.zeros(g.m, np.float32)
+        st = bc.run(s, scores)
+        assert st["iterations"] == levels
+        _bc_close(scores, want)
+        assert orc.bc_verify(g, s, scores)
+        assert st["edges_traversed"] == 2 * int(deg[depths >= 0].astype(np.int64).sum())
+    # the queue-based path and the plan agree within the same tolerance
+    scores2 = np.zeros(g.m, np.float32)
+    solvers.BCSolver(solvers.Graph(csr=g), sources[-1], scores2)
+    _bc_close(scores, scores2)
+    bc.close()

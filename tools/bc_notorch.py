@@ -24,9 +24,19 @@ sources = np.nonzero(hdeg > 0)[0][:3].tolist()
 scores = C.c_void_p()
 _cabi.check(L.gdn_dev_alloc(4 * m, C.byref(scores)))
 zero = np.zeros(m, np.float32)
+use_plan = len(sys.argv) > 2 and sys.argv[2] == "plan"
+plan = C.c_void_p()
+if use_plan:
+    _cabi.check(L.gdn_bc_plan_create(go, None, C.byref(plan)))
+out = np.empty(m, np.float32)
 for s in sources + sources[:1]:
     _cabi.check(L.gdn_dev_upload(scores, zero.ctypes.data_as(C.c_void_p), 4 * m))
     st = _cabi.GdnStats()
-    _cabi.check(L.gdn_bc_dev(go, int(s), scores, C.byref(st)))
-    print("BC RMAT-%d from %d: %.3f ms, %d levels, %d edge visits, %.1f GTEPS" % (
-        scale, s, st.solve_ms, st.iterations, st.edges_traversed, st.edges_traversed / st.solve_ms / 1e6), flush=True)
+    if use_plan:
+        _cabi.check(L.gdn_bc_run(plan, int(s), scores, C.byref(st)))
+    else:
+        _cabi.check(L.gdn_bc_dev(go, int(s), scores, C.byref(st)))
+    _cabi.check(L.gdn_dev_download(out.ctypes.data_as(C.c_void_p), scores, 4 * m))
+    print("BC%s RMAT-%d from %d: %.3f ms, %d levels, %d edge visits, %.1f GTEPS (prep %.0f ms; sum of scores %.6f)" % (
+        " plan" if use_plan else "", scale, s, st.solve_ms, st.iterations, st.edges_traversed,
+        st.edges_traversed / st.solve_ms / 1e6, st.prep_ms, float(out.astype(np.float64).sum())), flush=True)

@@ -176,6 +176,18 @@ def main():
     res[f"bc_rmat{args.trav_scale}"] = {"source": int(srcs[0]), "ms": st.solve_ms, "levels": st.iterations,
                                         "edge_visits": st.edges_traversed, "gteps": st.edges_traversed / st.solve_ms / 1e6,
                                         "model_GBps": bc_bytes / st.solve_ms / 1e6, "roofline_frac": bc_bytes / st.solve_ms / 1e6 / HBM}
+    # the resident plan: BFS plan for the depths, heavy levels as propagation-blocked sweeps
+    bplan = C.c_void_p()
+    _cabi.check(L.gdn_bc_plan_create(go, gi, C.byref(bplan)))
+    for _ in range(2):
+        sc.zero_()
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_bc_run(bplan, int(srcs[0]), ptr(sc), C.byref(st)))
+    res[f"bc_rmat{args.trav_scale}_plan"] = {"source": int(srcs[0]), "ms": st.solve_ms, "levels": st.iterations,
+                                             "edge_visits": st.edges_traversed, "gteps": st.edges_traversed / st.solve_ms / 1e6,
+                                             "prep_ms": st.prep_ms, "model_GBps": bc_bytes / st.solve_ms / 1e6,
+                                             "roofline_frac": bc_bytes / st.solve_ms / 1e6 / HBM}
+    L.gdn_bc_plan_free(bplan)
     del sc
     L.gdn_graph_free(gi)
     L.gdn_graph_free(go)
