@@ -8,6 +8,8 @@ properties -- the oracle cannot run at this size inside a test:
             edge (u,v) with u reached has depth[v] <= depth[u]+1; every reached v != source has
             depth >= 1; TEPS numerator = sum of out-degrees of the reached vertices
   SSSP      unit weights: distances == BFS depths (R-MAT scale 25)
+  BC        the resident plan (BFS depths + propagation-blocked heavy levels) and the queue-based path agree within the
+            reference verifier's tolerance on R-MAT scale 27; the largest score is 1, unreached vertices score 0
   graph     the device generator's CSR has ascending, duplicate-free, self-loop-free rows
 
 Needs ~120 GB of HBM; everything stays on the device (torch is only used for the checks)."""
@@ -148,3 +150,25 @@ def test_sssp_unit_weights_equal_bfs_depths():
     assert bool((dist == depth).all())
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
+
+
+def test_bc_plan_equals_queue_path_at_full_size(big):
+    """Two independent formulations (atomics + record gathers vs BFS-plan depths + propagation-blocked sweeps) of the
+    same Brandes pass on 2.1 G edges: |a - b| <= 1e-4 (|a| + |b|) + 1e-4 for every vertex (src/bc/verifier.cc:22-30)."""
+    torch, L, cabi = big["torch"], big["L"], big["cabi"]
+    m, dev = big["m"], big["dev"]
+    source = int(torch.nonzero(big["deg"][:1 << 16] > 0)[0].item())
+    a = torch.zeros(m, dtype=torch.float32, device=dev)
+    b = torch.zeros(m, dtype=torch.float32, device=dev)
+    st_a, st_b = cabi.GdnStats(), cabi.GdnStats()
+    cabi.check(L.gdn_bc_dev(big["go"], source, C.c_void_p(a.data_ptr()), C.byref(st_a)))
+    plan = C.c_void_p()
+    cabi.check(L.gdn_bc_plan_create(big["go"], big["gi"], C.byref(plan)))
+    cabi.check(L.gdn_bc_run(plan, source, C.c_void_p(b.data_ptr()), C.byref(st_b)))
+    L.gdn_bc_plan_free(plan)
+    assert st_a.iterations == st_b.iterations and st_a.edges_traversed == st_b.edges_traversed
+    assert bool(torch.isfinite(a).all()) and bool(torch.isfinite(b).all())
+    ad, bd = a.double(), b.double()
+    assert bool(((ad - bd).abs() <= 1e-4 * (ad.abs() + bd.abs()) + 1e-4).all())
+    assert float(a.max()) == 1.0 and float(b.max()) == 1.0
+    assert float(a.min()) >= 0.0 and float(b.min()) >= 0.0
