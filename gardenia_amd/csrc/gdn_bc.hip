@@ -621,8 +621,13 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 10)) < (int64_t)m) lc++;
     while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 10)) < (int64_t)m) lb++;
     // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
-    if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5))) break;
-    if ((st = pb_build(g, m, lc, lb, p->back, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5))) break;
+    PbScratch scratch;
+    if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
+                       0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch)))
+      break;
+    if ((st = pb_build(g, m, lc, lb, p->back, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
+                       0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch)))
+      break;
     const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     p->bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
     p->rowcap = (unsigned)(g->nnz / BC_BLOCK_ROW + 16);

@@ -11,6 +11,7 @@
 //   gdn_graph_transpose: reverse graph (csr_graph.h:170-194), rows ascending.
 // The reference builds both serially with vector<vector<int>> and an O(deg^2) erase loop.
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string.h>
 #include <stdlib.h>
@@ -126,7 +127,7 @@ static int bits_for(int32_t m) {
 
 // radix sort of the low `bits` bits; returns the buffer holding the result and frees the other
 static int sort_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n,
-                     unsigned bits, const unsigned long long **sorted_out) {
+                     unsigned bits, const unsigned long long **sorted_out, bool keep_both = false) {
   rocprim::double_buffer<unsigned long long> db(ka.p, kb.p);
   size_t tmp_bytes = 0;
   if (bits > 64) bits = 64;
@@ -146,9 +147,11 @@ static int sort_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> 
     }
   }
   const unsigned long long *sorted = db.current();
-  // free the non-current key buffer early: what follows needs the room at scale 27
-  if (sorted == ka.p) kb.release();
-  else ka.release();
+  // free the non-current key buffer early (unless the buffers are a plan's scratch, reused by its next build)
+  if (!keep_both) {
+    if (sorted == ka.p) kb.release();
+    else ka.release();
+  }
   *sorted_out = sorted;
   return GDN_OK;
 }
@@ -931,12 +934,14 @@ uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full) {
 int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, PbPlan &p, bool alloc_vals,
              const float *edge_vals_in, DevBuf<float> *edge_vals_out, bool compact, bool rows_are_sources, unsigned pad,
              int log_group, const uint8_t *src_class, int want_class, bool src_major, bool v_delta,
-             const uint8_t *dst_class, int want_dst, bool rows_of_class_only, bool no_gaps, int bin_balance_log) {
+             const uint8_t *dst_class, int want_dst, bool rows_of_class_only, bool no_gaps, int bin_balance_log,
+             PbScratch *scratch) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
   GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
   GDN_REQUIRE(!(src_class && rows_are_sources), "source classes: in-CSR only");
   GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
               "pad / log_group");
+  const auto t_begin = std::chrono::steady_clock::now();
   p.log_group = log_group;
   const unsigned grp = 1u << log_group;  // u16 local ids + one pad value
   GDN_REQUIRE(log_bin >= 8 && log_bin <= 15, "log_bin");
@@ -1072,12 +1077,13 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   GDN_TRY(p.errflag.alloc(1));
   GDN_HIP(hipMemset(p.errflag.p, 0, sizeof(unsigned)));
   {
-    DevBuf<unsigned long long> ka, kb, bigitems, nvalid;
+    DevBuf<unsigned long long> ka_own, kb_own, bigitems, nvalid;
+    DevBuf<unsigned long long> &ka = scratch ? scratch->ka : ka_own, &kb = scratch ? scratch->kb : kb_own;
     DevBuf<unsigned> cnt;
     const uint64_t bigcap64 = n / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-    GDN_TRY(ka.alloc(n));
-    GDN_TRY(kb.alloc(n));
+    if (ka.n < n || !ka.p) GDN_TRY(ka.alloc(n));
+    if (kb.n < n || !kb.p) GDN_TRY(kb.alloc(n));
     GDN_TRY(bigitems.alloc(bigcap));
     GDN_TRY(cnt.alloc(2));
     GDN_TRY(nvalid.alloc(1));
@@ -1123,7 +1129,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       p.nnz = n_use;
     }
     const unsigned long long *sorted = nullptr;
-    GDN_TRY(sort_keys(ka, kb, n, key_bits + ((src_class || dst_class) ? 1u : 0u), &sorted));
+    GDN_TRY(sort_keys(ka, kb, n, key_bits + ((src_class || dst_class) ? 1u : 0u), &sorted, /*keep_both=*/scratch != nullptr));
     if (n_use == 0) {
       hipLaunchKernelGGL(pb_fill_u64_kernel, dim3(gdn_nblocks(ntiles + 1)), dim3(GDN_BLOCK), 0, 0, tsu.p, ntiles + 1,
                          (eoff_t)0);
@@ -1292,6 +1298,9 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   GDN_TRY(p.partial.alloc(p.nbins));
   GDN_TRY(p.red_scratch.alloc(2 * ((size_t)p.nbins / 4096 + 2)));
   GDN_HIP(hipDeviceSynchronize());
+  if (getenv("GDN_PB_TRACE"))
+    fprintf(stderr, "[pb_build] %.0f ms wall\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return GDN_OK;
 }
 

@@ -88,6 +88,12 @@ struct PbPlan {
   }
 };
 
+// The two 8-byte-per-edge key buffers of a layout build, kept across the builds of ONE plan: a fresh 17 GB hipMalloc
+// costs ~1 s at RMAT-27 (page mapping), and a PageRank plan builds four layouts.
+struct PbScratch {
+  DevBuf<unsigned long long> ka, kb;
+};
+
 // implemented in gdn_build.hip (uses the radix sort)
 // alloc_vals = false: only the static layout (U, V, G, pointers, orders) -- BFS keeps 1 bit per edge
 // edge_vals_in (nullable, CSR order) -> *edge_vals_out in chunk-major order, pads = 0 (SpMV's Ax)
@@ -105,7 +111,8 @@ int pb_build(const gdn_graph *in_csr, int32_t m_global, int log_chunk, int log_b
              bool rows_of_class_only = false,     // the row slices hold the rows of that class only (hub-row layout)
              bool no_gaps = false,                // slice starts padded to `pad` only: with ONE bin (or chunk) U and V
                                                   // then sit at the same positions
-             int bin_balance_log = PB_MAX_LOG_BIN);  // bins of this size are spread over whole rounds of workgroups
+             int bin_balance_log = PB_MAX_LOG_BIN,  // bins of this size are spread over whole rounds of workgroups
+             struct PbScratch *scratch = nullptr);   // key buffers shared by the builds of one plan (see PbScratch)
 
 // Hub tier (gdn_pr.hip, gdn_spmv.hip): the edges of the <= 2^15 sources with the most out-edges live in a second layout
 // (one source chunk, tiles sorted by hub) that phase B reads directly; their source values come from a

@@ -330,6 +330,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     const char *ve = getenv("GDN_PB_V8");
     const bool v_delta = pad >= 32 && ve && ve[0] == '1';
     DevBuf<uint8_t> cls;
+    PbScratch scratch;  // the key buffers of the (up to four) layout builds below
     const char *he = getenv("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
     st = GDN_OK;
     uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
@@ -370,7 +371,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     }
     if (st == GDN_OK)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
-                    any_class ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0);
+                    any_class ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0, false, false,
+                    PB_MAX_LOG_BIN, &scratch);
     if (st == GDN_OK && p->n_hr &&
         4ull * (p->pb.chunk_slots + 4ull) + 8ull * p->n_hr + lds_static > 163840ull) {
       // cannot happen with out_degree == the column counts of in_csr (the slice size was derived from it)
@@ -416,7 +418,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       }
     }
     if (st == GDN_OK && p->n_hubs) {
-      st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true);
+      st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true, false,
+                    nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
         gdn_set_error("gdn_pr_plan_create: hub layout does not line up with the main layout (%u chunks, %u vs %u bins)",
                       p->hub.nchunks, p->hub.nbins, p->pb.nbins);
@@ -429,7 +432,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     }
     for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
       gdn_pr_plan::MidTier &mt = p->mid[t];
-      st = pb_build(in_csr, m_global, 15, lb, mt.layout, false, nullptr, nullptr, true, false, 16, 4, cls.p, 2 + t, true);
+      st = pb_build(in_csr, m_global, 15, lb, mt.layout, false, nullptr, nullptr, true, false, 16, 4, cls.p, 2 + t, true, false,
+                    nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && mt.layout.nbins != p->pb.nbins) {
         gdn_set_error("gdn_pr_plan_create: mid layout %d does not line up with the main layout (%u vs %u bins)", t,
                       mt.layout.nbins, p->pb.nbins);

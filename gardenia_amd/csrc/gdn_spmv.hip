@@ -169,6 +169,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     uint64_t hub_min_nnz = 1ull << 24;
     if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     DevBuf<uint8_t> cls;
+    PbScratch scratch;  // the key buffers of the layout builds below
     st = GDN_OK;
     const char *me = getenv("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
     int max_mid = me ? atoi(me) : PB_MAX_MID;
@@ -179,9 +180,11 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       st = pb_pick_tiers(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
     if (st == GDN_OK)
       st = pb_build(csr, n_cols, lc, lb, p->pb, true, d_Ax, &p->Axp, compact, false, /*pad=*/32, /*log_group=*/5,
-                    (p->n_hubs || n_mid[0]) ? cls.p : nullptr, 0, false, v_delta);
+                    (p->n_hubs || n_mid[0]) ? cls.p : nullptr, 0, false, v_delta, nullptr, 0, false, false, PB_MAX_LOG_BIN,
+                    &scratch);
     if (st == GDN_OK && p->n_hubs) {
-      st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true);
+      st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true, false,
+                    nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
         gdn_set_error("gdn_spmv_plan_create: hub layout does not line up with the main layout");
         st = GDN_ERR_INVALID;
@@ -192,7 +195,8 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     }
     for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
       gdn_spmv_plan::MidTier &mt = p->mid[t];
-      st = pb_build(csr, n_cols, 15, lb, mt.layout, false, d_Ax, &mt.Ax, true, false, 16, 4, cls.p, 2 + t, true);
+      st = pb_build(csr, n_cols, 15, lb, mt.layout, false, d_Ax, &mt.Ax, true, false, 16, 4, cls.p, 2 + t, true, false, nullptr, 0,
+                    false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && mt.layout.nbins != p->pb.nbins) {
         gdn_set_error("gdn_spmv_plan_create: mid layout %d does not line up with the main layout", t);
         st = GDN_ERR_INVALID;
