@@ -146,7 +146,14 @@ def main():
                               100.0 * me.value / max(snnz.value, 1))
     # on a squished graph 82 % of the state has out-edges: the dense in-place all-gather beats gather + scatter
     exchange = "dense" if (squish_first and args.exchange == "auto") else args.exchange
-    pr = ShardedPageRank(be, m_part, rank, world, dist if world > 1 else None, exchange=exchange)
+    # pipeline parts: every part's accumulate launch should still fill the 256 CUs (a part of 104 bins at N = 8 would
+    # leave 60 % of them idle): about 200 bins per part or more, the same count on every rank
+    parts = 4
+    if world > 1:
+        nb = torch.tensor([be.n_bins()], dtype=torch.int64, device=device)
+        dist.all_reduce(nb, op=dist.ReduceOp.MIN)
+        parts = max(1, min(4, int(nb.item()) // 200)) if int(nb.item()) > 0 else 4
+    pr = ShardedPageRank(be, m_part, rank, world, dist if world > 1 else None, exchange=exchange, parts=parts)
     pr.init_contrib()
 
     def barrier():

@@ -79,6 +79,7 @@ PROTOTYPES = {
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_pr_plan_mid": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_pr_plan_state_size": (C.c_int, [_vp, C.POINTER(_i32)]),
+    "gdn_pr_plan_bins": (C.c_int, [_vp, C.POINTER(_i32)]),
     "gdn_pr_import_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
     "gdn_pr_import_diff": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "gdn_pr_export_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),

@@ -875,6 +875,12 @@ int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edg
   return GDN_OK;
 }
 
+int gdn_pr_plan_bins(const gdn_pr_plan *plan, int32_t *n_bins) {
+  GDN_REQUIRE(plan != nullptr && n_bins != nullptr, "null argument");
+  *n_bins = plan->layout == GDN_LAYOUT_PB ? (int32_t)plan->pb.nbins : 0;
+  return GDN_OK;
+}
+
 int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges) {
   GDN_REQUIRE(plan != nullptr, "plan");
   int32_t ns = 0;

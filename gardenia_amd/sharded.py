@@ -296,6 +296,12 @@ class HipPageRankBackend:
                                                      C.c_void_p(self.diff.data_ptr()), float(damping), r0c, r1c, flags,
                                                      self._stream()))
 
+    def n_bins(self) -> int:
+        """Workgroups of the accumulate phase on this rank (0: CSR layout)."""
+        nb = C.c_int32(0)
+        self._cabi.check(self.L.gdn_pr_plan_bins(self.plan, C.byref(nb)))
+        return nb.value
+
     def export_scores(self, damping: float = 0.85):
         """The rank's scores in the caller's vertex order (m_local entries)."""
         if not self.squished:

@@ -187,6 +187,9 @@ int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edg
 /* mid tiers of the PB layout (the degree levels below the hubs, read by phase B as 32-bit (source, row) records):
  * number of tiers, their sources and their edges (0 / 0 / 0 when the plan has none) */
 int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges);
+/* destination bins of the PB layout = workgroups of the accumulate phase (0 for the CSR layout): a driver that cuts an
+ * iteration into row-range parts (gdn_pr_pull_rows_dev) keeps every part at a whole wave of workgroups or more */
+int gdn_pr_plan_bins(const gdn_pr_plan *plan, int32_t *n_bins);
 int gdn_pr_plan_check(gdn_pr_plan *plan);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* entries of the per-vertex state arrays (scores, contrib) the iteration calls of this plan work on: m_local, or the
