@@ -408,6 +408,10 @@ struct gdn_bfs_plan {
   DevBuf<vid_t> q0, q1;
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
+  BfsCounters *h_cnt = nullptr;  // pinned host copy of the level counters (one 32-byte read back per level)
+  ~gdn_bfs_plan() {
+    if (h_cnt) (void)hipHostFree(h_cnt);
+  }
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
@@ -433,6 +437,18 @@ bfs_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned lon
     n += rowptr[v + 1] > rowptr[v] ? 1u : 0u;
   n = gdn_wave_sum(n);
   if (gdn_lane() == 0 && n) atomicAdd(out, n);
+}
+
+// the per-level read back of the counters: into pinned memory (no staging copy in the runtime), then one stream sync
+static int bfs_read_counters(gdn_bfs_plan &p, BfsCounters &h) {
+  if (!p.h_cnt) {
+    GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+    return GDN_OK;
+  }
+  GDN_HIP(hipMemcpyAsync(p.h_cnt, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost, 0));
+  GDN_HIP(hipStreamSynchronize(0));
+  h = *p.h_cnt;
+  return GDN_OK;
 }
 
 static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *gin, bool dense) {
@@ -468,6 +484,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
   GDN_TRY(p.q1.alloc(p.qcap));
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
+  if (hipHostMalloc((void **)&p.h_cnt, sizeof(BfsCounters), hipHostMallocDefault) != hipSuccess) p.h_cnt = nullptr;
   if (gin) {
     GDN_TRY(p.front.alloc(p.nwords_pad));
     GDN_TRY(p.next.alloc(p.nwords_pad));
@@ -551,7 +568,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                              p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_dist, level + 1,
                              g->rowptr, p.cnt.p);
         }
-        GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+        GDN_TRY(bfs_read_counters(p, h));
         awake = (int64_t)h.awake;
         scout_count = (int64_t)h.scout;
         visited_total += awake;
@@ -572,7 +589,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
       hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
-      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_TRY(bfs_read_counters(p, h));
       nf = h.next_count;
       lap("bitmap2q", nf, 0);
       edges_to_check = 0;  // from here on only the top-down tail is left
@@ -588,7 +605,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
         hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                            p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
-        GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+        GDN_TRY(bfs_read_counters(p, h));
         awake = (int64_t)h.awake;
         unsigned *t = fr;
         fr = nx;
@@ -598,7 +615,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
       hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
-      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_TRY(bfs_read_counters(p, h));
       nf = h.next_count;
       scout_count = 1;
     } else {
@@ -624,7 +641,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                         ? 64u : (unsigned)EXP_BIG;
       hipLaunchKernelGGL(bfs_td_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nf, big, vis);
       hipLaunchKernelGGL(bfs_td_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
-      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_TRY(bfs_read_counters(p, h));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;
       visited_total += (int64_t)nf;
