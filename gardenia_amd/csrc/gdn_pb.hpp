@@ -187,9 +187,30 @@ pb_tier_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ 
 // plain-float table of a record tier (SpMV): val[k] = x[ids[k]] for k < n, 0 up to n_slots
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
-                          float *__restrict__ val) {
-  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (k < n_slots) val[k] = k < n ? x[ids[k]] : 0.0f;
+                          float *__restrict__ val, unsigned *__restrict__ absmax = nullptr) {
+  // grid-stride (the launch uses few workgroups): with absmax, ONE atomic per workgroup
+  __shared__ unsigned s_mx[GDN_WAVES_PER_BLOCK];
+  unsigned mx = 0u;
+  for (unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x; k < n_slots; k += gridDim.x * GDN_BLOCK) {
+    const float v = k < n ? x[ids[k]] : 0.0f;
+    val[k] = v;
+    const unsigned bts = __float_as_uint(v) & 0x7FFFFFFFu;
+    mx = bts > mx ? bts : mx;
+  }
+  if (absmax) {  // max |x| of the tier's columns (float bits), see pb_expand_scaled_kernel
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64);
+      mx = t > mx ? t : mx;
+    }
+    if (gdn_lane() == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0u;
+      for (int w = 0; w < GDN_WAVES_PER_BLOCK; w++) t = s_mx[w] > t ? s_mx[w] : t;
+      if (t) atomicMax(absmax, t);
+    }
+  }
 }
 
 static __global__ void __launch_bounds__(GDN_BLOCK)
@@ -643,18 +664,22 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
                         const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
                         const uint16_t *__restrict__ U, const uint32_t *__restrict__ G, const float *__restrict__ A,
                         float *__restrict__ vals, int log_group, const uint32_t *__restrict__ src_bits = nullptr,
-                        const uint32_t *__restrict__ chunk_lo = nullptr, unsigned pad_slot = 0) {
+                        const uint32_t *__restrict__ chunk_lo = nullptr, unsigned pad_slot = 0,
+                        // nullable: max |x| over the values this launch loads, as float bits (atomicMax): the fixed-point
+                        // scale of the accumulate phase needs it, and a pass of its own over x cost 10 % of a multiply
+                        unsigned *__restrict__ absmax = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];
   const unsigned ch = 1u << log_chunk;
   const unsigned c = chunk_order[blockIdx.x];
   const size_t base = (size_t)c << log_chunk;
+  unsigned n_slots = ch;
   if (src_bits) {  // compacted slice: the chunk's active columns, gathered from their original id range
     if ((reinterpret_cast<uintptr_t>(x) & 15u) == 0)
-      pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
+      n_slots = pb_load_slice4(x, m_global, src_bits, chunk_lo[c], chunk_lo[c + 1], s_x, s_bits, s_pref, s_scr);
     else
-      pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
-                    [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
+      n_slots = pb_walk_slice(src_bits, chunk_lo[c], chunk_lo[c + 1], s_bits, s_pref, s_scr,
+                              [&](unsigned id, unsigned k) { s_x[k] = x[id]; }, [](unsigned) {});
   } else {
     for (unsigned i = threadIdx.x; i < ch; i += PB_THREADS) {
       const size_t g = base + i;
@@ -663,6 +688,26 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
   }
   if (threadIdx.x == 0) s_x[pad_slot ? pad_slot : ch] = 0.0f;
   __syncthreads();
+  if (absmax) {
+    unsigned mx = 0u;
+    for (unsigned i = threadIdx.x; i < n_slots; i += PB_THREADS) {
+      const unsigned bts = __float_as_uint(s_x[i]) & 0x7FFFFFFFu;
+      mx = bts > mx ? bts : mx;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)mx, o, 64);
+      mx = t > mx ? t : mx;
+    }
+    // ONE atomic per workgroup: a hot address takes ~12 ns per atomic whoever issues it
+    if (gdn_lane() == 0) s_scr[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned t = 0u;
+      for (int w = 0; w < PB_WAVES; w++) t = s_scr[w] > t ? s_scr[w] : t;
+      if (t) atomicMax(absmax, t);
+    }
+  }
   const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
   const pb_u16x4 *U4 = reinterpret_cast<const pb_u16x4 *>(U);
   const pb_f32x4 *A4 = reinterpret_cast<const pb_f32x4 *>(A);

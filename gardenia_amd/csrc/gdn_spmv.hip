@@ -270,9 +270,9 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   }
   // ---- propagation-blocked path (Ax lives in the plan in tile order; d_Ax is not read)
   PbPlan &pb = plan->pb;
+  // max |x| (for the fixed-point scale of phase B) is collected by the launches that read x anyway: phase A over the
+  // columns of the main layout, the gather kernels over the tier columns -- every column that has a nonzero
   GDN_HIP(hipMemsetAsync(plan->mx.p + 1, 0, sizeof(unsigned), s));
-  hipLaunchKernelGGL(spmv_absmax_kernel, dim3(1024), dim3(GDN_BLOCK), 0, s, d_x, (size_t)plan->n_cols, plan->mx.p + 1);
-  hipLaunchKernelGGL(spmv_scale_kernel, dim3(1), dim3(64), 0, s, plan->mx.p, plan->scale.p);
   op.scale = plan->scale.p;
   const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
@@ -281,11 +281,11 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
                      pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
                      pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr,
-                     pb.chunk_slots);
+                     pb.chunk_slots, plan->mx.p + 1);
   PbMidArgs mid = PbMidArgs();
   if (plan->has_hub) {
-    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(gdn_nblocks(PB_HUB_SLOTS + 3)), dim3(GDN_BLOCK), 0, s, d_x,
-                       plan->hub_ids.p, plan->n_hubs, (unsigned)PB_HUB_SLOTS + 3u, plan->hub_val.p);
+    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(64), dim3(GDN_BLOCK), 0, s, d_x,
+                       plan->hub_ids.p, plan->n_hubs, (unsigned)PB_HUB_SLOTS + 3u, plan->hub_val.p, plan->mx.p + 1);
     mid.ptr[mid.n] = plan->hub.bin_ptr.p;
     mid.rec[mid.n] = plan->hub_rec.p;
     mid.val[mid.n] = plan->hub_val.p;
@@ -294,8 +294,8 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
     mid.form[mid.n++] = 1;
   }
   for (int t = 0; t < plan->n_mid_tiers; t++) {
-    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(gdn_nblocks((uint64_t)plan->mid[t].n + 4)), dim3(GDN_BLOCK), 0, s,
-                       d_x, plan->mid[t].ids.p, plan->mid[t].n, plan->mid[t].n + 4u, plan->mid[t].val.p);
+    hipLaunchKernelGGL(pb_tier_gather_f32_kernel, dim3(128), dim3(GDN_BLOCK), 0, s,
+                       d_x, plan->mid[t].ids.p, plan->mid[t].n, plan->mid[t].n + 4u, plan->mid[t].val.p, plan->mx.p + 1);
     mid.ptr[mid.n] = plan->mid[t].layout.bin_ptr.p;
     mid.rec[mid.n] = plan->mid[t].rec.p;
     mid.val[mid.n] = plan->mid[t].val.p;
@@ -303,6 +303,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
     mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
     mid.form[mid.n++] = 0;
   }
+  hipLaunchKernelGGL(spmv_scale_kernel, dim3(1), dim3(64), 0, s, plan->mx.p, plan->scale.p);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,
                      pb.m_local, pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p,
