@@ -26,10 +26,12 @@
 //       bin streamed with 16-/8-byte loads; each value is converted to 2^-62 fixed point and
 //       added with ds_add_u64 (integer LDS atomics are 14x faster than float ones here, and
 //       integer addition is associative, so the sums are BITWISE REPRODUCIBLE); then the fused
-//       epilogue of the rows (coalesced, 16-byte accesses).  Edges of HUB sources (second layout,
-//       sorted by hub) are read here directly as (hub, row) pairs, their value from a small table.
-//   HBM traffic per main-layout edge ~ (2 + 0.125 + 4) + (4 + 2) = 12.1 B, per hub edge 4 B, all
-//   streamed; no vector-memory gather or scatter is left on the per-edge path.
+//       epilogue of the rows (coalesced, 16-byte accesses).  The edges of high-degree sources (RECORD TIERS: hubs and
+//       up to two mid tiers, PbMidArgs) never pass through phase A: phase B reads them as 32-bit (source index, row)
+//       records sorted by source and takes the value from the tier's per-iteration table (L2 resident).
+//   PageRank sends fixed-point CODES through vals and the tables (pb_encode once per source, pb_decode per edge).
+//   HBM traffic per main-layout edge ~ (2 + 0.125 + 4) + (4 + 2) = 12.1 B, per tier edge 4 B, all
+//   streamed; no divergent vector-memory gather or scatter is left on the per-edge path.
 //
 // Fixed point: PageRank contributions lie in [0,1] and every row sum is <= the total rank mass
 // <= 1 (no dangling redistribution in the reference, src/pr/omp_base.cc), so sum*2^62 fits a
