@@ -433,22 +433,19 @@ bc_x_back_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level
 // light backward level, vertex-parallel: the rows at depth `level` (see bc_back_kernel for the row classes)
 __global__ void __launch_bounds__(GDN_BLOCK)
 bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int32_t level,
-                   bc_i32x4 *__restrict__ rec, float *__restrict__ scores, vid_t *__restrict__ big_rows, BcCounters *cnt,
-                   unsigned cap) {
+                   const int32_t *__restrict__ depth, bc_i32x4 *__restrict__ rec, float *__restrict__ scores,
+                   vid_t *__restrict__ big_rows, BcCounters *cnt, unsigned cap) {
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned lane = gdn_lane();
   const int32_t next_level = level + 1;
   eoff_t b = 0, e = 0;
   float pcs = 0.0f;
   bool mine = false;
-  if (i < (unsigned)m) {
-    const bc_i32x4 r = rec[i];
-    if (r.x == level) {
-      mine = true;
-      b = rowptr[i];
-      e = rowptr[i + 1];
-      pcs = (float)r.y;
-    }
+  if (i < (unsigned)m && depth[i] == level) {  // the 4-byte depth filters; only the level's vertices read their record
+    mine = true;
+    b = rowptr[i];
+    e = rowptr[i + 1];
+    pcs = (float)rec[i].y;
   }
   const vid_t v = (vid_t)i;
   const eoff_t deg = e - b;
@@ -738,7 +735,7 @@ int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *st
     if (ls.edges[d] >= heavy) GDN_TRY(bc_pb_sweep_back(p, d, d_scores, &done));
     if (!done) {
       hipLaunchKernelGGL(bc_back_all_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, m, d,
-                         p.rec.p, d_scores, p.big_rows.p, p.cnt.p, p.rowcap);
+                         p.depth.p, p.rec.p, d_scores, p.big_rows.p, p.cnt.p, p.rowcap);
       hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, p.big_rows.p, p.cnt.p,
                          p.rec.p, d_scores, d + 1, p.rowcap);
       GDN_HIP(hipMemsetAsync(&p.cnt.p->big_count, 0, sizeof(unsigned), 0));
