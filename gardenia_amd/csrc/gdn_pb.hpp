@@ -174,18 +174,6 @@ typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
 
 // hub_val[k] = x[hub_ids[k]] (PageRank: contrib, SpMV: x); the slots behind the hubs (incl. the pad slot 32768) stay 0
-__device__ __forceinline__ uint32_t pb_encode(float v, unsigned &bad);
-// table of a record tier (PageRank): val[k] = pb_encode(x[ids[k]]) for k < n, 0 (= the code of 0.0) up to n_slots
-static __global__ void __launch_bounds__(GDN_BLOCK)
-pb_tier_gather_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
-                      float *__restrict__ val, unsigned *__restrict__ errflag) {
-  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (k >= n_slots) return;
-  unsigned bad = 0u;
-  val[k] = k < n ? __uint_as_float(pb_encode(x[ids[k]], bad)) : 0.0f;
-  if (bad) *errflag = 1u;
-}
-
 // plain-float table of a record tier (SpMV): val[k] = x[ids[k]] for k < n, 0 up to n_slots
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
@@ -213,13 +201,6 @@ pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restric
       if (t) atomicMax(absmax, t);
     }
   }
-}
-
-static __global__ void __launch_bounds__(GDN_BLOCK)
-pb_hub_gather_kernel(const float *__restrict__ contrib, const uint32_t *__restrict__ hub_ids, unsigned n_hubs,
-                     float *__restrict__ hub_val) {
-  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (k < PB_HUB_SLOTS) hub_val[k] = k < n_hubs ? contrib[hub_ids[k]] : 0.0f;
 }
 
 
