@@ -173,7 +173,6 @@ typedef unsigned short pb_u16x4 __attribute__((ext_vector_type(4)));
 typedef float pb_f32x4 __attribute__((ext_vector_type(4)));
 typedef int pb_i32x4 __attribute__((ext_vector_type(4)));
 
-// hub_val[k] = x[hub_ids[k]] (PageRank: contrib, SpMV: x); the slots behind the hubs (incl. the pad slot 32768) stay 0
 // plain-float table of a record tier (SpMV): val[k] = x[ids[k]] for k < n, 0 up to n_slots
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restrict__ ids, unsigned n, unsigned n_slots,
