@@ -227,10 +227,14 @@ pr_dead_diff_kernel(const float *__restrict__ scores, const uint32_t *__restrict
 
 extern "C" {
 
-// slice sizes: as large as LDS allows on big graphs, but keep >= ~1024 workgroups per phase
-static int pb_pick_log(int64_t n, int max_log) {
+// slice sizes: as large as LDS allows on big graphs; smaller graphs keep >= 2^slices_log slices per phase BEFORE the
+// vertex compaction (about 40 % of them stay on an R-MAT graph).  Whole graphs take 2^9: every bin re-reads the tier
+// tables and every workgroup pays its ramp-up, so fewer, larger slices win well below one workgroup per CU (measured,
+// RMAT-20 / 22 / 24: 0.082 -> 0.070, 0.160 -> 0.134, 0.456 -> 0.447 ms per iteration); row shards
+// keep 2^10 (their parts pipeline wants a wave of workgroups per part, and the choice could not be measured on a node)
+static int pb_pick_log(int64_t n, int max_log, int slices_log) {
   int lg = 10;
-  while (lg < max_log && ((int64_t)1 << (lg + 10)) < n) lg++;
+  while (lg < max_log && ((int64_t)1 << (lg + slices_log)) < n) lg++;
   return lg;
 }
 
@@ -313,7 +317,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
-    int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN);
+    int slices_log = in_csr->m == m_global ? 9 : 10;
+    if (const char *e = getenv("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK, slices_log), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN, slices_log);
     if (const char *e = getenv("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
     if (const char *e = getenv("GDN_PB_LOG_BIN")) lb = atoi(e);
     // vertex compaction on by default (GDN_PB_COMPACT=0 switches it off for A/B measurements)

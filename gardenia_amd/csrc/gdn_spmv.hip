@@ -126,9 +126,11 @@ __global__ void spmv_scale_kernel(const unsigned *__restrict__ mx, float *__rest
 
 extern "C" {
 
-static int spmv_pick_log(int64_t n, int max_log) {
+// slice sizes as for PageRank (pb_pick_log in gdn_pr.hip): whole matrices keep >= 2^9 slices before the compaction, row
+// shards 2^10
+static int spmv_pick_log(int64_t n, int max_log, int slices_log) {
   int lg = 10;
-  while (lg < max_log && ((int64_t)1 << (lg + 10)) < n) lg++;
+  while (lg < max_log && ((int64_t)1 << (lg + slices_log)) < n) lg++;
   return lg;
 }
 
@@ -162,7 +164,9 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
   } else {
     // compacted like PageRank's layout (columns that occur / rows that have entries), rows of whole 128-byte lines;
     // GDN_PB_COMPACT=0 / GDN_PB_HUBS=0 switch the two refinements off (A/B measurements)
-    const int lc = spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK), lb = spmv_pick_log(csr->m, PB_MAX_LOG_BIN);
+    int slices_log = csr->m == n_cols ? 9 : 10;
+    if (const char *e = getenv("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    const int lc = spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK, slices_log), lb = spmv_pick_log(csr->m, PB_MAX_LOG_BIN, slices_log);
     const char *ce = getenv("GDN_PB_COMPACT"), *he = getenv("GDN_PB_HUBS"), *ve = getenv("GDN_PB_V8");
     const bool compact = !(ce && ce[0] == '0');
     const bool v_delta = ve && ve[0] == '1';  // off by default, see gdn_pr.hip
