@@ -615,8 +615,8 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     const int32_t m = g->m;
     if ((st = gdn_bfs_plan_create(g, gin, 1, &p->bfs))) break;
     int lc = 10, lb = 10;
-    while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 10)) < (int64_t)m) lc++;
-    while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 10)) < (int64_t)m) lb++;
+    while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 9)) < (int64_t)m) lc++;  // slice sizes as for PageRank (pb_pick_log)
+    while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 9)) < (int64_t)m) lb++;
     // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
     PbScratch scratch;
     if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
