@@ -522,7 +522,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int32_t level = 0;  // depth of the vertices in the current frontier
   int iter = 0;
   int64_t visited_total = 1;  // discovered so far (the source included)
-  int64_t bu_frac = 4;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered
+  int64_t bu_frac = 2;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered (measured on
+                              // RMAT-22..27: 2 beats 4 wherever a second heavy level follows the first, 1 loses)
   if (const char *e = getenv("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
   // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
   // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
