@@ -698,7 +698,9 @@ int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *st
   int32_t nlev = 0;
   for (int d = 0; d < BC_MAX_LEVELS; d++)
     if (ls.count[d]) nlev = d + 1;
-  const uint64_t heavy = g->nnz / 16 + 1;
+  uint64_t heavy_div = 16;  // a level is heavy (two blocked sweeps instead of atomics / gathers) from nnz / heavy_div out-edges on
+  if (const char *e = getenv("GDN_BC_HEAVY_DIV")) heavy_div = atoi(e) > 0 ? (uint64_t)atoi(e) : heavy_div;  // tuning knob
+  const uint64_t heavy = g->nnz / heavy_div + 1;
   GDN_HIP(hipMemsetAsync(p.pc.p, 0, (size_t)m * 4, 0));
   GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BcCounters), 0));
   GDN_HIP(hipMemsetAsync(p.mx.p, 0, 8, 0));
