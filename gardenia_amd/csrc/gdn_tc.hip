@@ -259,8 +259,12 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 // Rows with more than TC_LIGHT out-neighbours are cut into work items of TC_SLICE neighbours: the work of a row
 // grows with du * (length of its neighbours' lists), and on a skewed graph a third of all list elements belongs to
 // a few thousand hub rows -- one wave per row left the kernel waiting for them (profiles/r01_tc_pmc.md).
+#ifndef TC_LIGHT
 #define TC_LIGHT 64
+#endif
+#ifndef TC_SLICE
 #define TC_SLICE 256
+#endif
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ items,
