@@ -208,7 +208,9 @@ __device__ __forceinline__ void gdn_wl_push(vid_t *queue, unsigned *count, unsig
 // GDN_WL_STAGE - 64 items or so.  A single hot counter takes ~12 ns per atomic on this chip whatever issues it
 // (a top-down BFS level that pushed from 87 K wave steps spent 1 ms of its 1.5 ms there); staging divides the
 // count by ~4-16.  `n` is the wave-uniform fill of the strip; call gdn_wl_flush at the end of the kernel.
+#ifndef GDN_WL_STAGE
 #define GDN_WL_STAGE 256
+#endif
 struct GdnWlStage {
   vid_t *strip;  // GDN_WL_STAGE entries of LDS owned by this wave
   unsigned n;
