@@ -76,6 +76,9 @@ def lib():
         L.orc_cc_verify.restype = C.c_int
         L.orc_sample_frequent_element.argtypes = [C.c_int32, _i32p, C.c_int64]
         L.orc_sample_frequent_element.restype = C.c_int32
+        L.orc_pr_delta.argtypes = [C.c_int32, _u64p, _i32p, _u64p, _i32p, _i32p, _f32p, C.c_float, C.c_double, C.c_float,
+                                   C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_pr_delta.restype = C.c_int
         L.orc_bc.argtypes = [C.c_int32, _u64p, _i32p, C.c_int32, _f32p, C.c_void_p, C.c_void_p]
         L.orc_bc.restype = C.c_int
         L.orc_bc_verify.argtypes = [C.c_int32, _u64p, _i32p, C.c_int32, _f32p]
@@ -141,6 +144,21 @@ def pr_iterate(g_in, out_degree, scores, iters, damping=0.85, row_lo=0, row_hi=N
     err = lib().orc_pr_iterate(g_in.m, rp, ci, np.ascontiguousarray(out_degree, np.int32), scores,
                                damping, iters, row_lo, row_hi)
     return scores, float(err)
+
+
+def pr_delta(g_in, g_out, damping=0.85, epsilon=1e-4, epsilon2=1e-3, max_iter=100, push_div=10, scores=None):
+    """src/pr/omp_delta.cc:52 (push_div 10) / src/pr/delta.cu:140 (push_div 8).
+    Returns (scores, iterations, trace) with trace = dict(diff, items, mode) per iteration."""
+    m = g_in.m
+    if scores is None:
+        scores = np.full(m, np.float32(1.0) / np.float32(m), dtype=np.float32)
+    irp, ici = _g(g_in)
+    orp, oci = _g(g_out)
+    deg = np.ascontiguousarray(np.diff(g_out.rowptr.astype(np.int64)), np.int32)
+    td, ti, tm = np.zeros(max_iter), np.zeros(max_iter, np.int32), np.zeros(max_iter, np.int32)
+    it = lib().orc_pr_delta(m, irp, ici, orp, oci, deg, scores, damping, epsilon, epsilon2, max_iter, push_div,
+                            td.ctypes.data_as(C.c_void_p), ti.ctypes.data_as(C.c_void_p), tm.ctypes.data_as(C.c_void_p))
+    return scores, it, dict(diff=td[:it], items=ti[:it], mode=tm[:it])
 
 
 def pr_verify_error(g_out, scores, damping=0.85) -> float:

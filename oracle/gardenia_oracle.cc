@@ -730,4 +730,65 @@ int orc_bc_verify(int32_t m, const eoff_t *rowptr, const vid_t *colidx, int32_t 
   }
   return 1;
 }
+// Delta PageRank, src/pr/omp_delta.cc:52-107 (CUDA twin src/pr/delta.cu:140-202): scores start at 1/m (caller), deltas at
+// 1/m; an iteration PULLS the deltas of ALL vertices over the in-CSR (omp_delta.cc:32-49) while the frontier holds at
+// least m / push_div vertices, and PUSHES the deltas of the frontier's vertices over the out-CSR otherwise (:12-28;
+// push_div = 10 at omp_delta.cc:69, 8 at delta.cu:178); then delta = d * sum (first iteration: base + d * sum - 1/m,
+// :84-89), score += delta, and a vertex enters the next frontier iff |delta| > epsilon2 * score (:92, epsilon2 = 1e-3,
+// pr.h:8).  Stops when the frontier is empty, after max_iter iterations or when sum |delta| < epsilon (:96-103).
+// The push is serial here, in ascending vertex order (the reference's order depends on the thread schedule).
+// Returns the iterations executed (the reference PRINTS iter + 1, omp_delta.cc:105).
+// trace_diff[it], trace_items[it] (frontier after the iteration), trace_mode[it] (0 pull, 1 push): nullable.
+int orc_pr_delta(int32_t m, const eoff_t *in_rowptr, const vid_t *in_colidx, const eoff_t *out_rowptr,
+                 const vid_t *out_colidx, const int32_t *out_degree, float *scores, float damping, double epsilon,
+                 float epsilon2, int max_iter, int push_div, double *trace_diff, int32_t *trace_items,
+                 int32_t *trace_mode) {
+  const float base_score = (1.0f - damping) / m;
+  const float init_score = 1.0f / m;
+  std::vector<float> sums((size_t)m, 0.0f), deltas((size_t)m, init_score), contrib((size_t)m, 0.0f);
+  std::vector<vid_t> queue((size_t)m), next;
+  for (int32_t i = 0; i < m; i++) queue[i] = i;
+  int iter = 0;
+  while (!queue.empty() && iter < max_iter) {
+    ++iter;
+    const bool push = (int64_t)queue.size() < (int64_t)(m / push_div);
+    if (push) {
+      for (vid_t src : queue) {
+        const eoff_t b = out_rowptr[src], e = out_rowptr[src + 1];
+        const int degree = (int)(e - b);
+        const float c = deltas[src] / (float)degree;
+        for (eoff_t k = b; k < e; k++) sums[out_colidx[k]] += c;
+      }
+    } else {
+#pragma omp parallel for
+      for (int32_t n = 0; n < m; n++) contrib[n] = deltas[n] / out_degree[n];
+#pragma omp parallel for schedule(dynamic, 64)
+      for (int32_t dst = 0; dst < m; dst++) {
+        float incoming_total = 0;
+        for (eoff_t k = in_rowptr[dst]; k < in_rowptr[dst + 1]; k++) incoming_total += contrib[in_colidx[k]];
+        sums[dst] = incoming_total;
+      }
+    }
+    next.clear();
+    double error = 0;
+    for (int32_t u = 0; u < m; u++) {
+      if (iter == 1) {
+        deltas[u] = base_score + damping * sums[u];
+        deltas[u] -= init_score;
+      } else {
+        deltas[u] = damping * sums[u];
+      }
+      scores[u] += deltas[u];
+      sums[u] = 0;
+      if (fabs(deltas[u]) > epsilon2 * scores[u]) next.push_back(u);
+      error += fabs(deltas[u]);
+    }
+    queue.swap(next);
+    if (trace_diff) trace_diff[iter - 1] = error;
+    if (trace_items) trace_items[iter - 1] = (int32_t)queue.size();
+    if (trace_mode) trace_mode[iter - 1] = push ? 1 : 0;
+    if (error < epsilon) break;
+  }
+  return iter;
+}
 }  // extern "C"

@@ -23,8 +23,13 @@
 
 #if defined(K_BFS)
 #include "bfs.h"
-#elif defined(K_PR)
+#elif defined(K_PR) || defined(K_PRDELTA)
 #include "pr.h"
+#if defined(K_PRDELTA)
+// the legacy raw-array entry point src/pr/omp_delta.cc:52 still defines (an overload next to pr.h:31)
+void PRSolver(int m, int nnz, IndexT *row_offsets, IndexT *column_indices, IndexT *out_row_offsets,
+              IndexT *out_column_indices, int *degrees, ScoreT *scores);
+#endif
 #elif defined(K_SPMV)
 #include "spmv.h"
 #elif defined(K_SSSP)
@@ -36,7 +41,7 @@
 #elif defined(K_BC)
 #include "bc.h"
 #else
-#error "define one of K_BFS K_PR K_SPMV K_SSSP K_CC K_TC K_BC"
+#error "define one of K_BFS K_PR K_PRDELTA K_SPMV K_SSSP K_CC K_TC K_BC"
 #endif
 
 template <typename T>
@@ -112,6 +117,18 @@ int main(int argc, char **argv) {
   } else {
     auto s = slurp<ScoreT>(io, (size_t)m);
     PRVerifier(g, s.data(), EPSILON);
+  }
+#elif defined(K_PRDELTA)
+  {  // needs <reverse> = 1; offsets narrowed to the IndexT (int) arrays of the legacy signature
+    std::vector<IndexT> irp(m + 1), ici(nnz), orp(m + 1), oci(nnz);
+    std::vector<int> degrees(m);
+    for (size_t i = 0; i <= (size_t)m; i++) { irp[i] = (IndexT)g.in_rowptr()[i]; orp[i] = (IndexT)g.out_rowptr()[i]; }
+    for (size_t i = 0; i < (size_t)nnz; i++) { ici[i] = g.in_colidx()[i]; oci[i] = g.out_colidx()[i]; }
+    for (size_t i = 0; i < (size_t)m; i++) degrees[i] = orp[i + 1] - orp[i];
+    const ScoreT init_score = 1.0f / m;  // src/pr/main.cc:17
+    std::vector<ScoreT> scores(m, init_score);
+    PRSolver((int)m, (int)nnz, irp.data(), ici.data(), orp.data(), oci.data(), degrees.data(), scores.data());
+    dump(io + ".scores", scores.data(), (size_t)m);
   }
 #elif defined(K_SPMV)
   std::vector<ValueT> Ax(nnz, 0.2), x(m, 0.3), y0(m, 0.0);  // src/spmv/main.cc:29-36

@@ -92,6 +92,24 @@ def main():
     def binp(name):
         return ("bin", os.path.join(tmp, name))
 
+    # ---- delta PageRank (reference solver = omp_delta, the legacy raw-array PRSolver overload; single thread so that
+    #      the order of its atomic pushes is the queue's) ----
+    if len(sys.argv) > 1 and sys.argv[1] == "pr_delta":
+        for case, (ft, px), sym in [("test_pr", mtx("test_pr"), 0), ("chesapeake_sym", mtx("chesapeake"), 1),
+                                    ("test_bc_dir", mtx("test_bc"), 0), ("rmat10", binp("rmat10"), 0),
+                                    ("rmat12", binp("rmat12"), 0)]:
+            out = os.path.join(tmp, "prd_" + case)
+            so = run([os.path.join(REFBIN, "ref_pr_delta"), "solve", ft, px, str(sym), "1", out], {"OMP_NUM_THREADS": "1"})
+            tr = re.findall(r"^(push|pull):\s*(\d+)\s+([0-9.]+)$", so, re.M)
+            it = int(re.search(r"iterations = (\d+)", so).group(1))  # the reference prints iter + 1 (omp_delta.cc:105)
+            d = graph_arrays(out, True)
+            np.savez_compressed(os.path.join(HERE, f"prdelta_{case}.npz"), scores=load(out, "scores", np.float32),
+                                trace=np.array([float(t[2]) for t in tr]), mode=np.array([int(t[0] == "push") for t in tr]),
+                                iterations_printed=it, symmetrize=sym, **d)
+        shutil.rmtree(tmp)
+        print("delta-PageRank golden vectors written to", HERE)
+        return
+
     # ---- BC (reference solver = omp_base from ONE source, src/bc/main.cc; its verifier's verdict recorded) ----
     for case, (ft, px), sym, source in [
             ("test_bc_dir", mtx("test_bc"), 0, 0), ("test_bc_sym", mtx("test_bc"), 1, 0),
