@@ -50,6 +50,11 @@ PROTOTYPES = {
     "gdn_set_device": (C.c_int, [C.c_int]),
     "gdn_bfs": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _i32, _vp, _st]),
     "gdn_pr": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, _i32, _st]),
+    "gdn_pr_delta": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, C.c_float, C.c_double, C.c_float, _i32, _i32, _st]),
+    "gdn_pr_delta_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),
+    "gdn_pr_delta_run": (C.c_int, [_vp, _vp, C.c_float, C.c_double, C.c_float, _i32, _i32, _st]),
+    "gdn_pr_delta_trace": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp]),
+    "gdn_pr_delta_plan_free": (C.c_int, [_vp]),
     "gdn_spmv": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),

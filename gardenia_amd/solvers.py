@@ -89,6 +89,19 @@ def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_
     return st.as_dict()
 
 
+def PRDeltaSolver(g: Graph, scores: np.ndarray, damping: float = 0.85, epsilon: float = 1e-4, epsilon2: float = 1e-3,
+                  max_iter: int = 100, push_div: int = 8) -> dict:
+    """The delta-PageRank PRSolver of src/pr/delta.cu:140 (push_div 8) / src/pr/omp_delta.cc:52 (push_div 10).
+    scores: float32[m] pre-filled with 1/m (src/pr/main.cc:17); needs the reverse graph."""
+    assert scores.dtype == np.float32 and scores.flags.c_contiguous
+    irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+    orp, oci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+    st = _cabi.GdnStats()
+    _cabi.check(_cabi.lib().gdn_pr_delta(g.V(), g.E(), _p(irp), _p(ici), _p(orp), _p(oci), _p(scores), damping, epsilon,
+                                         epsilon2, max_iter, push_div, C.byref(st)))
+    return st.as_dict()
+
+
 def BCSolver(g: Graph, source: int, scores: np.ndarray) -> dict:
     """src/bc/bc.h:37.  scores: float32[m], zero-filled by the caller (src/bc/main.cc:21); one source."""
     assert scores.dtype == np.float32 and scores.flags.c_contiguous
@@ -240,6 +253,40 @@ class ResidentBC:
         if self.hi:
             self.L.gdn_graph_free(self.hi)
         self.L.gdn_graph_free(self.h)
+
+
+class ResidentPRDelta:
+    """Delta PageRank on resident graphs (gdn_pr_delta_plan_*); run() returns (stats, trace)."""
+
+    def __init__(self, g: Graph, layout: int = _cabi.GDN_LAYOUT_AUTO):
+        L = _cabi.lib()
+        self.L, self.m = L, g.V()
+        self.hi, self.ho, self.plan, self.d_scores = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
+        orp, oci = _arr(g.out_rowptr(), np.uint64), _arr(g.out_colidx(), np.int32)
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(irp), _p(ici), C.byref(self.hi)))
+        _cabi.check(L.gdn_graph_upload(g.V(), g.E(), _p(orp), _p(oci), C.byref(self.ho)))
+        _cabi.check(L.gdn_pr_delta_plan_create(self.hi, self.ho, layout, C.byref(self.plan)))
+        _cabi.check(L.gdn_dev_alloc(4 * self.m, C.byref(self.d_scores)))
+
+    def run(self, scores: np.ndarray, damping=0.85, epsilon=1e-4, epsilon2=1e-3, max_iter=100, push_div=8):
+        assert scores.dtype == np.float32 and scores.flags.c_contiguous
+        _cabi.check(self.L.gdn_dev_upload(self.d_scores, _p(scores), 4 * self.m))
+        st = _cabi.GdnStats()
+        _cabi.check(self.L.gdn_pr_delta_run(self.plan, self.d_scores, damping, epsilon, epsilon2, max_iter, push_div,
+                                            C.byref(st)))
+        _cabi.check(self.L.gdn_dev_download(_p(scores), self.d_scores, 4 * self.m))
+        n = C.c_int32(0)
+        diff, items, mode = np.zeros(max_iter), np.zeros(max_iter, np.int32), np.zeros(max_iter, np.int32)
+        _cabi.check(self.L.gdn_pr_delta_trace(self.plan, max_iter, C.byref(n), _p(diff), _p(items), _p(mode)))
+        k = n.value
+        return st.as_dict(), dict(diff=diff[:k], items=items[:k], mode=mode[:k])
+
+    def close(self):
+        self.L.gdn_pr_delta_plan_free(self.plan)
+        self.L.gdn_dev_free(self.d_scores)
+        self.L.gdn_graph_free(self.ho)
+        self.L.gdn_graph_free(self.hi)
 
 
 class ResidentPageRankShards:

@@ -101,6 +101,17 @@ int gdn_tc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colid
 int gdn_bc(int32_t m, uint64_t nnz, const uint64_t *out_rowptr, const int32_t *out_colidx, int32_t source, float *scores,
            gdn_stats *stats);
 
+/* Delta PageRank == the PRSolver of src/pr/delta.cu:140 / src/pr/omp_delta.cc:52 (raw-array signature
+ * PRSolver(m, nnz, in_row_offsets, in_column_indices, out_row_offsets, out_column_indices, degrees, scores); degrees are
+ * the out-CSR's row lengths and are taken from it).  scores in: 1/m (src/pr/main.cc:17), out.  An iteration pulls the
+ * deltas of all vertices over the in-CSR while the frontier (|delta| > epsilon2 * score; pr.h:8 epsilon2 = 1e-3) holds
+ * at least m / push_div vertices (8 in delta.cu:178, 10 in omp_delta.cc:69) and pushes the frontier's deltas over the
+ * out-CSR otherwise; stops on an empty frontier, after max_iter iterations or when the L1 norm of the deltas < epsilon.
+ * stats.iterations = iterations executed (omp_delta.cc:105 prints one more), stats.last_error = the last L1 norm. */
+int gdn_pr_delta(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in_colidx, const uint64_t *out_rowptr,
+                 const int32_t *out_colidx, float *scores, float damping, double epsilon, float epsilon2, int32_t max_iter,
+                 int32_t push_div, gdn_stats *stats);
+
 /* replaces CCSolver(Graph&, CompT* comp): src/cc/cc.h:28; caller src/cc/main.cc:16.
  * comp: in = i (main.cc:15), out = component label = minimum vertex id of the (weakly)
  * connected component (fixpoint of src/cc/omp_base.cc:24-43).  in_* nullable (directed
@@ -284,6 +295,17 @@ typedef struct gdn_bc_plan gdn_bc_plan;
 int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **plan);
 int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *stats);
 int gdn_bc_plan_free(gdn_bc_plan *plan);
+/* Delta PageRank (gdn_pr_delta above) on resident graphs.  layout: GDN_LAYOUT_AUTO / _CSR / _PB of the pull's SpMV plan
+ * (pattern matrix of the in-CSR).  d_scores: m floats in (1/m) / out.  gdn_pr_delta_trace copies what the last run did per
+ * iteration -- L1 norm, frontier size after it, mode (0 pull, 1 push) -- into arrays of `capacity` entries (nullable) and
+ * sets *n to the number of iterations. */
+typedef struct gdn_pr_delta_plan gdn_pr_delta_plan;
+int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, int32_t layout, gdn_pr_delta_plan **plan);
+int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, double epsilon, float epsilon2,
+                     int32_t max_iter, int32_t push_div, gdn_stats *stats);
+int gdn_pr_delta_trace(const gdn_pr_delta_plan *plan, int32_t capacity, int32_t *n, double *diff, int32_t *items,
+                       int32_t *mode);
+int gdn_pr_delta_plan_free(gdn_pr_delta_plan *plan);
 /* Reusable BFS state for many searches on one resident graph.  dense != 0 (needs in_csr) also
  * builds the propagation-blocked layout of the in-CSR once, so that heavy levels run as one
  * streaming sweep over all in-edges instead of a bottom-up step (built outside the timed search,

@@ -953,3 +953,84 @@ def test_bc_plan_vs_oracle_rmat(orc, scale, ef, seed, sym, with_reverse):
     solvers.BCSolver(solvers.Graph(csr=g), sources[-1], scores2)
     _bc_close(scores, scores2)
     bc.close()
+
+
+# ------------------------------------------------------------------ delta PageRank
+def _prd_check(scores, tr, st, want, it, wtr):
+    """Same pull/push decisions and iteration count as the oracle; scores within 1e-4 relative.  The frontier test
+    |delta| > 1e-3 * score sits on fp32 values that differ from the sequential sums by an ulp or two, so a vertex ON the
+    threshold may fall on the other side: its delta (1e-3 of its score) is then pushed or not, which is why a handful of
+    scores are allowed the size of such a term and the frontier sizes a small slack."""
+    assert st["iterations"] == it
+    assert np.array_equal(tr["mode"], wtr["mode"])
+    assert np.all(np.abs(tr["items"].astype(np.int64) - wtr["items"]) <= 2 + wtr["items"] // 2000)
+    np.testing.assert_allclose(tr["diff"], wtr["diff"], rtol=1e-4, atol=1e-7)
+    rel = np.abs(scores - want) / np.maximum(np.abs(want), 1e-30)
+    assert np.count_nonzero(rel > REL_TOL) <= len(want) // 5000, rel.max()
+    assert rel.max() < 2e-3
+
+
+@pytest.mark.parametrize("case", ["test_pr", "chesapeake_sym", "test_bc_dir", "rmat10", "rmat12"])
+def test_pr_delta_golden(case):
+    """src/pr/omp_delta.cc run by the reference build itself (tests/golden/make_golden.py pr_delta)."""
+    d = golden("prdelta_" + case)
+    g = solvers.Graph(csr=csr_from(d), in_csr=csr_from(d, "in_"))
+    scores = np.full(g.V(), np.float32(1.0) / np.float32(g.V()), np.float32)
+    st = solvers.PRDeltaSolver(g, scores, push_div=10)
+    assert st["iterations"] + 1 == int(d["iterations_printed"])  # omp_delta.cc:105 prints iter + 1
+    np.testing.assert_allclose(scores, d["scores"], rtol=REL_TOL, atol=0)
+    assert abs(st["last_error"] - d["trace"][-1]) < 2e-6
+
+
+@pytest.mark.parametrize("scale,ef,seed", [(14, 16, 5), (17, 16, 6), (12, 64, 7)])
+@pytest.mark.parametrize("push_div", [8, 10, 2])
+def test_pr_delta_vs_oracle_rmat(orc, scale, ef, seed, push_div):
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    gi = graphio.transpose(g)
+    want, it, wtr = orc.pr_delta(gi, g, push_div=push_div)
+    if push_div == 2:
+        assert wtr["mode"].any()  # the push path is exercised
+    r = solvers.ResidentPRDelta(solvers.Graph(csr=g, in_csr=gi))
+    scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st, tr = r.run(scores, push_div=push_div)
+    r.close()
+    _prd_check(scores, tr, st, want, it, wtr)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_pr_delta_layouts_and_reruns(orc, layout):
+    """Both layouts of the pull's SpMV plan; a plan can be run again; pull-only runs repeat bit for bit."""
+    g = graphio.rmat_graph(16, 16, seed=21)
+    gi = graphio.transpose(g)
+    want, it, wtr = orc.pr_delta(gi, g, push_div=8)
+    r = solvers.ResidentPRDelta(solvers.Graph(csr=g, in_csr=gi), layout=layout)
+    runs = []
+    for _ in range(2):
+        scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st, tr = r.run(scores, push_div=8)
+        _prd_check(scores, tr, st, want, it, wtr)
+        runs.append((scores, tr))
+    k = int(np.argmax(wtr["mode"])) if wtr["mode"].any() else it  # iterations before the first push
+    assert np.array_equal(runs[0][1]["diff"][:k], runs[1][1]["diff"][:k])
+    if not wtr["mode"].any():
+        assert np.array_equal(runs[0][0], runs[1][0])
+    # max_iter cuts the run like the reference's loop condition
+    scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st, tr = r.run(scores, max_iter=3)
+    w3, it3, _ = orc.pr_delta(gi, g, push_div=8, max_iter=3)
+    assert st["iterations"] == it3 == 3
+    np.testing.assert_allclose(scores, w3, rtol=REL_TOL, atol=0)
+    r.close()
+
+
+def test_pr_delta_degenerate_graphs(orc):
+    """Vertices without out-edges (quotient by 0 in the reference, never read), without in-edges, an empty graph."""
+    for g in [graphio.build_csr(5, np.array([0, 0, 1, 3], np.int64), np.array([1, 2, 2, 2], np.int64)),
+              graphio.build_csr(4, np.zeros(0, np.int64), np.zeros(0, np.int64)),
+              graphio.build_csr(70000, np.arange(69999, dtype=np.int64), np.arange(1, 70000, dtype=np.int64))]:
+        gi = graphio.transpose(g)
+        want, it, wtr = orc.pr_delta(gi, g, push_div=8)
+        scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRDeltaSolver(solvers.Graph(csr=g, in_csr=gi), scores)
+        assert st["iterations"] == it
+        np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
