@@ -11,8 +11,13 @@
 //     propagation-blocked layout with its record tiers for graphs above 2^22 edges, whose SIGNED fixed-point
 //     accumulation takes the negative deltas the unsigned PageRank layout of gdn_pr.hip cannot; the result is the
 //     exactly-summed, once-rounded row sum (order independent, run-to-run identical);
-//   * push = the wave64 neighbour expansion of gdn_expand.hpp over the vertices flagged active, hardware fp32 atomic adds
-//     (global_atomic_add_f32) like the reference's atomicAdd -- the one order-dependent step, as in the reference;
+//   * push = what the reference's push computes -- sums[dst] = sum of the contributions of dst's in-neighbours IN THE
+//     FRONTIER -- in one of two ways, by the number of out-edges the frontier has (counted by the update kernel):
+//     a heavy frontier (>= nnz / 64 edges; GDN_PRD_PUSH_DIV) runs as the same pull with the contributions of the
+//     vertices outside the frontier masked to 0 -- 1.3 ms at RMAT-25 whatever the frontier, deterministic, where 3.4 M
+//     frontier vertices took 16 ms of fp32 atomics --; a light one runs the wave64 neighbour expansion of
+//     gdn_expand.hpp over the vertices flagged active with hardware fp32 atomic adds (global_atomic_add_f32) like the
+//     reference's atomicAdd, the one order-dependent step, as in the reference;
 //   * update + frontier + L1 norm are ONE kernel (the reference: update, Worklist2 push per vertex, l1norm): the frontier
 //     is a byte flag per vertex, not a queue -- a queue costs one hot-counter atomic per wave of vertices (~12 ns each on
 //     this chip, 25 ms at m = 2^27) and the push kernel's scan of m flags costs 0.03 ms --, counts and the norm go through
@@ -21,6 +26,7 @@
 #include "gdn_common.hpp"
 #include "gdn_expand.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -30,6 +36,7 @@
 struct PrdCounters {
   double diff;
   unsigned long long items;
+  unsigned long long edges;  // out-edges of the frontier
   unsigned big_count;
   unsigned overflow;
 };
@@ -44,6 +51,7 @@ struct gdn_pr_delta_plan {
   DevBuf<uint8_t> active;
   DevBuf<double> pdiff;
   DevBuf<unsigned> pitems;
+  DevBuf<unsigned long long> pedges;
   DevBuf<PrdCounters> cnt;
   DevBuf<unsigned long long> bigitems;
   unsigned bigcap = 0;
@@ -78,11 +86,13 @@ prd_init_kernel(int32_t m, float *__restrict__ sums, float *__restrict__ deltas,
 // delta.cu:40-45.  A vertex without out-edges is no row's source: its quotient (inf or nan in the reference) is never
 // read, and 0 keeps it out of the max |x| the fixed-point scale of the pull is taken from
 __global__ void __launch_bounds__(GDN_BLOCK)
-prd_contrib_kernel(const float *__restrict__ deltas, const int32_t *__restrict__ deg, int32_t m, float *__restrict__ contrib) {
+prd_contrib_kernel(const float *__restrict__ deltas, const int32_t *__restrict__ deg, int32_t m, float *__restrict__ contrib,
+                   const uint8_t *__restrict__ active /* nullable: only the frontier contributes (push semantics) */) {
   const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (v < (size_t)m) {
     const int32_t d = deg[v];
-    contrib[v] = d ? __fdiv_rn(deltas[v], (float)d) : 0.0f;
+    const bool on = d != 0 && (active == nullptr || active[v] != 0);
+    contrib[v] = on ? __fdiv_rn(deltas[v], (float)d) : 0.0f;
   }
 }
 
@@ -130,10 +140,13 @@ prd_push_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PrdPushVi
 template <bool FIRST>
 __global__ void __launch_bounds__(GDN_BLOCK)
 prd_update_kernel(int32_t m, float *__restrict__ scores, float *__restrict__ sums, float *__restrict__ deltas,
-                  uint8_t *__restrict__ active, float base_score, float init_score, float damping, float epsilon2,
-                  double *__restrict__ pdiff, unsigned *__restrict__ pitems) {
+                  uint8_t *__restrict__ active, const int32_t *__restrict__ deg, float base_score, float init_score,
+                  float damping, float epsilon2, double *__restrict__ pdiff, unsigned *__restrict__ pitems,
+                  unsigned long long *__restrict__ pedges) {
   __shared__ double s_d[GDN_WAVES_PER_BLOCK];
   __shared__ unsigned s_n[GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned long long s_e[GDN_WAVES_PER_BLOCK];
+  unsigned long long edges = 0;
   // a workgroup owns ONE contiguous range (fixed by m and the grid): its partial does not depend on scheduling
   const size_t per = (((size_t)m + PRD_GRID - 1) / PRD_GRID + 3) & ~(size_t)3;
   const size_t lo = (size_t)blockIdx.x * per;
@@ -150,31 +163,38 @@ prd_update_kernel(int32_t m, float *__restrict__ scores, float *__restrict__ sum
     const bool a = fabsf(d) > __fmul_rn(epsilon2, s);
     active[u] = a ? 1 : 0;
     items += a ? 1u : 0u;
+    edges += a ? (unsigned long long)(unsigned)deg[u] : 0ull;
     diff += (double)fabsf(d);
   }
   diff = gdn_block_sum(diff, s_d);
   items = gdn_block_sum(items, s_n);
+  edges = gdn_block_sum(edges, s_e);
   if (threadIdx.x == 0) {
     pdiff[blockIdx.x] = diff;
     pitems[blockIdx.x] = items;
+    pedges[blockIdx.x] = edges;
   }
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
-prd_reduce_kernel(const double *__restrict__ pdiff, const unsigned *__restrict__ pitems, PrdCounters *__restrict__ out) {
+prd_reduce_kernel(const double *__restrict__ pdiff, const unsigned *__restrict__ pitems,
+                  const unsigned long long *__restrict__ pedges, PrdCounters *__restrict__ out) {
   __shared__ double s_d[GDN_WAVES_PER_BLOCK];
   __shared__ unsigned long long s_n[GDN_WAVES_PER_BLOCK];
   double d = 0.0;
-  unsigned long long n = 0;
+  unsigned long long n = 0, e = 0;
   for (unsigned i = threadIdx.x; i < PRD_GRID; i += GDN_BLOCK) {
     d += pdiff[i];
     n += pitems[i];
+    e += pedges[i];
   }
   d = gdn_block_sum(d, s_d);
   n = gdn_block_sum(n, s_n);
+  e = gdn_block_sum(e, s_n);
   if (threadIdx.x == 0) {
     out->diff = d;
     out->items = n;
+    out->edges = e;
   }
 }
 
@@ -199,7 +219,7 @@ int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, 
     if ((rc = gdn_spmv_plan_create(in_csr, p->ones.p, layout, &p->sp))) break;
     if (layout == GDN_LAYOUT_PB) p->ones.release();  // the values live in the plan now
     if ((rc = p->deg.alloc(m)) || (rc = p->sums.alloc(m)) || (rc = p->deltas.alloc(m)) || (rc = p->contrib.alloc(m)) ||
-        (rc = p->active.alloc(m)) || (rc = p->pdiff.alloc(PRD_GRID)) || (rc = p->pitems.alloc(PRD_GRID)) ||
+        (rc = p->active.alloc(m)) || (rc = p->pdiff.alloc(PRD_GRID)) || (rc = p->pitems.alloc(PRD_GRID)) || (rc = p->pedges.alloc(PRD_GRID)) ||
         (rc = p->cnt.alloc(1)))
       break;
     const uint64_t bigcap64 = nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
@@ -249,6 +269,9 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
   big.count = &p.cnt.p->big_count;
   big.overflow = &p.cnt.p->overflow;
   long long nitems = m;
+  unsigned long long fedges = p.gin->nnz;  // out-edges of the frontier
+  unsigned long long heavy_div = 64;
+  if (const char *e = getenv("GDN_PRD_PUSH_DIV")) heavy_div = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;
   int iter = 0;
   uint64_t pull_iters = 0;
   PrdCounters h;
@@ -256,7 +279,8 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
   do {
     ++iter;
     const bool push = nitems < (long long)(m / push_div);  // delta.cu:178 (8), omp_delta.cc:69 (10)
-    if (push) {
+    const bool masked = push && fedges * heavy_div >= p.gin->nnz;  // heavy frontier: the pull, frontier terms only
+    if (push && !masked) {
       PrdPushVis vis;
       vis.colidx = p.gout->colidx;
       vis.deltas = p.deltas.p;
@@ -268,17 +292,18 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
       hipLaunchKernelGGL(prd_push_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p.gout->rowptr, big, vis);
       GDN_HIP(hipMemsetAsync(&p.cnt.p->big_count, 0, sizeof(unsigned), 0));
     } else {
-      hipLaunchKernelGGL(prd_contrib_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, p.deltas.p, p.deg.p, m, p.contrib.p);
+      hipLaunchKernelGGL(prd_contrib_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, p.deltas.p, p.deg.p, m, p.contrib.p,
+                         masked ? p.active.p : nullptr);
       GDN_TRY(gdn_spmv_dev(p.sp, p.ones.p, p.contrib.p, p.sums.p, nullptr));  // sums are 0 here: sums += A 1 contrib
       pull_iters++;
     }
     if (iter == 1)
       hipLaunchKernelGGL(prd_update_kernel<true>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.deltas.p,
-                         p.active.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p);
+                         p.active.p, p.deg.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p, p.pedges.p);
     else
       hipLaunchKernelGGL(prd_update_kernel<false>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.deltas.p,
-                         p.active.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p);
-    hipLaunchKernelGGL(prd_reduce_kernel, dim3(1), dim3(GDN_BLOCK), 0, 0, p.pdiff.p, p.pitems.p, p.cnt.p);
+                         p.active.p, p.deg.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p, p.pedges.p);
+    hipLaunchKernelGGL(prd_reduce_kernel, dim3(1), dim3(GDN_BLOCK), 0, 0, p.pdiff.p, p.pitems.p, p.pedges.p, p.cnt.p);
     GDN_HIP(hipGetLastError());
     GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));  // delta.cu:193,195: one read back per iteration
     if (h.overflow) {
@@ -286,9 +311,10 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
       return GDN_ERR_OVERFLOW;
     }
     nitems = (long long)h.items;
+    fedges = h.edges;
     p.tr_diff.push_back(h.diff);
     p.tr_items.push_back((int32_t)nitems);
-    p.tr_mode.push_back(push ? 1 : 0);
+    p.tr_mode.push_back(push ? (masked ? 3 : 1) : 0);
     if (h.diff < epsilon) break;  // delta.cu:197
   } while (nitems > 0 && iter < max_iter);
   GDN_HIP(hipDeviceSynchronize());
@@ -296,7 +322,7 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
   GDN_TRY(gdn_spmv_plan_check(p.sp));
   st.iterations = iter;  // delta.cu:200 (omp_delta.cc:105 prints iter + 1)
   st.last_error = h.diff;
-  st.edges_traversed = p.gin->nnz * pull_iters;  // the pushes' edges are not counted
+  st.edges_traversed = p.gin->nnz * pull_iters;  // sweeps over all edges; the atomic pushes' edges are not counted
   if (stats) *stats = st;
   return GDN_OK;
 }

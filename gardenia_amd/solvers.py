@@ -280,7 +280,8 @@ class ResidentPRDelta:
         diff, items, mode = np.zeros(max_iter), np.zeros(max_iter, np.int32), np.zeros(max_iter, np.int32)
         _cabi.check(self.L.gdn_pr_delta_trace(self.plan, max_iter, C.byref(n), _p(diff), _p(items), _p(mode)))
         k = n.value
-        return st.as_dict(), dict(diff=diff[:k], items=items[:k], mode=mode[:k])
+        # mode: 0 pull, 1 push (the reference's print); masked: the push ran as a pull of the frontier's terms
+        return st.as_dict(), dict(diff=diff[:k], items=items[:k], mode=mode[:k] & 1, masked=mode[:k] >> 1)
 
     def close(self):
         self.L.gdn_pr_delta_plan_free(self.plan)

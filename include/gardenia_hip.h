@@ -297,7 +297,8 @@ int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *st
 int gdn_bc_plan_free(gdn_bc_plan *plan);
 /* Delta PageRank (gdn_pr_delta above) on resident graphs.  layout: GDN_LAYOUT_AUTO / _CSR / _PB of the pull's SpMV plan
  * (pattern matrix of the in-CSR).  d_scores: m floats in (1/m) / out.  gdn_pr_delta_trace copies what the last run did per
- * iteration -- L1 norm, frontier size after it, mode (0 pull, 1 push) -- into arrays of `capacity` entries (nullable) and
+ * iteration -- L1 norm, frontier size after it, mode (0 pull, 1 push with atomics, 3 push semantics executed as a pull of the
+ * frontier's terms only: heavy frontiers) -- into arrays of `capacity` entries (nullable) and
  * sets *n to the number of iterations. */
 typedef struct gdn_pr_delta_plan gdn_pr_delta_plan;
 int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, int32_t layout, gdn_pr_delta_plan **plan);

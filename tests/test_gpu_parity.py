@@ -984,7 +984,10 @@ def test_pr_delta_golden(case):
 
 @pytest.mark.parametrize("scale,ef,seed", [(14, 16, 5), (17, 16, 6), (12, 64, 7)])
 @pytest.mark.parametrize("push_div", [8, 10, 2])
-def test_pr_delta_vs_oracle_rmat(orc, scale, ef, seed, push_div):
+@pytest.mark.parametrize("heavy_div", ["1", "64", "1000000000"])
+def test_pr_delta_vs_oracle_rmat(orc, monkeypatch, scale, ef, seed, push_div, heavy_div):
+    """heavy_div (GDN_PRD_PUSH_DIV): 1 = every push with atomics, 10^9 = every push as a pull of the frontier's terms."""
+    monkeypatch.setenv("GDN_PRD_PUSH_DIV", heavy_div)
     g = graphio.rmat_graph(scale, ef, seed=seed)
     gi = graphio.transpose(g)
     want, it, wtr = orc.pr_delta(gi, g, push_div=push_div)
@@ -995,6 +998,9 @@ def test_pr_delta_vs_oracle_rmat(orc, scale, ef, seed, push_div):
     st, tr = r.run(scores, push_div=push_div)
     r.close()
     _prd_check(scores, tr, st, want, it, wtr)
+    if heavy_div != "64" and wtr["mode"][:-1].any():
+        pushes = tr["mode"] == 1
+        assert np.array_equal(tr["masked"][pushes][:-1], np.full(pushes.sum() - 1, int(heavy_div != "1")))
 
 
 @pytest.mark.parametrize("layout", [0, 1])

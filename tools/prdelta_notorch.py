@@ -38,8 +38,8 @@ for rep in range(3):
                                      items.ctypes.data_as(C.c_void_p), mode.ctypes.data_as(C.c_void_p)))
     _cabi.check(L.gdn_dev_download(out.ctypes.data_as(C.c_void_p), scores, 4 * m))
     k = n.value
-    print("delta PR RMAT-%d: %.3f ms, %d iterations (%d pull, %d push), %.3f ms/iteration, last L1 %.3e, crc %08x" % (
-        scale, st.solve_ms, st.iterations, int((mode[:k] == 0).sum()), int(mode[:k].sum()), st.solve_ms / st.iterations,
+    print("delta PR RMAT-%d: %.3f ms, %d iterations (%d pull, %d push as masked pull, %d push with atomics), %.3f ms/iteration, last L1 %.3e, crc %08x" % (
+        scale, st.solve_ms, st.iterations, int((mode[:k] == 0).sum()), int((mode[:k] == 3).sum()), int((mode[:k] == 1).sum()), st.solve_ms / st.iterations,
         st.last_error, zlib.crc32(out.tobytes())), flush=True)
 print("  frontier after each iteration:", items[:k].tolist())
 print("  L1 norm of the deltas:", ["%.2e" % d for d in diff[:k]])
