@@ -33,6 +33,7 @@ typedef int32_t VertexId;
 #define kDistInf (UINT_MAX / 2)
 #define EPSILON 0.0001
 const float kDamp = 0.85f;
+const float epsilon2 = 0.001f;  // src/pr/pr.h:8
 #define MAX_ITER 100
 
 class VertexSet {  // include/csr_graph.h:13-37 (the slice of it the solvers/verifiers use)
@@ -94,6 +95,7 @@ VertexId read_mtx_edges(const std::string &fname, std::vector<VertexId> &src, st
 // ---- solvers: each is ONE call through the C-ABI (solvers.cc)
 void BFSSolver(Graph &g, int source, DistT *dist);
 void PRSolver(Graph &g, ScoreT *scores);
+void PRDeltaSolver(Graph &g, ScoreT *scores);  // the delta variant, src/pr/delta.cu:140 (pr_delta_hip)
 void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y);
 void SSSPSolver(Graph &g, int source, DistT *weight, DistT *dist, int delta);
 void CCSolver(Graph &g, CompT *comp);

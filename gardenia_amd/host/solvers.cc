@@ -32,6 +32,42 @@ void PRSolver(Graph &g, ScoreT *scores) {  // src/pr/pr.h:31
   printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
 }
 
+// The delta variant of PRSolver (src/pr/delta.cu:140; link-time choice in the reference, src/pr/Makefile): prints the
+// reference's per-iteration "pull:" / "push:" lines.
+void PRDeltaSolver(Graph &g, ScoreT *scores) {
+  gdn_graph *gi = nullptr, *go = nullptr;
+  gdn_pr_delta_plan *plan = nullptr;
+  void *d_scores = nullptr;
+  const uint64_t bytes = sizeof(ScoreT) * (uint64_t)g.V();
+  gdn_stats st;
+  try {
+    must(gdn_graph_upload(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), &gi), "PRDeltaSolver");
+    must(gdn_graph_upload(g.V(), g.E(), g.out_rowptr(), g.out_colidx(), &go), "PRDeltaSolver");
+    must(gdn_pr_delta_plan_create(gi, go, GDN_LAYOUT_AUTO, &plan), "PRDeltaSolver");
+    must(gdn_dev_alloc(bytes, &d_scores), "PRDeltaSolver");
+    must(gdn_dev_upload(d_scores, scores, bytes), "PRDeltaSolver");
+    must(gdn_pr_delta_run(plan, (float *)d_scores, kDamp, EPSILON, epsilon2, MAX_ITER, 8, &st), "PRDeltaSolver");
+    must(gdn_dev_download(scores, d_scores, bytes), "PRDeltaSolver");
+    std::vector<double> diff(MAX_ITER);
+    std::vector<int32_t> mode(MAX_ITER);
+    int32_t n = 0;
+    must(gdn_pr_delta_trace(plan, MAX_ITER, &n, diff.data(), nullptr, mode.data()), "PRDeltaSolver");
+    for (int32_t i = 0; i < n; i++) printf("%s %2d    %lf\n", (mode[i] & 1) ? "push:" : "pull:", i + 1, diff[i]);
+  } catch (...) {
+    if (d_scores) gdn_dev_free(d_scores);
+    if (plan) gdn_pr_delta_plan_free(plan);
+    if (go) gdn_graph_free(go);
+    if (gi) gdn_graph_free(gi);
+    throw;
+  }
+  gdn_dev_free(d_scores);
+  gdn_pr_delta_plan_free(plan);
+  gdn_graph_free(go);
+  gdn_graph_free(gi);
+  printf("\titerations = %d.\n", st.iterations);
+  printf("\truntime [hip_gfx950_delta] = %f ms.\n", st.solve_ms);
+}
+
 void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y) {  // src/spmv/spmv.h:29
   gdn_stats st;
   must(gdn_spmv(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), Ax, x, y, &st), "SpmvSolver");

@@ -21,7 +21,7 @@ def run(exe, *args):
 
 
 def test_mains_exist_and_load_graphs_like_the_reference():
-    for k in ("bfs", "pr", "spmv", "sssp", "cc", "tc", "bc"):
+    for k in ("bfs", "pr", "pr_delta", "spmv", "sssp", "cc", "tc", "bc"):
         assert os.path.exists(os.path.join(BIN, k + "_hip")), "run __graft_entry__.build()"
     rc, out = run("bfs_hip", "mtx", os.path.join(G, "test_bc"), 1, 0, 0)
     assert "|V| 7 |E| 26" in out  # BASELINE.md known answer
@@ -37,6 +37,8 @@ def test_mains_print_correct(tmp_path):
              ("bfs_hip", ["mtx", os.path.join(G, "chesapeake"), 1, 0, 0]),
              ("pr_hip", ["mtx", os.path.join(G, "test_pr"), 0]),
              ("pr_hip", ["mtx", os.path.join(G, "chesapeake"), 1]),
+             ("pr_delta_hip", ["mtx", os.path.join(G, "test_pr"), 0]),
+             ("pr_delta_hip", ["mtx", os.path.join(G, "chesapeake"), 1]),
              ("spmv_hip", ["mtx", os.path.join(G, "test_bc"), 0, 1]),
              ("sssp_hip", ["mtx", os.path.join(G, "test_bc"), 0, 0, 0, 1]),
              ("cc_hip", ["mtx", os.path.join(G, "test_cc"), 1, 0]),
@@ -48,6 +50,7 @@ def test_mains_print_correct(tmp_path):
     graphio.write_bin(str(tmp_path / "rms"), graphio.symmetrize(g))
     s = graphio.first_nonisolated(g)
     cases += [("bfs_hip", ["bin", tmp_path / "rm", 0, 1, s]), ("pr_hip", ["bin", tmp_path / "rm", 0]),
+              ("pr_delta_hip", ["bin", tmp_path / "rm", 0]),
               ("sssp_hip", ["bin", tmp_path / "rm", 0, 0, s, 2]), ("cc_hip", ["bin", tmp_path / "rms", 1, 0]),
               ("tc_hip", [tmp_path / "rms"]), ("spmv_hip", ["bin", tmp_path / "rm", 0, 1]),
               ("bc_hip", ["bin", tmp_path / "rm", 0, 0, s]), ("bc_hip", ["bin", tmp_path / "rms", 1, 0, s])]
@@ -58,3 +61,6 @@ def test_mains_print_correct(tmp_path):
     assert "iterations = 15." in out  # test/reference/graph-pr.mtx.out:28
     rc, out = run("tc_hip", "mtx", os.path.join(G, "chesapeake"))
     assert "total_num_triangles = 194" in out
+    rc, out = run("pr_delta_hip", "mtx", os.path.join(G, "chesapeake"), 1)
+    # the reference's own run of src/pr/omp_delta.cc on this graph: 12 pull iterations, last L1 norm 0.000359
+    assert out.count("pull:") == 12 and "pull: 12    0.000359" in out and "iterations = 12." in out
