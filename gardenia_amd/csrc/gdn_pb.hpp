@@ -640,7 +640,8 @@ pb_hubrow_reduce_kernel(const unsigned long long *__restrict__ partial, unsigned
   }
 }
 
-// phase A with a per-edge factor (SpMV): vals[8*G[g] + i] = A[8*g + i] * x[chunk*CH + U[8*g + i]]
+// phase A with a per-edge factor (SpMV): vals[8*G[g] + i] = A[8*g + i] * x[chunk*CH + U[8*g + i]]; A == nullptr: the
+// pattern matrix (factor 1, no value stream)
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk,
                         const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
@@ -706,7 +707,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
       const eoff_t hh = h + (eoff_t)r * PB_THREADS;
       if (hh < h1) {
         u[r] = __builtin_nontemporal_load(U4 + hh);
-        a[r] = __builtin_nontemporal_load(A4 + hh);
+        if (A) a[r] = __builtin_nontemporal_load(A4 + hh);
         d[r] = __builtin_nontemporal_load(G + (hh >> lq));
       }
     }
@@ -715,10 +716,16 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
       const eoff_t hh = h + (eoff_t)r * PB_THREADS;
       if (hh < h1) {
         pb_f32x4 o;
-        o.x = __fmul_rn(s_x[u[r].x], a[r].x);
-        o.y = __fmul_rn(s_x[u[r].y], a[r].y);
-        o.z = __fmul_rn(s_x[u[r].z], a[r].z);
-        o.w = __fmul_rn(s_x[u[r].w], a[r].w);
+        o.x = s_x[u[r].x];
+        o.y = s_x[u[r].y];
+        o.z = s_x[u[r].z];
+        o.w = s_x[u[r].w];
+        if (A) {
+          o.x = __fmul_rn(o.x, a[r].x);
+          o.y = __fmul_rn(o.y, a[r].y);
+          o.z = __fmul_rn(o.z, a[r].z);
+          o.w = __fmul_rn(o.w, a[r].w);
+        }
         X4[(((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask)] = o;
       }
     }

@@ -7,7 +7,7 @@
 // sum = 0, and the L1 norm of the deltas is the convergence test (delta.cu:187-197).
 //
 // How it runs here:
-//   * pull = one SpMV with the pattern matrix of the in-CSR (values 1) on the SpMV plan of gdn_spmv.hip: the
+//   * pull = one SpMV with the pattern matrix of the in-CSR on the SpMV plan of gdn_spmv.hip: the value-free form of the
 //     propagation-blocked layout with its record tiers for graphs above 2^22 edges, whose SIGNED fixed-point
 //     accumulation takes the negative deltas the unsigned PageRank layout of gdn_pr.hip cannot; the result is the
 //     exactly-summed, once-rounded row sum (order independent, run-to-run identical);
@@ -45,7 +45,7 @@ struct gdn_pr_delta_plan {
   const gdn_graph *gin = nullptr, *gout = nullptr;
   gdn_spmv_plan *sp = nullptr;
   int32_t layout = 0;
-  DevBuf<float> ones;  // CSR layout: the pattern's values (the PB layout keeps them inside the plan)
+  DevBuf<float> ones;  // CSR layout: the pattern's values (the PB layout is built value-free)
   DevBuf<int32_t> deg;
   DevBuf<float> sums, deltas, contrib;
   DevBuf<uint8_t> active;
@@ -214,10 +214,11 @@ int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, 
   do {
     if (layout == GDN_LAYOUT_AUTO) layout = nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
     p->layout = layout;
-    if ((rc = p->ones.alloc(nnz ? nnz : 1))) break;
-    hipLaunchKernelGGL(prd_fill_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p->ones.p, (size_t)nnz, 1.0f);
+    if (layout == GDN_LAYOUT_CSR) {  // the merge-path kernel reads a value per nonzero; the PB layout has a pattern form
+      if ((rc = p->ones.alloc(nnz ? nnz : 1))) break;
+      hipLaunchKernelGGL(prd_fill_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p->ones.p, (size_t)nnz, 1.0f);
+    }
     if ((rc = gdn_spmv_plan_create(in_csr, p->ones.p, layout, &p->sp))) break;
-    if (layout == GDN_LAYOUT_PB) p->ones.release();  // the values live in the plan now
     if ((rc = p->deg.alloc(m)) || (rc = p->sums.alloc(m)) || (rc = p->deltas.alloc(m)) || (rc = p->contrib.alloc(m)) ||
         (rc = p->active.alloc(m)) || (rc = p->pdiff.alloc(PRD_GRID)) || (rc = p->pitems.alloc(PRD_GRID)) || (rc = p->pedges.alloc(PRD_GRID)) ||
         (rc = p->cnt.alloc(1)))

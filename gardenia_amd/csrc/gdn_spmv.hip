@@ -36,6 +36,7 @@ struct gdn_spmv_plan {
     DevBuf<uint32_t> ids, rec;
     DevBuf<float> val, Ax;
   } mid[PB_MAX_MID];
+  bool pattern = false;  // PB layout of a 0/1 matrix: no Ax stream
   DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] max row length
   DevBuf<float> scale;  // PB: [0] = 2^shift, [1] = 2^-shift (per call)
 };
@@ -152,8 +153,9 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
     else layout = (d_Ax != nullptr && csr->nnz >= (1ull << 22)) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
   }
-  GDN_REQUIRE(layout == GDN_LAYOUT_CSR || d_Ax != nullptr, "the PB layout stores Ax inside the plan: pass d_Ax");
+  // PB without values = the PATTERN matrix (every nonzero 1): no value stream in either phase (delta PageRank's pull)
   gdn_spmv_plan *p = new gdn_spmv_plan();
+  p->pattern = layout == GDN_LAYOUT_PB && d_Ax == nullptr;
   p->layout = layout;
   p->m = csr->m;
   p->n_cols = n_cols;
@@ -205,7 +207,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
         gdn_set_error("gdn_spmv_plan_create: mid layout %d does not line up with the main layout", t);
         st = GDN_ERR_INVALID;
       }
-      if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec, &mt.Ax);
+      if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec, p->pattern ? nullptr : &mt.Ax);
       if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
       if (st == GDN_OK) {
         mt.n = n_mid[t];
@@ -222,14 +224,18 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       int nt = 0;
       if (p->has_hub) tp[nt++] = p->hub.bin_ptr.p;
       for (int t = 0; t < p->n_mid_tiers; t++) tp[nt++] = p->mid[t].layout.bin_ptr.p;
-      st = pb_order_bins_by_work(p->pb, nt, tp, 6.0, 8.0, 8.0);
+      st = pb_order_bins_by_work(p->pb, nt, tp, 6.0, p->pattern ? 4.0 : 8.0, 8.0);
     }
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
     if (st == GDN_OK) {
       (void)hipMemset(p->mx.p, 0, 16);
-      if (csr->nnz)
+      if (p->pattern) {
+        const float one = 1.0f;
+        (void)hipMemcpy(p->mx.p, &one, 4, hipMemcpyHostToDevice);  // max |Ax| = 1
+      } else if (csr->nnz) {
         hipLaunchKernelGGL(spmv_absmax_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_Ax, (size_t)csr->nnz, p->mx.p);
+      }
       hipLaunchKernelGGL(spmv_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->m, p->mx.p + 2);
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
@@ -283,7 +289,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
-                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->Axp.p, pb.vals.p,
+                     pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, plan->pattern ? nullptr : plan->Axp.p, pb.vals.p,
                      pb.log_group, pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr,
                      pb.chunk_slots, plan->mx.p + 1);
   PbMidArgs mid = PbMidArgs();
@@ -293,7 +299,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
     mid.ptr[mid.n] = plan->hub.bin_ptr.p;
     mid.rec[mid.n] = plan->hub_rec.p;
     mid.val[mid.n] = plan->hub_val.p;
-    mid.A[mid.n] = plan->hub_Ax.p;
+    mid.A[mid.n] = plan->pattern ? nullptr : plan->hub_Ax.p;
     mid.zrec[mid.n] = plan->n_hubs << PB_MID_ROW_BITS;
     mid.form[mid.n++] = 1;
   }
@@ -303,7 +309,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
     mid.ptr[mid.n] = plan->mid[t].layout.bin_ptr.p;
     mid.rec[mid.n] = plan->mid[t].rec.p;
     mid.val[mid.n] = plan->mid[t].val.p;
-    mid.A[mid.n] = plan->mid[t].Ax.p;
+    mid.A[mid.n] = plan->pattern ? nullptr : plan->mid[t].Ax.p;
     mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
     mid.form[mid.n++] = 0;
   }
@@ -383,7 +389,7 @@ int gdn_spmv_plan_check(gdn_spmv_plan *plan) {
 uint64_t gdn_spmv_bytes(const gdn_spmv_plan *plan) {
   if (!plan) return 0;
   const uint64_t m = (uint64_t)plan->m, nnz = plan->nnz;
-  return 8 * (m + 1) + 12 * nnz + 8 * m;
+  return 8 * (m + 1) + (plan->pattern ? 8 : 12) * nnz + 8 * m;
 }
 
 // Host API: one call == SpmvSolver(g, Ax, x, y) (src/spmv/main.cc:39).

@@ -1040,3 +1040,43 @@ def test_pr_delta_degenerate_graphs(orc):
         st = solvers.PRDeltaSolver(solvers.Graph(csr=g, in_csr=gi), scores)
         assert st["iterations"] == it
         np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+
+
+@pytest.mark.parametrize("tiers", ["0", "2"])
+def test_spmv_pattern_plan_equals_unit_values(orc, monkeypatch, tiers):
+    """GDN_LAYOUT_PB without values = the pattern matrix: the same bits as the plan that stores Ax = 1."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    if tiers == "2":
+        monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    else:
+        monkeypatch.setenv("GDN_PB_HUBS", "0")
+    g = graphio.transpose(graphio.rmat_graph(16, 16, seed=31))
+    rng = np.random.default_rng(3)
+    x = (rng.random(g.m, dtype=np.float32) - np.float32(0.5)) * np.float32(3.0)
+    L = _cabi.lib()
+    h = C.c_void_p()
+    rp, ci = np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32)
+    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), C.byref(h)))
+    dA, dx, dy = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    ones = np.ones(g.nnz, np.float32)
+    for d, a in ((dA, ones), (dx, x), (dy, np.zeros(g.m, np.float32))):
+        _cabi.check(L.gdn_dev_alloc(a.nbytes, C.byref(d)))
+        _cabi.check(L.gdn_dev_upload(d, a.ctypes.data_as(C.c_void_p), a.nbytes))
+    outs = []
+    for ax in (dA, None):
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_spmv_plan_create(h, ax, _cabi.GDN_LAYOUT_PB, C.byref(plan)))
+        y = np.zeros(g.m, np.float32)
+        _cabi.check(L.gdn_dev_upload(dy, y.ctypes.data_as(C.c_void_p), y.nbytes))
+        _cabi.check(L.gdn_spmv_dev(plan, None, dx, dy, None))
+        _cabi.check(L.gdn_spmv_plan_check(plan))
+        _cabi.check(L.gdn_dev_download(y.ctypes.data_as(C.c_void_p), dy, y.nbytes))
+        outs.append(y)
+        L.gdn_spmv_plan_free(plan)
+    for d in (dA, dx, dy):
+        L.gdn_dev_free(d)
+    L.gdn_graph_free(h)
+    assert np.array_equal(outs[0], outs[1])
+    want = orc.spmv(g, ones, x, np.zeros(g.m, np.float32))
+    np.testing.assert_allclose(outs[1], want, rtol=REL_TOL, atol=1e-5)
