@@ -109,7 +109,7 @@ __global__ void bc_seed_kernel(int32_t source, int32_t *depth, int32_t *pc, vid_
 
 // one term of src/bc/omp_base.cc:87-88, in the reference's operation order and without contraction
 __device__ __forceinline__ float bc_term(float pcs, int32_t pcd, float delta_dst) {
-  return __fmul_rn(__fdiv_rn(pcs, (float)pcd), __fadd_rn(1.0f, delta_dst));
+  return gdn_fmul(__fdiv_rn(pcs, (float)pcd), gdn_fadd(1.0f, delta_dst));
 }
 
 // What the backward sweep reads of a successor, in ONE 16-byte record (one divergent access per edge instead of three):
@@ -167,10 +167,10 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
+      for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
+    for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
     if ((int)lane == leader) acc = part;
   }
   // short rows: one lane, CSR order, the reference's arithmetic (the loads of BC_UNR edges in flight, added in order)
@@ -183,12 +183,12 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) acc = __fadd_rn(acc, t[r]);
+      for (int r = 0; r < BC_UNR; r++) acc = gdn_fadd(acc, t[r]);
     }
   }
   if (i < nf && !is_big) {
     rec[v].z = __float_as_int(acc);
-    scores[v] = __fadd_rn(scores[v], acc);
+    scores[v] = gdn_fadd(scores[v], acc);
   }
 }
 
@@ -214,18 +214,18 @@ bc_back_big_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
+      for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
+    for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
     __syncthreads();
     if (gdn_lane() == 0) s_red[threadIdx.x >> 6] = part;
     __syncthreads();
     if (threadIdx.x == 0) {
       float t = 0.0f;
-      for (int w = 0; w < BC_BIG_THREADS / 64; w++) t = __fadd_rn(t, s_red[w]);
+      for (int w = 0; w < BC_BIG_THREADS / 64; w++) t = gdn_fadd(t, s_red[w]);
       rec[v].z = __float_as_int(t);
-      scores[v] = __fadd_rn(scores[v], t);
+      scores[v] = gdn_fadd(scores[v], t);
     }
   }
 }
@@ -305,9 +305,9 @@ struct BcBackOp {  // epilogue of the backward sweep: rows at depth `level` get 
   __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{rec[row]}; }
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
     if (p.r.x == level) {
-      const float dl = __fmul_rn((float)p.r.y, __fmul_rn(sum, unscale));
+      const float dl = gdn_fmul((float)p.r.y, gdn_fmul(sum, unscale));
       rec[row].z = __float_as_int(dl);
-      scores[row] = __fadd_rn(scores[row], dl);
+      scores[row] = gdn_fadd(scores[row], dl);
     }
     return 0.0;
   }
@@ -398,7 +398,7 @@ bc_x_fwd_kernel(const int32_t *__restrict__ depth, const int32_t *__restrict__ p
 }
 
 // backward sweep: w[v] = (1 + delta[v]) / pc[v] of the vertices at depth next_level; first its maximum, then x = w * scale
-__device__ __forceinline__ float bc_w(const bc_i32x4 r) { return __fdiv_rn(__fadd_rn(1.0f, __int_as_float(r.z)), (float)r.y); }
+__device__ __forceinline__ float bc_w(const bc_i32x4 r) { return __fdiv_rn(gdn_fadd(1.0f, __int_as_float(r.z)), (float)r.y); }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 bc_w_max_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level, unsigned *__restrict__ out) {
@@ -424,7 +424,7 @@ bc_x_back_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level
   float xv = 0.0f;
   if (r.x == next_level) {
     const float w = bc_w(r);
-    if (w >= 0.0f && w < 3.0e38f) xv = __fmul_rn(w, scale);
+    if (w >= 0.0f && w < 3.0e38f) xv = gdn_fmul(w, scale);
     else *odd = 1u;  // a non-finite term: this level falls back to the gather path (same arithmetic as the reference)
   }
   x[v] = xv;
@@ -467,10 +467,10 @@ bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) part = __fadd_rn(part, t[r]);
+      for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = __fadd_rn(part, __shfl_xor(part, o, 64));
+    for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
     if ((int)lane == leader) acc = part;
   }
   if (mine && deg < BC_WAVE_ROW) {
@@ -482,12 +482,12 @@ bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) acc = __fadd_rn(acc, t[r]);
+      for (int r = 0; r < BC_UNR; r++) acc = gdn_fadd(acc, t[r]);
     }
   }
   if (mine && !is_big) {
     rec[v].z = __float_as_int(acc);
-    scores[v] = __fadd_rn(scores[v], acc);
+    scores[v] = gdn_fadd(scores[v], acc);
   }
 }
 

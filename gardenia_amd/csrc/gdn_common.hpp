@@ -123,6 +123,24 @@ int gdn_fill_i32(int32_t *d, int32_t v, size_t n, hipStream_t s);
 // ------------------------------------------------------------------------------------------
 // wave64 primitives
 // ------------------------------------------------------------------------------------------
+// IEEE single-precision operations the compiler must NOT contract into an fma.  hipcc compiles with
+// -ffp-contract=fast-honor-pragmas and the __fmul_rn / __fadd_rn of <__clang_hip_math.h> are plain operators, so
+// __fadd_rn(score, __fmul_rn(d, sum)) became ONE v_fmac_f32 -- a single rounding where the reference's CPU solvers
+// (g++ -O3 for baseline x86-64: no fma) round twice.  Wherever a result is compared with the reference operation by
+// operation, multiply with gdn_fmul: a product without the `contract` flag cannot be fused into the add that uses it.
+__device__ __forceinline__ float gdn_fmul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float gdn_fadd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float gdn_fsub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
+
 __device__ __forceinline__ unsigned gdn_lane() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }

@@ -144,7 +144,7 @@ mp_tile_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
     outv[s] = 0.0f;
     if (dd + s < total) {
       if ((unsigned)tj < re) {
-        running = __fadd_rn(running, s_val[tj + (tj >> 5)]);
+        running = gdn_fadd(running, s_val[tj + (tj >> 5)]);
         tj++;
       } else {
         outv[s] = running;
@@ -167,7 +167,7 @@ mp_tile_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
     const float pv = __shfl_up(v, o, 64);
     const int pf = __shfl_up(f, o, 64);
     if (lane >= (unsigned)o) {
-      if (!f) v = __fadd_rn(pv, v);
+      if (!f) v = gdn_fadd(pv, v);
       f |= pf;
     }
   }
@@ -177,8 +177,8 @@ mp_tile_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
   }
   __syncthreads();  // also: every thread is done reading s_val
   float open_prev = 0.0f;
-  for (unsigned ww = 0; ww < w; ww++) open_prev = s_wave_f[ww] ? s_wave_v[ww] : __fadd_rn(open_prev, s_wave_v[ww]);
-  const float open = f ? v : __fadd_rn(open_prev, v);
+  for (unsigned ww = 0; ww < w; ww++) open_prev = s_wave_f[ww] ? s_wave_v[ww] : gdn_fadd(open_prev, s_wave_v[ww]);
+  const float open = f ? v : gdn_fadd(open_prev, v);
   float carry_in = __shfl_up(open, 1, 64);
   if (lane == 0) carry_in = open_prev;
   if (tid == GDN_BLOCK - 1) tile_carry[t] = open;
@@ -190,7 +190,7 @@ mp_tile_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
 #pragma unroll
     for (int s = 0; s < MP_IPT; s++) {
       if (emit_mask & (1u << s)) {
-        s_val[r] = first ? __fadd_rn(carry_in, outv[s]) : outv[s];
+        s_val[r] = first ? gdn_fadd(carry_in, outv[s]) : outv[s];
         first = false;
         r++;
       }
@@ -227,8 +227,8 @@ mp_fixup_kernel(const eoff_t *__restrict__ rowptr, const int32_t *__restrict__ t
         uint32_t ts = t - 1;
         while (ts > 0 && tile_row[ts] == i0) ts--;
         float sum = 0.0f;
-        for (uint32_t tt = ts; tt < t; tt++) sum = __fadd_rn(sum, tile_carry[tt]);
-        sum = __fadd_rn(sum, tile_head[t]);
+        for (uint32_t tt = ts; tt < t; tt++) sum = gdn_fadd(sum, tile_carry[tt]);
+        sum = gdn_fadd(sum, tile_head[t]);
         d = op.finish(i0, sum);
       }
     }

@@ -721,10 +721,10 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
         o.z = s_x[u[r].z];
         o.w = s_x[u[r].w];
         if (A) {
-          o.x = __fmul_rn(o.x, a[r].x);
-          o.y = __fmul_rn(o.y, a[r].y);
-          o.z = __fmul_rn(o.z, a[r].z);
-          o.w = __fmul_rn(o.w, a[r].w);
+          o.x = gdn_fmul(o.x, a[r].x);
+          o.y = gdn_fmul(o.y, a[r].y);
+          o.z = gdn_fmul(o.z, a[r].z);
+          o.w = gdn_fmul(o.w, a[r].w);
         }
         X4[(((size_t)d[r]) << lq) + (size_t)((unsigned)hh & qmask)] = o;
       }
@@ -931,7 +931,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
 #pragma unroll
             for (int k = 0; k < 8; k++) {
               if (k > 0 && hu[r][k] != hu[r][k - 1]) xv = hub_val[hu[r][k]];
-              atomicAdd(&s_acc[hv[r][k]], op.to_fixed(__fmul_rn(xv, av[k]), bad));
+              atomicAdd(&s_acc[hv[r][k]], op.to_fixed(gdn_fmul(xv, av[k]), bad));
             }
           }
         }
@@ -986,7 +986,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         for (int r = 0; r < MUNR; r++) f[r] = T[rc[r] >> PB_MID_ROW_BITS];
 #pragma unroll
         for (int r = 0; r < MUNR; r++)
-          atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(FA ? __fmul_rn(f[r], a[r]) : f[r], bad));
+          atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(FA ? gdn_fmul(f[r], a[r]) : f[r], bad));
       }
       continue;
     }
@@ -1019,7 +1019,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
           const unsigned d = (rc[r][j] >> PB_MID_ROW_BITS) - k0;
           float f = d == 0 ? w[r].x : (d == 1 ? w[r].y : (d == 2 ? w[r].z : w[r].w));
           if (d > 3u) f = T[rc[r][j] >> PB_MID_ROW_BITS];  // also a source in FRONT of k0 (never in a sorted stream)
-          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(FA4 ? __fmul_rn(f, a[r][j]) : f, bad));
+          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(FA4 ? gdn_fmul(f, a[r][j]) : f, bad));
         }
       }
     }

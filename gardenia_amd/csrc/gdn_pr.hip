@@ -89,10 +89,10 @@ struct PrOp {
   };
   __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{scores[row], out_degree[row]}; }
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
-    const float new_score = __fadd_rn(base_score, __fmul_rn(damping, sum));
+    const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
     scores[row] = new_score;
     contrib_out[row] = __fdiv_rn(new_score, (float)p.deg);
-    return (double)fabsf(__fsub_rn(new_score, p.old_score));
+    return (double)fabsf(gdn_fsub(new_score, p.old_score));
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
   // 16-byte row accesses of the PB epilogue (pb_epilogue4); vec_ok = all three row arrays 16-byte aligned
@@ -109,10 +109,10 @@ struct PrOp {
     double d = 0.0;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      const float new_score = __fadd_rn(base_score, __fmul_rn(damping, sum[c]));
+      const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum[c]));
       ns[c] = new_score;
       nc[c] = __fdiv_rn(new_score, (float)p.deg[c]);
-      d += (double)fabsf(__fsub_rn(new_score, p.old_score[c]));
+      d += (double)fabsf(gdn_fsub(new_score, p.old_score[c]));
     }
     *reinterpret_cast<pb_f32x4 *>(scores + row) = ns;
     *reinterpret_cast<pb_f32x4 *>(contrib_out + row) = nc;
@@ -220,7 +220,7 @@ pr_dead_diff_kernel(const float *__restrict__ scores, const uint32_t *__restrict
                     double *__restrict__ out) {
   double acc = 0.0;
   for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += (size_t)gridDim.x * GDN_BLOCK)
-    if (!((bits[v >> 5] >> (v & 31u)) & 1u)) acc += (double)fabsf(__fsub_rn(base, scores[v]));
+    if (!((bits[v >> 5] >> (v & 31u)) & 1u)) acc += (double)fabsf(gdn_fsub(base, scores[v]));
   acc = gdn_wave_sum(acc);
   if (gdn_lane() == 0 && acc != 0.0) atomicAdd(out, acc);
 }

@@ -47,7 +47,7 @@ struct gdn_pr_delta_plan {
   int32_t layout = 0;
   DevBuf<float> ones;  // CSR layout: the pattern's values (the PB layout is built value-free)
   DevBuf<int32_t> deg;
-  DevBuf<float> sums, deltas, contrib;
+  DevBuf<float> sums, contrib, masked;  // masked: allocated by the first push that runs as a pull
   DevBuf<uint8_t> active;
   DevBuf<double> pdiff;
   DevBuf<unsigned> pitems;
@@ -73,40 +73,36 @@ prd_fill_kernel(float *__restrict__ p, size_t n, float v) {
   for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) p[i] = v;
 }
 
-// delta.cu:15-22
+// delta.cu:15-22 with the first contrib (delta = 1/m).  A vertex without out-edges is no row's source: its quotient (inf
+// or nan in the reference) is never read, and 0 keeps it out of the max |x| the fixed-point scale of the pull is taken from
 __global__ void __launch_bounds__(GDN_BLOCK)
-prd_init_kernel(int32_t m, float *__restrict__ sums, float *__restrict__ deltas, float init_score) {
+prd_init_kernel(int32_t m, float *__restrict__ sums, float *__restrict__ contrib, const int32_t *__restrict__ deg, float init_score) {
   const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (v < (size_t)m) {
     sums[v] = 0.0f;
-    deltas[v] = init_score;
+    const int32_t d = deg[v];
+    contrib[v] = d ? __fdiv_rn(init_score, (float)d) : 0.0f;
   }
 }
 
-// delta.cu:40-45.  A vertex without out-edges is no row's source: its quotient (inf or nan in the reference) is never
-// read, and 0 keeps it out of the max |x| the fixed-point scale of the pull is taken from
+// delta.cu:40-45 (contrib = delta / degree) is part of the update kernel below.  A push that runs as a pull of the
+// frontier's terms reads this masked copy instead: only the frontier contributes
 __global__ void __launch_bounds__(GDN_BLOCK)
-prd_contrib_kernel(const float *__restrict__ deltas, const int32_t *__restrict__ deg, int32_t m, float *__restrict__ contrib,
-                   const uint8_t *__restrict__ active /* nullable: only the frontier contributes (push semantics) */) {
+prd_mask_kernel(const float *__restrict__ contrib, const uint8_t *__restrict__ active, int32_t m, float *__restrict__ masked) {
   const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (v < (size_t)m) {
-    const int32_t d = deg[v];
-    const bool on = d != 0 && (active == nullptr || active[v] != 0);
-    contrib[v] = on ? __fdiv_rn(deltas[v], (float)d) : 0.0f;
-  }
+  if (v < (size_t)m) masked[v] = active[v] ? contrib[v] : 0.0f;
 }
 
 // delta.cu:24-38 on the expansion tiers of gdn_expand.hpp
 struct PrdPushVis {
   const vid_t *__restrict__ colidx;
-  const float *__restrict__ deltas;
-  const int32_t *__restrict__ deg;
+  const float *__restrict__ contrib;  // delta / out-degree, written by the update kernel
   float *__restrict__ sums;
   float c;
   int big;
   __device__ __forceinline__ void begin_big(vid_t v) {
     big = 1;
-    c = __fdiv_rn(deltas[v], (float)deg[v]);
+    c = contrib[v];
   }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     const float cc = big ? c : __shfl(c, owner, 64);
@@ -124,7 +120,7 @@ prd_push_kernel(const eoff_t *__restrict__ rowptr, int32_t m, const uint8_t *__r
   if (v < (unsigned)m && active[v]) {
     b = rowptr[v];
     e = rowptr[v + 1];
-    if (e > b) vis.c = __fdiv_rn(vis.deltas[v], (float)(int32_t)(e - b));
+    vis.c = vis.contrib[v];
   }
   gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
 }
@@ -139,7 +135,7 @@ prd_push_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, PrdPushVi
 // delta.cu:103-129 (update_first / update), the frontier test and l1norm (:131-138) in one pass
 template <bool FIRST>
 __global__ void __launch_bounds__(GDN_BLOCK)
-prd_update_kernel(int32_t m, float *__restrict__ scores, float *__restrict__ sums, float *__restrict__ deltas,
+prd_update_kernel(int32_t m, float *__restrict__ scores, float *__restrict__ sums, float *__restrict__ contrib,
                   uint8_t *__restrict__ active, const int32_t *__restrict__ deg, float base_score, float init_score,
                   float damping, float epsilon2, double *__restrict__ pdiff, unsigned *__restrict__ pitems,
                   unsigned long long *__restrict__ pedges) {
@@ -154,16 +150,17 @@ prd_update_kernel(int32_t m, float *__restrict__ scores, float *__restrict__ sum
   double diff = 0.0;
   unsigned items = 0;
   for (size_t u = lo + threadIdx.x; u < hi; u += GDN_BLOCK) {
-    float d = __fmul_rn(damping, sums[u]);
-    if (FIRST) d = __fsub_rn(__fadd_rn(base_score, d), init_score);
-    const float s = __fadd_rn(scores[u], d);
-    deltas[u] = d;
+    float d = gdn_fmul(damping, sums[u]);
+    if (FIRST) d = gdn_fsub(gdn_fadd(base_score, d), init_score);
+    const float s = gdn_fadd(scores[u], d);
+    const int32_t dg = deg[u];
+    contrib[u] = dg ? __fdiv_rn(d, (float)dg) : 0.0f;  // the next iteration's contribution (delta.cu:43, :32)
     scores[u] = s;
     sums[u] = 0.0f;
-    const bool a = fabsf(d) > __fmul_rn(epsilon2, s);
+    const bool a = fabsf(d) > gdn_fmul(epsilon2, s);
     active[u] = a ? 1 : 0;
     items += a ? 1u : 0u;
-    edges += a ? (unsigned long long)(unsigned)deg[u] : 0ull;
+    edges += a ? (unsigned long long)(unsigned)dg : 0ull;
     diff += (double)fabsf(d);
   }
   diff = gdn_block_sum(diff, s_d);
@@ -219,7 +216,7 @@ int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, 
       hipLaunchKernelGGL(prd_fill_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p->ones.p, (size_t)nnz, 1.0f);
     }
     if ((rc = gdn_spmv_plan_create(in_csr, p->ones.p, layout, &p->sp))) break;
-    if ((rc = p->deg.alloc(m)) || (rc = p->sums.alloc(m)) || (rc = p->deltas.alloc(m)) || (rc = p->contrib.alloc(m)) ||
+    if ((rc = p->deg.alloc(m)) || (rc = p->sums.alloc(m)) || (rc = p->contrib.alloc(m)) ||
         (rc = p->active.alloc(m)) || (rc = p->pdiff.alloc(PRD_GRID)) || (rc = p->pitems.alloc(PRD_GRID)) || (rc = p->pedges.alloc(PRD_GRID)) ||
         (rc = p->cnt.alloc(1)))
       break;
@@ -261,7 +258,7 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
   p.tr_items.clear();
   p.tr_mode.clear();
   HostTimer tsolve;
-  hipLaunchKernelGGL(prd_init_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, m, p.sums.p, p.deltas.p, init_score);
+  hipLaunchKernelGGL(prd_init_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, m, p.sums.p, p.contrib.p, p.deg.p, init_score);
   GDN_HIP(hipDeviceSynchronize());
   tsolve.start();  // delta.cu:174
   ExpBigList big;
@@ -284,8 +281,7 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
     if (push && !masked) {
       PrdPushVis vis;
       vis.colidx = p.gout->colidx;
-      vis.deltas = p.deltas.p;
-      vis.deg = p.deg.p;
+      vis.contrib = p.contrib.p;
       vis.sums = p.sums.p;
       vis.c = 0.0f;
       vis.big = 0;
@@ -293,16 +289,20 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
       hipLaunchKernelGGL(prd_push_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, p.gout->rowptr, big, vis);
       GDN_HIP(hipMemsetAsync(&p.cnt.p->big_count, 0, sizeof(unsigned), 0));
     } else {
-      hipLaunchKernelGGL(prd_contrib_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, p.deltas.p, p.deg.p, m, p.contrib.p,
-                         masked ? p.active.p : nullptr);
-      GDN_TRY(gdn_spmv_dev(p.sp, p.ones.p, p.contrib.p, p.sums.p, nullptr));  // sums are 0 here: sums += A 1 contrib
+      const float *x = p.contrib.p;
+      if (masked) {
+        if (!p.masked.p) GDN_TRY(p.masked.alloc(m));
+        hipLaunchKernelGGL(prd_mask_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, p.contrib.p, p.active.p, m, p.masked.p);
+        x = p.masked.p;
+      }
+      GDN_TRY(gdn_spmv_dev(p.sp, p.ones.p, x, p.sums.p, nullptr));  // sums are 0 here: sums += A x
       pull_iters++;
     }
     if (iter == 1)
-      hipLaunchKernelGGL(prd_update_kernel<true>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.deltas.p,
+      hipLaunchKernelGGL(prd_update_kernel<true>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.contrib.p,
                          p.active.p, p.deg.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p, p.pedges.p);
     else
-      hipLaunchKernelGGL(prd_update_kernel<false>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.deltas.p,
+      hipLaunchKernelGGL(prd_update_kernel<false>, dim3(PRD_GRID), dim3(GDN_BLOCK), 0, 0, m, d_scores, p.sums.p, p.contrib.p,
                          p.active.p, p.deg.p, base_score, init_score, damping, epsilon2, p.pdiff.p, p.pitems.p, p.pedges.p);
     hipLaunchKernelGGL(prd_reduce_kernel, dim3(1), dim3(GDN_BLOCK), 0, 0, p.pdiff.p, p.pitems.p, p.pedges.p, p.cnt.p);
     GDN_HIP(hipGetLastError());

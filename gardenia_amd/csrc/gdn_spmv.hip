@@ -46,14 +46,14 @@ struct SpmvOp {
   const float *__restrict__ x;
   float *__restrict__ y;
   __device__ __forceinline__ float load(uint64_t j, vid_t col) const {
-    return __fmul_rn(x[col], __builtin_nontemporal_load(Ax + j));
+    return gdn_fmul(x[col], __builtin_nontemporal_load(Ax + j));
   }
   struct Pre {
     float y;
   };
   __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{y[row]}; }
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
-    y[row] = __fadd_rn(p.y, sum);
+    y[row] = gdn_fadd(p.y, sum);
     return 0.0;
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
@@ -65,7 +65,7 @@ struct SpmvOp {
   __device__ __forceinline__ double fin4(int32_t row, const float (&sum)[4], const Pre4 &p) const {
     pb_f32x4 o;
 #pragma unroll
-    for (int c = 0; c < 4; c++) o[c] = __fadd_rn(p.y[c], sum[c]);
+    for (int c = 0; c < 4; c++) o[c] = gdn_fadd(p.y[c], sum[c]);
     *reinterpret_cast<pb_f32x4 *>(y + row) = o;
     return 0.0;
   }
@@ -75,7 +75,7 @@ struct SpmvOp {
     return pb_to_fixed_signed(v, scale[0], bad);
   }
   __device__ __forceinline__ float from_fixed(unsigned long long a, unsigned &) const {
-    return __fmul_rn((float)(long long)a, scale[1]);
+    return gdn_fmul((float)(long long)a, scale[1]);
   }
 };
 

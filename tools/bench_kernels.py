@@ -87,6 +87,27 @@ def main():
             "gteps": nnz * (it + 1) / dt / 1e9, "algorithmic_GBps": b * (it + 1) / dt / 1e9,
             "roofline_frac": b * (it + 1) / dt / 1e9 / HBM}
         L.gdn_pr_plan_free(plan)
+    # delta PageRank (src/pr/delta.cu) to ITS stop on the same graph.  Byte model per sweep over all
+    # edges (pull, or a push run as a masked pull): 8(m+1) + 8 nnz + 8 m (the pattern SpMV) + 21 m (contrib r/w + degree,
+    # update: sums r/w, scores r/w, delta w, flag w, degree r)
+    dplan = C.c_void_p()
+    _cabi.check(L.gdn_pr_delta_plan_create(gi, go, _cabi.GDN_LAYOUT_AUTO, C.byref(dplan)))
+    for _ in range(2):
+        scores = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_pr_delta_run(dplan, ptr(scores), 0.85, 1e-4, 1e-3, 100, 8, C.byref(st)))
+    n = C.c_int32()
+    mode = (C.c_int32 * 100)()
+    _cabi.check(L.gdn_pr_delta_trace(dplan, 100, C.byref(n), None, None, mode))
+    sweeps = sum(1 for i in range(n.value) if mode[i] != 1)
+    b = (8 * (m + 1) + 8 * nnz + 8 * m + 21 * m) * sweeps
+    res[f"pr_delta_rmat{args.pr_scale}"] = {
+        "iterations": st.iterations, "pull": sum(1 for i in range(n.value) if mode[i] == 0),
+        "push_as_masked_pull": sum(1 for i in range(n.value) if mode[i] == 3),
+        "push_with_atomics": sum(1 for i in range(n.value) if mode[i] == 1), "solve_ms": st.solve_ms,
+        "ms_per_iter": st.solve_ms / st.iterations, "last_l1": st.last_error, "model_GBps": b / st.solve_ms / 1e6,
+        "roofline_frac": b / st.solve_ms / 1e6 / HBM}
+    L.gdn_pr_delta_plan_free(dplan)
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
     del deg, scores, c
