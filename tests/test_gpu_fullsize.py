@@ -8,6 +8,8 @@ properties -- the oracle cannot run at this size inside a test:
             edge (u,v) with u reached has depth[v] <= depth[u]+1; every reached v != source has
             depth >= 1; TEPS numerator = sum of out-degrees of the reached vertices
   SSSP      unit weights: distances == BFS depths (R-MAT scale 25)
+  delta PR  pull-only iterates equal the plain solver's iterates, the L1 trace equals a torch recomputation, runs repeat
+            bit for bit, the converged vector stays within the variant's stop of the plain solver's (R-MAT scale 27)
   BC        the resident plan (BFS depths + propagation-blocked heavy levels) and the queue-based path agree within the
             reference verifier's tolerance on R-MAT scale 27; the largest score is 1, unreached vertices score 0
   graph     the device generator's CSR has ascending, duplicate-free, self-loop-free rows
@@ -172,3 +174,58 @@ def test_bc_plan_equals_queue_path_at_full_size(big):
     assert bool(((ad - bd).abs() <= 1e-4 * (ad.abs() + bd.abs()) + 1e-4).all())
     assert float(a.max()) == 1.0 and float(b.max()) == 1.0
     assert float(a.min()) >= 0.0 and float(b.min()) >= 0.0
+
+
+def test_delta_pagerank_at_full_size(big):
+    """Delta PageRank on R-MAT scale 27 through properties that need no oracle:
+    while every iteration is a pull, score_k = 1/m + sum of the deltas IS the plain pull PageRank's k-th iterate (the
+    two solvers share nothing but the graph: signed fixed-point SpMV plan on all vertices vs the unsigned layout on the
+    live ones); the reported L1 norm of the deltas equals sum |score_k - score_(k-1)|; runs without an atomic push repeat
+    bit for bit; the converged vector stays within the variant's own stop of the plain solver's."""
+    torch, L, cabi, dev, m = big["torch"], big["L"], big["cabi"], big["dev"], big["m"]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    dplan = C.c_void_p()
+    cabi.check(L.gdn_pr_delta_plan_create(big["gi"], big["go"], cabi.GDN_LAYOUT_AUTO, C.byref(dplan)))
+
+    def delta_run(max_iter):
+        s = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+        st = cabi.GdnStats()
+        cabi.check(L.gdn_pr_delta_run(dplan, p(s), 0.85, 1e-4, 1e-3, max_iter, 8, C.byref(st)))
+        n = C.c_int32()
+        diff, mode = np.zeros(100), np.zeros(100, np.int32)
+        cabi.check(L.gdn_pr_delta_trace(dplan, 100, C.byref(n), diff.ctypes.data_as(C.c_void_p), None,
+                                        mode.ctypes.data_as(C.c_void_p)))
+        return s, st, diff[:n.value], mode[:n.value]
+
+    plan = C.c_void_p()
+    cabi.check(L.gdn_pr_plan_create(big["gi"], p(big["deg"]), m, 0, 1, C.byref(plan)))
+    scores = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+    c = [torch.zeros(m, dtype=torch.float32, device=dev) for _ in range(2)]
+    dd = torch.zeros(1, dtype=torch.float64, device=dev)
+    cabi.check(L.gdn_pr_contrib_dev(plan, p(scores), p(c[0]), None))
+    prev = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+    for k in range(1, 4):
+        cabi.check(L.gdn_pr_pull_dev(plan, p(c[(k - 1) & 1]), p(scores), p(c[k & 1]), p(dd), 0.85, None))
+        s, st, diff, mode = delta_run(k)
+        assert st.iterations == k and not mode.any()  # pulls only this early
+        rel = ((s - scores).abs() / scores).max()
+        assert float(rel) < 2e-5, (k, float(rel))
+        if k > 1:
+            l1 = float((s - prev).abs().double().sum())
+            assert abs(l1 - diff[-1]) < 1e-5 * l1, (k, l1, diff[-1])
+        prev = s
+    # to convergence
+    a, st, diff, mode = delta_run(100)
+    b, st2, diff2, mode2 = delta_run(100)
+    assert st.iterations == st2.iterations and np.array_equal(mode, mode2)
+    if not (mode == 1).any():
+        assert torch.equal(a, b) and np.array_equal(diff, diff2)
+    for k in range(4, 21):
+        cabi.check(L.gdn_pr_pull_dev(plan, p(c[(k - 1) & 1]), p(scores), p(c[k & 1]), p(dd), 0.85, None))
+    torch.cuda.synchronize()
+    l1 = float((a - scores).abs().double().sum())
+    assert l1 < 2e-3, l1  # rank mass is ~0.47 here; the variant drops deltas below 1e-3 of a score
+    assert abs(float(a.double().sum()) - float(scores.double().sum())) < 2e-3
+    cabi.check(L.gdn_pr_plan_check(plan))
+    L.gdn_pr_plan_free(plan)
+    L.gdn_pr_delta_plan_free(dplan)
