@@ -43,7 +43,9 @@
 
 #include "gdn_common.hpp"
 
+#ifndef PB_THREADS
 #define PB_THREADS 1024
+#endif
 #define PB_WAVES (PB_THREADS / 64)
 #define PB_MAX_LOG_CHUNK 15  // 32768 floats = 128 KB of LDS
 #define PB_MAX_LOG_BIN 14    // 16384 u64    = 128 KB of LDS
