@@ -120,6 +120,8 @@ PROTOTYPES = {
     "gdn_sssp_run": (C.c_int, [_vp, _i32, _i32, _vp, _st]),
     "gdn_cc_dev": (C.c_int, [_vp, _vp, _vp, _st]),
     "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),
+    "gdn_graph_orient": (C.c_int, [_vp, _pp]),
+    "gdn_tc_rows_dev": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64), _st]),
 }
 
 _lib = None

@@ -267,11 +267,11 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 #endif
 
 __global__ void __launch_bounds__(GDN_BLOCK)
-tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ items,
+tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t row_lo, int32_t row_hi, unsigned long long *__restrict__ items,
                       unsigned capacity, unsigned *__restrict__ n_items, unsigned *__restrict__ overflow) {
-  const unsigned u = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned u = (unsigned)row_lo + blockIdx.x * GDN_BLOCK + threadIdx.x;  // source rows [row_lo, row_hi)
   eoff_t du = 0;
-  if (u < (unsigned)m) du = rowptr[u + 1] - rowptr[u];
+  if (u < (unsigned)row_hi) du = rowptr[u + 1] - rowptr[u];
   const unsigned n = du > TC_LIGHT ? (unsigned)((du + TC_SLICE - 1) / TC_SLICE) : 0u;
   // wave-aggregated reservation: one atomic per wave
   const unsigned incl = gdn_wave_incl_scan(n);
@@ -401,11 +401,54 @@ static int tc_orient(const gdn_graph *g, gdn_graph **out) {
 
 extern "C" {
 
+// triangles closed over the source rows [row_lo, row_hi) of an oriented graph (the light-row cursor starts at row_lo and
+// the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
+static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st) {
+  DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
+  DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
+  const uint64_t cap64 = dag->nnz / TC_LIGHT + 1024;  // a heavy row of du > TC_LIGHT ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT items
+  const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
+  HostTimer tprep, tsolve;
+  tprep.start();
+  GDN_TRY(d_total.alloc(1));
+  GDN_TRY(d_items.alloc(cap));
+  GDN_TRY(d_ctl.alloc(4));
+  const unsigned ctl0[4] = {0u, (unsigned)row_lo, 0u, 0u};
+  GDN_HIP(hipMemset(d_total.p, 0, 8));
+  GDN_HIP(hipMemcpy(d_ctl.p, ctl0, 16, hipMemcpyHostToDevice));
+  st.prep_ms += tprep.stop_ms();
+  *total = 0;
+  if (row_hi <= row_lo) return GDN_OK;
+  tsolve.start();  // src/tc/gpu_base.cu:52-58
+  const uint64_t rows = (uint64_t)(row_hi - row_lo);
+  hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, row_lo, row_hi,
+                     d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
+  unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
+  if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
+  hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, row_hi, d_items.p,
+                     d_ctl.p + 2, d_ctl.p, d_total.p);
+  unsigned long long h = 0;
+  unsigned ctl[4] = {0, 0, 0, 0};
+  if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(ctl, d_ctl.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+    gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+    return GDN_ERR_HIP;
+  }
+  if (ctl[3]) {
+    gdn_set_error("gdn_tc: heavy-row work list overflow");
+    return GDN_ERR_OVERFLOW;
+  }
+  st.solve_ms = tsolve.stop_ms();
+  *total = h;
+  st.iterations = 1;
+  return GDN_OK;
+}
+
 int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats *stats) {
   GDN_REQUIRE(g != nullptr && total != nullptr, "graph / total");
   gdn_stats st;
   memset(&st, 0, sizeof(st));
-  HostTimer tprep, tsolve;
+  HostTimer tprep;
   const gdn_graph *dag = g;
   gdn_graph *own = nullptr;
   tprep.start();
@@ -413,39 +456,35 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
     GDN_TRY(tc_orient(g, &own));
     dag = own;
   }
-  DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
-  DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
-  const uint64_t cap64 = dag->nnz / TC_LIGHT + 1024;  // a heavy row of du > TC_LIGHT ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT items
-  const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
-  int rc = d_total.alloc(1);
-  if (rc == GDN_OK) rc = d_items.alloc(cap);
-  if (rc == GDN_OK) rc = d_ctl.alloc(4);
-  if (rc == GDN_OK && (hipMemset(d_total.p, 0, 8) != hipSuccess || hipMemset(d_ctl.p, 0, 16) != hipSuccess)) rc = GDN_ERR_HIP;
   st.prep_ms = tprep.stop_ms();
-  if (rc == GDN_OK) {
-    tsolve.start();  // src/tc/gpu_base.cu:52-58
-    hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks((uint64_t)dag->m)), dim3(GDN_BLOCK), 0, 0, dag->rowptr,
-                       dag->m, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
-    unsigned nb = gdn_nblocks((uint64_t)dag->m, GDN_WAVES_PER_BLOCK * 16);
-    if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
-    hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, d_items.p,
-                       d_ctl.p + 2, d_ctl.p, d_total.p);
-    unsigned long long h = 0;
-    unsigned ctl[4] = {0, 0, 0, 0};
-    if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(ctl, d_ctl.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
-      gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));
-      rc = GDN_ERR_HIP;
-    } else if (ctl[3]) {
-      gdn_set_error("gdn_tc: heavy-row work list overflow");
-      rc = GDN_ERR_OVERFLOW;
-    }
-    st.solve_ms = tsolve.stop_ms();
-    *total = h;
-    st.iterations = 1;
-    st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
-  }
+  const int rc = tc_count_rows(dag, 0, dag->m, total, st);
+  st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
   if (own) gdn_graph_free(own);
+  if (stats) *stats = st;
+  return rc;
+}
+
+// The DAG orientation alone (src/common/graph.cc:67-113): what `Graph g(prefix, USE_DAG)` hands to TCSolver.
+int gdn_graph_orient(const gdn_graph *g, gdn_graph **dag) {
+  GDN_REQUIRE(g != nullptr && dag != nullptr, "graph / dag");
+  *dag = nullptr;
+  return tc_orient(g, dag);
+}
+
+// Triangles whose lowest-ranked vertex lies in the row range [row_lo, row_hi) of an ORIENTED graph: the shard of a
+// multi-GPU count (every rank holds the DAG, the ranges partition its rows, the partial counts add up).
+int gdn_tc_rows_dev(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats *stats) {
+  GDN_REQUIRE(dag != nullptr && total != nullptr, "graph / total");
+  GDN_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= dag->m, "row range");
+  gdn_stats st;
+  memset(&st, 0, sizeof(st));
+  const int rc = tc_count_rows(dag, row_lo, row_hi, total, st);
+  if (rc == GDN_OK) {
+    eoff_t b[2] = {0, 0};
+    GDN_HIP(hipMemcpy(&b[0], dag->rowptr + row_lo, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    GDN_HIP(hipMemcpy(&b[1], dag->rowptr + row_hi, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    st.edges_traversed = b[1] - b[0];  // DAG edges of the range
+  }
   if (stats) *stats = st;
   return rc;
 }

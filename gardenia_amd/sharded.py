@@ -383,3 +383,70 @@ class HipSpMVBackend:
             self._cabi.check(self.L.gdn_spmv_plan_check(self.plan))
             self.L.gdn_spmv_plan_free(self.plan)
             self.plan = C.c_void_p()
+
+
+def edge_balanced_ranges(rowptr, world: int):
+    """Row ranges [lo,hi) of `world` ranks with about nnz/world edges each (binary search on the row offsets).
+    rowptr: numpy array of m+1 offsets."""
+    import numpy as np
+    rp = np.asarray(rowptr).astype(np.int64)
+    m, nnz = len(rp) - 1, int(rp[-1])
+    bounds = [0]
+    for r in range(1, world):
+        b = int(np.searchsorted(rp, nnz * r // world, side="left"))
+        bounds.append(min(max(b, bounds[-1]), m))
+    bounds.append(m)
+    return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+class ShardedTC:
+    """Triangle count over `world` ranks: every rank holds the oriented graph, counts the
+    triangles whose lowest-ranked vertex lies in its row range -- ranges of equal DAG-edge count -- and ONE 8-byte
+    all-reduce(sum) gives the total.  No other exchange: the count reads the whole DAG but writes nothing shared."""
+
+    def __init__(self, backend, dag_rowptr, rank: int = 0, world: int = 1, dist=None):
+        self.be, self.rank, self.world, self.dist = backend, rank, world, dist
+        self.ranges = edge_balanced_ranges(dag_rowptr, world)
+        self.lo, self.hi = self.ranges[rank]
+
+    def count(self) -> int:
+        local = int(self.be.count_rows(self.lo, self.hi))
+        if self.world <= 1:
+            return local
+        import torch
+        t = torch.tensor([local], dtype=torch.int64, device=self.be.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return int(t.item())
+
+
+class HipTCBackend:
+    """The oriented graph resident on one MI355X (gdn_graph_orient unless already a DAG) + gdn_tc_rows_dev."""
+
+    def __init__(self, graph_handle, oriented: bool, device):
+        from . import _cabi
+        self._cabi, self.L, self.device = _cabi, _cabi.lib(), device
+        self.own = C.c_void_p()
+        self.dag = graph_handle
+        if not oriented:
+            _cabi.check(self.L.gdn_graph_orient(graph_handle, C.byref(self.own)))
+            self.dag = self.own
+        self.last_ms = 0.0
+
+    def rowptr(self):
+        import numpy as np
+        m, nnz, rp = C.c_int32(), C.c_uint64(), C.c_void_p()
+        self._cabi.check(self.L.gdn_graph_info(self.dag, C.byref(m), C.byref(nnz), C.byref(rp), None))
+        h = np.empty(m.value + 1, np.uint64)
+        self._cabi.check(self.L.gdn_dev_download(h.ctypes.data_as(C.c_void_p), rp, 8 * (m.value + 1)))
+        return h
+
+    def count_rows(self, lo: int, hi: int) -> int:
+        total, st = C.c_uint64(0), self._cabi.GdnStats()
+        self._cabi.check(self.L.gdn_tc_rows_dev(self.dag, lo, hi, C.byref(total), C.byref(st)))
+        self.last_ms = st.solve_ms
+        return int(total.value)
+
+    def close(self):
+        if self.own:
+            self.L.gdn_graph_free(self.own)
+            self.own = C.c_void_p()

@@ -331,6 +331,12 @@ int gdn_sssp_run(gdn_sssp_plan *plan, int32_t source, int32_t delta, int32_t *d_
 int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,
                gdn_stats *stats);
 int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stats *stats);
+/* The DAG orientation alone (src/common/graph.cc:67-113, what `Graph g(prefix, USE_DAG)` hands to TCSolver), and the count
+ * over the source rows [row_lo, row_hi) of an ORIENTED graph: the shard of a multi-GPU count -- every rank holds the DAG,
+ * the ranges partition its rows (by DAG-edge count), the partial counts add up (gardenia_amd.sharded.ShardedTC).
+ * stats.edges_traversed = DAG edges of the range. */
+int gdn_graph_orient(const gdn_graph *csr, gdn_graph **dag);
+int gdn_tc_rows_dev(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats *stats);
 
 #ifdef __cplusplus
 }

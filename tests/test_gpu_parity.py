@@ -1080,3 +1080,30 @@ def test_spmv_pattern_plan_equals_unit_values(orc, monkeypatch, tiers):
     assert np.array_equal(outs[0], outs[1])
     want = orc.spmv(g, ones, x, np.zeros(g.m, np.float32))
     np.testing.assert_allclose(outs[1], want, rtol=REL_TOL, atol=1e-5)
+
+
+@pytest.mark.parametrize("world", [1, 2, 5])
+def test_tc_row_range_shards_add_up(orc, world):
+    """The multi-GPU triangle count on one device: the DAG is oriented once (gdn_graph_orient), every 'rank' counts the
+    rows of its edge-balanced range (gdn_tc_rows_dev), the partial counts add up to the oracle's total."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    from gardenia_amd.sharded import HipTCBackend, ShardedTC
+    g = graphio.symmetrize(graphio.rmat_graph(15, 16, seed=41))
+    want = orc.tc(orc.tc_orient(g))
+    L = _cabi.lib()
+    h = C.c_void_p()
+    rp, ci = np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32)
+    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), C.byref(h)))
+    be = HipTCBackend(h, oriented=False, device=None)
+    drp = be.rowptr()
+    assert np.array_equal(drp, orc.tc_orient(g).rowptr)  # the device orientation is the reference's
+    parts = [ShardedTC(be, drp, r, world, dist=None) for r in range(world)]
+    assert parts[0].lo == 0 and parts[-1].hi == g.m and all(a.hi == b.lo for a, b in zip(parts, parts[1:]))
+    got = [be.count_rows(p.lo, p.hi) for p in parts]
+    assert sum(got) == want > 0
+    if world > 1:
+        assert max(got) < want  # a proper split
+    assert be.count_rows(7, 7) == 0
+    be.close()
+    L.gdn_graph_free(h)

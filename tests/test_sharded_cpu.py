@@ -98,3 +98,36 @@ def test_sharded_spmv_gloo(orc, tmp_path, world):
     want = orc.spmv(g, Ax, x, y0)
     got = np.concatenate([np.load(f"{out}.{r}.npy") for r in range(world)])
     np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)
+
+
+def test_edge_balanced_ranges():
+    from gardenia_amd.sharded import edge_balanced_ranges
+    rp = np.array([0, 0, 10, 10, 11, 30, 30, 31, 40], np.uint64)
+    for w in (1, 2, 3, 8, 11):
+        r = edge_balanced_ranges(rp, w)
+        assert len(r) == w and r[0][0] == 0 and r[-1][1] == 8
+        assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(r, r[1:]))
+    assert edge_balanced_ranges(rp, 2) == [(0, 5), (5, 8)]  # the first row boundary at or behind nnz / 2 edges
+    assert edge_balanced_ranges(np.zeros(4, np.uint64), 3)[-1] == (0, 3)  # no edges: everything to the last rank
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_tc_gloo(orc, tmp_path, world):
+    """Row ranges of equal DAG-edge count, partial counts, one all-reduce."""
+    scale, ef = 7, 8
+    out = str(tmp_path / "tc.npy")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_tc_worker.py"),
+                                       str(scale), str(ef), out], env=env))
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=78))
+    dag = graphio.orient_dag(g)
+    want = orc.tc(dag)
+    got = np.load(out)
+    assert int(got[0]) == want > 0
+    assert 0 == got[1] < got[2] < dag.m  # rank 0 counted a proper part

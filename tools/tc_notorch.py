@@ -23,3 +23,21 @@ for r in range(reps):
     print("RMAT-%d sym: |V| %d |E| %d dag %d triangles %d count %.3f ms orient %.3f ms  %.3f G dag edges/s" % (
         scale, m.value, nnz.value, st.edges_traversed, total.value, st.solve_ms, st.prep_ms,
         st.edges_traversed / st.solve_ms / 1e6))
+# the row-range shards of a multi-GPU count, one after the other on this device (balance check): tc_notorch.py S reps N
+if len(sys.argv) > 3:
+    from gardenia_amd.sharded import HipTCBackend, ShardedTC
+    world = int(sys.argv[3])
+    be = HipTCBackend(gs, oriented=False, device=None)
+    rp = be.rowptr()
+    ms, cnt = [], []
+    for r in range(world):
+        p = ShardedTC(be, rp, r, world, dist=None)
+        best = 1e30
+        for _ in range(2):
+            c = be.count_rows(p.lo, p.hi)
+            best = min(best, be.last_ms)
+        ms.append(best)
+        cnt.append(c)
+    print("%d row-range shards of equal DAG-edge count: sum %d, ms per shard %s, max/mean %.2f" % (
+        world, sum(cnt), ["%.2f" % t for t in ms], max(ms) / (sum(ms) / world)))
+    be.close()
