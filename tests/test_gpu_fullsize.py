@@ -22,7 +22,9 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-SCALE = 27
+import os
+
+SCALE = int(os.environ.get("GDN_FULLSIZE_SCALE", "27"))  # 28 (4.26 G edges, beyond 2^32 in every edge offset) also runs
 
 
 @pytest.fixture(scope="module")
@@ -57,7 +59,7 @@ def _view(torch, ptr, n, dtype, dev):
 
 def test_generated_graph_is_clean(big):
     torch, m, nnz = big["torch"], big["m"], big["nnz"]
-    assert m == 1 << SCALE and 2_000_000_000 < nnz < 2_147_483_648
+    assert m == 1 << SCALE and 15 * m < nnz < 16 * m
     rp = _view(torch, big["out_rowptr"], m + 1, torch.int64, big["dev"])
     ci = _view(torch, big["out_colidx"], nnz, torch.int32, big["dev"])
     assert int(rp[0]) == 0 and int(rp[-1]) == nnz and bool((rp[1:] >= rp[:-1]).all())
