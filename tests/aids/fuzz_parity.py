@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep: N random graphs (random size, density, skew, isolated vertices, stars, chains) through every
+drop-in solver of the C-ABI, each result against the CPU oracle.  Exit code 1 on the first mismatch (the seed is printed).
+
+    python tests/aids/fuzz_parity.py [n_graphs] [first_seed]
+
+The oracle is the CHECKER here (tests/ infrastructure); nothing of it is on the measured or shipped path."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from gardenia_amd import graphio, solvers
+from oracle import binding as orc
+
+REL = 1e-4
+
+
+def random_graph(rng):
+    kind = rng.integers(0, 6)
+    m = int(rng.integers(1, 6000)) if rng.random() < 0.8 else int(rng.integers(6000, 150000))
+    if kind == 0:    # uniform
+        n = int(rng.integers(0, 12 * m + 1))
+        src, dst = rng.integers(0, m, n), rng.integers(0, m, n)
+    elif kind == 1:  # skewed: a few hubs on both sides
+        n = int(rng.integers(0, 16 * m + 1))
+        src = (rng.random(n) ** 3 * m).astype(np.int64)
+        dst = (rng.random(n) ** 2 * m).astype(np.int64)
+    elif kind == 2:  # star(s) + chain (short: every level / bucket of a search is a host round trip, like the reference's)
+        m = min(m, 1500)
+        hubs = rng.integers(0, m, 3)
+        src = np.concatenate([np.repeat(hubs, m // 3 + 1)[:m], np.arange(m - 1)])
+        dst = np.concatenate([rng.integers(0, m, m), np.arange(1, m)])
+    elif kind == 3:  # many small components, long paths (short for the same reason)
+        m = min(m, 1500)
+        n = int(rng.integers(0, 2 * m + 1))
+        src = rng.integers(0, m, n)
+        dst = np.clip(src + rng.integers(-3, 4, n), 0, m - 1)
+    elif kind == 4:  # dense block inside a sparse graph
+        k = min(m, int(rng.integers(2, 200)))
+        a = rng.integers(0, k, 20 * k)
+        b = rng.integers(0, k, 20 * k)
+        n = int(rng.integers(0, 3 * m + 1))
+        src = np.concatenate([a, rng.integers(0, m, n)])
+        dst = np.concatenate([b, rng.integers(0, m, n)])
+    else:            # half of the vertices isolated
+        n = int(rng.integers(0, 8 * m + 1))
+        src, dst = rng.integers(0, max(m // 2, 1), n), rng.integers(0, max(m // 2, 1), n)
+    return graphio.build_csr(m, src.astype(np.int64), dst.astype(np.int64))
+
+
+STAGE = {}
+
+
+def lap(name, t0):
+    STAGE[name] = STAGE.get(name, 0.0) + time.time() - t0
+    return time.time()
+
+
+def check(seed):
+    rng = np.random.default_rng(seed)
+    g = random_graph(rng)
+    gi = graphio.transpose(g)
+    gs = graphio.symmetrize(g)
+    m = g.m
+    G = solvers.Graph(csr=g, in_csr=gi, need_reverse=True)
+    deg = np.diff(g.rowptr.astype(np.int64))
+    source = int(rng.integers(0, m))
+    tag = f"seed {seed} (m {m}, nnz {g.nnz})"
+    t0 = time.time()
+    # BFS with and without the reverse graph
+    want = orc.bfs_serial(g, source)
+    for GG in (G, solvers.Graph(csr=g)):
+        d = np.full(m, 1000000000, np.int32)
+        solvers.BFSSolver(GG, source, d)
+        assert np.array_equal(d, want), f"BFS {tag}"
+    t0 = lap("bfs", t0)
+    # SSSP
+    wmax = int(rng.choice([2, 16, 256]))
+    w = rng.integers(1, wmax, g.nnz).astype(np.int32)
+    delta = int(rng.choice([1, 3] if wmax <= 16 else [16, 64]))
+    want = orc.sssp_dijkstra(g, w, source)
+    d = np.full(m, 2147483647, np.int32)
+    solvers.SSSPSolver(G, source, w, d, delta)
+    assert np.array_equal(d, want), f"SSSP {tag} delta {delta}"
+    t0 = lap("sssp", t0)
+    # PageRank (vertices without out-edges divide by zero in the reference; their quotient is never read)
+    want, it, _ = orc.pr(gi, deg.astype(np.int32))
+    s = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    st = solvers.PRSolver(G, s)
+    assert st["iterations"] == it and np.allclose(s, want, rtol=REL, atol=0), f"PR {tag}"
+    t0 = lap("pr", t0)
+    # delta PageRank
+    want, it, wtr = orc.pr_delta(gi, g, push_div=8)
+    s = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+    st = solvers.PRDeltaSolver(G, s)
+    rel = np.abs(s - want) / np.maximum(np.abs(want), 1e-30)
+    # a vertex ON the frontier threshold may flip (its sum differs by an ulp): 0.85 * 1e-3 of its score is then pushed to
+    # its out-neighbours or not -- the scores beyond 1e-4 may differ, in all, by four such terms
+    off = float(np.abs(s - want)[rel > REL].sum())
+    assert st["iterations"] == it and off <= 4 * 0.85e-3 * float(want.max()) and rel.max() < 2e-3, \
+        f"delta PR {tag}: {st['iterations']} vs {it}, max rel {rel.max():.3e}, {int((rel > REL).sum())} beyond 1e-4"
+    t0 = lap("pr_delta", t0)
+    # SpMV
+    Ax = (rng.random(g.nnz, dtype=np.float32) - np.float32(0.5)).astype(np.float32)
+    x = rng.random(m, dtype=np.float32)
+    y0 = rng.random(m, dtype=np.float32)
+    want = orc.spmv(gi, Ax, x, y0)
+    y = y0.copy()
+    solvers.SpmvSolver(G, Ax, x, y)
+    assert orc.spmv_max_rel_error(y, want) <= 5 * np.sqrt(np.finfo(np.float32).eps), f"SpMV {tag}"
+    t0 = lap("spmv", t0)
+    # CC: directed with reverse graph, directed without, symmetrized
+    want, _ = orc.cc_sv(gs)
+    for GG in (G, solvers.Graph(csr=g), solvers.Graph(csr=gs, symmetrize=True)):
+        comp = np.arange(m, dtype=np.int32)
+        solvers.CCSolver(GG, comp)
+        assert np.array_equal(comp, want), f"CC {tag}"
+    t0 = lap("cc", t0)
+    # TC on the symmetrized graph
+    want = orc.tc(orc.tc_orient(gs))
+    got, _ = solvers.TCSolver(solvers.Graph(csr=gs, symmetrize=True))
+    assert got == want, f"TC {tag}: {got} vs {want}"
+    t0 = lap("tc", t0)
+    # BC
+    sc = np.zeros(m, np.float32)
+    solvers.BCSolver(G, source, sc)
+    assert orc.bc_verify(g, source, sc), f"BC {tag}"
+    lap("bc", t0)
+    return m, g.nnz
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    edges = 0
+    for seed in range(first, first + n):
+        try:
+            m, nnz = check(seed)
+        except AssertionError as e:
+            print("MISMATCH:", e, flush=True)
+            sys.exit(1)
+        edges += nnz
+        if (seed - first) % 10 == 9 or os.environ.get("FUZZ_VERBOSE"):
+            print(f"{seed - first + 1} graphs ok ({edges} edges so far); seconds per stage incl. the oracle:",
+                  {k: round(v, 1) for k, v in STAGE.items()}, flush=True)
+    print(f"fuzz parity: {n} random graphs, every solver equal to the oracle ({edges} edges)")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Delta PageRank against the oracle on an R-MAT graph of scale S (debug aid: crc of the scores, per-iteration trace)."""
 import os, sys, zlib
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gardenia_amd import graphio, solvers
 from oracle import binding as orc

@@ -1,0 +1,20 @@
+"""Randomised parity sweep (tests/aids/fuzz_parity.py): random graphs of six shapes through every drop-in solver of the
+C-ABI, each result against the CPU oracle.  Run as a child process with four OpenMP threads for the oracle: on the GPU
+box's 128 hardware threads an OpenMP region per tiny graph costs seconds."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("first_seed", [1, 100001])
+def test_random_graphs_every_solver_equals_the_oracle(first_seed):
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "aids", "fuzz_parity.py"), "200", str(first_seed)],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and "every solver equal to the oracle" in p.stdout, p.stdout[-2000:]

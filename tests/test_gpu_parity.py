@@ -959,14 +959,17 @@ def test_bc_plan_vs_oracle_rmat(orc, scale, ef, seed, sym, with_reverse):
 def _prd_check(scores, tr, st, want, it, wtr):
     """Same pull/push decisions and iteration count as the oracle; scores within 1e-4 relative.  The frontier test
     |delta| > 1e-3 * score sits on fp32 values that differ from the sequential sums by an ulp or two, so a vertex ON the
-    threshold may fall on the other side: its delta (1e-3 of its score) is then pushed or not, which is why a handful of
-    scores are allowed the size of such a term and the frontier sizes a small slack."""
+    threshold may fall on the other side: its delta (1e-3 of its score) is then pushed or not, which is why the scores
+    beyond 1e-4 are allowed, IN ALL, the size of four such terms and the frontier sizes a small slack."""
     assert st["iterations"] == it
     assert np.array_equal(tr["mode"], wtr["mode"])
     assert np.all(np.abs(tr["items"].astype(np.int64) - wtr["items"]) <= 2 + wtr["items"] // 2000)
     np.testing.assert_allclose(tr["diff"], wtr["diff"], rtol=1e-4, atol=1e-7)
     rel = np.abs(scores - want) / np.maximum(np.abs(want), 1e-30)
-    assert np.count_nonzero(rel > REL_TOL) <= max(4, len(want) // 5000), rel.max()
+    bad = rel > REL_TOL
+    # what up to four flipped vertices can move in all: each pushes (or not) 0.85 * delta, |delta| ~ 1e-3 * its score,
+    # spread over its out-neighbours (tests/aids/fuzz_parity.py seed 176: one flip, five neighbours 2e-4 off)
+    assert float(np.abs(scores - want)[bad].sum()) <= 4 * 0.85e-3 * float(want.max()), (int(bad.sum()), rel.max())
     assert rel.max() < 2e-3
 
 
