@@ -96,6 +96,96 @@ bfs_td_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsTdVis vi
   vis.finish();
 }
 
+// ---- fused light levels (the "fusion" variant of the reference, src/bfs/fusion.cu, without its grid barrier): ONE
+// workgroup runs consecutive top-down levels for as long as the frontier stays tiny -- a wave per frontier vertex, the
+// queues ping-pong in global memory, the level boundary is a __syncthreads() -- and returns to the host when the frontier
+// outgrows one CU (or empties).  A level costs a few dependent memory round trips here (~5 us) instead of a memset, two
+// launches and a blocking read back (~55 us): the first and last levels of every search, and every level of a
+// high-diameter graph (a 150 000-vertex chain took 9 s level by level).
+#define BFS_SMALL_THREADS 1024
+struct BfsSmallOut {
+  unsigned levels;      // levels expanded
+  unsigned nf;          // size of the frontier left for the host (0 = the search is over)
+  unsigned which;       // queue that holds it (0 = q0, 1 = q1)
+  unsigned overflow;
+  unsigned long long scout;       // sum of out-degrees of that frontier
+  unsigned long long checked;     // sum of the scout counts of the frontiers expanded here
+  unsigned long long discovered;  // vertices discovered here
+};
+
+__global__ void __launch_bounds__(BFS_SMALL_THREADS)
+bfs_td_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, unsigned *__restrict__ visited,
+                    int32_t *__restrict__ depth, vid_t *q0, vid_t *q1, unsigned which, unsigned nf, unsigned cap,
+                    int32_t level, unsigned long long scout_cur, unsigned max_nf, unsigned long long max_scout,
+                    unsigned max_levels, BfsSmallOut *__restrict__ out) {
+  __shared__ unsigned s_cnt, s_over;
+  __shared__ unsigned long long s_scout;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6, nwaves = BFS_SMALL_THREADS / 64;
+  unsigned levels = 0;
+  unsigned long long checked = 0, discovered = 0;
+  if (threadIdx.x == 0) s_over = 0u;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      s_cnt = 0u;
+      s_scout = 0ull;
+    }
+    __syncthreads();
+    const vid_t *qin = which ? q1 : q0;
+    vid_t *qout = which ? q0 : q1;
+    unsigned long long scout = 0;
+    for (unsigned i = wave; i < nf; i += nwaves) {
+      // the queues are written and read by this workgroup only, but through different waves: device-scope loads
+      const vid_t v = __hip_atomic_load(qin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const eoff_t b = rowptr[v], e = rowptr[v + 1];
+      for (eoff_t k0 = b; k0 < e; k0 += 64) {
+        const eoff_t k = k0 + lane;
+        bool claim = false;
+        vid_t dst = 0;
+        if (k < e) {
+          dst = colidx[k];
+          const unsigned bit = 1u << (dst & 31);
+          if (!(visited[dst >> 5] & bit)) claim = !(atomicOr(&visited[dst >> 5], bit) & bit);
+        }
+        const unsigned long long mask = __ballot(claim);
+        if (mask) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_cnt, (unsigned)__popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (claim) {
+            depth[dst] = level + 1;
+            scout += rowptr[dst + 1] - rowptr[dst];
+            const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
+            if (pos < cap) __hip_atomic_store(qout + pos, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else s_over = 1u;
+          }
+        }
+      }
+    }
+    scout = gdn_wave_sum(scout);
+    if (lane == 0 && scout) atomicAdd(&s_scout, scout);
+    __threadfence();
+    __syncthreads();
+    checked += scout_cur;
+    nf = s_cnt;
+    scout_cur = s_scout;
+    discovered += nf;
+    which ^= 1u;
+    level++;
+    levels++;
+    __syncthreads();  // everybody has read s_cnt / s_scout before the next level resets them
+    if (nf == 0 || nf > max_nf || scout_cur > max_scout || levels >= max_levels || s_over) break;
+  }
+  if (threadIdx.x == 0) {
+    out->levels = levels;
+    out->nf = nf;
+    out->which = which;
+    out->overflow = s_over;
+    out->scout = scout_cur;
+    out->checked = checked;
+    out->discovered = discovered;
+  }
+}
+
 // Bottom-up step: one thread per vertex, early exit on the first parent found in the frontier
 // bitmap (omp_beamer.cc:13-31).  A wave owns two bitmap words, so next/visited words are
 // written whole, without atomics.  Persistent grid: the awake / scout totals are kept in registers and added
@@ -408,6 +498,7 @@ struct gdn_bfs_plan {
   DevBuf<vid_t> q0, q1;
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
+  DevBuf<BfsSmallOut> small_out;
   BfsCounters *h_cnt = nullptr;  // pinned host copy of the level counters (one 32-byte read back per level)
   ~gdn_bfs_plan() {
     if (h_cnt) (void)hipHostFree(h_cnt);
@@ -484,7 +575,8 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
   GDN_TRY(p.q1.alloc(p.qcap));
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
-  if (hipHostMalloc((void **)&p.h_cnt, sizeof(BfsCounters), hipHostMallocDefault) != hipSuccess) p.h_cnt = nullptr;
+  GDN_TRY(p.small_out.alloc(1));
+  if (hipHostMalloc((void **)&p.h_cnt, 64 /* BfsCounters or BfsSmallOut */, hipHostMallocDefault) != hipSuccess) p.h_cnt = nullptr;
   if (gin) {
     GDN_TRY(p.front.alloc(p.nwords_pad));
     GDN_TRY(p.next.alloc(p.nwords_pad));
@@ -530,6 +622,13 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
   int64_t bu_stay = 256;
   if (const char *e = getenv("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
+  // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
+  // (measured: 1024 / 16384 made RMAT-20..24 searches 5-15 % slower -- 16 K edges on ONE CU are no faster than a launch
+  // over all of them --, a 100 000-vertex chain 4.6x faster; the smaller limits keep the second without the first)
+  unsigned small_nf = 256;
+  unsigned long long small_scout = 2048;
+  if (const char *e = getenv("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
+  if (const char *e = getenv("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   BfsCounters h;
   memset(&h, 0, sizeof(h));
   ExpBigList big;
@@ -620,6 +719,34 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       nf = h.next_count;
       scout_count = 1;
     } else {
+      // ---- tiny frontier: consecutive top-down levels inside one workgroup (bfs_td_small_kernel)
+      if (small_nf > 0 && nf <= small_nf && (unsigned long long)scout_count <= small_scout) {
+        hipLaunchKernelGGL(bfs_td_small_kernel, dim3(1), dim3(BFS_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, p.visited.p, d_dist,
+                           p.q0.p, p.q1.p, qin == p.q1.p ? 1u : 0u, nf, p.qcap, level, (unsigned long long)scout_count, small_nf,
+                           small_scout, 1u << 30, p.small_out.p);
+        BfsSmallOut so;
+        if (p.h_cnt) {  // pinned staging (sizeof(BfsSmallOut) <= the pinned block)
+          GDN_HIP(hipMemcpyAsync(p.h_cnt, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost, 0));
+          GDN_HIP(hipStreamSynchronize(0));
+          memcpy(&so, p.h_cnt, sizeof(so));
+        } else {
+          GDN_HIP(hipMemcpy(&so, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost));
+        }
+        if (so.overflow) {
+          gdn_set_error("gdn_bfs: device worklist overflow");
+          return GDN_ERR_OVERFLOW;
+        }
+        iter += (int)so.levels;
+        level += (int32_t)so.levels;
+        edges_to_check -= (int64_t)so.checked;
+        visited_total += (int64_t)so.discovered;
+        nf = so.nf;
+        scout_count = (int64_t)so.scout;
+        qin = so.which ? p.q1.p : p.q0.p;
+        qout = so.which ? p.q0.p : p.q1.p;
+        lap("small", nf, scout_count);
+        continue;
+      }
       // ---- top-down step (omp_beamer.cc:143-146)
       ++iter;
       edges_to_check -= scout_count;

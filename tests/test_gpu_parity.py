@@ -1110,3 +1110,25 @@ def test_tc_row_range_shards_add_up(orc, world):
     assert be.count_rows(7, 7) == 0
     be.close()
     L.gdn_graph_free(h)
+
+
+@pytest.mark.parametrize("small_nf", ["0", "256", "100000"])
+def test_bfs_fused_light_levels(orc, monkeypatch, small_nf):
+    """bfs_td_small_kernel (consecutive tiny levels inside one workgroup): off, default limits, and limits so wide that
+    whole searches of small graphs run fused -- same depths and level counts as the serial BFS."""
+    monkeypatch.setenv("GDN_BFS_SMALL_NF", small_nf)
+    if small_nf == "100000":
+        monkeypatch.setenv("GDN_BFS_SMALL_SCOUT", "100000000")
+    m = 6000
+    chain = graphio.build_csr(m, np.arange(m - 1, dtype=np.int64), np.arange(1, m, dtype=np.int64))
+    cases = [(chain, 0), (chain, 5990), (graphio.rmat_graph(12, 8, seed=9), None), (graphio.rmat_graph(15, 16, seed=10), None),
+             (graphio.symmetrize(graphio.rmat_graph(10, 4, seed=11)), None)]
+    for g, src in cases:
+        src = graphio.first_nonisolated(g) if src is None else src
+        want = orc.bfs_serial(g, src)
+        for G in (solvers.Graph(csr=g), solvers.Graph(csr=g, need_reverse=True)):
+            d = np.full(g.m, 1000000000, np.int32)
+            st = solvers.BFSSolver(G, src, d)
+            assert np.array_equal(d, want)
+            if g is chain and not G.has_reverse_graph():
+                assert st["iterations"] == m - src  # one level per vertex, the last one discovers nothing
