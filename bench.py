@@ -221,8 +221,9 @@ def main():
         "gteps_pr": value / 1e9, "pr_last_l1_change": last_err, "graph_build_s": t_build,
     }
 
-    # ---- BFS GTEPS on the same graph (single GPU, rank 0 only, outside the timed region)
-    if rank == 0 and not args.no_bfs:
+    # ---- BFS GTEPS on the same graph (single GPU: the N = 1 run carries it; BFS stays single-GPU per north_star, and the
+    # other ranks of an N > 1 job would only wait in the final barrier for it), outside the timed region
+    if rank == 0 and world == 1 and not args.no_bfs:
         try:
             # source: first vertices with out-degree > 0
             nz = torch.nonzero(out_degree[:1 << 16] > 0)[:4].flatten().tolist()
