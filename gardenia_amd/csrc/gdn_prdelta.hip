@@ -209,7 +209,12 @@ int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, 
   p->gout = out_csr;
   int rc = GDN_OK;
   do {
-    if (layout == GDN_LAYOUT_AUTO) layout = nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
+    if (layout == GDN_LAYOUT_AUTO) {
+      const char *env = getenv("GDN_PRD_LAYOUT");  // test knob: 'p' / 'c' force the layout of the pull's plan
+      if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
+      else if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
+      else layout = nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
+    }
     p->layout = layout;
     if (layout == GDN_LAYOUT_CSR) {  // the merge-path kernel reads a value per nonzero; the PB layout has a pattern form
       if ((rc = p->ones.alloc(nnz ? nnz : 1))) break;
