@@ -127,7 +127,23 @@ def check(seed):
     sc = np.zeros(m, np.float32)
     solvers.BCSolver(G, source, sc)
     assert orc.bc_verify(g, source, sc), f"BC {tag}"
-    lap("bc", t0)
+    t0 = lap("bc", t0)
+    if os.environ.get("FUZZ_PLANS"):  # the resident plans: dense BFS / SSSP sweeps, BC's blocked levels
+        rb = solvers.ResidentBFS(G, dense=True)
+        for src in (source, int(rng.integers(0, m))):
+            d, _ = rb.run(src)
+            assert np.array_equal(d, orc.bfs_serial(g, src)), f"BFS plan {tag} source {src}"
+        rb.close()
+        rs = solvers.ResidentSSSP(G, w, dense=True)
+        d, _ = rs.run(source, delta)
+        assert np.array_equal(d, orc.sssp_dijkstra(g, w, source)), f"SSSP plan {tag} delta {delta}"
+        rs.close()
+        rc = solvers.ResidentBC(G, with_reverse=True)
+        sc = np.zeros(m, np.float32)
+        rc.run(source, sc)
+        assert orc.bc_verify(g, source, sc), f"BC plan {tag}"
+        rc.close()
+        lap("plans", t0)
     return m, g.nnz
 
 

@@ -12,9 +12,12 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("first_seed,blocked", [(1, False), (100001, False), (200001, True)])
+@pytest.mark.parametrize("first_seed,blocked", [(1, False), (100001, False), (200001, True), (300001, "plans")])
 def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
     env = dict(os.environ, OMP_NUM_THREADS="4")
+    if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels
+        env.update(FUZZ_PLANS="1")
+        blocked = False
     if blocked:  # the propagation-blocked layouts with their record tiers on these small graphs too (normally >= 2^22 edges)
         env.update(GDN_PR_LAYOUT="p", GDN_SPMV_LAYOUT="p", GDN_PRD_LAYOUT="p", GDN_PB_HUB_MIN_NNZ="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "aids", "fuzz_parity.py"), "200", str(first_seed)],
