@@ -143,6 +143,13 @@ def check(seed):
         rc.run(source, sc)
         assert orc.bc_verify(g, source, sc), f"BC plan {tag}"
         rc.close()
+        # the multi-GPU PageRank data path on this one device: vertex-range shards with their own plans, row-range parts
+        world, layout, parts = int(rng.choice([2, 3, 8])), int(rng.integers(0, 2)), int(rng.choice([1, 4]))
+        want, it, _ = orc.pr(gi, deg.astype(np.int32))
+        sh = solvers.ResidentPageRankShards(G, world, layout=layout, parts=parts)
+        s, it2, _ = sh.solve()
+        sh.close()
+        assert it2 == it and np.allclose(s, want, rtol=REL, atol=0), f"PR shards {tag} world {world} layout {layout} parts {parts}"
         lap("plans", t0)
     return m, g.nnz
 
