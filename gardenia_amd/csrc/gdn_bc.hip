@@ -96,6 +96,106 @@ bc_fwd_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BcFwdVis vi
   vis.finish();
 }
 
+// ---- fused light levels of the forward phase (cf. bfs_td_small_kernel, gdn_bfs.hip): ONE workgroup runs consecutive
+// levels while the frontier stays tiny -- a wave per frontier vertex, the level boundary is a __syncthreads() -- and
+// reports the tail of `order` after every level.  A level costs ~5 us here instead of two launches and a blocking read
+// back: every level of a high-diameter graph.  Path counts are integer atomics: the same bits in any order.
+#define BC_SMALL_THREADS 1024
+#define BC_SMALL_MAX_LEVELS 2048
+struct BcSmallOut {
+  unsigned levels;    // levels expanded here (0: the frontier handed in was too heavy, nothing was touched)
+  unsigned overflow;
+  unsigned tails[BC_SMALL_MAX_LEVELS];  // entries of `order` after each of them
+};
+
+__global__ void __launch_bounds__(BC_SMALL_THREADS)
+bc_fwd_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t *__restrict__ depth,
+                    int32_t *pc, vid_t *order, unsigned l0, unsigned nf, unsigned cap, int32_t level, unsigned max_nf,
+                    unsigned long long max_scout, BcCounters *cnt, BcSmallOut *__restrict__ out) {
+  __shared__ unsigned s_tail, s_over;
+  __shared__ unsigned long long s_scout;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6, nwaves = BC_SMALL_THREADS / 64;
+  unsigned levels = 0, tail = l0 + nf;
+  // out-edges of the frontier handed in: a heavy one goes back to the host untouched
+  if (threadIdx.x == 0) {
+    s_scout = 0ull;
+    s_over = 0u;
+  }
+  __syncthreads();
+  {
+    unsigned long long sc = 0;
+    for (unsigned i = threadIdx.x; i < nf; i += BC_SMALL_THREADS) {
+      const vid_t v = __hip_atomic_load(order + l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sc += rowptr[v + 1] - rowptr[v];
+    }
+    sc = gdn_wave_sum(sc);
+    if (lane == 0 && sc) atomicAdd(&s_scout, sc);
+  }
+  __syncthreads();
+  unsigned long long scout_cur = s_scout;
+  __syncthreads();
+  while (nf > 0 && nf <= max_nf && scout_cur <= max_scout && levels < BC_SMALL_MAX_LEVELS && !s_over) {
+    if (threadIdx.x == 0) {
+      s_tail = tail;
+      s_scout = 0ull;
+    }
+    __syncthreads();
+    unsigned long long scout = 0;
+    for (unsigned i = wave; i < nf; i += nwaves) {
+      // values other waves of this workgroup wrote (queue entries, path counts summed by atomics): device-scope loads
+      const vid_t v = __hip_atomic_load(order + l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t ps = __hip_atomic_load(pc + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const eoff_t b = rowptr[v], e = rowptr[v + 1];
+      for (eoff_t k0 = b; k0 < e; k0 += 64) {
+        const eoff_t k = k0 + lane;
+        bool claim = false;
+        vid_t dst = 0;
+        if (k < e) {
+          dst = colidx[k];
+          int32_t d = depth[dst];  // a stale -1 is settled by the CAS
+          if (d == -1) {
+            const int32_t old = atomicCAS(&depth[dst], -1, level + 1);
+            claim = old == -1;
+            d = claim ? level + 1 : old;
+          }
+          if (d == level + 1) atomicAdd(&pc[dst], ps);  // src/bc/omp_base.cc:39-42
+        }
+        const unsigned long long mask = __ballot(claim);
+        if (mask) {
+          unsigned base = 0;
+          if (lane == 0) base = atomicAdd(&s_tail, (unsigned)__popcll(mask));
+          base = __shfl(base, 0, 64);
+          if (claim) {
+            scout += rowptr[dst + 1] - rowptr[dst];
+            const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
+            if (pos < cap) __hip_atomic_store(order + pos, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else s_over = 1u;
+          }
+        }
+      }
+    }
+    scout = gdn_wave_sum(scout);
+    if (lane == 0 && scout) atomicAdd(&s_scout, scout);
+    __threadfence();
+    __syncthreads();
+    const unsigned new_tail = s_tail;
+    scout_cur = s_scout;
+    if (threadIdx.x == 0) out->tails[levels] = new_tail;
+    l0 = tail;
+    nf = new_tail - tail;
+    tail = new_tail;
+    level++;
+    levels++;
+    __syncthreads();  // everybody has read s_tail / s_scout before the next level resets them
+  }
+  if (threadIdx.x == 0) {
+    out->levels = levels;
+    out->overflow = s_over;
+    if (levels) cnt->tail = tail < cap ? tail : cap;
+    if (s_over) cnt->overflow = 1u;
+  }
+}
+
 __global__ void bc_seed_kernel(int32_t source, int32_t *depth, int32_t *pc, vid_t *order, BcCounters *cnt) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     depth[source] = 0;
@@ -805,9 +905,33 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   big.count = &cnt.p->big_count;
   big.overflow = &cnt.p->overflow;
   BcCounters h;
-  for (int32_t level = 0;; level++) {
+  // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
+  unsigned small_nf = 256;
+  unsigned long long small_scout = 2048;
+  if (const char *e = getenv("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
+  if (const char *e = getenv("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  DevBuf<BcSmallOut> small_out;
+  if (small_nf) GDN_TRY(small_out.alloc(1));
+  for (int32_t level = 0;;) {
     const unsigned l0 = lp[(size_t)level], nf = lp[(size_t)level + 1] - l0;
     if (nf == 0) break;
+    if (small_nf && nf <= small_nf) {
+      hipLaunchKernelGGL(bc_fwd_small_kernel, dim3(1), dim3(BC_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, depth.p, pc.p, order.p,
+                         l0, nf, (unsigned)m, level, small_nf, small_scout, cnt.p, small_out.p);
+      unsigned hdr[2] = {0, 0};
+      GDN_HIP(hipMemcpy(hdr, small_out.p, sizeof(hdr), hipMemcpyDeviceToHost));
+      if (hdr[1]) {
+        gdn_set_error("gdn_bc: device worklist overflow");
+        return GDN_ERR_OVERFLOW;
+      }
+      if (hdr[0]) {
+        const size_t at = lp.size();
+        lp.resize(at + hdr[0]);
+        GDN_HIP(hipMemcpy(lp.data() + at, small_out.p->tails, (size_t)hdr[0] * sizeof(unsigned), hipMemcpyDeviceToHost));
+        level += (int32_t)hdr[0];
+        continue;
+      }
+    }
     BcFwdVis vis;
     vis.colidx = g->colidx;
     vis.depth = depth.p;
@@ -827,6 +951,7 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
     }
     lp.push_back(h.tail);
     GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
+    level++;
   }
   const int32_t nlev = (int32_t)lp.size() - 2;  // non-empty levels 0 .. nlev-1
   // backward: the deepest level has no successors (its deltas stay 0, like the reference's first sweep)

@@ -1132,3 +1132,25 @@ def test_bfs_fused_light_levels(orc, monkeypatch, small_nf):
             assert np.array_equal(d, want)
             if g is chain and not G.has_reverse_graph():
                 assert st["iterations"] == m - src  # one level per vertex, the last one discovers nothing
+
+
+@pytest.mark.parametrize("small_nf", ["0", "256", "1000000"])
+def test_bc_fused_light_levels(orc, monkeypatch, small_nf):
+    """bc_fwd_small_kernel (consecutive tiny forward levels inside one workgroup): off, default limits, and limits so
+    wide that whole forward phases run fused -- the reference verifier's criterion and the same level count."""
+    monkeypatch.setenv("GDN_BC_SMALL_NF", small_nf)
+    if small_nf == "1000000":
+        monkeypatch.setenv("GDN_BC_SMALL_SCOUT", "100000000000")
+    m = 3000
+    chain = graphio.build_csr(m, np.arange(m - 1, dtype=np.int64), np.arange(1, m, dtype=np.int64))
+    ladder = graphio.build_csr(m, np.concatenate([np.arange(m - 2), np.arange(m - 2)]).astype(np.int64),
+                               np.concatenate([np.arange(1, m - 1), np.arange(2, m)]).astype(np.int64))
+    for g, src in [(chain, 0), (ladder, 0), (graphio.rmat_graph(12, 8, seed=9), None),
+                   (graphio.symmetrize(graphio.rmat_graph(11, 4, seed=11)), None), (graphio.rmat_graph(15, 16, seed=10), None)]:
+        src = graphio.first_nonisolated(g) if src is None else src
+        want, levels, _, _ = orc.bc(g, src)
+        sc = np.zeros(g.m, np.float32)
+        st = solvers.BCSolver(solvers.Graph(csr=g), src, sc)
+        assert orc.bc_verify(g, src, sc)
+        _bc_close(sc, want)
+        assert st["iterations"] == levels
