@@ -55,6 +55,14 @@ PROTOTYPES = {
     "gdn_pr_delta_run": (C.c_int, [_vp, _vp, C.c_float, C.c_double, C.c_float, _i32, _i32, _st]),
     "gdn_pr_delta_trace": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp]),
     "gdn_pr_delta_plan_free": (C.c_int, [_vp]),
+    "gdn_pr_last_trace": (C.c_int, [_i32, C.POINTER(_i32), _vp]),
+    "gdn_pr_multi": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, _i32, _i32, _vp, _st]),
+    "gdn_spmv_multi": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _st]),
+    "gdn_multi_ranges": (C.c_int, [_i32, _vp, _i32, _vp, C.POINTER(_i32)]),
+    "gdn_graph_upload_rows": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _pp]),
+    "gdn_graph_validate": (C.c_int, [_vp, _i32]),
+    "gdn_graph_balanced_ranges": (C.c_int, [_vp, _i32, _vp]),
+    "gdn_graph_slice_padded": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _pp]),
     "gdn_spmv": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
@@ -121,6 +129,7 @@ PROTOTYPES = {
     "gdn_cc_dev": (C.c_int, [_vp, _vp, _vp, _st]),
     "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),
     "gdn_graph_orient": (C.c_int, [_vp, _pp]),
+    "gdn_tc_model_bytes": (C.c_int, [_vp, C.POINTER(_u64)]),
     "gdn_tc_rows_dev": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64), _st]),
 }
 

@@ -118,6 +118,8 @@ static inline unsigned gdn_nblocks(uint64_t n, unsigned per_block = GDN_BLOCK) {
 // device-wide helpers implemented in gdn_graph.hip
 int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n, hipStream_t s);
 int gdn_fill_i32(int32_t *d, int32_t v, size_t n, hipStream_t s);
+void gdn_pr_trace_set(const double *diff, int32_t n);  // gdn_pr.hip: the trace gdn_pr_last_trace returns
+int gdn_graph_pad_cols(gdn_graph *s, int32_t world, const int32_t *bounds, int32_t chunk);
 
 #ifdef __HIPCC__
 // ------------------------------------------------------------------------------------------

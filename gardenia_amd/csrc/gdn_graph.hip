@@ -135,6 +135,77 @@ rebase_rowptr_kernel(const eoff_t *__restrict__ rowptr, int32_t row_lo, int32_t 
   if (i <= n) out[i] = rowptr[row_lo + i] - rowptr[row_lo];
 }
 
+// ---- validation of caller-supplied CSR arrays (gdn_graph_upload*, gdn_graph_validate): monotone offsets inside
+// [0, nnz] and column ids inside [0, n_cols).  A malformed .bin or caller array would otherwise turn into out-of-bounds
+// device accesses in every solver (bitmap atomics, depth stores).  flag: bit0 offsets, bit1 column ids.
+__global__ void __launch_bounds__(GDN_BLOCK)
+graph_validate_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, uint64_t nnz,
+                      int32_t n_cols, unsigned *__restrict__ flag) {
+  unsigned bad = 0;
+  const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
+  for (size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; v < (size_t)m; v += stride) {
+    const eoff_t a = rowptr[v], b = rowptr[v + 1];
+    if (a > b || b > nnz) bad |= 1u;
+  }
+  for (size_t e = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; e < nnz; e += stride) {
+    const vid_t c = __builtin_nontemporal_load(colidx + e);
+    if (c < 0 || c >= n_cols) bad |= 2u;
+  }
+  if (bad) atomicOr(flag, bad);
+}
+
+// column ids of a row shard moved into the PADDED vertex space of a sharded run (gdn_graph_slice_padded):
+// vertex v of range r = [bounds[r], bounds[r+1]) -> r * chunk + (v - bounds[r])
+__global__ void __launch_bounds__(GDN_BLOCK)
+graph_pad_cols_kernel(vid_t *__restrict__ colidx, uint64_t nnz, const int32_t *__restrict__ bounds, int32_t world,
+                      int32_t chunk) {
+  __shared__ int32_t s_b[GDN_BLOCK + 1];
+  for (int i = threadIdx.x; i <= world; i += GDN_BLOCK) s_b[i] = bounds[i];
+  __syncthreads();
+  const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
+  for (size_t e = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; e < nnz; e += stride) {
+    const vid_t c = colidx[e];
+    int lo = 0, hi = world;  // last r with bounds[r] <= c
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (s_b[mid] <= c) lo = mid;
+      else hi = mid;
+    }
+    colidx[e] = (vid_t)((int64_t)lo * chunk + (c - s_b[lo]));
+  }
+}
+
+static int graph_validate(const gdn_graph *g, int32_t n_cols, const char *who) {
+  DevBuf<unsigned> flag;
+  GDN_TRY(flag.alloc(1));
+  GDN_HIP(hipMemset(flag.p, 0, sizeof(unsigned)));
+  const uint64_t work = g->nnz > (uint64_t)g->m ? g->nnz : (uint64_t)g->m;
+  unsigned nb = gdn_nblocks(work);
+  if (nb > 16384u) nb = 16384u;
+  hipLaunchKernelGGL(graph_validate_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, g->m, g->nnz, n_cols, flag.p);
+  unsigned f = 0;
+  GDN_HIP(hipMemcpy(&f, flag.p, sizeof(unsigned), hipMemcpyDeviceToHost));
+  if (f) {
+    gdn_set_error("%s: malformed CSR (%s%s%s)", who, (f & 1u) ? "row offsets not ascending within [0, nnz]" : "",
+                  f == 3u ? "; " : "", (f & 2u) ? "column id outside [0, n_cols)" : "");
+    return GDN_ERR_INVALID;
+  }
+  return GDN_OK;
+}
+
+// in place: the column ids of a row shard into the padded vertex space (bounds: world + 1 host ints)
+int gdn_graph_pad_cols(gdn_graph *s, int32_t world, const int32_t *bounds, int32_t chunk) {
+  if (!s->nnz) return GDN_OK;
+  DevBuf<int32_t> d_b;
+  GDN_TRY(d_b.alloc((size_t)world + 1));
+  GDN_HIP(hipMemcpy(d_b.p, bounds, ((size_t)world + 1) * 4, hipMemcpyHostToDevice));
+  unsigned nb = gdn_nblocks(s->nnz);
+  if (nb > 16384u) nb = 16384u;
+  hipLaunchKernelGGL(graph_pad_cols_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, s->colidx, s->nnz, d_b.p, world, chunk);
+  GDN_HIP(hipDeviceSynchronize());
+  return GDN_OK;
+}
+
 extern "C" {
 
 const char *gdn_last_error(void) { return g_err; }
@@ -200,8 +271,60 @@ int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int3
     gdn_graph_free(g);
     return e == hipErrorOutOfMemory ? GDN_ERR_OOM : GDN_ERR_HIP;
   }
+  const int vst = graph_validate(g, m, "gdn_graph_upload");
+  if (vst != GDN_OK) {
+    gdn_graph_free(g);
+    return vst;
+  }
   *out = g;
   return GDN_OK;
+}
+
+// rows [row_lo, row_hi) of a HOST CSR as an independent resident graph (offsets rebased on the device, column ids
+// unchanged and validated against n_cols): the vertex-range shard one device of gdn_pr_multi / gdn_spmv_multi holds
+int gdn_graph_upload_rows(int32_t m, const uint64_t *rowptr, const int32_t *colidx, int32_t row_lo, int32_t row_hi,
+                          int32_t n_cols, gdn_graph **out) {
+  GDN_REQUIRE(out != nullptr, "out");
+  *out = nullptr;
+  GDN_REQUIRE(rowptr != nullptr && m > 0, "rowptr / m");
+  GDN_REQUIRE(0 <= row_lo && row_lo < row_hi && row_hi <= m, "row range");
+  GDN_REQUIRE(rowptr[row_lo] <= rowptr[row_hi], "row offsets");
+  GDN_TRY(gdn_require_device());
+  const uint64_t e0 = rowptr[row_lo], nnz = rowptr[row_hi] - e0;
+  GDN_REQUIRE(colidx != nullptr || nnz == 0, "colidx");
+  gdn_graph *s = new gdn_graph();
+  s->m = row_hi - row_lo;
+  s->nnz = nnz;
+  s->owned = true;
+  DevBuf<eoff_t> raw;
+  int st = raw.alloc((size_t)s->m + 1);
+  hipError_t e = st == GDN_OK ? hipMalloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t)) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = hipMalloc((void **)&s->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
+  if (e == hipSuccess) e = hipMemcpy(raw.p, rowptr + row_lo, ((size_t)s->m + 1) * sizeof(eoff_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess && nnz) e = hipMemcpy(s->colidx, colidx + e0, nnz * sizeof(vid_t), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    gdn_set_error("gdn_graph_upload_rows: %s", hipGetErrorString(e));
+    gdn_graph_free(s);
+    return e == hipErrorOutOfMemory ? GDN_ERR_OOM : GDN_ERR_HIP;
+  }
+  hipLaunchKernelGGL(rebase_rowptr_kernel, dim3(gdn_nblocks((uint64_t)s->m + 1)), dim3(GDN_BLOCK), 0, 0, raw.p, 0, s->m, s->rowptr);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    gdn_set_error("gdn_graph_upload_rows: rebase failed");
+    gdn_graph_free(s);
+    return GDN_ERR_HIP;
+  }
+  st = graph_validate(s, n_cols, "gdn_graph_upload_rows");
+  if (st != GDN_OK) {
+    gdn_graph_free(s);
+    return st;
+  }
+  *out = s;
+  return GDN_OK;
+}
+
+int gdn_graph_validate(const gdn_graph *g, int32_t n_cols) {
+  GDN_REQUIRE(g != nullptr && n_cols > 0, "graph / n_cols");
+  return graph_validate(g, n_cols, "gdn_graph_validate");
 }
 
 int gdn_graph_wrap_dev(int32_t m, uint64_t nnz, const uint64_t *d_rowptr, const int32_t *d_colidx,
@@ -272,6 +395,56 @@ int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn
                      g->rowptr, row_lo, s->m, s->rowptr);
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());
+  *out = s;
+  return GDN_OK;
+}
+
+// smallest row b with rowptr[b] >= target (a handful of 8-byte reads of the resident offsets)
+static int graph_lower_bound_row(const gdn_graph *g, eoff_t target, int32_t *row) {
+  int64_t lo = 0, hi = g->m;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    eoff_t v = 0;
+    GDN_HIP(hipMemcpy(&v, g->rowptr + mid, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    if (v >= target) hi = mid;
+    else lo = mid + 1;
+  }
+  *row = (int32_t)lo;
+  return GDN_OK;
+}
+
+int gdn_graph_balanced_ranges(const gdn_graph *g, int32_t world, int32_t *bounds) {
+  GDN_REQUIRE(g != nullptr && bounds != nullptr && world >= 1, "graph / bounds / world");
+  GDN_REQUIRE(world <= g->m, "more ranges than rows");
+  bounds[0] = 0;
+  for (int32_t r = 1; r < world; r++) {
+    int32_t b = 0;
+    GDN_TRY(graph_lower_bound_row(g, (eoff_t)((unsigned __int128)g->nnz * (unsigned)r / (unsigned)world), &b));
+    // every range keeps at least one row (an empty shard has no plan), boundaries ascending
+    if (b < bounds[r - 1] + 1) b = bounds[r - 1] + 1;
+    if (b > g->m - (world - r)) b = g->m - (world - r);
+    bounds[r] = b;
+  }
+  bounds[world] = g->m;
+  return GDN_OK;
+}
+
+int gdn_graph_slice_padded(const gdn_graph *g, int32_t world, const int32_t *bounds, int32_t chunk, int32_t rank,
+                           gdn_graph **out) {
+  GDN_REQUIRE(g != nullptr && out != nullptr && bounds != nullptr, "graph / out / bounds");
+  *out = nullptr;
+  GDN_REQUIRE(world >= 1 && world <= GDN_BLOCK && rank >= 0 && rank < world, "world / rank");
+  GDN_REQUIRE(bounds[0] == 0 && bounds[world] == g->m, "bounds must cover [0, m)");
+  for (int32_t r = 0; r < world; r++)
+    GDN_REQUIRE(bounds[r] < bounds[r + 1] && bounds[r + 1] - bounds[r] <= chunk, "every range non-empty and at most chunk rows");
+  GDN_REQUIRE((int64_t)chunk * world <= 2147483647ll, "chunk * world must fit a vertex id");
+  gdn_graph *s = nullptr;
+  GDN_TRY(gdn_graph_slice_rows(g, bounds[rank], bounds[rank + 1], &s));
+  const int st = gdn_graph_pad_cols(s, world, bounds, chunk);
+  if (st != GDN_OK) {
+    gdn_graph_free(s);
+    return st;
+  }
   *out = s;
   return GDN_OK;
 }

@@ -225,7 +225,19 @@ pr_dead_diff_kernel(const float *__restrict__ scores, const uint32_t *__restrict
   if (gdn_lane() == 0 && acc != 0.0) atomicAdd(out, acc);
 }
 
+// the per-iteration L1 changes of the calling thread's last gdn_pr / gdn_pr_multi solve (the reference prints them as it
+// goes, src/pr/omp_base.cc:35; gdn_pr_last_trace hands them to the wrapper that prints)
+static thread_local std::vector<double> g_pr_trace;
+void gdn_pr_trace_set(const double *diff, int32_t n) { g_pr_trace.assign(diff, diff + (n > 0 ? n : 0)); }
+
 extern "C" {
+
+int gdn_pr_last_trace(int32_t capacity, int32_t *n, double *diff) {
+  GDN_REQUIRE(n != nullptr && capacity >= 0 && (diff != nullptr || capacity == 0), "n / diff");
+  *n = (int32_t)g_pr_trace.size();
+  for (int32_t i = 0; i < *n && i < capacity; i++) diff[i] = g_pr_trace[(size_t)i];
+  return GDN_OK;
+}
 
 // slice sizes: as large as LDS allows on big graphs; smaller graphs keep >= 2^slices_log slices per phase BEFORE the
 // vertex compaction (about 40 % of them stay on an R-MAT graph).  Whole graphs take 2^9: every bin re-reads the tier
@@ -607,7 +619,8 @@ int gdn_pr_squish_export_dev(gdn_pr_squish *sq, const float *d_state, float *d_s
 
 // plans built on (shards of) a squished graph: the base score is (1 - d) / m of the ORIGINAL vertex count
 int gdn_pr_plan_set_base(gdn_pr_plan *plan, int32_t m_base) {
-  GDN_REQUIRE(plan != nullptr && m_base >= plan->m_global, "m_base");
+  // m_base < m_global: shards of a PADDED vertex space (gdn_graph_slice_padded: the slots hold more ids than vertices)
+  GDN_REQUIRE(plan != nullptr && m_base >= 1, "m_base");
   plan->m_base = m_base;
   if (!plan->squished) plan->m_orig = m_base;  // gdn_pr_iter_bytes counts the caller's vertices
   return GDN_OK;
@@ -957,6 +970,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     float *cin = d_c0.p, *cout = d_c1.p;
     int iter = 0;
     double diff = 0;
+    g_pr_trace.clear();
     for (iter = 0; iter < max_iter; iter++) {
       if ((rc = gdn_pr_pull_dev(plan, cin, d_state.p, cout, d_diff.p, damping, nullptr))) break;
       if (hipMemcpy(&diff, d_diff.p, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
@@ -965,6 +979,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
         break;
       }
       if (iter == 0) diff += dead_diff;  // the vertices outside the state move to the base score in the first iteration
+      g_pr_trace.push_back(diff);
       float *tmp = cin;
       cin = cout;
       cout = tmp;

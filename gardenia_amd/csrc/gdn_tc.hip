@@ -399,7 +399,38 @@ static int tc_orient(const gdn_graph *g, gdn_graph **out) {
   return GDN_OK;
 }
 
+// SURVEY 8d's merge-equivalent traffic of a count: SUM over DAG edges (u,v) of d+(u) + d+(v) (a merge intersect reads both lists)
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_model_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned long long *__restrict__ out) {
+  unsigned long long acc = 0;
+  const unsigned lane = gdn_lane();
+  const size_t wave = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
+  for (size_t u = wave; u < (size_t)m; u += nwaves) {
+    const eoff_t a = rowptr[u], b = rowptr[u + 1];
+    const unsigned long long du = b - a;
+    for (eoff_t e = a + lane; e < b; e += 64) {
+      const vid_t v = colidx[e];
+      acc += du + (rowptr[v + 1] - rowptr[v]);
+    }
+  }
+  acc = gdn_wave_sum(acc);
+  if (lane == 0 && acc) atomicAdd(out, acc);
+}
+
 extern "C" {
+
+// bytes = 4 * SUM_{(u,v) in DAG} (d+(u) + d+(v)) + 4 nnz [src list] + 4 nnz [colidx] + 8 (m + 1)   (TC row)
+int gdn_tc_model_bytes(const gdn_graph *dag, uint64_t *bytes) {
+  GDN_REQUIRE(dag != nullptr && bytes != nullptr, "dag / bytes");
+  DevBuf<unsigned long long> acc;
+  GDN_TRY(acc.alloc(1));
+  GDN_HIP(hipMemset(acc.p, 0, 8));
+  hipLaunchKernelGGL(tc_model_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, acc.p);
+  unsigned long long h = 0;
+  GDN_HIP(hipMemcpy(&h, acc.p, 8, hipMemcpyDeviceToHost));
+  *bytes = 4ull * h + 8ull * dag->nnz + 8ull * ((uint64_t)dag->m + 1);
+  return GDN_OK;
+}
 
 // triangles closed over the source rows [row_lo, row_hi) of an oriented graph (the light-row cursor starts at row_lo and
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)

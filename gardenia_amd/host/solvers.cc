@@ -2,6 +2,7 @@
 // Prints the lines the reference solvers print ("\titerations = %d.", "\truntime [..] = %f ms.")
 // so outputs stay diff-able (SURVEY 5 metrics/logging).  No CPU fallback: failures throw.
 #include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -22,12 +23,31 @@ void BFSSolver(Graph &g, int source, DistT *dist) {  // src/bfs/bfs.h:43
          (unsigned long long)st.edges_traversed);
 }
 
+// GDN_NUM_GPUS: the devices PRSolver / SpmvSolver spread over -- the multi-GPU analogue of the OMP_NUM_THREADS the
+// reference's OpenMP solvers honour (src/pr/omp_base.cc:11-16 prints the thread count the same way)
+static int num_gpus() {
+  const char *e = getenv("GDN_NUM_GPUS");
+  const int n = e ? atoi(e) : 1;
+  return n < 1 ? 1 : n;
+}
+
 void PRSolver(Graph &g, ScoreT *scores) {  // src/pr/pr.h:31
   std::vector<int32_t> deg(g.V());
   for (VertexId v = 0; v < g.V(); v++) deg[v] = g.get_degree(v);
   gdn_stats st;
-  must(gdn_pr(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), deg.data(), scores, kDamp, EPSILON, MAX_ITER, &st), "PRSolver");
-  printf(" %2d    %lf\n", st.iterations, st.last_error);
+  const int ngpus = num_gpus();
+  if (ngpus > 1) {
+    printf("Launching HIP PR solver (%d GPUs) ...\n", ngpus);
+    must(gdn_pr_multi(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), deg.data(), scores, kDamp, EPSILON, MAX_ITER, ngpus, nullptr,
+                      &st), "PRSolver");
+  } else {
+    must(gdn_pr(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), deg.data(), scores, kDamp, EPSILON, MAX_ITER, &st), "PRSolver");
+  }
+  // the per-iteration trace exactly as src/pr/omp_base.cc:35 prints it (iteration numbers from 1)
+  std::vector<double> trace(MAX_ITER);
+  int32_t n = 0;
+  must(gdn_pr_last_trace(MAX_ITER, &n, trace.data()), "PRSolver");
+  for (int32_t i = 0; i < n && i < MAX_ITER; i++) printf(" %2d    %lf\n", i + 1, trace[i]);
   printf("\titerations = %d.\n", st.iterations);
   printf("\truntime [hip_gfx950] = %f ms.\n", st.solve_ms);
 }
@@ -70,7 +90,11 @@ void PRDeltaSolver(Graph &g, ScoreT *scores) {
 
 void SpmvSolver(Graph &g, const ValueT *Ax, const ValueT *x, ValueT *y) {  // src/spmv/spmv.h:29
   gdn_stats st;
-  must(gdn_spmv(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), Ax, x, y, &st), "SpmvSolver");
+  const int ngpus = num_gpus();
+  if (ngpus > 1)
+    must(gdn_spmv_multi(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), Ax, x, y, ngpus, nullptr, &st), "SpmvSolver");
+  else
+    must(gdn_spmv(g.V(), g.E(), g.in_rowptr(), g.in_colidx(), Ax, x, y, &st), "SpmvSolver");
   const double t = st.solve_ms;
   const double bytes = 8.0 * (g.V() + 1) + 12.0 * g.E() + 8.0 * g.V();  // SURVEY 8d byte model
   printf("\truntime [hip_gfx950] = %.4f ms ( %5.2f GFLOP/s %5.1f GB/s)\n", t, t > 0 ? 2.0 * g.E() / t / 1e6 : 0.0,

@@ -2,7 +2,11 @@
 
 The reference has no multi-GPU path; this is the MI355X-native addition the north star asks
 for: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI), rows of the
-in-CSR split into `world` contiguous vertex ranges of equal length, column ids global.
+in-CSR split into `world` contiguous vertex ranges, column ids global.  Ranges: equal vertex counts
+(`vertex_range`) or -- what bench.py uses -- about nnz/world edges each (`gdn_graph_balanced_ranges`) with
+the graph moved into a PADDED vertex space (`padded_chunk`, `gdn_graph_slice_padded`: range r occupies the slot
+[r*chunk, r*chunk + len_r) of chunk*world ids), so that unequal ranges still exchange equal all-gather slots; in that
+space every rank's range is again `vertex_range(rank, world, chunk*world)`, which is all this module needs to know.
 Per iteration each rank
 
   1. runs the fused pull kernel on its rows: reads the full contrib vector, writes its slice of
@@ -44,30 +48,82 @@ def vertex_range(rank: int, world: int, m: int) -> Tuple[int, int, int]:
     return lo, hi, chunk
 
 
+def padded_chunk(bounds) -> int:
+    """Slot length of the padded vertex space for the ranges [bounds[r], bounds[r+1]): the longest range, rounded up to
+    4 entries (16-byte aligned slices)."""
+    longest = max(int(bounds[r + 1]) - int(bounds[r]) for r in range(len(bounds) - 1))
+    return (longest + 3) & ~3
+
+
 class ShardedPageRank:
     def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None,
-                 damping: float = 0.85, parts: int = 4, exchange: str = "auto"):
+                 damping: float = 0.85, parts: int = 4, exchange: str = "auto", first_diff_extra: float = 0.0,
+                 force_collectives: bool = False):
+        """force_collectives (test aid): run the exchange collectives even with a single rank.  first_diff_extra: L1 change of vertices OUTSIDE the sharded state in the first iteration of solve() (the
+        dead vertices of a squished graph move from 1/m to the base score; gdn_pr_squish_import_dev reports it)."""
         self.be = backend
-        self.parts = max(1, int(parts)) if world > 1 and hasattr(backend, "pull_rows") else 1
+        self._multi = world > 1 or (force_collectives and dist is not None)
+        self.parts = max(1, int(parts)) if self._multi and hasattr(backend, "pull_rows") else 1
         self.m = m_global
         self.rank, self.world, self.dist = rank, world, dist
         self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
         self.damping = damping
-        self._inplace = True
+        self.first_diff_extra = float(first_diff_extra)
         self.cur = 0  # index of the contrib buffer holding the current iteration's input
         self.iterations = 0
         self.n_full = self.chunk * world
+        self._diff_cache = None
+        # Which collectives this backend takes is decided ONCE, here, on dummy tensors, and agreed by all ranks
+        # (all-reduce MIN): no iteration is ever repeated, and no rank can take another path than its peers.
+        self._inplace, list_ok = (True, True) if (not self._multi or dist is None) else self._probe_collectives()
+        if not list_ok:
+            self.parts = 1  # the pipelined exchange gathers into strided views
         # exchange: "dense" = every row's contribution, "compact" = only rows with out-edges (see the module docstring)
         self.exchange = "dense"
         self._cx = None
-        if world > 1 and hasattr(backend, "active_sources") and exchange in ("compact", "auto"):
+        if self._multi and dist is not None and hasattr(backend, "active_sources") and exchange in ("compact", "auto"):
+            ok = 1
             try:
-                self._setup_compact()
-                self.exchange = "compact"
+                if self.be.contrib_full(0).numel() < self.n_full + 1:
+                    raise ValueError("the contrib buffers have no dummy slot behind chunk * world entries")
             except (RuntimeError, ValueError, NotImplementedError) as e:
                 import sys
                 print(f"[sharded] compact exchange unavailable ({e}); using the dense all-gather", file=sys.stderr, flush=True)
-                self._cx = None
+                ok = 0
+            if self._agree(ok):
+                self._setup_compact()
+                self.exchange = "compact"
+
+    def _agree(self, ok: int) -> bool:
+        """True iff EVERY rank says ok (all-reduce MIN)."""
+        import torch
+        t = torch.tensor([int(ok)], dtype=torch.int32, device=self.be.contrib_full(0).device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def _probe_collectives(self):
+        """(in-place all_gather_into_tensor ok, all_gather into a list of strided views ok) for this process group, tried
+        on dummy tensors of the contrib vector's device; a form ANY rank cannot run is off for all of them."""
+        import torch
+        dev = self.be.contrib_full(0).device
+        flags = []
+        for form in ("inplace", "list"):
+            ok = 1
+            try:
+                buf = torch.zeros(8 * self.world, dtype=torch.float32, device=dev)
+                if form == "inplace":
+                    self.dist.all_gather_into_tensor(buf, buf[8 * self.rank:8 * self.rank + 8])
+                else:
+                    outs = [buf[8 * r + 4:8 * r + 8] for r in range(self.world)]
+                    self.dist.all_gather(outs, outs[self.rank], async_op=True).wait()
+            except (RuntimeError, ValueError, NotImplementedError, TypeError) as e:
+                import sys
+                print(f"[sharded] rank {self.rank}: {form} all-gather unavailable on this backend ({e})", file=sys.stderr, flush=True)
+                ok = 0
+            flags.append(ok)
+        t = torch.tensor(flags, dtype=torch.int32, device=dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t[0].item())), bool(int(t[1].item()))
 
     def _setup_compact(self):
         """Index lists of the compact exchange, one set per pipeline part: `my` = positions (in the full vector) of this
@@ -75,8 +131,6 @@ class ShardedPageRank:
         n_full; `all` = the same lists of every rank, in all-gather order."""
         import torch
         full = self.be.contrib_full(0)
-        if full.numel() < self.n_full + 1:
-            raise ValueError("the contrib buffers have no dummy slot behind chunk * world entries")
         act = self.be.active_sources()
         ml = self.hi - self.lo
         cx = []
@@ -106,16 +160,12 @@ class ShardedPageRank:
         self._gather(self.cur)
 
     def _gather(self, which):
-        if self.world > 1:
+        if self._multi:
             full = self.be.contrib_full(which)[:self.n_full]
             mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
-            if self._inplace:
-                try:  # in-place all-gather: each rank's slice already sits at its place in `full`
-                    self.dist.all_gather_into_tensor(full, mine)
-                    return
-                except (RuntimeError, ValueError):
-                    self._inplace = False  # a backend that rejects aliasing: gather from a copy
-            self.dist.all_gather_into_tensor(full, mine.clone())
+            # in-place: each rank's slice already sits at its place in `full` (a backend that rejects the aliasing --
+            # found by the probe at setup -- gathers from a copy)
+            self.dist.all_gather_into_tensor(full, mine if self._inplace else mine.clone())
 
     def part_ranges(self):
         """Row ranges [r0,r1) (relative to a rank's first row) of the pipeline parts: equal on every rank,
@@ -158,59 +208,50 @@ class ShardedPageRank:
                 full.index_copy_(0, cx["all"][b:], cx["recv"][b:])
 
     def step(self):
-        """One PageRank iteration; returns nothing (the L1 change stays on the device)."""
+        """One PageRank iteration; returns nothing (the L1 change stays on the device).  The exchange form was fixed at
+        setup (probe + agreement of all ranks): a collective that fails here is an error, never a silent redo -- the pull
+        updates the scores in place, so a repeated pull would report an L1 change of ~0 and fake convergence."""
         nxt = self.cur ^ 1
         if self._cx is not None:
-            try:
-                self._step_compact(nxt)
-            except (RuntimeError, ValueError, NotImplementedError) as e:
-                # a backend that rejects one of the collectives: redo the iteration with the dense exchange (the pull
-                # only reads contrib[cur], so repeating it is exact)
-                import sys
-                print(f"[sharded] compact exchange failed ({e}); falling back to the dense all-gather", file=sys.stderr, flush=True)
-                self._cx = None
-                self.exchange = "dense"
-                return self.step()
+            self._step_compact(nxt)
         elif self.parts <= 1:
             self.be.pull(self.cur, nxt, self.damping)
             self._gather(nxt)
         else:
-            try:
-                ranges = self.part_ranges()
-                works = []
-                for j, (r0, r1) in enumerate(ranges):
-                    self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
-                    if r1 > r0:
-                        works.append(self._gather_rows_async(nxt, r0, r1))
-                for w in works:
-                    w.wait()
-            except (RuntimeError, ValueError, NotImplementedError) as e:
-                # a backend that cannot gather into strided views: redo the iteration unpipelined (the pull only
-                # reads contrib[cur], so repeating it is exact; the L1 change of THIS step is the repeated one)
-                import sys
-                print(f"[sharded] pipelined exchange unavailable ({e}); falling back to one all-gather per iteration",
-                      file=sys.stderr, flush=True)
-                self.parts = 1
-                self.be.pull(self.cur, nxt, self.damping)
-                self._gather(nxt)
+            ranges = self.part_ranges()
+            works = []
+            for j, (r0, r1) in enumerate(ranges):
+                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
+                if r1 > r0:
+                    works.append(self._gather_rows_async(nxt, r0, r1))
+            for w in works:
+                w.wait()
         self.cur = nxt
         self.iterations += 1
+        self._diff_cache = None
 
     def global_diff(self) -> float:
-        """Sum of the local L1 changes of the LAST step over all ranks (blocking)."""
-        d = self.be.diff_tensor()
-        if self.world > 1:
-            self.dist.all_reduce(d)
-        return float(d.item())
+        """Sum of the local L1 changes of the LAST step over all ranks (blocking; safe to call more than once)."""
+        if self._diff_cache is None:
+            d = self.be.diff_tensor().clone()  # never reduce the backend's tensor in place: a second call would
+            if self._multi:                    # return world times the value
+                self.dist.all_reduce(d)
+            self._diff_cache = float(d.item())
+        return self._diff_cache
 
     def solve(self, epsilon: float = 1e-4, max_iter: int = 100) -> Tuple[int, float]:
         """Iterate like src/pr/omp_base.cc:20-37; returns (iterations as printed, last error)."""
         self.init_contrib()
         err = 0.0
         it = 0
+        extra = self.first_diff_extra
+        if hasattr(self.be, "first_iteration_extra"):
+            extra += float(self.be.first_iteration_extra())
         for it in range(max_iter):
             self.step()
             err = self.global_diff()
+            if it == 0:
+                err += extra  # vertices outside the state (no edge at all) move to the base score in iteration 1
             if err < epsilon:
                 break
         return it + 1, err
@@ -220,9 +261,10 @@ class HipPageRankBackend:
     """Local shard on one MI355X: torch device tensors + the _dev entry points of the C-ABI."""
 
     def __init__(self, torch, in_csr_handle, out_degree_local, m_global: int, lo: int, hi: int, chunk: int,
-                 world: int, device, layout: int = -1, m_base: int = 0):
-        """m_base > 0: the shard belongs to a squished graph of m_global live vertices (gdn_pr_squish_*) whose original
-        vertex count m_base sets the base score and the start scores."""
+                 world: int, device, layout: int = -1, m_base: int = 0, force_sharded: bool = False):
+        """m_global: size of the vertex space the shard's column ids live in (the padded space chunk * world of a sharded
+        run); m_base > 0: the ORIGINAL vertex count, which sets the base score and the start scores (a squished and / or
+        padded space has another size).  force_sharded: treat a single rank like one of many (no plan-internal squish)."""
         from . import _cabi
         self.torch, self._cabi, self.L = torch, _cabi, _cabi.lib()
         self.device = device
@@ -235,7 +277,8 @@ class HipPageRankBackend:
         # a single rank that holds the whole graph works on the LIVE vertices only (GDN_LAYOUT_PB_SQUISHED: vertices without
         # any edge keep the base score and are left out of the per-iteration state; GDN_PR_SQUISH=0 keeps them in)
         import os
-        if world == 1 and layout in (_cabi.GDN_LAYOUT_AUTO, _cabi.GDN_LAYOUT_PB) and os.environ.get("GDN_PR_SQUISH", "1") != "0":
+        single = world == 1 and not force_sharded
+        if single and layout in (_cabi.GDN_LAYOUT_AUTO, _cabi.GDN_LAYOUT_PB) and os.environ.get("GDN_PR_SQUISH", "1") != "0":
             nnz = C.c_uint64(0)
             _cabi.check(self.L.gdn_graph_info(in_csr_handle, None, C.byref(nnz), None, None))
             env = os.environ.get("GDN_PR_LAYOUT", "")
@@ -249,7 +292,7 @@ class HipPageRankBackend:
         _cabi.check(self.L.gdn_pr_plan_layout(self.plan, C.byref(lay), C.byref(lg)))
         _cabi.check(self.L.gdn_pr_plan_state_size(self.plan, C.byref(ms)))
         self.layout, self.log_blk, self.m_state = lay.value, lg.value, ms.value
-        self.squished = world == 1 and self.m_state != self.m_local
+        self.squished = single and self.m_state != self.m_local
         n_vec = self.m_state if self.squished else n_full
         # + 4 entries behind the vector: [n_full] is the dummy slot of the compact exchange (16-byte alignment kept)
         self.contribs = [torch.zeros(n_vec + 4, dtype=torch.float32, device=device) for _ in range(2)]
@@ -268,6 +311,12 @@ class HipPageRankBackend:
 
     def contrib_full(self, which):
         return self.contribs[which]
+
+    def first_iteration_extra(self) -> float:
+        """L1 change of the vertices outside this plan's state in the first iteration after the import (squished plan)."""
+        d = C.c_double(0.0)
+        self._cabi.check(self.L.gdn_pr_import_diff(self.plan, C.byref(d)))
+        return d.value
 
     def active_sources(self):
         """Rows of this rank whose contribution anybody reads: the vertices with out-edges."""
@@ -337,18 +386,17 @@ class ShardedSpMV:
     rows [lo,hi) with global column ids and its slice of x; one all-gather of x (m*4 B) precedes the local multiply,
     y stays distributed.  Iterated use (power method) repeats exactly this exchange per multiply."""
 
-    def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None):
+    def __init__(self, backend, m_global: int, rank: int = 0, world: int = 1, dist=None, inplace: bool = False):
+        """inplace: gather x in place (RCCL and gloo take the aliasing; off by default: one copy of the slice)."""
         self.be, self.m, self.rank, self.world, self.dist = backend, m_global, rank, world, dist
         self.lo, self.hi, self.chunk = vertex_range(rank, world, m_global)
+        self.inplace = inplace
 
     def gather_x(self):
         if self.world > 1:
             full = self.be.x_full()
             mine = full[self.rank * self.chunk:(self.rank + 1) * self.chunk]
-            try:
-                self.dist.all_gather_into_tensor(full, mine)
-            except (RuntimeError, ValueError):
-                self.dist.all_gather_into_tensor(full, mine.clone())
+            self.dist.all_gather_into_tensor(full, mine if self.inplace else mine.clone())
 
     def multiply(self):
         self.gather_x()
@@ -385,18 +433,31 @@ class HipSpMVBackend:
             self.plan = C.c_void_p()
 
 
-def edge_balanced_ranges(rowptr, world: int):
+def edge_balanced_ranges(rowptr, world: int, min_rows: int = 0):
     """Row ranges [lo,hi) of `world` ranks with about nnz/world edges each (binary search on the row offsets).
-    rowptr: numpy array of m+1 offsets."""
+    rowptr: numpy array of m+1 offsets.  min_rows = 1: every range keeps at least one row (what the C-ABI's
+    gdn_graph_balanced_ranges / gdn_multi_ranges do -- a PageRank / SpMV shard without rows has no plan)."""
     import numpy as np
     rp = np.asarray(rowptr).astype(np.int64)
     m, nnz = len(rp) - 1, int(rp[-1])
+    assert min_rows * world <= m
     bounds = [0]
     for r in range(1, world):
         b = int(np.searchsorted(rp, nnz * r // world, side="left"))
-        bounds.append(min(max(b, bounds[-1]), m))
+        b = max(b, bounds[-1] + min_rows)
+        bounds.append(min(b, m - min_rows * (world - r)))
     bounds.append(m)
     return [(bounds[r], bounds[r + 1]) for r in range(world)]
+
+
+def pad_columns(colidx, bounds, chunk: int):
+    """Column ids moved into the padded vertex space (numpy mirror of gdn_graph_slice_padded's relabelling):
+    vertex v of range r -> r * chunk + (v - bounds[r])."""
+    import numpy as np
+    b = np.asarray(bounds, dtype=np.int64)
+    c = np.asarray(colidx).astype(np.int64)
+    r = np.searchsorted(b, c, side="right") - 1
+    return (r * chunk + (c - b[r])).astype(np.int32)
 
 
 class ShardedTC:

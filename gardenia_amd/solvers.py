@@ -78,15 +78,44 @@ def BFSSolver(g: Graph, source: int, dist: np.ndarray) -> dict:
     return st.as_dict()
 
 
-def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_iter=MAX_ITER) -> dict:
-    """src/pr/pr.h:31.  scores: float32[m], pre-filled with 1/m by the caller."""
+def num_gpus() -> int:
+    """GDN_NUM_GPUS: how many devices PRSolver / SpmvSolver spread over (the reference's OMP_NUM_THREADS analogue)."""
+    import os
+    try:
+        return max(1, int(os.environ.get("GDN_NUM_GPUS", "1")))
+    except ValueError:
+        return 1
+
+
+def pr_last_trace() -> np.ndarray:
+    """L1 change of every iteration of this thread's last PRSolver call (what src/pr/omp_base.cc:35 prints)."""
+    n = C.c_int32(0)
+    _cabi.check(_cabi.lib().gdn_pr_last_trace(0, C.byref(n), None))
+    d = np.zeros(max(n.value, 1), np.float64)
+    _cabi.check(_cabi.lib().gdn_pr_last_trace(n.value, C.byref(n), _p(d)))
+    return d[:n.value]
+
+
+def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_iter=MAX_ITER, ngpus: Optional[int] = None,
+             devices=None) -> dict:
+    """src/pr/pr.h:31.  scores: float32[m], pre-filled with 1/m by the caller.  ngpus (default GDN_NUM_GPUS or 1) > 1
+    or an explicit `devices` list: gdn_pr_multi, vertex-range shards on that many devices."""
     assert scores.dtype == np.float32 and scores.flags.c_contiguous
     irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
     deg = _arr(g.out_degrees(), np.int32)
     st = _cabi.GdnStats()
-    _cabi.check(_cabi.lib().gdn_pr(g.V(), g.E(), _p(irp), _p(ici), _p(deg), _p(scores), float(damping),
-                                   float(epsilon), int(max_iter), C.byref(st)))
-    return st.as_dict()
+    n = num_gpus() if ngpus is None else int(ngpus)
+    if devices is not None or n > 1:
+        dv = None if devices is None else _arr(devices, np.int32)
+        n = n if dv is None else len(dv)
+        _cabi.check(_cabi.lib().gdn_pr_multi(g.V(), g.E(), _p(irp), _p(ici), _p(deg), _p(scores), float(damping),
+                                             float(epsilon), int(max_iter), n, _p(dv), C.byref(st)))
+    else:
+        _cabi.check(_cabi.lib().gdn_pr(g.V(), g.E(), _p(irp), _p(ici), _p(deg), _p(scores), float(damping),
+                                       float(epsilon), int(max_iter), C.byref(st)))
+    out = st.as_dict()
+    out["trace"] = pr_last_trace()
+    return out
 
 
 def PRDeltaSolver(g: Graph, scores: np.ndarray, damping: float = 0.85, epsilon: float = 1e-4, epsilon2: float = 1e-3,
@@ -111,13 +140,19 @@ def BCSolver(g: Graph, source: int, scores: np.ndarray) -> dict:
     return st.as_dict()
 
 
-def SpmvSolver(g: Graph, Ax: np.ndarray, x: np.ndarray, y: np.ndarray) -> dict:
-    """src/spmv/spmv.h:29.  y += A x over the rows of (in_rowptr, in_colidx)."""
+def SpmvSolver(g: Graph, Ax: np.ndarray, x: np.ndarray, y: np.ndarray, ngpus: Optional[int] = None, devices=None) -> dict:
+    """src/spmv/spmv.h:29.  y += A x over the rows of (in_rowptr, in_colidx).  ngpus / devices as for PRSolver."""
     assert y.dtype == np.float32 and y.flags.c_contiguous
     irp, ici = _arr(g.in_rowptr(), np.uint64), _arr(g.in_colidx(), np.int32)
     Ax, x = _arr(Ax, np.float32), _arr(x, np.float32)
     st = _cabi.GdnStats()
-    _cabi.check(_cabi.lib().gdn_spmv(g.V(), g.E(), _p(irp), _p(ici), _p(Ax), _p(x), _p(y), C.byref(st)))
+    n = num_gpus() if ngpus is None else int(ngpus)
+    if devices is not None or n > 1:
+        dv = None if devices is None else _arr(devices, np.int32)
+        n = n if dv is None else len(dv)
+        _cabi.check(_cabi.lib().gdn_spmv_multi(g.V(), g.E(), _p(irp), _p(ici), _p(Ax), _p(x), _p(y), n, _p(dv), C.byref(st)))
+    else:
+        _cabi.check(_cabi.lib().gdn_spmv(g.V(), g.E(), _p(irp), _p(ici), _p(Ax), _p(x), _p(y), C.byref(st)))
     return st.as_dict()
 
 
@@ -191,7 +226,7 @@ class ResidentBFS:
 class ResidentSpMV:
     """y += A x with the matrix resident (gdn_spmv_plan_*).  layout: 0 CSR merge-path, 1 PB."""
 
-    def __init__(self, g: Graph, Ax: np.ndarray, layout: int = _cabi.GDN_LAYOUT_PB):
+    def __init__(self, g: Graph, Ax: np.ndarray, layout: int = _cabi.GDN_LAYOUT_AUTO):
         L = _cabi.lib()
         self.L, self.m, self.nnz = L, g.V(), g.E()
         self.h, self.plan = C.c_void_p(), C.c_void_p()

@@ -7,7 +7,7 @@
  * shape of the reference's legacy solvers (m, nnz, row_offsets, column_indices,
  * labels/values -- e.g. src/bfs/topo_base.cu:35, src/pr/vector.cu:83) with the widths of
  * the live Graph class (include/csr_graph.h:50-51: uint64_t offsets, int32_t vertex ids).
- * gardenia_amd/host/solvers.hpp adapts them 1:1 to the live `XxxSolver(Graph&, ...)`
+ * gardenia_amd/host/solvers.cc (declarations: gardenia_host.hpp) adapts them 1:1 to the live `XxxSolver(Graph&, ...)`
  * signatures, so a main.cc written like the reference's links unchanged.
  *
  * Conventions
@@ -43,7 +43,7 @@ typedef enum gdn_status {
  * it excludes h2d_ms (graph + label upload) and includes prep_ms only where stated. */
 typedef struct gdn_stats {
   int32_t iterations;       /* PR iterations / BFS levels / CC rounds / SSSP phases */
-  int32_t reserved;
+  int32_t reserved;         /* gdn_pr_multi: the exchange that ran (1 RCCL all-gather, 2 peer copies); else 0 */
   double solve_ms;
   double h2d_ms;
   double prep_ms;           /* solver-private layout preparation (tile tables, orientation) */
@@ -75,11 +75,39 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
            const int32_t *out_degree, float *scores, float damping, double epsilon, int32_t max_iter,
            gdn_stats *stats);
 
+/* The per-iteration L1 changes of the calling thread's last gdn_pr / gdn_pr_multi solve: what the reference prints as it
+ * iterates (" %2d    %lf", src/pr/omp_base.cc:35; the only golden it ships is that trace,
+ * test/reference/graph-pr.mtx.out:13-27).  *n = iterations recorded; the first min(*n, capacity) go to diff. */
+int gdn_pr_last_trace(int32_t capacity, int32_t *n, double *diff);
+
+/* PRSolver on `ngpus` devices of this node (SURVEY 8b `gdn_pr(..., int ngpus, gdn_stats*)`, 8e; supersedes the
+ * edge-list slicing stub of include/graph_gpu.h:145-165 -- the reference has no multi-GPU hot path).  Same arguments
+ * and results as gdn_pr.  One process, one host thread per device; the rows of the in-CSR are cut into ngpus contiguous
+ * vertex ranges of about nnz / ngpus edges (binary search on the row offsets); per iteration every device pulls its
+ * rows and the slices of the next contribution vector are exchanged -- an in-place RCCL all-gather over xGMI (librccl is
+ * dlopen'ed on first use), or peer copies pipelined behind the pull kernels (GDN_MULTI_EXCHANGE=p2p, and whenever a
+ * device is listed twice: RCCL refuses that, and it is how a 1-GPU box exercises this path); the 8-byte L1 changes are
+ * summed on the host in rank order.  devices: ngpus HIP device ids (NULL = 0 .. ngpus-1).  ngpus > m is clamped.
+ * With the propagation-blocked layout (shards of >= 2^22 edges, or GDN_PR_LAYOUT=pb) the scores are bit-identical to
+ * gdn_pr's for every ngpus.  stats.reserved reports the exchange that ran. */
+int gdn_pr_multi(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in_colidx,
+                 const int32_t *out_degree, float *scores, float damping, double epsilon, int32_t max_iter,
+                 int32_t ngpus, const int32_t *devices, gdn_stats *stats);
+/* the vertex ranges gdn_pr_multi / gdn_spmv_multi cut a host CSR into: bounds[ngpus + 1] (range r = [bounds[r],
+ * bounds[r+1])), *chunk (nullable) = slot length of the padded vertex space */
+int gdn_multi_ranges(int32_t m, const uint64_t *rowptr, int32_t ngpus, int32_t *bounds, int32_t *chunk);
+
 /* replaces SpmvSolver(Graph&, const ValueT* Ax, const ValueT* x, ValueT* y):
  * src/spmv/spmv.h:29; caller src/spmv/main.cc:39.  y[i] += sum_k Ax[k]*x[Aj[k]] over the rows
  * of (Ap, Aj) = g.in_rowptr()/g.in_colidx() (src/spmv/omp_base.cc:10-11). */
 int gdn_spmv(int32_t m, uint64_t nnz, const uint64_t *Ap, const int32_t *Aj, const float *Ax,
              const float *x, float *y, gdn_stats *stats);
+
+/* SpmvSolver on `ngpus` devices (SURVEY 8b `gdn_spmv(..., ngpus, ...)`): row ranges as for gdn_pr_multi, x replicated
+ * (one upload per device: a single multiply needs no exchange), every device multiplies its rows and returns its slice
+ * of y.  Same results as gdn_spmv bit for bit (the merge-path row sums do not depend on the cut). */
+int gdn_spmv_multi(int32_t m, uint64_t nnz, const uint64_t *Ap, const int32_t *Aj, const float *Ax, const float *x,
+                   float *y, int32_t ngpus, const int32_t *devices, gdn_stats *stats);
 
 /* replaces SSSPSolver(Graph&, int source, DistT* weight, DistT* dist, int delta):
  * src/sssp/sssp.h:47; caller src/sssp/main.cc:27.  dist: in = kDistInf (INT_MAX,
@@ -132,7 +160,14 @@ typedef struct gdn_graph gdn_graph;
 
 int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
                      gdn_graph **out);
-/* wrap device arrays owned by the caller (e.g. torch tensors); nothing is copied */
+/* gdn_graph_upload checks the arrays on the device (offsets ascending within [0, nnz], column ids within [0, m)) and
+ * returns GDN_ERR_INVALID for a malformed CSR instead of letting a solver read out of bounds.  gdn_graph_upload_rows:
+ * rows [row_lo, row_hi) of a host CSR as an independent graph (offsets rebased, column ids < n_cols unchanged) -- the
+ * shard one device of gdn_pr_multi / gdn_spmv_multi holds.  gdn_graph_validate: the same check for wrapped arrays. */
+int gdn_graph_upload_rows(int32_t m, const uint64_t *rowptr, const int32_t *colidx, int32_t row_lo, int32_t row_hi,
+                          int32_t n_cols, gdn_graph **out);
+int gdn_graph_validate(const gdn_graph *g, int32_t n_cols);
+/* wrap device arrays owned by the caller (e.g. torch tensors); nothing is copied (and nothing checked) */
 int gdn_graph_wrap_dev(int32_t m, uint64_t nnz, const uint64_t *d_rowptr, const int32_t *d_colidx,
                        gdn_graph **out);
 int gdn_graph_free(gdn_graph *g);
@@ -148,6 +183,14 @@ int gdn_graph_symmetrize(const gdn_graph *g, gdn_graph **out);
 /* rows [row_lo,row_hi) as an independent graph (column ids stay global): the vertex-range
  * shard one GPU holds in the multi-GPU PageRank/SpMV path */
 int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn_graph **out);
+/* nnz-balanced vertex ranges of a resident graph (binary search on row_offsets): bounds[world + 1],
+ * bounds[0] = 0, bounds[world] = m, range r = [bounds[r], bounds[r+1]) holds about nnz / world edges and at least one row */
+int gdn_graph_balanced_ranges(const gdn_graph *g, int32_t world, int32_t *bounds);
+/* rows of range `rank` as an independent graph whose column ids are moved into the PADDED vertex space of a sharded
+ * run: vertex v of range r -> r * chunk + (v - bounds[r]) (chunk >= the longest range).  Every rank's slice of a
+ * replicated per-vertex vector then starts at a multiple of chunk: equal all-gather slots for unequal ranges. */
+int gdn_graph_slice_padded(const gdn_graph *g, int32_t world, const int32_t *bounds, int32_t chunk, int32_t rank,
+                           gdn_graph **out);
 /* Device ingest: edge list (host arrays, 0-based ids) -> resident CSR with the clean-up of the reference
  * loader (include/csr_graph.h:108 self loops dropped, :127 rows sorted ascending, :132-143 duplicates
  * dropped; symmetrize != 0 also inserts every reverse edge, :112-115).  One radix sort on the device
@@ -336,6 +379,9 @@ int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stat
  * the ranges partition its rows (by DAG-edge count), the partial counts add up (gardenia_amd.sharded.ShardedTC).
  * stats.edges_traversed = DAG edges of the range. */
 int gdn_graph_orient(const gdn_graph *csr, gdn_graph **dag);
+/* algorithmic bytes of one count on an oriented graph, SURVEY 8d's merge-equivalent model (the roofline denominator of
+ * TC): 4 * SUM over DAG edges (u,v) of (d+(u) + d+(v)) + 4 nnz [source list] + 4 nnz [column ids] + 8 (m + 1) */
+int gdn_tc_model_bytes(const gdn_graph *dag, uint64_t *bytes);
 int gdn_tc_rows_dev(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats *stats);
 
 #ifdef __cplusplus

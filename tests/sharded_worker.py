@@ -11,17 +11,21 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gardenia_amd import graphio  # noqa: E402
-from gardenia_amd.sharded import ShardedPageRank, vertex_range  # noqa: E402
+from gardenia_amd.sharded import (ShardedPageRank, edge_balanced_ranges, pad_columns, padded_chunk,  # noqa: E402
+                                  vertex_range)
 
 
 class NumpyBackend:
     """Row-range pull in numpy fp32 (test stand-in for HipPageRankBackend)."""
 
-    def __init__(self, g_in, out_degree, m, lo, hi, chunk, world):
+    def __init__(self, g_in, out_degree, m, lo, hi, chunk, world, row0=None, colidx=None):
+        """Rows [row0, row0 + hi - lo) of g_in; they sit at [lo, hi) of the (possibly padded) vertex space that `colidx`
+        (default: g_in's) addresses.  m = the ORIGINAL vertex count (base score)."""
+        row0 = lo if row0 is None else row0
         self.m, self.lo, self.hi = m, lo, hi
-        self.rowptr = g_in.rowptr[lo:hi + 1].astype(np.int64)
-        self.colidx = g_in.colidx
-        self.deg = out_degree[lo:hi].astype(np.float32)
+        self.rowptr = g_in.rowptr[row0:row0 + (hi - lo) + 1].astype(np.int64)
+        self.colidx = g_in.colidx if colidx is None else colidx
+        self.deg = out_degree[row0:row0 + (hi - lo)].astype(np.float32)
         self.contribs = [torch.zeros(chunk * world + 4, dtype=torch.float32) for _ in range(2)]  # + the dummy slot
         self.scores = np.full(hi - lo, np.float32(1.0) / np.float32(m), np.float32)
         self.diff = torch.zeros(1, dtype=torch.float64)
@@ -73,10 +77,23 @@ def main():
     src, dst = graphio.csr_to_coo(g)
     g = graphio.build_csr(m, src[keep], dst[keep])
     gi = graphio.transpose(g)
-    lo, hi, chunk = vertex_range(rank, world, m)
-    be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world)
+    if os.environ.get("GDN_TEST_BALANCED") == "1":
+        # nnz-balanced ranges in the padded vertex space (what bench.py --gpus N and gdn_pr_multi do)
+        ranges = edge_balanced_ranges(gi.rowptr, world, min_rows=1)
+        bounds = [a for a, _ in ranges] + [m]
+        chunk = padded_chunk(bounds)
+        blo, bhi = ranges[rank]
+        lo, hi = rank * chunk, rank * chunk + (bhi - blo)
+        be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world, row0=blo, colidx=pad_columns(gi.colidx, bounds, chunk))
+        m_space = chunk * world
+        if rank == 0:
+            np.save(f"{out}.bounds.npy", np.array(bounds))
+    else:
+        lo, hi, chunk = vertex_range(rank, world, m)
+        be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world)
+        m_space = m
     parts = int(os.environ.get("GDN_TEST_PARTS", "4"))
-    pr = ShardedPageRank(be, m, rank, world, dist, parts=parts, exchange=os.environ.get("GDN_TEST_EXCHANGE", "auto"))
+    pr = ShardedPageRank(be, m_space, rank, world, dist, parts=parts, exchange=os.environ.get("GDN_TEST_EXCHANGE", "auto"))
     assert pr.exchange == os.environ.get("GDN_TEST_EXCHANGE", "dense"), pr.exchange
     if pr.exchange == "compact":
         assert pr.exchanged_bytes() < 4 * chunk * world

@@ -23,7 +23,7 @@ def _free_port():
 
 def _bench(extra, launcher=None):
     cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "4", "--warmup",
-                                                 "1", "--no-bfs", "--no-cpu"] + extra
+                                                 "1", "--no-bfs", "--no-cpu", "--no-extras"] + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -41,3 +41,55 @@ def test_bench_two_ranks_on_one_device_match_single():
         assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == (not extra)
         assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     assert "roofline" in single and single["roofline"]["frac"] > 0
+    assert single["step_ms"]["n"] >= 10 and single["step_ms"]["min"] <= single["step_ms"]["median"]
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must run TWO ranks (it spawns them before
+    touching the GPU) and report n_gpus 2 -- not fall back to one rank."""
+    env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "3", "--warmup", "1", "--gpus", "2",
+           "--share-device", "--no-bfs", "--no-cpu", "--no-extras"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_clean)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["n_gpus"] == 2 and "vertex-range x2 (balanced ranges" in r["config"]["partition"]
+    single = _bench([])
+    assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+    # a failing child makes the parent fail too (exit code passed through)
+    bad = subprocess.run(cmd + ["--scale", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_clean)
+    assert bad.returncode != 0
+
+
+def test_bench_equal_ranges_and_rccl_backend_with_one_rank():
+    """--ranges equal gives the same bits as the balanced cut; --force-dist runs the N>1 code path (process group, padded
+    ranges, in-place and strided all-gathers, all-reduces) through the RCCL backend with the single rank of this box."""
+    single = _bench([])
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    r = _bench(["--gpus", "2", "--share-device", "--ranges", "equal"], launcher)
+    assert "equal ranges" in r["config"]["partition"]
+    assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+    for ex in ("dense", "compact"):
+        f = _bench(["--force-dist", "--exchange", ex])
+        assert f["n_gpus"] == 1 and "RCCL all-gather" in f["config"]["partition"] and ex + " exchange" in f["config"]["partition"]
+        assert abs(f["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+
+
+def test_bench_line_carries_bfs_spmv_tc_blocks():
+    """BASELINE configs 3 and 4 and the BFS block ride on the N = 1 line (small scales here): ms median + min over >= 10
+    repetitions, GB/s against SURVEY 8d's bytes, the one-shot drop-in next to the resident plan."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "3", "--warmup", "1", "--no-cpu",
+           "--spmv-scale", "20", "--tc-scale", "16"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r["bfs"]["ms_stats"]["n"] >= 10 and 0 < r["bfs"]["roofline"]["frac"] < 1
+    assert r["bfs"]["roofline"]["algorithmic_bytes"] == 16 * r["bfs"]["reached"] + 8 * r["bfs"]["edges_traversed"] + 4 * r["config"]["vertices"]
+    sp = r["spmv"]
+    assert sp["ms"]["n"] >= 10 and 0 < sp["roofline"]["frac"] < 1
+    assert sp["roofline"]["algorithmic_bytes_per_launch"] == 8 * (sp["rows"] + 1) + 12 * sp["nnz"] + 8 * sp["rows"]
+    assert len(sp["oneshot_gdn_spmv"]) == 2 and sp["oneshot_gdn_spmv"][0]["solve_ms"] > 0
+    tc = r["tc"]
+    assert tc["ms"]["n"] >= 10 and tc["triangles"] > 0 and 0 < tc["roofline"]["frac"] < 1
+    assert tc["roofline"]["algorithmic_bytes_per_launch"] > 8 * tc["dag_edges"]

@@ -48,16 +48,20 @@ def test_part_ranges_cover_the_chunk_and_agree_across_ranks():
     assert ShardedPageRank(B(), 100, 0, 1, dist=None, parts=4).parts == 1  # a single rank is never cut
 
 
-@pytest.mark.parametrize("world,parts,exchange", [(2, 4, "dense"), (3, 4, "dense"), (2, 1, "dense"), (3, 7, "dense"),
-                                                  (2, 4, "compact"), (3, 3, "compact"), (2, 1, "compact")])
-def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange):
+@pytest.mark.parametrize("world,parts,exchange,balanced",
+                         [(2, 4, "dense", 0), (3, 4, "dense", 0), (2, 1, "dense", 0), (3, 7, "dense", 0),
+                          (2, 4, "compact", 0), (3, 3, "compact", 0), (2, 1, "compact", 0),
+                          (2, 4, "dense", 1), (3, 3, "compact", 1), (3, 1, "dense", 1)])
+def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange, balanced):
+    """balanced = 1: nnz-balanced vertex ranges in the padded vertex space, as bench.py --gpus N cuts them."""
     scale, ef = 8, 8
     out = str(tmp_path / "pr")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts), GDN_TEST_EXCHANGE=exchange)
+                   MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts), GDN_TEST_EXCHANGE=exchange,
+                   GDN_TEST_BALANCED=str(balanced))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"),
                                        str(scale), str(ef), out], env=env))
     for p in procs:
@@ -71,6 +75,10 @@ def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange):
     gi = graphio.transpose(g)
     want, it, trace = orc.pr(gi, g.degrees())
     got = np.concatenate([np.load(f"{out}.{r}.npy") for r in range(world)])
+    if balanced:  # the cut follows the edges, not the vertex count
+        b = np.load(f"{out}.bounds.npy")
+        per = np.diff(gi.rowptr[b].astype(np.int64))
+        assert per.max() <= gi.nnz / world + gi.degrees().max() + 1
     meta = np.load(f"{out}.meta.npy")
     assert int(meta[0]) == it
     assert got.shape == want.shape
@@ -109,6 +117,20 @@ def test_edge_balanced_ranges():
         assert all(a[1] == b[0] and a[0] <= a[1] for a, b in zip(r, r[1:]))
     assert edge_balanced_ranges(rp, 2) == [(0, 5), (5, 8)]  # the first row boundary at or behind nnz / 2 edges
     assert edge_balanced_ranges(np.zeros(4, np.uint64), 3)[-1] == (0, 3)  # no edges: everything to the last rank
+    for w in (1, 2, 3, 8):  # min_rows = 1: nobody is left without a row
+        r = edge_balanced_ranges(rp, w, min_rows=1)
+        assert r[0][0] == 0 and r[-1][1] == 8 and all(hi > lo for lo, hi in r)
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    assert edge_balanced_ranges(np.zeros(4, np.uint64), 3, min_rows=1) == [(0, 1), (1, 2), (2, 3)]
+
+
+def test_pad_columns_and_padded_chunk():
+    from gardenia_amd.sharded import pad_columns, padded_chunk
+    bounds = [0, 5, 6, 13]
+    chunk = padded_chunk(bounds)
+    assert chunk == 8
+    got = pad_columns(np.array([0, 4, 5, 6, 12], np.int32), bounds, chunk)
+    assert got.tolist() == [0, 4, 8, 16, 22]
 
 
 @pytest.mark.parametrize("world", [2, 3])
