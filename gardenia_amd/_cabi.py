@@ -28,7 +28,7 @@ class GdnStats(C.Structure):
                 ("last_error", C.c_double)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 
 class GardeniaError(RuntimeError):

@@ -48,7 +48,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must run TWO ranks (it spawns them before
     touching the GPU) and report n_gpus 2 -- not fall back to one rank."""
     env_clean = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "3", "--warmup", "1", "--gpus", "2",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "4", "--warmup", "1", "--gpus", "2",
            "--share-device", "--no-bfs", "--no-cpu", "--no-extras"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_clean)
     assert out.returncode == 0, out.stderr[-2000:]
