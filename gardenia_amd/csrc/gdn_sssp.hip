@@ -15,6 +15,7 @@
 // (src/sssp/verifier.cc:8-39).
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "gdn_expand.hpp"
 #include "gdn_pb.hpp"
@@ -25,7 +26,7 @@ struct SsspCounters {
   unsigned big_count;
   unsigned overflow;
   int min_far;
-  unsigned pad;
+  int max_dist;  // largest distance written since the counters were reset (the dense sweeps size their candidates by it)
   unsigned long long relaxed;
 };
 
@@ -44,6 +45,7 @@ struct SsspVis {
   int32_t thr_hi;
   int32_t pass;
   int32_t du;  // per-lane: distance of this lane's source vertex
+  int32_t max_d;  // per-lane: largest distance this lane wrote
   GdnWlStage near_st, far_st;  // per-wave LDS strips: one atomic on the hot counters per flush, not per wave step
   __device__ __forceinline__ void begin_big(vid_t v) { du = dist[v]; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
@@ -56,6 +58,7 @@ struct SsspVis {
       if (nd < dist[dst]) {
         const int32_t old = atomicMin(&dist[dst], nd);
         if (nd < old) {
+          max_d = nd > max_d ? nd : max_d;
           if (nd < thr_hi) {
             push_near = atomicExch(&stamp[dst], pass) != pass;
             if (push_near) near_edges += rowptr[dst + 1] - rowptr[dst];
@@ -73,6 +76,14 @@ struct SsspVis {
     gdn_wl_flush(far_st, far_out, &cnt->far_count, cap, &cnt->overflow);
     const unsigned long long s = gdn_wave_sum(near_edges);
     if (gdn_lane() == 0 && s) atomicAdd(&cnt->relaxed, s);
+    int32_t mx = max_d;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int32_t t = __shfl_xor(mx, o, 64);
+      mx = t > mx ? t : mx;
+    }
+    // one hot address: only a wave that raises the maximum touches it
+    if (gdn_lane() == 0 && mx > __hip_atomic_load(&cnt->max_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->max_dist, mx);
   }
 };
 
@@ -84,6 +95,7 @@ sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ n
   vis.near_st.strip = s_stage[0][threadIdx.x >> 6];
   vis.far_st.strip = s_stage[1][threadIdx.x >> 6];
   vis.near_st.n = vis.far_st.n = 0;
+  vis.max_d = 0;
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
   eoff_t b = 0, e = 0;
   vid_t v = 0;
@@ -109,6 +121,7 @@ sssp_relax_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, SsspVis
   vis.far_st.strip = s_stage[1][threadIdx.x >> 6];
   vis.near_st.n = vis.far_st.n = 0;
   vis.du = 0;
+  vis.max_d = 0;
   vis.near_edges = 0;
   gdn_expand_big_items(rowptr, big, vis);
   vis.finish();
@@ -195,14 +208,37 @@ int gdn_reached_edges(const gdn_graph *g, const int32_t *d_dist, int32_t unreach
 //   phase B (per destination bin): ds_min_u32 into the bin's LDS minima, then dist[v] = min(dist[v], .)
 //           for the bin's rows; improved rows are counted and flagged in a bitmap (the next worklist)
 // ------------------------------------------------------------------------------------------
-typedef unsigned short sssp_u16x4 __attribute__((ext_vector_type(4)));
+// Bytes per edge are what a sweep costs, so both per-edge streams are as narrow as the DATA allows (decided per plan /
+// per sweep on the host, every variant exact):
+//   weights    WB = 0: all weights equal (no stream at all -- unit weights, the reference main's input, src/sssp/main.cc:26),
+//              1 / 2: every weight < 2^8 / 2^16 (narrowed once at plan build), 4: int32 as given
+//   candidates CT = u8 / u16 while (largest finite distance + largest weight) < 0xFF / 0xFFFF -- the host tracks the largest
+//              distance written (SsspCounters::max_dist) --, u32 otherwise; INF is the all-ones pattern of the type
+// One thread handles one GROUP of 8 edges per step (16 B of U, 8 x WB B of weights, one G entry, 8 x sizeof(CT) B out).
 typedef unsigned sssp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sssp_u32x2 __attribute__((ext_vector_type(2)));
 
+template <typename CT>
+struct SsspCand;
+template <>
+struct SsspCand<uint16_t> {
+  static constexpr unsigned INF = 0xFFFFu;
+};
+template <>
+struct SsspCand<uint32_t> {
+  static constexpr unsigned INF = 0xFFFFFFFFu;
+};
+template <>
+struct SsspCand<uint8_t> {
+  static constexpr unsigned INF = 0xFFu;
+};
+
+template <int WB, typename CT>
 __global__ void __launch_bounds__(PB_THREADS)
 sssp_pb_expand_kernel(const int32_t *__restrict__ dist, int32_t m_src, int log_chunk,
                       const eoff_t *__restrict__ chunk_ptr, const uint32_t *__restrict__ chunk_order,
                       const uint16_t *__restrict__ U, const uint32_t *__restrict__ G,
-                      const uint32_t *__restrict__ W, unsigned *__restrict__ cand) {
+                      const void *__restrict__ Wv, unsigned w_uniform, CT *__restrict__ cand, unsigned *__restrict__ bad) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_d[];
   const unsigned ch = 1u << log_chunk;
   const unsigned c = chunk_order[blockIdx.x];
@@ -213,76 +249,135 @@ sssp_pb_expand_kernel(const int32_t *__restrict__ dist, int32_t m_src, int log_c
   }
   if (threadIdx.x == 0) s_d[ch] = (unsigned)GDN_DIST_INF;  // pad edges
   __syncthreads();
-  const eoff_t h0 = chunk_ptr[c] >> 2, h1 = chunk_ptr[c + 1] >> 2;
-  const sssp_u16x4 *U4 = reinterpret_cast<const sssp_u16x4 *>(U);
-  const sssp_u32x4 *W4 = reinterpret_cast<const sssp_u32x4 *>(W);
-  sssp_u32x4 *C4 = reinterpret_cast<sssp_u32x4 *>(cand);
+  const eoff_t g0 = chunk_ptr[c] >> 3, g1 = chunk_ptr[c + 1] >> 3;
+  const sssp_u32x4 *U8 = reinterpret_cast<const sssp_u32x4 *>(U);
   constexpr int UNR = 4;
-  for (eoff_t h = h0 + threadIdx.x; h < h1; h += UNR * PB_THREADS) {
-    sssp_u16x4 u[UNR];
-    sssp_u32x4 w[UNR];
+  constexpr unsigned CINF = SsspCand<CT>::INF;
+  unsigned overflowed = 0;
+  for (eoff_t g = g0 + threadIdx.x; g < g1; g += UNR * PB_THREADS) {
+    sssp_u32x4 u[UNR];
+    unsigned w[UNR][8];
     unsigned d[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
-      if (hh < h1) {
-        u[r] = __builtin_nontemporal_load(U4 + hh);
-        w[r] = __builtin_nontemporal_load(W4 + hh);
-        d[r] = __builtin_nontemporal_load(G + (hh >> 1));
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        u[r] = __builtin_nontemporal_load(U8 + gg);
+        d[r] = __builtin_nontemporal_load(G + gg);
+        if (WB == 1) {
+          const sssp_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const sssp_u32x2 *>(Wv) + gg);
+#pragma unroll
+          for (int k = 0; k < 8; k++) w[r][k] = ((k < 4 ? t.x : t.y) >> (8 * (k & 3))) & 0xFFu;
+        } else if (WB == 2) {
+          const sssp_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const sssp_u32x4 *>(Wv) + gg);
+#pragma unroll
+          for (int k = 0; k < 8; k++) w[r][k] = (t[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+        } else if (WB == 4) {
+          const sssp_u32x4 t0 = __builtin_nontemporal_load(reinterpret_cast<const sssp_u32x4 *>(Wv) + 2 * gg);
+          const sssp_u32x4 t1 = __builtin_nontemporal_load(reinterpret_cast<const sssp_u32x4 *>(Wv) + 2 * gg + 1);
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            w[r][k] = t0[k];
+            w[r][4 + k] = t1[k];
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < 8; k++) w[r][k] = w_uniform;
+        }
       }
     }
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
-      const eoff_t hh = h + (eoff_t)r * PB_THREADS;
-      if (hh < h1) {
-        const unsigned INF = (unsigned)GDN_DIST_INF;
-        sssp_u32x4 o;
-        unsigned t;
-        t = s_d[u[r].x]; t = t >= INF ? INF : t + w[r].x; o.x = t < INF ? t : INF;
-        t = s_d[u[r].y]; t = t >= INF ? INF : t + w[r].y; o.y = t < INF ? t : INF;
-        t = s_d[u[r].z]; t = t >= INF ? INF : t + w[r].z; o.z = t < INF ? t : INF;
-        t = s_d[u[r].w]; t = t >= INF ? INF : t + w[r].w; o.w = t < INF ? t : INF;
-        C4[2 * (size_t)d[r] + (size_t)(hh & 1)] = o;
+      const eoff_t gg = g + (eoff_t)r * PB_THREADS;
+      if (gg < g1) {
+        unsigned o[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const unsigned uu = (u[r][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+          const unsigned t = s_d[uu];
+          unsigned nd = t + w[r][k];  // < 2^32: both are <= INT_MAX
+          if (t >= (unsigned)GDN_DIST_INF || nd >= (unsigned)GDN_DIST_INF) nd = CINF;  // no path yet (or beyond the int range)
+          else if (sizeof(CT) < 4 && nd >= CINF) {
+            overflowed = 1u;  // cannot happen: the host switches to 32-bit candidates before a distance gets here
+            nd = CINF;
+          }
+          o[k] = nd;
+        }
+        if (sizeof(CT) == 1) {
+          sssp_u32x2 v;
+          v.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+          v.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+          reinterpret_cast<sssp_u32x2 *>(cand)[(size_t)d[r]] = v;
+        } else if (sizeof(CT) == 2) {
+          sssp_u32x4 v;
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = o[2 * k] | (o[2 * k + 1] << 16);
+          reinterpret_cast<sssp_u32x4 *>(cand)[(size_t)d[r]] = v;
+        } else {
+          sssp_u32x4 v0, v1;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            v0[k] = o[k];
+            v1[k] = o[4 + k];
+          }
+          reinterpret_cast<sssp_u32x4 *>(cand)[2 * (size_t)d[r]] = v0;
+          reinterpret_cast<sssp_u32x4 *>(cand)[2 * (size_t)d[r] + 1] = v1;
+        }
       }
     }
   }
+  if (overflowed) *bad = 1u;
 }
 
+template <typename CT>
 __global__ void __launch_bounds__(PB_THREADS)
 sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__ bin_ptr,
                           const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
-                          const unsigned *__restrict__ cand, int32_t *__restrict__ dist,
+                          const CT *__restrict__ cand, int32_t *__restrict__ dist,
                           unsigned *__restrict__ improved_bits, SsspCounters *cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_min[];
   __shared__ unsigned long long s_red[PB_WAVES];
+  __shared__ int s_max[PB_WAVES];
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order[blockIdx.x];
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_min[i] = (unsigned)GDN_DIST_INF;
   __syncthreads();
-  const eoff_t q0 = bin_ptr[b] >> 2, q1 = bin_ptr[b + 1] >> 2;
-  const sssp_u32x4 *C4 = reinterpret_cast<const sssp_u32x4 *>(cand);
-  const sssp_u16x4 *V4 = reinterpret_cast<const sssp_u16x4 *>(V);
+  const eoff_t q0 = bin_ptr[b] >> 3, q1 = bin_ptr[b + 1] >> 3;
+  const sssp_u32x4 *V8 = reinterpret_cast<const sssp_u32x4 *>(V);
+  const sssp_u32x4 *C = reinterpret_cast<const sssp_u32x4 *>(cand);
   constexpr int UNR = 4;
+  constexpr unsigned CINF = SsspCand<CT>::INF;
   for (eoff_t q = q0 + threadIdx.x; q < q1; q += UNR * PB_THREADS) {
-    sssp_u32x4 xs[UNR];
-    sssp_u16x4 vs[UNR];
+    sssp_u32x4 xs[UNR][sizeof(CT) == 4 ? 2 : 1];
+    sssp_u32x4 vs[UNR];
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
       if (qq < q1) {
-        xs[r] = __builtin_nontemporal_load(C4 + qq);
-        vs[r] = __builtin_nontemporal_load(V4 + qq);
+        if (sizeof(CT) == 1) {
+          const sssp_u32x2 t = __builtin_nontemporal_load(reinterpret_cast<const sssp_u32x2 *>(cand) + qq);
+          xs[r][0].x = t.x;
+          xs[r][0].y = t.y;
+        } else if (sizeof(CT) == 2) xs[r][0] = __builtin_nontemporal_load(C + qq);
+        else {
+          xs[r][0] = __builtin_nontemporal_load(C + 2 * qq);
+          xs[r][sizeof(CT) == 4 ? 1 : 0] = __builtin_nontemporal_load(C + 2 * qq + 1);
+        }
+        vs[r] = __builtin_nontemporal_load(V8 + qq);
       }
     }
 #pragma unroll
     for (int r = 0; r < UNR; r++) {
       const eoff_t qq = q + (eoff_t)r * PB_THREADS;
       if (qq < q1) {
-        const unsigned INF = (unsigned)GDN_DIST_INF;
-        if (xs[r].x < INF) atomicMin(&s_min[vs[r].x], xs[r].x);
-        if (xs[r].y < INF) atomicMin(&s_min[vs[r].y], xs[r].y);
-        if (xs[r].z < INF) atomicMin(&s_min[vs[r].z], xs[r].z);
-        if (xs[r].w < INF) atomicMin(&s_min[vs[r].w], xs[r].w);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const unsigned x = sizeof(CT) == 1   ? ((xs[r][0][k >> 2] >> (8 * (k & 3))) & 0xFFu)
+                             : sizeof(CT) == 2 ? ((xs[r][0][k >> 1] >> (16 * (k & 1))) & 0xFFFFu)
+                                               : xs[r][sizeof(CT) == 4 ? (k >> 2) : 0][k & 3];
+          const unsigned v = (vs[r][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+          if (x != CINF) atomicMin(&s_min[v], x);
+        }
       }
     }
   }
@@ -291,6 +386,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
   const unsigned lane = gdn_lane();
   const size_t row0 = (size_t)b << log_bin;
   unsigned long long improved = 0;
+  int mx = 0;
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
     const size_t row = row0 + i;
     bool imp = false;
@@ -299,6 +395,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
       const unsigned old = (unsigned)dist[row];
       if (nm < old) {
         dist[row] = (int32_t)nm;
+        mx = (int)nm > mx ? (int)nm : mx;
         imp = true;
       }
     }
@@ -307,38 +404,309 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
     if (lane == 0) improved += (unsigned long long)__popcll(mask);
   }
   improved = gdn_wave_sum(improved);
-  if (lane == 0) s_red[threadIdx.x >> 6] = improved;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if (lane == 0) {
+    s_red[threadIdx.x >> 6] = improved;
+    s_max[threadIdx.x >> 6] = mx;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long t = 0;
-    for (int i = 0; i < PB_WAVES; i++) t += s_red[i];
+    int m2 = 0;
+    for (int i = 0; i < PB_WAVES; i++) {
+      t += s_red[i];
+      m2 = s_max[i] > m2 ? s_max[i] : m2;
+    }
     if (t) atomicAdd(&cnt->relaxed, t);
+    if (m2 > __hip_atomic_load(&cnt->max_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->max_dist, m2);
   }
 }
 
+// weights in tile order, narrowed to WT (plan build; every weight fits by the host's check of the maximum)
+template <typename WT>
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_narrow_weights_kernel(const uint32_t *__restrict__ w, size_t n, WT *__restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) out[i] = (WT)w[i];
+}
+
+// [0] = min, [1] = max of the weights (as signed ints), [2] = 1 if any is negative
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_weight_range_kernel(const int32_t *__restrict__ w, size_t n, int32_t *__restrict__ out) {
+  int32_t lo = 0x7FFFFFFF, hi = -0x7FFFFFFF - 1;
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const int32_t x = w[i];
+    lo = x < lo ? x : lo;
+    hi = x > hi ? x : hi;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t a = __shfl_xor(lo, o, 64), b2 = __shfl_xor(hi, o, 64);
+    lo = a < lo ? a : lo;
+    hi = b2 > hi ? b2 : hi;
+  }
+  if (gdn_lane() == 0) {
+    atomicMin(&out[0], lo);
+    atomicMax(&out[1], hi);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Light phases without the host (the reference's "fusion" idea, src/bfs/fusion.cu:163 / include/gbar.h, for the part of a
+// search where a grid has nothing to do): ONE 1024-thread workgroup runs consecutive relax passes AND bucket changes --
+// the minimum over FAR, the split into the next bucket -- while the NEAR list holds at most SSSP_SMALL_V vertices /
+// SSSP_SMALL_E out-edges and the FAR list at most SSSP_SMALL_FAR entries; pass and bucket boundaries are
+// __syncthreads().  A pass costs a few microseconds here instead of two launches and a blocking read back.  The lists are
+// written and read by this workgroup only, but through different waves and in alternating roles: device-scope accesses.
+// ------------------------------------------------------------------------------------------
+#define SSSP_SMALL_THREADS 1024
+#define SSSP_SMALL_V 512u
+#define SSSP_SMALL_E 8192ull
+#define SSSP_SMALL_FAR 65536u
+struct SsspSmallState {
+  unsigned n_near, n_far;
+  unsigned long long near_edges;
+  long long thr_lo, thr_hi;
+  int pass;
+  int status;  // out: 0 finished (both lists empty), 1 the NEAR list outgrew the workgroup, 2 the FAR list did (next bucket)
+  unsigned near_sel, far_sel;  // which buffer of each pair is current
+  unsigned overflow;
+  int max_dist;
+  unsigned passes, buckets;
+};
+
+__device__ __forceinline__ vid_t sssp_ld(const vid_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sssp_st(vid_t *p, vid_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ void __launch_bounds__(SSSP_SMALL_THREADS)
+sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ weight,
+                  int32_t *dist, int32_t *stamp, unsigned *in_far, vid_t *near0, vid_t *near1, vid_t *far0, vid_t *far1,
+                  unsigned cap, int32_t delta, unsigned max_v, unsigned long long max_e, unsigned max_far,
+                  SsspSmallState *state) {
+  __shared__ unsigned s_nn, s_nf, s_over;
+  __shared__ unsigned long long s_edges;
+  __shared__ int s_min, s_maxd;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6, nwaves = SSSP_SMALL_THREADS / 64;
+  unsigned n_near = state->n_near, n_far = state->n_far;
+  unsigned long long near_edges = state->near_edges;
+  long long thr_lo = state->thr_lo, thr_hi = state->thr_hi;
+  int pass = state->pass, status = 0;
+  unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0;
+  auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
+  if (threadIdx.x == 0) {
+    s_over = 0u;
+    s_maxd = 0;
+  }
+  __syncthreads();
+  for (;;) {
+    if (n_near > 0) {
+      // ---- one relax pass over NEAR (sssp_relax_kernel's work)
+      ++pass;
+      ++passes;
+      if (threadIdx.x == 0) {
+        s_nn = 0u;
+        s_nf = n_far;
+        s_edges = 0ull;
+      }
+      __syncthreads();
+      const vid_t *near_in = near_sel ? near1 : near0;
+      vid_t *near_out = near_sel ? near0 : near1;
+      vid_t *far_cur = far_sel ? far1 : far0;
+      const int32_t lo = clamp(thr_lo), hi = clamp(thr_hi);
+      int32_t maxd = 0;
+      // 64 list entries at a time, one per lane (every wave loads the batch: 64 parallel loads instead of a chain of
+      // dependent ones); a row of 256 edges or more is walked by ALL waves together, shorter ones by one wave each
+      for (unsigned base = 0; base < n_near; base += 64) {
+        const unsigned i = base + lane;
+        eoff_t bb = 0, ee = 0;
+        int32_t dd = 0;
+        if (i < n_near) {
+          const vid_t v = sssp_ld(near_in + i);
+          dd = __hip_atomic_load(dist + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (dd >= lo) {  // else: settled in an earlier bucket (omp_base.cc:40)
+            bb = rowptr[v];
+            ee = rowptr[v + 1];
+          }
+        }
+        const unsigned cnt = n_near - base < 64u ? n_near - base : 64u;
+        for (unsigned j = 0; j < cnt; j++) {
+          const eoff_t b = __shfl(bb, (int)j, 64), e = __shfl(ee, (int)j, 64);
+          if (e == b) continue;
+          const bool coop = e - b >= 256u;
+          if (!coop && (j & (nwaves - 1u)) != wave) continue;
+          const int32_t du = __shfl(dd, (int)j, 64);
+          const unsigned step = coop ? (unsigned)SSSP_SMALL_THREADS : 64u;
+          for (eoff_t k = b + (coop ? threadIdx.x : lane); k < e; k += step) {
+            const vid_t dst = colidx[k];
+            const int32_t nd = du + weight[k];
+            if (nd < __hip_atomic_load(dist + dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              const int32_t old = atomicMin(&dist[dst], nd);
+              if (nd < old) {
+                maxd = nd > maxd ? nd : maxd;
+                if (nd < hi) {
+                  if (atomicExch(&stamp[dst], pass) != pass) {
+                    const unsigned pos = atomicAdd(&s_nn, 1u);
+                    if (pos < cap) sssp_st(near_out + pos, dst);
+                    else s_over = 1u;
+                    atomicAdd(&s_edges, (unsigned long long)(rowptr[dst + 1] - rowptr[dst]));
+                  }
+                } else if (atomicExch(&in_far[dst], 1u) == 0u) {
+                  const unsigned pos = atomicAdd(&s_nf, 1u);
+                  if (pos < cap) sssp_st(far_cur + pos, dst);
+                  else s_over = 1u;
+                }
+              }
+            }
+          }
+        }
+      }
+      if (maxd > 0) atomicMax(&s_maxd, maxd);
+      __threadfence();
+      __syncthreads();
+      n_near = s_nn;
+      n_far = s_nf;
+      near_edges = s_edges;
+      near_sel ^= 1u;
+      __syncthreads();  // everybody has read the counters before they are reset
+      if (s_over) break;
+      if (n_near > 0) {
+        if (n_near > max_v || near_edges > max_e) {
+          status = 1;
+          break;
+        }
+        continue;
+      }
+    }
+    // ---- NEAR is empty: the next non-empty bucket (omp_base.cc:66-72)
+    if (n_far == 0) {
+      status = 0;
+      break;
+    }
+    if (n_far > max_far) {
+      status = 2;
+      break;
+    }
+    vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
+    vid_t *near_in = near_sel ? near1 : near0;
+    if (threadIdx.x == 0) {
+      s_min = GDN_DIST_INF;
+      s_nn = 0u;
+      s_nf = 0u;
+      s_edges = 0ull;
+    }
+    __syncthreads();
+    {
+      const int32_t hi = clamp(thr_hi);
+      int32_t d = GDN_DIST_INF;
+      for (unsigned i = threadIdx.x; i < n_far; i += SSSP_SMALL_THREADS) {
+        const int32_t x = __hip_atomic_load(dist + sssp_ld(far_cur + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x >= hi && x < d) d = x;  // stale entries are ignored
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int32_t t = __shfl_xor(d, o, 64);
+        d = t < d ? t : d;
+      }
+      if (lane == 0 && d != GDN_DIST_INF) atomicMin(&s_min, d);
+    }
+    __syncthreads();
+    const int32_t mn = s_min;
+    if (mn == GDN_DIST_INF) {  // only stale entries were left
+      n_far = 0;
+      status = 0;
+      break;
+    }
+    const long long old_hi = thr_hi;
+    thr_lo = ((long long)mn / delta) * (long long)delta;
+    thr_hi = thr_lo + delta;
+    ++buckets;
+    {
+      const int32_t ohi = clamp(old_hi), nhi = clamp(thr_hi);
+      for (unsigned i = threadIdx.x; i < n_far; i += SSSP_SMALL_THREADS) {
+        const vid_t w = sssp_ld(far_cur + i);
+        const int32_t d = __hip_atomic_load(dist + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d >= nhi) {
+          sssp_st(far_nxt + atomicAdd(&s_nf, 1u), w);
+        } else {
+          __hip_atomic_store(in_far + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (d >= ohi) {
+            sssp_st(near_in + atomicAdd(&s_nn, 1u), w);
+            atomicAdd(&s_edges, (unsigned long long)(rowptr[w + 1] - rowptr[w]));
+          }
+        }
+      }
+    }
+    __threadfence();
+    __syncthreads();
+    n_near = s_nn;
+    n_far = s_nf;
+    near_edges = s_edges;
+    far_sel ^= 1u;
+    __syncthreads();
+    if (n_near > max_v || near_edges > max_e) {
+      status = 1;
+      break;
+    }
+  }
+  if (threadIdx.x == 0) {
+    state->n_near = n_near;
+    state->n_far = n_far;
+    state->near_edges = near_edges;
+    state->thr_lo = thr_lo;
+    state->thr_hi = thr_hi;
+    state->pass = pass;
+    state->status = status;
+    state->near_sel = near_sel;
+    state->far_sel = far_sel;
+    state->overflow = s_over;
+    state->max_dist = s_maxd;
+    state->passes = passes;
+    state->buckets = buckets;
+  }
+}
+
+// improved-row bitmap -> vertex queue.  Persistent grid: a workgroup owns a contiguous range of words, counts its rows
+// first and reserves its part of the queue with ONE atomic (one per wave on the hot counter cost 0.19 ms for 8192 waves),
+// then writes the rows in order; also sums their out-degrees (the host's dense / worklist decision).
+#define SSSP_B2Q_BLOCKS 512
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_bitmap_to_queue(const unsigned *__restrict__ bits, unsigned nwords, int32_t m, vid_t *__restrict__ q,
-                     SsspCounters *cnt, unsigned cap) {
-  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  unsigned word = (w < nwords) ? bits[w] : 0u;
-  const unsigned n = __popc(word);
-  const unsigned incl = gdn_wave_incl_scan(n);
-  const unsigned total = __shfl(incl, 63, 64);
-  if (total == 0) return;
-  unsigned base = 0;
-  if (gdn_lane() == 63) base = atomicAdd(&cnt->near_count, total);
-  base = __shfl(base, 63, 64);
-  unsigned pos = base + incl - n;
-  while (word) {
-    const int k = __ffs((int)word) - 1;
-    word &= word - 1u;
-    const unsigned v = w * 32u + (unsigned)k;
-    if (v < (unsigned)m) {
-      if (pos < cap) q[pos] = (vid_t)v;
-      else cnt->overflow = 1u;
+                     SsspCounters *cnt, unsigned cap, const eoff_t *__restrict__ rowptr) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned s_base;
+  const unsigned per = (nwords + gridDim.x - 1) / gridDim.x;
+  const unsigned w0 = blockIdx.x * per, w1 = w0 + per < nwords ? w0 + per : nwords;
+  unsigned mine = 0;
+  for (unsigned w = w0 + threadIdx.x; w < w1; w += GDN_BLOCK) mine += __popc(bits[w]);
+  const unsigned tot = gdn_block_sum(mine, s_scan);
+  if (tot == 0) return;
+  if (threadIdx.x == 0) s_base = atomicAdd(&cnt->near_count, tot);
+  __syncthreads();
+  unsigned base = s_base;
+  unsigned long long deg = 0;
+  for (unsigned t0 = w0; t0 < w1; t0 += GDN_BLOCK) {  // block-uniform trip count
+    const unsigned w = t0 + threadIdx.x;
+    unsigned word = (w < w1) ? bits[w] : 0u;
+    unsigned total;
+    unsigned pos = base + gdn_block_excl_scan((unsigned)__popc(word), s_scan, &total);
+    base += total;
+    while (word) {
+      const int k = __ffs((int)word) - 1;
+      word &= word - 1u;
+      const unsigned v = w * 32u + (unsigned)k;
+      if (v < (unsigned)m) {
+        if (pos < cap) q[pos] = (vid_t)v;
+        else cnt->overflow = 1u;
+        deg += rowptr[v + 1] - rowptr[v];
+      }
       pos++;
     }
   }
+  deg = gdn_wave_sum(deg);
+  if (gdn_lane() == 0 && deg) atomicAdd(&cnt->relaxed, deg);
 }
 
 struct gdn_sssp_plan {
@@ -346,9 +714,18 @@ struct gdn_sssp_plan {
   const int32_t *d_weight = nullptr;
   bool dense = false;
   PbPlan pb;               // of the OUT-CSR (rows are sources), no fp32 vals
-  DevBuf<float> Wp;        // weights in tile order (int32 bits)
-  DevBuf<unsigned> cand;   // candidate distances, bin-major
+  DevBuf<float> Wp;        // weights in tile order (int32 bits); released when a narrower copy serves
+  DevBuf<uint8_t> Wn;      // the same as u8 / u16 (w_bytes 1 / 2)
+  int w_bytes = 4;         // 0: all weights equal (w_min), no stream
+  int32_t w_min = 0, w_max = 0;
+  DevBuf<unsigned> cand;   // candidate distances, bin-major (u16 or u32 per sweep)
   DevBuf<unsigned> improved;
+  DevBuf<unsigned> bad;    // 1 word: a 16-bit candidate overflowed (cannot happen; checked)
+  DevBuf<SsspSmallState> small;
+  void *h_pin = nullptr;   // pinned staging for the counter read-backs
+  ~gdn_sssp_plan() {
+    if (h_pin) (void)hipHostFree(h_pin);
+  }
   DevBuf<vid_t> near0, near1, far0, far1;
   DevBuf<int32_t> stamp;
   DevBuf<unsigned> in_far;
@@ -375,30 +752,112 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
   GDN_TRY(p.in_far.alloc(m));
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
+  GDN_TRY(p.small.alloc(1));
+  if (hipHostMalloc(&p.h_pin, 256, hipHostMallocDefault) != hipSuccess) p.h_pin = nullptr;  // falls back to pageable copies
   if (dense && g->nnz > 0) {
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
+    // tiles padded so that a tile's candidates are whole 128-byte lines (a line shared by two tiles is written by two
+    // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
+    // would cost more than the partial lines
+    const double avg_tile = (double)g->nnz / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lg) + 1));
+    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 512.0 ? 64u : 32u;
+    if (const char *e = getenv("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
     GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
-                     /*compact=*/false, /*rows_are_sources=*/true,
-                     /*pad=*/getenv("GDN_SSSP_PAD") ? (unsigned)atoi(getenv("GDN_SSSP_PAD")) : 32u, /*log_group=*/3));
+                     /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3));
     GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
-    // slots in the alignment gaps of the layout are never written by phase A: keep them neutral
-    GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), GDN_DIST_INF, (size_t)p.pb.n_pad + 8, 0));
+    GDN_TRY(p.bad.alloc(1));
+    GDN_HIP(hipMemset(p.bad.p, 0, 4));
+    // slots in the alignment gaps of the layout are never written by phase A: keep them neutral (all ones = INF of both
+    // candidate widths)
+    GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), -1, (size_t)p.pb.n_pad + 8, 0));
+    // the weight stream as narrow as the weights allow
+    {
+      DevBuf<int32_t> rng;
+      GDN_TRY(rng.alloc(2));
+      const int32_t init[2] = {0x7FFFFFFF, -0x7FFFFFFF - 1};
+      GDN_HIP(hipMemcpy(rng.p, init, 8, hipMemcpyHostToDevice));
+      hipLaunchKernelGGL(sssp_weight_range_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_weight, (size_t)g->nnz, rng.p);
+      int32_t h[2];
+      GDN_HIP(hipMemcpy(h, rng.p, 8, hipMemcpyDeviceToHost));
+      p.w_min = h[0];
+      p.w_max = h[1];
+      const char *e = getenv("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
+      const int force = e ? atoi(e) : -1;
+      const size_t n = (size_t)p.pb.n_pad;
+      if (p.w_min < 0) p.w_bytes = 4;  // negative weights: not narrowed (the solvers assume none, like the reference)
+      else if (p.w_min == p.w_max && force < 0) p.w_bytes = 0;
+      else if (p.w_max < 256 && (force < 0 || force == 1)) p.w_bytes = 1;
+      else if (p.w_max < 65536 && (force < 0 || force == 2)) p.w_bytes = 2;
+      else p.w_bytes = 4;
+      if (p.w_bytes == 1 || p.w_bytes == 2) {
+        GDN_TRY(p.Wn.alloc(n * (size_t)p.w_bytes + 64));
+        if (p.w_bytes == 1)
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_narrow_weights_kernel<uint8_t>), dim3(4096), dim3(GDN_BLOCK), 0, 0,
+                             reinterpret_cast<const uint32_t *>(p.Wp.p), n, p.Wn.p);
+        else
+          hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_narrow_weights_kernel<uint16_t>), dim3(4096), dim3(GDN_BLOCK), 0, 0,
+                             reinterpret_cast<const uint32_t *>(p.Wp.p), n, reinterpret_cast<uint16_t *>(p.Wn.p));
+        GDN_HIP(hipDeviceSynchronize());
+      }
+      if (p.w_bytes != 4) p.Wp.release();
+    }
     p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lg) / 32u);
     GDN_TRY(p.improved.alloc(p.nwords + 64));
     const int lds = (int)((sizeof(unsigned) << lg) + 16);
-    hipError_t e = hipFuncSetAttribute((const void *)sssp_pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e == hipSuccess)
-      e = hipFuncSetAttribute((const void *)sssp_pb_accumulate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) {
-      gdn_set_error("hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
-      return GDN_ERR_HIP;
+    const void *fns[] = {(const void *)sssp_pb_expand_kernel<0, uint16_t>, (const void *)sssp_pb_expand_kernel<1, uint16_t>,
+                         (const void *)sssp_pb_expand_kernel<2, uint16_t>, (const void *)sssp_pb_expand_kernel<4, uint16_t>,
+                         (const void *)sssp_pb_expand_kernel<0, uint32_t>, (const void *)sssp_pb_expand_kernel<1, uint32_t>,
+                         (const void *)sssp_pb_expand_kernel<2, uint32_t>, (const void *)sssp_pb_expand_kernel<4, uint32_t>,
+                         (const void *)sssp_pb_expand_kernel<0, uint8_t>, (const void *)sssp_pb_expand_kernel<1, uint8_t>,
+                         (const void *)sssp_pb_expand_kernel<2, uint8_t>, (const void *)sssp_pb_expand_kernel<4, uint8_t>,
+                         (const void *)sssp_pb_accumulate_kernel<uint8_t>, (const void *)sssp_pb_accumulate_kernel<uint16_t>,
+                         (const void *)sssp_pb_accumulate_kernel<uint32_t>};
+    for (const void *fn : fns) {
+      const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) {
+        gdn_set_error("hipFuncSetAttribute(dynamic LDS): %s", hipGetErrorString(e));
+        return GDN_ERR_HIP;
+      }
     }
     p.dense = true;
   }
   GDN_HIP(hipDeviceSynchronize());
   p.prep_ms = t.stop_ms();
   return GDN_OK;
+}
+
+// blocking read of a small device struct through the plan's pinned block (a pageable hipMemcpy costs ~2x the latency)
+template <typename T>
+static int sssp_read(gdn_sssp_plan &p, const T *d_src, T &out) {
+  if (p.h_pin && sizeof(T) <= 256) {
+    GDN_HIP(hipMemcpyAsync(p.h_pin, d_src, sizeof(T), hipMemcpyDeviceToHost, 0));
+    GDN_HIP(hipStreamSynchronize(0));
+    memcpy(&out, p.h_pin, sizeof(T));
+  } else {
+    GDN_HIP(hipMemcpy(&out, d_src, sizeof(T), hipMemcpyDeviceToHost));
+  }
+  return GDN_OK;
+}
+
+template <typename CT>
+static void sssp_launch_sweep(gdn_sssp_plan &p, int32_t m, int32_t *d_dist) {
+  const size_t lds = (sizeof(unsigned) << p.pb.log_chunk) + 16;
+  CT *cand = reinterpret_cast<CT *>(p.cand.p);
+  const void *W = p.w_bytes == 4 ? (const void *)p.Wp.p : (const void *)p.Wn.p;
+#define SSSP_EXPAND(WB)                                                                                                      \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_pb_expand_kernel<WB, CT>), dim3(p.pb.nchunks), dim3(PB_THREADS), lds, 0, d_dist, m, \
+                     p.pb.log_chunk, p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, W, (unsigned)p.w_min, cand,   \
+                     p.bad.p)
+  switch (p.w_bytes) {
+    case 0: SSSP_EXPAND(0); break;
+    case 1: SSSP_EXPAND(1); break;
+    case 2: SSSP_EXPAND(2); break;
+    default: SSSP_EXPAND(4); break;
+  }
+#undef SSSP_EXPAND
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_pb_accumulate_kernel<CT>), dim3(p.pb.nbins), dim3(PB_THREADS), lds, 0, m, p.pb.log_bin,
+                     p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, cand, d_dist, p.improved.p, p.cnt.p);
 }
 
 static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_dist, gdn_stats *stats) {
@@ -420,35 +879,106 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   int64_t thr_lo = 0, thr_hi = delta;
   int32_t pass = 0;
   int phases = 0;
+  int32_t max_finite = 0;  // largest finite distance written so far
   SsspCounters h;
   ExpBigList big;
   big.items = p.bigitems.p;
   big.capacity = p.bigcap;
   const unsigned cap = p.cap;
   auto clamp = [](int64_t x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
+  const bool trace = getenv("GDN_SSSP_TRACE") != nullptr;  // per-phase log on stderr (tools/)
+  auto wall_us = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+  double t_prev = 0;
+  if (trace) {
+    (void)hipDeviceSynchronize();
+    t_prev = wall_us();
+  }
+  auto lap = [&]() { const double t = wall_us(), d = t - t_prev; t_prev = t; return d; };
   // dense sweeps start when the NEAR list owns more than nnz / dense_in out-edges and go on while more than m / dense_out
   // rows improve per sweep (tuning knobs)
   unsigned long long dense_in = 24, dense_out = 16;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 takes 7.2 / 9.2 ms to 6.2 / 7.5 ms
   if (const char *e = getenv("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
   if (const char *e = getenv("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
+  // light phases run inside ONE workgroup (sssp_small_kernel); GDN_SSSP_SMALL=0 keeps every phase on the host loop, =2
+  // forces every phase into it that fits the lists (tests)
+  unsigned small_v = SSSP_SMALL_V, small_far = SSSP_SMALL_FAR;
+  unsigned long long small_e = SSSP_SMALL_E;
+  if (const char *e = getenv("GDN_SSSP_SMALL")) {
+    if (atoi(e) == 0) small_v = 0;
+    else if (atoi(e) == 2) {
+      small_v = cap;
+      small_e = ~0ull;
+      small_far = cap;
+    }
+  }
   for (;;) {
-    while (n_near > 0) {
+    if (n_near == 0 && n_far == 0) break;
+    if (n_near > 0 || (small_v && n_far <= small_far)) {
+      // (a bucket change with a short FAR list also runs inside the workgroup)
+      if (small_v && n_near <= small_v && near_edges <= small_e && (n_near > 0 || n_far <= small_far)) {
+        // ---- light phases: passes and bucket changes inside one workgroup until a list outgrows it
+        SsspSmallState ss;
+        memset(&ss, 0, sizeof(ss));
+        ss.n_near = n_near;
+        ss.n_far = n_far;
+        ss.near_edges = near_edges;
+        ss.thr_lo = thr_lo;
+        ss.thr_hi = thr_hi;
+        ss.pass = pass;
+        ss.near_sel = near_in == p.near1.p ? 1u : 0u;
+        ss.far_sel = far_cur == p.far1.p ? 1u : 0u;
+        GDN_HIP(hipMemcpyAsync(p.small.p, &ss, sizeof(ss), hipMemcpyHostToDevice, 0));
+        hipLaunchKernelGGL(sssp_small_kernel, dim3(1), dim3(SSSP_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, d_weight, d_dist,
+                           p.stamp.p, p.in_far.p, p.near0.p, p.near1.p, p.far0.p, p.far1.p, cap, delta, small_v, small_e,
+                           small_far, p.small.p);
+        GDN_TRY(sssp_read(p, p.small.p, ss));
+        if (ss.overflow) {
+          gdn_set_error("gdn_sssp: device worklist overflow");
+          return GDN_ERR_OVERFLOW;
+        }
+        if (trace)
+          fprintf(stderr, "[sssp] %7.1f us small: %u passes, %u buckets -> status %d, bucket [%lld,%lld): near %u (%llu edges) far %u\n",
+                  lap(), ss.passes, ss.buckets, ss.status, ss.thr_lo, ss.thr_hi, ss.n_near, ss.near_edges, ss.n_far);
+        phases += (int)ss.passes;
+        n_near = ss.n_near;
+        n_far = ss.n_far;
+        near_edges = ss.near_edges;
+        thr_lo = ss.thr_lo;
+        thr_hi = ss.thr_hi;
+        pass = ss.pass;
+        max_finite = ss.max_dist > max_finite ? ss.max_dist : max_finite;
+        near_in = ss.near_sel ? p.near1.p : p.near0.p;
+        near_out = ss.near_sel ? p.near0.p : p.near1.p;
+        far_cur = ss.far_sel ? p.far1.p : p.far0.p;
+        far_nxt = ss.far_sel ? p.far0.p : p.far1.p;
+        continue;  // status 0: both lists empty; 1: NEAR outgrew the workgroup; 2: NEAR empty, FAR too long for it
+      }
+    }
+    if (n_near > 0) {
       if (p.dense && near_edges * dense_in > (unsigned long long)g->nnz) {
         // ---- heavy frontier: Bellman-Ford sweeps over all edges until few rows still improve
-        const size_t lds = (sizeof(unsigned) << p.pb.log_chunk) + 16;
         unsigned long long improved = 0;
         do {
           ++phases;
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
           GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
-          hipLaunchKernelGGL(sssp_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), lds, 0, d_dist, m,
-                             p.pb.log_chunk, p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p,
-                             reinterpret_cast<const uint32_t *>(p.Wp.p), p.cand.p);
-          hipLaunchKernelGGL(sssp_pb_accumulate_kernel, dim3(p.pb.nbins), dim3(PB_THREADS), lds, 0, m, p.pb.log_bin,
-                             p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.cand.p, d_dist, p.improved.p, p.cnt.p);
-          GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+          // 8- / 16-bit candidates while every finite candidate (a finite distance + a weight) stays below 0xFF / 0xFFFF
+          // (GDN_SSSP_CAND32 / GDN_SSSP_CAND16: test knobs that keep the wider form)
+          const int64_t bound = (int64_t)max_finite + (int64_t)p.w_max;
+          const int cbits = getenv("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !getenv("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
+          // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
+          // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
+          // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
+          if (cbits == 8) sssp_launch_sweep<uint8_t>(p, m, d_dist);
+          else if (cbits == 16) sssp_launch_sweep<uint16_t>(p, m, d_dist);
+          else sssp_launch_sweep<uint32_t>(p, m, d_dist);
+          GDN_TRY(sssp_read(p, p.cnt.p, h));
           improved = h.relaxed;
+          max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
+          if (trace)
+            fprintf(stderr, "[sssp] %7.1f us phase %d dense sweep (%d-byte weights, %d-bit candidates): %llu rows improved, max distance %d\n",
+                    lap(), phases, p.w_bytes, cbits, improved, max_finite);
         } while (improved * dense_out > (unsigned long long)m);
         // the rows improved by the LAST sweep are the only ones with unpropagated distances: they
         // become a plain Bellman-Ford worklist (one infinite bucket); the parked FAR list is
@@ -457,14 +987,16 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         h.min_far = GDN_DIST_INF;
         GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
         GDN_HIP(hipMemsetAsync(p.in_far.p, 0, (size_t)m * 4, 0));
-        hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(gdn_nblocks(p.nwords)), dim3(GDN_BLOCK), 0, 0, p.improved.p,
-                           p.nwords, m, near_in, p.cnt.p, cap);
-        GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p,
+                           p.nwords, m, near_in, p.cnt.p, cap, g->rowptr);
+        GDN_TRY(sssp_read(p, p.cnt.p, h));
+        if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> queue of %u (%llu edges)\n", lap(), h.near_count, h.relaxed);
         n_near = h.near_count;
         n_far = 0;
-        near_edges = 0;  // at most m / dense_out rows: back to the worklist
+        near_edges = h.relaxed;  // out-degree sum of the queue (counted by the conversion)
         thr_lo = 0;
         thr_hi = (int64_t)GDN_DIST_INF;
+        if (near_edges * dense_in > (unsigned long long)g->nnz) near_edges = (unsigned long long)g->nnz / dense_in;  // no way back into the sweeps
         continue;
       }
       ++pass;
@@ -474,7 +1006,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       h.big_count = 0;
       h.overflow = 0;
       h.min_far = GDN_DIST_INF;
-      h.pad = 0;
+      h.max_dist = 0;
       h.relaxed = 0;
       GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
       SsspVis vis;
@@ -492,36 +1024,46 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       vis.thr_hi = clamp(thr_hi);
       vis.pass = pass;
       vis.du = 0;
+      vis.max_d = 0;
       big.count = &p.cnt.p->big_count;
       big.overflow = &p.cnt.p->overflow;
+      // a short list of long rows: hand every row of a wave's width or more to the persistent item kernel (walked one
+      // after the other by the few waves of such a pass they cost 0.4 ms on RMAT-24; gdn_bfs.hip does the same)
+      big.min_deg = ((uint64_t)n_near < 65536u && (uint64_t)n_near + near_edges / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
+                        ? 64u : (unsigned)EXP_BIG;
       hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near)), dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
                          n_near, clamp(thr_lo), big, vis);
       hipLaunchKernelGGL(sssp_relax_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
-      GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      GDN_TRY(sssp_read(p, p.cnt.p, h));
       if (h.overflow) {
         gdn_set_error("gdn_sssp: device worklist overflow");
         return GDN_ERR_OVERFLOW;
       }
+      if (trace)
+        fprintf(stderr, "[sssp] %7.1f us phase %d relax [%lld,%lld): near %u (%llu edges) -> near %u (%llu edges) far %u big %u\n", lap(), phases,
+                (long long)thr_lo, (long long)thr_hi, n_near, near_edges, h.near_count, h.relaxed, h.far_count, h.big_count);
       n_near = h.near_count;
       n_far = h.far_count;
       near_edges = h.relaxed;
+      max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
       vid_t *t = near_in;
       near_in = near_out;
       near_out = t;
+      continue;
     }
-    if (n_far == 0) break;
     // ---- next non-empty bucket (omp_base.cc:66-72 votes for the smallest non-empty bin)
     h.near_count = 0;
     h.far_count = 0;
     h.big_count = 0;
     h.overflow = 0;
     h.min_far = GDN_DIST_INF;
+    h.max_dist = 0;
     h.relaxed = 0;
     GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
     hipLaunchKernelGGL(sssp_far_min_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
                        far_cur, n_far, d_dist,
                        clamp(thr_hi), p.cnt.p);
-    GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+    GDN_TRY(sssp_read(p, p.cnt.p, h));
     if (h.min_far == GDN_DIST_INF) break;  // only stale entries were left
     const int64_t old_hi = thr_hi;
     thr_lo = ((int64_t)h.min_far / delta) * (int64_t)delta;
@@ -529,11 +1071,14 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
     hipLaunchKernelGGL(sssp_far_split_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
                        far_cur, n_far, d_dist,
                        clamp(old_hi), clamp(thr_hi), p.in_far.p, near_in, far_nxt, p.cnt.p, cap, g->rowptr);
-    GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+    GDN_TRY(sssp_read(p, p.cnt.p, h));
     if (h.overflow) {
       gdn_set_error("gdn_sssp: device worklist overflow");
       return GDN_ERR_OVERFLOW;
     }
+    if (trace)
+      fprintf(stderr, "[sssp] %7.1f us split far %u at min %d -> bucket [%lld,%lld): near %u (%llu edges) far %u\n", lap(), n_far, h.min_far,
+              (long long)thr_lo, (long long)thr_hi, h.near_count, h.relaxed, h.far_count);
     n_near = h.near_count;
     n_far = h.far_count;
     near_edges = h.relaxed;
@@ -542,6 +1087,14 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
     far_nxt = t;
   }
   GDN_HIP(hipGetLastError());
+  if (p.dense) {
+    unsigned bad = 0;
+    GDN_HIP(hipMemcpy(&bad, p.bad.p, 4, hipMemcpyDeviceToHost));
+    if (bad) {
+      gdn_set_error("gdn_sssp: a 16-bit candidate distance overflowed (internal error)");
+      return GDN_ERR_OVERFLOW;
+    }
+  }
   st.solve_ms = tsolve.stop_ms();
   st.iterations = phases;
   uint64_t te = 0;

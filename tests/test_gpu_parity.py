@@ -720,6 +720,51 @@ def test_sssp_resident_dense_sweeps(orc, scale, ef, seed, wmax):
     sp.close()
 
 
+@pytest.mark.parametrize("wlo,whi,delta", [(7, 7, 3), (1, 255, 16), (200, 60000, 5000), (1, 1 << 20, 1 << 18), (0, 3, 1),
+                                           (1, 3000, 64)])
+@pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_SMALL": "0"}, {"GDN_SSSP_SMALL": "2"}, {"GDN_SSSP_CAND32": "1"},
+                                   {"GDN_SSSP_CAND16": "1"}, {"GDN_SSSP_WBYTES": "4"}, {"GDN_SSSP_PAD": "128"}, {"GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_DENSE_OUT": "100000"}])
+def test_sssp_plan_stream_widths_and_fused_phases(orc, monkeypatch, wlo, whi, delta, knobs):
+    """The dense sweeps pick the width of their two per-edge streams from the data -- no weight stream at all when every
+    weight is equal, 8 / 16 / 32-bit weights, 16-bit candidates while the largest distance + weight stays below 0xFFFF and
+    32-bit ones beyond (the (1, 3000) case crosses over in the middle of a solve) -- and the light phases run inside one
+    workgroup (GDN_SSSP_SMALL = 0: never, 2: whenever the lists fit at all).  Every combination: exact distances."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = graphio.rmat_graph(15, 16, seed=61)
+    rng = np.random.default_rng(wlo + whi)
+    wt = rng.integers(wlo, whi + 1, size=g.nnz).astype(np.int32)
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    deg = g.degrees()
+    for s in (graphio.first_nonisolated(g), int(np.argmax(deg))):
+        want = orc.sssp_dijkstra(g, wt, s)
+        dist, st = sp.run(s, delta)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+    sp.close()
+    # the plan-less drop-in takes the same fused light phases
+    dist = np.full(g.m, solvers.K_DIST_INF, np.int32)
+    s = graphio.first_nonisolated(g)
+    solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, dist, delta)
+    assert np.array_equal(dist, orc.sssp_dijkstra(g, wt, s))
+
+
+def test_sssp_long_weighted_path_runs_inside_one_workgroup(orc):
+    """A 30 000-vertex path with a few shortcuts and delta = 1: tens of thousands of buckets of one or two vertices.  Every
+    pass and bucket change stays on the device (stats.iterations counts the passes)."""
+    n = 30000
+    src = np.concatenate([np.arange(n - 1), np.arange(0, n - 50, 50)])
+    dst = np.concatenate([np.arange(1, n), np.arange(40, n - 10, 50)])
+    g = graphio.build_csr(n, src, dst)
+    rng = np.random.default_rng(3)
+    wt = rng.integers(1, 4, size=g.nnz).astype(np.int32)
+    want = orc.sssp_dijkstra(g, wt, 0)
+    for delta in (1, 5):
+        dist = np.full(n, solvers.K_DIST_INF, np.int32)
+        st = solvers.SSSPSolver(solvers.Graph(csr=g), 0, wt, dist, delta)
+        assert np.array_equal(dist, want)
+        assert st["iterations"] > 1000 and st["solve_ms"] < 2000
+
+
 # ------------------------------------------------------------------ CC
 @pytest.mark.parametrize("case", ["test_cc_sym", "chesapeake_sym", "rmat10_sym", "rmat10_dir"])
 def test_cc_golden(orc, case):
