@@ -23,11 +23,10 @@
 #define BC_WAVE_ROW 32     // rows at least this long: whole wave
 #define BC_BLOCK_ROW 4096  // rows at least this long: one workgroup each (second launch)
 
-struct BcCounters {  // device
-  unsigned tail;       // entries of `order` (the next level is appended behind the current one)
-  unsigned big_count;  // forward: big-row work items; backward: rows left to the workgroup kernel
-  unsigned overflow;
-  unsigned pad;
+struct BcCounters {  // device; the two hot counters on 128-byte lines of their own (atomics on one line serialise, gdn_sssp.hip)
+  alignas(128) unsigned tail;       // entries of `order` (the next level is appended behind the current one)
+  alignas(128) unsigned big_count;  // forward: big-row work items; backward: rows left to the workgroup kernel
+  alignas(128) unsigned overflow;
 };
 
 struct BcFwdVis {

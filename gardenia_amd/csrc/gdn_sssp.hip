@@ -20,14 +20,17 @@
 #include "gdn_expand.hpp"
 #include "gdn_pb.hpp"
 
+// Every hot counter sits on a 128-byte line of its own: atomics on ONE line serialise at ~12-25 ns each whatever issues
+// them (a 228 K-vertex pass -- 3.5 K waves, three counters -- spent 0.2 of its 0.26 ms there); lines of their own go
+// through different L2 channels side by side.
 struct SsspCounters {
-  unsigned near_count;
-  unsigned far_count;
-  unsigned big_count;
+  alignas(128) unsigned near_count;
+  alignas(128) unsigned far_count;
+  alignas(128) unsigned big_count;
+  alignas(128) unsigned long long relaxed;
+  alignas(128) int max_dist;  // largest distance written since the counters were reset (the dense sweeps size their candidates by it)
+  alignas(128) int min_far;
   unsigned overflow;
-  int min_far;
-  int max_dist;  // largest distance written since the counters were reset (the dense sweeps size their candidates by it)
-  unsigned long long relaxed;
 };
 
 struct SsspVis {
@@ -44,6 +47,7 @@ struct SsspVis {
   unsigned cap;
   int32_t thr_hi;
   int32_t pass;
+  int32_t no_push;  // != 0: only the distances are lowered, no list is built (the pass in front of the dense sweeps)
   int32_t du;  // per-lane: distance of this lane's source vertex
   int32_t max_d;  // per-lane: largest distance this lane wrote
   GdnWlStage near_st, far_st;  // per-wave LDS strips: one atomic on the hot counters per flush, not per wave step
@@ -59,7 +63,9 @@ struct SsspVis {
         const int32_t old = atomicMin(&dist[dst], nd);
         if (nd < old) {
           max_d = nd > max_d ? nd : max_d;
-          if (nd < thr_hi) {
+          if (no_push) {
+            near_edges += 1;  // improved vertices (only a count is kept)
+          } else if (nd < thr_hi) {
             push_near = atomicExch(&stamp[dst], pass) != pass;
             if (push_near) near_edges += rowptr[dst + 1] - rowptr[dst];
           } else {
@@ -68,6 +74,7 @@ struct SsspVis {
         }
       }
     }
+    if (no_push) return;  // uniform
     gdn_wl_push_staged(near_st, near_out, &cnt->near_count, cap, push_near, dst, &cnt->overflow);
     gdn_wl_push_staged(far_st, far_out, &cnt->far_count, cap, push_far, dst, &cnt->overflow);
   }
@@ -478,6 +485,17 @@ struct SsspSmallState {
   unsigned passes, buckets;
 };
 
+// wave-aggregated slot reservation on an LDS counter (all lanes of the wave must call it; a lane per item serialises on
+// the one address: 34 K far entries cost 0.1 ms that way)
+__device__ __forceinline__ unsigned sssp_lds_slot(unsigned *counter, bool want) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return 0u;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)gdn_lane() == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+  return __shfl(base, leader, 64) + (unsigned)__popcll(mask & gdn_lanemask_lt());
+}
+
 __device__ __forceinline__ vid_t sssp_ld(const vid_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void sssp_st(vid_t *p, vid_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -601,9 +619,19 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
     {
       const int32_t hi = clamp(thr_hi);
       int32_t d = GDN_DIST_INF;
-      for (unsigned i = threadIdx.x; i < n_far; i += SSSP_SMALL_THREADS) {
-        const int32_t x = __hip_atomic_load(dist + sssp_ld(far_cur + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (x >= hi && x < d) d = x;  // stale entries are ignored
+      for (unsigned i0 = threadIdx.x; i0 < n_far; i0 += 4 * SSSP_SMALL_THREADS) {  // 4 entries in flight per thread
+        vid_t w[4];
+        int32_t x[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned i = i0 + (unsigned)r * SSSP_SMALL_THREADS;
+          w[r] = i < n_far ? sssp_ld(far_cur + i) : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) x[r] = w[r] >= 0 ? __hip_atomic_load(dist + w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : GDN_DIST_INF;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (x[r] >= hi && x[r] < d) d = x[r];  // stale entries are ignored
       }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
@@ -625,19 +653,34 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
     ++buckets;
     {
       const int32_t ohi = clamp(old_hi), nhi = clamp(thr_hi);
-      for (unsigned i = threadIdx.x; i < n_far; i += SSSP_SMALL_THREADS) {
-        const vid_t w = sssp_ld(far_cur + i);
-        const int32_t d = __hip_atomic_load(dist + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d >= nhi) {
-          sssp_st(far_nxt + atomicAdd(&s_nf, 1u), w);
-        } else {
-          __hip_atomic_store(in_far + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          if (d >= ohi) {
-            sssp_st(near_in + atomicAdd(&s_nn, 1u), w);
-            atomicAdd(&s_edges, (unsigned long long)(rowptr[w + 1] - rowptr[w]));
+      unsigned long long deg_sum = 0;
+      for (unsigned i0 = wave * 64u; i0 < n_far; i0 += 4 * SSSP_SMALL_THREADS) {  // wave-uniform bounds
+        vid_t w[4];
+        int32_t d[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const unsigned i = i0 + lane + (unsigned)r * SSSP_SMALL_THREADS;
+          w[r] = i < n_far ? sssp_ld(far_cur + i) : -1;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) d[r] = w[r] >= 0 ? __hip_atomic_load(dist + w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {  // (wave-uniform trip count: the reservations below are convergent)
+          const bool live = w[r] >= 0;
+          const bool to_far = live && d[r] >= nhi;
+          const bool to_near = live && !to_far && d[r] >= ohi;
+          if (live && !to_far) __hip_atomic_store(in_far + w[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned pf = sssp_lds_slot(&s_nf, to_far);
+          if (to_far) sssp_st(far_nxt + pf, w[r]);
+          const unsigned pn = sssp_lds_slot(&s_nn, to_near);
+          if (to_near) {
+            sssp_st(near_in + pn, w[r]);
+            deg_sum += rowptr[w[r] + 1] - rowptr[w[r]];
           }
         }
       }
+      deg_sum = gdn_wave_sum(deg_sum);
+      if (lane == 0 && deg_sum) atomicAdd(&s_edges, deg_sum);
     }
     __threadfence();
     __syncthreads();
@@ -753,10 +796,11 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
   GDN_TRY(p.small.alloc(1));
-  if (hipHostMalloc(&p.h_pin, 256, hipHostMallocDefault) != hipSuccess) p.h_pin = nullptr;  // falls back to pageable copies
+  if (hipHostMalloc(&p.h_pin, 1024, hipHostMallocDefault) != hipSuccess) p.h_pin = nullptr;  // falls back to pageable copies
   if (dense && g->nnz > 0) {
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
+    if (const char *e = getenv("GDN_SSSP_LOG")) lg = atoi(e) >= 10 && atoi(e) <= 15 ? atoi(e) : lg;  // tuning knob
     // tiles padded so that a tile's candidates are whole 128-byte lines (a line shared by two tiles is written by two
     // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
     // would cost more than the partial lines
@@ -830,7 +874,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
 // blocking read of a small device struct through the plan's pinned block (a pageable hipMemcpy costs ~2x the latency)
 template <typename T>
 static int sssp_read(gdn_sssp_plan &p, const T *d_src, T &out) {
-  if (p.h_pin && sizeof(T) <= 256) {
+  if (p.h_pin && sizeof(T) <= 1024) {
     GDN_HIP(hipMemcpyAsync(p.h_pin, d_src, sizeof(T), hipMemcpyDeviceToHost, 0));
     GDN_HIP(hipStreamSynchronize(0));
     memcpy(&out, p.h_pin, sizeof(T));
@@ -896,6 +940,9 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   auto lap = [&]() { const double t = wall_us(), d = t - t_prev; t_prev = t; return d; };
   // dense sweeps start when the NEAR list owns more than nnz / dense_in out-edges and go on while more than m / dense_out
   // rows improve per sweep (tuning knobs)
+  bool pre_dense_done = false;
+  unsigned long long dense_pre = 192;  // = dense_in x the growth of a frontier per pass this early (GDN_SSSP_DENSE_PRE)
+  if (const char *e = getenv("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
   unsigned long long dense_in = 24, dense_out = 16;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 takes 7.2 / 9.2 ms to 6.2 / 7.5 ms
   if (const char *e = getenv("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
   if (const char *e = getenv("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
@@ -913,8 +960,9 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   }
   for (;;) {
     if (n_near == 0 && n_far == 0) break;
-    if (n_near > 0 || (small_v && n_far <= small_far)) {
-      // (a bucket change with a short FAR list also runs inside the workgroup)
+    if (!pre_dense_done && (n_near > 0 || (small_v && n_far <= small_far))) {
+      // (a bucket change with a short FAR list also runs inside the workgroup; after a pass that built no lists the
+      // sweeps below come first)
       if (small_v && n_near <= small_v && near_edges <= small_e && (n_near > 0 || n_far <= small_far)) {
         // ---- light phases: passes and bucket changes inside one workgroup until a list outgrows it
         SsspSmallState ss;
@@ -955,7 +1003,8 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       }
     }
     if (n_near > 0) {
-      if (p.dense && near_edges * dense_in > (unsigned long long)g->nnz) {
+      if (p.dense && (near_edges * dense_in > (unsigned long long)g->nnz || pre_dense_done)) {
+        pre_dense_done = false;
         // ---- heavy frontier: Bellman-Ford sweeps over all edges until few rows still improve
         unsigned long long improved = 0;
         do {
@@ -999,6 +1048,10 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         if (near_edges * dense_in > (unsigned long long)g->nnz) near_edges = (unsigned long long)g->nnz / dense_in;  // no way back into the sweeps
         continue;
       }
+      // A pass whose input already owns more than nnz / dense_pre out-edges will be followed by the dense sweeps on a
+      // low-diameter graph (the frontier grows several-fold per pass): it then only lowers distances -- no stamp, no FAR
+      // flag, no degree read, no list -- since the sweeps work from the distances alone and drop both lists anyway.
+      const bool pre_dense = p.dense && thr_hi < (int64_t)GDN_DIST_INF && near_edges * dense_pre > (unsigned long long)g->nnz;
       ++pass;
       ++phases;
       h.near_count = 0;
@@ -1023,6 +1076,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       vis.cap = cap;
       vis.thr_hi = clamp(thr_hi);
       vis.pass = pass;
+      vis.no_push = pre_dense ? 1 : 0;
       vis.du = 0;
       vis.max_d = 0;
       big.count = &p.cnt.p->big_count;
@@ -1030,7 +1084,8 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       // a short list of long rows: hand every row of a wave's width or more to the persistent item kernel (walked one
       // after the other by the few waves of such a pass they cost 0.4 ms on RMAT-24; gdn_bfs.hip does the same)
       big.min_deg = ((uint64_t)n_near < 65536u && (uint64_t)n_near + near_edges / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
-                        ? 64u : (unsigned)EXP_BIG;
+                        ? 64u : (unsigned)EXP_BIG;  // (on a 228 K-vertex list the item detour cost 0.42 ms instead of 0.28)
+      if (const char *e = getenv("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
       hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near)), dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
                          n_near, clamp(thr_lo), big, vis);
       hipLaunchKernelGGL(sssp_relax_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
@@ -1042,10 +1097,15 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       if (trace)
         fprintf(stderr, "[sssp] %7.1f us phase %d relax [%lld,%lld): near %u (%llu edges) -> near %u (%llu edges) far %u big %u\n", lap(), phases,
                 (long long)thr_lo, (long long)thr_hi, n_near, near_edges, h.near_count, h.relaxed, h.far_count, h.big_count);
+      max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
+      if (pre_dense) {  // no lists were built: the sweeps take over from the distances
+        pre_dense_done = true;
+        n_near = 1;  // (placeholder: the dense branch does not read the list)
+        continue;
+      }
       n_near = h.near_count;
       n_far = h.far_count;
       near_edges = h.relaxed;
-      max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
       vid_t *t = near_in;
       near_in = near_out;
       near_out = t;
