@@ -737,13 +737,15 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
 // signed value * 2^shift -> two's complement fixed point (SpMV); |v * 2^shift| must stay < 2^62.  Branch-free form
 // of (long long)(v * scale) (truncation toward zero): mantissa at bits 39..62, one clamped right shift, conditional
 // negation -- the compiler's float -> int64 conversion is a long divergent sequence, and phase B pays it per edge.
-__device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float scale, unsigned &bad) {
+// *lossy (nullable): 0 < |v * 2^shift| < 2^23, i.e. mantissa bits may have been shifted out
+__device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float scale, unsigned &bad, bool *lossy = nullptr) {
   const float t = v * scale;  // exact: scale is a power of two
   const unsigned bits = __float_as_uint(t);
   const unsigned mag_bits = bits & 0x7FFFFFFFu;
   const bool ok = mag_bits < 0x5E800000u;  // |t| < 2^62 (also rejects inf / nan)
   bad |= ok ? 0u : 1u;
   const unsigned e = mag_bits >> 23;
+  if (lossy) *lossy = mag_bits != 0u && e < 150u;
   const unsigned mant = (mag_bits & 0x7FFFFFu) | 0x800000u;
   const unsigned long long m62 = (unsigned long long)(mant << 7) << 32;  // mant * 2^39
   unsigned sh = 189u - e;  // |t| = mant * 2^(e - 150) = m62 >> (189 - e); e <= 188 when ok
@@ -752,6 +754,19 @@ __device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float 
   const unsigned long long r = (bits >> 31) ? (0ull - mag) : mag;
   return ok ? r : 0ull;
 }
+
+// Ops with `static constexpr bool kTrackLossy = true` (SpMV) get a per-bin LDS bitmap of the rows that received a product
+// whose fixed-point conversion dropped bits (Op::lossy(v)); such a row whose sum is too small for the dropped bits not to
+// matter is handed to the op as NaN and recomputed exactly by it (gdn_spmv.hip).  Other ops: no code at all.
+template <class T, class = void>
+struct PbTracksLossy {
+  static constexpr bool value = false;
+};
+template <class T>
+struct PbTracksLossy<T, decltype((void)T::kTrackLossy)> {
+  static constexpr bool value = T::kTrackLossy;
+};
+#define PB_LOSSY_MIN_SUM (1ull << 32)  // units: below this a row with a lossy product is recomputed
 
 // phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then the fused epilogue of the rows (op).
 template <class Op>
@@ -782,6 +797,10 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order ? bin_order[blockIdx.x] : bin_begin + blockIdx.x;
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
+  constexpr bool LZ = PbTracksLossy<Op>::value;
+  unsigned *s_lossy = reinterpret_cast<unsigned *>(s_acc + bn);  // bn / 32 words behind the accumulators (LZ launches only)
+  if constexpr (LZ)
+    for (unsigned i = threadIdx.x; i < (bn >> 5); i += PB_THREADS) s_lossy[i] = 0u;
   __syncthreads();
   if (hrb_ptr) {
     for (unsigned i = hrb_ptr[b] + threadIdx.x; i < hrb_ptr[b + 1]; i += PB_THREADS) s_acc[hrb_vl[i]] = hr_total[i];
@@ -793,6 +812,27 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   const pb_f32x4 *X4 = reinterpret_cast<const pb_f32x4 *>(vals);
   const pb_u16x4 *V4 = reinterpret_cast<const pb_u16x4 *>(V);
   unsigned bad = 0u;
+  // value -> fixed point for `row` of this bin (+ the lossy mark of the ops that track it)
+  // fxl: the conversion + whether it dropped bits; mark(row): the lossy mark.  Call sites convert a group of values
+  // first and branch ONCE on "any of them lossy" (one exec-mask region per group instead of one per product: the
+  // tracking cost 7 % of an SpMV product by product)
+  auto fxl = [&](float val, bool &lz) -> unsigned long long {
+    if constexpr (LZ) {
+      return op.to_fixed_lossy(val, bad, lz);
+    } else {
+      lz = false;
+      return op.to_fixed(val, bad);
+    }
+  };
+  auto mark = [&](unsigned row) { atomicOr(&s_lossy[row >> 5], 1u << (row & 31u)); };
+  auto fx = [&](float val, unsigned row) -> unsigned long long {
+    bool lz;
+    const unsigned long long f = fxl(val, lz);
+    if constexpr (LZ) {
+      if (lz) mark(row);
+    }
+    return f;
+  };
   constexpr int UNR = 4;
   pb_f32x4 xs[UNR], nx[UNR];
   pb_u16x4 vs[UNR], nv[UNR];
@@ -843,8 +883,16 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       return;
     }
     // run sums by selects, then one predicated atomic per run end (no nested divergent regions)
-    const unsigned long long f0 = op.to_fixed(x.x, bad), f1 = op.to_fixed(x.y, bad), f2 = op.to_fixed(x.z, bad),
-                             f3 = op.to_fixed(x.w, bad);
+    bool l0, l1, l2, l3;
+    const unsigned long long f0 = fxl(x.x, l0), f1 = fxl(x.y, l1), f2 = fxl(x.z, l2), f3 = fxl(x.w, l3);
+    if constexpr (LZ) {
+      if (l0 | l1 | l2 | l3) {
+        if (l0) mark(v.x);
+        if (l1) mark(v.y);
+        if (l2) mark(v.z);
+        if (l3) mark(v.w);
+      }
+    }
     const bool e1 = v.y == v.x, e2 = v.z == v.y, e3 = v.w == v.z;
     const unsigned long long p1 = f1 + (e1 ? f0 : 0ull);
     const unsigned long long p2 = f2 + (e2 ? p1 : 0ull);
@@ -933,7 +981,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
 #pragma unroll
             for (int k = 0; k < 8; k++) {
               if (k > 0 && hu[r][k] != hu[r][k - 1]) xv = hub_val[hu[r][k]];
-              atomicAdd(&s_acc[hv[r][k]], op.to_fixed(gdn_fmul(xv, av[k]), bad));
+              atomicAdd(&s_acc[hv[r][k]], fx(gdn_fmul(xv, av[k]), hv[r][k]));
             }
           }
         }
@@ -986,9 +1034,22 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         }
 #pragma unroll
         for (int r = 0; r < MUNR; r++) f[r] = T[rc[r] >> PB_MID_ROW_BITS];
+        bool lz[MUNR], any = false;
+        unsigned long long fv[MUNR];
 #pragma unroll
-        for (int r = 0; r < MUNR; r++)
-          atomicAdd(&s_acc[rc[r] & RMASK], op.to_fixed(FA ? gdn_fmul(f[r], a[r]) : f[r], bad));
+        for (int r = 0; r < MUNR; r++) {
+          fv[r] = fxl(FA ? gdn_fmul(f[r], a[r]) : f[r], lz[r]);
+          any |= lz[r];
+        }
+        if constexpr (LZ) {
+          if (any) {
+#pragma unroll
+            for (int r = 0; r < MUNR; r++)
+              if (lz[r]) mark(rc[r] & RMASK);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < MUNR; r++) atomicAdd(&s_acc[rc[r] & RMASK], fv[r]);
       }
       continue;
     }
@@ -1021,7 +1082,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
           const unsigned d = (rc[r][j] >> PB_MID_ROW_BITS) - k0;
           float f = d == 0 ? w[r].x : (d == 1 ? w[r].y : (d == 2 ? w[r].z : w[r].w));
           if (d > 3u) f = T[rc[r][j] >> PB_MID_ROW_BITS];  // also a source in FRONT of k0 (never in a sorted stream)
-          atomicAdd(&s_acc[rc[r][j] & RMASK], op.to_fixed(FA4 ? gdn_fmul(f, a[r][j]) : f, bad));
+          atomicAdd(&s_acc[rc[r][j] & RMASK], fx(FA4 ? gdn_fmul(f, a[r][j]) : f, rc[r][j] & RMASK));
         }
       }
     }
@@ -1033,12 +1094,19 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const size_t row0 = (size_t)b << log_bin;
     const unsigned lo = dst_bits ? bin_lo[b] : (unsigned)row0;
     const unsigned hi = dst_bits ? bin_lo[b + 1] : (unsigned)((row0 + bn < (size_t)m_local) ? row0 + bn : (size_t)m_local);
-    if (op.vec_ok && !(dbg & 4))
-      dsum = pb_epilogue4(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
-                          [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
-    else
-      dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op,
-                         [&](unsigned k) { return op.from_fixed(s_acc[k], bad); });
+    // the row's sum; NaN = "recompute me" for a row that took a lossy product and whose sum is too small to hide it
+    auto row_sum = [&](unsigned k) -> float {
+      const unsigned long long a = s_acc[k];
+      if constexpr (LZ) {
+        if ((s_lossy[k >> 5] >> (k & 31u)) & 1u) {
+          const unsigned long long mag = (long long)a < 0 ? 0ull - a : a;
+          if (mag < PB_LOSSY_MIN_SUM) return __uint_as_float(0x7FC00000u);
+        }
+      }
+      return op.from_fixed(a, bad);
+    };
+    if (op.vec_ok && !(dbg & 4)) dsum = pb_epilogue4(dst_bits, lo, hi, s_bits, s_pref, s_scr, op, row_sum);
+    else dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op, row_sum);
   }
   if (bad) *errflag = 1u;
   dsum = gdn_wave_sum(dsum);

@@ -37,8 +37,14 @@ struct gdn_spmv_plan {
     DevBuf<float> val, Ax;
   } mid[PB_MAX_MID];
   bool pattern = false;  // PB layout of a 0/1 matrix: no Ax stream
-  DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] max row length
+  DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] rows to recompute (per call), [3] max row length
   DevBuf<float> scale;  // PB: [0] = 2^shift, [1] = 2^-shift (per call)
+  // PB: the rows phase B hands back because a product lost bits in the fixed-point conversion and the row's sum is too
+  // small to hide it (gdn_pb.hpp PbTracksLossy) are recomputed from the CSR the plan was built on -- which therefore has
+  // to stay alive as long as the plan (like d_Ax, which gdn_spmv_dev is handed per call)
+  const gdn_graph *csr = nullptr;
+  DevBuf<int32_t> repair_rows;  // m entries
+  bool track_lossy = false;
 };
 
 struct SpmvOp {
@@ -53,7 +59,8 @@ struct SpmvOp {
   };
   __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{y[row]}; }
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
-    y[row] = gdn_fadd(p.y, sum);
+    if (sum != sum) repair(row);  // y[row] stays as it is: the repair pass adds the row's sum
+    else y[row] = gdn_fadd(p.y, sum);
     return 0.0;
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
@@ -65,11 +72,36 @@ struct SpmvOp {
   __device__ __forceinline__ double fin4(int32_t row, const float (&sum)[4], const Pre4 &p) const {
     pb_f32x4 o;
 #pragma unroll
-    for (int c = 0; c < 4; c++) o[c] = gdn_fadd(p.y[c], sum[c]);
+    for (int c = 0; c < 4; c++) {
+      if (sum[c] != sum[c]) {
+        repair(row + c);
+        o[c] = p.y[c];
+      } else {
+        o[c] = gdn_fadd(p.y[c], sum[c]);
+      }
+    }
     *reinterpret_cast<pb_f32x4 *>(y + row) = o;
     return 0.0;
   }
-  // PB layout: signed fixed point with a per-call power-of-two scale (gdn_pb.hpp)
+  // PB layout: signed fixed point with a per-call power-of-two scale (gdn_pb.hpp).  A product below 2^23 units loses
+  // bits in the conversion; where that could show in a row's result (|sum| < 2^32 units) phase B passes NaN and the row
+  // goes onto the repair list instead of being written: spmv_repair_kernel adds its sum computed in fp32 like the
+  // reference's loop.  Every other row's sum is the exact sum of its (at most 1 unit off) products, rounded once:
+  // relative error <= (lossy products of the row) * 2^-32.
+  static constexpr bool kTrackLossy = true;
+  bool track;                   // false: pattern plans (delta PageRank sums signed deltas to an absolute tolerance)
+  unsigned *repair_cnt;         // 1 counter
+  int32_t *repair_rows;
+  unsigned repair_cap;
+  __device__ __forceinline__ unsigned long long to_fixed_lossy(float v, unsigned &bad, bool &lz) const {
+    const unsigned long long f = pb_to_fixed_signed(v, scale[0], bad, &lz);
+    lz = lz && track;
+    return f;
+  }
+  __device__ __forceinline__ void repair(int32_t row) const {
+    const unsigned pos = atomicAdd(repair_cnt, 1u);
+    if (pos < repair_cap) repair_rows[pos] = row;
+  }
   const float *__restrict__ scale;
   __device__ __forceinline__ unsigned long long to_fixed(float v, unsigned &bad) const {
     return pb_to_fixed_signed(v, scale[0], bad);
@@ -115,7 +147,7 @@ spmv_maxdeg_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned *__res
 __global__ void spmv_scale_kernel(const unsigned *__restrict__ mx, float *__restrict__ scale) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float a = __uint_as_float(mx[0]), x = __uint_as_float(mx[1]);
-  const float bound = a * x * (float)(mx[2] ? mx[2] : 1u);
+  const float bound = a * x * (float)(mx[3] ? mx[3] : 1u);
   int e = 0;
   if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &e);  // bound < 2^e
   int shift = 61 - e;
@@ -123,6 +155,26 @@ __global__ void spmv_scale_kernel(const unsigned *__restrict__ mx, float *__rest
   if (shift < -120) shift = -120;
   scale[0] = ldexpf(1.0f, shift);
   scale[1] = ldexpf(1.0f, -shift);
+}
+
+// y[row] += SUM Ax[k] * x[Aj[k]] for the rows on the repair list: one wave per row, fp32 products and sums like the
+// reference's loop (src/spmv/omp_base.cc:22-33), lane-strided partial sums folded by a wave reduction
+__global__ void __launch_bounds__(GDN_BLOCK)
+spmv_repair_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const float *__restrict__ Ax,
+                   const float *__restrict__ x, float *__restrict__ y, const int32_t *__restrict__ rows,
+                   const unsigned *__restrict__ count, unsigned cap) {
+  unsigned n = *count;
+  n = n > cap ? cap : n;
+  const unsigned lane = gdn_lane();
+  const unsigned nwaves = gridDim.x * GDN_WAVES_PER_BLOCK;
+  for (unsigned i = blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); i < n; i += nwaves) {
+    const int32_t row = rows[i];
+    float acc = 0.0f;
+    for (eoff_t k = rowptr[row] + lane; k < rowptr[row + 1]; k += 64) acc = gdn_fadd(acc, gdn_fmul(x[colidx[k]], Ax ? Ax[k] : 1.0f));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc = gdn_fadd(acc, __shfl_xor(acc, o, 64));
+    if (lane == 0) y[row] = gdn_fadd(y[row], acc);
+  }
 }
 
 extern "C" {
@@ -160,6 +212,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
   p->m = csr->m;
   p->n_cols = n_cols;
   p->nnz = csr->nnz;
+  p->csr = csr;
   int st;
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, csr, 0);
@@ -228,6 +281,8 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     }
     if (st == GDN_OK) st = p->mx.alloc(4);
     if (st == GDN_OK) st = p->scale.alloc(2);
+    p->track_lossy = !p->pattern;
+    if (st == GDN_OK && p->track_lossy) st = p->repair_rows.alloc((size_t)csr->m);
     if (st == GDN_OK) {
       (void)hipMemset(p->mx.p, 0, 16);
       if (p->pattern) {
@@ -236,9 +291,9 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       } else if (csr->nnz) {
         hipLaunchKernelGGL(spmv_absmax_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_Ax, (size_t)csr->nnz, p->mx.p);
       }
-      hipLaunchKernelGGL(spmv_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->m, p->mx.p + 2);
+      hipLaunchKernelGGL(spmv_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->m, p->mx.p + 3);
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
-      const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
+      const int lds_b = (int)((sizeof(unsigned long long) << p->pb.log_bin) + ((size_t)1 << p->pb.log_bin) / 8);
       hipError_t e = hipFuncSetAttribute((const void *)pb_expand_scaled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
       if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<SpmvOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
@@ -267,7 +322,13 @@ int gdn_spmv_plan_free(gdn_spmv_plan *plan) {
 
 int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float *d_y, void *stream) {
   GDN_REQUIRE(plan && d_x && d_y, "null argument");
+  GDN_REQUIRE(d_Ax != nullptr || plan->layout != GDN_LAYOUT_PB || plan->pattern,
+              "d_Ax (the values in CSR order: rows that lose bits in the fixed-point layout are recomputed from them)");
   SpmvOp op;
+  op.track = false;
+  op.repair_cnt = nullptr;
+  op.repair_rows = nullptr;
+  op.repair_cap = 0;
   op.Ax = d_Ax;
   op.x = d_x;
   op.y = d_y;
@@ -282,10 +343,14 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   PbPlan &pb = plan->pb;
   // max |x| (for the fixed-point scale of phase B) is collected by the launches that read x anyway: phase A over the
   // columns of the main layout, the gather kernels over the tier columns -- every column that has a nonzero
-  GDN_HIP(hipMemsetAsync(plan->mx.p + 1, 0, sizeof(unsigned), s));
+  GDN_HIP(hipMemsetAsync(plan->mx.p + 1, 0, 2 * sizeof(unsigned), s));  // max |x| and the repair count
   op.scale = plan->scale.p;
+  op.track = plan->track_lossy;
+  op.repair_cnt = plan->mx.p + 2;
+  op.repair_rows = plan->repair_rows.p;
+  op.repair_cap = (unsigned)plan->m;
   const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
-  const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
+  const size_t lds_b = (sizeof(unsigned long long) << pb.log_bin) + ((size_t)1 << pb.log_bin) / 8;  // + the lossy-row bitmap
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,
@@ -320,6 +385,9 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
                      pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op, 0, 0u,
                      nullptr, nullptr, nullptr, nullptr, pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, nullptr,
                      nullptr, nullptr, nullptr, mid);
+  if (plan->track_lossy)  // the rows handed back (usually a handful or none: the kernel reads the count on the device)
+    hipLaunchKernelGGL(spmv_repair_kernel, dim3(256), dim3(GDN_BLOCK), 0, s, plan->csr->rowptr, plan->csr->colidx, d_Ax, d_x, d_y,
+                       plan->repair_rows.p, plan->mx.p + 2, (unsigned)plan->m);
   if (timed) {
     GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
     pb.ev_used += 3;

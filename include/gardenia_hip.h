@@ -305,7 +305,11 @@ uint64_t gdn_pr_iter_bytes(const gdn_pr_plan *plan);
 typedef struct gdn_spmv_plan gdn_spmv_plan;
 /* layout as for PageRank.  GDN_LAYOUT_PB keeps Ax inside the plan in tile order (pass d_Ax here; the
  * d_Ax argument of gdn_spmv_dev is then ignored) and accumulates in signed fixed point whose
- * power-of-two scale is derived per call from max|Ax|*max|x|*max row length on the device.
+ * power-of-two scale is derived per call from max|Ax|*max|x|*max row length on the device: a product is converted with
+ * an absolute error below one unit = that bound * 2^-61, so every product within 2^-37 of the bound is exact; a row that
+ * received a smaller one and whose sum stays below 2^32 units is recomputed from the CSR in fp32 like the reference's
+ * loop (csr and d_Ax therefore have to outlive the plan / be passed to gdn_spmv_dev); for every other row the relative
+ * error is at most (its inexact products) * 2^-32.  Sums are bitwise reproducible.
  * GDN_LAYOUT_PB with d_Ax == NULL builds the plan of the PATTERN matrix (every nonzero 1): no value stream at all,
  * 8 instead of 12 bytes per nonzero (what delta PageRank's pull multiplies with). */
 int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax /*nullable for CSR*/, int32_t layout,

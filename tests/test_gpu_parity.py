@@ -682,6 +682,34 @@ def test_spmv_resident_layouts(orc, layout, scale, ef, seed, signed):
     sp.close()
 
 
+@pytest.mark.parametrize("tiers", [False, True])
+def test_spmv_pb_wide_dynamic_range(orc, monkeypatch, tiers):
+    """The propagation-blocked layout accumulates in fixed point with ONE scale per multiply.  Rows whose products sit
+    far below the largest ones (here: row scales from 1e-30 to 1e+5, x from 1e-12 to 1) lose bits in the conversion --
+    phase B hands exactly those rows back and they are recomputed in fp32 like the reference's loop, so every row still
+    meets the 1e-4 bound (and SpmvVerifier's criterion); tiny rows must not flush to zero."""
+    if tiers:
+        monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    g = graphio.rmat_graph(15, 16, seed=71)
+    gi = graphio.transpose(g)
+    rng = np.random.default_rng(71)
+    row_scale = np.float32(10.0) ** rng.integers(-30, 6, gi.m).astype(np.float32)
+    rows = np.repeat(np.arange(gi.m), np.diff(gi.rowptr.astype(np.int64)))
+    Ax = (rng.random(gi.nnz, dtype=np.float32) + np.float32(0.5)) * row_scale[rows]
+    x = (rng.random(gi.m, dtype=np.float32) + np.float32(0.5)) * np.float32(10.0) ** rng.integers(-12, 1, gi.m).astype(np.float32)
+    y0 = np.zeros(gi.m, np.float32)
+    want = orc.spmv(gi, Ax, x, y0)
+    assert (want != 0).sum() > gi.m // 4
+    sp = solvers.ResidentSpMV(solvers.Graph(csr=g, in_csr=gi), Ax, layout=1)  # GDN_LAYOUT_PB
+    got = sp.multiply(x, y0)
+    sp.close()
+    nz = want != 0
+    assert np.array_equal(got[~nz], want[~nz])
+    rel = np.abs(got[nz] - want[nz]) / np.abs(want[nz])
+    assert float(rel.max()) < 1e-4, (float(rel.max()), int(nz.nonzero()[0][rel.argmax()]))
+    assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)
+
+
 # ------------------------------------------------------------------ SSSP
 @pytest.mark.parametrize("case", ["test_bc_unit", "chesapeake_unit", "rmat10_unit", "rmat10_w255"])
 @pytest.mark.parametrize("delta", [1, 7, 1 << 20])
@@ -1092,7 +1120,7 @@ def test_pr_delta_degenerate_graphs(orc):
 
 @pytest.mark.parametrize("tiers", ["0", "2"])
 def test_spmv_pattern_plan_equals_unit_values(orc, monkeypatch, tiers):
-    """GDN_LAYOUT_PB without values = the pattern matrix: the same bits as the plan that stores Ax = 1."""
+    """GDN_LAYOUT_PB without values = the pattern matrix: the same sums as the plan that stores Ax = 1."""
     import ctypes as C
     from gardenia_amd import _cabi
     if tiers == "2":
@@ -1117,7 +1145,7 @@ def test_spmv_pattern_plan_equals_unit_values(orc, monkeypatch, tiers):
         _cabi.check(L.gdn_spmv_plan_create(h, ax, _cabi.GDN_LAYOUT_PB, C.byref(plan)))
         y = np.zeros(g.m, np.float32)
         _cabi.check(L.gdn_dev_upload(dy, y.ctypes.data_as(C.c_void_p), y.nbytes))
-        _cabi.check(L.gdn_spmv_dev(plan, None, dx, dy, None))
+        _cabi.check(L.gdn_spmv_dev(plan, ax, dx, dy, None))
         _cabi.check(L.gdn_spmv_plan_check(plan))
         _cabi.check(L.gdn_dev_download(y.ctypes.data_as(C.c_void_p), dy, y.nbytes))
         outs.append(y)
@@ -1125,7 +1153,11 @@ def test_spmv_pattern_plan_equals_unit_values(orc, monkeypatch, tiers):
     for d in (dA, dx, dy):
         L.gdn_dev_free(d)
     L.gdn_graph_free(h)
-    assert np.array_equal(outs[0], outs[1])
+    # the same bits -- except the few rows the VALUE plan recomputes in fp32 because a product lost bits in the fixed-point
+    # conversion while the row's sum is tiny (signed x: cancellation); the pattern plan keeps its exact integer sums there
+    same = outs[0] == outs[1]
+    assert same.mean() > 0.99
+    np.testing.assert_allclose(outs[0][~same], outs[1][~same], rtol=1e-4, atol=1e-6)
     want = orc.spmv(g, ones, x, np.zeros(g.m, np.float32))
     np.testing.assert_allclose(outs[1], want, rtol=REL_TOL, atol=1e-5)
 
