@@ -12,6 +12,7 @@
 // Counting: one wavefront per source vertex u with N+(u) staged in LDS; the neighbour lists of 64
 // out-neighbours at a time are walked lane-packed (gdn_expand.hpp) and looked up by binary search in
 // LDS; uint64 count reduced per wave then one atomicAdd per workgroup.  Exact (integer sum).
+#include <stdlib.h>
 #include <string.h>
 
 #include "gdn_expand.hpp"
@@ -209,9 +210,11 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
 // One wave: count the triangles closed by the out-neighbours v = colidx[vlo..vhi) of the row [ub,ue) (vlo..vhi is
 // the whole row for a light row, a slice of it for a heavy one).  N+(u) is staged in the wave's LDS hash set TC_CAP
 // ids at a time (one pass for all but a few hub rows; every pass walks all the lists of the slice).
+// ncol: the array the neighbours [vlo,vhi) are read from -- colidx itself (the row's own list: "for u, for v in N+(u)") or
+// the in-CSR's column ids (the v-centric count: the set is N+(v), the neighbours are the u with u -> v, see tc_count_kernel).
 __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
-                                                           eoff_t ub, eoff_t ue, eoff_t vlo, eoff_t vhi, vid_t *s_tab,
-                                                           unsigned char *s_own) {
+                                                           const vid_t *__restrict__ ncol, eoff_t ub, eoff_t ue, eoff_t vlo,
+                                                           eoff_t vhi, vid_t *s_tab, unsigned char *s_own) {
   const unsigned lane = gdn_lane();
   const int du = (int)(ue - ub);
   unsigned long long count = 0;
@@ -234,7 +237,7 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
       const eoff_t i = i0 + lane;
       eoff_t vb = 0, ve = 0;
       if (i < vhi) {
-        const vid_t v = i0 == cb ? x0 : colidx[i];
+        const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
         vb = rowptr[v];
         ve = rowptr[v + 1];
       }
@@ -267,11 +270,12 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 #endif
 
 __global__ void __launch_bounds__(GDN_BLOCK)
-tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t row_lo, int32_t row_hi, unsigned long long *__restrict__ items,
-                      unsigned capacity, unsigned *__restrict__ n_items, unsigned *__restrict__ overflow) {
-  const unsigned u = (unsigned)row_lo + blockIdx.x * GDN_BLOCK + threadIdx.x;  // source rows [row_lo, row_hi)
-  eoff_t du = 0;
-  if (u < (unsigned)row_hi) du = rowptr[u + 1] - rowptr[u];
+tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ nrowptr, int32_t row_lo, int32_t row_hi,
+                      unsigned long long *__restrict__ items, unsigned capacity, unsigned *__restrict__ n_items,
+                      unsigned *__restrict__ overflow) {
+  const unsigned u = (unsigned)row_lo + blockIdx.x * GDN_BLOCK + threadIdx.x;  // rows [row_lo, row_hi)
+  eoff_t du = 0;  // neighbours of the row (what the items slice); a row without a set closes nothing
+  if (u < (unsigned)row_hi && rowptr[u + 1] > rowptr[u]) du = nrowptr[u + 1] - nrowptr[u];
   const unsigned n = du > TC_LIGHT ? (unsigned)((du + TC_SLICE - 1) / TC_SLICE) : 0u;
   // wave-aggregated reservation: one atomic per wave
   const unsigned incl = gdn_wave_incl_scan(n);
@@ -287,7 +291,14 @@ tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, int32_t row_lo, int32_t
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK, TC_WAVES_PER_EU)
-tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m,
+// Two formulations, same total.  u-centric (nrowptr == rowptr, ncolidx == colidx; the reference's loop, src/tc/omp_base.cc:
+// 16-22): row u, set N+(u), neighbours v in N+(u), the elements of N+(v) are looked up -- SUM over edges of d+(v) probes.
+// v-centric (nrowptr / ncolidx = the TRANSPOSED DAG): row v, set N+(v), neighbours the u with u -> v, the elements of
+// N+(u) are looked up -- SUM over edges of d+(u) probes.  With the degree orientation v is the endpoint of higher degree
+// and its out-list the longer one (R-MAT-19: 1.71 G against 1.01 G probes): gdn_tc_dev counts both sums and transposes
+// the DAG when the v-centric form is the cheaper one.
+tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const eoff_t *__restrict__ nrowptr,
+                const vid_t *__restrict__ ncolidx, int32_t m,
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
                 unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
                 unsigned long long *__restrict__ total) {
@@ -309,9 +320,10 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     const unsigned long long item = items[it];
     const unsigned u = (unsigned)(item & 0xFFFFFFFFull), c = (unsigned)(item >> 32);
     const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
-    const eoff_t vlo = ub + (eoff_t)c * TC_SLICE;
-    const eoff_t vhi = vlo + TC_SLICE < ue ? vlo + TC_SLICE : ue;
-    count += tc_row_slice(rowptr, colidx, ub, ue, vlo, vhi, s_tab[w], s_own[w]);
+    const eoff_t nb0 = nrowptr[u], ne0 = nrowptr[u + 1];
+    const eoff_t vlo = nb0 + (eoff_t)c * TC_SLICE;
+    const eoff_t vhi = vlo + TC_SLICE < ne0 ? vlo + TC_SLICE : ne0;
+    count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w]);
   }
   // ---- light rows: 16 consecutive vertices per grab (one atomic per 16 rows)
   for (;;) {
@@ -320,13 +332,19 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     u0 = __shfl(u0, 0, 64);
     if (u0 >= (unsigned)m) break;
     const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
-    eoff_t rp = 0;  // the 17 row offsets of the batch in one load
-    if (u0 + lane <= u1) rp = rowptr[u0 + lane];
+    eoff_t rp = 0, np = 0;  // the 17 row offsets of the batch in one load (per array)
+    if (u0 + lane <= u1) {
+      rp = rowptr[u0 + lane];
+      np = nrowptr == rowptr ? rp : nrowptr[u0 + lane];
+    }
     for (unsigned u = u0; u < u1; u++) {
       const eoff_t ub = __shfl(rp, (int)(u - u0), 64), ue = __shfl(rp, (int)(u - u0) + 1, 64);
-      const eoff_t du = ue - ub;
-      if (du < 2 || du > TC_LIGHT) continue;  // a single out-neighbour closes no triangle; heavy rows are done
-      count += tc_row_slice(rowptr, colidx, ub, ue, ub, ue, s_tab[w], s_own[w]);
+      const eoff_t nb0 = __shfl(np, (int)(u - u0), 64), ne0 = __shfl(np, (int)(u - u0) + 1, 64);
+      const eoff_t dn = ne0 - nb0;
+      // nothing to close without a set or a neighbour; heavy rows are done
+      if (ue == ub || dn == 0 || dn > TC_LIGHT) continue;
+      if (nrowptr == rowptr && dn < 2) continue;  // u-centric: a single out-neighbour closes no triangle
+      count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w]);
     }
   }
   count = gdn_block_sum(count, s_red);
@@ -402,7 +420,8 @@ static int tc_orient(const gdn_graph *g, gdn_graph **out) {
 // SURVEY 8d's merge-equivalent traffic of a count: SUM over DAG edges (u,v) of d+(u) + d+(v) (a merge intersect reads both lists)
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_model_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned long long *__restrict__ out) {
-  unsigned long long acc = 0;
+  // out[0] += SUM d+(u) + d+(v); out[1] += SUM d+(u) alone (the probes of the v-centric count; the rest are the u-centric's)
+  unsigned long long acc = 0, acc_u = 0;
   const unsigned lane = gdn_lane();
   const size_t wave = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
   for (size_t u = wave; u < (size_t)m; u += nwaves) {
@@ -411,10 +430,15 @@ tc_model_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     for (eoff_t e = a + lane; e < b; e += 64) {
       const vid_t v = colidx[e];
       acc += du + (rowptr[v + 1] - rowptr[v]);
+      acc_u += du;
     }
   }
   acc = gdn_wave_sum(acc);
-  if (lane == 0 && acc) atomicAdd(out, acc);
+  acc_u = gdn_wave_sum(acc_u);
+  if (lane == 0 && acc) {
+    atomicAdd(out, acc);
+    atomicAdd(out + 1, acc_u);
+  }
 }
 
 extern "C" {
@@ -423,18 +447,34 @@ extern "C" {
 int gdn_tc_model_bytes(const gdn_graph *dag, uint64_t *bytes) {
   GDN_REQUIRE(dag != nullptr && bytes != nullptr, "dag / bytes");
   DevBuf<unsigned long long> acc;
-  GDN_TRY(acc.alloc(1));
-  GDN_HIP(hipMemset(acc.p, 0, 8));
+  GDN_TRY(acc.alloc(2));
+  GDN_HIP(hipMemset(acc.p, 0, 16));
   hipLaunchKernelGGL(tc_model_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, acc.p);
-  unsigned long long h = 0;
-  GDN_HIP(hipMemcpy(&h, acc.p, 8, hipMemcpyDeviceToHost));
-  *bytes = 4ull * h + 8ull * dag->nnz + 8ull * ((uint64_t)dag->m + 1);
+  unsigned long long h[2] = {0, 0};
+  GDN_HIP(hipMemcpy(h, acc.p, 16, hipMemcpyDeviceToHost));
+  *bytes = 4ull * h[0] + 8ull * dag->nnz + 8ull * ((uint64_t)dag->m + 1);
+  return GDN_OK;
+}
+
+// the probes of the two formulations of tc_count_kernel: probes[0] u-centric (SUM d+(v)), probes[1] v-centric (SUM d+(u))
+static int tc_probe_counts(const gdn_graph *dag, unsigned long long probes[2]) {
+  DevBuf<unsigned long long> acc;
+  GDN_TRY(acc.alloc(2));
+  GDN_HIP(hipMemset(acc.p, 0, 16));
+  hipLaunchKernelGGL(tc_model_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m, acc.p);
+  unsigned long long h[2] = {0, 0};
+  GDN_HIP(hipMemcpy(h, acc.p, 16, hipMemcpyDeviceToHost));
+  probes[0] = h[0] - h[1];
+  probes[1] = h[1];
   return GDN_OK;
 }
 
 // triangles closed over the source rows [row_lo, row_hi) of an oriented graph (the light-row cursor starts at row_lo and
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
-static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st) {
+// dag_in != nullptr: the v-centric count over the rows [row_lo, row_hi) of the TRANSPOSED DAG's row space (same vertices)
+static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
+                         const gdn_graph *dag_in = nullptr) {
+  const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
   const uint64_t cap64 = dag->nnz / TC_LIGHT + 1024;  // a heavy row of du > TC_LIGHT ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT items
@@ -452,12 +492,12 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   if (row_hi <= row_lo) return GDN_OK;
   tsolve.start();  // src/tc/gpu_base.cu:52-58
   const uint64_t rows = (uint64_t)(row_hi - row_lo);
-  hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, row_lo, row_hi,
-                     d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
+  hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
+                     row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
-  hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, row_hi, d_items.p,
-                     d_ctl.p + 2, d_ctl.p, d_total.p);
+  hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
+                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p);
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -487,9 +527,21 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
     GDN_TRY(tc_orient(g, &own));
     dag = own;
   }
+  // which formulation probes less (tc_count_kernel): the v-centric one needs the transposed DAG (built here, part of the
+  // preparation like the orientation: the reference orients while loading, src/tc/main.cc:12); GDN_TC_FORM=u|v forces one
+  unsigned long long probes[2] = {0, 0};
+  gdn_graph *dag_in = nullptr;
+  int rc = tc_probe_counts(dag, probes);
+  if (rc == GDN_OK) {
+    const char *e = getenv("GDN_TC_FORM");
+    const bool vform = e ? e[0] == 'v' : (double)probes[1] < 0.85 * (double)probes[0];
+    if (vform && dag->nnz) rc = gdn_graph_transpose(dag, &dag_in);
+  }
   st.prep_ms = tprep.stop_ms();
-  const int rc = tc_count_rows(dag, 0, dag->m, total, st);
+  if (rc == GDN_OK) rc = tc_count_rows(dag, 0, dag->m, total, st, dag_in);
   st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
+  st.reserved = dag_in ? 1 : 0;  // 1: the v-centric formulation ran
+  if (dag_in) gdn_graph_free(dag_in);
   if (own) gdn_graph_free(own);
   if (stats) *stats = st;
   return rc;
