@@ -18,6 +18,7 @@
 // (SURVEY 7 "Determinism"), independent of scheduling.  On a directed graph the hook is
 // symmetric in (u,v) like omp_base.cc:27-36, so the out-CSR alone yields weakly connected
 // components; in_csr is accepted for API parity and unused by this variant.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -159,7 +160,10 @@ cc_finish_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int32_t c, int sk
   if (v < (unsigned)m && vis.comp[v] != c) {
     b = rowptr[v];
     e = rowptr[v + 1];
-    b = (b + (eoff_t)skip < e) ? b + skip : e;
+    // a big row is cut into work items counted from the row's FIRST edge (gdn_expand_big_items): it keeps its sampled
+    // neighbours (re-linking them is harmless) -- skipping them here would shorten the item count and lose the row's
+    // last `skip` edges
+    if (e - b < big.min_deg) b = (b + (eoff_t)skip < e) ? b + skip : e;
   }
   gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
 }
@@ -183,9 +187,13 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
 int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_stats *stats) {
   GDN_REQUIRE(g != nullptr && d_comp != nullptr, "graph / d_comp");
   GDN_REQUIRE(gin == nullptr || gin->m == g->m, "in-CSR vertex count");
-  // With the reverse graph (or the graph itself for a symmetric one) every edge can be seen from
-  // both ends: Afforest.  Without it only the symmetric SV hook is safe on a directed graph.
-  if (gin != nullptr) return cc_afforest(g, gin, d_comp, stats);
+  // With the reverse graph (or the graph itself for a symmetric one) every edge can be seen from both ends: Afforest
+  // with its skip of the giant component.  Without it (a directed graph, out-edges only) the skip is not safe -- an edge
+  // from inside the giant component to a vertex outside it would never be linked -- but everything else is: the two
+  // sampling rounds, then ONE pass that links the remaining out-edges of EVERY vertex (a link whose two ends already
+  // share a root costs two loads).  That is a single sweep over the edges instead of Shiloach-Vishkin's ~5 (RMAT-24:
+  // 21.9 ms); GDN_CC_SV=1 keeps the SV rounds (the reference's src/cc/omp_base.cc algorithm) for comparison.
+  if (gin != nullptr || !getenv("GDN_CC_SV")) return cc_afforest(g, gin, d_comp, stats);
   const int32_t m = g->m;
   gdn_stats st;
   memset(&st, 0, sizeof(st));
@@ -247,7 +255,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   DevBuf<CcCounters> cnt;
   DevBuf<int32_t> d_sample;
   const int nsample = 1024;  // src/cc/verifier.cc:13 SampleFrequentElement(num_samples = 1024)
-  const uint64_t nn = g->nnz > gin->nnz ? g->nnz : gin->nnz;
+  const uint64_t nn = (gin && gin->nnz > g->nnz) ? gin->nnz : g->nnz;
   const uint64_t bigcap64 = nn / EXP_CHUNK + (uint64_t)m / 64 + 1024;
   const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
   GDN_TRY(bigitems.alloc(bigcap));
@@ -289,9 +297,10 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   vis.comp = d_comp;
   vis.v = 0;
   vis.colidx = g->colidx;
-  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, c, neighbor_rounds, big, vis);
+  // gin == nullptr (out-edges only): nobody is skipped (label -1 matches no vertex)
+  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, gin ? c : -1, neighbor_rounds, big, vis);
   hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, vis);
-  if (gin != g) {  // directed: the in-edges too (omp_afforest.cc:72-74)
+  if (gin && gin != g) {  // directed: the in-edges too (omp_afforest.cc:72-74)
     GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
     vis.colidx = gin->colidx;
     hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, gin->rowptr, m, c, 0, big, vis);

@@ -841,6 +841,33 @@ def test_cc_many_small_components(orc):
     assert np.array_equal(comp, want)
 
 
+def test_cc_directed_without_reverse_links_every_out_edge(orc):
+    """A directed graph handed over WITHOUT its reverse (gdn_cc's in_* = NULL): two sampling rounds, then one pass over the
+    remaining out-edges of every vertex.  Stars whose leaves have no out-edge of their own hang on the hub's row alone --
+    also its LAST edges, which a big row (cut into work items from its first edge) once lost when the two sampled
+    neighbours were skipped."""
+    rng = np.random.default_rng(5)
+    hubs = [(0, 700), (1, 513), (2, 514), (3, 3000), (4, 63), (5, 2)]
+    src, dst, nxt = [], [], 10
+    for h, k in hubs:
+        src += [h] * k
+        dst += list(range(nxt, nxt + k))
+        nxt += k
+    m = nxt + 1000
+    extra = rng.integers(nxt, m, (2000, 2))  # a random sparse part behind the stars
+    src += extra[:, 0].tolist()
+    dst += extra[:, 1].tolist()
+    g = graphio.build_csr(m, np.array(src, np.int64), np.array(dst, np.int64))
+    want, _ = orc.cc_sv(g)
+    comp = np.arange(m, dtype=np.int32)
+    solvers.CCSolver(solvers.Graph(csr=g), comp)  # no reverse graph
+    assert np.array_equal(comp, want)
+    lo = 10
+    for h, k in hubs:
+        assert np.all(comp[lo:lo + k] == h)
+        lo += k
+
+
 # ------------------------------------------------------------------ TC
 @pytest.mark.parametrize("case", ["chesapeake_sym", "rmat10_sym"])
 def test_tc_golden(case):
