@@ -187,6 +187,138 @@ bfs_td_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__
   }
 }
 
+// Light levels of a high-diameter graph beyond one workgroup: the same loop on a COOPERATIVE grid -- one workgroup per CU,
+// every level ends in a grid barrier (cooperative_groups::grid_group::sync, the CDNA form of the reference's software
+// global barrier include/gbar.h:24-65 under its persistent "fusion" kernels, src/bfs/fusion.cu:163-178) instead of a
+// kernel boundary and a blocking read back.  A 4096 x 4096 road-like grid (8 191 levels of <= 4 096 vertices) is the
+// case: 28 us per level on the host loop.  Three counter sets rotate (the set of level L+1 is zeroed while level L runs;
+// the set of level L-1 may still be read by a late workgroup), each counter on a cache line of its own.
+#define BFS_COOP_THREADS 256
+struct BfsCoopCnt {
+  alignas(128) unsigned count;
+  alignas(128) unsigned long long scout;
+  alignas(128) unsigned over;
+};
+
+// all workgroups of a cooperative launch (co-resident by construction): arrive on bar[0], the last one bumps the
+// generation bar[32] the others spin on.  (cooperative_groups' grid.sync() cost ~30 us per level here.)
+__device__ __forceinline__ void bfs_grid_barrier(unsigned *bar, unsigned nblocks) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(bar, 1u) == nblocks - 1u) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      atomicAdd(bar + 32, 1u);
+    } else {
+      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(BFS_COOP_THREADS)
+bfs_td_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, unsigned *__restrict__ visited,
+                   int32_t *__restrict__ depth, vid_t *q0, vid_t *q1, unsigned which, unsigned nf, unsigned cap, int32_t level,
+                   unsigned long long scout_cur, unsigned max_nf, unsigned long long max_scout, unsigned min_nf,
+                   BfsCoopCnt *cnt /* 3 sets, zeroed by the host */, unsigned *bar /* 64 words, zeroed by the host */,
+                   BfsSmallOut *__restrict__ out) {
+  const unsigned lane = gdn_lane();
+  const unsigned gt = blockIdx.x * BFS_COOP_THREADS + threadIdx.x, nt = gridDim.x * BFS_COOP_THREADS;
+  unsigned levels = 0;
+  unsigned long long checked = 0, discovered = 0;
+  bool over = false;
+  for (;;) {
+    BfsCoopCnt *cur = cnt + (levels % 3u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      BfsCoopCnt *nxt = cnt + ((levels + 1u) % 3u);
+      __hip_atomic_store(&nxt->count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&nxt->scout, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const vid_t *qin = which ? q1 : q0;
+    vid_t *qout = which ? q0 : q1;
+    unsigned long long scout = 0;
+    // one edge of `dst` per lane and step: claim it, push the claimed ones with one counter add per wave step
+    auto visit = [&](bool valid, vid_t dst) {
+      bool claim = false;
+      if (valid) {
+        const unsigned bit = 1u << (dst & 31);
+        if (!(__hip_atomic_load(visited + (dst >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit))
+          claim = !(atomicOr(&visited[dst >> 5], bit) & bit);
+      }
+      const unsigned long long mask = __ballot(claim);
+      if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        unsigned base = 0;
+        if ((int)lane == leader) base = atomicAdd(&cur->count, (unsigned)__popcll(mask));
+        base = __shfl(base, leader, 64);
+        if (claim) {
+          depth[dst] = level + 1;
+          scout += rowptr[dst + 1] - rowptr[dst];
+          const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
+          if (pos < cap) __hip_atomic_store(qout + pos, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else over = true;
+        }
+      }
+    };
+    for (unsigned i0 = gt - lane; i0 < nf; i0 += nt) {  // a wave takes 64 frontier vertices, one per lane
+      const unsigned i = i0 + lane;
+      eoff_t b = 0, e = 0;
+      if (i < nf) {
+        const vid_t v = __hip_atomic_load(qin + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        b = rowptr[v];
+        e = rowptr[v + 1];
+      }
+      // rows of a wave's width or more: the whole wave walks them one after the other
+      unsigned long long longs = __ballot(e - b >= 64u);
+      const bool mine_long = e - b >= 64u;
+      while (longs) {
+        const int leader = __ffsll((long long)longs) - 1;
+        longs &= longs - 1ull;
+        const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
+        for (eoff_t k0 = bb; k0 < ee; k0 += 64) {
+          const eoff_t k = k0 + lane;
+          visit(k < ee, k < ee ? colidx[k] : 0);
+        }
+      }
+      if (mine_long) b = e;
+      // short rows: every lane walks its own row (64 rows in flight per wave instead of one)
+      for (eoff_t j = 0; __any(b + j < e); j++) {
+        const bool valid = b + j < e;
+        visit(valid, valid ? colidx[b + j] : 0);
+      }
+    }
+    scout = gdn_wave_sum(scout);
+    if (lane == 0 && scout) atomicAdd(&cur->scout, scout);
+    if (__any(over) && lane == 0) __hip_atomic_store(&cur->over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bfs_grid_barrier(bar, gridDim.x);
+    checked += scout_cur;
+    nf = __hip_atomic_load(&cur->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    scout_cur = __hip_atomic_load(&cur->scout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned ov = __hip_atomic_load(&cur->over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    discovered += nf;
+    which ^= 1u;
+    level++;
+    levels++;
+    // leave when the frontier is empty, too heavy for this grid, or light enough for the one-workgroup kernel again
+    if (nf == 0 || nf > max_nf || scout_cur > max_scout || nf < min_nf || ov) {
+      over = ov != 0u;
+      break;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out->levels = levels;
+    out->nf = nf;
+    out->which = which;
+    out->overflow = over ? 1u : 0u;
+    out->scout = scout_cur;
+    out->checked = checked;
+    out->discovered = discovered;
+  }
+}
+
 // Bottom-up step: one thread per vertex, early exit on the first parent found in the frontier
 // bitmap (omp_beamer.cc:13-31).  A wave owns two bitmap words, so next/visited words are
 // written whole, without atomics.  Persistent grid: the awake / scout totals are kept in registers and added
@@ -499,6 +631,9 @@ struct gdn_bfs_plan {
   DevBuf<vid_t> q0, q1;
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
+  DevBuf<BfsCoopCnt> coop_cnt;  // 3 rotating sets of the cooperative light-level kernel
+  DevBuf<unsigned> coop_bar;    // its grid barrier: [0] arrivals, [32] generation
+  int coop_blocks = 0;          // 0: cooperative launches unavailable
   DevBuf<BfsSmallOut> small_out;
   BfsCounters *h_cnt = nullptr;  // pinned host copy of the level counters (one 32-byte read back per level)
   ~gdn_bfs_plan() {
@@ -577,6 +712,17 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
   GDN_TRY(p.small_out.alloc(1));
+  {  // the cooperative light-level kernel: one workgroup per CU if the device takes cooperative launches
+    int dev = 0, coop = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess &&
+        coop && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfs_td_coop_kernel, BFS_COOP_THREADS, 0) == hipSuccess && per_cu >= 1) {
+      p.coop_blocks = cus;
+      GDN_TRY(p.coop_cnt.alloc(3));
+      GDN_TRY(p.coop_bar.alloc(64));
+    }
+    (void)hipGetLastError();
+  }
   if (hipHostMalloc((void **)&p.h_cnt, sizeof(BfsCounters) > 64 ? sizeof(BfsCounters) : 64 /* BfsCounters or BfsSmallOut */, hipHostMallocDefault) != hipSuccess) p.h_cnt = nullptr;
   if (gin) {
     GDN_TRY(p.front.alloc(p.nwords_pad));
@@ -630,6 +776,17 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   unsigned long long small_scout = 2048;
   if (const char *e = getenv("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
   if (const char *e = getenv("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  // light levels that outgrow the one workgroup go to the cooperative grid (bfs_td_coop_kernel) once `coop_streak` light
+  // levels in a row say "high diameter" (an R-MAT search has 2-3 light levels on either side of its heavy ones and never
+  // gets there; GDN_BFS_COOP=0 switches the path off, =1 takes it from the first light level: tests)
+  unsigned coop_nf = 65536, coop_streak = 8;
+  unsigned long long coop_scout = 1ull << 20;
+  if (const char *e = getenv("GDN_BFS_COOP")) {
+    if (atoi(e) == 0) coop_nf = 0;
+    else coop_streak = 0;
+  }
+  if (p.coop_blocks == 0) coop_nf = 0;
+  unsigned light_streak = 0;
   BfsCounters h;
   memset(&h, 0, sizeof(h));
   ExpBigList big;
@@ -648,6 +805,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   while (nf > 0) {
     if (p.dense && scout_count > (int64_t)(g->nnz / alpha_dense)) {
       // ---- dense phase: propagation-blocked sweeps while the frontier stays heavy
+      light_streak = 0;
       GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
       hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
       unsigned *fr = p.front.p, *nx = p.next.p;
@@ -696,6 +854,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       edges_to_check = 0;  // from here on only the top-down tail is left
     } else if (!p.dense && gin != nullptr && scout_count > edges_to_check / alpha) {
       // ---- bottom-up phase (omp_beamer.cc:130-141)
+      light_streak = 0;
       GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
       hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
       int64_t awake = (int64_t)nf, old_awake;
@@ -745,7 +904,52 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         scout_count = (int64_t)so.scout;
         qin = so.which ? p.q1.p : p.q0.p;
         qout = so.which ? p.q0.p : p.q1.p;
+        light_streak += so.levels;
         lap("small", nf, scout_count);
+        continue;
+      }
+      // ---- light levels beyond one workgroup on a high-diameter graph: the cooperative grid, a barrier per level
+      if (coop_nf > 0 && light_streak >= coop_streak && nf <= coop_nf && (unsigned long long)scout_count <= coop_scout) {
+        GDN_HIP(hipMemsetAsync(p.coop_cnt.p, 0, 3 * sizeof(BfsCoopCnt), 0));
+        GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, 64 * sizeof(unsigned), 0));
+        const eoff_t *a_rowptr = g->rowptr;
+        const vid_t *a_colidx = g->colidx;
+        unsigned *a_visited = p.visited.p;
+        int32_t *a_depth = d_dist;
+        vid_t *a_q0 = p.q0.p, *a_q1 = p.q1.p;
+        unsigned a_which = qin == p.q1.p ? 1u : 0u, a_nf = nf, a_cap = p.qcap;
+        int32_t a_level = level;
+        unsigned long long a_scout = (unsigned long long)scout_count, a_max_scout = coop_scout;
+        unsigned a_max_nf = coop_nf, a_min_nf = small_nf ? small_nf / 8u : 0u;
+        BfsCoopCnt *a_cnt = p.coop_cnt.p;
+        unsigned *a_bar = p.coop_bar.p;
+        BfsSmallOut *a_out = p.small_out.p;
+        void *args[] = {&a_rowptr, &a_colidx, &a_visited, &a_depth, &a_q0, &a_q1, &a_which, &a_nf, &a_cap, &a_level, &a_scout,
+                        &a_max_nf, &a_max_scout, &a_min_nf, &a_cnt, &a_bar, &a_out};
+        GDN_HIP(hipLaunchCooperativeKernel((const void *)bfs_td_coop_kernel, dim3((unsigned)p.coop_blocks), dim3(BFS_COOP_THREADS), args,
+                                           0, 0));
+        BfsSmallOut so;
+        if (p.h_cnt) {
+          GDN_HIP(hipMemcpyAsync(p.h_cnt, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost, 0));
+          GDN_HIP(hipStreamSynchronize(0));
+          memcpy(&so, p.h_cnt, sizeof(so));
+        } else {
+          GDN_HIP(hipMemcpy(&so, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost));
+        }
+        if (so.overflow) {
+          gdn_set_error("gdn_bfs: device worklist overflow");
+          return GDN_ERR_OVERFLOW;
+        }
+        iter += (int)so.levels;
+        level += (int32_t)so.levels;
+        edges_to_check -= (int64_t)so.checked;
+        visited_total += (int64_t)so.discovered;
+        nf = so.nf;
+        scout_count = (int64_t)so.scout;
+        qin = so.which ? p.q1.p : p.q0.p;
+        qout = so.which ? p.q0.p : p.q1.p;
+        light_streak += so.levels;
+        lap("coop", nf, scout_count);
         continue;
       }
       // ---- top-down step (omp_beamer.cc:143-146)
@@ -778,6 +982,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       qin = qout;
       qout = t;
       level++;
+      light_streak = (coop_nf > 0 && nf <= coop_nf && (unsigned long long)scout_count <= coop_scout) ? light_streak + 1 : 0;
       lap("top-down", nf, scout_count);
     }
     if (h.overflow) {

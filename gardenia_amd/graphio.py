@@ -250,6 +250,33 @@ def rmat_graph(scale: int, edge_factor: int = 16, seed: int = K_RAND_SEED,
     return build_csr(1 << scale, src, dst)
 
 
+# ---- non-R-MAT shapes (SURVEY 8d stand-ins for real graphs: the heuristics of the solvers -- tier picker, level / bucket
+# choosers, dense-sweep triggers -- were tuned on R-MAT; these exercise the other regimes).  Edge lists, numpy, seeded.
+def grid2d_edges(nx: int, ny: int) -> Tuple[int, np.ndarray, np.ndarray]:
+    """Road-like: nx x ny lattice, 4 neighbours, both directions; diameter nx + ny, every degree <= 4."""
+    idx = np.arange(nx * ny, dtype=np.int64).reshape(ny, nx)
+    a = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel()])
+    b = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel()])
+    return nx * ny, np.concatenate([a, b]), np.concatenate([b, a])
+
+
+def uniform_edges(m: int, n_edges: int, seed: int = 1) -> Tuple[int, np.ndarray, np.ndarray]:
+    """Erdos-Renyi-like: endpoints uniform; no hubs at all (Poisson degrees)."""
+    rng = np.random.default_rng(seed)
+    return m, rng.integers(0, m, n_edges, dtype=np.int64), rng.integers(0, m, n_edges, dtype=np.int64)
+
+
+def small_world_edges(m: int, k: int, p: float, seed: int = 1) -> Tuple[int, np.ndarray, np.ndarray]:
+    """Watts-Strogatz: ring lattice of the k nearest neighbours (both directions), each far end rewired with probability
+    p: clustered like a social graph (many triangles), low diameter, narrow degree distribution."""
+    rng = np.random.default_rng(seed)
+    src = np.repeat(np.arange(m, dtype=np.int64), k // 2)
+    dst = (src + np.tile(np.arange(1, k // 2 + 1, dtype=np.int64), m)) % m
+    rew = rng.random(src.size) < p
+    dst = np.where(rew, rng.integers(0, m, src.size, dtype=np.int64), dst)
+    return m, np.concatenate([src, dst]), np.concatenate([dst, src])
+
+
 def first_nonisolated(g: CSR) -> int:
     deg = g.degrees()
     nz = np.nonzero(deg)[0]

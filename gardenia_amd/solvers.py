@@ -35,7 +35,8 @@ class Graph:
             else:
                 raise ValueError("filetype must be 'mtx' or 'bin'")
         self._out = csr
-        self._directed = (not symmetrize) and need_reverse
+        # directed = the reverse graph is a graph of its own (built here, or handed in as in_csr)
+        self._directed = (not symmetrize) and (need_reverse or (in_csr is not None and in_csr is not csr))
         self._in = None
         if in_csr is not None:
             self._in = in_csr

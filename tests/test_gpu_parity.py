@@ -73,6 +73,34 @@ def test_bfs_star_and_chain(orc):
     assert dist[-1] == 301
 
 
+@pytest.mark.parametrize("coop", [None, "0", "1"])
+def test_bfs_cooperative_light_levels(orc, monkeypatch, coop):
+    """High-diameter graphs: light levels that outgrow the one-workgroup kernel run on a cooperative grid with a barrier
+    per level (bfs_td_coop_kernel; GDN_BFS_COOP=1: from the first light level, 0: never, default: after 8 light levels in
+    a row).  A 300 x 300 lattice (598 levels of up to 300 vertices), a lattice with random shortcuts, and an R-MAT graph
+    (where the path must not change anything): depths exact, from the resident plan and the drop-in."""
+    if coop is not None:
+        monkeypatch.setenv("GDN_BFS_COOP", coop)
+    rng = np.random.default_rng(8)
+    m, src, dst = graphio.grid2d_edges(300, 300)
+    extra = rng.integers(0, m, (200, 2))
+    graphs = [graphio.build_csr(m, src, dst),
+              graphio.build_csr(m, np.concatenate([src, extra[:, 0]]), np.concatenate([dst, extra[:, 1]])),
+              graphio.rmat_graph(15, 16, seed=9)]
+    for g in graphs:
+        G = solvers.Graph(csr=g, need_reverse=True)
+        bfs = solvers.ResidentBFS(G, dense=True)
+        for s in (graphio.first_nonisolated(g), int(g.m // 2 + 7)):
+            want = orc.bfs_serial(g, s)
+            dist, st = bfs.run(s)
+            assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+            assert st["edges_traversed"] == int(g.degrees()[want != solvers.MYINFINITY].astype(np.int64).sum())
+            d2 = np.full(g.m, solvers.MYINFINITY, np.int32)
+            solvers.BFSSolver(solvers.Graph(csr=g), s, d2)
+            assert np.array_equal(d2, want)
+        bfs.close()
+
+
 # ------------------------------------------------------------------ PR
 @pytest.fixture(params=["csr", "pb"])
 def pr_layout(request, monkeypatch):
