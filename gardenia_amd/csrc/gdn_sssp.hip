@@ -711,6 +711,256 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same loop -- relax passes AND bucket changes -- on a COOPERATIVE grid (one workgroup per CU, a grid barrier per
+// phase) for the lists that outgrow one workgroup on a high-diameter graph: a road-like lattice with U[1,255] weights
+// takes tens of thousands of buckets of a few thousand vertices each, 33 us per phase on the host loop.  The CDNA form of
+// the reference's persistent kernels over a software global barrier (include/gbar.h:24-65, src/sssp fusion variants).
+// Counters: three rotating sets, one per phase (the set of phase p+1 is reset while phase p runs), each on cache lines
+// of its own; a wave takes 64 list entries, one per lane: short rows are walked lane-private (64 rows in flight), rows
+// of a wave's width or more by the whole wave.
+// ------------------------------------------------------------------------------------------
+#define SSSP_COOP_THREADS 256
+struct SsspCoopCnt {
+  alignas(128) unsigned nn;        // NEAR entries produced by the phase
+  alignas(128) unsigned nf;        // FAR entries appended (relax) / kept (split)
+  alignas(128) unsigned long long edges;
+  alignas(128) int min_far;
+  unsigned over;
+};
+
+__device__ __forceinline__ void sssp_grid_barrier(unsigned *bar, unsigned nblocks) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(bar, 1u) == nblocks - 1u) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __threadfence();
+      atomicAdd(bar + 32, 1u);
+    } else {
+      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// wave-aggregated slot reservation on a GLOBAL counter (all lanes of the wave must call it)
+__device__ __forceinline__ unsigned sssp_global_slot(unsigned *counter, bool want) {
+  const unsigned long long mask = __ballot(want);
+  if (mask == 0ull) return 0u;
+  const int leader = __ffsll((long long)mask) - 1;
+  unsigned base = 0;
+  if ((int)gdn_lane() == leader) base = atomicAdd(counter, (unsigned)__popcll(mask));
+  return __shfl(base, leader, 64) + (unsigned)__popcll(mask & gdn_lanemask_lt());
+}
+
+__global__ void __launch_bounds__(SSSP_COOP_THREADS)
+sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ weight,
+                 int32_t *dist, int32_t *stamp, unsigned *in_far, vid_t *near0, vid_t *near1, vid_t *far0, vid_t *far1,
+                 unsigned cap, int32_t delta, unsigned max_v, unsigned long long max_e, unsigned max_far,
+                 SsspCoopCnt *cnt /* 3 sets, reset by the host */, unsigned *bar /* 64 words, zeroed by the host */,
+                 SsspSmallState *state) {
+  const unsigned lane = gdn_lane();
+  const unsigned gt = blockIdx.x * SSSP_COOP_THREADS + threadIdx.x, nt = gridDim.x * SSSP_COOP_THREADS;
+  unsigned n_near = state->n_near, n_far = state->n_far;
+  unsigned long long near_edges = state->near_edges;
+  long long thr_lo = state->thr_lo, thr_hi = state->thr_hi;
+  int pass = state->pass, status = 0;
+  unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0, ph = 0;
+  int32_t maxd = 0;
+  bool over = false;
+  auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
+  // every phase: its counter set, and the reset of the next phase's
+  auto begin_phase = [&]() -> SsspCoopCnt * {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      SsspCoopCnt *nxt = cnt + ((ph + 1u) % 3u);
+      __hip_atomic_store(&nxt->nn, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&nxt->nf, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&nxt->edges, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&nxt->min_far, (int)GDN_DIST_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return cnt + (ph % 3u);
+  };
+  for (;;) {
+    if (n_near > 0) {
+      // ---- one relax pass over NEAR
+      SsspCoopCnt *cur = begin_phase();
+      ++pass;
+      ++passes;
+      const vid_t *near_in = near_sel ? near1 : near0;
+      vid_t *near_out = near_sel ? near0 : near1;
+      vid_t *far_cur = far_sel ? far1 : far0;
+      const int32_t lo = clamp(thr_lo), hi = clamp(thr_hi);
+      unsigned long long edges = 0;
+      auto relax = [&](bool valid, eoff_t k, int32_t du) {  // convergent: one edge per lane
+        bool to_near = false, to_far = false;
+        vid_t dst = 0;
+        if (valid) {
+          dst = colidx[k];
+          const int32_t nd = du + weight[k];
+          if (nd < __hip_atomic_load(dist + dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            const int32_t old = atomicMin(&dist[dst], nd);
+            if (nd < old) {
+              maxd = nd > maxd ? nd : maxd;
+              if (nd < hi) to_near = atomicExch(&stamp[dst], pass) != pass;
+              else to_far = atomicExch(&in_far[dst], 1u) == 0u;
+            }
+          }
+        }
+        const unsigned pn = sssp_global_slot(&cur->nn, to_near);
+        if (to_near) {
+          if (pn < cap) sssp_st(near_out + pn, dst);
+          else over = true;
+          edges += rowptr[dst + 1] - rowptr[dst];
+        }
+        const unsigned pf = sssp_global_slot(&cur->nf, to_far);
+        if (to_far) {
+          if (n_far + pf < cap) sssp_st(far_cur + n_far + pf, dst);
+          else over = true;
+        }
+      };
+      for (unsigned i0 = gt - lane; i0 < n_near; i0 += nt) {
+        const unsigned i = i0 + lane;
+        eoff_t b = 0, e = 0;
+        int32_t du = 0;
+        if (i < n_near) {
+          const vid_t v = sssp_ld(near_in + i);
+          du = __hip_atomic_load(dist + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (du >= lo) {  // else: settled in an earlier bucket (omp_base.cc:40)
+            b = rowptr[v];
+            e = rowptr[v + 1];
+          }
+        }
+        const bool mine_long = e - b >= 64u;
+        unsigned long long longs = __ballot(mine_long);
+        while (longs) {
+          const int leader = __ffsll((long long)longs) - 1;
+          longs &= longs - 1ull;
+          const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
+          const int32_t dd = __shfl(du, leader, 64);
+          for (eoff_t k0 = bb; k0 < ee; k0 += 64) relax(k0 + lane < ee, k0 + lane, dd);
+        }
+        if (mine_long) b = e;
+        for (eoff_t j = 0; __any(b + j < e); j++) relax(b + j < e, b + j, du);
+      }
+      edges = gdn_wave_sum(edges);
+      if (lane == 0 && edges) atomicAdd(&cur->edges, edges);
+      if (__any(over) && lane == 0) __hip_atomic_store(&cur->over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      sssp_grid_barrier(bar, gridDim.x);
+      ph++;
+      n_near = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n_far += __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      near_edges = __hip_atomic_load(&cur->edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      near_sel ^= 1u;
+      if (__hip_atomic_load(&cur->over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        over = true;
+        break;
+      }
+      if (n_near > 0) {
+        if (n_near > max_v || near_edges > max_e) {
+          status = 1;
+          break;
+        }
+        continue;
+      }
+    }
+    // ---- NEAR is empty: the next non-empty bucket (omp_base.cc:66-72)
+    if (n_far == 0) {
+      status = 0;
+      break;
+    }
+    if (n_far > max_far) {
+      status = 2;
+      break;
+    }
+    vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
+    vid_t *near_in = near_sel ? near1 : near0;
+    {
+      SsspCoopCnt *cur = begin_phase();
+      const int32_t hi = clamp(thr_hi);
+      int32_t d = GDN_DIST_INF;
+      for (unsigned i = gt; i < n_far; i += nt) {
+        const int32_t x = __hip_atomic_load(dist + sssp_ld(far_cur + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (x >= hi && x < d) d = x;  // stale entries are ignored
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int32_t t = __shfl_xor(d, o, 64);
+        d = t < d ? t : d;
+      }
+      if (lane == 0 && d != GDN_DIST_INF) atomicMin(&cur->min_far, d);
+      sssp_grid_barrier(bar, gridDim.x);
+      ph++;
+      const int32_t mn = __hip_atomic_load(&cur->min_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (mn == GDN_DIST_INF) {  // only stale entries were left
+        n_far = 0;
+        status = 0;
+        break;
+      }
+      const long long old_hi = thr_hi;
+      thr_lo = ((long long)mn / delta) * (long long)delta;
+      thr_hi = thr_lo + delta;
+      ++buckets;
+      cur = begin_phase();
+      const int32_t ohi = clamp(old_hi), nhi = clamp(thr_hi);
+      unsigned long long deg_sum = 0;
+      for (unsigned i0 = gt - lane; i0 < n_far; i0 += nt) {
+        const unsigned i = i0 + lane;
+        vid_t w = -1;
+        int32_t dd = 0;
+        if (i < n_far) {
+          w = sssp_ld(far_cur + i);
+          dd = __hip_atomic_load(dist + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const bool live = w >= 0, to_far = live && dd >= nhi, to_near = live && !to_far && dd >= ohi;
+        if (live && !to_far) __hip_atomic_store(in_far + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned pf = sssp_global_slot(&cur->nf, to_far);
+        if (to_far) sssp_st(far_nxt + pf, w);
+        const unsigned pn = sssp_global_slot(&cur->nn, to_near);
+        if (to_near) {
+          sssp_st(near_in + pn, w);
+          deg_sum += rowptr[w + 1] - rowptr[w];
+        }
+      }
+      deg_sum = gdn_wave_sum(deg_sum);
+      if (lane == 0 && deg_sum) atomicAdd(&cur->edges, deg_sum);
+      sssp_grid_barrier(bar, gridDim.x);
+      ph++;
+      n_near = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      n_far = __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      near_edges = __hip_atomic_load(&cur->edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      far_sel ^= 1u;
+    }
+    if (n_near > max_v || near_edges > max_e) {
+      status = 1;
+      break;
+    }
+  }
+  // largest distance written: one atomic per wave that raises it
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t t = __shfl_xor(maxd, o, 64);
+    maxd = t > maxd ? t : maxd;
+  }
+  if (lane == 0 && maxd > __hip_atomic_load(&state->max_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&state->max_dist, maxd);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    state->n_near = n_near;
+    state->n_far = n_far;
+    state->near_edges = near_edges;
+    state->thr_lo = thr_lo;
+    state->thr_hi = thr_hi;
+    state->pass = pass;
+    state->status = status;
+    state->near_sel = near_sel;
+    state->far_sel = far_sel;
+    state->overflow = over ? 1u : 0u;
+    state->passes = passes;
+    state->buckets = buckets;
+  }
+}
+
 // improved-row bitmap -> vertex queue.  Persistent grid: a workgroup owns a contiguous range of words, counts its rows
 // first and reserves its part of the queue with ONE atomic (one per wave on the hot counter cost 0.19 ms for 8192 waves),
 // then writes the rows in order; also sums their out-degrees (the host's dense / worklist decision).
@@ -765,6 +1015,9 @@ struct gdn_sssp_plan {
   DevBuf<unsigned> improved;
   DevBuf<unsigned> bad;    // 1 word: a 16-bit candidate overflowed (cannot happen; checked)
   DevBuf<SsspSmallState> small;
+  DevBuf<SsspCoopCnt> coop_cnt;  // 3 rotating counter sets of sssp_coop_kernel
+  DevBuf<unsigned> coop_bar;     // its grid barrier
+  int coop_blocks = 0;           // 0: no cooperative launches
   void *h_pin = nullptr;   // pinned staging for the counter read-backs
   ~gdn_sssp_plan() {
     if (h_pin) (void)hipHostFree(h_pin);
@@ -796,6 +1049,17 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
   GDN_TRY(p.bigitems.alloc(p.bigcap));
   GDN_TRY(p.cnt.alloc(1));
   GDN_TRY(p.small.alloc(1));
+  {  // the cooperative kernel: one workgroup per CU if the device takes cooperative launches
+    int dev = 0, coop = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess &&
+        coop && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sssp_coop_kernel, SSSP_COOP_THREADS, 0) == hipSuccess && per_cu >= 1) {
+      p.coop_blocks = cus;
+      GDN_TRY(p.coop_cnt.alloc(3));
+      GDN_TRY(p.coop_bar.alloc(64));
+    }
+    (void)hipGetLastError();
+  }
   if (hipHostMalloc(&p.h_pin, 1024, hipHostMallocDefault) != hipSuccess) p.h_pin = nullptr;  // falls back to pageable copies
   if (dense && g->nnz > 0) {
     int lg = 10;
@@ -958,6 +1222,15 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       small_far = cap;
     }
   }
+  // lists beyond one workgroup go to the cooperative grid (sssp_coop_kernel) once `coop_streak` light phases in a row say
+  // "high diameter" (GDN_SSSP_COOP=0: never, =1: from the first such phase -- tests)
+  unsigned coop_v = 65536, coop_far = 1u << 22, coop_streak = 8, light_streak = 0;
+  unsigned long long coop_e = 1ull << 20;
+  if (const char *e = getenv("GDN_SSSP_COOP")) {
+    if (atoi(e) == 0) coop_v = 0;
+    else coop_streak = 0;
+  }
+  if (p.coop_blocks == 0) coop_v = 0;
   for (;;) {
     if (n_near == 0 && n_far == 0) break;
     if (!pre_dense_done && (n_near > 0 || (small_v && n_far <= small_far))) {
@@ -999,13 +1272,73 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         near_out = ss.near_sel ? p.near0.p : p.near1.p;
         far_cur = ss.far_sel ? p.far1.p : p.far0.p;
         far_nxt = ss.far_sel ? p.far0.p : p.far1.p;
+        light_streak += ss.passes + ss.buckets;
         continue;  // status 0: both lists empty; 1: NEAR outgrew the workgroup; 2: NEAR empty, FAR too long for it
       }
+    }
+    if (!pre_dense_done && coop_v && light_streak >= coop_streak && n_near <= coop_v && near_edges <= coop_e && n_far <= coop_far &&
+        !(p.dense && near_edges * dense_in > (unsigned long long)g->nnz)) {
+      // ---- mid-size phases of a high-diameter search: passes and bucket changes on the cooperative grid
+      SsspSmallState ss;
+      memset(&ss, 0, sizeof(ss));
+      ss.n_near = n_near;
+      ss.n_far = n_far;
+      ss.near_edges = near_edges;
+      ss.thr_lo = thr_lo;
+      ss.thr_hi = thr_hi;
+      ss.pass = pass;
+      ss.near_sel = near_in == p.near1.p ? 1u : 0u;
+      ss.far_sel = far_cur == p.far1.p ? 1u : 0u;
+      SsspCoopCnt init[3];
+      memset(init, 0, sizeof(init));
+      for (int k = 0; k < 3; k++) init[k].min_far = GDN_DIST_INF;
+      GDN_HIP(hipMemcpyAsync(p.small.p, &ss, sizeof(ss), hipMemcpyHostToDevice, 0));
+      GDN_HIP(hipMemcpyAsync(p.coop_cnt.p, init, sizeof(init), hipMemcpyHostToDevice, 0));
+      GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, 64 * sizeof(unsigned), 0));
+      const eoff_t *a_rowptr = g->rowptr;
+      const vid_t *a_colidx = g->colidx;
+      const int32_t *a_w = d_weight;
+      int32_t *a_dist = d_dist, *a_stamp = p.stamp.p;
+      unsigned *a_in_far = p.in_far.p;
+      vid_t *a_n0 = p.near0.p, *a_n1 = p.near1.p, *a_f0 = p.far0.p, *a_f1 = p.far1.p;
+      unsigned a_cap = cap, a_max_v = coop_v, a_max_far = coop_far;
+      int32_t a_delta = delta;
+      unsigned long long a_max_e = coop_e;
+      SsspCoopCnt *a_cnt = p.coop_cnt.p;
+      unsigned *a_bar = p.coop_bar.p;
+      SsspSmallState *a_state = p.small.p;
+      void *args[] = {&a_rowptr, &a_colidx, &a_w, &a_dist, &a_stamp, &a_in_far, &a_n0, &a_n1, &a_f0, &a_f1, &a_cap, &a_delta,
+                      &a_max_v, &a_max_e, &a_max_far, &a_cnt, &a_bar, &a_state};
+      GDN_HIP(hipLaunchCooperativeKernel((const void *)sssp_coop_kernel, dim3((unsigned)p.coop_blocks), dim3(SSSP_COOP_THREADS), args, 0, 0));
+      GDN_TRY(sssp_read(p, p.small.p, ss));
+      if (ss.overflow) {
+        gdn_set_error("gdn_sssp: device worklist overflow");
+        return GDN_ERR_OVERFLOW;
+      }
+      if (trace)
+        fprintf(stderr, "[sssp] %7.1f us coop: %u passes, %u buckets -> status %d, bucket [%lld,%lld): near %u (%llu edges) far %u\n",
+                lap(), ss.passes, ss.buckets, ss.status, ss.thr_lo, ss.thr_hi, ss.n_near, ss.near_edges, ss.n_far);
+      phases += (int)ss.passes;
+      n_near = ss.n_near;
+      n_far = ss.n_far;
+      near_edges = ss.near_edges;
+      thr_lo = ss.thr_lo;
+      thr_hi = ss.thr_hi;
+      pass = ss.pass;
+      max_finite = ss.max_dist > max_finite ? ss.max_dist : max_finite;
+      near_in = ss.near_sel ? p.near1.p : p.near0.p;
+      near_out = ss.near_sel ? p.near0.p : p.near1.p;
+      far_cur = ss.far_sel ? p.far1.p : p.far0.p;
+      far_nxt = ss.far_sel ? p.far0.p : p.far1.p;
+      light_streak += ss.passes + ss.buckets;
+      if (ss.passes + ss.buckets == 0) coop_v = 0;  // (cannot happen: the entry test mirrors the kernel's; no endless loop)
+      continue;
     }
     if (n_near > 0) {
       if (p.dense && (near_edges * dense_in > (unsigned long long)g->nnz || pre_dense_done)) {
         pre_dense_done = false;
         // ---- heavy frontier: Bellman-Ford sweeps over all edges until few rows still improve
+        light_streak = 0;
         unsigned long long improved = 0;
         do {
           ++phases;
@@ -1098,6 +1431,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         fprintf(stderr, "[sssp] %7.1f us phase %d relax [%lld,%lld): near %u (%llu edges) -> near %u (%llu edges) far %u big %u\n", lap(), phases,
                 (long long)thr_lo, (long long)thr_hi, n_near, near_edges, h.near_count, h.relaxed, h.far_count, h.big_count);
       max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
+      light_streak++;
       if (pre_dense) {  // no lists were built: the sweeps take over from the distances
         pre_dense_done = true;
         n_near = 1;  // (placeholder: the dense branch does not read the list)

@@ -779,7 +779,8 @@ def test_sssp_resident_dense_sweeps(orc, scale, ef, seed, wmax):
 @pytest.mark.parametrize("wlo,whi,delta", [(7, 7, 3), (1, 255, 16), (200, 60000, 5000), (1, 1 << 20, 1 << 18), (0, 3, 1),
                                            (1, 3000, 64)])
 @pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_SMALL": "0"}, {"GDN_SSSP_SMALL": "2"}, {"GDN_SSSP_CAND32": "1"},
-                                   {"GDN_SSSP_CAND16": "1"}, {"GDN_SSSP_WBYTES": "4"}, {"GDN_SSSP_PAD": "128"}, {"GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_DENSE_OUT": "100000"}])
+                                   {"GDN_SSSP_CAND16": "1"}, {"GDN_SSSP_WBYTES": "4"}, {"GDN_SSSP_PAD": "128"},
+                                   {"GDN_SSSP_COOP": "1"}, {"GDN_SSSP_COOP": "1", "GDN_SSSP_SMALL": "0"}, {"GDN_SSSP_COOP": "0"}, {"GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_DENSE_OUT": "100000"}])
 def test_sssp_plan_stream_widths_and_fused_phases(orc, monkeypatch, wlo, whi, delta, knobs):
     """The dense sweeps pick the width of their two per-edge streams from the data -- no weight stream at all when every
     weight is equal, 8 / 16 / 32-bit weights, 16-bit candidates while the largest distance + weight stays below 0xFFFF and
@@ -802,6 +803,29 @@ def test_sssp_plan_stream_widths_and_fused_phases(orc, monkeypatch, wlo, whi, de
     s = graphio.first_nonisolated(g)
     solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, dist, delta)
     assert np.array_equal(dist, orc.sssp_dijkstra(g, wt, s))
+
+
+@pytest.mark.parametrize("coop", [None, "1"])
+def test_sssp_lattice_runs_on_the_cooperative_grid(orc, monkeypatch, coop):
+    """A 200 x 200 lattice (+ a few shortcuts) with U[1,255] weights and small deltas: thousands of buckets of a few
+    hundred vertices.  Lists that outgrow the one-workgroup kernel run on the cooperative grid (sssp_coop_kernel: a grid
+    barrier per pass and per bucket change); distances exact, from the plan (dense sweeps available) and the drop-in."""
+    if coop is not None:
+        monkeypatch.setenv("GDN_SSSP_COOP", coop)
+    rng = np.random.default_rng(12)
+    m, src, dst = graphio.grid2d_edges(200, 200)
+    extra = rng.integers(0, m, (50, 2))
+    g = graphio.build_csr(m, np.concatenate([src, extra[:, 0]]), np.concatenate([dst, extra[:, 1]]))
+    wt = rng.integers(1, 256, size=g.nnz).astype(np.int32)
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    for s, delta in ((0, 16), (m // 2 + 13, 64), (m - 1, 3)):
+        want = orc.sssp_dijkstra(g, wt, s)
+        dist, st = sp.run(s, delta)
+        assert np.array_equal(dist, want), (s, delta, int((dist != want).sum()))
+        d2 = np.full(m, solvers.K_DIST_INF, np.int32)
+        solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, d2, delta)
+        assert np.array_equal(d2, want)
+    sp.close()
 
 
 def test_sssp_long_weighted_path_runs_inside_one_workgroup(orc):
