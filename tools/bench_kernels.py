@@ -178,7 +178,14 @@ def main():
     # CC = weakly connected components of the directed graph: SV (out-CSR only, symmetric hook) and
     # Afforest (out- and in-CSR)
     comp = torch.empty(m, dtype=torch.int32, device=dev)
-    for name, rev in (("sv", None), ("afforest", gi)):
+    for name, rev in (("sv_rounds", None), ("out_edges_only", None), ("afforest", gi)):
+        # without the reverse graph: Afforest's sampling + one link pass over every out-edge (GDN_CC_SV=1: the SV rounds)
+        if name == "sv_rounds":
+            os.environ["GDN_CC_SV"] = "1"
+        else:
+            os.environ.pop("GDN_CC_SV", None)
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_cc_dev(go, rev, ptr(comp), C.byref(st)))
         st = _cabi.GdnStats()
         _cabi.check(L.gdn_cc_dev(go, rev, ptr(comp), C.byref(st)))
         ncomp = int((comp == torch.arange(m, dtype=torch.int32, device=dev)).sum().item())
@@ -214,17 +221,29 @@ def main():
     L.gdn_graph_free(go)
     del comp, dist, deg
 
-    # ---------------- TC (config 4 stand-in): symmetrize on the host with numpy at this scale
-    g = graphio.symmetrize(graphio.rmat_graph(args.tc_scale, 16))
+    # ---------------- TC (config 4 stand-in): symmetrized on the device; both formulations of the count
+    go, _ = build(args.tc_scale, want_in=False)
     h = C.c_void_p()
-    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, g.rowptr.ctypes.data_as(C.c_void_p), g.colidx.ctypes.data_as(C.c_void_p),
-                                   C.byref(h)))
-    total = C.c_uint64(0)
-    st = _cabi.GdnStats()
-    _cabi.check(L.gdn_tc_dev(h, 0, C.byref(total), C.byref(st)))
-    res[f"tc_rmat{args.tc_scale}_sym"] = {"vertices": g.m, "sym_edges": g.nnz, "dag_edges": st.edges_traversed,
-                                          "triangles": int(total.value), "count_ms": st.solve_ms,
-                                          "orient_ms": st.prep_ms, "gteps_dag": st.edges_traversed / st.solve_ms / 1e6}
+    _cabi.check(L.gdn_graph_symmetrize(go, C.byref(h)))
+    L.gdn_graph_free(go)
+    gm, gnnz = info(h)
+    for form in ("auto", "u", "v"):
+        if form == "auto":
+            os.environ.pop("GDN_TC_FORM", None)
+        else:
+            os.environ["GDN_TC_FORM"] = form
+        best = None
+        for _ in range(3):
+            total = C.c_uint64(0)
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_tc_dev(h, 0, C.byref(total), C.byref(st)))
+            if best is None or st.solve_ms < best[0]:
+                best = (st.solve_ms, st.prep_ms, st.reserved)
+        res[f"tc_rmat{args.tc_scale}_sym_{form}"] = {"vertices": gm, "sym_edges": gnnz, "dag_edges": st.edges_traversed,
+                                                     "triangles": int(total.value), "count_ms": best[0], "prep_ms": best[1],
+                                                     "form": "v-centric" if best[2] else "u-centric",
+                                                     "gteps_dag": st.edges_traversed / best[0] / 1e6}
+    os.environ.pop("GDN_TC_FORM", None)
     L.gdn_graph_free(h)
     print(json.dumps(res, indent=1))
 

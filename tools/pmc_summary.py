@@ -14,8 +14,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01_pb"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02_pb"
 out = os.path.join(ROOT, "profiles")
+SRC = "gpurun_out/r02"  # written by tools/profile_r02.sh (one session, one box)
 
 
 def counters(pat):
@@ -26,17 +27,20 @@ def counters(pat):
     return agg
 
 
-stats = glob.glob(os.path.join(ROOT, "gpurun_out/prof_pb_trace/runc/*_kernel_stats.csv"))[0]
+stats = glob.glob(os.path.join(ROOT, SRC, "trace/*/*_kernel_stats.csv"))[0]
+session = " / ".join(" ".join(x.split()) for x in open(os.path.join(ROOT, SRC, "session.txt")).read().splitlines()
+                     if x.strip() and not x.startswith("="))
 shutil.copyfile(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 3 --no-cpu  (RMAT-27, PB layout)\n\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extras  (RMAT-27, PB layout)\n\n")
+    f.write("Session (one box, tools/profile_r02.sh): %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n\n" % (session, tag))
     f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
     for r in rows[:18]:
         f.write(f"| `{r['Name'].split('(')[0][:80]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | "
                 f"{float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |\n")
-fetch = counters("gpurun_out/prof_pb_fetch/runc/*_counter_collection.csv")
-write = counters("gpurun_out/prof_pb_write/runc/*_counter_collection.csv")
+fetch = counters(SRC + "/fetch/*/*_counter_collection.csv")
+write = counters(SRC + "/write/*/*_counter_collection.csv")
 kern = {}
 total = 0.0
 for k in ("pb_expand_kernel", "void pb_accumulate_kernel<PrOp>"):
@@ -45,13 +49,18 @@ for k in ("pb_expand_kernel", "void pb_accumulate_kernel<PrOp>"):
     kern[k] = {"FETCH_SIZE_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "WRITE_SIZE_bytes": wk,
                "hbm_bytes": 2 * fk + wk, "dispatches": len(fetch[k])}
     total += 2 * fk + wk
-bench = json.load(open(os.path.join(ROOT, "gpurun_out/prof_pb_bench.json")))
-res = {"scale": 27, "n_gpus": 1, "layout": bench["config"]["layout"], "hbm_bytes_per_launch": total,
+bench = json.load(open(os.path.join(ROOT, SRC, "bench_under_rocprof.json")))
+plain = json.load(open(os.path.join(ROOT, SRC, "bench.json")))
+res = {"scale": 27, "n_gpus": 1, "session": session, "layout": bench["config"]["layout"], "hbm_bytes_per_launch": total,
+       "unprofiled_same_session": {"ms_per_step": plain["ms_per_step"], "kernel_ms": plain["roofline"]["kernel_ms"],
+                                   "frac": plain["roofline"]["frac"], "step_ms": plain.get("step_ms")},
        "note": "one launch = one PageRank iteration = pb_expand_kernel + pb_accumulate_kernel<PrOp>; "
                "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md, WRITE_SIZE (KB) as is; separate --pmc passes",
        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"], "kernels": kern,
        "kernel_ms_under_rocprof": bench["roofline"]["kernel_ms"]}
 json.dump(res, open(os.path.join(out, "pr_traffic.json"), "w"), indent=1)
-shutil.copyfile(os.path.join(ROOT, "gpurun_out/prof_pb_bench.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+shutil.copyfile(os.path.join(ROOT, SRC, "bench_under_rocprof.json"), os.path.join(out, f"{tag}_bench_under_rocprof.json"))
+shutil.copyfile(os.path.join(ROOT, SRC, "bench.json"), os.path.join(out, f"{tag}_bench_same_session.json"))
+shutil.copyfile(os.path.join(ROOT, SRC, "session.txt"), os.path.join(out, f"{tag}_session.txt"))
 print(json.dumps(res, indent=1))
 print(open(os.path.join(out, f"{tag}_kernel_stats.md")).read())
