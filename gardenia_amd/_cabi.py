@@ -46,6 +46,8 @@ _st = C.POINTER(GdnStats)
 # name -> (restype, argtypes); must list every symbol of include/gardenia_hip.h
 PROTOTYPES = {
     "gdn_last_error": (C.c_char_p, []),
+    "gdn_option_set": (C.c_int, [C.c_char_p, C.c_char_p]),
+    "gdn_option_get": (C.c_int, [C.c_char_p, C.c_char_p, _i32]),
     "gdn_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "gdn_set_device": (C.c_int, [C.c_int]),
     "gdn_bfs": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _i32, _vp, _st]),

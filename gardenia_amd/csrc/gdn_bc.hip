@@ -798,7 +798,7 @@ int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *st
   for (int d = 0; d < BC_MAX_LEVELS; d++)
     if (ls.count[d]) nlev = d + 1;
   uint64_t heavy_div = 16;  // a level is heavy (two blocked sweeps instead of atomics / gathers) from nnz / heavy_div out-edges on
-  if (const char *e = getenv("GDN_BC_HEAVY_DIV")) heavy_div = atoi(e) > 0 ? (uint64_t)atoi(e) : heavy_div;  // tuning knob
+  if (const char *e = gdn_option("GDN_BC_HEAVY_DIV")) heavy_div = atoi(e) > 0 ? (uint64_t)atoi(e) : heavy_div;  // tuning knob
   const uint64_t heavy = g->nnz / heavy_div + 1;
   GDN_HIP(hipMemsetAsync(p.pc.p, 0, (size_t)m * 4, 0));
   GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BcCounters), 0));
@@ -907,8 +907,8 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
   unsigned small_nf = 256;
   unsigned long long small_scout = 2048;
-  if (const char *e = getenv("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
-  if (const char *e = getenv("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_option("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
+  if (const char *e = gdn_option("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   DevBuf<BcSmallOut> small_out;
   if (small_nf) GDN_TRY(small_out.alloc(1));
   for (int32_t level = 0;;) {

@@ -751,7 +751,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
 
   const int alpha = 15, beta = 18;   // omp_beamer.cc:111
   int alpha_dense = 32;              // a dense sweep costs about nnz/32 top-down edge visits
-  if (const char *e = getenv("GDN_BFS_ALPHA_DENSE")) alpha_dense = atoi(e) > 0 ? atoi(e) : 32;  // tuning knob
+  if (const char *e = gdn_option("GDN_BFS_ALPHA_DENSE")) alpha_dense = atoi(e) > 0 ? atoi(e) : 32;  // tuning knob
   vid_t *qin = p.q0.p, *qout = p.q1.p;
   unsigned nf = 1;
   int64_t edges_to_check = (int64_t)g->nnz;
@@ -763,25 +763,25 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int64_t visited_total = 1;  // discovered so far (the source included)
   int64_t bu_frac = 2;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered (measured on
                               // RMAT-22..27: 2 beats 4 wherever a second heavy level follows the first, 1 loses)
-  if (const char *e = getenv("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
+  if (const char *e = gdn_option("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
   // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
   // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
   // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
   int64_t bu_stay = 256;
-  if (const char *e = getenv("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
+  if (const char *e = gdn_option("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
   // (measured: 1024 / 16384 made RMAT-20..24 searches 5-15 % slower -- 16 K edges on ONE CU are no faster than a launch
   // over all of them --, a 100 000-vertex chain 4.6x faster; the smaller limits keep the second without the first)
   unsigned small_nf = 256;
   unsigned long long small_scout = 2048;
-  if (const char *e = getenv("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
-  if (const char *e = getenv("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_option("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
+  if (const char *e = gdn_option("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   // light levels that outgrow the one workgroup go to the cooperative grid (bfs_td_coop_kernel) once `coop_streak` light
   // levels in a row say "high diameter" (an R-MAT search has 2-3 light levels on either side of its heavy ones and never
   // gets there; GDN_BFS_COOP=0 switches the path off, =1 takes it from the first light level: tests)
   unsigned coop_nf = 65536, coop_streak = 8;
   unsigned long long coop_scout = 1ull << 20;
-  if (const char *e = getenv("GDN_BFS_COOP")) {
+  if (const char *e = gdn_option("GDN_BFS_COOP")) {
     if (atoi(e) == 0) coop_nf = 0;
     else coop_streak = 0;
   }
@@ -792,7 +792,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   ExpBigList big;
   big.items = p.bigitems.p;
   big.capacity = p.bigcap;
-  const bool trace = getenv("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
+  const bool trace = gdn_option("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
   HostTimer tl;
   auto lap = [&](const char *what, long long a, long long b) {
     if (trace) fprintf(stderr, "[bfs] level %d %-10s nf/awake=%lld scout=%lld  %.3f ms\n", level, what, a, b, tl.stop_ms());

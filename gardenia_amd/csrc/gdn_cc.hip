@@ -193,7 +193,7 @@ int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_st
   // sampling rounds, then ONE pass that links the remaining out-edges of EVERY vertex (a link whose two ends already
   // share a root costs two loads).  That is a single sweep over the edges instead of Shiloach-Vishkin's ~5 (RMAT-24:
   // 21.9 ms); GDN_CC_SV=1 keeps the SV rounds (the reference's src/cc/omp_base.cc algorithm) for comparison.
-  if (gin != nullptr || !getenv("GDN_CC_SV")) return cc_afforest(g, gin, d_comp, stats);
+  if (gin != nullptr || !gdn_option("GDN_CC_SV")) return cc_afforest(g, gin, d_comp, stats);
   const int32_t m = g->m;
   gdn_stats st;
   memset(&st, 0, sizeof(st));

@@ -52,6 +52,8 @@ void gdn_set_error(const char *fmt, ...);
   } while (0)
 
 int gdn_require_device();
+// value of a library option: the environment variable `name` if set, else what gdn_option_set stored, else nullptr
+const char *gdn_option(const char *name);
 
 // RAII device buffer (solver-private scratch)
 template <typename T>

@@ -4,11 +4,30 @@
 // solver (src/bfs/linear_base.cu:42-51, src/pr/base.cu:83-99) with an explicit handle, so
 // iterations can be timed with the graph resident (SURVEY 8b "resident-graph variant").
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "gdn_common.hpp"
 
 static thread_local char g_err[512] = "";
+
+// ---- options: every tuning / test knob of the library ("GDN_...") is an OPTION that a caller sets through the API
+// (gdn_option_set) and the environment variable of the same name OVERRIDES (so measurements and tests can flip a knob
+// without touching the caller).  Values are strings, parsed where they are used, exactly like the environment's.
+#include <map>
+#include <mutex>
+static std::mutex g_opt_mu;
+static std::map<std::string, std::string> &gdn_opt_map() {
+  static std::map<std::string, std::string> m;
+  return m;
+}
+const char *gdn_option(const char *name) {
+  if (const char *e = getenv(name)) return e;
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  auto &m = gdn_opt_map();
+  auto it = m.find(name);
+  return it == m.end() ? nullptr : it->second.c_str();  // (the string lives until the option is set again)
+}
 
 void gdn_set_error(const char *fmt, ...) {
   va_list ap;
@@ -209,6 +228,24 @@ int gdn_graph_pad_cols(gdn_graph *s, int32_t world, const int32_t *bounds, int32
 extern "C" {
 
 const char *gdn_last_error(void) { return g_err; }
+
+int gdn_option_set(const char *name, const char *value) {
+  GDN_REQUIRE(name != nullptr && strncmp(name, "GDN_", 4) == 0, "option names start with GDN_");
+  std::lock_guard<std::mutex> lk(g_opt_mu);
+  if (value) gdn_opt_map()[name] = value;
+  else gdn_opt_map().erase(name);
+  return GDN_OK;
+}
+
+int gdn_option_get(const char *name, char *value, int32_t capacity) {
+  GDN_REQUIRE(name != nullptr && value != nullptr && capacity > 0, "name / value");
+  const char *v = gdn_option(name);
+  value[0] = 0;
+  if (!v) return GDN_OK;
+  strncpy(value, v, (size_t)capacity - 1);
+  value[capacity - 1] = 0;
+  return GDN_OK;
+}
 
 int gdn_device_count(int *count) {
   GDN_REQUIRE(count != nullptr, "count");

@@ -349,7 +349,7 @@ int multi_setup(Shared &S, int32_t m, const uint64_t *rowptr, int32_t ngpus, con
   // XxxSolver(Graph&, ...) wrappers; two ranks on one device is how a 1-GPU box runs the path)
   std::vector<int32_t> envdev;
   if (!devices)
-    if (const char *e = getenv("GDN_MULTI_DEVICES")) {
+    if (const char *e = gdn_option("GDN_MULTI_DEVICES")) {
       for (const char *c = e; *c;) {
         envdev.push_back((int32_t)strtol(c, const_cast<char **>(&c), 10));
         while (*c == ',' || *c == ' ') c++;
@@ -382,7 +382,7 @@ int multi_setup(Shared &S, int32_t m, const uint64_t *rowptr, int32_t ngpus, con
   S.t_h2d.assign((size_t)n, 0.0);
   S.t_prep.assign((size_t)n, 0.0);
   S.use_rccl = false;
-  const char *ex_env = getenv("GDN_MULTI_EXCHANGE");
+  const char *ex_env = gdn_option("GDN_MULTI_EXCHANGE");
   // GDN_MULTI_EXCHANGE=rccl takes the RCCL path even for one rank (a 1-GPU box then drives librccl: dlopen, communicator,
   // the in-place all-gather call)
   if (want_exchange && (n > 1 || (ex_env && ex_env[0] == 'r'))) {

@@ -261,7 +261,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   GDN_REQUIRE(layout != GDN_LAYOUT_PB_SQUISHED || (row_base == 0 && in_csr->m == m_global),
               "GDN_LAYOUT_PB_SQUISHED: whole graphs only (row_base 0, m_local == m_global)");
   if (layout == GDN_LAYOUT_AUTO) {
-    const char *env = getenv("GDN_PR_LAYOUT");
+    const char *env = gdn_option("GDN_PR_LAYOUT");
     if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
     else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
     else layout = in_csr->nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
@@ -330,30 +330,30 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
     int slices_log = in_csr->m == m_global ? 9 : 10;
-    if (const char *e = getenv("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    if (const char *e = gdn_option("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
     int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK, slices_log), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN, slices_log);
-    if (const char *e = getenv("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
-    if (const char *e = getenv("GDN_PB_LOG_BIN")) lb = atoi(e);
+    if (const char *e = gdn_option("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
+    if (const char *e = gdn_option("GDN_PB_LOG_BIN")) lb = atoi(e);
     // vertex compaction on by default (GDN_PB_COMPACT=0 switches it off for A/B measurements)
-    const char *ce = getenv("GDN_PB_COMPACT");
+    const char *ce = gdn_option("GDN_PB_COMPACT");
     // tiles padded to 32 edges = whole 128-byte lines of vals (a line shared by two tiles is written by two
     // workgroups at different times: measured 3.9 -> 3.0 ms for phase A on RMAT-27), one G entry per 32 edges
     unsigned pad = 32;
     int lg = 5;
-    if (const char *e = getenv("GDN_PB_PAD")) pad = (unsigned)atoi(e);
-    if (const char *e = getenv("GDN_PB_LOG_GROUP")) lg = atoi(e);
+    if (const char *e = gdn_option("GDN_PB_PAD")) pad = (unsigned)atoi(e);
+    if (const char *e = gdn_option("GDN_PB_LOG_GROUP")) lg = atoi(e);
     const bool compact = !(ce && ce[0] == '0');
     // 8-bit delta-coded rows (PbPlan::v8) are OFF by default: they save 0.94 B/edge of phase B's reads but the decode
     // (3 DPP steps + unpack per quad) cost more than that on RMAT-27 (B 3.0 -> 3.5 ms); GDN_PB_V8=1 builds them
-    const char *ve = getenv("GDN_PB_V8");
+    const char *ve = gdn_option("GDN_PB_V8");
     const bool v_delta = pad >= 32 && ve && ve[0] == '1';
     DevBuf<uint8_t> cls;
     PbScratch scratch;  // the key buffers of the (up to four) layout builds below
-    const char *he = getenv("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
+    const char *he = gdn_option("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
     st = GDN_OK;
     uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
-    if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
-    const char *me = getenv("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    if (const char *e = gdn_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    const char *me = gdn_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
     int max_mid = me ? atoi(me) : PB_MAX_MID;
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
@@ -366,7 +366,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     DevBuf<uint8_t> dcls;
     // OFF by default (GDN_PB_HUB_ROWS=1 builds it): it takes 1.1 GB out of an iteration (phase B -0.2 ms) but phase A
     // pays the same back -- any wave of a CU that folds instead of streaming lowers the CU's bytes in flight
-    const char *re = getenv("GDN_PB_HUB_ROWS");
+    const char *re = gdn_option("GDN_PB_HUB_ROWS");
     const unsigned lds_static = 8704;             // s_bits + s_pref + s_scr of pb_expand_kernel, rounded up
     unsigned slots_assumed = 1u << lc;
     if (st == GDN_OK && compact && lc == PB_MAX_LOG_CHUNK && in_csr->nnz >= hub_min_nnz && re && re[0] == '1') {
@@ -730,7 +730,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
     static unsigned split = 0;
     if (split == 0) {
-      const char *e = getenv("GDN_PB_SPLIT");
+      const char *e = gdn_option("GDN_PB_SPLIT");
       split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
       if (split < 1 || split > 64) split = 1;
     }
@@ -751,7 +751,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                        pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
-                       getenv("GDN_PB_AVAR") ? atoi(getenv("GDN_PB_AVAR")) : 0,
+                       gdn_option("GDN_PB_AVAR") ? atoi(gdn_option("GDN_PB_AVAR")) : 0,
 #else
                        0,
 #endif
@@ -781,7 +781,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     mid.form[mid.n++] = 0;
   }
 #ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)
-  if (const char *e = getenv("GDN_PB_MIDVAR"))
+  if (const char *e = gdn_option("GDN_PB_MIDVAR"))
     for (int t = 0; t < mid.n; t++) mid.form[t] = (atoi(e) >> t) & 1;
 #endif
   // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
@@ -793,7 +793,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        pb.log_bin, pb.bin_ptr.p, whole ? pb.bin_order.p : nullptr, pb.V.p, pb.vals.p, pb.partial.p,
                        pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
-                       getenv("GDN_PB_DBG") ? atoi(getenv("GDN_PB_DBG")) : 0,
+                       gdn_option("GDN_PB_DBG") ? atoi(gdn_option("GDN_PB_DBG")) : 0,
 #else
                        0,
 #endif
@@ -952,7 +952,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     // the PB layout works on the live vertices only (GDN_LAYOUT_PB_SQUISHED; GDN_PR_SQUISH=0: the caller's vertex space)
     int32_t layout = GDN_LAYOUT_AUTO;
     {
-      const char *env = getenv("GDN_PR_LAYOUT"), *sq = getenv("GDN_PR_SQUISH");
+      const char *env = gdn_option("GDN_PR_LAYOUT"), *sq = gdn_option("GDN_PR_SQUISH");
       const bool pb = (env && env[0] == 'p') || (!(env && env[0] == 'c') && nnz >= (1ull << 22));
       if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
     }

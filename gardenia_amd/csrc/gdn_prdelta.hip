@@ -210,7 +210,7 @@ int gdn_pr_delta_plan_create(const gdn_graph *in_csr, const gdn_graph *out_csr, 
   int rc = GDN_OK;
   do {
     if (layout == GDN_LAYOUT_AUTO) {
-      const char *env = getenv("GDN_PRD_LAYOUT");  // test knob: 'p' / 'c' force the layout of the pull's plan
+      const char *env = gdn_option("GDN_PRD_LAYOUT");  // test knob: 'p' / 'c' force the layout of the pull's plan
       if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
       else if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
       else layout = nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
@@ -274,7 +274,7 @@ int gdn_pr_delta_run(gdn_pr_delta_plan *plan, float *d_scores, float damping, do
   long long nitems = m;
   unsigned long long fedges = p.gin->nnz;  // out-edges of the frontier
   unsigned long long heavy_div = 64;
-  if (const char *e = getenv("GDN_PRD_PUSH_DIV")) heavy_div = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;
+  if (const char *e = gdn_option("GDN_PRD_PUSH_DIV")) heavy_div = strtoull(e, nullptr, 10) ? strtoull(e, nullptr, 10) : 1;
   int iter = 0;
   uint64_t pull_iters = 0;
   PrdCounters h;

@@ -200,7 +200,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
   GDN_REQUIRE(n_cols >= 1, "n_cols");
   GDN_REQUIRE(layout == GDN_LAYOUT_CSR || layout == GDN_LAYOUT_PB || layout == GDN_LAYOUT_AUTO, "layout");
   if (layout == GDN_LAYOUT_AUTO) {
-    const char *env = getenv("GDN_SPMV_LAYOUT");
+    const char *env = gdn_option("GDN_SPMV_LAYOUT");
     if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
     else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
     else layout = (d_Ax != nullptr && csr->nnz >= (1ull << 22)) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
@@ -220,17 +220,17 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     // compacted like PageRank's layout (columns that occur / rows that have entries), rows of whole 128-byte lines;
     // GDN_PB_COMPACT=0 / GDN_PB_HUBS=0 switch the two refinements off (A/B measurements)
     int slices_log = csr->m == n_cols ? 9 : 10;
-    if (const char *e = getenv("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    if (const char *e = gdn_option("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
     const int lc = spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK, slices_log), lb = spmv_pick_log(csr->m, PB_MAX_LOG_BIN, slices_log);
-    const char *ce = getenv("GDN_PB_COMPACT"), *he = getenv("GDN_PB_HUBS"), *ve = getenv("GDN_PB_V8");
+    const char *ce = gdn_option("GDN_PB_COMPACT"), *he = gdn_option("GDN_PB_HUBS"), *ve = gdn_option("GDN_PB_V8");
     const bool compact = !(ce && ce[0] == '0');
     const bool v_delta = ve && ve[0] == '1';  // off by default, see gdn_pr.hip
     uint64_t hub_min_nnz = 1ull << 24;
-    if (const char *e = getenv("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    if (const char *e = gdn_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     DevBuf<uint8_t> cls;
     PbScratch scratch;  // the key buffers of the layout builds below
     st = GDN_OK;
-    const char *me = getenv("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    const char *me = gdn_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
     int max_mid = me ? atoi(me) : PB_MAX_MID;
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];

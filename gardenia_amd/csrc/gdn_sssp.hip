@@ -1064,13 +1064,13 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
   if (dense && g->nnz > 0) {
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
-    if (const char *e = getenv("GDN_SSSP_LOG")) lg = atoi(e) >= 10 && atoi(e) <= 15 ? atoi(e) : lg;  // tuning knob
+    if (const char *e = gdn_option("GDN_SSSP_LOG")) lg = atoi(e) >= 10 && atoi(e) <= 15 ? atoi(e) : lg;  // tuning knob
     // tiles padded so that a tile's candidates are whole 128-byte lines (a line shared by two tiles is written by two
     // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
     // would cost more than the partial lines
     const double avg_tile = (double)g->nnz / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lg) + 1));
     unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 512.0 ? 64u : 32u;
-    if (const char *e = getenv("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
+    if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
     GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
                      /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3));
     GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
@@ -1090,7 +1090,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       GDN_HIP(hipMemcpy(h, rng.p, 8, hipMemcpyDeviceToHost));
       p.w_min = h[0];
       p.w_max = h[1];
-      const char *e = getenv("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
+      const char *e = gdn_option("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
       const int force = e ? atoi(e) : -1;
       const size_t n = (size_t)p.pb.n_pad;
       if (p.w_min < 0) p.w_bytes = 4;  // negative weights: not narrowed (the solvers assume none, like the reference)
@@ -1194,7 +1194,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   big.capacity = p.bigcap;
   const unsigned cap = p.cap;
   auto clamp = [](int64_t x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
-  const bool trace = getenv("GDN_SSSP_TRACE") != nullptr;  // per-phase log on stderr (tools/)
+  const bool trace = gdn_option("GDN_SSSP_TRACE") != nullptr;  // per-phase log on stderr (tools/)
   auto wall_us = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
   double t_prev = 0;
   if (trace) {
@@ -1206,15 +1206,15 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   // rows improve per sweep (tuning knobs)
   bool pre_dense_done = false;
   unsigned long long dense_pre = 192;  // = dense_in x the growth of a frontier per pass this early (GDN_SSSP_DENSE_PRE)
-  if (const char *e = getenv("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
+  if (const char *e = gdn_option("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
   unsigned long long dense_in = 24, dense_out = 16;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 takes 7.2 / 9.2 ms to 6.2 / 7.5 ms
-  if (const char *e = getenv("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
-  if (const char *e = getenv("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
+  if (const char *e = gdn_option("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
+  if (const char *e = gdn_option("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
   // light phases run inside ONE workgroup (sssp_small_kernel); GDN_SSSP_SMALL=0 keeps every phase on the host loop, =2
   // forces every phase into it that fits the lists (tests)
   unsigned small_v = SSSP_SMALL_V, small_far = SSSP_SMALL_FAR;
   unsigned long long small_e = SSSP_SMALL_E;
-  if (const char *e = getenv("GDN_SSSP_SMALL")) {
+  if (const char *e = gdn_option("GDN_SSSP_SMALL")) {
     if (atoi(e) == 0) small_v = 0;
     else if (atoi(e) == 2) {
       small_v = cap;
@@ -1226,7 +1226,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   // "high diameter" (GDN_SSSP_COOP=0: never, =1: from the first such phase -- tests)
   unsigned coop_v = 65536, coop_far = 1u << 22, coop_streak = 8, light_streak = 0;
   unsigned long long coop_e = 1ull << 20;
-  if (const char *e = getenv("GDN_SSSP_COOP")) {
+  if (const char *e = gdn_option("GDN_SSSP_COOP")) {
     if (atoi(e) == 0) coop_v = 0;
     else coop_streak = 0;
   }
@@ -1348,7 +1348,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
           // 8- / 16-bit candidates while every finite candidate (a finite distance + a weight) stays below 0xFF / 0xFFFF
           // (GDN_SSSP_CAND32 / GDN_SSSP_CAND16: test knobs that keep the wider form)
           const int64_t bound = (int64_t)max_finite + (int64_t)p.w_max;
-          const int cbits = getenv("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !getenv("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
+          const int cbits = gdn_option("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !gdn_option("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
           // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
           // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
           // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
@@ -1418,7 +1418,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       // after the other by the few waves of such a pass they cost 0.4 ms on RMAT-24; gdn_bfs.hip does the same)
       big.min_deg = ((uint64_t)n_near < 65536u && (uint64_t)n_near + near_edges / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
                         ? 64u : (unsigned)EXP_BIG;  // (on a 228 K-vertex list the item detour cost 0.42 ms instead of 0.28)
-      if (const char *e = getenv("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
+      if (const char *e = gdn_option("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
       hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near)), dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
                          n_near, clamp(thr_lo), big, vis);
       hipLaunchKernelGGL(sssp_relax_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);

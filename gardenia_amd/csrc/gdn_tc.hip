@@ -533,7 +533,7 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
   gdn_graph *dag_in = nullptr;
   int rc = tc_probe_counts(dag, probes);
   if (rc == GDN_OK) {
-    const char *e = getenv("GDN_TC_FORM");
+    const char *e = gdn_option("GDN_TC_FORM");
     const bool vform = e ? e[0] == 'v' : (double)probes[1] < 0.85 * (double)probes[0];
     if (vform && dag->nnz) rc = gdn_graph_transpose(dag, &dag_in);
   }

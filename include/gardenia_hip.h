@@ -52,6 +52,14 @@ typedef struct gdn_stats {
 } gdn_stats;
 
 const char *gdn_last_error(void);
+/* Library options.  Every tuning knob (layout choices, thresholds of the level / bucket / sweep choosers, test switches:
+ * GDN_PR_LAYOUT, GDN_SSSP_DENSE_IN, GDN_BFS_COOP, GDN_TC_FORM, GDN_MULTI_EXCHANGE ...; DESIGN.md names them where they
+ * act) is an option a caller sets here, process wide, before creating the plan or calling the solver it concerns
+ * (value NULL = unset).  The environment variable of the same name OVERRIDES the stored value, so that a measurement or a
+ * test can flip a knob without touching the caller.  Names start with "GDN_"; values are the strings the environment
+ * would carry.  gdn_option_get copies the effective value ("" when unset). */
+int gdn_option_set(const char *name, const char *value);
+int gdn_option_get(const char *name, char *value, int32_t capacity);
 int gdn_device_count(int *count);
 int gdn_set_device(int device);
 

@@ -56,3 +56,19 @@ def test_invalid_arguments_are_reported_not_fatal():
     assert L.gdn_bfs(0, 0, None, None, None, None, 0, None, C.byref(st)) == _cabi.GDN_ERR_INVALID
     assert b"invalid argument" in L.gdn_last_error()
     assert L.gdn_pr(4, 0, None, None, None, None, 0.85, 1e-4, 100, None) == _cabi.GDN_ERR_INVALID
+
+
+def test_options_api_roundtrip_and_environment_override(monkeypatch):
+    """Every GDN_* knob is an option set through the API; the environment variable of the same name overrides it."""
+    L = _cabi.lib()
+    buf = C.create_string_buffer(64)
+    monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+    assert L.gdn_option_get(b"GDN_PR_LAYOUT", buf, 64) == _cabi.GDN_OK and buf.value == b""
+    assert L.gdn_option_set(b"GDN_PR_LAYOUT", b"csr") == _cabi.GDN_OK
+    assert L.gdn_option_get(b"GDN_PR_LAYOUT", buf, 64) == _cabi.GDN_OK and buf.value == b"csr"
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    assert L.gdn_option_get(b"GDN_PR_LAYOUT", buf, 64) == _cabi.GDN_OK and buf.value == b"pb"
+    monkeypatch.delenv("GDN_PR_LAYOUT")
+    assert L.gdn_option_set(b"GDN_PR_LAYOUT", None) == _cabi.GDN_OK
+    assert L.gdn_option_get(b"GDN_PR_LAYOUT", buf, 64) == _cabi.GDN_OK and buf.value == b""
+    assert L.gdn_option_set(b"PATH", b"x") == _cabi.GDN_ERR_INVALID

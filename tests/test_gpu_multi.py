@@ -182,3 +182,29 @@ def test_spmv_main_on_two_ranks(tmp_path):
     p = subprocess.run([exe, "bin", str(tmp_path / "rm"), "0", "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
                        timeout=300, env=dict(os.environ, GDN_NUM_GPUS="3", GDN_MULTI_DEVICES="0,0,0"))
     assert p.returncode == 0 and "Correct" in p.stdout, p.stdout[-800:]
+
+
+def test_option_set_through_the_api_picks_the_layout(monkeypatch):
+    """gdn_option_set("GDN_PR_LAYOUT", ...) steers the AUTO layout of a plan like the environment variable does."""
+    monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+    L = _cabi.lib()
+    g = graphio.transpose(graphio.rmat_graph(14, 16, seed=3))
+    rp, ci = np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32)
+    h, d_deg = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), C.byref(h)))
+    _cabi.check(L.gdn_dev_alloc(4 * g.m, C.byref(d_deg)))
+    _cabi.check(L.gdn_graph_degrees_dev(h, d_deg, None))
+    got = {}
+    try:
+        for val in (None, b"pb", b"csr"):
+            _cabi.check(L.gdn_option_set(b"GDN_PR_LAYOUT", val))
+            plan, lay = C.c_void_p(), C.c_int32(-9)
+            _cabi.check(L.gdn_pr_plan_create(h, d_deg, g.m, 0, _cabi.GDN_LAYOUT_AUTO, C.byref(plan)))
+            _cabi.check(L.gdn_pr_plan_layout(plan, C.byref(lay), None))
+            L.gdn_pr_plan_free(plan)
+            got[val] = lay.value
+    finally:
+        L.gdn_option_set(b"GDN_PR_LAYOUT", None)
+        L.gdn_dev_free(d_deg)
+        L.gdn_graph_free(h)
+    assert got == {None: _cabi.GDN_LAYOUT_CSR, b"pb": _cabi.GDN_LAYOUT_PB, b"csr": _cabi.GDN_LAYOUT_CSR}  # 262 K edges: CSR by size
