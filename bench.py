@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line: metric value = whole-job edges/s; "roofline" = algo
 HBM peak; "cpu_baseline" = the CPU oracle's OpenMP pull iteration on a bounded row sample of the same graph.  At N=1 the
 line also carries, measured OUTSIDE the PageRank timed region on the same box: "bfs" (GTEPS + bytes/roofline on the same
 graph), "spmv" (BASELINE config 3: fp32 SpMV on RMAT-25, resident plan and the one-shot drop-in) and "tc" (config 4's
-stand-in: triangle count on symmetrized RMAT-23, Orkut-sized) -- each with median + min over >= 10 repetitions.
+stand-in: triangle count on symmetrized RMAT-23, Orkut-sized) and "traversal" (SSSP unit / U[1,255] weights and CC on
+RMAT-24) -- each with median + min over >= 10 repetitions.
 """
 import argparse
 import ctypes as C
@@ -91,6 +92,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the SpMV (RMAT-25) and TC (RMAT-23) blocks")
     ap.add_argument("--spmv-scale", type=int, default=25)
     ap.add_argument("--tc-scale", type=int, default=23)
+    ap.add_argument("--trav-scale", type=int, default=24, help="R-MAT scale of the SSSP / CC block")
     ap.add_argument("--reps", type=int, default=12, help="repetitions behind every median / min")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
     args = ap.parse_args()
@@ -404,6 +406,10 @@ def main():
             out["tc"] = bench_tc(L, _cabi, graphio, torch, np, device, args)
         except Exception as e:
             log(f"[bench] tc block skipped: {e}")
+        try:
+            out["traversal"] = bench_traversal(L, _cabi, graphio, torch, np, device, args)
+        except Exception as e:
+            log(f"[bench] traversal block skipped: {e}")
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -523,6 +529,61 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
                         "model": "4 SUM_(u,v) (d+(u) + d+(v)) + 8 nnz_dag + 8(m+1) (SURVEY 8d, merge-equivalent)",
                         "kernel": "tc_count_kernel"}}
     log(f"[bench] tc: {rec}")
+    return rec
+
+
+def bench_traversal(L, _cabi, graphio, torch, np, device, args):
+    """SSSP (resident plan: dense sweeps + fused light phases) and CC on R-MAT-<trav-scale> x16, directed.  SSSP bytes =
+    the BFS model + 4 B of weight per reached edge: SUM_reached (16 + 12 outdeg) + 4 m; CC reports edges/s."""
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(args.trav_scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+    m, nnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), None, None))
+    m, nnz = m.value, nnz.value
+    deg = torch.empty(m, dtype=torch.int32, device=device)
+    _cabi.check(L.gdn_graph_degrees_dev(go, C.c_void_p(deg.data_ptr()), None))
+    src = int(torch.nonzero(deg[:1 << 16] > 0)[0].item())
+    dist = torch.empty(m, dtype=torch.int32, device=device)
+    reps = max(args.reps, 10)
+    rec = {"workload": "R-MAT scale %d avg degree 16, directed" % args.trav_scale, "vertices": m, "edges": nnz, "source": src}
+    gen = torch.Generator(device=device)
+    gen.manual_seed(5)
+    for name, w, delta in (("sssp_unit", torch.ones(nnz, dtype=torch.int32, device=device), 1),
+                           ("sssp_u1_255_delta16", torch.randint(1, 256, (nnz,), dtype=torch.int32, device=device, generator=gen), 16)):
+        plan = C.c_void_p()
+        t0 = time.time()
+        _cabi.check(L.gdn_sssp_plan_create(go, C.c_void_p(w.data_ptr()), 1, C.byref(plan)))
+        t_plan = time.time() - t0
+        ms = []
+        for i in range(reps + 1):
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_sssp_run(plan, src, delta, C.c_void_p(dist.data_ptr()), C.byref(st)))
+            if i:
+                ms.append(st.solve_ms)
+        L.gdn_sssp_plan_free(plan)
+        reached = int((dist != 2147483647).sum().item())
+        b = 16 * reached + 12 * st.edges_traversed + 4 * m
+        mm = med_min(ms)
+        rec[name] = {"ms": mm, "phases": st.iterations, "edges_traversed": st.edges_traversed, "plan_build_s": t_plan,
+                     "gteps": st.edges_traversed / (mm["median"] * 1e-3) / 1e9,
+                     "roofline": {"bound": "hbm", "achieved": b / (mm["median"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": b / (mm["median"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": b,
+                                  "model": "SUM_reached (16 + 12 outdeg) + 4 m (SURVEY 8d: BFS bytes + 4 B weight per edge)"}}
+        del w
+    comp = torch.empty(m, dtype=torch.int32, device=device)
+    for name, rev in (("cc_with_reverse_graph", gi), ("cc_out_edges_only", None)):
+        ms = []
+        for i in range(reps + 1):
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_cc_dev(go, rev, C.c_void_p(comp.data_ptr()), C.byref(st)))
+            if i:
+                ms.append(st.solve_ms)
+        mm = med_min(ms)
+        rec[name] = {"ms": mm, "passes": st.iterations, "edges_per_s": nnz / (mm["median"] * 1e-3),
+                     "components": int((comp == torch.arange(m, dtype=torch.int32, device=device)).sum().item())}
+    L.gdn_graph_free(go)
+    L.gdn_graph_free(gi)
+    log(f"[bench] traversal: {rec}")
     return rec
 
 

@@ -80,7 +80,7 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     """BASELINE configs 3 and 4 and the BFS block ride on the N = 1 line (small scales here): ms median + min over >= 10
     repetitions, GB/s against SURVEY 8d's bytes, the one-shot drop-in next to the resident plan."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "3", "--warmup", "1", "--no-cpu",
-           "--spmv-scale", "20", "--tc-scale", "16"]
+           "--spmv-scale", "20", "--tc-scale", "16", "--trav-scale", "18"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -93,3 +93,7 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     tc = r["tc"]
     assert tc["ms"]["n"] >= 10 and tc["triangles"] > 0 and 0 < tc["roofline"]["frac"] < 1
     assert tc["roofline"]["algorithmic_bytes_per_launch"] > 8 * tc["dag_edges"]
+    tr = r["traversal"]
+    for k in ("sssp_unit", "sssp_u1_255_delta16"):
+        assert tr[k]["ms"]["n"] >= 10 and tr[k]["edges_traversed"] > 0 and 0 < tr[k]["roofline"]["frac"] < 1
+    assert tr["cc_with_reverse_graph"]["components"] == tr["cc_out_edges_only"]["components"] > 0
