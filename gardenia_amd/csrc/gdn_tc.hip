@@ -83,42 +83,93 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 static_assert((1 << TC_HASH_BITS) == TC_HASH, "TC_CAP must be 128, 256, 512 or 1024");
 __device__ __forceinline__ unsigned tc_hash(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - TC_HASH_BITS); }
 
-// membership of w in the staged part of N+(u): LDS hash set, expected ~1.3 probes
+// membership of w in the staged part of N+(u): LDS hash set of 4-slot BUCKETS (TC_HASH / 4 of them), a bucket is one
+// aligned 16-byte LDS read.  Keys go into the first free slot of their bucket (slots fill in order, so "slot 3 taken" =
+// "bucket full") and spill into the next bucket only then: at the usual loads (a few hundred ids in 2048 slots) 99.7 % of
+// the lookups -- hits and misses -- are settled by ONE read and four compares.  With one slot per probe and linear
+// probing every wave instruction had some lane that needed a second and third dependent LDS round trip inside a
+// divergent loop (a slot is taken with probability = the load factor, and 64 lanes probe at once): those loops and their
+// exec-mask bookkeeping were most of the 53 VALU + 43 SALU instructions per 64 probes (profiles/r02_tc_pmc.md).
+typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
+#define TC_BUCKETS (TC_HASH / 4)
+// (a 24-bit multiply -- v_mul_u32_u24 is full rate where v_mul_lo_u32 is quarter rate -- of the id folded onto itself was
+// measured: 3 % SLOWER on RMAT-21 / 23, it spreads the ids less evenly over the buckets)
+__device__ __forceinline__ unsigned tc_bucket(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - (TC_HASH_BITS - 2)); }
+
 struct TcSet {
-  const vid_t *table;
-  __device__ __forceinline__ unsigned slow(vid_t w, unsigned h) const {  // continue a probe sequence that collided
-    for (;;) {
-      h = (h + 1) & (TC_HASH - 1);
-      const vid_t x = table[h];
-      if (x == w) return 1u;
-      if (x == TC_EMPTY) return 0u;
-    }
-  }
-  // N candidates at once: the first probes are independent LDS reads (in flight together)
+  const vid_t *table;  // 16-byte aligned
+  // N candidates at once: the N bucket reads are independent (in flight together); the rare spill-over is followed for
+  // all of them together, one bucket per wave-uniform round.  `vm[r]` = ballot of the lanes whose candidate r is real.
+  // All the bookkeeping -- hit counts, pending sets -- is done on the 64-bit lane masks, i.e. on the scalar unit: the
+  // count is a wave total anyway (the caller adds the return value ONCE per wave, not per lane), and flags kept as 0/1
+  // values in vector registers were a third of the loop's VALU instructions.
   template <int N>
-  __device__ __forceinline__ unsigned count(const vid_t (&w)[N], const bool (&valid)[N]) const {
+  __device__ __forceinline__ unsigned count(const vid_t (&w)[N], const unsigned long long (&vm)[N]) const {
     unsigned c = 0;
-    unsigned h[N];
-    vid_t x[N];
+    unsigned hb[N];
+    tc_i32x4 b[N];
+    unsigned long long pend[N];
 #pragma unroll
     for (int r = 0; r < N; r++) {
-      h[r] = tc_hash(w[r]);
-      x[r] = table[h[r]];
+      hb[r] = tc_bucket(w[r]);
+      b[r] = *reinterpret_cast<const tc_i32x4 *>(table + 4u * hb[r]);
     }
+    unsigned long long any = 0ull;
 #pragma unroll
     for (int r = 0; r < N; r++) {
-      if (!valid[r]) continue;
-      if (x[r] == w[r]) c++;
-      else if (x[r] != TC_EMPTY) c += slow(w[r], h[r]);
+      const unsigned long long hit = __ballot((b[r].x == w[r]) | (b[r].y == w[r]) | (b[r].z == w[r]) | (b[r].w == w[r])) & vm[r];
+      c += (unsigned)__popcll(hit);
+      pend[r] = __ballot(b[r].w != TC_EMPTY) & vm[r] & ~hit;  // bucket full and not found: look in the next one
+      any |= pend[r];
     }
-    return c;
+    while (any) {
+      any = 0ull;
+#pragma unroll
+      for (int r = 0; r < N; r++) {
+        if (pend[r]) {  // uniform
+          hb[r] = (hb[r] + 1u) & (TC_BUCKETS - 1);
+          b[r] = *reinterpret_cast<const tc_i32x4 *>(table + 4u * hb[r]);
+          const unsigned long long hit = __ballot((b[r].x == w[r]) | (b[r].y == w[r]) | (b[r].z == w[r]) | (b[r].w == w[r])) & pend[r];
+          c += (unsigned)__popcll(hit);
+          pend[r] = __ballot(b[r].w != TC_EMPTY) & pend[r] & ~hit;
+          any |= pend[r];
+        }
+      }
+    }
+    return c;  // wave total (the same in every lane)
   }
 };
+
+// insert / remove one key (each lane its own; keys of one list are distinct)
+__device__ __forceinline__ void tc_insert(vid_t *tab, vid_t x) {
+  unsigned h = tc_bucket(x);
+  for (;;) {
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++)
+      if (atomicCAS(&tab[4u * h + sl], TC_EMPTY, x) == TC_EMPTY) return;
+    h = (h + 1u) & (TC_BUCKETS - 1);
+  }
+}
+__device__ __forceinline__ void tc_remove(vid_t *tab, vid_t x) {
+  unsigned h = tc_bucket(x);
+  for (;;) {  // x is there until THIS lane removes it: a bucket that does not hold it was full when x arrived
+#pragma unroll
+    for (int sl = 0; sl < 4; sl++)
+      if (tab[4u * h + sl] == x) {
+        tab[4u * h + sl] = TC_EMPTY;
+        return;
+      }
+    h = (h + 1u) & (TC_BUCKETS - 1);
+  }
+}
 
 // neighbour-list elements per lane in flight: the kernel is latency bound (67 % of its wave cycles were spent in
 // s_waitcnt with one element per lane, profiles/r01_tc_pmc.md)
 #ifndef TC_UNR
-#define TC_UNR 8
+#define TC_UNR 4  // chunks per step; two steps are in flight (measured on RMAT-21 / 23: 4 and 8 alike, 16 spills: 3x slower)
+#endif
+#ifndef TC_LONG
+#define TC_LONG 48  // lists at least this long are walked in 64-element chunks, shorter ones packed
 #endif
 #ifndef TC_WAVES_PER_EU
 #define TC_WAVES_PER_EU 4  // LDS allows 4 workgroups per CU; measured: 8 waves/SIMD with 4 KB sets is slower
@@ -134,28 +185,56 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
   const unsigned lane = gdn_lane();
   unsigned long long count = 0;
   unsigned deg = (unsigned)(ve - vb);
-  {  // lists of a wave's width or more: one list at a time, 64 * TC_UNR consecutive elements per step
-    unsigned long long mask = __ballot(deg >= 64u);
-    while (mask) {
-      const int leader = __ffsll((long long)mask) - 1;
-      mask &= mask - 1ull;
-      const eoff_t bb = __shfl(vb, leader, 64);
-      const eoff_t ee = __shfl(ve, leader, 64);
-      for (eoff_t k0 = bb; k0 < ee; k0 += 64 * TC_UNR) {
-        vid_t w[TC_UNR];
-        bool valid[TC_UNR];
+  {  // Lists of TC_LONG elements or more, cut into 64-element CHUNKS; the chunks of all of them form one stream that is
+     // walked TC_UNR chunks per step, with the NEXT step's loads issued before this step's probes (two steps in flight per
+     // wave).  Walking one list at a time in 512-slot steps left 45-60 % of the slots empty (the lists of a degree-ordered
+     // DAG are 100-1000 long) and made every step pay a full memory round trip on its own: the count was bound by that
+     // latency at 32 KB in flight per CU (profiles/r02_tc_pmc.md).  A chunk's list is wave-uniform: one ballot finds it,
+     // its base pointer is scalar, positions are 32-bit offsets, loads are unpredicated (a position past the end reads the
+     // list's last element and is masked in `valid`).
+    const unsigned nch = deg >= (unsigned)TC_LONG ? (deg + 63u) >> 6 : 0u;
+    const unsigned incl = gdn_wave_incl_scan(nch);
+    const unsigned total = __shfl(incl, 63, 64);
+    const unsigned excl = incl - nch;
+    const unsigned total_s = (unsigned)__builtin_amdgcn_readfirstlane((int)total);  // scalar copy: uniform branches
+    // the TC_UNR chunks from q0 on: every load is ISSUED (a chunk past the end re-reads the last chunk and gets an empty
+    // lane mask), so that the compiler can count the outstanding loads and wait for one step's only
+    auto load_step = [&](unsigned q0, vid_t (&w)[TC_UNR], unsigned long long (&vm)[TC_UNR]) {
 #pragma unroll
-        for (int r = 0; r < TC_UNR; r++) {
-          const eoff_t k = k0 + (eoff_t)(64 * r) + lane;
-          valid[r] = k < ee;
-          w[r] = valid[r] ? colidx[k] : 0;
-        }
-        count += set.count(w, valid);
+      for (int r = 0; r < TC_UNR; r++) {
+        const unsigned qr = q0 + (unsigned)r;                       // scalar
+        const unsigned q = qr < total_s ? qr : total_s - 1u;        // scalar
+        const unsigned long long m = __ballot(nch > 0u && excl <= q);  // the last lane that owns chunks and starts at or before q
+        const int owner = 63 - __clzll((long long)m);
+        const eoff_t ob = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(vb >> 32), owner) << 32) |
+                          (unsigned)__builtin_amdgcn_readlane((int)vb, owner);
+        const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)deg, owner);
+        const unsigned oex = (unsigned)__builtin_amdgcn_readlane((int)excl, owner);
+        const unsigned o = ((q - oex) << 6) + lane;
+        const bool ok = o < len;
+        vm[r] = qr < total_s ? __ballot(ok) : 0ull;
+        w[r] = (colidx + ob)[ok ? o : len - 1u];
       }
+    };
+    if (total_s) {
+      vid_t w0[TC_UNR], w1[TC_UNR];
+      unsigned long long m0[TC_UNR], m1[TC_UNR];
+      unsigned cw = 0;  // wave total
+      load_step(0u, w0, m0);
+      for (unsigned q0 = 0; q0 < total_s; q0 += 2 * TC_UNR) {
+        load_step(q0 + TC_UNR, w1, m1);
+        cw += set.count(w0, m0);
+        load_step(q0 + 2 * TC_UNR, w0, m0);
+        cw += set.count(w1, m1);
+      }
+      if (lane == 0) count += cw;
     }
-    if (deg >= 64u) deg = 0;
+    if (nch) deg = 0;
   }
   {  // shorter lists, packed
+#if defined(TC_ABL) && TC_ABL == 6  // timing-only ablation: no packed path
+    deg = 0;
+#endif
     const unsigned incl = gdn_wave_incl_scan(deg);
     const unsigned total = __shfl(incl, 63, 64);
     if (total) {
@@ -198,7 +277,11 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
           const unsigned oex = __shfl(excl, owner, 64);
           w[r] = valid[r] ? colidx[ob + (idx[r] - oex)] : 0;
         }
-        count += set.count(w, valid);
+        unsigned long long vmask[TC_UNR];
+#pragma unroll
+        for (int r = 0; r < TC_UNR; r++) vmask[r] = __ballot(valid[r]);
+        const unsigned cw = set.count(w, vmask);
+        if (lane == 0) count += cw;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -226,14 +309,16 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     vid_t x0 = 0;  // the first 64 ids of the pass: loaded once for the hash build and the clean-up
     if (lane < (unsigned)cn) x0 = colidx[cb + lane];
     for (int i = lane; i < cn; i += 64) {  // build: integer LDS CAS, linear probing
-      const vid_t x = i < 64 ? x0 : colidx[cb + i];
-      unsigned h = tc_hash(x);
-      while (atomicCAS(&s_tab[h], TC_EMPTY, x) != TC_EMPTY) h = (h + 1) & (TC_HASH - 1);
+      tc_insert(s_tab, i < 64 ? x0 : colidx[cb + i]);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if defined(TC_ABL) && TC_ABL == 5  // timing-only ablation: set build + clear only, no walk
+    for (eoff_t i0 = vlo; i0 < vlo; i0 += 64) {
+#else
     for (eoff_t i0 = vlo; i0 < vhi; i0 += 64) {
+#endif
       const eoff_t i = i0 + lane;
       eoff_t vb = 0, ve = 0;
       if (i < vhi) {
@@ -241,18 +326,19 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
         vb = rowptr[v];
         ve = rowptr[v + 1];
       }
+#if defined(TC_ABL) && TC_ABL == 7  // timing-only ablation: neighbour ids + bounds loaded, lists not walked
+      count += (unsigned long long)((ve - vb) & 1);
+#else
       count += tc_walk_lists(colidx, vb, ve, set, s_own);
+#endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < cn; i += 64) {  // clear only the slots that were used
-      const vid_t x = i < 64 ? x0 : colidx[cb + i];
-      unsigned h = tc_hash(x);
-      while (s_tab[h] != x) h = (h + 1) & (TC_HASH - 1);
-      s_tab[h] = TC_EMPTY;
+      tc_remove(s_tab, i < 64 ? x0 : colidx[cb + i]);
     }
-    // (the search above walks past emptied slots: every key is still present until ITS lane
-    // clears it, so all keys are found and the table is empty again afterwards)
+    // (a removal in progress leaves holes, but every key is still present until ITS lane removes it, and the search
+    // scans whole buckets: all keys are found and the table is empty again afterwards.  Holes never outlive the pass.)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -266,7 +352,7 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 #define TC_LIGHT 64
 #endif
 #ifndef TC_SLICE
-#define TC_SLICE 256
+#define TC_SLICE 512  // (256 -> 512: 2 % faster, fewer set rebuilds; 1024 the same)
 #endif
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -302,7 +388,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
                 unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
                 unsigned long long *__restrict__ total) {
-  __shared__ vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
+  __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane();
@@ -311,7 +397,11 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
   for (int i = lane; i < TC_HASH; i += 64) s_tab[w][i] = TC_EMPTY;
   for (int i = lane; i < 64 * TC_UNR; i += 64) s_own[w][i] = 0;
   // ---- heavy rows first (they are the long work items): one (row, slice) item per grab
+#if defined(TC_ABL) && TC_ABL == 4  // timing-only ablation: no heavy items
+  const unsigned n_items = 0;
+#else
   const unsigned n_items = *n_items_p;
+#endif
   for (;;) {
     unsigned it = 0;
     if (lane == 0) it = atomicAdd(&cursors[0], 1u);
@@ -330,6 +420,9 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     unsigned u0 = 0;
     if (lane == 0) u0 = atomicAdd(&cursors[1], 16u);
     u0 = __shfl(u0, 0, 64);
+#if defined(TC_ABL) && TC_ABL == 3  // timing-only ablation: no light rows
+    break;
+#endif
     if (u0 >= (unsigned)m) break;
     const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
     eoff_t rp = 0, np = 0;  // the 17 row offsets of the batch in one load (per array)
