@@ -15,6 +15,7 @@
 // second launch (fixed reduction trees: deterministic, within 1e-6 of the sequential sum).
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "gdn_expand.hpp"
@@ -96,11 +97,14 @@ bc_fwd_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BcFwdVis vi
 }
 
 // ---- fused light levels of the forward phase (cf. bfs_td_small_kernel, gdn_bfs.hip): ONE workgroup runs consecutive
-// levels while the frontier stays tiny -- a wave per frontier vertex, the level boundary is a __syncthreads() -- and
+// levels while the frontier stays small -- a lane per short row, a wave per longer one, the level boundary is a
+// __syncthreads() -- and
 // reports the tail of `order` after every level.  A level costs ~5 us here instead of two launches and a blocking read
 // back: every level of a high-diameter graph.  Path counts are integer atomics: the same bits in any order.
 #define BC_SMALL_THREADS 1024
 #define BC_SMALL_MAX_LEVELS 2048
+#define BC_SMALL_LANE_ROW 32  // rows up to this long: one lane each
+#define BC_SMALL_UNR 4
 struct BcSmallOut {
   unsigned levels;    // levels expanded here (0: the frontier handed in was too heavy, nothing was touched)
   unsigned overflow;
@@ -111,14 +115,20 @@ __global__ void __launch_bounds__(BC_SMALL_THREADS)
 bc_fwd_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t *__restrict__ depth,
                     int32_t *pc, vid_t *order, unsigned l0, unsigned nf, unsigned cap, int32_t level, unsigned max_nf,
                     unsigned long long max_scout, BcCounters *cnt, BcSmallOut *__restrict__ out) {
-  __shared__ unsigned s_tail, s_over;
+  __shared__ unsigned s_tail, s_over, s_nlong;
   __shared__ unsigned long long s_scout;
+  __shared__ vid_t s_long[BC_SMALL_THREADS];
+  // the level just discovered, with its rows' bounds (read for the scout count anyway): vertex and row pointers of the
+  // next level's lanes come from LDS instead of two dependent global reads
+  __shared__ vid_t s_qv[2][BC_SMALL_THREADS];
+  __shared__ eoff_t s_qb[2][BC_SMALL_THREADS], s_qe[2][BC_SMALL_THREADS];
   const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6, nwaves = BC_SMALL_THREADS / 64;
-  unsigned levels = 0, tail = l0 + nf;
+  unsigned levels = 0, tail = l0 + nf, par = 0;
   // out-edges of the frontier handed in: a heavy one goes back to the host untouched
   if (threadIdx.x == 0) {
     s_scout = 0ull;
     s_over = 0u;
+    s_nlong = 0u;
   }
   __syncthreads();
   {
@@ -140,43 +150,83 @@ bc_fwd_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__
     }
     __syncthreads();
     unsigned long long scout = 0;
-    for (unsigned i = wave; i < nf; i += nwaves) {
-      // values other waves of this workgroup wrote (queue entries, path counts summed by atomics): device-scope loads
-      const vid_t v = __hip_atomic_load(order + l0 + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int32_t ps = __hip_atomic_load(pc + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const eoff_t b = rowptr[v], e = rowptr[v + 1];
-      for (eoff_t k0 = b; k0 < e; k0 += 64) {
-        const eoff_t k = k0 + lane;
-        bool claim = false;
-        vid_t dst = 0;
-        if (k < e) {
-          dst = colidx[k];
-          int32_t d = depth[dst];  // a stale -1 is settled by the CAS
-          if (d == -1) {
-            const int32_t old = atomicCAS(&depth[dst], -1, level + 1);
-            claim = old == -1;
-            d = claim ? level + 1 : old;
-          }
-          if (d == level + 1) atomicAdd(&pc[dst], ps);  // src/bc/omp_base.cc:39-42
-        }
-        const unsigned long long mask = __ballot(claim);
-        if (mask) {
-          unsigned base = 0;
-          if (lane == 0) base = atomicAdd(&s_tail, (unsigned)__popcll(mask));
-          base = __shfl(base, 0, 64);
-          if (claim) {
-            scout += rowptr[dst + 1] - rowptr[dst];
-            const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
-            if (pos < cap) __hip_atomic_store(order + pos, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else s_over = 1u;
+    // one edge: discovery = CAS on depth, path counts = integer atomics (src/bc/omp_base.cc:39-42); a claimed vertex goes
+    // to the tail of `order`, one LDS atomic per wave step
+    auto visit = [&](bool valid, vid_t dst, int32_t ps) {
+      bool claim = false;
+      if (valid) {  // no read in front of the CAS: every memory round trip of a light level is on its critical path
+        const int32_t old = atomicCAS(&depth[dst], -1, level + 1);
+        claim = old == -1;
+        if (claim || old == level + 1) atomicAdd(&pc[dst], ps);
+      }
+      const unsigned long long mask = __ballot(claim);
+      if (mask) {
+        unsigned base = 0;
+        if (lane == 0) base = atomicAdd(&s_tail, (unsigned)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (claim) {
+          const eoff_t db = rowptr[dst], de = rowptr[dst + 1];
+          scout += de - db;
+          const unsigned pos = base + (unsigned)__popcll(mask & gdn_lanemask_lt());
+          if (pos < cap) __hip_atomic_store(order + pos, dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else s_over = 1u;
+          if (pos - tail < BC_SMALL_THREADS) {  // the next level finds its first entries (all, when it is small) here
+            s_qv[par ^ 1u][pos - tail] = dst;
+            s_qb[par ^ 1u][pos - tail] = db;
+            s_qe[par ^ 1u][pos - tail] = de;
           }
         }
       }
+    };
+    const bool from_lds = levels > 0 && nf <= BC_SMALL_THREADS;
+    for (unsigned c0 = 0; c0 < nf; c0 += BC_SMALL_THREADS) {
+      // values other waves of this workgroup wrote (queue entries, path counts summed by atomics): device-scope loads
+      eoff_t b = 0, e = 0;
+      int32_t ps = 0;
+      if (c0 + threadIdx.x < nf) {
+        vid_t v;
+        if (from_lds) {
+          v = s_qv[par][threadIdx.x];
+          b = s_qb[par][threadIdx.x];
+          e = s_qe[par][threadIdx.x];
+        } else {
+          v = __hip_atomic_load(order + l0 + c0 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          b = rowptr[v];
+          e = rowptr[v + 1];
+        }
+        ps = __hip_atomic_load(pc + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e - b > BC_SMALL_LANE_ROW) {
+          s_long[atomicAdd(&s_nlong, 1u)] = v;
+          e = b;
+        }
+      }
+      // short rows: a lane each, BC_SMALL_UNR edges of it in flight
+      for (eoff_t k0 = b; __any(k0 < e); k0 += BC_SMALL_UNR) {
+        vid_t dst[BC_SMALL_UNR];
+#pragma unroll
+        for (int r = 0; r < BC_SMALL_UNR; r++) dst[r] = k0 + r < e ? colidx[k0 + r] : -1;
+#pragma unroll
+        for (int r = 0; r < BC_SMALL_UNR; r++) visit(dst[r] >= 0, dst[r], ps);
+      }
+      __syncthreads();
+      // longer rows: a wave each
+      const unsigned nlong = s_nlong;
+      for (unsigned i = wave; i < nlong; i += nwaves) {
+        const vid_t v = s_long[i];
+        const int32_t pv = __hip_atomic_load(pc + v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const eoff_t bb = rowptr[v], ee = rowptr[v + 1];
+        for (eoff_t k0 = bb; k0 < ee; k0 += 64) {
+          const eoff_t k = k0 + lane;
+          visit(k < ee, k < ee ? colidx[k] : 0, pv);
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_nlong = 0u;
+      if (c0 + BC_SMALL_THREADS < nf) __syncthreads();
     }
     scout = gdn_wave_sum(scout);
     if (lane == 0 && scout) atomicAdd(&s_scout, scout);
-    __threadfence();
-    __syncthreads();
+    gdn_wg_level_sync();
     const unsigned new_tail = s_tail;
     scout_cur = s_scout;
     if (threadIdx.x == 0) out->tails[levels] = new_tail;
@@ -185,6 +235,7 @@ bc_fwd_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__
     tail = new_tail;
     level++;
     levels++;
+    par ^= 1u;
     __syncthreads();  // everybody has read s_tail / s_scout before the next level resets them
   }
   if (threadIdx.x == 0) {
@@ -221,34 +272,36 @@ bc_pack_kernel(const int32_t *__restrict__ depth, const int32_t *__restrict__ pc
   if (v < (size_t)m) rec[v] = bc_i32x4{depth[v], pc[v], 0, 0};
 }
 
-__device__ __forceinline__ float bc_edge_term(const bc_i32x4 *__restrict__ rec, vid_t dst, int32_t next_level, float pcs) {
-  const bc_i32x4 r = rec[dst];
+// FUSED: the deltas were written one level ago by other waves of the SAME launch (bc_back_small_kernel) -- device-scope
+// loads, past this CU's vector cache
+template <bool FUSED>
+__device__ __forceinline__ float bc_edge_term(const bc_i32x4 *rec, vid_t dst, int32_t next_level, float pcs) {
+  bc_i32x4 r;
+  if (FUSED) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(rec + dst);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r = bc_i32x4{(int)(unsigned)lo, (int)(unsigned)(lo >> 32), (int)(unsigned)hi, 0};
+  } else {
+    r = rec[dst];
+  }
   return r.x == next_level ? bc_term(pcs, r.y, __int_as_float(r.z)) : 0.0f;
 }
 
 // backward step of one level: delta[src] = SUM over successors, scores[src] += delta[src].  A term of a non-successor
 // is +0.0f, which leaves every partial sum unchanged (the sums are never -0.0f), so the loops carry no branch.
+// The three row classes and their summation orders are the same in every kernel that calls these two functions: a
+// vertex's delta does not depend on which kernel ran its level.
 #define BC_UNR 4
-__global__ void __launch_bounds__(GDN_BLOCK)
-bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ level, unsigned nf,
-               bc_i32x4 *__restrict__ rec, float *__restrict__ scores, int32_t next_level, vid_t *__restrict__ big_rows,
-               BcCounters *cnt, unsigned cap) {
-  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+#define BC_BIG_THREADS 1024
+
+// rows below BC_BLOCK_ROW edges, one per lane (b == e in idle lanes); returns the lane's row sum
+template <bool FUSED>
+__device__ __forceinline__ float bc_back_wave_rows(const vid_t *__restrict__ colidx, const bc_i32x4 *rec, int32_t next_level, eoff_t b,
+                                                   eoff_t e, float pcs, bool is_big) {
   const unsigned lane = gdn_lane();
-  eoff_t b = 0, e = 0;
-  vid_t v = 0;
-  float pcs = 0.0f;
-  if (i < nf) {
-    v = level[i];
-    b = rowptr[v];
-    e = rowptr[v + 1];
-    pcs = (float)rec[v].y;
-  }
   const eoff_t deg = e - b;
   float acc = 0.0f;
-  // rows for the workgroup kernel
-  const bool is_big = deg >= BC_BLOCK_ROW;
-  gdn_wl_push(big_rows, &cnt->big_count, cap, is_big, v, &cnt->overflow);
   // medium rows: the whole wave, one row at a time; lane l sums edges l, l + 64, ... (BC_UNR of them in flight), then a
   // fixed shuffle tree
   unsigned long long mask = __ballot(deg >= BC_WAVE_ROW && !is_big);
@@ -264,7 +317,7 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + 64 * r < ee ? colidx[k0 + 64 * r] : -1;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term<FUSED>(rec, dst[r], next_level, ps) : 0.0f;
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
     }
@@ -273,26 +326,72 @@ bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
     if ((int)lane == leader) acc = part;
   }
   // short rows: one lane, CSR order, the reference's arithmetic (the loads of BC_UNR edges in flight, added in order)
-  if (i < nf && deg < BC_WAVE_ROW) {
+  if (deg < BC_WAVE_ROW) {
     for (eoff_t k0 = b; k0 < e; k0 += BC_UNR) {
       vid_t dst[BC_UNR];
       float t[BC_UNR];
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + r < e ? colidx[k0 + r] : -1;
 #pragma unroll
-      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
+      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term<FUSED>(rec, dst[r], next_level, pcs) : 0.0f;
 #pragma unroll
       for (int r = 0; r < BC_UNR; r++) acc = gdn_fadd(acc, t[r]);
     }
   }
+  return acc;
+}
+
+// one row from BC_BLOCK_ROW edges on by a whole 1024-thread workgroup, BC_UNR edges per thread in flight; the sum is
+// returned in thread 0 (s_red: BC_BIG_THREADS / 64 floats; contains __syncthreads)
+template <bool FUSED>
+__device__ __forceinline__ float bc_back_block_row(const vid_t *__restrict__ colidx, const bc_i32x4 *rec, int32_t next_level, eoff_t b,
+                                                   eoff_t e, float pcs, float *s_red) {
+  float part = 0.0f;
+  for (eoff_t k0 = b + threadIdx.x; k0 < e; k0 += (eoff_t)BC_BIG_THREADS * BC_UNR) {
+    vid_t dst[BC_UNR];
+    float t[BC_UNR];
+#pragma unroll
+    for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + (eoff_t)BC_BIG_THREADS * r < e ? colidx[k0 + (eoff_t)BC_BIG_THREADS * r] : -1;
+#pragma unroll
+    for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term<FUSED>(rec, dst[r], next_level, pcs) : 0.0f;
+#pragma unroll
+    for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
+  __syncthreads();
+  if (gdn_lane() == 0) s_red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  float t = 0.0f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < BC_BIG_THREADS / 64; w++) t = gdn_fadd(t, s_red[w]);
+  return t;
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_back_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ level, unsigned nf,
+               bc_i32x4 *__restrict__ rec, float *__restrict__ scores, int32_t next_level, vid_t *__restrict__ big_rows,
+               BcCounters *cnt, unsigned cap) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vid_t v = 0;
+  float pcs = 0.0f;
+  if (i < nf) {
+    v = level[i];
+    b = rowptr[v];
+    e = rowptr[v + 1];
+    pcs = (float)rec[v].y;
+  }
+  // rows for the workgroup kernel
+  const bool is_big = e - b >= BC_BLOCK_ROW;
+  gdn_wl_push(big_rows, &cnt->big_count, cap, is_big, v, &cnt->overflow);
+  const float acc = bc_back_wave_rows<false>(colidx, rec, next_level, b, e, pcs, is_big);
   if (i < nf && !is_big) {
     rec[v].z = __float_as_int(acc);
     scores[v] = gdn_fadd(scores[v], acc);
   }
 }
 
-// rows from BC_BLOCK_ROW edges on: one 1024-thread workgroup each, BC_UNR edges per thread in flight
-#define BC_BIG_THREADS 1024
 __global__ void __launch_bounds__(BC_BIG_THREADS)
 bc_back_big_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ big_rows,
                    const BcCounters *__restrict__ cnt, bc_i32x4 *__restrict__ rec, float *__restrict__ scores, int32_t next_level,
@@ -302,31 +401,89 @@ bc_back_big_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
   if (n > cap) n = cap;
   for (unsigned r0 = blockIdx.x; r0 < n; r0 += gridDim.x) {
     const vid_t v = big_rows[r0];
-    const eoff_t b = rowptr[v], e = rowptr[v + 1];
-    const float pcs = (float)rec[v].y;
-    float part = 0.0f;
-    for (eoff_t k0 = b + threadIdx.x; k0 < e; k0 += (eoff_t)BC_BIG_THREADS * BC_UNR) {
-      vid_t dst[BC_UNR];
-      float t[BC_UNR];
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + (eoff_t)BC_BIG_THREADS * r < e ? colidx[k0 + (eoff_t)BC_BIG_THREADS * r] : -1;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
-    __syncthreads();
-    if (gdn_lane() == 0) s_red[threadIdx.x >> 6] = part;
-    __syncthreads();
+    const float t = bc_back_block_row<false>(colidx, rec, next_level, rowptr[v], rowptr[v + 1], (float)rec[v].y, s_red);
     if (threadIdx.x == 0) {
-      float t = 0.0f;
-      for (int w = 0; w < BC_BIG_THREADS / 64; w++) t = gdn_fadd(t, s_red[w]);
       rec[v].z = __float_as_int(t);
       scores[v] = gdn_fadd(scores[v], t);
     }
   }
+}
+
+// ---- fused light levels of the backward phase (the mirror of bc_fwd_small_kernel): ONE workgroup walks consecutive
+// levels from `d` down while a level has at most max_nf (<= 1024) vertices and max_scout out-edges -- a lane per short row,
+// a wave per medium row, the workgroup per long row, exactly as the per-level kernels sum them -- and reports the first
+// level it did not take (-1: none left).  lp[d] .. lp[d+1] = the level's entries of `order`.
+__global__ void __launch_bounds__(BC_SMALL_THREADS)
+bc_back_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const vid_t *__restrict__ order,
+                     const unsigned *__restrict__ lp, int32_t d, unsigned max_nf, unsigned long long max_scout, bc_i32x4 *rec,
+                     float *__restrict__ scores, int32_t *__restrict__ out_next) {
+  static_assert(BC_SMALL_THREADS == BC_BIG_THREADS, "long rows are summed by BC_BIG_THREADS threads in every kernel");
+  __shared__ float s_red[BC_BIG_THREADS / 64];
+  __shared__ unsigned long long s_scout[2];
+  __shared__ unsigned s_nbig[2];
+  __shared__ vid_t s_big[BC_SMALL_THREADS];
+  if (threadIdx.x < 2) {
+    s_scout[threadIdx.x] = 0ull;
+    s_nbig[threadIdx.x] = 0u;
+  }
+  __syncthreads();
+  // a level's vertices, row bounds and path counts are final: the NEXT level's are loaded while this one is summed, off
+  // the critical path of dependent reads
+  struct Lvl {
+    unsigned nf;
+    vid_t v;
+    eoff_t b, e;
+    float pcs;
+  };
+  auto load_level = [&](int32_t dd) {
+    Lvl L{0xFFFFFFFFu, 0, 0, 0, 0.0f};
+    if (dd < 0) return L;
+    const unsigned l0 = lp[dd];
+    L.nf = lp[dd + 1] - l0;
+    if (L.nf <= max_nf && threadIdx.x < L.nf) {
+      L.v = order[l0 + threadIdx.x];
+      L.b = rowptr[L.v];
+      L.e = rowptr[L.v + 1];
+      L.pcs = (float)rec[L.v].y;  // depth and path count of a record are final since bc_pack_kernel
+    }
+    return L;
+  };
+  Lvl nxt = load_level(d);
+  for (unsigned par = 0; d >= 0; d--, par ^= 1u) {
+    const Lvl cur = nxt;
+    const unsigned nf = cur.nf;
+    if (nf > max_nf) break;
+    nxt = load_level(d - 1);
+    const vid_t v = cur.v;
+    const eoff_t b = cur.b, e = cur.e;
+    const float pcs = cur.pcs;
+    const unsigned long long sc = gdn_wave_sum((unsigned long long)(e - b));
+    if (gdn_lane() == 0 && sc) atomicAdd(&s_scout[par], sc);
+    const bool is_big = e - b >= BC_BLOCK_ROW;
+    if (is_big) s_big[atomicAdd(&s_nbig[par], 1u)] = v;
+    __syncthreads();
+    if (s_scout[par] > max_scout) break;  // nothing of this level has been written yet
+    if (threadIdx.x == 0) {                // the other parity's cells: read by everybody one barrier ago at the latest
+      s_scout[par ^ 1u] = 0ull;
+      s_nbig[par ^ 1u] = 0u;
+    }
+    const float acc = bc_back_wave_rows<true>(colidx, rec, d + 1, b, e, pcs, is_big);
+    if (threadIdx.x < nf && !is_big) {
+      __hip_atomic_store(reinterpret_cast<int *>(rec + v) + 2, __float_as_int(acc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      scores[v] = gdn_fadd(scores[v], acc);
+    }
+    const unsigned nbig = s_nbig[par];
+    for (unsigned r0 = 0; r0 < nbig; r0++) {
+      const vid_t bv = s_big[r0];
+      const float t = bc_back_block_row<true>(colidx, rec, d + 1, rowptr[bv], rowptr[bv + 1], (float)rec[bv].y, s_red);
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(reinterpret_cast<int *>(rec + bv) + 2, __float_as_int(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        scores[bv] = gdn_fadd(scores[bv], t);
+      }
+    }
+    gdn_wg_level_sync();
+  }
+  if (threadIdx.x == 0) *out_next = d;
 }
 
 // max of non-negative floats as their bit patterns (NaN inputs do not occur: scores start finite and grow by finite terms)
@@ -535,7 +692,6 @@ bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
                    const int32_t *__restrict__ depth, bc_i32x4 *__restrict__ rec, float *__restrict__ scores,
                    vid_t *__restrict__ big_rows, BcCounters *cnt, unsigned cap) {
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  const unsigned lane = gdn_lane();
   const int32_t next_level = level + 1;
   eoff_t b = 0, e = 0;
   float pcs = 0.0f;
@@ -547,43 +703,9 @@ bc_back_all_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
     pcs = (float)rec[i].y;
   }
   const vid_t v = (vid_t)i;
-  const eoff_t deg = e - b;
-  float acc = 0.0f;
-  const bool is_big = deg >= BC_BLOCK_ROW;
+  const bool is_big = e - b >= BC_BLOCK_ROW;
   gdn_wl_push(big_rows, &cnt->big_count, cap, is_big, v, &cnt->overflow);
-  unsigned long long mask = __ballot(deg >= BC_WAVE_ROW && !is_big);
-  while (mask) {
-    const int leader = __ffsll((long long)mask) - 1;
-    mask &= mask - 1ull;
-    const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
-    const float ps = __shfl(pcs, leader, 64);
-    float part = 0.0f;
-    for (eoff_t k0 = bb + lane; k0 < ee; k0 += 64 * BC_UNR) {
-      vid_t dst[BC_UNR];
-      float t[BC_UNR];
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + 64 * r < ee ? colidx[k0 + 64 * r] : -1;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, ps) : 0.0f;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) part = gdn_fadd(part, t[r]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
-    if ((int)lane == leader) acc = part;
-  }
-  if (mine && deg < BC_WAVE_ROW) {
-    for (eoff_t k0 = b; k0 < e; k0 += BC_UNR) {
-      vid_t dst[BC_UNR];
-      float t[BC_UNR];
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) dst[r] = k0 + r < e ? colidx[k0 + r] : -1;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) t[r] = dst[r] >= 0 ? bc_edge_term(rec, dst[r], next_level, pcs) : 0.0f;
-#pragma unroll
-      for (int r = 0; r < BC_UNR; r++) acc = gdn_fadd(acc, t[r]);
-    }
-  }
+  const float acc = bc_back_wave_rows<false>(colidx, rec, next_level, b, e, pcs, is_big);
   if (mine && !is_big) {
     rec[v].z = __float_as_int(acc);
     scores[v] = gdn_fadd(scores[v], acc);
@@ -905,8 +1027,8 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   big.overflow = &cnt.p->overflow;
   BcCounters h;
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
-  unsigned small_nf = 256;
-  unsigned long long small_scout = 2048;
+  unsigned small_nf = 1024;
+  unsigned long long small_scout = 8192;
   if (const char *e = gdn_option("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
   if (const char *e = gdn_option("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   DevBuf<BcSmallOut> small_out;
@@ -955,8 +1077,30 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   const int32_t nlev = (int32_t)lp.size() - 2;  // non-empty levels 0 .. nlev-1
   // backward: the deepest level has no successors (its deltas stay 0, like the reference's first sweep)
   hipLaunchKernelGGL(bc_pack_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, depth.p, pc.p, m, rec.p);
+  // runs of light levels (at most back_nf vertices, back_scout out-edges each) stay inside one workgroup
+  unsigned back_nf = BC_SMALL_THREADS;
+  unsigned long long back_scout = 8192;
+  if (const char *e = gdn_option("GDN_BC_BACK_NF")) back_nf = std::min((unsigned)atoi(e), (unsigned)BC_SMALL_THREADS);  // tuning / test knobs
+  if (const char *e = gdn_option("GDN_BC_BACK_SCOUT")) back_scout = strtoull(e, nullptr, 10);
+  DevBuf<unsigned> d_lp;
+  DevBuf<int32_t> d_next;
+  if (back_nf && nlev >= 2) {
+    GDN_TRY(d_lp.alloc(lp.size()));
+    GDN_TRY(d_next.alloc(1));
+    GDN_HIP(hipMemcpyAsync(d_lp.p, lp.data(), lp.size() * sizeof(unsigned), hipMemcpyHostToDevice, 0));
+  }
   for (int32_t d = nlev - 2; d >= 0; d--) {
     const unsigned l0 = lp[(size_t)d], nf = lp[(size_t)d + 1] - l0;
+    if (back_nf && nf <= back_nf) {
+      hipLaunchKernelGGL(bc_back_small_kernel, dim3(1), dim3(BC_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, order.p, d_lp.p, d, back_nf,
+                         back_scout, rec.p, d_scores, d_next.p);
+      int32_t next = d;
+      GDN_HIP(hipMemcpy(&next, d_next.p, sizeof(next), hipMemcpyDeviceToHost));
+      if (next < d) {  // levels d .. next + 1 are done
+        d = next + 1;
+        continue;
+      }
+    }
     hipLaunchKernelGGL(bc_back_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, order.p + l0, nf,
                        rec.p, d_scores, d + 1, big_rows.p, cnt.p, rowcap);
     hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, big_rows.p, cnt.p, rec.p,

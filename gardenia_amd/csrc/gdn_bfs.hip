@@ -164,8 +164,7 @@ bfs_td_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__
     }
     scout = gdn_wave_sum(scout);
     if (lane == 0 && scout) atomicAdd(&s_scout, scout);
-    __threadfence();
-    __syncthreads();
+    gdn_wg_level_sync();
     checked += scout_cur;
     nf = s_cnt;
     scout_cur = s_scout;
@@ -200,30 +199,12 @@ struct BfsCoopCnt {
   alignas(128) unsigned over;
 };
 
-// all workgroups of a cooperative launch (co-resident by construction): arrive on bar[0], the last one bumps the
-// generation bar[32] the others spin on.  (cooperative_groups' grid.sync() cost ~30 us per level here.)
-__device__ __forceinline__ void bfs_grid_barrier(unsigned *bar, unsigned nblocks) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicAdd(bar, 1u) == nblocks - 1u) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      atomicAdd(bar + 32, 1u);
-    } else {
-      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
-    }
-    __threadfence();
-  }
-  __syncthreads();
-}
-
+// (the barrier: gdn_grid_barrier, gdn_common.hpp; cooperative_groups' grid.sync() cost ~30 us per level here)
 __global__ void __launch_bounds__(BFS_COOP_THREADS)
 bfs_td_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, vid_t *q0, vid_t *q1, unsigned which, unsigned nf, unsigned cap, int32_t level,
                    unsigned long long scout_cur, unsigned max_nf, unsigned long long max_scout, unsigned min_nf,
-                   BfsCoopCnt *cnt /* 3 sets, zeroed by the host */, unsigned *bar /* 64 words, zeroed by the host */,
+                   BfsCoopCnt *cnt /* 3 sets, zeroed by the host */, unsigned *bar /* GDN_GBAR_WORDS, zeroed by the host */,
                    BfsSmallOut *__restrict__ out) {
   const unsigned lane = gdn_lane();
   const unsigned gt = blockIdx.x * BFS_COOP_THREADS + threadIdx.x, nt = gridDim.x * BFS_COOP_THREADS;
@@ -293,7 +274,7 @@ bfs_td_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
     scout = gdn_wave_sum(scout);
     if (lane == 0 && scout) atomicAdd(&cur->scout, scout);
     if (__any(over) && lane == 0) __hip_atomic_store(&cur->over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bfs_grid_barrier(bar, gridDim.x);
+    gdn_grid_barrier(bar, gridDim.x);
     checked += scout_cur;
     nf = __hip_atomic_load(&cur->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     scout_cur = __hip_atomic_load(&cur->scout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -632,7 +613,7 @@ struct gdn_bfs_plan {
   DevBuf<unsigned long long> bigitems;
   DevBuf<BfsCounters> cnt;
   DevBuf<BfsCoopCnt> coop_cnt;  // 3 rotating sets of the cooperative light-level kernel
-  DevBuf<unsigned> coop_bar;    // its grid barrier: [0] arrivals, [32] generation
+  DevBuf<unsigned> coop_bar;    // its grid barrier (gdn_grid_barrier, gdn_common.hpp)
   int coop_blocks = 0;          // 0: cooperative launches unavailable
   DevBuf<BfsSmallOut> small_out;
   BfsCounters *h_cnt = nullptr;  // pinned host copy of the level counters (one 32-byte read back per level)
@@ -719,7 +700,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfs_td_coop_kernel, BFS_COOP_THREADS, 0) == hipSuccess && per_cu >= 1) {
       p.coop_blocks = cus;
       GDN_TRY(p.coop_cnt.alloc(3));
-      GDN_TRY(p.coop_bar.alloc(64));
+      GDN_TRY(p.coop_bar.alloc(GDN_GBAR_WORDS));
     }
     (void)hipGetLastError();
   }
@@ -911,7 +892,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       // ---- light levels beyond one workgroup on a high-diameter graph: the cooperative grid, a barrier per level
       if (coop_nf > 0 && light_streak >= coop_streak && nf <= coop_nf && (unsigned long long)scout_count <= coop_scout) {
         GDN_HIP(hipMemsetAsync(p.coop_cnt.p, 0, 3 * sizeof(BfsCoopCnt), 0));
-        GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, 64 * sizeof(unsigned), 0));
+        GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, GDN_GBAR_WORDS * sizeof(unsigned), 0));
         const eoff_t *a_rowptr = g->rowptr;
         const vid_t *a_colidx = g->colidx;
         unsigned *a_visited = p.visited.p;

@@ -149,6 +149,42 @@ __device__ __forceinline__ unsigned gdn_lane() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Level boundary inside ONE workgroup (the fused light-level kernels): all its waves go through the same vector L1 and the
+// same L2, so waiting for the outstanding accesses and a barrier orders them.  __threadfence() is the device-scope form --
+// buffer_wbl2 sc1 + buffer_inv sc1 on gfx950: a write-back of the L2 and an invalidate of the L1 per level, microseconds
+// each, that only a reader on another XCD needs.  What ATOMICS wrote (they execute in the L2) is still read past the L1
+// with device-scope atomic loads.
+__device__ __forceinline__ void gdn_wg_level_sync() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+// Grid barrier of a cooperative launch (all workgroups co-resident), for kernels that touch their shared MUTABLE data
+// with device-scope accesses only (atomics, `sc1` loads and stores -- the queues, counters, distances and bitmaps of the
+// persistent traversal kernels): every wave drains its own accesses, the workgroup meets, one lane arrives on bar[0], the
+// last arriver resets it and bumps the generation bar[32] the others poll.  No cache write-back / invalidate is needed
+// then (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the signal + sc1 loads behind it);
+// three __threadfence() per barrier, as first written, cost a third of a light level (4096 x 4096 lattice BFS: 15.6 ->
+// 10.0 us per level).  Arrivals per XCD with a second level on top (eight counters in parallel, XCD read from
+// HW_REG_XCC_ID) measured the same 9.9 us: the level is bound by its chain of dependent accesses, not by the 256
+// arrivals -- the flat form stays.
+#define GDN_GBAR_WORDS 64  // zeroed by the host before every launch
+__device__ __forceinline__ void gdn_grid_barrier(unsigned *bar, unsigned nblocks) {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicAdd(bar, 1u) == nblocks - 1u) {
+      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the reset has landed before anybody is released
+      atomicAdd(bar + 32, 1u);
+    } else {
+      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+}
+
 __device__ __forceinline__ unsigned long long gdn_lanemask_lt() {
   return (1ull << gdn_lane()) - 1ull;
 }

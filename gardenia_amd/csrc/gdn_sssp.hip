@@ -582,8 +582,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
         }
       }
       if (maxd > 0) atomicMax(&s_maxd, maxd);
-      __threadfence();
-      __syncthreads();
+      gdn_wg_level_sync();
       n_near = s_nn;
       n_far = s_nf;
       near_edges = s_edges;
@@ -682,8 +681,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
       deg_sum = gdn_wave_sum(deg_sum);
       if (lane == 0 && deg_sum) atomicAdd(&s_edges, deg_sum);
     }
-    __threadfence();
-    __syncthreads();
+    gdn_wg_level_sync();
     n_near = s_nn;
     n_far = s_nf;
     near_edges = s_edges;
@@ -729,23 +727,6 @@ struct SsspCoopCnt {
   unsigned over;
 };
 
-__device__ __forceinline__ void sssp_grid_barrier(unsigned *bar, unsigned nblocks) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicAdd(bar, 1u) == nblocks - 1u) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __threadfence();
-      atomicAdd(bar + 32, 1u);
-    } else {
-      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
-    }
-    __threadfence();
-  }
-  __syncthreads();
-}
-
 // wave-aggregated slot reservation on a GLOBAL counter (all lanes of the wave must call it)
 __device__ __forceinline__ unsigned sssp_global_slot(unsigned *counter, bool want) {
   const unsigned long long mask = __ballot(want);
@@ -760,7 +741,7 @@ __global__ void __launch_bounds__(SSSP_COOP_THREADS)
 sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ weight,
                  int32_t *dist, int32_t *stamp, unsigned *in_far, vid_t *near0, vid_t *near1, vid_t *far0, vid_t *far1,
                  unsigned cap, int32_t delta, unsigned max_v, unsigned long long max_e, unsigned max_far,
-                 SsspCoopCnt *cnt /* 3 sets, reset by the host */, unsigned *bar /* 64 words, zeroed by the host */,
+                 SsspCoopCnt *cnt /* 3 sets, reset by the host */, unsigned *bar /* GDN_GBAR_WORDS, zeroed by the host */,
                  SsspSmallState *state) {
   const unsigned lane = gdn_lane();
   const unsigned gt = blockIdx.x * SSSP_COOP_THREADS + threadIdx.x, nt = gridDim.x * SSSP_COOP_THREADS;
@@ -848,7 +829,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       edges = gdn_wave_sum(edges);
       if (lane == 0 && edges) atomicAdd(&cur->edges, edges);
       if (__any(over) && lane == 0) __hip_atomic_store(&cur->over, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      sssp_grid_barrier(bar, gridDim.x);
+      gdn_grid_barrier(bar, gridDim.x);
       ph++;
       n_near = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       n_far += __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -891,7 +872,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
         d = t < d ? t : d;
       }
       if (lane == 0 && d != GDN_DIST_INF) atomicMin(&cur->min_far, d);
-      sssp_grid_barrier(bar, gridDim.x);
+      gdn_grid_barrier(bar, gridDim.x);
       ph++;
       const int32_t mn = __hip_atomic_load(&cur->min_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (mn == GDN_DIST_INF) {  // only stale entries were left
@@ -926,7 +907,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       }
       deg_sum = gdn_wave_sum(deg_sum);
       if (lane == 0 && deg_sum) atomicAdd(&cur->edges, deg_sum);
-      sssp_grid_barrier(bar, gridDim.x);
+      gdn_grid_barrier(bar, gridDim.x);
       ph++;
       n_near = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       n_far = __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1056,7 +1037,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, sssp_coop_kernel, SSSP_COOP_THREADS, 0) == hipSuccess && per_cu >= 1) {
       p.coop_blocks = cus;
       GDN_TRY(p.coop_cnt.alloc(3));
-      GDN_TRY(p.coop_bar.alloc(64));
+      GDN_TRY(p.coop_bar.alloc(GDN_GBAR_WORDS));
     }
     (void)hipGetLastError();
   }
@@ -1294,7 +1275,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       for (int k = 0; k < 3; k++) init[k].min_far = GDN_DIST_INF;
       GDN_HIP(hipMemcpyAsync(p.small.p, &ss, sizeof(ss), hipMemcpyHostToDevice, 0));
       GDN_HIP(hipMemcpyAsync(p.coop_cnt.p, init, sizeof(init), hipMemcpyHostToDevice, 0));
-      GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, 64 * sizeof(unsigned), 0));
+      GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, GDN_GBAR_WORDS * sizeof(unsigned), 0));
       const eoff_t *a_rowptr = g->rowptr;
       const vid_t *a_colidx = g->colidx;
       const int32_t *a_w = d_weight;

@@ -1310,3 +1310,47 @@ def test_bc_fused_light_levels(orc, monkeypatch, small_nf):
         assert orc.bc_verify(g, src, sc)
         _bc_close(sc, want)
         assert st["iterations"] == levels
+
+
+def test_bc_fused_backward_levels_same_bits(orc, monkeypatch):
+    """bc_back_small_kernel (consecutive light backward levels inside one workgroup) off / default / every level that
+    fits: the scores are the SAME BITS -- every row class is summed in one order whichever kernel runs its level --
+    and satisfy the reference verifier.  The funnel graph puts a 6000-edge row (workgroup class) and 100-edge rows
+    (wave class) into one-vertex levels."""
+    m = 3000
+    chain = graphio.build_csr(m, np.arange(m - 1, dtype=np.int64), np.arange(1, m, dtype=np.int64))
+    hub, nleaf = 20, 6000
+    src_l = list(range(hub)) + [hub] * nleaf
+    dst_l = list(range(1, hub + 1)) + list(range(hub + 1, hub + 1 + nleaf))
+    mid = hub + 1 + nleaf  # every leaf -> 100 collectors -> a tail chain
+    for leaf in range(hub + 1, hub + 1 + nleaf):
+        src_l += [leaf, leaf]
+        dst_l += [mid + leaf % 100, mid + (leaf * 7) % 100]
+    tail = mid + 100
+    for c in range(100):
+        src_l.append(mid + c)
+        dst_l.append(tail)
+    for t in range(50):
+        src_l.append(tail + t)
+        dst_l.append(tail + t + 1)
+    funnel = graphio.build_csr(tail + 51, np.array(src_l, np.int64), np.array(dst_l, np.int64))
+    cases = [(chain, 0), (funnel, 0), (graphio.symmetrize(graphio.rmat_graph(11, 4, seed=11)), None),
+             (graphio.rmat_graph(15, 16, seed=10), None)]
+    got = {}
+    for mode in ("off", "default", "wide"):
+        if mode == "off":
+            monkeypatch.setenv("GDN_BC_BACK_NF", "0")
+        elif mode == "wide":
+            monkeypatch.setenv("GDN_BC_BACK_NF", "1024")
+            monkeypatch.setenv("GDN_BC_BACK_SCOUT", "100000000000")
+        else:
+            monkeypatch.delenv("GDN_BC_BACK_NF", raising=False)
+        for k, (g, src) in enumerate(cases):
+            src = graphio.first_nonisolated(g) if src is None else src
+            sc = np.zeros(g.m, np.float32)
+            st = solvers.BCSolver(solvers.Graph(csr=g), src, sc)
+            assert orc.bc_verify(g, src, sc), (mode, k)
+            got[(mode, k)] = sc
+    for k in range(len(cases)):
+        for mode in ("default", "wide"):
+            assert np.array_equal(got[("off", k)].view(np.uint32), got[(mode, k)].view(np.uint32)), (mode, k)
