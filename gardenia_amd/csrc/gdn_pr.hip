@@ -225,10 +225,269 @@ pr_dead_diff_kernel(const float *__restrict__ scores, const uint32_t *__restrict
   if (gdn_lane() == 0 && acc != 0.0) atomicAdd(out, acc);
 }
 
+// ------------------------------------------------------------------------------------------
+// The whole solve in ONE launch (the reference's persistent "fusion" PageRank, src/pr/fusion.cu:45-56 over the software
+// global barrier include/gbar.h:24-65) for graphs whose iteration is shorter than its launches: a cooperative grid pulls
+// over the in-CSR -- a lane per short row in CSR order with the reference's fp32 operations (src/pr/omp_base.cc:24-33:
+// the same bits as its sequential loop for such rows), a wave per row from 64 edges on -- writes score and next
+// contribution, and meets in ONE grid barrier per iteration; behind it every workgroup adds the per-workgroup L1 changes
+// in the same fixed order, so all of them take the same decision (omp_base.cc:36) without the host.  The contributions
+// change hands between workgroups: device-scope (sc1) stores and loads; a vertex's score stays with one lane.
+// ------------------------------------------------------------------------------------------
+// Graphs of at most PR_SMALL_M vertices: ONE workgroup, the contributions of both iterations in LDS (the gathers never
+// leave the CU), the iteration boundary a __syncthreads() -- an iteration of a 12 K-edge graph takes a microsecond or two
+// instead of the ~17 us of a grid barrier's device-scope round trips or the ~25 us of launches and a blocking read.
+#define PR_SMALL_THREADS 1024
+#define PR_SMALL_M 16384
+#define PR_FUSED_UNR 16  // a row of up to 16 edges: one round trip for its columns, one for its gathers
+__global__ void __launch_bounds__(PR_SMALL_THREADS)
+pr_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ out_degree, int32_t m,
+                float *__restrict__ scores, float base_score, float damping, double epsilon, int32_t max_iter,
+                double *__restrict__ trace /* max_iter */, int32_t *__restrict__ out_iter) {
+  extern __shared__ float s_contrib[];  // 2 x m
+  __shared__ double s_red[PR_SMALL_THREADS / 64];
+  __shared__ double s_diff;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
+  float *cin = s_contrib, *cout = s_contrib + m;
+  for (unsigned v = threadIdx.x; v < (unsigned)m; v += PR_SMALL_THREADS) cin[v] = __fdiv_rn(scores[v], (float)out_degree[v]);
+  __syncthreads();
+  int32_t iter = 0;
+  for (; iter < max_iter; iter++) {
+    double d = 0.0;
+    for (unsigned i0 = threadIdx.x - lane; i0 < (unsigned)m; i0 += PR_SMALL_THREADS) {  // the same lane owns a vertex every iteration
+      const unsigned v = i0 + lane;
+      eoff_t b = 0, e = 0;
+      if (v < (unsigned)m) {
+        b = rowptr[v];
+        e = rowptr[v + 1];
+      }
+      float sum = 0.0f;
+      const bool mine_long = e - b >= 64u;
+      unsigned long long longs = __ballot(mine_long);
+      while (longs) {
+        const int leader = __ffsll((long long)longs) - 1;
+        longs &= longs - 1ull;
+        const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
+        float part = 0.0f;
+        for (eoff_t k = bb + lane; k < ee; k += 64) part = gdn_fadd(part, cin[colidx[k]]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
+        if ((int)lane == leader) sum = part;
+      }
+      if (!mine_long) {
+        for (eoff_t k0 = b; k0 < e; k0 += PR_FUSED_UNR) {  // PR_FUSED_UNR column reads in flight, added in CSR order
+          vid_t c[PR_FUSED_UNR];
+#pragma unroll
+          for (int r = 0; r < PR_FUSED_UNR; r++) c[r] = k0 + r < e ? colidx[k0 + r] : -1;
+#pragma unroll
+          for (int r = 0; r < PR_FUSED_UNR; r++)
+            if (c[r] >= 0) sum = gdn_fadd(sum, cin[c[r]]);
+        }
+      }
+      if (v < (unsigned)m) {
+        const float old_score = scores[v];
+        const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
+        scores[v] = new_score;
+        cout[v] = __fdiv_rn(new_score, (float)out_degree[v]);
+        d += (double)fabsf(gdn_fsub(new_score, old_score));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) s_red[wave] = d;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0;
+      for (int w = 0; w < PR_SMALL_THREADS / 64; w++) a += s_red[w];
+      s_diff = a;
+      trace[iter] = a;
+    }
+    __syncthreads();
+    float *tmp = cin;
+    cin = cout;
+    cout = tmp;
+    if (s_diff < epsilon) break;  // omp_base.cc:36
+  }
+  if (threadIdx.x == 0) *out_iter = iter;
+}
+
+#define PR_FUSED_THREADS 256
+__device__ __forceinline__ float pr_ld_dev(const float *p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pr_st_dev(float *p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void __launch_bounds__(PR_FUSED_THREADS)
+pr_fused_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ out_degree, int32_t m,
+                float *scores, float *c0, float *c1, float base_score, float damping, double epsilon, int32_t max_iter,
+                double *partial /* 2 x gridDim.x */, unsigned *bar /* GDN_GBAR_WORDS, zeroed by the host */,
+                double *__restrict__ trace /* max_iter */, int32_t *__restrict__ out_iter) {
+  __shared__ double s_red[PR_FUSED_THREADS / 64];
+  __shared__ double s_diff;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
+  const unsigned gt = blockIdx.x * PR_FUSED_THREADS + threadIdx.x, nt = gridDim.x * PR_FUSED_THREADS;
+  for (unsigned v = gt; v < (unsigned)m; v += nt) pr_st_dev(c0 + v, __fdiv_rn(scores[v], (float)out_degree[v]));
+  gdn_grid_barrier(bar, gridDim.x);
+  const float *cin = c0;
+  float *cout = c1;
+  int32_t iter = 0;
+  for (; iter < max_iter; iter++) {
+    double d = 0.0;
+    for (unsigned i0 = gt - lane; i0 < (unsigned)m; i0 += nt) {  // a wave takes 64 consecutive rows, one per lane
+      const unsigned v = i0 + lane;
+      eoff_t b = 0, e = 0;
+      if (v < (unsigned)m) {
+        b = rowptr[v];
+        e = rowptr[v + 1];
+      }
+      float sum = 0.0f;
+      // rows of a wave's width or more: the whole wave, lane l adds edges l, l + 64, ..., then a fixed shuffle tree
+      const bool mine_long = e - b >= 64u;
+      unsigned long long longs = __ballot(mine_long);
+      while (longs) {
+        const int leader = __ffsll((long long)longs) - 1;
+        longs &= longs - 1ull;
+        const eoff_t bb = __shfl(b, leader, 64), ee = __shfl(e, leader, 64);
+        float part = 0.0f;
+        for (eoff_t k = bb + lane; k < ee; k += 64) part = gdn_fadd(part, pr_ld_dev(cin + colidx[k]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part = gdn_fadd(part, __shfl_xor(part, o, 64));
+        if ((int)lane == leader) sum = part;
+      }
+      if (!mine_long) {
+        for (eoff_t k0 = b; k0 < e; k0 += PR_FUSED_UNR) {  // PR_FUSED_UNR gathers in flight, added in CSR order
+          vid_t ci[PR_FUSED_UNR];
+          float c[PR_FUSED_UNR];
+#pragma unroll
+          for (int r = 0; r < PR_FUSED_UNR; r++) ci[r] = k0 + r < e ? colidx[k0 + r] : -1;
+#pragma unroll
+          for (int r = 0; r < PR_FUSED_UNR; r++) c[r] = ci[r] >= 0 ? pr_ld_dev(cin + ci[r]) : 0.0f;
+#pragma unroll
+          for (int r = 0; r < PR_FUSED_UNR; r++)
+            if (ci[r] >= 0) sum = gdn_fadd(sum, c[r]);
+        }
+      }
+      if (v < (unsigned)m) {
+        const float old_score = scores[v];
+        const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
+        scores[v] = new_score;
+        pr_st_dev(cout + v, __fdiv_rn(new_score, (float)out_degree[v]));
+        d += (double)fabsf(gdn_fsub(new_score, old_score));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o, 64);
+    if (lane == 0) s_red[wave] = d;
+    __syncthreads();
+    double *mine = partial + (size_t)(iter & 1) * gridDim.x;
+    if (threadIdx.x == 0) {
+      double t = 0.0;
+      for (int w = 0; w < PR_FUSED_THREADS / 64; w++) t += s_red[w];
+      __hip_atomic_store(mine + blockIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gdn_grid_barrier(bar, gridDim.x);
+    // the total, in the same order in every workgroup
+    double t = 0.0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += PR_FUSED_THREADS) t += __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+    if (lane == 0) s_red[wave] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double a = 0.0;
+      for (int w = 0; w < PR_FUSED_THREADS / 64; w++) a += s_red[w];
+      s_diff = a;
+    }
+    __syncthreads();
+    const double diff = s_diff;
+    if (blockIdx.x == 0 && threadIdx.x == 0) trace[iter] = diff;
+    const float *tmp = cin;
+    cin = cout;
+    cout = const_cast<float *>(tmp);
+    if (diff < epsilon) break;  // omp_base.cc:36
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *out_iter = iter;
+}
+
 // the per-iteration L1 changes of the calling thread's last gdn_pr / gdn_pr_multi solve (the reference prints them as it
 // goes, src/pr/omp_base.cc:35; gdn_pr_last_trace hands them to the wrapper that prints)
 static thread_local std::vector<double> g_pr_trace;
 void gdn_pr_trace_set(const double *diff, int32_t n) { g_pr_trace.assign(diff, diff + (n > 0 ? n : 0)); }
+
+// the fused solve of gdn_pr; *done = 0 when the device takes no cooperative launch (the caller runs the loop instead)
+static int pr_solve_fused(const gdn_graph *g, const int32_t *d_deg, float *d_scores, float damping, double epsilon, int32_t max_iter,
+                          gdn_stats *st, int *done) {
+  *done = 0;
+  const int32_t m = g->m;
+  unsigned small_m = 1024;  // measured (R-MAT, 16 edges per vertex): 10 us per iteration at 2^10 vertices, the grid form wins from 2^12 on
+  if (const char *e = gdn_option("GDN_PR_SMALL_M")) small_m = (unsigned)std::min(atoi(e), PR_SMALL_M);  // tuning / test knob
+  const bool one_wg = (unsigned)m <= small_m;
+  unsigned blocks = 1;
+  if (one_wg) {
+    if (hipFuncSetAttribute((const void *)pr_small_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * PR_SMALL_M * (int)sizeof(float)) !=
+        hipSuccess) {
+      (void)hipGetLastError();
+      return GDN_OK;
+    }
+  } else {
+    int dev = 0, coop = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) != hipSuccess || !coop ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, pr_fused_kernel, PR_FUSED_THREADS, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      return GDN_OK;
+    }
+    // one workgroup per CU at most, and no more workgroups than the rows fill
+    blocks = (unsigned)std::min<uint64_t>((uint64_t)cus, ((uint64_t)m + PR_FUSED_THREADS - 1) / PR_FUSED_THREADS);
+  }
+  DevBuf<float> c0, c1;
+  DevBuf<double> partial, trace;
+  DevBuf<unsigned> bar;
+  DevBuf<int32_t> out_iter;
+  if (!one_wg) {
+    GDN_TRY(c0.alloc((size_t)m));
+    GDN_TRY(c1.alloc((size_t)m));
+    GDN_TRY(partial.alloc(2 * (size_t)blocks));
+    GDN_TRY(bar.alloc(GDN_GBAR_WORDS));
+  }
+  GDN_TRY(trace.alloc((size_t)max_iter));
+  GDN_TRY(out_iter.alloc(1));
+  HostTimer tsolve;
+  tsolve.start();  // timed region == src/pr/base.cu:110-128
+  const float base = (1.0f - damping) / (float)m;  // as gdn_pr_pull_rows_dev computes it
+  if (one_wg) {
+    hipLaunchKernelGGL(pr_small_kernel, dim3(1), dim3(PR_SMALL_THREADS), 2 * (size_t)m * sizeof(float), 0, g->rowptr, g->colidx, d_deg, m,
+                       d_scores, base, damping, epsilon, max_iter, trace.p, out_iter.p);
+    GDN_HIP(hipGetLastError());
+  } else {
+    GDN_HIP(hipMemsetAsync(bar.p, 0, GDN_GBAR_WORDS * sizeof(unsigned), 0));
+    const eoff_t *a_rowptr = g->rowptr;
+    const vid_t *a_colidx = g->colidx;
+    int32_t a_m = m, a_max_iter = max_iter;
+    float *a_scores = d_scores, *a_c0 = c0.p, *a_c1 = c1.p;
+    float a_base = base, a_damping = damping;
+    double a_eps = epsilon;
+    double *a_partial = partial.p, *a_trace = trace.p;
+    unsigned *a_bar = bar.p;
+    int32_t *a_out = out_iter.p;
+    void *args[] = {&a_rowptr, &a_colidx, &d_deg, &a_m, &a_scores, &a_c0, &a_c1, &a_base, &a_damping, &a_eps, &a_max_iter,
+                    &a_partial, &a_bar, &a_trace, &a_out};
+    GDN_HIP(hipLaunchCooperativeKernel((const void *)pr_fused_kernel, dim3(blocks), dim3(PR_FUSED_THREADS), args, 0, 0));
+  }
+  int32_t iter = 0;
+  GDN_HIP(hipMemcpy(&iter, out_iter.p, sizeof(iter), hipMemcpyDeviceToHost));
+  st->solve_ms = tsolve.stop_ms();
+  const int32_t n_trace = iter < max_iter ? iter + 1 : max_iter;
+  g_pr_trace.resize((size_t)n_trace);
+  GDN_HIP(hipMemcpy(g_pr_trace.data(), trace.p, (size_t)n_trace * sizeof(double), hipMemcpyDeviceToHost));
+  st->iterations = iter + 1;  // the reference prints iter+1 (omp_base.cc:39)
+  st->last_error = g_pr_trace.back();
+  st->edges_traversed = g->nnz * (uint64_t)n_trace;
+  *done = 1;
+  return GDN_OK;
+}
 
 extern "C" {
 
@@ -948,6 +1207,20 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       break;
     }
     st.h2d_ms = th2d.stop_ms();
+    // graphs of the CSR regime: the whole solve in one cooperative launch (GDN_PR_FUSED=0: the per-iteration loop)
+    {
+      const char *env = gdn_option("GDN_PR_LAYOUT"), *fz = gdn_option("GDN_PR_FUSED");
+      const bool want = fz ? fz[0] != '0' : (!env && nnz < (1ull << 18));  // measured: 20 us per iteration against the loop's 27 at 0.23 M edges, 35 against 30 at 1 M
+      int fused = 0;
+      if (want && (rc = pr_solve_fused(g, d_deg.p, d_scores.p, damping, epsilon, max_iter, &st, &fused))) break;
+      if (fused) {
+        if (hipMemcpy(scores, d_scores.p, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) {
+          gdn_set_error("gdn_pr: download failed");
+          rc = GDN_ERR_HIP;
+        }
+        break;
+      }
+    }
     tprep.start();
     // the PB layout works on the live vertices only (GDN_LAYOUT_PB_SQUISHED; GDN_PR_SQUISH=0: the caller's vertex space)
     int32_t layout = GDN_LAYOUT_AUTO;

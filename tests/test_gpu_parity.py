@@ -102,10 +102,15 @@ def test_bfs_cooperative_light_levels(orc, monkeypatch, coop):
 
 
 # ------------------------------------------------------------------ PR
-@pytest.fixture(params=["csr", "pb"])
+@pytest.fixture(params=["csr", "pb", "fused"])
 def pr_layout(request, monkeypatch):
-    """Both edge layouts of the PageRank plan (include/gardenia_hip.h GDN_LAYOUT_*)."""
-    monkeypatch.setenv("GDN_PR_LAYOUT", request.param)
+    """Both edge layouts of the PageRank plan (include/gardenia_hip.h GDN_LAYOUT_*) under the per-iteration loop, and the
+    whole solve in one cooperative launch (pr_fused_kernel, what gdn_pr picks by itself below 2^22 edges)."""
+    if request.param == "fused":
+        monkeypatch.setenv("GDN_PR_FUSED", "1")
+        monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+    else:
+        monkeypatch.setenv("GDN_PR_LAYOUT", request.param)
     return request.param
 
 
@@ -1354,3 +1359,48 @@ def test_bc_fused_backward_levels_same_bits(orc, monkeypatch):
     for k in range(len(cases)):
         for mode in ("default", "wide"):
             assert np.array_equal(got[("off", k)].view(np.uint32), got[(mode, k)].view(np.uint32)), (mode, k)
+
+
+
+def test_pr_fused_solve(orc, monkeypatch):
+    """pr_fused_kernel against the per-iteration loop and the oracle: the same iteration count, every line of the trace,
+    scores within 1e-4 (short rows: the reference's own summation order), the same bits run after run, max_iter honoured,
+    hub rows (wave class) and vertices without in-edges included."""
+    monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+    # (a 300-leaf star: the reference's sequential fp32 sum of n equal terms is itself off by ~n/2 ulp, 1.6e-4 at n = 3000)
+    star_src = np.concatenate([np.arange(1, 300), np.zeros(40, np.int64)]).astype(np.int64)
+    star_dst = np.concatenate([np.zeros(299, np.int64), np.arange(1, 41)]).astype(np.int64)
+    graphs = [graphio.rmat_graph(9, 4, seed=3), graphio.rmat_graph(14, 16, seed=5), graphio.rmat_graph(12, 64, seed=7),
+              graphio.build_csr(3000, star_src, star_dst)]
+    for gk, g in enumerate(graphs):
+        gi = graphio.transpose(g)
+        G = solvers.Graph(csr=g, in_csr=gi)
+        want, it, trace = orc.pr(gi, g.degrees())
+        res = {}
+        for mode in ("0", "1", "1"):
+            monkeypatch.setenv("GDN_PR_FUSED", mode)
+            s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+            st = solvers.PRSolver(G, s)
+            assert st["iterations"] == it, (gk, mode)
+            np.testing.assert_allclose(s, want, rtol=REL_TOL, atol=0, err_msg="graph %d mode %s" % (gk, mode))
+            assert len(st["trace"]) == len(trace)
+            np.testing.assert_allclose(st["trace"], trace, rtol=1e-3, atol=1e-9)
+            assert abs(st["last_error"] - st["trace"][-1]) == 0
+            if mode == "1" and "1" in res:
+                assert np.array_equal(res["1"].view(np.uint32), s.view(np.uint32))
+            res[mode] = s
+        np.testing.assert_allclose(res["1"], res["0"], rtol=2e-5, atol=0)
+        s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(G, s, max_iter=3)
+        assert st["iterations"] in (3, 4) and len(st["trace"]) == 3  # the loop ran 3 times without converging
+    # the one-workgroup form on a graph the grid form would take by itself, and the other way round
+    g = graphio.rmat_graph(13, 8, seed=21)
+    gi = graphio.transpose(g)
+    want, it, _ = orc.pr(gi, g.degrees())
+    monkeypatch.setenv("GDN_PR_FUSED", "1")
+    for small_m in ("16384", "0"):
+        monkeypatch.setenv("GDN_PR_SMALL_M", small_m)
+        s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), s)
+        assert st["iterations"] == it
+        np.testing.assert_allclose(s, want, rtol=REL_TOL, atol=0)
