@@ -155,7 +155,11 @@ __device__ __forceinline__ unsigned gdn_lane() {
 // each, that only a reader on another XCD needs.  What ATOMICS wrote (they execute in the L2) is still read past the L1
 // with device-scope atomic loads.
 __device__ __forceinline__ void gdn_wg_level_sync() {
+#ifdef GDN_ABL_LEVEL_FENCE  // A/B builds only (tools/build_variant.sh): the device-scope fence this replaced
+  __threadfence();
+#else
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
 }
 
