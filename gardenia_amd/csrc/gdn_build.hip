@@ -1,6 +1,6 @@
 // gdn_build.hip -- device-side graph construction (ingest row of SURVEY 8f + the synthetic
-// input of SURVEY 8d).  NOT on the solver hot path: this is the only file that uses a library
-// primitive (rocPRIM radix sort of 64-bit edge keys); every solver kernel is hand written.
+// input of SURVEY 8d).  NOT on the solver hot path.  The sorts are gdn_sort.hip's radix sort (no library primitive is
+// left anywhere: round 1 called rocPRIM here).
 //
 //   gdn_rmat_build     : Graph500 R-MAT edge stream (include/generator.h:81-114; A=.57 B=.19
 //                        C=.19) from the counter-based RNG specified in
@@ -16,7 +16,6 @@
 #include <string.h>
 #include <stdlib.h>
 
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "gdn_expand.hpp"
 #include "gdn_pb.hpp"
@@ -125,28 +124,16 @@ static int bits_for(int32_t m) {
   return b;
 }
 
-// stable radix sort on the bits [begin_bit, bits) of the keys; returns the buffer holding the result and frees the other
+// stable radix sort on the bits [begin_bit, bits) of the keys (gdn_sort.hip); returns the buffer holding the result and
+// frees the other
+int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
+                       const unsigned long long **sorted);
+
 static int sort_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n,
                      unsigned bits, const unsigned long long **sorted_out, bool keep_both = false, unsigned begin_bit = 0) {
-  rocprim::double_buffer<unsigned long long> db(ka.p, kb.p);
-  size_t tmp_bytes = 0;
   if (bits > 64) bits = 64;
-  hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, db, (size_t)n, begin_bit, bits, 0);
-  if (e != hipSuccess) {
-    gdn_set_error("rocprim::radix_sort_keys(size query): %s", hipGetErrorString(e));
-    return GDN_ERR_HIP;
-  }
-  {
-    DevBuf<char> tmp;
-    GDN_TRY(tmp.alloc(tmp_bytes));
-    e = rocprim::radix_sort_keys((void *)tmp.p, tmp_bytes, db, (size_t)n, begin_bit, bits, 0);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
-    if (e != hipSuccess) {
-      gdn_set_error("rocprim::radix_sort_keys: %s", hipGetErrorString(e));
-      return GDN_ERR_HIP;
-    }
-  }
-  const unsigned long long *sorted = db.current();
+  const unsigned long long *sorted = nullptr;
+  GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, n, begin_bit, bits, &sorted));
   // free the non-current key buffer early (unless the buffers are a plan's scratch, reused by its next build)
   if (!keep_both) {
     if (sorted == ka.p) kb.release();

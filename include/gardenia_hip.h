@@ -161,6 +161,12 @@ int gdn_dev_free(void *d_ptr);
 int gdn_dev_upload(void *d_dst, const void *h_src, uint64_t bytes);
 int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes);
 
+/* Stable radix sort of n 64-bit keys by their bits [begin_bit, end_bit) on the device (gdn_sort.hip: the primitive under
+ * every graph and layout build here, where the reference's builds call std::sort and its kernels CUB,
+ * include/worklistc.h:6).  d_keys holds the input, d_tmp n more keys; *d_sorted is whichever of the two holds the
+ * result.  Blocking. */
+int gdn_sort_u64_dev(uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int32_t begin_bit, int32_t end_bit, uint64_t **d_sorted);
+
 /* ------------------------------------------------------------------------------------------
  * Resident graphs (the reference re-uploads per Solver call: src/bfs/linear_base.cu:42-49).
  * ---------------------------------------------------------------------------------------- */
