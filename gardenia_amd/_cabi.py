@@ -79,6 +79,7 @@ PROTOTYPES = {
     "gdn_dev_upload": (C.c_int, [_vp, _vp, _u64]),
     "gdn_dev_download": (C.c_int, [_vp, _vp, _u64]),
     "gdn_sort_u64_dev": (C.c_int, [_vp, _vp, _u64, _i32, _i32, _pp]),
+    "gdn_worklist_filter_dev": (C.c_int, [_vp, _i32, _i32, _vp, C.c_uint32, _vp, _vp]),
     "gdn_graph_upload": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
     "gdn_graph_wrap_dev": (C.c_int, [_i32, _u64, _vp, _vp, _pp]),
     "gdn_graph_free": (C.c_int, [_vp]),

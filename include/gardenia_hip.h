@@ -167,6 +167,13 @@ int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes);
  * result.  Blocking. */
 int gdn_sort_u64_dev(uint64_t *d_keys, uint64_t *d_tmp, uint64_t n, int32_t begin_bit, int32_t end_bit, uint64_t **d_sorted);
 
+/* The worklist push of the traversal kernels on its own (replaces Worklist::push / Worklist2::push_1item,
+ * include/worklistc.h:44-50, :66-89): every index i < n with d_flags[i] != 0 is appended to d_queue, one counter add per
+ * wavefront step (staged = 0) or per ~256 items collected in LDS (staged != 0).  *d_count = items pushed, including the
+ * ones beyond `capacity`, which are not stored and set *d_overflow (the reference drops them silently, :46-47).  Blocking. */
+int gdn_worklist_filter_dev(const int32_t *d_flags, int32_t n, int32_t staged, int32_t *d_queue, uint32_t capacity,
+                            uint32_t *d_count, uint32_t *d_overflow);
+
 /* ------------------------------------------------------------------------------------------
  * Resident graphs (the reference re-uploads per Solver call: src/bfs/linear_base.cu:42-49).
  * ---------------------------------------------------------------------------------------- */

@@ -16,9 +16,11 @@ pytestmark = pytest.mark.gpu
                                                 (700001, "fused")])
 def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
     env = dict(os.environ, OMP_NUM_THREADS="4")
-    if blocked == "fused":  # every BFS level and every forward level of BC inside the one-workgroup kernels
+    if blocked == "fused":  # every BFS level, every forward and every backward level of BC that fits, and PageRank's
+        # whole solve inside the one-workgroup kernels
         env.update(GDN_BFS_SMALL_NF="100000", GDN_BFS_SMALL_SCOUT="1000000000", GDN_BC_SMALL_NF="1000000",
-                   GDN_BC_SMALL_SCOUT="1000000000000", FUZZ_PLANS="1")
+                   GDN_BC_SMALL_SCOUT="1000000000000", GDN_BC_BACK_NF="1024", GDN_BC_BACK_SCOUT="1000000000000",
+                   GDN_PR_FUSED="1", GDN_PR_SMALL_M="16384", FUZZ_PLANS="1")
         blocked = False
     if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels
         env.update(FUZZ_PLANS="1")
