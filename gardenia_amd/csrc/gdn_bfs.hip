@@ -748,6 +748,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
   // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
   // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
+  int64_t bu_edge_div = 3;  // see the engine choice of a heavy level below (0 = off)
+  if (const char *e = gdn_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
   int64_t bu_stay = 256;
   if (const char *e = gdn_option("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
@@ -796,8 +798,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
         // engine of this heavy level: the sweep over all in-edges, or -- once few rows are left to discover --
         // the bottom-up step over the unvisited rows (omp_beamer.cc:13-31)
+        // the bottom-up step also wins while MANY rows are left when the frontier owns a large share p of all edges: an
+        // undiscovered row then finds a parent after ~1/p probes (Beamer's own criterion, omp_beamer.cc:130).  Measured on
+        // RMAT-27: p = 0.72 bottom-up 1.70 ms against the sweep's 2.80; p = 0.13 4.11 against 2.73 -- the costs cross
+        // near p = 1/4, the switch sits at 1/3
         const int64_t left = (int64_t)p.active_rows - visited_total;
-        const bool bottom_up = left * bu_frac <= (int64_t)p.active_rows;
+        const bool bottom_up = left * bu_frac <= (int64_t)p.active_rows || (bu_edge_div > 0 && scout_count * bu_edge_div >= (int64_t)g->nnz);
         if (bottom_up) {
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                              p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
