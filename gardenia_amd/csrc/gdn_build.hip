@@ -242,12 +242,9 @@ struct PbKeyVis {
   unsigned long long sentinel = 0;
   unsigned long long nvalid = 0;
   unsigned long long *nvalid_out = nullptr;
-  unsigned long long *append = nullptr;  // class-filtered layouts that are sorted on the whole key: see edge()
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     unsigned row = (unsigned)__shfl(v, owner, 64);
-    bool real = false;
-    unsigned long long key = 0;
     if (valid) {
       unsigned col = (unsigned)colidx[k];
       if (transposed) {
@@ -256,28 +253,16 @@ struct PbKeyVis {
         col = t;
       }
       if ((cls && (int)cls[col] != want) || (dcls && (int)dcls[row] != dwant)) {
-        if (!append) keys[k] = sentinel;
-      } else {
-        real = true;
-        nvalid++;
-        if (cs) col = (unsigned)cs[col];
-        if (cd) row = (unsigned)cd[row];
-        const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
-        const unsigned long long vl = row & ((1u << log_bin) - 1u), ul = col & ((1u << log_chunk) - 1u);
-        const unsigned long long in_tile = src_major ? ((ul << log_bin) | vl) : ((vl << log_chunk) | ul);
-        key = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | in_tile;
-        if (!append) keys[k] = key;
+        keys[k] = sentinel;
+        return;
       }
-    }
-    if (append) {  // the real keys only, packed in any order (one counter add per wave step): what a FULL sort wants
-      const unsigned long long mask = __ballot(real);
-      if (mask) {
-        const int leader = __ffsll((long long)mask) - 1;
-        unsigned long long base = 0;
-        if ((int)gdn_lane() == leader) base = atomicAdd(append, (unsigned long long)__popcll(mask));
-        base = __shfl(base, leader, 64);
-        if (real) keys[base + (unsigned long long)__popcll(mask & gdn_lanemask_lt())] = key;
-      }
+      nvalid++;
+      if (cs) col = (unsigned)cs[col];
+      if (cd) row = (unsigned)cd[row];
+      const unsigned long long chunk = col >> log_chunk, bin = row >> log_bin;
+      const unsigned long long vl = row & ((1u << log_bin) - 1u), ul = col & ((1u << log_chunk) - 1u);
+      const unsigned long long in_tile = src_major ? ((ul << log_bin) | vl) : ((vl << log_chunk) | ul);
+      keys[k] = (chunk << (bin_bits + log_bin + log_chunk)) | (bin << (log_bin + log_chunk)) | in_tile;
     }
   }
   __device__ __forceinline__ void finish() {
@@ -1114,19 +1099,6 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     vis.src_major = src_major ? 1 : 0;
     vis.sentinel = 1ull << key_bits;
     vis.nvalid_out = (src_class || dst_class) ? nvalid.p : nullptr;
-    // The keys were written in CSR order = (bin, row, chunk, source) ascending (rows ascending, columns ascending in a
-    // row; the compact indices are monotone): the tile order (chunk, bin, row, source) is a STABLE sort by the chunk field
-    // alone -- 11-12 bits instead of ~58, two radix passes instead of eight.  (A caller's row with unsorted columns only
-    // changes the order of one row's edges inside a tile, which nothing depends on.)  Not for the out-CSR form and the
-    // (source, row) tile order, whose inner order CSR order does not give: those sort the whole key -- of their OWN edges
-    // only when a class filter leaves most of the graph out (the hub / mid tiers: 9-24 % of RMAT-27 each).
-    const bool by_chunk_only = !rows_are_sources && !src_major && !gdn_option("GDN_PB_FULL_SORT");
-    DevBuf<unsigned long long> n_app;
-    if (!by_chunk_only && (src_class || dst_class)) {
-      GDN_TRY(n_app.alloc(1));
-      GDN_HIP(hipMemset(n_app.p, 0, 8));
-      vis.append = n_app.p;
-    }
     hipLaunchKernelGGL(pb_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, vis);
     hipLaunchKernelGGL(pb_keys_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
     GDN_HIP(hipGetLastError());
@@ -1144,11 +1116,14 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       p.nnz = n_use;
     }
     const unsigned long long *sorted = nullptr;
-    if (vis.append)  // packed real keys: no sentinel bit, n_use of them
-      GDN_TRY(sort_keys(ka, kb, n_use, key_bits, &sorted, /*keep_both=*/scratch != nullptr, 0u));
-    else
-      GDN_TRY(sort_keys(ka, kb, n, key_bits + ((src_class || dst_class) ? 1u : 0u), &sorted, /*keep_both=*/scratch != nullptr,
-                        by_chunk_only ? key_bits - (unsigned)chunk_bits : 0u));
+    // The keys were written in CSR order = (bin, row, chunk, source) ascending (rows ascending, columns ascending in a
+    // row; the compact indices are monotone): the tile order (chunk, bin, row, source) is a STABLE sort by the chunk field
+    // alone -- 11-12 bits instead of ~58, two radix passes instead of eight.  (A caller's row with unsorted columns only
+    // changes the order of one row's edges inside a tile, which nothing depends on.)  Not for the out-CSR form and the
+    // (source, row) tile order, whose inner order CSR order does not give.
+    const bool by_chunk_only = !rows_are_sources && !src_major && !gdn_option("GDN_PB_FULL_SORT");
+    GDN_TRY(sort_keys(ka, kb, n, key_bits + ((src_class || dst_class) ? 1u : 0u), &sorted, /*keep_both=*/scratch != nullptr,
+                      by_chunk_only ? key_bits - (unsigned)chunk_bits : 0u));
     if (n_use == 0) {
       hipLaunchKernelGGL(pb_fill_u64_kernel, dim3(gdn_nblocks(ntiles + 1)), dim3(GDN_BLOCK), 0, 0, tsu.p, ntiles + 1,
                          (eoff_t)0);
