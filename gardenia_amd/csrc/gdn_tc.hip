@@ -345,12 +345,13 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
   return count;
 }
 
-// Rows with more than TC_LIGHT out-neighbours are cut into work items of TC_SLICE neighbours: the work of a row
+// Rows with more than `light` out-neighbours are cut into work items of TC_SLICE neighbours: the work of a row
 // grows with du * (length of its neighbours' lists), and on a skewed graph a third of all list elements belongs to
 // a few thousand hub rows -- one wave per row left the kernel waiting for them (profiles/r01_tc_pmc.md).
-#ifndef TC_LIGHT
-#define TC_LIGHT 64
-#endif
+// (the limit is a launch argument: measured on symmetrized R-MAT, count kernel only, limit 64 / 256 / 512: scale 19
+// 2.00 / 1.85 / 2.17 ms, scale 21 10.4 / 10.08 / 9.76, scale 23 68.8 / 66.3 / 66.3 -- fewer set rebuilds and item grabs
+// with a higher limit, until whole rows on single waves make the tail of a small graph)
+#define TC_LIGHT_MIN 64
 #ifndef TC_SLICE
 #define TC_SLICE 512  // (256 -> 512: 2 % faster, fewer set rebuilds; 1024 the same)
 #endif
@@ -358,11 +359,11 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ nrowptr, int32_t row_lo, int32_t row_hi,
                       unsigned long long *__restrict__ items, unsigned capacity, unsigned *__restrict__ n_items,
-                      unsigned *__restrict__ overflow) {
+                      unsigned *__restrict__ overflow, unsigned light) {
   const unsigned u = (unsigned)row_lo + blockIdx.x * GDN_BLOCK + threadIdx.x;  // rows [row_lo, row_hi)
   eoff_t du = 0;  // neighbours of the row (what the items slice); a row without a set closes nothing
   if (u < (unsigned)row_hi && rowptr[u + 1] > rowptr[u]) du = nrowptr[u + 1] - nrowptr[u];
-  const unsigned n = du > TC_LIGHT ? (unsigned)((du + TC_SLICE - 1) / TC_SLICE) : 0u;
+  const unsigned n = du > light ? (unsigned)((du + TC_SLICE - 1) / TC_SLICE) : 0u;
   // wave-aggregated reservation: one atomic per wave
   const unsigned incl = gdn_wave_incl_scan(n);
   const unsigned tot = __shfl(incl, 63, 64);
@@ -387,7 +388,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
                 const vid_t *__restrict__ ncolidx, int32_t m,
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
                 unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
-                unsigned long long *__restrict__ total) {
+                unsigned long long *__restrict__ total, unsigned light) {
   __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
@@ -435,7 +436,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       const eoff_t nb0 = __shfl(np, (int)(u - u0), 64), ne0 = __shfl(np, (int)(u - u0) + 1, 64);
       const eoff_t dn = ne0 - nb0;
       // nothing to close without a set or a neighbour; heavy rows are done
-      if (ue == ub || dn == 0 || dn > TC_LIGHT) continue;
+      if (ue == ub || dn == 0 || dn > light) continue;
       if (nrowptr == rowptr && dn < 2) continue;  // u-centric: a single out-neighbour closes no triangle
       count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w]);
     }
@@ -570,7 +571,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
-  const uint64_t cap64 = dag->nnz / TC_LIGHT + 1024;  // a heavy row of du > TC_LIGHT ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT items
+  const uint64_t cap64 = dag->nnz / TC_LIGHT_MIN + 1024;  // a heavy row of du > light >= TC_LIGHT_MIN ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT_MIN items
   const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
   HostTimer tprep, tsolve;
   tprep.start();
@@ -585,12 +586,14 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   if (row_hi <= row_lo) return GDN_OK;
   tsolve.start();  // src/tc/gpu_base.cu:52-58
   const uint64_t rows = (uint64_t)(row_hi - row_lo);
+  unsigned light = dag->m >= (1 << 21) ? 512u : 256u;  // rows up to this many neighbours: one wave, whole (see TC_LIGHT_MIN)
+  if (const char *e = gdn_option("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
   hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
-                     row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3);
+                     row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3, light);
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
-                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p);
+                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light);
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
