@@ -149,6 +149,24 @@ __device__ __forceinline__ unsigned gdn_lane() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
+// Ops with `static constexpr bool kSkippable = true` and a member `const unsigned *skip` (PageRank): a launch whose
+// *skip is non-zero returns at once -- the host queues a BATCH of iterations without reading the L1 change back after
+// each, a one-thread kernel behind every iteration sets the flag at convergence (gdn_pr.hip), and the iterations queued
+// behind it leave the state alone.  Other ops: no code at all.
+template <class T, class = void>
+struct GdnSkippable {
+  static constexpr bool value = false;
+};
+template <class T>
+struct GdnSkippable<T, decltype((void)T::kSkippable)> {
+  static constexpr bool value = T::kSkippable;
+};
+template <class Op>
+__device__ __forceinline__ bool gdn_skip_launch(const Op &op) {
+  if constexpr (GdnSkippable<Op>::value) return op.skip != nullptr && *op.skip != 0u;
+  return false;
+}
+
 // Level boundary inside ONE workgroup (the fused light-level kernels): all its waves go through the same vector L1 and the
 // same L2, so waiting for the outstanding accesses and a barrier orders them.  __threadfence() is the device-scope form --
 // buffer_wbl2 sc1 + buffer_inv sc1 on gfx950: a write-back of the L2 and an invalidate of the L1 per level, microseconds

@@ -78,6 +78,7 @@ mp_tile_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ coli
                const int32_t *__restrict__ tile_row, uint64_t total_items,
                float *__restrict__ tile_carry, float *__restrict__ tile_head,
                double *__restrict__ partial, Op op) {
+  if (gdn_skip_launch(op)) return;
   __shared__ uint16_t s_rowend[MP_TILE + 2];
   __shared__ float s_val[MP_TILE + MP_TILE / 32];
   __shared__ float s_wave_v[GDN_WAVES_PER_BLOCK];
@@ -216,6 +217,7 @@ __global__ void __launch_bounds__(GDN_BLOCK)
 mp_fixup_kernel(const eoff_t *__restrict__ rowptr, const int32_t *__restrict__ tile_row,
                 uint32_t ntiles, const float *__restrict__ tile_carry,
                 const float *__restrict__ tile_head, double *__restrict__ partial_out, Op op) {
+  if (gdn_skip_launch(op)) return;
   __shared__ double s_red[GDN_WAVES_PER_BLOCK];
   const uint32_t t = blockIdx.x * GDN_BLOCK + threadIdx.x;
   double d = 0.0;

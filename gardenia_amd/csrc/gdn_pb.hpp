@@ -152,6 +152,7 @@ struct PbTierRefresh {  // kernel argument of phase A (PageRank): the tier table
   float *val[PB_MAX_REC_TIERS];           // slots[t] entries: the code of x[ids[k]] for k < n[t], 0 behind
   unsigned n[PB_MAX_REC_TIERS], slots[PB_MAX_REC_TIERS];
   int ntiers = 0;
+  const unsigned *skip = nullptr;  // see GdnSkippable (gdn_common.hpp): a non-zero word = this launch does nothing
 };
 int pb_pick_tiers(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
                   unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid);
@@ -481,6 +482,7 @@ pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, c
                  unsigned long long *__restrict__ hr_partial = nullptr, unsigned *__restrict__ errflag = nullptr,
                  unsigned pad_slot = 0,  // PbPlan::chunk_slots (0 = 2^log_chunk)
                  PbTierRefresh tiers = PbTierRefresh()) {
+  if (tiers.skip && *tiers.skip) return;
   extern __shared__ __attribute__((aligned(16))) float s_x[];
   // every workgroup first refreshes its share of the tier tables phase B reads (a few hundred entries: three tiny
   // launches between A and B otherwise)
@@ -791,6 +793,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const unsigned long long *__restrict__ hr_total = nullptr,
                      // mid tiers: per bin one stream of (source index, row) records per tier, values from the tier's table
                      PbMidArgs mid = PbMidArgs()) {
+  if (gdn_skip_launch(op)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
   __shared__ unsigned s_bits[PB_THREADS], s_pref[PB_THREADS], s_scr[PB_WAVES + 1];

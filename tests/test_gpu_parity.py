@@ -1404,3 +1404,34 @@ def test_pr_fused_solve(orc, monkeypatch):
         st = solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), s)
         assert st["iterations"] == it
         np.testing.assert_allclose(s, want, rtol=REL_TOL, atol=0)
+
+
+@pytest.mark.parametrize("layout", ["csr", "pb"])
+def test_pr_batched_loop_stops_where_the_per_iteration_loop_stops(orc, monkeypatch, layout):
+    """gdn_pr queues its iterations in batches and tests convergence on the device (pr_check_kernel + GdnSkippable): the
+    scores are the bits of the per-iteration loop (GDN_PR_BATCH=1) for every batch size, the trace and the iteration
+    count are the oracle's, and max_iter is honoured inside a batch."""
+    monkeypatch.setenv("GDN_PR_LAYOUT", layout)
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    for g in (graphio.rmat_graph(13, 8, seed=2), graphio.rmat_graph(16, 16, seed=3)):
+        gi = graphio.transpose(g)
+        G = solvers.Graph(csr=g, in_csr=gi)
+        want, it, trace = orc.pr(gi, g.degrees())
+        ref = None
+        for batch in ("1", "3", "8", "64"):
+            monkeypatch.setenv("GDN_PR_BATCH", batch)
+            s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+            st = solvers.PRSolver(G, s)
+            assert st["iterations"] == it and len(st["trace"]) == len(trace)
+            np.testing.assert_allclose(st["trace"], trace, rtol=1e-3, atol=1e-9)
+            np.testing.assert_allclose(s, want, rtol=REL_TOL, atol=0)
+            if ref is None:
+                ref = (s, st["trace"])
+            else:
+                assert np.array_equal(ref[0].view(np.uint32), s.view(np.uint32))
+                assert np.array_equal(np.asarray(ref[1]), np.asarray(st["trace"]))
+        for batch in ("1", "8"):
+            monkeypatch.setenv("GDN_PR_BATCH", batch)
+            s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+            st = solvers.PRSolver(G, s, max_iter=5)
+            assert len(st["trace"]) == 5 and st["iterations"] == 6

@@ -8,6 +8,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gardenia_amd import graphio, solvers  # noqa: E402
 
+# GDN_PR_BATCH=1 in the environment: the loop reads the L1 change back after every iteration (round 1's form)
 for scale in [int(a) for a in sys.argv[1:]] or [10, 14, 16, 18]:
     g = graphio.rmat_graph(scale, 16, seed=5)
     G = solvers.Graph(csr=g, need_reverse=True)
