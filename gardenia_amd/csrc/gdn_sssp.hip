@@ -606,87 +606,83 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
       status = 2;
       break;
     }
-    vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
+    // One pass per bucket change where the reference's scan needs two (the minimum over FAR, then the split): the split
+    // is run at once for the bucket right BEHIND the old one -- on a graph whose buckets are dense (a road-like lattice:
+    // tens of thousands of them) that IS the next non-empty bucket -- and collects the minimum of what it keeps on the
+    // way; only when nothing moved does a second pass split at the bucket of that minimum (omp_base.cc:66-72 finds the
+    // same bucket either way).
     vid_t *near_in = near_sel ? near1 : near0;
-    if (threadIdx.x == 0) {
-      s_min = GDN_DIST_INF;
-      s_nn = 0u;
-      s_nf = 0u;
-      s_edges = 0ull;
-    }
-    __syncthreads();
-    {
-      const int32_t hi = clamp(thr_hi);
-      int32_t d = GDN_DIST_INF;
-      for (unsigned i0 = threadIdx.x; i0 < n_far; i0 += 4 * SSSP_SMALL_THREADS) {  // 4 entries in flight per thread
-        vid_t w[4];
-        int32_t x[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const unsigned i = i0 + (unsigned)r * SSSP_SMALL_THREADS;
-          w[r] = i < n_far ? sssp_ld(far_cur + i) : -1;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; r++) x[r] = w[r] >= 0 ? __hip_atomic_load(dist + w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : GDN_DIST_INF;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-          if (x[r] >= hi && x[r] < d) d = x[r];  // stale entries are ignored
+    long long spec_lo = thr_hi, spec_hi = thr_hi + delta;
+    for (;;) {
+      vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
+      if (threadIdx.x == 0) {
+        s_min = GDN_DIST_INF;
+        s_nn = 0u;
+        s_nf = 0u;
+        s_edges = 0ull;
       }
+      __syncthreads();
+      {
+        const int32_t ohi = clamp(thr_hi), nhi = clamp(spec_hi);
+        unsigned long long deg_sum = 0;
+        int32_t dmin = GDN_DIST_INF;
+        for (unsigned i0 = wave * 64u; i0 < n_far; i0 += 4 * SSSP_SMALL_THREADS) {  // wave-uniform bounds
+          vid_t w[4];
+          int32_t d[4];
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int32_t t = __shfl_xor(d, o, 64);
-        d = t < d ? t : d;
-      }
-      if (lane == 0 && d != GDN_DIST_INF) atomicMin(&s_min, d);
-    }
-    __syncthreads();
-    const int32_t mn = s_min;
-    if (mn == GDN_DIST_INF) {  // only stale entries were left
-      n_far = 0;
-      status = 0;
-      break;
-    }
-    const long long old_hi = thr_hi;
-    thr_lo = ((long long)mn / delta) * (long long)delta;
-    thr_hi = thr_lo + delta;
-    ++buckets;
-    {
-      const int32_t ohi = clamp(old_hi), nhi = clamp(thr_hi);
-      unsigned long long deg_sum = 0;
-      for (unsigned i0 = wave * 64u; i0 < n_far; i0 += 4 * SSSP_SMALL_THREADS) {  // wave-uniform bounds
-        vid_t w[4];
-        int32_t d[4];
+          for (int r = 0; r < 4; r++) {
+            const unsigned i = i0 + lane + (unsigned)r * SSSP_SMALL_THREADS;
+            w[r] = i < n_far ? sssp_ld(far_cur + i) : -1;
+          }
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const unsigned i = i0 + lane + (unsigned)r * SSSP_SMALL_THREADS;
-          w[r] = i < n_far ? sssp_ld(far_cur + i) : -1;
-        }
+          for (int r = 0; r < 4; r++) d[r] = w[r] >= 0 ? __hip_atomic_load(dist + w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
 #pragma unroll
-        for (int r = 0; r < 4; r++) d[r] = w[r] >= 0 ? __hip_atomic_load(dist + w[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {  // (wave-uniform trip count: the reservations below are convergent)
-          const bool live = w[r] >= 0;
-          const bool to_far = live && d[r] >= nhi;
-          const bool to_near = live && !to_far && d[r] >= ohi;
-          if (live && !to_far) __hip_atomic_store(in_far + w[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned pf = sssp_lds_slot(&s_nf, to_far);
-          if (to_far) sssp_st(far_nxt + pf, w[r]);
-          const unsigned pn = sssp_lds_slot(&s_nn, to_near);
-          if (to_near) {
-            sssp_st(near_in + pn, w[r]);
-            deg_sum += rowptr[w[r] + 1] - rowptr[w[r]];
+          for (int r = 0; r < 4; r++) {  // (wave-uniform trip count: the reservations below are convergent)
+            const bool live = w[r] >= 0;
+            const bool to_far = live && d[r] >= nhi;
+            const bool to_near = live && !to_far && d[r] >= ohi;  // below the old bucket: a stale entry, dropped
+            if (live && !to_far) __hip_atomic_store(in_far + w[r], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned pf = sssp_lds_slot(&s_nf, to_far);
+            if (to_far) {
+              sssp_st(far_nxt + pf, w[r]);
+              dmin = d[r] < dmin ? d[r] : dmin;
+            }
+            const unsigned pn = sssp_lds_slot(&s_nn, to_near);
+            if (to_near) {
+              sssp_st(near_in + pn, w[r]);
+              deg_sum += rowptr[w[r] + 1] - rowptr[w[r]];
+            }
           }
         }
+        deg_sum = gdn_wave_sum(deg_sum);
+        if (lane == 0 && deg_sum) atomicAdd(&s_edges, deg_sum);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const int32_t t = __shfl_xor(dmin, o, 64);
+          dmin = t < dmin ? t : dmin;
+        }
+        if (lane == 0 && dmin != GDN_DIST_INF) atomicMin(&s_min, dmin);
       }
-      deg_sum = gdn_wave_sum(deg_sum);
-      if (lane == 0 && deg_sum) atomicAdd(&s_edges, deg_sum);
+      gdn_wg_level_sync();
+      const unsigned nn = s_nn, nf = s_nf;
+      const int32_t mn = s_min;
+      near_edges = s_edges;
+      far_sel ^= 1u;
+      n_far = nf;
+      __syncthreads();
+      if (nn > 0 || nf == 0) {
+        if (nn > 0) {
+          thr_lo = spec_lo;
+          thr_hi = spec_hi;
+          ++buckets;
+        }
+        n_near = nn;
+        break;
+      }
+      thr_hi = spec_hi;  // that bucket was empty and everything kept lies behind it: nothing is stale against it
+      spec_lo = ((long long)mn / delta) * (long long)delta;
+      spec_hi = spec_lo + delta;
     }
-    gdn_wg_level_sync();
-    n_near = s_nn;
-    n_far = s_nf;
-    near_edges = s_edges;
-    far_sel ^= 1u;
-    __syncthreads();
     if (n_near > max_v || near_edges > max_e) {
       status = 1;
       break;
@@ -856,37 +852,15 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       status = 2;
       break;
     }
-    vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
+    // one pass per bucket change wherever the bucket behind the old one is not empty (see sssp_small_kernel)
     vid_t *near_in = near_sel ? near1 : near0;
-    {
+    long long spec_lo = thr_hi, spec_hi = thr_hi + delta;
+    for (;;) {
+      vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
       SsspCoopCnt *cur = begin_phase();
-      const int32_t hi = clamp(thr_hi);
-      int32_t d = GDN_DIST_INF;
-      for (unsigned i = gt; i < n_far; i += nt) {
-        const int32_t x = __hip_atomic_load(dist + sssp_ld(far_cur + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (x >= hi && x < d) d = x;  // stale entries are ignored
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const int32_t t = __shfl_xor(d, o, 64);
-        d = t < d ? t : d;
-      }
-      if (lane == 0 && d != GDN_DIST_INF) atomicMin(&cur->min_far, d);
-      gdn_grid_barrier(bar, gridDim.x);
-      ph++;
-      const int32_t mn = __hip_atomic_load(&cur->min_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (mn == GDN_DIST_INF) {  // only stale entries were left
-        n_far = 0;
-        status = 0;
-        break;
-      }
-      const long long old_hi = thr_hi;
-      thr_lo = ((long long)mn / delta) * (long long)delta;
-      thr_hi = thr_lo + delta;
-      ++buckets;
-      cur = begin_phase();
-      const int32_t ohi = clamp(old_hi), nhi = clamp(thr_hi);
+      const int32_t ohi = clamp(thr_hi), nhi = clamp(spec_hi);
       unsigned long long deg_sum = 0;
+      int32_t dmin = GDN_DIST_INF;
       for (unsigned i0 = gt - lane; i0 < n_far; i0 += nt) {
         const unsigned i = i0 + lane;
         vid_t w = -1;
@@ -898,7 +872,10 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
         const bool live = w >= 0, to_far = live && dd >= nhi, to_near = live && !to_far && dd >= ohi;
         if (live && !to_far) __hip_atomic_store(in_far + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned pf = sssp_global_slot(&cur->nf, to_far);
-        if (to_far) sssp_st(far_nxt + pf, w);
+        if (to_far) {
+          sssp_st(far_nxt + pf, w);
+          dmin = dd < dmin ? dd : dmin;
+        }
         const unsigned pn = sssp_global_slot(&cur->nn, to_near);
         if (to_near) {
           sssp_st(near_in + pn, w);
@@ -907,12 +884,32 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       }
       deg_sum = gdn_wave_sum(deg_sum);
       if (lane == 0 && deg_sum) atomicAdd(&cur->edges, deg_sum);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const int32_t t = __shfl_xor(dmin, o, 64);
+        dmin = t < dmin ? t : dmin;
+      }
+      if (lane == 0 && dmin != GDN_DIST_INF) atomicMin(&cur->min_far, dmin);
       gdn_grid_barrier(bar, gridDim.x);
       ph++;
-      n_near = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      n_far = __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned nn = __hip_atomic_load(&cur->nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned nf = __hip_atomic_load(&cur->nf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int32_t mn = __hip_atomic_load(&cur->min_far, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       near_edges = __hip_atomic_load(&cur->edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       far_sel ^= 1u;
+      n_far = nf;
+      if (nn > 0 || nf == 0) {
+        if (nn > 0) {
+          thr_lo = spec_lo;
+          thr_hi = spec_hi;
+          ++buckets;
+        }
+        n_near = nn;
+        break;
+      }
+      thr_hi = spec_hi;  // that bucket was empty and everything kept lies behind it
+      spec_lo = ((long long)mn / delta) * (long long)delta;
+      spec_hi = spec_lo + delta;
     }
     if (n_near > max_v || near_edges > max_e) {
       status = 1;
