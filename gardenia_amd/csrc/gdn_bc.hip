@@ -96,6 +96,43 @@ bc_fwd_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BcFwdVis vi
   vis.finish();
 }
 
+// ---- forward levels queued in BATCHES (mid-size levels of a high-diameter graph: a lattice level of a few thousand
+// vertices is two launches and a blocking read of its size, ~25 us): the level kernels take the bounds of their level
+// from a device array the previous level's closing kernel has written, so the host queues several levels before it
+// reads anything back; a level behind the last one finds itself empty.  Level j of the batch = order[tails[j], tails[j+1]).
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_fwd_lvl_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ order, const unsigned *__restrict__ tails, int j,
+                  ExpBigList big, BcFwdVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  const unsigned l0 = tails[j], nf = tails[j + 1] - l0;
+  vis.stage.strip = s_stage[threadIdx.x >> 6];
+  vis.stage.n = 0;
+  for (unsigned base = blockIdx.x * GDN_BLOCK; base < nf; base += gridDim.x * GDN_BLOCK) {
+    const unsigned i = base + threadIdx.x;
+    eoff_t b = 0, e = 0;
+    vid_t v = 0;
+    vis.pc_src = 0;
+    if (i < nf) {
+      v = order[l0 + i];
+      b = rowptr[v];
+      e = rowptr[v + 1];
+      vis.pc_src = vis.pc[v];
+    }
+    vis.big = 0;
+    gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
+  }
+  vis.finish();
+}
+
+__global__ void bc_fwd_lvl_end_kernel(BcCounters *cnt, unsigned *tails, int j, unsigned cap) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const unsigned t = cnt->tail;
+    tails[j + 2] = t < cap ? t : cap;
+    cnt->big_count = 0;
+  }
+}
+
 // ---- fused light levels of the forward phase (cf. bfs_td_small_kernel, gdn_bfs.hip): ONE workgroup runs consecutive
 // levels while the frontier stays small -- a lane per short row, a wave per longer one, the level boundary is a
 // __syncthreads() -- and
@@ -1033,6 +1070,14 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   if (const char *e = gdn_option("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   DevBuf<BcSmallOut> small_out;
   if (small_nf) GDN_TRY(small_out.alloc(1));
+  // levels of up to batch_nf vertices are queued fwd_batch at a time (1 = every level read back, the form for heavy levels)
+  int fwd_batch = 8;
+  unsigned batch_nf = 65536;
+  if (const char *e = gdn_option("GDN_BC_FWD_BATCH")) fwd_batch = atoi(e) > 0 ? atoi(e) : 1;  // tuning / test knobs
+  if (const char *e = gdn_option("GDN_BC_BATCH_NF")) batch_nf = (unsigned)atoi(e);
+  DevBuf<unsigned> d_tails;
+  GDN_TRY(d_tails.alloc((size_t)fwd_batch + 2));
+  int mid_streak = 0;
   for (int32_t level = 0;;) {
     const unsigned l0 = lp[(size_t)level], nf = lp[(size_t)level + 1] - l0;
     if (nf == 0) break;
@@ -1063,6 +1108,34 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
     vis.next_level = level + 1;
     vis.pc_src = 0;
     vis.big = 0;
+    // (only behind a run of such levels: an R-MAT search passes through one mid-size level on its way to millions)
+    mid_streak = nf <= batch_nf ? mid_streak + 1 : 0;
+    if (fwd_batch > 1 && nf <= batch_nf && mid_streak > 4) {
+      // ---- a batch of levels without a read-back in between (bc_fwd_lvl_kernel)
+      const unsigned seed[2] = {l0, l0 + nf};
+      GDN_HIP(hipMemcpyAsync(d_tails.p, seed, sizeof(seed), hipMemcpyHostToDevice, 0));
+      unsigned blocks = gdn_nblocks((uint64_t)nf * 4u);
+      blocks = blocks < 64u ? 64u : (blocks > 2048u ? 2048u : blocks);
+      for (int j = 0; j < fwd_batch; j++) {
+        vis.next_level = level + 1 + j;
+        hipLaunchKernelGGL(bc_fwd_lvl_kernel, dim3(blocks), dim3(GDN_BLOCK), 0, 0, g->rowptr, order.p, d_tails.p, j, big, vis);
+        hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(256), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+        hipLaunchKernelGGL(bc_fwd_lvl_end_kernel, dim3(1), dim3(64), 0, 0, cnt.p, d_tails.p, j, (unsigned)m);
+      }
+      std::vector<unsigned> ht((size_t)fwd_batch + 2);
+      GDN_HIP(hipMemcpy(ht.data(), d_tails.p, ht.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+      GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
+      if (h.overflow) {
+        gdn_set_error("gdn_bc: device worklist overflow");
+        return GDN_ERR_OVERFLOW;
+      }
+      for (int j = 0; j < fwd_batch; j++) {  // the tails behind the levels that ran; an empty level ends the search
+        lp.push_back(ht[(size_t)j + 2]);
+        level++;
+        if (ht[(size_t)j + 2] == ht[(size_t)j + 1]) break;
+      }
+      continue;
+    }
     hipLaunchKernelGGL(bc_fwd_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, order.p + l0, nf, big, vis);
     hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
     GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
