@@ -1053,6 +1053,16 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   GDN_HIP(hipMemsetAsync(pc.p, 0, (size_t)m * 4, 0));
   GDN_HIP(hipMemsetAsync(mx.p, 0, 4, 0));
   hipLaunchKernelGGL(bc_seed_kernel, dim3(1), dim3(64), 0, 0, source, depth.p, pc.p, order.p, cnt.p);
+  // the longest row decides which per-level launches exist at all: without a row of EXP_BIG edges no level has big-row
+  // work items, without one of BC_BLOCK_ROW no backward level has rows for the workgroup kernel -- a road-like graph then
+  // runs one launch per level and phase instead of two and a counter reset
+  DevBuf<unsigned long long> d_maxdeg;
+  GDN_TRY(d_maxdeg.alloc(1));
+  GDN_HIP(hipMemsetAsync(d_maxdeg.p, 0, 8, 0));
+  hipLaunchKernelGGL(bc_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, d_maxdeg.p);
+  unsigned long long max_deg = 0;
+  GDN_HIP(hipMemcpy(&max_deg, d_maxdeg.p, 8, hipMemcpyDeviceToHost));
+  const bool fwd_big = max_deg >= EXP_BIG, back_big = max_deg >= BC_BLOCK_ROW;
   // forward: level d = order[lp[d] .. lp[d+1])
   std::vector<unsigned> lp;
   lp.push_back(0);
@@ -1119,7 +1129,7 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
       for (int j = 0; j < fwd_batch; j++) {
         vis.next_level = level + 1 + j;
         hipLaunchKernelGGL(bc_fwd_lvl_kernel, dim3(blocks), dim3(GDN_BLOCK), 0, 0, g->rowptr, order.p, d_tails.p, j, big, vis);
-        hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(256), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+        if (fwd_big) hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(256), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
         hipLaunchKernelGGL(bc_fwd_lvl_end_kernel, dim3(1), dim3(64), 0, 0, cnt.p, d_tails.p, j, (unsigned)m);
       }
       std::vector<unsigned> ht((size_t)fwd_batch + 2);
@@ -1137,14 +1147,14 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
       continue;
     }
     hipLaunchKernelGGL(bc_fwd_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, order.p + l0, nf, big, vis);
-    hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+    if (fwd_big) hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
     GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
     if (h.overflow) {
       gdn_set_error("gdn_bc: device worklist overflow");
       return GDN_ERR_OVERFLOW;
     }
     lp.push_back(h.tail);
-    GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
+    if (fwd_big) GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
     level++;
   }
   const int32_t nlev = (int32_t)lp.size() - 2;  // non-empty levels 0 .. nlev-1
@@ -1164,7 +1174,12 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   }
   for (int32_t d = nlev - 2; d >= 0; d--) {
     const unsigned l0 = lp[(size_t)d], nf = lp[(size_t)d + 1] - l0;
-    if (back_nf && nf <= back_nf) {
+    // (the fused kernel ends in a blocking read of where it stopped: worth it for a RUN of light levels -- the level
+    // sizes are all known here -- not for one between two larger ones, which a single queued launch serves in ~5 us)
+    int run = 0;
+    if (back_nf && nf <= back_nf)
+      for (int32_t dd = d; dd >= 0 && run < 8 && lp[(size_t)dd + 1] - lp[(size_t)dd] <= back_nf; dd--) run++;
+    if (run >= 8 || (run > 0 && run == d + 1)) {
       hipLaunchKernelGGL(bc_back_small_kernel, dim3(1), dim3(BC_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, order.p, d_lp.p, d, back_nf,
                          back_scout, rec.p, d_scores, d_next.p);
       int32_t next = d;
@@ -1176,9 +1191,11 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
     }
     hipLaunchKernelGGL(bc_back_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, order.p + l0, nf,
                        rec.p, d_scores, d + 1, big_rows.p, cnt.p, rowcap);
-    hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, big_rows.p, cnt.p, rec.p,
-                       d_scores, d + 1, rowcap);
-    GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
+    if (back_big) {
+      hipLaunchKernelGGL(bc_back_big_kernel, dim3(512), dim3(BC_BIG_THREADS), 0, 0, g->rowptr, g->colidx, big_rows.p, cnt.p, rec.p,
+                         d_scores, d + 1, rowcap);
+      GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
+    }
   }
   hipLaunchKernelGGL(bc_max_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_scores, m, mx.p);
   hipLaunchKernelGGL(bc_normalize_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, d_scores, m, mx.p);
