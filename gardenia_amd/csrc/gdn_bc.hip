@@ -40,6 +40,10 @@ struct BcFwdVis {
   int32_t next_level;
   int32_t pc_src;  // path count of this lane's frontier vertex (big items: of the item's vertex, same in every lane)
   int big;
+  // batched levels (bc_fwd_lvl_kernel): the next level is appended at q[*qcount ...] instead of order[cnt->tail ...]
+  vid_t *q = nullptr;
+  unsigned *qcount = nullptr;
+  unsigned qcap = 0;
   GdnWlStage stage;
   __device__ __forceinline__ void begin_big(vid_t v) {
     big = 1;
@@ -59,9 +63,9 @@ struct BcFwdVis {
       }
       if (d == next_level) atomicAdd(&pc[dst], ps);  // src/bc/omp_base.cc:39-42
     }
-    gdn_wl_push_staged(stage, order, &cnt->tail, cap, claim, dst, &cnt->overflow);
+    gdn_wl_push_staged(stage, q ? q : order, q ? qcount : &cnt->tail, q ? qcap : cap, claim, dst, &cnt->overflow);
   }
-  __device__ __forceinline__ void finish() { gdn_wl_flush(stage, order, &cnt->tail, cap, &cnt->overflow); }
+  __device__ __forceinline__ void finish() { gdn_wl_flush(stage, q ? q : order, q ? qcount : &cnt->tail, q ? qcap : cap, &cnt->overflow); }
 };
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -101,11 +105,18 @@ bc_fwd_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BcFwdVis vi
 // from a device array the previous level's closing kernel has written, so the host queues several levels before it
 // reads anything back; a level behind the last one finds itself empty.  Level j of the batch = order[tails[j], tails[j+1]).
 __global__ void __launch_bounds__(GDN_BLOCK)
-bc_fwd_lvl_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ order, const unsigned *__restrict__ tails, int j,
-                  ExpBigList big, BcFwdVis vis) {
+bc_fwd_lvl_kernel(const eoff_t *__restrict__ rowptr, vid_t *order, unsigned *counts /* [0] start of level 0 of the batch, [1 + j] size of level j */,
+                  int j, ExpBigList big, BcFwdVis vis) {
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
   __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
-  const unsigned l0 = tails[j], nf = tails[j + 1] - l0;
+  unsigned l0 = counts[0];
+  for (int i = 0; i < j; i++) l0 += counts[1 + i];  // the levels in front of this one are complete
+  const unsigned nf = counts[1 + j];
+  // the vertices this level discovers go behind it, counted in counts[2 + j] (zero when the batch was queued): no closing
+  // kernel between two levels
+  vis.q = order + l0 + nf;
+  vis.qcount = counts + 2 + j;
+  vis.qcap = vis.cap - (l0 + nf);
   vis.stage.strip = s_stage[threadIdx.x >> 6];
   vis.stage.n = 0;
   for (unsigned base = blockIdx.x * GDN_BLOCK; base < nf; base += gridDim.x * GDN_BLOCK) {
@@ -125,12 +136,26 @@ bc_fwd_lvl_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ o
   vis.finish();
 }
 
-__global__ void bc_fwd_lvl_end_kernel(BcCounters *cnt, unsigned *tails, int j, unsigned cap) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const unsigned t = cnt->tail;
-    tails[j + 2] = t < cap ? t : cap;
-    cnt->big_count = 0;
-  }
+// big-row work items of a batched level (same queue indirection), and the reset of their counter for the next level
+__global__ void __launch_bounds__(GDN_BLOCK)
+bc_fwd_lvl_big_kernel(const eoff_t *__restrict__ rowptr, unsigned *counts, int j, ExpBigList big, BcFwdVis vis) {
+  __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  unsigned l0 = counts[0];
+  for (int i = 0; i < j; i++) l0 += counts[1 + i];
+  const unsigned nf = counts[1 + j];
+  vis.q = vis.order + l0 + nf;
+  vis.qcount = counts + 2 + j;
+  vis.qcap = vis.cap - (l0 + nf);
+  vis.stage.strip = s_stage[threadIdx.x >> 6];
+  vis.stage.n = 0;
+  vis.big = 1;
+  vis.pc_src = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+  vis.finish();
+}
+
+__global__ void bc_fwd_lvl_end_kernel(BcCounters *cnt) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) cnt->big_count = 0;
 }
 
 // ---- fused light levels of the forward phase (cf. bfs_td_small_kernel, gdn_bfs.hip): ONE workgroup runs consecutive
@@ -1122,22 +1147,33 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
     mid_streak = nf <= batch_nf ? mid_streak + 1 : 0;
     if (fwd_batch > 1 && nf <= batch_nf && mid_streak > 4) {
       // ---- a batch of levels without a read-back in between (bc_fwd_lvl_kernel)
-      const unsigned seed[2] = {l0, l0 + nf};
-      GDN_HIP(hipMemcpyAsync(d_tails.p, seed, sizeof(seed), hipMemcpyHostToDevice, 0));
+      std::vector<unsigned> hc((size_t)fwd_batch + 2, 0u);  // [0] start, [1] size of the first level, the rest zero
+      hc[0] = l0;
+      hc[1] = nf;
+      GDN_HIP(hipMemcpyAsync(d_tails.p, hc.data(), hc.size() * sizeof(unsigned), hipMemcpyHostToDevice, 0));
       unsigned blocks = gdn_nblocks((uint64_t)nf * 4u);
       blocks = blocks < 64u ? 64u : (blocks > 2048u ? 2048u : blocks);
       for (int j = 0; j < fwd_batch; j++) {
         vis.next_level = level + 1 + j;
         hipLaunchKernelGGL(bc_fwd_lvl_kernel, dim3(blocks), dim3(GDN_BLOCK), 0, 0, g->rowptr, order.p, d_tails.p, j, big, vis);
-        if (fwd_big) hipLaunchKernelGGL(bc_fwd_big_kernel, dim3(256), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
-        hipLaunchKernelGGL(bc_fwd_lvl_end_kernel, dim3(1), dim3(64), 0, 0, cnt.p, d_tails.p, j, (unsigned)m);
+        if (fwd_big) {
+          hipLaunchKernelGGL(bc_fwd_lvl_big_kernel, dim3(256), dim3(GDN_BLOCK), 0, 0, g->rowptr, d_tails.p, j, big, vis);
+          hipLaunchKernelGGL(bc_fwd_lvl_end_kernel, dim3(1), dim3(64), 0, 0, cnt.p);
+        }
       }
-      std::vector<unsigned> ht((size_t)fwd_batch + 2);
-      GDN_HIP(hipMemcpy(ht.data(), d_tails.p, ht.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+      GDN_HIP(hipMemcpy(hc.data(), d_tails.p, hc.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
       GDN_HIP(hipMemcpy(&h, cnt.p, sizeof(h), hipMemcpyDeviceToHost));
       if (h.overflow) {
         gdn_set_error("gdn_bc: device worklist overflow");
         return GDN_ERR_OVERFLOW;
+      }
+      std::vector<unsigned> ht((size_t)fwd_batch + 2);  // ht[j + 1] = end of level j of the batch
+      ht[0] = l0;
+      for (int j = 0; j <= fwd_batch; j++) ht[(size_t)j + 1] = ht[(size_t)j] + hc[(size_t)j + 1];
+      {  // the per-level kernels and the fused one append at cnt->tail
+        const unsigned t = ht[(size_t)fwd_batch + 1];
+        GDN_HIP(hipMemcpyAsync(&cnt.p->tail, &t, sizeof(unsigned), hipMemcpyHostToDevice, 0));
+        GDN_HIP(hipStreamSynchronize(0));
       }
       for (int j = 0; j < fwd_batch; j++) {  // the tails behind the levels that ran; an empty level ends the search
         lp.push_back(ht[(size_t)j + 2]);
