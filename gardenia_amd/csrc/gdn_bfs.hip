@@ -603,6 +603,240 @@ bfs_pb_accumulate_kernel(int32_t m, int log_bin, const eoff_t *__restrict__ bin_
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// BINNED top-down level: propagation blocking made on the fly, for a frontier that owns between ~1/256 and 1/3 of the
+// edges.  The plain top-down step pays a random access per edge (the visited word) and three per discovery; the dense
+// sweep streams ALL edges whatever the frontier is (RMAT-27: 2.7 ms); the bottom-up step needs the frontier to own a
+// third of the edges.  Here only the frontier's out-edges move, all of it as streams:
+//   bfs_btd_bin_kernel    the load-balanced expansion of the frontier (gdn_expand.hpp); a wave step's destinations are
+//                         grouped by bin (dst >> logb: a ballot match), each group reserves room in its bin's list with one
+//                         atomic and writes its ids side by side.  BFS_BTD_SUB lists per bin, one per XCD, keep the
+//                         reservation counters off each other's cache lines and every list inside one L2.
+//   bfs_btd_apply_kernel  one workgroup per bin: its lists are streamed once, the ids set bits of the bin's slice of the
+//                         vertex space in LDS (2^logb bits), and the epilogue of the dense sweep follows -- new = bits &
+//                         ~visited, next frontier / visited / depth / counters, all coalesced.
+// 4 B read + 4 B written + 4 B read per frontier edge.  A list that would overflow (ids far from uniform over the bins) sets
+// a flag, the apply kernel then does nothing, and the host runs the level on another engine.
+// ------------------------------------------------------------------------------------------
+#define BFS_BTD_SUB 8  // one list per XCD: a list's lines are then written through ONE L2 and leave it whole
+__device__ __forceinline__ unsigned bfs_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }  // hwreg(HW_REG_XCC_ID, 0, 4)
+// A list's counter is only ever added to from the CUs of ONE XCD (sub = its id), and read by the apply kernel behind a
+// kernel boundary: the add can stay in that XCD's L2 (workgroup scope = no sc1) instead of travelling to the memory side
+// like a device-scope atomic -- a third of its latency, and the four reservations of a work item wait for it.
+__device__ __forceinline__ unsigned bfs_btd_reserve(unsigned *counter, unsigned n) {
+  return __hip_atomic_fetch_add(counter, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#define BFS_BTD_MAX_LOGB 19  // 64 KB of LDS bits per bin
+#define BFS_BTD_THREADS 1024
+struct BfsBinVis {
+  const vid_t *__restrict__ colidx;
+  vid_t *__restrict__ buf;
+  unsigned *cur;  // counter of list (bin, sub) at cur[(bin * SUB + sub) * 32]: a 128-byte line each
+  unsigned *overflow;
+  unsigned cap_each, sub;
+  int logb, bin_bits;
+  __device__ __forceinline__ void begin_big(vid_t) {}
+  __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
+    vid_t dst = 0;
+    unsigned bin = 0;
+    if (valid) {
+      dst = __builtin_nontemporal_load(colidx + k);
+      bin = (unsigned)dst >> logb;
+    }
+    unsigned long long peers = __ballot(valid);
+    if (peers == 0ull) return;
+    for (int b = 0; b < bin_bits; b++) {
+      const bool one = (bin >> b) & 1u;
+      const unsigned long long mk = __ballot(one && valid);
+      peers &= one ? mk : ~mk;
+    }
+    const unsigned lane = gdn_lane();
+    const unsigned rank = (unsigned)__popcll(peers & gdn_lanemask_lt());
+    const size_t slot = (size_t)bin * BFS_BTD_SUB + sub;
+    unsigned base = 0;
+    if (valid && rank == 0u) base = bfs_btd_reserve(cur + slot * 32, (unsigned)__popcll(peers));
+    base = __shfl(base, valid ? __ffsll((long long)peers) - 1 : (int)lane, 64);
+    if (valid) {
+      const unsigned pos = base + rank;
+      if (pos < cap_each) buf[slot * cap_each + pos] = dst;
+      else *overflow = 1u;
+    }
+  }
+  __device__ __forceinline__ void finish() {}
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_btd_bin_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ inq, unsigned nf, ExpBigList big, BfsBinVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vid_t v = 0;
+  if (i < nf) {
+    v = inq[i];
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  vis.sub = bfs_xcc_id() & (BFS_BTD_SUB - 1);
+  gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+// the big-row work items (EXP_CHUNK = 256 consecutive edges of one row: four wave steps): all four steps' ids are loaded,
+// matched and reserved before the first id is stored -- a step at a time, every step waited for its reservation to come
+// back (a device-scope atomic under load: 1-2 us) before the next load was issued, and 278 M edges took 1.5 ms
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_btd_bin_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsBinVis vis) {
+  static_assert(EXP_CHUNK == 256, "four wave steps per work item");
+  const unsigned lane = gdn_lane();
+  const unsigned nwaves = gridDim.x * GDN_WAVES_PER_BLOCK;
+  const unsigned gw = blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6);
+  const unsigned sub = bfs_xcc_id() & (BFS_BTD_SUB - 1);
+  const unsigned long long lt = gdn_lanemask_lt();
+  unsigned n = *big.count;
+  if (n > big.capacity) n = big.capacity;
+  // (the ids of the NEXT item are on their way while this one is matched and stored: two items' loads in flight per wave)
+  vid_t nxt[4];
+  bool nok[4];
+  auto fetch = [&](unsigned it) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      nok[r] = false;
+      nxt[r] = 0;
+    }
+    if (it >= n) return;
+    const unsigned long long item = big.items[it];
+    const vid_t v = (vid_t)(unsigned)(item & 0xFFFFFFFFull);
+    const unsigned c = (unsigned)(item >> 32);
+    const eoff_t rb = rowptr[v], re = rowptr[v + 1];
+    const eoff_t bb = rb + (eoff_t)c * EXP_CHUNK;
+    const eoff_t ee = (bb + EXP_CHUNK < re) ? bb + EXP_CHUNK : re;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const eoff_t k = bb + (eoff_t)r * 64 + lane;
+      nok[r] = k < ee;
+      nxt[r] = nok[r] ? __builtin_nontemporal_load(vis.colidx + k) : 0;
+    }
+  };
+  fetch(gw);
+  for (unsigned it = gw; it < n; it += nwaves) {
+    vid_t dst[4];
+    bool ok[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      dst[r] = nxt[r];
+      ok[r] = nok[r];
+    }
+    fetch(it + nwaves);
+    unsigned base[4], rank[4];
+    size_t slot[4];
+    int src[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const unsigned bin = (unsigned)dst[r] >> vis.logb;
+      unsigned long long peers = __ballot(ok[r]);
+      for (int b = 0; b < vis.bin_bits; b++) {
+        const bool one = (bin >> b) & 1u;
+        const unsigned long long mk = __ballot(one && ok[r]);
+        peers &= one ? mk : ~mk;
+      }
+      rank[r] = (unsigned)__popcll(peers & lt);
+      slot[r] = (size_t)bin * BFS_BTD_SUB + sub;
+      src[r] = ok[r] ? __ffsll((long long)peers) - 1 : (int)lane;
+      base[r] = 0;
+      if (ok[r] && rank[r] == 0u) base[r] = bfs_btd_reserve(vis.cur + slot[r] * 32, (unsigned)__popcll(peers));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const unsigned pos = __shfl(base[r], src[r], 64) + rank[r];
+      if (ok[r]) {
+        if (pos < vis.cap_each) vis.buf[slot[r] * vis.cap_each + pos] = dst[r];
+        else *vis.overflow = 1u;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BFS_BTD_THREADS)
+bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigned *__restrict__ overflow, unsigned cap_each, int logb,
+                     int32_t m, unsigned nwords_pad, unsigned *__restrict__ visited, unsigned *__restrict__ next_front,
+                     int32_t *__restrict__ depth, int32_t next_level, const eoff_t *__restrict__ out_rowptr, BfsCounters *cnt) {
+  extern __shared__ unsigned s_bits[];  // 2^(logb - 5) words
+  __shared__ unsigned long long s_red[2 * (BFS_BTD_THREADS / 64)];
+  const unsigned bin = blockIdx.x, words = 1u << (logb - 5);
+  const bool skip = *overflow != 0u;  // the lists are incomplete: the host repeats the level on another engine
+  for (unsigned i = threadIdx.x; i < words; i += BFS_BTD_THREADS) s_bits[i] = 0u;
+  __syncthreads();
+  const unsigned idmask = (1u << logb) - 1u;
+  for (unsigned sub = 0; sub < BFS_BTD_SUB && !skip; sub++) {
+    const size_t slot = (size_t)bin * BFS_BTD_SUB + sub;
+    unsigned n = cur[slot * 32];
+    n = n < cap_each ? n : cap_each;
+    const vid_t *__restrict__ src = buf + slot * cap_each;
+    constexpr int UNR = 4;
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += UNR * BFS_BTD_THREADS) {
+      vid_t id[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const unsigned i = i0 + (unsigned)r * BFS_BTD_THREADS;
+        id[r] = i < n ? __builtin_nontemporal_load(src + i) : -1;
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; r++)
+        if (id[r] >= 0) atomicOr(&s_bits[((unsigned)id[r] & idmask) >> 5], 1u << ((unsigned)id[r] & 31u));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < BFS_BTD_SUB) cur[((size_t)bin * BFS_BTD_SUB + threadIdx.x) * 32] = 0u;  // ready for the next level
+  if (skip) return;
+  const size_t w0 = (size_t)bin * words;
+  for (unsigned i = threadIdx.x; i < words; i += BFS_BTD_THREADS) {
+    unsigned nb = 0;
+    if (w0 + i < nwords_pad) {
+      const unsigned vis = visited[w0 + i];
+      nb = s_bits[i] & ~vis;
+      next_front[w0 + i] = nb;
+      if (nb) visited[w0 + i] = vis | nb;
+    }
+    s_bits[i] = nb;
+  }
+  __syncthreads();
+  // one lane per ROW (a wave covers two words): depth stores and row-offset loads of the discovered rows are consecutive
+  unsigned long long awake = 0, scout = 0;
+  {
+    const unsigned lane = gdn_lane(), wv = threadIdx.x >> 6;
+    for (unsigned i0 = wv * 2u; i0 < words; i0 += 2u * (BFS_BTD_THREADS / 64)) {
+      const unsigned i = i0 + (lane >> 5);
+      const unsigned nb = i < words ? s_bits[i] : 0u;
+      if ((nb >> (lane & 31u)) & 1u) {
+        const size_t row = (w0 + i) * 32 + (lane & 31u);
+        if (row < (size_t)m) {
+          depth[row] = next_level;
+          awake++;
+          scout += out_rowptr[row + 1] - out_rowptr[row];
+        }
+      }
+    }
+  }
+  awake = gdn_wave_sum(awake);
+  scout = gdn_wave_sum(scout);
+  const unsigned w = threadIdx.x >> 6;
+  if (gdn_lane() == 0) {
+    s_red[w] = awake;
+    s_red[BFS_BTD_THREADS / 64 + w] = scout;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, sc = 0;
+    for (int i = 0; i < BFS_BTD_THREADS / 64; i++) {
+      a += s_red[i];
+      sc += s_red[BFS_BTD_THREADS / 64 + i];
+    }
+    if (a) {
+      atomicAdd(&cnt->awake, a);
+      atomicAdd(&cnt->scout, sc);
+    }
+  }
+}
+
 struct gdn_bfs_plan {
   const gdn_graph *g = nullptr, *gin = nullptr;
   bool dense = false;
@@ -623,6 +857,12 @@ struct gdn_bfs_plan {
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
+  // binned top-down levels (bfs_btd_*): nbins x BFS_BTD_SUB id lists of btd_cap_each entries, their counters, the flag
+  DevBuf<vid_t> btd_buf;
+  DevBuf<unsigned> btd_cur, btd_flag;
+  unsigned btd_cap_each = 0, btd_nbins = 0;
+  int btd_logb = 0, btd_bin_bits = 0;
+  uint64_t btd_max_edges = 0;  // frontiers of up to this many out-edges (0: the engine is off)
   double prep_ms = 0;
 };
 
@@ -683,6 +923,37 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     GDN_HIP(hipMemset(nact.p, 0, 8));
     hipLaunchKernelGGL(bfs_count_rows_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, gin->rowptr, m, nact.p);
     GDN_HIP(hipMemcpy(&p.active_rows, nact.p, 8, hipMemcpyDeviceToHost));
+    if (!(gdn_option("GDN_BFS_BTD") && atoi(gdn_option("GDN_BFS_BTD")) == 0)) {
+      // binned top-down levels: about 256 bins of up to 2^19 ids (more bins beyond 2^27 vertices); room for frontiers of
+      // up to a third of the edges (beyond, the bottom-up step takes the level) with a factor 2 of slack per list
+      int lb = 14;
+      int64_t want_bins = 256;  // measured on RMAT-27 (278 M frontier edges): 512 bins 2.19 ms, 256 bins 2.03
+      if (const char *e = gdn_option("GDN_BFS_BTD_BINS")) want_bins = atoi(e) > 0 ? atoi(e) : want_bins;  // tuning knob
+      while (lb < BFS_BTD_MAX_LOGB && (want_bins << lb) < (int64_t)m) lb++;
+      p.btd_logb = lb;
+      p.btd_nbins = (unsigned)(((uint64_t)m + (1ull << lb) - 1) >> lb);
+      p.btd_bin_bits = 1;
+      while ((1u << p.btd_bin_bits) < p.btd_nbins) p.btd_bin_bits++;
+      p.btd_max_edges = g->nnz / 3 + 1;
+      const uint64_t lists = (uint64_t)p.btd_nbins * BFS_BTD_SUB;
+      uint64_t each = (2 * p.btd_max_edges + lists - 1) / lists;
+      each = (each + 63) & ~63ull;
+      if (each < 256) each = 256;
+      if (each < 0x7FFFFFFFull) {
+        p.btd_cap_each = (unsigned)each;
+        GDN_TRY(p.btd_buf.alloc(lists * each));
+        GDN_TRY(p.btd_cur.alloc(lists * 32));
+        GDN_TRY(p.btd_flag.alloc(1));
+        GDN_HIP(hipMemset(p.btd_cur.p, 0, lists * 32 * sizeof(unsigned)));
+        GDN_HIP(hipMemset(p.btd_flag.p, 0, sizeof(unsigned)));
+        if (hipFuncSetAttribute((const void *)bfs_btd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << (BFS_BTD_MAX_LOGB - 5)) != hipSuccess) {
+          (void)hipGetLastError();
+          p.btd_max_edges = 0;
+        }
+      } else {
+        p.btd_max_edges = 0;
+      }
+    }
   }
   p.qcap = (unsigned)m;
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
@@ -748,6 +1019,18 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
   // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
   // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
+  // binned top-down levels (bfs_btd_*): frontiers from nnz / alpha_btd edges (and btd_min_edges) up to a third of all
+  // (GDN_BFS_BTD=2 forces them wherever they apply -- tests; GDN_BFS_ALPHA_BTD lets the bitmap phase start earlier for them:
+  // a 10 M-edge frontier of RMAT-27 took 0.60 ms binned, 0.53 ms plain top-down, hence the default = alpha_dense)
+  uint64_t alpha_btd = (uint64_t)alpha_dense;
+  int64_t btd_min_edges = 1 << 22;
+  bool btd_on = true, btd_force = false;
+  if (const char *e = gdn_option("GDN_BFS_ALPHA_BTD")) alpha_btd = atoi(e) > 0 ? (uint64_t)atoi(e) : alpha_btd;  // tuning knobs
+  if (const char *e = gdn_option("GDN_BFS_BTD_MIN")) btd_min_edges = atoll(e);
+  if (const char *e = gdn_option("GDN_BFS_BTD")) {
+    btd_on = atoi(e) != 0;
+    btd_force = atoi(e) == 2;
+  }
   int64_t bu_edge_div = 3;  // see the engine choice of a heavy level below (0 = off)
   if (const char *e = gdn_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
   int64_t bu_stay = 256;
@@ -786,13 +1069,18 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     tl.start();
   }
   while (nf > 0) {
-    if (p.dense && scout_count > (int64_t)(g->nnz / alpha_dense)) {
-      // ---- dense phase: propagation-blocked sweeps while the frontier stays heavy
+    // the bitmap engines take a level from nnz / alpha_dense frontier edges on; with the binned top-down level (which
+    // moves only the frontier's edges) already from nnz / alpha_btd on
+    const int64_t heavy_from = (int64_t)(g->nnz / (uint64_t)(p.btd_max_edges && btd_on ? alpha_btd : alpha_dense));
+    if (p.dense && scout_count > heavy_from && (scout_count > (int64_t)(g->nnz / alpha_dense) || scout_count >= btd_min_edges)) {
+      // ---- dense phase: bitmap levels while the frontier stays heavy
       light_streak = 0;
       GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
       hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
       unsigned *fr = p.front.p, *nx = p.next.p;
       int64_t awake = 0;
+      bool have_queue = true;  // qin / nfq hold the frontier as a vertex list (what the binned level expands)
+      unsigned nfq = nf;
       do {
         ++iter;
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
@@ -804,7 +1092,55 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         // near p = 1/4, the switch sits at 1/3
         const int64_t left = (int64_t)p.active_rows - visited_total;
         const bool bottom_up = left * bu_frac <= (int64_t)p.active_rows || (bu_edge_div > 0 && scout_count * bu_edge_div >= (int64_t)g->nnz);
-        if (bottom_up) {
+        // below that share: the binned top-down level (only the frontier's edges move) instead of the sweep over all
+        // (measured, RMAT-22 .. 28: the sweep costs ~1.3 ps per edge of the GRAPH, the binned level ~0.35 ms + 6 ps per
+        // edge of the FRONTIER -- it pays from about a billion edges on: RMAT-27 p = 0.13 2.73 -> 2.03 ms, RMAT-28 two of
+        // three sources 10.2 -> 7.6 / 8.7 ms; below, it loses: RMAT-22 0.36 -> 0.7 ms when forced)
+        bool btd = !bottom_up && btd_on && p.btd_max_edges && (uint64_t)scout_count <= p.btd_max_edges &&
+                   (btd_force || 100 * scout_count + 5800000000ll < 21 * (int64_t)g->nnz);
+        const char *engine = bottom_up ? "bottom-up" : "dense";
+        if (btd) {
+          if (!have_queue) {  // the frontier exists as a bitmap only: list it
+            hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr,
+                               p.nwords, qin, p.cnt.p, p.qcap);
+            GDN_TRY(bfs_read_counters(p, h));
+            nfq = h.next_count;
+            have_queue = true;
+            GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+          }
+          ExpBigList bbig;
+          bbig.items = p.bigitems.p;
+          bbig.capacity = p.bigcap;
+          bbig.count = &p.cnt.p->big_count;
+          bbig.overflow = &p.cnt.p->overflow;
+          BfsBinVis bv;
+          bv.colidx = g->colidx;
+          bv.buf = p.btd_buf.p;
+          bv.cur = p.btd_cur.p;
+          bv.overflow = p.btd_flag.p;
+          bv.cap_each = p.btd_cap_each;
+          bv.sub = 0;
+          bv.logb = p.btd_logb;
+          bv.bin_bits = p.btd_bin_bits;
+          hipLaunchKernelGGL(bfs_btd_bin_kernel, dim3(gdn_nblocks(nfq)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nfq, bbig, bv);
+          hipLaunchKernelGGL(bfs_btd_bin_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, bbig, bv);
+          hipLaunchKernelGGL(bfs_btd_apply_kernel, dim3(p.btd_nbins), dim3(BFS_BTD_THREADS), (size_t)4 << (p.btd_logb - 5), 0,
+                             p.btd_buf.p, p.btd_cur.p, p.btd_flag.p, p.btd_cap_each, p.btd_logb, m, p.nwords_pad, p.visited.p, nx, d_dist,
+                             level + 1, g->rowptr, p.cnt.p);
+          unsigned flag = 0;
+          GDN_HIP(hipMemcpy(&flag, p.btd_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
+          if (flag) {  // a bin's list was too short for this frontier: nothing was applied; the sweep takes the level,
+            // and this search stays away from the binned engine
+            GDN_HIP(hipMemsetAsync(p.btd_flag.p, 0, sizeof(unsigned), 0));
+            GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+            btd = false;
+            btd_on = false;
+          } else {
+            engine = "binned";
+          }
+        }
+        if (btd) {
+        } else if (bottom_up) {
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                              p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
         } else {
@@ -815,6 +1151,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                              g->rowptr, p.cnt.p);
         }
         GDN_TRY(bfs_read_counters(p, h));
+        if (h.overflow) {
+          gdn_set_error("gdn_bfs: device worklist overflow");
+          return GDN_ERR_OVERFLOW;
+        }
         awake = (int64_t)h.awake;
         scout_count = (int64_t)h.scout;
         visited_total += awake;
@@ -822,10 +1162,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         fr = nx;
         nx = t;
         level++;
-        lap(bottom_up ? "bottom-up" : "dense", awake, scout_count);
+        have_queue = false;
+        lap(engine, awake, scout_count);
         // stay on bitmaps while the frontier is heavy, or while the cheap bottom-up engine beats a top-down
         // step over scout_count edges (a late level with millions of frontier vertices but few discoveries)
       } while (awake > 0 && (scout_count > (int64_t)(g->nnz / alpha_dense) ||
+                             (btd_on && p.btd_max_edges && scout_count > (int64_t)(g->nnz / alpha_btd) && scout_count >= btd_min_edges) ||
                              (((int64_t)p.active_rows - visited_total) * bu_frac <= (int64_t)p.active_rows &&
                               scout_count > (int64_t)m / bu_stay)));
       if (awake == 0) {

@@ -1435,3 +1435,32 @@ def test_pr_batched_loop_stops_where_the_per_iteration_loop_stops(orc, monkeypat
             s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
             st = solvers.PRSolver(G, s, max_iter=5)
             assert len(st["trace"]) == 5 and st["iterations"] == 6
+
+
+@pytest.mark.parametrize("mode", ["forced", "forced_early", "overflow"])
+def test_bfs_binned_top_down_level(orc, monkeypatch, mode):
+    """The binned top-down level (bfs_btd_*: the frontier's out-edges binned by destination range, then applied per bin in
+    LDS) forced onto graphs far below the size at which the plan picks it: exact depths against the oracle; `forced_early`
+    also lets the bitmap phase start for small frontiers; `overflow`: lists far too short for a frontier whose destinations
+    are not spread over the bins (every edge of a star lands in a few bins) -- the flag sends the level to the sweep."""
+    monkeypatch.setenv("GDN_BFS_BTD", "2")
+    if mode == "forced_early":
+        monkeypatch.setenv("GDN_BFS_ALPHA_BTD", "100000")
+        monkeypatch.setenv("GDN_BFS_BTD_MIN", "1")
+    graphs = [graphio.rmat_graph(16, 16, seed=3), graphio.symmetrize(graphio.rmat_graph(15, 8, seed=4)),
+              graphio.rmat_graph(18, 8, seed=5)]
+    if mode == "overflow":
+        m = 1 << 17  # 8 bins of 16384 ids; vertex 0 points at 16000 ids of bin 0 alone, whose 8 lists hold ~10 K of them
+        hub_dst = np.arange(1, 16001, dtype=np.int64)
+        src = np.concatenate([np.zeros(16000, np.int64), hub_dst, np.arange(16001, m - 1)])
+        dst = np.concatenate([hub_dst, (hub_dst * 7919) % m, np.arange(16002, m)])
+        graphs = [graphio.build_csr(m, src, dst)]
+    for g in graphs:
+        gi = graphio.transpose(g)
+        G = solvers.Graph(csr=g, in_csr=gi)
+        bfs = solvers.ResidentBFS(G, dense=True)
+        for s in ([0] if mode == "overflow" else [graphio.first_nonisolated(g), int(np.argmax(g.degrees()))]):
+            want = orc.bfs_serial(g, s)
+            d, st = bfs.run(s)
+            assert np.array_equal(d, want), (mode, s)
+        bfs.close()
