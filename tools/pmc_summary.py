@@ -19,15 +19,20 @@ out = os.path.join(ROOT, "profiles")
 SRC = "gpurun_out/r02"  # written by tools/profile_r02.sh (one session, one box)
 
 
+def newest(pat):
+    """gpurun merges every session's files into the same local directory: take the file of the LAST session"""
+    return max(glob.glob(os.path.join(ROOT, pat)), key=os.path.getmtime)
+
+
 def counters(pat):
-    f = glob.glob(os.path.join(ROOT, pat))[0]
+    f = newest(pat)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
     return agg
 
 
-stats = glob.glob(os.path.join(ROOT, SRC, "trace/*/*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(SRC, "trace/*/*_kernel_stats.csv"))
 session = " / ".join(" ".join(x.split()) for x in open(os.path.join(ROOT, SRC, "session.txt")).read().splitlines()
                      if x.strip() and not x.startswith("="))
 shutil.copyfile(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
