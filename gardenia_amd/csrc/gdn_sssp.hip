@@ -1185,7 +1185,9 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   bool pre_dense_done = false;
   unsigned long long dense_pre = 192;  // = dense_in x the growth of a frontier per pass this early (GDN_SSSP_DENSE_PRE)
   if (const char *e = gdn_option("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
-  unsigned long long dense_in = 24, dense_out = 16;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 takes 7.2 / 9.2 ms to 6.2 / 7.5 ms
+  unsigned long long dense_in = 24, dense_out = 8;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 took 7.2 / 9.2 ms to 6.2 / 7.5 ms
+                                                     // (round 1); with this round's worklist passes m/16 -> m/8: delta 16
+                                                     // 3.9 -> 3.66 ms, unit weights 1.74 -> 1.44 ms (m/4: 4.5 / 1.46)
   if (const char *e = gdn_option("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
   if (const char *e = gdn_option("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
   // light phases run inside ONE workgroup (sssp_small_kernel); GDN_SSSP_SMALL=0 keeps every phase on the host loop, =2
