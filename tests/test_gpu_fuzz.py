@@ -22,8 +22,9 @@ def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
                    GDN_BC_SMALL_SCOUT="1000000000000", GDN_BC_BACK_NF="1024", GDN_BC_BACK_SCOUT="1000000000000",
                    GDN_PR_FUSED="1", GDN_PR_SMALL_M="16384", FUZZ_PLANS="1")
         blocked = False
-    if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels
-        env.update(FUZZ_PLANS="1")
+    if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels -- with the binned
+        # top-down level forced onto every heavy BFS level below a third of the edges
+        env.update(FUZZ_PLANS="1", GDN_BFS_BTD="2", GDN_BFS_ALPHA_BTD="100000", GDN_BFS_BTD_MIN="1")
         blocked = False
     if blocked:  # the propagation-blocked layouts with their record tiers on these small graphs too (normally >= 2^22 edges)
         env.update(GDN_PR_LAYOUT="p", GDN_SPMV_LAYOUT="p", GDN_PRD_LAYOUT="p", GDN_PB_HUB_MIN_NNZ="1")
