@@ -792,11 +792,7 @@ int pb_mid_finish(PbPlan &p, unsigned n_src, DevBuf<uint32_t> &rec, DevBuf<float
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());
   if (ev) {
-    ev->release();
-    ev->p = ev_b.p;
-    ev->n = ev_b.n;
-    ev_b.p = nullptr;
-    ev_b.n = 0;
+    ev->take(ev_b);
   }
   p.U.release();
   p.V.release();

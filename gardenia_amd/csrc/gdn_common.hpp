@@ -55,17 +55,25 @@ int gdn_require_device();
 // value of a library option: the environment variable `name` if set, else what gdn_option_set stored, else nullptr
 const char *gdn_option(const char *name);
 
+// Byte offset for the next large allocation (gdn_graph.hip).  0 unless the option GDN_ALLOC_STAGGER names a granule
+// (a multiple of 256 bytes): then the k-th buffer of >= 1 MiB starts (2k + 1) mod 127 granules behind its hipMalloc
+// base -- an A/B knob for the placement spread of DESIGN.md 4.1 (streams that start at power-of-two-aligned bases
+// walk the memory channels in step).
+size_t gdn_alloc_stagger_next(size_t bytes);
+
 // RAII device buffer (solver-private scratch)
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
+  void *base = nullptr;  // what hipMalloc returned (p may sit a staggered offset behind it)
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (base) (void)hipFree(base);
+    base = nullptr;
     p = nullptr;
     n = 0;
   }
@@ -73,13 +81,25 @@ struct DevBuf {
     release();
     n = count;
     if (count == 0) count = 1;
-    hipError_t e = hipMalloc((void **)&p, count * sizeof(T));
+    const size_t off = gdn_alloc_stagger_next(count * sizeof(T));
+    hipError_t e = hipMalloc(&base, count * sizeof(T) + off);
     if (e != hipSuccess) {
+      base = nullptr;
       p = nullptr;
-      gdn_set_error("hipMalloc(%zu bytes) -> %s", count * sizeof(T), hipGetErrorString(e));
+      gdn_set_error("hipMalloc(%zu bytes) -> %s", count * sizeof(T) + off, hipGetErrorString(e));
       return GDN_ERR_OOM;
     }
+    p = reinterpret_cast<T *>(static_cast<char *>(base) + off);
     return GDN_OK;
+  }
+  void take(DevBuf &o) {  // this buffer takes o's memory over
+    release();
+    p = o.p;
+    n = o.n;
+    base = o.base;
+    o.p = nullptr;
+    o.base = nullptr;
+    o.n = 0;
   }
 };
 

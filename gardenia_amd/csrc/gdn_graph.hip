@@ -14,6 +14,7 @@ static thread_local char g_err[512] = "";
 // ---- options: every tuning / test knob of the library ("GDN_...") is an OPTION that a caller sets through the API
 // (gdn_option_set) and the environment variable of the same name OVERRIDES (so measurements and tests can flip a knob
 // without touching the caller).  Values are strings, parsed where they are used, exactly like the environment's.
+#include <atomic>
 #include <map>
 #include <mutex>
 static std::mutex g_opt_mu;
@@ -27,6 +28,16 @@ const char *gdn_option(const char *name) {
   auto &m = gdn_opt_map();
   auto it = m.find(name);
   return it == m.end() ? nullptr : it->second.c_str();  // (the string lives until the option is set again)
+}
+
+size_t gdn_alloc_stagger_next(size_t bytes) {
+  static std::atomic<unsigned> k{0};
+  if (bytes < (1u << 20)) return 0;
+  const char *e = gdn_option("GDN_ALLOC_STAGGER");
+  if (!e) return 0;
+  const size_t g = (size_t)strtoull(e, nullptr, 10) & ~(size_t)255;
+  if (g == 0) return 0;
+  return (size_t)((2u * k.fetch_add(1u) + 1u) % 127u) * g;
 }
 
 void gdn_set_error(const char *fmt, ...) {

@@ -134,7 +134,9 @@ int pb_pick_hubs(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<
 // record per lane, and fetches the value from the tier's table (<= 1 MB, refreshed per iteration, L2 resident).  Sorted
 // by source and one record per lane, the 64 gathers of a wave instruction fall into a handful of consecutive cache
 // lines: a near-coalesced load, not a divergent gather.  4 B/edge of HBM traffic instead of 12.1.
-#define PB_MAX_MID 2
+#ifndef PB_MAX_MID
+#define PB_MAX_MID 2  // tools/build_variant.sh sweeps it (profiles/r03_pb_tier_sweep.txt)
+#endif
 #define PB_MID_ROW_BITS 14
 #define PB_MID_MAX ((1u << (32 - PB_MID_ROW_BITS)) - 1u)  // sources per tier; index PB_MID_MAX can be the zero slot
 #define PB_MAX_REC_TIERS (1 + PB_MAX_MID)  // record streams of phase B: PageRank's hubs + the mid tiers

@@ -737,10 +737,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
       if (st == GDN_OK) {
         mt.n = n_mid[t];
-        mt.ids.p = mid_ids[t].p;  // take the buffer over
-        mt.ids.n = mid_ids[t].n;
-        mid_ids[t].p = nullptr;
-        mid_ids[t].n = 0;
+        mt.ids.take(mid_ids[t]);
         p->n_mid_tiers = t + 1;
       }
     }

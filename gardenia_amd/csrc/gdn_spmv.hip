@@ -264,10 +264,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
       if (st == GDN_OK) {
         mt.n = n_mid[t];
-        mt.ids.p = mid_ids[t].p;  // take the buffer over
-        mt.ids.n = mid_ids[t].n;
-        mid_ids[t].p = nullptr;
-        mid_ids[t].n = 0;
+        mt.ids.take(mid_ids[t]);
         p->n_mid_tiers = t + 1;
       }
     }

@@ -1,0 +1,93 @@
+"""The reference's OWN harness around this repository's solvers (link-time substitution of XxxSolver,
+src/<k>/Makefile): oracle/_ref/dropin_<k> = /root/reference/src/<k>/main.cc + verifier.cc compiled where they lie,
+linked with integration/hip_mi355x_<k>.cc and libgardenia_hip.so (oracle/Makefile, target `dropin`).  CPU: they exist,
+resolve the library, load the fixture graphs with the reference's loader and fail loudly without a GPU.  GPU: the
+reference's CLI on the fixture graphs and an R-MAT .bin, the reference's verifier prints "Correct", and PageRank prints
+the 15 trace lines of test/reference/graph-pr.mtx.out:13-27."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from conftest import GOLDEN, ROOT
+from gardenia_amd import _cabi, graphio
+
+REFBIN = os.path.join(ROOT, "oracle", "_ref")
+G = os.path.join(GOLDEN, "graphs")
+KERNELS = ("bfs", "pr", "pr_delta", "spmv", "sssp", "cc", "tc", "bc")
+
+pytestmark = pytest.mark.skipif(not os.path.exists(os.path.join(REFBIN, "dropin_bfs")),
+                                reason="oracle/_ref/dropin_* not built (needs /root/reference: make -C oracle dropin)")
+
+
+def run(exe, *args):
+    p = subprocess.run([os.path.join(REFBIN, exe), *map(str, args)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       text=True, timeout=600)
+    return p.returncode, p.stdout
+
+
+def test_dropins_link_against_the_library_and_use_the_reference_loader():
+    for k in KERNELS:
+        exe = os.path.join(REFBIN, "dropin_" + k)
+        assert os.path.exists(exe), "run __graft_entry__.build() where /root/reference is present"
+        ldd = subprocess.run(["ldd", exe], stdout=subprocess.PIPE, text=True).stdout
+        assert "libgardenia_hip.so" in ldd and "not found" not in ldd.split("libgardenia_hip.so")[1].splitlines()[0], ldd
+    rc, out = run("dropin_bfs", "mtx", os.path.join(G, "test_bc"), 0, 1, 0)
+    assert "|V| 7 |E| 15" in out  # the reference loader's line for datasets/test_bc.mtx
+    if _cabi.device_count() == 0:
+        assert rc != 0 and "no HIP device" in out  # the wrapper exits like CUDA_SAFE_CALL; no CPU fallback
+
+
+@pytest.mark.gpu
+def test_dropins_print_correct_with_the_reference_verifiers(tmp_path):
+    cases = [("dropin_bfs", ["mtx", os.path.join(G, "test_bc"), 0, 1, 0]),
+             ("dropin_bfs", ["mtx", os.path.join(G, "chesapeake"), 1, 0, 0]),
+             ("dropin_pr", ["mtx", os.path.join(G, "test_pr"), 0]),
+             ("dropin_pr", ["mtx", os.path.join(G, "chesapeake"), 1]),
+             ("dropin_pr_delta", ["mtx", os.path.join(G, "test_pr"), 0]),
+             ("dropin_spmv", ["mtx", os.path.join(G, "test_bc"), 0, 1]),
+             ("dropin_spmv", ["mtx", os.path.join(G, "chesapeake"), 1, 0]),
+             ("dropin_sssp", ["mtx", os.path.join(G, "test_bc"), 0, 1, 0, 1]),
+             ("dropin_sssp", ["mtx", os.path.join(G, "chesapeake"), 1, 0, 0, 2]),
+             ("dropin_cc", ["mtx", os.path.join(G, "test_cc"), 1, 0]),
+             ("dropin_cc", ["mtx", os.path.join(G, "chesapeake"), 1, 0]),
+             ("dropin_bc", ["mtx", os.path.join(G, "test_bc"), 1, 0, 0]),
+             ("dropin_bc", ["mtx", os.path.join(G, "chesapeake"), 1, 0, 0])]
+    g = graphio.rmat_graph(16, 16, seed=5)
+    graphio.write_bin(str(tmp_path / "rm"), g)
+    gs = graphio.symmetrize(g)
+    graphio.write_bin(str(tmp_path / "rms"), gs)
+    s = graphio.first_nonisolated(g)
+    cases += [("dropin_bfs", ["bin", tmp_path / "rm", 0, 1, s]), ("dropin_pr", ["bin", tmp_path / "rm", 0]),
+              ("dropin_spmv", ["bin", tmp_path / "rm", 0, 1]), ("dropin_sssp", ["bin", tmp_path / "rm", 0, 1, s, 2]),
+              ("dropin_cc", ["bin", tmp_path / "rms", 1, 0]), ("dropin_cc", ["bin", tmp_path / "rm", 0, 1]),
+              ("dropin_bc", ["bin", tmp_path / "rms", 1, 0, s])]
+    for exe, args in cases:
+        rc, out = run(exe, *args)
+        assert rc == 0 and "Correct" in out and "runtime [hip_mi355x" in out, (exe, args, out[-800:])
+
+
+@pytest.mark.gpu
+def test_dropin_pr_prints_the_reference_trace():
+    rc, out = run("dropin_pr", "mtx", os.path.join(G, "test_pr"), 0)
+    assert rc == 0, out
+    gold = json.load(open(os.path.join(GOLDEN, "pr_trace_golden.json")))
+    solver_part = out.split("Verifying...")[0]
+    lines = [ln for ln in solver_part.splitlines() if ln[:3].strip().isdigit() and "." in ln]
+    want = [" %2d    %lf" % (i + 1, v) for i, v in enumerate(gold["trace"])]
+    assert lines == want, (lines, want)
+    assert "\titerations = %d." % gold["iterations"] in solver_part
+    # and the reference's verifier (src/pr/verifier.cc) re-runs its own loop behind it and agrees
+    assert "Correct" in out.split("Verifying...")[1]
+
+
+@pytest.mark.gpu
+def test_dropin_tc_counts_like_the_oracle(tmp_path):
+    from oracle import binding as orc
+    g = graphio.symmetrize(graphio.rmat_graph(14, 16, seed=9))
+    graphio.write_bin(str(tmp_path / "t"), g)
+    rc, out = run("dropin_tc", tmp_path / "t")
+    assert rc == 0, out
+    want = orc.tc(graphio.orient_dag(g))
+    assert "total_num_triangles = %d" % want in out, out[-400:]
