@@ -604,6 +604,24 @@ pb_hub_hist_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restr
   if (threadIdx.x < PB_HUB_BUCKETS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
 
+// the same counts as a LINEAR histogram (one bin per count, counts >= PB_LIN_BINS - 1 in the last bin): the mid tiers
+// are cut at arbitrary counts, not at bucket floors -- a tier holds at most PB_MID_MAX sources, and below the hubs one
+// quarter-octave bucket of an R-MAT graph holds more than that
+#define PB_LIN_BINS 4096
+__global__ void __launch_bounds__(GDN_BLOCK)
+pb_hub_hist_lin_kernel(const uint32_t *__restrict__ cnt, size_t n, unsigned *__restrict__ hist /*PB_LIN_BINS*/) {
+  __shared__ unsigned s_h[PB_LIN_BINS];
+  for (unsigned i = threadIdx.x; i < PB_LIN_BINS; i += GDN_BLOCK) s_h[i] = 0;
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
+    const unsigned c = cnt[i];
+    if (c) atomicAdd(&s_h[c < PB_LIN_BINS - 1u ? c : PB_LIN_BINS - 1u], 1u);
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < PB_LIN_BINS; i += GDN_BLOCK)
+    if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
 // class of every source from its sampled count: 1 = hub (>= thr[0]), 1 + t = mid tier t (thr[t] <= count < thr[t-1]),
 // 0 = main layout; the ids of every class are collected (unordered) in ids[class - 1]
 struct PbTierArgs {
@@ -694,16 +712,43 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
   ta.ntiers = 1;
   uint64_t mid16 = PB_MID_MIN_PER_BIN16;
   if (const char *e = gdn_option("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
-  unsigned top = bk0 < PB_HUB_BUCKETS ? bk0 : PB_HUB_BUCKETS;
   uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
   if (const char *e = gdn_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
-  for (int t = 0; t < max_mid; t++) {
-    const unsigned bk = pick((nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4), top, mid_cap);
-    if (bk >= top) break;
-    ta.thr[1 + t] = pb_hub_bucket_floor(bk);
-    ta.cap[1 + t] = PB_MID_MAX;
-    ta.ntiers = 2 + t;
-    top = bk;
+  if (max_mid > 0) {
+    // mid tiers: consecutive count ranges [thr[t], thr[t-1]) below the hubs, each filled up to mid_cap sources, down
+    // to the count that stands for mid16 / 16 edges per average bin
+    DevBuf<unsigned> lin;
+    GDN_TRY(lin.alloc(PB_LIN_BINS));
+    GDN_HIP(hipMemset(lin.p, 0, PB_LIN_BINS * 4));
+    hipLaunchKernelGGL(pb_hub_hist_lin_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, cnt.p, (size_t)m_global, lin.p);
+    GDN_HIP(hipGetLastError());
+    std::vector<unsigned> hl(PB_LIN_BINS);
+    GDN_HIP(hipMemcpy(hl.data(), lin.p, PB_LIN_BINS * 4, hipMemcpyDeviceToHost));
+    uint64_t n_hub_src = 0;
+    for (unsigned j = bk0; j < PB_HUB_BUCKETS; j++) n_hub_src += h[j];
+    // sources with a count in [c, top): the last linear bin also holds everything beyond it, the hubs included
+    uint64_t top = bk0 < PB_HUB_BUCKETS ? ta.thr[0] : 0xFFFFFFFFull;
+    uint64_t want = (nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4);
+    if (want < 4) want = 4;
+    for (int t = 0; t < max_mid && top > want; t++) {
+      uint64_t acc = 0, thr = top;
+      for (uint64_t c = (top < PB_LIN_BINS ? top : PB_LIN_BINS) - 1;; c--) {
+        uint64_t here = hl[c];
+        if (c == PB_LIN_BINS - 1) {  // the open-ended bin: not cut inside; take it whole or not at all
+          if (top <= c) here = 0;
+          else here -= (here >= n_hub_src ? n_hub_src : here);
+        }
+        if (acc + here > mid_cap) break;
+        acc += here;
+        thr = c;
+        if (c <= want) break;
+      }
+      if (thr >= top || acc == 0) break;
+      ta.thr[1 + t] = (unsigned)thr;
+      ta.cap[1 + t] = PB_MID_MAX;
+      ta.ntiers = 2 + t;
+      top = thr;
+    }
   }
   if (bk0 >= PB_HUB_BUCKETS && ta.ntiers == 1) return GDN_OK;
   GDN_TRY(cls.alloc((size_t)m_global));

@@ -203,25 +203,30 @@ __device__ __forceinline__ void gdn_wg_level_sync() {
 
 // Grid barrier of a cooperative launch (all workgroups co-resident), for kernels that touch their shared MUTABLE data
 // with device-scope accesses only (atomics, `sc1` loads and stores -- the queues, counters, distances and bitmaps of the
-// persistent traversal kernels): every wave drains its own accesses, the workgroup meets, one lane arrives on bar[0], the
-// last arriver resets it and bumps the generation bar[32] the others poll.  No cache write-back / invalidate is needed
-// then (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the signal + sc1 loads behind it);
-// three __threadfence() per barrier, as first written, cost a third of a light level (4096 x 4096 lattice BFS: 15.6 ->
-// 10.0 us per level).  Arrivals per XCD with a second level on top (eight counters in parallel, XCD read from
-// HW_REG_XCC_ID) measured the same 9.9 us: the level is bound by its chain of dependent accesses, not by the 256
-// arrivals -- the flat form stays.
+// persistent traversal kernels): every wave drains its own accesses, the workgroup meets, one lane takes a TICKET on
+// bar[0] (never reset during a launch), the workgroup whose ticket completes a generation publishes that generation's
+// number on bar[32] (a line of its own), the others poll it.  A workgroup derives the generation it waits for from its
+// OWN ticket, so nothing has to be read before arriving: the first form sampled the generation word with a relaxed
+// load and then arrived on another line, and had the arrival been performed first the last arriver could have bumped
+// the generation in between -- this workgroup would have polled for ever.  No cache write-back /
+// invalidate is needed (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores drained before the signal + sc1
+// loads behind it); three __threadfence() per barrier, as first written, cost a third of a light level (4096 x 4096
+// lattice BFS: 15.6 -> 10.0 us per level).  Arrivals per XCD with a second level on top (eight counters in parallel,
+// XCD read from HW_REG_XCC_ID) measured the same 9.9 us: the level is bound by its chain of dependent accesses, not
+// by the 256 arrivals -- the flat form stays.  Tickets wrap after 2^32 arrivals per launch (16 M barriers of a
+// 256-workgroup grid); the comparison below is wrap-safe anyway.
 #define GDN_GBAR_WORDS 64  // zeroed by the host before every launch
 __device__ __forceinline__ void gdn_grid_barrier(unsigned *bar, unsigned nblocks) {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned gen = __hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicAdd(bar, 1u) == nblocks - 1u) {
-      __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the reset has landed before anybody is released
-      atomicAdd(bar + 32, 1u);
+    const unsigned t = atomicAdd(bar, 1u);
+    const unsigned gen = t / nblocks + 1u;  // the generation this arrival belongs to (1, 2, ...)
+    if (t % nblocks == nblocks - 1u) {
+      __hip_atomic_store(bar + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      while (__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) __builtin_amdgcn_s_sleep(1);
+      while ((int)(__hip_atomic_load(bar + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0)
+        __builtin_amdgcn_s_sleep(1);
     }
   }
   __syncthreads();

@@ -41,6 +41,7 @@ struct Rccl {
   void *h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
   std::string why;
@@ -55,6 +56,7 @@ struct Rccl {
     }
     CommInitAll = (decltype(CommInitAll))dlsym(h, "ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))dlsym(h, "ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
     AllGather = (decltype(AllGather))dlsym(h, "ncclAllGather");
     GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
     if (!CommInitAll || !CommDestroy || !AllGather) {
@@ -118,6 +120,8 @@ struct Shared {
   int32_t chunk = 0;
   bool use_rccl = false;
   std::vector<ncclComm_t> comm;
+  std::mutex abort_mu;
+  bool aborted = false;  // the communicators were ended with ncclCommAbort (they must not be destroyed again)
   Barrier *bar = nullptr;
   std::vector<float *> contrib[2];  // per rank: its two replicated vectors (padded space)
   std::vector<double> diff[2];      // per rank L1 change, slot = iteration & 1
@@ -232,11 +236,24 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
     };
     // contrib = score / out_degree of the own rows (src/pr/base.cu:14), then the first exchange
     MT_CHECK(gdn_pr_contrib_dev(plan, d_scores.p, d_c[0].p, nullptr));
-    if (S.use_rccl) {
-      if (rc == GDN_OK && g_rccl.AllGather(d_c[0].p + base, d_c[0].p, (size_t)chunk, kNcclFloat, S.comm[r], nullptr) != 0) {
+    // a rank that skips a collective its peers have entered leaves them waiting for ever: every rank publishes its
+    // status and all agree BEFORE each all-gather; a failed enqueue aborts every communicator so that the peers'
+    // kernels end
+    auto all_gather = [&](float *vec) {
+      if (g_rccl.AllGather(vec + base, vec, (size_t)chunk, kNcclFloat, S.comm[r], nullptr) != 0) {
         rc = GDN_ERR_HIP;
         S.err[r] = "ncclAllGather failed";
+        std::lock_guard<std::mutex> lk(S.abort_mu);
+        if (g_rccl.CommAbort && !S.aborted) {
+          S.aborted = true;
+          for (int q = 0; q < n; q++)
+            if (S.comm[q]) (void)g_rccl.CommAbort(S.comm[q]);
+        }
       }
+    };
+    if (S.use_rccl) {
+      MT_SYNC_OR_QUIT();
+      all_gather(d_c[0].p);
     } else {
       exchange(d_c[0].p, 0, chunk, nullptr);
     }
@@ -249,10 +266,8 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
       float *cin = d_c[cur].p, *cout = d_c[cur ^ 1].p;
       if (S.use_rccl) {
         MT_CHECK(gdn_pr_pull_dev(plan, cin, d_scores.p, cout, d_diff.p, damping, nullptr));
-        if (rc == GDN_OK && g_rccl.AllGather(cout + base, cout, (size_t)chunk, kNcclFloat, S.comm[r], nullptr) != 0) {
-          rc = GDN_ERR_HIP;
-          S.err[r] = "ncclAllGather failed";
-        }
+        MT_SYNC_OR_QUIT();
+        all_gather(cout);
       } else {
         for (int j = 0; j < parts; j++) {
           const int32_t r0 = j * seg < chunk ? j * seg : chunk, r1 = (j == parts - 1) ? chunk : ((j + 1) * seg < chunk ? (j + 1) * seg : chunk);
@@ -277,7 +292,7 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
     }
     if (r == 0) {
       S.solve_ms = now_ms() - t_solve;
-      S.iterations = iter < max_iter ? iter + 1 : max_iter;  // the reference prints iter + 1 (omp_base.cc:39)
+      S.iterations = iter + 1;  // the reference prints iter + 1 (omp_base.cc:39: MAX_ITER + 1 when it did not converge), like gdn_pr
       S.last = total;
     }
     MT_CHECK(gdn_pr_plan_check(plan));
@@ -351,7 +366,14 @@ int multi_setup(Shared &S, int32_t m, const uint64_t *rowptr, int32_t ngpus, con
   if (!devices)
     if (const char *e = gdn_option("GDN_MULTI_DEVICES")) {
       for (const char *c = e; *c;) {
-        envdev.push_back((int32_t)strtol(c, const_cast<char **>(&c), 10));
+        char *end = nullptr;
+        const long v = strtol(c, &end, 10);
+        if (end == c || envdev.size() >= 64 || (*end && *end != ',' && *end != ' ')) {
+          gdn_set_error("GDN_MULTI_DEVICES=\"%s\": expected at most 64 device numbers separated by commas", e);
+          return GDN_ERR_INVALID;
+        }
+        envdev.push_back((int32_t)v);
+        c = end;
         while (*c == ',' || *c == ' ') c++;
       }
       if ((int)envdev.size() >= n) devices = envdev.data();
@@ -414,7 +436,7 @@ int multi_finish(Shared &S, const char *who) {
   int cur = 0;
   (void)hipGetDevice(&cur);
   for (size_t r = 0; r < S.comm.size(); r++)
-    if (S.comm[r]) (void)g_rccl.CommDestroy(S.comm[r]);
+    if (S.comm[r] && !S.aborted) (void)g_rccl.CommDestroy(S.comm[r]);
   for (int r = 0; r < S.n; r++)
     if (S.rc[r] != GDN_OK) {
       gdn_set_error("%s: rank %d (device %d): %s", who, r, S.dev[r], S.err[r].empty() ? "failed" : S.err[r].c_str());

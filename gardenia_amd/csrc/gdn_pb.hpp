@@ -189,7 +189,7 @@ pb_tier_gather_f32_kernel(const float *__restrict__ x, const uint32_t *__restric
     const float v = k < n ? x[ids[k]] : 0.0f;
     val[k] = v;
     const unsigned bts = __float_as_uint(v) & 0x7FFFFFFFu;
-    mx = bts > mx ? bts : mx;
+    mx = (bts > mx && bts < 0x7F800000u) ? bts : mx;  // finite values only: inf / nan products are repaired row by row
   }
   if (absmax) {  // max |x| of the tier's columns (float bits), see pb_expand_scaled_kernel
 #pragma unroll
@@ -681,7 +681,7 @@ pb_expand_scaled_kernel(const float *__restrict__ x, int32_t m_global, int log_c
     unsigned mx = 0u;
     for (unsigned i = threadIdx.x; i < n_slots; i += PB_THREADS) {
       const unsigned bts = __float_as_uint(s_x[i]) & 0x7FFFFFFFu;
-      mx = bts > mx ? bts : mx;
+      mx = (bts > mx && bts < 0x7F800000u) ? bts : mx;  // finite values only (see pb_tier_gather_f32_kernel)
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -761,7 +761,11 @@ __device__ __forceinline__ unsigned long long pb_to_fixed_signed(float v, float 
 
 // Ops with `static constexpr bool kTrackLossy = true` (SpMV) get a per-bin LDS bitmap of the rows that received a product
 // whose fixed-point conversion dropped bits (Op::lossy(v)); such a row whose sum is too small for the dropped bits not to
-// matter is handed to the op as NaN and recomputed exactly by it (gdn_spmv.hip).  Other ops: no code at all.
+// matter is handed to the op as the PB_REPAIR_ROW pattern and recomputed exactly by it (gdn_spmv.hip).  A second bitmap
+// marks the rows that took a product fixed point cannot hold at all (Op::must_repair(v): inf, nan, or beyond the
+// scale): those are always recomputed, so they come out inf / nan exactly like the reference's fp32 loop
+// (src/spmv/omp_base.cc:22-33).  Other ops: no code at all.
+#define PB_REPAIR_ROW 0x7FC0DEADu  // a quiet NaN no arithmetic produces: from_fixed never returns NaN at all
 template <class T, class = void>
 struct PbTracksLossy {
   static constexpr bool value = false;
@@ -804,8 +808,9 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_acc[i] = 0ull;
   constexpr bool LZ = PbTracksLossy<Op>::value;
   unsigned *s_lossy = reinterpret_cast<unsigned *>(s_acc + bn);  // bn / 32 words behind the accumulators (LZ launches only)
+  unsigned *s_force = s_lossy + (bn >> 5);                        // and bn / 32 more: rows that must be recomputed
   if constexpr (LZ)
-    for (unsigned i = threadIdx.x; i < (bn >> 5); i += PB_THREADS) s_lossy[i] = 0u;
+    for (unsigned i = threadIdx.x; i < (bn >> 4); i += PB_THREADS) s_lossy[i] = 0u;
   __syncthreads();
   if (hrb_ptr) {
     for (unsigned i = hrb_ptr[b] + threadIdx.x; i < hrb_ptr[b + 1]; i += PB_THREADS) s_acc[hrb_vl[i]] = hr_total[i];
@@ -829,12 +834,17 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       return op.to_fixed(val, bad);
     }
   };
-  auto mark = [&](unsigned row) { atomicOr(&s_lossy[row >> 5], 1u << (row & 31u)); };
+  auto mark = [&](unsigned row, float val) {
+    atomicOr(&s_lossy[row >> 5], 1u << (row & 31u));
+    if constexpr (LZ) {
+      if (op.must_repair(val)) atomicOr(&s_force[row >> 5], 1u << (row & 31u));
+    }
+  };
   auto fx = [&](float val, unsigned row) -> unsigned long long {
     bool lz;
     const unsigned long long f = fxl(val, lz);
     if constexpr (LZ) {
-      if (lz) mark(row);
+      if (lz) mark(row, val);
     }
     return f;
   };
@@ -892,10 +902,10 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const unsigned long long f0 = fxl(x.x, l0), f1 = fxl(x.y, l1), f2 = fxl(x.z, l2), f3 = fxl(x.w, l3);
     if constexpr (LZ) {
       if (l0 | l1 | l2 | l3) {
-        if (l0) mark(v.x);
-        if (l1) mark(v.y);
-        if (l2) mark(v.z);
-        if (l3) mark(v.w);
+        if (l0) mark(v.x, x.x);
+        if (l1) mark(v.y, x.y);
+        if (l2) mark(v.z, x.z);
+        if (l3) mark(v.w, x.w);
       }
     }
     const bool e1 = v.y == v.x, e2 = v.z == v.y, e3 = v.w == v.z;
@@ -1043,14 +1053,15 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
         unsigned long long fv[MUNR];
 #pragma unroll
         for (int r = 0; r < MUNR; r++) {
-          fv[r] = fxl(FA ? gdn_fmul(f[r], a[r]) : f[r], lz[r]);
+          if (FA) f[r] = gdn_fmul(f[r], a[r]);
+          fv[r] = fxl(f[r], lz[r]);
           any |= lz[r];
         }
         if constexpr (LZ) {
           if (any) {
 #pragma unroll
             for (int r = 0; r < MUNR; r++)
-              if (lz[r]) mark(rc[r] & RMASK);
+              if (lz[r]) mark(rc[r] & RMASK, f[r]);
           }
         }
 #pragma unroll
@@ -1099,13 +1110,14 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const size_t row0 = (size_t)b << log_bin;
     const unsigned lo = dst_bits ? bin_lo[b] : (unsigned)row0;
     const unsigned hi = dst_bits ? bin_lo[b + 1] : (unsigned)((row0 + bn < (size_t)m_local) ? row0 + bn : (size_t)m_local);
-    // the row's sum; NaN = "recompute me" for a row that took a lossy product and whose sum is too small to hide it
+    // the row's sum; PB_REPAIR_ROW = "recompute me" for a row that took a lossy product and whose sum is too small to
+    // hide it, or a product fixed point cannot hold
     auto row_sum = [&](unsigned k) -> float {
       const unsigned long long a = s_acc[k];
       if constexpr (LZ) {
         if ((s_lossy[k >> 5] >> (k & 31u)) & 1u) {
           const unsigned long long mag = (long long)a < 0 ? 0ull - a : a;
-          if (mag < PB_LOSSY_MIN_SUM) return __uint_as_float(0x7FC00000u);
+          if (mag < PB_LOSSY_MIN_SUM || ((s_force[k >> 5] >> (k & 31u)) & 1u)) return __uint_as_float(PB_REPAIR_ROW);
         }
       }
       return op.from_fixed(a, bad);

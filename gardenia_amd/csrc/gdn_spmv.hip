@@ -59,7 +59,9 @@ struct SpmvOp {
   };
   __device__ __forceinline__ Pre pre(int32_t row) const { return Pre{y[row]}; }
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
-    if (sum != sum) repair(row);  // y[row] stays as it is: the repair pass adds the row's sum
+    // PB_REPAIR_ROW (PB plans with `track` only): y[row] stays as it is, the repair pass adds the row's sum.  Any other
+    // NaN is a NaN sum (nan / inf in Ax or x on the CSR layout) and is stored like the reference's loop stores it.
+    if (track && __float_as_uint(sum) == PB_REPAIR_ROW) repair(row);
     else y[row] = gdn_fadd(p.y, sum);
     return 0.0;
   }
@@ -73,7 +75,7 @@ struct SpmvOp {
     pb_f32x4 o;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      if (sum[c] != sum[c]) {
+      if (track && __float_as_uint(sum[c]) == PB_REPAIR_ROW) {
         repair(row + c);
         o[c] = p.y[c];
       } else {
@@ -94,11 +96,17 @@ struct SpmvOp {
   int32_t *repair_rows;
   unsigned repair_cap;
   __device__ __forceinline__ unsigned long long to_fixed_lossy(float v, unsigned &bad, bool &lz) const {
-    const unsigned long long f = pb_to_fixed_signed(v, scale[0], bad, &lz);
-    lz = lz && track;
+    unsigned unfit = 0u;  // inf, nan or beyond the scale (the scale is made for the FINITE values): 0 is added and the
+    const unsigned long long f = pb_to_fixed_signed(v, scale[0], unfit, &lz);  // row is recomputed (must_repair)
+    lz = (lz || unfit) && track;
+    if (!track) bad |= unfit;
     return f;
   }
+  __device__ __forceinline__ bool must_repair(float v) const {
+    return (__float_as_uint(v * scale[0]) & 0x7FFFFFFFu) >= 0x5E800000u;  // pb_to_fixed_signed's range test
+  }
   __device__ __forceinline__ void repair(int32_t row) const {
+    if (!repair_cnt) return;
     const unsigned pos = atomicAdd(repair_cnt, 1u);
     if (pos < repair_cap) repair_rows[pos] = row;
   }
@@ -117,7 +125,7 @@ spmv_absmax_kernel(const float *__restrict__ v, size_t n, unsigned *__restrict__
   unsigned mx = 0;
   for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * GDN_BLOCK) {
     const unsigned b = __float_as_uint(v[i]) & 0x7FFFFFFFu;
-    mx = b > mx ? b : mx;
+    mx = (b > mx && b < 0x7F800000u) ? b : mx;  // finite values only (inf / nan products are repaired row by row)
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -149,7 +157,9 @@ __global__ void spmv_scale_kernel(const unsigned *__restrict__ mx, float *__rest
   const float a = __uint_as_float(mx[0]), x = __uint_as_float(mx[1]);
   const float bound = a * x * (float)(mx[3] ? mx[3] : 1u);
   int e = 0;
-  if (bound > 0.0f && bound < 3.0e38f) (void)frexpf(bound, &e);  // bound < 2^e
+  if (!(bound < 3.0e38f)) e = 128;  // the bound itself overflows fp32 (the maxima are finite): the coarsest scale;
+                                    // ordinary products then lose bits and their rows are recomputed in fp32
+  else if (bound > 0.0f) (void)frexpf(bound, &e);  // bound < 2^e
   int shift = 61 - e;
   if (shift > 120) shift = 120;
   if (shift < -120) shift = -120;
@@ -290,7 +300,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       }
       hipLaunchKernelGGL(spmv_maxdeg_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->m, p->mx.p + 3);
       const int lds_a = (int)((sizeof(float) << p->pb.log_chunk) + 16);
-      const int lds_b = (int)((sizeof(unsigned long long) << p->pb.log_bin) + ((size_t)1 << p->pb.log_bin) / 8);
+      const int lds_b = (int)((sizeof(unsigned long long) << p->pb.log_bin) + ((size_t)1 << p->pb.log_bin) / 4);
       hipError_t e = hipFuncSetAttribute((const void *)pb_expand_scaled_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
       if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<SpmvOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
@@ -347,7 +357,7 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
   op.repair_rows = plan->repair_rows.p;
   op.repair_cap = (unsigned)plan->m;
   const size_t lds_a = (sizeof(float) << pb.log_chunk) + 16;
-  const size_t lds_b = (sizeof(unsigned long long) << pb.log_bin) + ((size_t)1 << pb.log_bin) / 8;  // + the lossy-row bitmap
+  const size_t lds_b = (sizeof(unsigned long long) << pb.log_bin) + ((size_t)1 << pb.log_bin) / 4;  // + the lossy / must-repair bitmaps
   const bool timed = pb.timing && pb.ev_used + 3 <= pb.ev.size();
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
   hipLaunchKernelGGL(pb_expand_scaled_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, s, d_x, pb.m_global,

@@ -743,6 +743,48 @@ def test_spmv_pb_wide_dynamic_range(orc, monkeypatch, tiers):
     assert orc.spmv_max_rel_error(got, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)
 
 
+@pytest.mark.parametrize("layout,tiers", [(0, False), (1, False), (1, True)])
+def test_spmv_nonfinite_values_propagate_like_the_reference(orc, monkeypatch, layout, tiers):
+    """NaN / inf in x (or a product that overflows) must come out of SpmvSolver the way the reference's fp32 loop
+    (src/spmv/omp_base.cc:22-33) produces them: NaN rows NaN, inf rows inf, every other row within 1e-4.  The
+    merge-path layout (one-shot gdn_spmv, CSR plans) stores the NaN sum; the fixed-point layout cannot hold such a
+    product, marks the row and recomputes it in fp32 (it used to take NaN as its internal repair signal and
+    dereference a null repair list on the CSR layout)."""
+    if tiers:
+        monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    g = graphio.rmat_graph(14, 16, seed=73)
+    gi = graphio.transpose(g)
+    rng = np.random.default_rng(73)
+    Ax = rng.random(gi.nnz, dtype=np.float32) + np.float32(0.5)
+    x = rng.random(gi.m, dtype=np.float32) + np.float32(0.5)
+    deg = np.diff(g.rowptr.astype(np.int64))  # columns of gi = sources of g: pick columns that occur
+    used = np.flatnonzero(deg > 0)
+    x[used[3]] = np.nan
+    x[used[40]] = np.inf
+    x[used[-5]] = np.float32(3e38)  # finite, but 3e38 * 1.4 overflows in some rows
+    hub = int(np.argmax(deg))
+    x[hub] = np.inf  # a column the tiers serve from their table
+    y0 = rng.random(gi.m, dtype=np.float32)
+    with np.errstate(all="ignore"):
+        want = orc.spmv(gi, Ax, x, y0.copy())
+    assert np.isnan(want).any() and np.isinf(want).any() and np.isfinite(want).sum() > 0
+    if layout == 0:
+        got = y0.copy()
+        solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x, got)
+        got2 = None
+    sp = solvers.ResidentSpMV(solvers.Graph(csr=g, in_csr=gi), Ax, layout=layout)
+    got_plan = sp.multiply(x, y0.copy())
+    sp.close()
+    for res in ([got, got_plan] if layout == 0 else [got_plan]):
+        assert np.array_equal(np.isnan(res), np.isnan(want))
+        inf = np.isinf(want)
+        assert np.array_equal(res[inf], want[inf])
+        fin = np.isfinite(want)
+        assert np.isfinite(res[fin]).all()
+        rel = np.abs(res[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-30)
+        assert float(rel.max()) < 1e-4
+
+
 # ------------------------------------------------------------------ SSSP
 @pytest.mark.parametrize("case", ["test_bc_unit", "chesapeake_unit", "rmat10_unit", "rmat10_w255"])
 @pytest.mark.parametrize("delta", [1, 7, 1 << 20])
