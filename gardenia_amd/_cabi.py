@@ -134,6 +134,7 @@ PROTOTYPES = {
     "gdn_tc_dev": (C.c_int, [_vp, _i32, C.POINTER(_u64), _st]),
     "gdn_graph_orient": (C.c_int, [_vp, _pp]),
     "gdn_tc_model_bytes": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "gdn_tc_probe_counts": (C.c_int, [_vp, C.POINTER(_u64)]),
     "gdn_tc_rows_dev": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64), _st]),
 }
 

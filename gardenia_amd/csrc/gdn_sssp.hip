@@ -483,6 +483,7 @@ struct SsspSmallState {
   unsigned overflow;
   int max_dist;
   unsigned passes, buckets;
+  unsigned long long relaxed_edges;  // out: out-degree sum of the NEAR lists the passes of this launch walked
 };
 
 // wave-aggregated slot reservation on an LDS counter (all lanes of the wave must call it; a lane per item serialises on
@@ -513,6 +514,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
   long long thr_lo = state->thr_lo, thr_hi = state->thr_hi;
   int pass = state->pass, status = 0;
   unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0;
+  unsigned long long relaxed_edges = 0;
   auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
   if (threadIdx.x == 0) {
     s_over = 0u;
@@ -524,6 +526,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
       // ---- one relax pass over NEAR (sssp_relax_kernel's work)
       ++pass;
       ++passes;
+      relaxed_edges += near_edges;
       if (threadIdx.x == 0) {
         s_nn = 0u;
         s_nf = n_far;
@@ -702,6 +705,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
     state->max_dist = s_maxd;
     state->passes = passes;
     state->buckets = buckets;
+    state->relaxed_edges = relaxed_edges;
   }
 }
 
@@ -746,6 +750,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
   long long thr_lo = state->thr_lo, thr_hi = state->thr_hi;
   int pass = state->pass, status = 0;
   unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0, ph = 0;
+  unsigned long long relaxed_edges = 0;
   int32_t maxd = 0;
   bool over = false;
   auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
@@ -766,6 +771,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       SsspCoopCnt *cur = begin_phase();
       ++pass;
       ++passes;
+      relaxed_edges += near_edges;
       const vid_t *near_in = near_sel ? near1 : near0;
       vid_t *near_out = near_sel ? near0 : near1;
       vid_t *far_cur = far_sel ? far1 : far0;
@@ -936,6 +942,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
     state->overflow = over ? 1u : 0u;
     state->passes = passes;
     state->buckets = buckets;
+    state->relaxed_edges = relaxed_edges;
   }
 }
 
@@ -978,6 +985,23 @@ sssp_bitmap_to_queue(const unsigned *__restrict__ bits, unsigned nwords, int32_t
   }
   deg = gdn_wave_sum(deg);
   if (gdn_lane() == 0 && deg) atomicAdd(&cnt->relaxed, deg);
+}
+
+// out-degree sum of the rows a bitmap marks (what a frontier-proportional pass over them would relax)
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_bitmap_edges_kernel(const unsigned *__restrict__ bits, unsigned nwords, int32_t m, const eoff_t *__restrict__ rowptr,
+                         unsigned long long *__restrict__ out) {
+  unsigned long long deg = 0;
+  for (unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x; w < nwords; w += gridDim.x * GDN_BLOCK) {
+    unsigned word = bits[w];
+    while (word) {
+      const unsigned v = w * 32u + (unsigned)(__ffs((int)word) - 1);
+      word &= word - 1u;
+      if (v < (unsigned)m) deg += rowptr[v + 1] - rowptr[v];
+    }
+  }
+  deg = gdn_wave_sum(deg);
+  if (gdn_lane() == 0 && deg) atomicAdd(out, deg);
 }
 
 struct gdn_sssp_plan {
@@ -1166,6 +1190,8 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   int32_t pass = 0;
   int phases = 0;
   int32_t max_finite = 0;  // largest finite distance written so far
+  unsigned long long relaxed_total = 0;  // edges relaxed ("x re-relaxation count"): list passes count the out-edges
+                                         // of their list, a dense sweep all nnz; reported in stats.last_error
   SsspCounters h;
   ExpBigList big;
   big.items = p.bigitems.p;
@@ -1241,6 +1267,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
           fprintf(stderr, "[sssp] %7.1f us small: %u passes, %u buckets -> status %d, bucket [%lld,%lld): near %u (%llu edges) far %u\n",
                   lap(), ss.passes, ss.buckets, ss.status, ss.thr_lo, ss.thr_hi, ss.n_near, ss.near_edges, ss.n_far);
         phases += (int)ss.passes;
+        relaxed_total += ss.relaxed_edges;
         n_near = ss.n_near;
         n_far = ss.n_far;
         near_edges = ss.near_edges;
@@ -1299,6 +1326,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         fprintf(stderr, "[sssp] %7.1f us coop: %u passes, %u buckets -> status %d, bucket [%lld,%lld): near %u (%llu edges) far %u\n",
                 lap(), ss.passes, ss.buckets, ss.status, ss.thr_lo, ss.thr_hi, ss.n_near, ss.near_edges, ss.n_far);
       phases += (int)ss.passes;
+      relaxed_total += ss.relaxed_edges;
       n_near = ss.n_near;
       n_far = ss.n_far;
       near_edges = ss.near_edges;
@@ -1322,6 +1350,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         unsigned long long improved = 0;
         do {
           ++phases;
+          relaxed_total += g->nnz;
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
           GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
@@ -1338,9 +1367,18 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
           GDN_TRY(sssp_read(p, p.cnt.p, h));
           improved = h.relaxed;
           max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
-          if (trace)
-            fprintf(stderr, "[sssp] %7.1f us phase %d dense sweep (%d-byte weights, %d-bit candidates): %llu rows improved, max distance %d\n",
-                    lap(), phases, p.w_bytes, cbits, improved, max_finite);
+          if (trace) {
+            const double us = lap();
+            unsigned long long ie = 0;  // (trace only) the out-edges of the improved rows
+            DevBuf<unsigned long long> d_ie;
+            if (d_ie.alloc(1) == GDN_OK && hipMemset(d_ie.p, 0, 8) == hipSuccess) {
+              hipLaunchKernelGGL(sssp_bitmap_edges_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, p.improved.p, p.nwords, m, g->rowptr, d_ie.p);
+              (void)hipMemcpy(&ie, d_ie.p, 8, hipMemcpyDeviceToHost);
+            }
+            fprintf(stderr, "[sssp] %7.1f us phase %d dense sweep (%d-byte weights, %d-bit candidates): %llu rows improved (%llu out-edges = %.1f %% of the graph), max distance %d\n",
+                    us, phases, p.w_bytes, cbits, improved, ie, 100.0 * (double)ie / (double)(g->nnz ? g->nnz : 1), max_finite);
+            (void)lap();
+          }
         } while (improved * dense_out > (unsigned long long)m);
         // the rows improved by the LAST sweep are the only ones with unpropagated distances: they
         // become a plain Bellman-Ford worklist (one infinite bucket); the parked FAR list is
@@ -1367,6 +1405,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       const bool pre_dense = p.dense && thr_hi < (int64_t)GDN_DIST_INF && near_edges * dense_pre > (unsigned long long)g->nnz;
       ++pass;
       ++phases;
+      relaxed_total += near_edges;
       h.near_count = 0;
       h.far_count = n_far;
       h.big_count = 0;
@@ -1474,6 +1513,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   uint64_t te = 0;
   GDN_TRY(gdn_reached_edges(g, d_dist, GDN_DIST_INF, &te));
   st.edges_traversed = te;
+  st.last_error = (double)relaxed_total;  // SSSP: edges relaxed over the whole solve (exact below 2^53)
   if (stats) *stats = st;
   return GDN_OK;
 }
@@ -1511,8 +1551,16 @@ int gdn_sssp_dev(const gdn_graph *g, const int32_t *d_weight, int32_t source, in
   GDN_REQUIRE(g != nullptr && d_dist != nullptr && (d_weight != nullptr || g->nnz == 0), "null argument");
   GDN_REQUIRE(source >= 0 && source < g->m, "source out of range");
   GDN_REQUIRE(delta >= 1, "delta must be >= 1");
+  // The blocked layout the dense sweeps need is built INSIDE the call from 2^24 edges on and reported as prep_ms -- where
+  // the reference's blocked solvers do their preprocessing (before t.Start(): src/pr/push_pb.cu:271,339,
+  // include/segmenting.h:31-176).  RMAT-24: 33 ms of build against a solve that drops from 32.6 to 3.6 ms; below 2^24 edges
+  // the worklists alone are faster than the build.  Not cached across calls: a caller that solves from many sources
+  // holds a plan (gdn_sssp_plan_create / gdn_sssp_run) -- keying a hidden cache on caller pointers would return stale
+  // layouts for arrays rewritten in place.  GDN_SSSP_ONESHOT_DENSE_MIN moves the threshold (0 = never).
+  unsigned long long dense_min = 1ull << 24;
+  if (const char *e = gdn_option("GDN_SSSP_ONESHOT_DENSE_MIN")) dense_min = strtoull(e, nullptr, 10);
   gdn_sssp_plan p;
-  GDN_TRY(sssp_plan_init(p, g, d_weight, /*dense=*/false));
+  GDN_TRY(sssp_plan_init(p, g, d_weight, /*dense=*/dense_min != 0 && g->nnz >= dense_min));
   return sssp_run(p, source, delta, d_dist, stats);
 }
 

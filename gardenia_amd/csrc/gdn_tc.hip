@@ -445,6 +445,93 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
   if (threadIdx.x == 0 && count) atomicAdd(total, count);
 }
 
+// ------------------------------------------------------------------------------------------
+// The north star's formulation, kept as a measured alternative (GDN_TC_FORM=bs): one WAVEFRONT per DAG edge (u, v),
+// the elements of the SHORTER of N+(u) / N+(v) are looked up in the LONGER by binary search -- the reference's
+// warp_edge kernel (src/tc/gpu_base.cu:11-23 over include/graph_gpu.h:253 warp_intersect_cache and
+// include/search.cuh:45 binary_search_2phase_cta), re-cut for 64 lanes: 64 evenly spaced PIVOTS of the longer list sit in
+// the wave's LDS strip, a key first finds its segment among the pivots (6 LDS steps), then finishes in global memory
+// inside that segment (log2(len / 64) dependent loads; none for lists of up to 64 ids, which the strip holds whole).
+// A wave owns the edges of 16 consecutive rows per grab; heavy rows are not cut (the A/B is run at sizes where that
+// tail does not dominate).  Same count as the hash-set kernel (tests); measured against it in bench.py / DESIGN 4.6.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_bs_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t row_lo, int32_t row_hi,
+                   unsigned *__restrict__ cursor, unsigned long long *__restrict__ total) {
+  __shared__ vid_t s_piv[GDN_WAVES_PER_BLOCK][64];
+  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
+  vid_t *piv = s_piv[w];
+  unsigned long long count = 0;
+  for (;;) {
+    unsigned u0 = 0;
+    if (lane == 0) u0 = atomicAdd(cursor, 16u);
+    u0 = (unsigned)row_lo + __shfl(u0, 0, 64);
+    if (u0 >= (unsigned)row_hi) break;
+    const unsigned u1 = u0 + 16u < (unsigned)row_hi ? u0 + 16u : (unsigned)row_hi;
+    for (unsigned u = u0; u < u1; u++) {
+      const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
+      const unsigned du = (unsigned)(ue - ub);
+      if (du < 2u) continue;  // a single out-neighbour closes no triangle
+      for (eoff_t e = ub; e < ue; e++) {
+        const vid_t v = colidx[e];
+        const eoff_t vb = rowptr[v], ve = rowptr[v + 1];
+        const unsigned dv = (unsigned)(ve - vb);
+        if (dv == 0u) continue;
+        const bool u_short = du <= dv;
+        const vid_t *__restrict__ S = colidx + (u_short ? ub : vb);
+        const vid_t *__restrict__ Lg = colidx + (u_short ? vb : ub);
+        const unsigned ns = u_short ? du : dv, nl = u_short ? dv : du;
+        // pivot j = Lg[floor(j * nl / 64)]: pivot 0 is the first id, segments are [p_j, p_{j+1})
+        piv[lane] = Lg[(unsigned)(((unsigned long long)lane * nl) >> 6)];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned hits = 0;
+        for (unsigned i = lane; i < ns; i += 64) {
+          const vid_t key = S[i];
+          if (key < piv[0]) continue;
+          int lo = 0, hi = 63;  // largest j with piv[j] <= key
+#pragma unroll
+          for (int st = 0; st < 6; st++) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (piv[mid] <= key) lo = mid;
+            else hi = mid - 1;
+          }
+          if (piv[lo] == key) {
+            hits++;
+            continue;
+          }
+          unsigned a = (unsigned)(((unsigned long long)lo * nl) >> 6) + 1u;          // behind the pivot itself
+          unsigned b = (unsigned)(((unsigned long long)(lo + 1) * nl) >> 6);         // exclusive: the next pivot's position
+          if (b > nl) b = nl;
+          while (a < b) {
+            const unsigned mid = (a + b) >> 1;
+            const vid_t x = Lg[mid];
+            if (x == key) {
+              hits++;
+              break;
+            }
+            if (x < key) a = mid + 1u;
+            else b = mid;
+          }
+        }
+        count += hits;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // the strip is refilled for the next edge
+      }
+    }
+  }
+  count = gdn_wave_sum(count);
+  if (lane == 0) s_red[w] = count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) t += s_red[i];
+    if (t) atomicAdd(total, t);
+  }
+}
+
 int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n, hipStream_t s);
 
 // symmetric graph -> DAG (device arrays owned by the returned graph)
@@ -563,11 +650,20 @@ static int tc_probe_counts(const gdn_graph *dag, unsigned long long probes[2]) {
   return GDN_OK;
 }
 
+int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes) {
+  GDN_REQUIRE(dag != nullptr && probes != nullptr, "dag / probes");
+  unsigned long long p[2] = {0, 0};
+  GDN_TRY(tc_probe_counts(dag, p));
+  probes[0] = p[0];
+  probes[1] = p[1];
+  return GDN_OK;
+}
+
 // triangles closed over the source rows [row_lo, row_hi) of an oriented graph (the light-row cursor starts at row_lo and
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
 // dag_in != nullptr: the v-centric count over the rows [row_lo, row_hi) of the TRANSPOSED DAG's row space (same vertices)
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
-                         const gdn_graph *dag_in = nullptr) {
+                         const gdn_graph *dag_in = nullptr, bool binary_search = false) {
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
@@ -586,6 +682,20 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   if (row_hi <= row_lo) return GDN_OK;
   tsolve.start();  // src/tc/gpu_base.cu:52-58
   const uint64_t rows = (uint64_t)(row_hi - row_lo);
+  if (binary_search) {  // GDN_TC_FORM=bs: wave-per-edge binary-search intersect (tc_bs_count_kernel)
+    GDN_HIP(hipMemset(d_ctl.p, 0, 16));
+    hipLaunchKernelGGL(tc_bs_count_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, row_lo, row_hi, d_ctl.p,
+                       d_total.p);
+    unsigned long long hb = 0;
+    if (hipMemcpy(&hb, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+      gdn_set_error("gdn_tc: binary-search count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+      return GDN_ERR_HIP;
+    }
+    st.solve_ms = tsolve.stop_ms();
+    *total = hb;
+    st.iterations = 1;
+    return GDN_OK;
+  }
   unsigned light = dag->m >= (1 << 21) ? 512u : 256u;  // rows up to this many neighbours: one wave, whole (see TC_LIGHT_MIN)
   if (const char *e = gdn_option("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
   hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
@@ -627,16 +737,18 @@ int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats 
   // preparation like the orientation: the reference orients while loading, src/tc/main.cc:12); GDN_TC_FORM=u|v forces one
   unsigned long long probes[2] = {0, 0};
   gdn_graph *dag_in = nullptr;
+  bool bs = false;
   int rc = tc_probe_counts(dag, probes);
   if (rc == GDN_OK) {
     const char *e = gdn_option("GDN_TC_FORM");
+    bs = e && e[0] == 'b';
     const bool vform = e ? e[0] == 'v' : (double)probes[1] < 0.85 * (double)probes[0];
     if (vform && dag->nnz) rc = gdn_graph_transpose(dag, &dag_in);
   }
   st.prep_ms = tprep.stop_ms();
-  if (rc == GDN_OK) rc = tc_count_rows(dag, 0, dag->m, total, st, dag_in);
+  if (rc == GDN_OK) rc = tc_count_rows(dag, 0, dag->m, total, st, dag_in, bs);
   st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
-  st.reserved = dag_in ? 1 : 0;  // 1: the v-centric formulation ran
+  st.reserved = bs ? 2 : dag_in ? 1 : 0;  // 1: the v-centric formulation ran, 2: the binary-search intersect
   if (dag_in) gdn_graph_free(dag_in);
   if (own) gdn_graph_free(own);
   if (stats) *stats = st;

@@ -48,7 +48,8 @@ typedef struct gdn_stats {
   double h2d_ms;
   double prep_ms;           /* solver-private layout preparation (tile tables, orientation) */
   uint64_t edges_traversed; /* BFS/SSSP: sum of out-degrees of reached vertices; else nnz*iters */
-  double last_error;        /* PR: L1 change of the last iteration */
+  double last_error;        /* PR: L1 change of the last iteration; SSSP: edges RELAXED over the solve (list passes count the
+                             * out-edges of their list, a dense sweep every edge) -- SURVEY 8d's re-relaxation count */
 } gdn_stats;
 
 const char *gdn_last_error(void);
@@ -407,6 +408,11 @@ int gdn_graph_orient(const gdn_graph *csr, gdn_graph **dag);
 /* algorithmic bytes of one count on an oriented graph, SURVEY 8d's merge-equivalent model (the roofline denominator of
  * TC): 4 * SUM over DAG edges (u,v) of (d+(u) + d+(v)) + 4 nnz [source list] + 4 nnz [column ids] + 8 (m + 1) */
 int gdn_tc_model_bytes(const gdn_graph *dag, uint64_t *bytes);
+/* the list elements a count on `dag` walks: probes[0] the u-centric form (SUM over edges of d+(v); the reference's loop,
+ * src/tc/omp_base.cc:16-22), probes[1] the v-centric one (SUM of d+(u)).  gdn_tc_dev runs the cheaper one
+ * (GDN_TC_FORM=u|v forces one; GDN_TC_FORM=bs runs the wave-per-edge binary-search intersect of src/tc/gpu_base.cu:11-23
+ * instead; stats.reserved says which ran: 0 / 1 / 2).  4 B x probes = what the kernel requests from memory. */
+int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes);
 int gdn_tc_rows_dev(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats *stats);
 
 #ifdef __cplusplus

@@ -785,6 +785,68 @@ def test_spmv_nonfinite_values_propagate_like_the_reference(orc, monkeypatch, la
         assert float(rel.max()) < 1e-4
 
 
+# ------------------------------------------------------------------ PageRank: rows with very many in-edges
+@pytest.mark.parametrize("layout", ["csr", "pb"])
+def test_pr_hub_row_deviation_is_bounded_by_the_in_degree(orc, monkeypatch, layout):
+    """The reference adds a row's contributions ONE BY ONE in fp32 (src/pr/omp_base.cc:27-33): with n in-edges its sum
+    carries up to (n - 1) * 2^-24 relative error (all terms are positive), typically ~sqrt(n) * 2^-24.  This library sums a
+    row exactly (2^-62 fixed point, gdn_pb.hpp) or pairwise (merge-path tiles) and rounds once, so on rows with >= 10^4
+    in-edges it can differ from `omp_base` by more than the north star's 1e-4 -- towards the exact value.  Pinned here on
+    star-heavy rows of 10^3 .. 10^6 in-edges, one iteration from a non-uniform score vector:
+      * the GPU score is the fp64 evaluation of the row rounded to fp32 (<= 1 ulp off),
+      * it is at least as close to that evaluation as the sequential-fp32 oracle,
+      * |GPU - oracle| / oracle <= (n + 2) * 2^-24, the worst case of the reference's own summation order.
+    INTEGRATION.md section 2 tells a maintainer; tests/test_gpu_configs.py asserts the same on the hub rows of RMAT-27."""
+    monkeypatch.setenv("GDN_PR_LAYOUT", layout)
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")  # record tiers on: hub SOURCES exist too (the rows below feed each other)
+    rng = np.random.default_rng(77)
+    m = 1 << 21
+    hubs = {10 ** 3: 5, 10 ** 4: 6, 10 ** 5: 7, 10 ** 6: 8}  # in-degree -> hub row id
+    src_l, dst_l = [], []
+    for n, h in hubs.items():
+        srcs = rng.choice(np.arange(16, m, dtype=np.int64), size=n, replace=False)
+        src_l.append(srcs)
+        dst_l.append(np.full(n, h, np.int64))
+    # background: every vertex gets a couple of out-edges, so that contributions differ by out-degree
+    bg = 4 * m
+    src_l.append(rng.integers(0, m, bg))
+    dst_l.append(rng.integers(16, m, bg))
+    g = graphio.build_csr(m, np.concatenate(src_l), np.concatenate(dst_l))
+    gi = graphio.transpose(g)
+    deg = g.degrees()
+    scores0 = (rng.random(m, dtype=np.float32) + np.float32(0.25)) / np.float32(m)  # non-uniform, sums to ~0.75
+    want = scores0.copy()
+    orc.pr_iterate(gi, deg, want, 1)  # the reference's loop, one iteration
+    got = scores0.copy()
+    st = solvers.PRSolver(solvers.Graph(csr=g, in_csr=gi), got, epsilon=0.0, max_iter=1)
+    assert st["iterations"] == 2  # MAX_ITER + 1: did not converge (src/pr/omp_base.cc:39 prints iter + 1)
+    contrib = np.zeros(m, np.float32)
+    nzd = deg > 0
+    contrib[nzd] = scores0[nzd] / deg[nzd].astype(np.float32)
+    d = np.float32(0.85)
+    base = (np.float32(1.0) - d) / np.float32(m)  # src/pr/omp_base.cc:10 base_score, in fp32
+    table = {}
+    for n, h in hubs.items():
+        lo, hi = int(gi.rowptr[h]), int(gi.rowptr[h + 1])
+        assert hi - lo >= n
+        s64 = float(contrib[gi.colidx[lo:hi]].astype(np.float64).sum())
+        exact = np.float32(base + np.float32(d * np.float32(s64)))  # the reference's formula on the exactly summed row
+        ulp = float(np.spacing(exact))
+        # the fixed-point layout rounds the exact sum once; the merge-path layout adds tile partials pairwise in fp32
+        slack = ulp if layout == "pb" else 16 * ulp
+        assert abs(float(got[h]) - float(exact)) <= slack, (n, got[h], exact)
+        e64 = float(base) + float(d) * s64
+        assert abs(float(got[h]) - e64) <= abs(float(want[h]) - e64) + slack, (n, got[h], want[h], e64)
+        dev = abs(float(got[h]) - float(want[h])) / float(want[h])
+        assert dev <= (hi - lo + 2) * 2.0 ** -24, (n, dev)
+        table[n] = dev
+    print("hub-row deviation from the sequential-fp32 oracle by in-degree:", {k: "%.2e" % v for k, v in table.items()})
+    # every ordinary row (in-degree of a handful) is within the north star's 1e-4
+    small = np.diff(gi.rowptr.astype(np.int64)) < 1000
+    rel = np.abs(got[small] - want[small]) / want[small]
+    assert float(rel.max()) < 1e-4
+
+
 # ------------------------------------------------------------------ SSSP
 @pytest.mark.parametrize("case", ["test_bc_unit", "chesapeake_unit", "rmat10_unit", "rmat10_w255"])
 @pytest.mark.parametrize("delta", [1, 7, 1 << 20])
@@ -794,6 +856,25 @@ def test_sssp_golden(case, delta):
     dist = np.full(g.V(), solvers.K_DIST_INF, np.int32)
     solvers.SSSPSolver(g, int(d["source"]), d["weight"], dist, delta)
     assert np.array_equal(dist, d["dist"])
+
+
+@pytest.mark.parametrize("unit", [False, True])
+def test_sssp_oneshot_builds_the_dense_plan_inside_the_call(orc, monkeypatch, unit):
+    """SSSPSolver (one call, src/sssp/main.cc:27) builds the blocked layout itself from 2^24 edges on and reports it as
+    prep_ms; the threshold is forced down here so that the path runs at test size -- distances exact either way."""
+    g = graphio.rmat_graph(16, 16, seed=29)
+    rng = np.random.default_rng(29)
+    wt = np.ones(g.nnz, np.int32) if unit else rng.integers(1, 256, size=g.nnz).astype(np.int32)
+    s = graphio.first_nonisolated(g)
+    want = orc.sssp_dijkstra(g, wt, s)
+    for dense_min in ("0", "1"):
+        monkeypatch.setenv("GDN_SSSP_ONESHOT_DENSE_MIN", dense_min)
+        monkeypatch.setenv("GDN_SSSP_DENSE_IN", "100000")  # sweeps from m / 100000 improved rows on: they do run
+        dist = np.full(g.m, solvers.K_DIST_INF, np.int32)
+        st = solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, dist, 16)
+        assert np.array_equal(dist, want), dense_min
+        if dense_min == "1":
+            assert st["prep_ms"] > 0.0
 
 
 @pytest.mark.parametrize("scale,ef,seed,delta", [(14, 16, 21, 1), (16, 16, 22, 32), (17, 8, 23, 100)])
@@ -968,8 +1049,12 @@ def test_cc_directed_without_reverse_links_every_out_edge(orc):
 
 
 # ------------------------------------------------------------------ TC
+@pytest.mark.parametrize("form", ["u", "v", "bs"])
 @pytest.mark.parametrize("case", ["chesapeake_sym", "rmat10_sym"])
-def test_tc_golden(case):
+def test_tc_golden(case, form, monkeypatch):
+    """Every formulation of the count -- the LDS hash set walked u- or v-centric, and the north star's wave-per-edge
+    binary-search intersect (GDN_TC_FORM=bs: src/tc/gpu_base.cu:11-23 re-cut for wave64) -- gives the reference's total."""
+    monkeypatch.setenv("GDN_TC_FORM", form)
     d = golden("tc_" + case)
     total, st = solvers.TCSolver(solvers.Graph(csr=csr_from(d, "sym_"), symmetrize=True))
     assert total == int(d["total"])
@@ -979,11 +1064,14 @@ def test_tc_golden(case):
 
 
 @pytest.mark.parametrize("scale,ef,seed", [(13, 16, 41), (16, 8, 42)])
-def test_tc_vs_oracle_rmat(orc, scale, ef, seed):
+def test_tc_vs_oracle_rmat(orc, scale, ef, seed, monkeypatch):
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
     want = orc.tc(orc.tc_orient(g))
     total, _ = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
     assert total == want
+    monkeypatch.setenv("GDN_TC_FORM", "bs")  # the binary-search intersect: lists from 0 to ~10^3 ids, pivots + segments
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want and st["reserved"] == 2
 
 
 # ------------------------------------------------------------------ device graph builder
