@@ -660,7 +660,7 @@ pb_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long
 #define PB_HUB_MIN_PER_BIN 2
 #define PB_MID_MIN_PER_BIN16 4
 int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
-                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid) {
+                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid, unsigned min16) {
   *n_hubs = 0;
   if (max_mid > PB_MAX_MID) max_mid = PB_MAX_MID;
   for (int t = 0; t < max_mid; t++) n_mid[t] = 0;
@@ -710,7 +710,7 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
   ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
   ta.cap[0] = 1u << PB_HUB_LOG;
   ta.ntiers = 1;
-  uint64_t mid16 = PB_MID_MIN_PER_BIN16;
+  uint64_t mid16 = min16 ? min16 : PB_MID_MIN_PER_BIN16;
   if (const char *e = gdn_option("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
   uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
   if (const char *e = gdn_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;

@@ -135,7 +135,7 @@ int pb_pick_hubs(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<
 // by source and one record per lane, the 64 gathers of a wave instruction fall into a handful of consecutive cache
 // lines: a near-coalesced load, not a divergent gather.  4 B/edge of HBM traffic instead of 12.1.
 #ifndef PB_MAX_MID
-#define PB_MAX_MID 2  // tools/build_variant.sh sweeps it (profiles/r03_pb_tier_sweep.txt)
+#define PB_MAX_MID 4  // PageRank's default (SpMV keeps 2: its records carry Ax, 8 B per edge); profiles/r03_pb_tier_sweep*.txt
 #endif
 #define PB_MID_ROW_BITS 14
 #define PB_MID_MAX ((1u << (32 - PB_MID_ROW_BITS)) - 1u)  // sources per tier; index PB_MID_MAX can be the zero slot
@@ -156,8 +156,9 @@ struct PbTierRefresh {  // kernel argument of phase A (PageRank): the tier table
   int ntiers = 0;
   const unsigned *skip = nullptr;  // see GdnSkippable (gdn_common.hpp): a non-zero word = this launch does nothing
 };
+// min16: a mid-tier source owns at least min16 / 16 edges per average bin (0 = PB_MID_MIN_PER_BIN16; GDN_PB_MID_MIN16 overrides)
 int pb_pick_tiers(const gdn_graph *in_csr, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
-                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid);
+                  unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid, unsigned min16 = 0);
 // turns the layout pb_build made for one mid class (log_chunk 15, src_major, same bins as the main layout) into the
 // bin-major record stream; releases U, V and G of the layout
 // ev (nullable): the layout's per-edge values (pb_build's edge_vals_out, chunk-major) are moved into record order

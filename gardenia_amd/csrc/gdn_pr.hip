@@ -633,9 +633,12 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int max_mid = me ? atoi(me) : PB_MAX_MID;
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
-    unsigned n_mid[PB_MAX_MID] = {0, 0};
+    unsigned n_mid[PB_MAX_MID] = {};
     if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
-      st = pb_pick_tiers(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
+      // four mid tiers down to 1/16 edge per source and bin: RMAT-27 62 % of the edges in record tiers, 4.12 -> 3.78 ms
+      // per iteration against two tiers down to 1/4 (profiles/r03_pb_tier_sweep_reps.txt; a fifth and sixth tier give it
+      // back: their table lines are fetched for one record each)
+      st = pb_pick_tiers(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid, 1u);
     const bool any_class = p->n_hubs || n_mid[0];
     // hub rows: as many as phase A's LDS can hold accumulators for behind the slice (the slice size is known when
     // this plan covers the whole graph: sources = vertices with out-edges; a row shard takes the safe bound)

@@ -241,10 +241,10 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     PbScratch scratch;  // the key buffers of the layout builds below
     st = GDN_OK;
     const char *me = gdn_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
-    int max_mid = me ? atoi(me) : PB_MAX_MID;
+    int max_mid = me ? atoi(me) : 2;  // two here (PageRank takes PB_MAX_MID): an SpMV record carries its Ax, 8 B per edge
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
-    unsigned n_mid[PB_MAX_MID] = {0, 0};
+    unsigned n_mid[PB_MAX_MID] = {};
     if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
       st = pb_pick_tiers(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
     if (st == GDN_OK)

@@ -31,6 +31,7 @@ struct SsspCounters {
   alignas(128) int max_dist;  // largest distance written since the counters were reset (the dense sweeps size their candidates by it)
   alignas(128) int min_far;
   unsigned overflow;
+  alignas(128) unsigned long long improved_edges;  // binned relax pass: out-edges of the rows it improved
 };
 
 struct SsspVis {
@@ -341,9 +342,10 @@ __global__ void __launch_bounds__(PB_THREADS)
 sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__ bin_ptr,
                           const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
                           const CT *__restrict__ cand, int32_t *__restrict__ dist,
-                          unsigned *__restrict__ improved_bits, SsspCounters *cnt) {
+                          unsigned *__restrict__ improved_bits, SsspCounters *cnt,
+                          const eoff_t *__restrict__ out_rowptr = nullptr) {  // nullable: count the improved rows' out-edges
   extern __shared__ __attribute__((aligned(16))) unsigned s_min[];
-  __shared__ unsigned long long s_red[PB_WAVES];
+  __shared__ unsigned long long s_red[2 * PB_WAVES];
   __shared__ int s_max[PB_WAVES];
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order[blockIdx.x];
@@ -392,7 +394,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
   // epilogue: one row per thread and step; a wave covers 64 consecutive rows = 2 bitmap words
   const unsigned lane = gdn_lane();
   const size_t row0 = (size_t)b << log_bin;
-  unsigned long long improved = 0;
+  unsigned long long improved = 0, edges = 0;
   int mx = 0;
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) {
     const size_t row = row0 + i;
@@ -403,6 +405,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
       if (nm < old) {
         dist[row] = (int32_t)nm;
         mx = (int)nm > mx ? (int)nm : mx;
+        if (out_rowptr) edges += out_rowptr[row + 1] - out_rowptr[row];
         imp = true;
       }
     }
@@ -411,6 +414,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
     if (lane == 0) improved += (unsigned long long)__popcll(mask);
   }
   improved = gdn_wave_sum(improved);
+  edges = gdn_wave_sum(edges);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const int t = __shfl_xor(mx, o, 64);
@@ -418,17 +422,20 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
   }
   if (lane == 0) {
     s_red[threadIdx.x >> 6] = improved;
+    s_red[PB_WAVES + (threadIdx.x >> 6)] = edges;
     s_max[threadIdx.x >> 6] = mx;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long t = 0;
+    unsigned long long t = 0, te = 0;
     int m2 = 0;
     for (int i = 0; i < PB_WAVES; i++) {
       t += s_red[i];
+      te += s_red[PB_WAVES + i];
       m2 = s_max[i] > m2 ? s_max[i] : m2;
     }
     if (t) atomicAdd(&cnt->relaxed, t);
+    if (te) atomicAdd(&cnt->improved_edges, te);
     if (m2 > __hip_atomic_load(&cnt->max_dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&cnt->max_dist, m2);
   }
 }
@@ -987,6 +994,201 @@ sssp_bitmap_to_queue(const unsigned *__restrict__ bits, unsigned nwords, int32_t
   if (gdn_lane() == 0 && deg) atomicAdd(&cnt->relaxed, deg);
 }
 
+// ------------------------------------------------------------------------------------------
+// BINNED relax pass: Bellman-Ford over a LIST of rows whose out-edges are a fraction of the graph -- what a dense sweep
+// does for all edges (9.5 B per edge of the GRAPH, RMAT-24: 0.59 ms whatever improved), done for the list's edges only,
+// and still without a random access per edge (a worklist pass pays a divergent probe + a global atomicMin per edge).
+// Propagation blocking made on the fly, the binned top-down BFS level (gdn_bfs.hip, bfs_btd_*) with a payload:
+//   sssp_bin_kernel / sssp_bin_big_kernel   expand the list's rows (gdn_expand.hpp); a wave step's (destination,
+//       candidate) pairs are grouped by destination bin (ballot match), each group reserves room in its bin's list with
+//       one atomic and writes its 8-byte entries side by side.  SSSP_BIN_SUB lists per bin, one per XCD.
+//   sssp_bin_apply_kernel   one workgroup per bin: its lists are streamed once, candidates are min-ed into the bin's
+//       2^logb LDS words, then the sweep's epilogue -- rows whose minimum beats their distance are written, marked in
+//       the improved bitmap and counted with their out-edges.
+// 8 B (colidx + weight) read + 8 B written + 8 B read per LIST edge.  A list that would overflow sets a flag, the apply
+// kernel then only resets the counters, and the host runs a dense sweep instead (which needs nothing from the lists).
+// ------------------------------------------------------------------------------------------
+#define SSSP_BIN_SUB 8
+#define SSSP_BIN_LOGB 15  // 2^15 rows per bin: 128 KB of LDS minima
+#define SSSP_BIN_THREADS 1024
+#define SSSP_BIN_FRAC 4   // a binned pass takes lists whose rows own at most nnz / 4 out-edges ...
+#define SSSP_BIN_SLACK 3  // ... and every list has room for 3 times its even share
+__device__ __forceinline__ unsigned sssp_xcc_id() { return __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u; }  // HW_REG_XCC_ID
+struct SsspBinVis {
+  const vid_t *__restrict__ colidx;
+  const int32_t *__restrict__ weight;
+  const int32_t *__restrict__ dist;
+  unsigned long long *__restrict__ buf;  // entries: candidate << 32 | destination
+  unsigned *cur;                         // counter of list (bin, sub) at cur[(bin * SUB + sub) * 32]: a 128-byte line each
+  unsigned *overflow;
+  unsigned cap_each, sub;
+  int bin_bits;
+  int32_t du;  // per-lane: distance of this lane's row
+  __device__ __forceinline__ void begin_big(vid_t v) { du = dist[v]; }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t d_src = __shfl(du, owner, 64);
+    vid_t dst = 0;
+    unsigned bin = 0, cand = 0;
+    if (valid) {
+      dst = __builtin_nontemporal_load(colidx + k);
+      cand = (unsigned)(d_src + __builtin_nontemporal_load(weight + k));
+      bin = (unsigned)dst >> SSSP_BIN_LOGB;
+    }
+    unsigned long long peers = __ballot(valid);
+    if (peers == 0ull) return;
+    for (int b = 0; b < bin_bits; b++) {
+      const bool one = (bin >> b) & 1u;
+      const unsigned long long mk = __ballot(one && valid);
+      peers &= one ? mk : ~mk;
+    }
+    const unsigned lane = gdn_lane();
+    const unsigned rank = (unsigned)__popcll(peers & gdn_lanemask_lt());
+    const size_t slot = (size_t)bin * SSSP_BIN_SUB + sub;
+    unsigned base = 0;
+    // the counter is only added to from ONE XCD (sub = its id) and read behind a kernel boundary: workgroup scope keeps
+    // the add in that XCD's L2 (gdn_bfs.hip, bfs_btd_reserve)
+    if (valid && rank == 0u) base = __hip_atomic_fetch_add(cur + slot * 32, (unsigned)__popcll(peers), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    base = __shfl(base, valid ? __ffsll((long long)peers) - 1 : (int)lane, 64);
+    if (valid) {
+      const unsigned pos = base + rank;
+      if (pos < cap_each) buf[slot * cap_each + pos] = ((unsigned long long)cand << 32) | (unsigned)dst;
+      else *overflow = 1u;
+    }
+  }
+  __device__ __forceinline__ void finish() {}
+};
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_bin_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ inq, unsigned n, ExpBigList big, SsspBinVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vid_t v = 0;
+  vis.du = 0;
+  if (i < n) {
+    v = inq[i];
+    vis.du = vis.dist[v];
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  vis.sub = sssp_xcc_id() & (SSSP_BIN_SUB - 1);
+  gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_bin_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, SsspBinVis vis) {
+  vis.du = 0;
+  vis.sub = sssp_xcc_id() & (SSSP_BIN_SUB - 1);
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
+__global__ void __launch_bounds__(SSSP_BIN_THREADS)
+sssp_bin_apply_kernel(const unsigned long long *__restrict__ buf, unsigned *cur, const unsigned *__restrict__ overflow,
+                      unsigned cap_each, int32_t m, int32_t *__restrict__ dist, unsigned *__restrict__ improved_bits,
+                      const eoff_t *__restrict__ rowptr, SsspCounters *cnt, vid_t *__restrict__ queue, unsigned qcap) {
+  extern __shared__ __attribute__((aligned(16))) unsigned s_min[];  // 2^SSSP_BIN_LOGB words
+  __shared__ unsigned long long s_red[SSSP_BIN_THREADS / 64];
+  __shared__ int s_max[SSSP_BIN_THREADS / 64];
+  const unsigned bin = blockIdx.x, bn = 1u << SSSP_BIN_LOGB;
+  const bool skip = *overflow != 0u;  // the lists are incomplete: the host runs a dense sweep instead
+  if (!skip)
+    for (unsigned i = threadIdx.x; i < bn; i += SSSP_BIN_THREADS) s_min[i] = (unsigned)GDN_DIST_INF;
+  __syncthreads();
+  for (unsigned sub = 0; sub < SSSP_BIN_SUB && !skip; sub++) {
+    const size_t slot = (size_t)bin * SSSP_BIN_SUB + sub;
+    unsigned n = cur[slot * 32];
+    n = n < cap_each ? n : cap_each;
+    const unsigned long long *__restrict__ src = buf + slot * cap_each;
+    constexpr int UNR = 4;
+    for (unsigned i0 = threadIdx.x; i0 < n; i0 += UNR * SSSP_BIN_THREADS) {
+      unsigned long long e[UNR];
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const unsigned i = i0 + (unsigned)r * SSSP_BIN_THREADS;
+        e[r] = i < n ? __builtin_nontemporal_load(src + i) : ~0ull;
+      }
+#pragma unroll
+      for (int r = 0; r < UNR; r++)
+        if (e[r] != ~0ull) atomicMin(&s_min[(unsigned)e[r] & (bn - 1u)], (unsigned)(e[r] >> 32));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < SSSP_BIN_SUB) cur[((size_t)bin * SSSP_BIN_SUB + threadIdx.x) * 32] = 0u;  // ready for the next pass
+  if (skip) return;
+  // epilogue: one row per thread and step (a wave covers 64 consecutive rows = 2 bitmap words); the improved rows also go
+  // into the queue of the next pass: a thread remembers its 32 steps' outcomes in one mask, the workgroup reserves its
+  // share of the queue with ONE atomic, the second walk places the rows
+  static_assert((1u << SSSP_BIN_LOGB) / SSSP_BIN_THREADS == 32u, "one mask bit per step");
+  const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
+  const size_t row0 = (size_t)bin << SSSP_BIN_LOGB;
+  unsigned mine = 0u, wave_cnt = 0u;
+  unsigned long long edges = 0;
+  int mx = 0;
+#pragma unroll 4
+  for (unsigned k = 0; k < 32u; k++) {
+    const unsigned i = k * SSSP_BIN_THREADS + threadIdx.x;
+    const size_t row = row0 + i;
+    bool imp = false;
+    const unsigned nm = s_min[i];
+    if (row < (size_t)m && nm != (unsigned)GDN_DIST_INF) {
+      const unsigned old = (unsigned)dist[row];
+      if (nm < old) {
+        dist[row] = (int32_t)nm;
+        mx = (int)nm > mx ? (int)nm : mx;
+        edges += rowptr[row + 1] - rowptr[row];
+        imp = true;
+      }
+    }
+    const unsigned long long mask = __ballot(imp);
+    if ((lane & 31u) == 0 && row < (((size_t)m + 31) & ~(size_t)31)) improved_bits[row >> 5] = (unsigned)(mask >> (lane & 32u));
+    mine |= imp ? (1u << k) : 0u;
+    wave_cnt += (unsigned)__popcll(mask);
+  }
+  edges = gdn_wave_sum(edges);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  __shared__ unsigned s_wcnt[SSSP_BIN_THREADS / 64], s_base;
+  if (lane == 0) {
+    s_wcnt[w] = wave_cnt;
+    s_red[w] = edges;
+    s_max[w] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long ed = 0;
+    unsigned a = 0;
+    int mm = 0;
+    for (int i = 0; i < SSSP_BIN_THREADS / 64; i++) {
+      a += s_wcnt[i];
+      ed += s_red[i];
+      mm = s_max[i] > mm ? s_max[i] : mm;
+    }
+    s_base = 0u;
+    if (a) {
+      s_base = atomicAdd(&cnt->near_count, a);  // the queue of the next pass
+      atomicAdd(&cnt->relaxed, (unsigned long long)a);  // rows improved (as the sweep's epilogue counts them)
+      atomicAdd(&cnt->improved_edges, ed);              // their out-edges
+      atomicMax(&cnt->max_dist, mm);
+    }
+  }
+  __syncthreads();
+  unsigned pos = s_base;
+  for (unsigned i = 0; i < w; i++) pos += s_wcnt[i];
+  for (unsigned k = 0; k < 32u && wave_cnt; k++) {  // wave_cnt is wave-uniform
+    const bool imp = (mine >> k) & 1u;
+    const unsigned long long mask = __ballot(imp);
+    if (imp) {
+      const unsigned at = pos + (unsigned)__popcll(mask & gdn_lanemask_lt());
+      if (at < qcap) queue[at] = (vid_t)(row0 + k * SSSP_BIN_THREADS + threadIdx.x);
+      else cnt->overflow = 1u;
+    }
+    pos += (unsigned)__popcll(mask);
+  }
+}
+
 // out-degree sum of the rows a bitmap marks (what a frontier-proportional pass over them would relax)
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_bitmap_edges_kernel(const unsigned *__restrict__ bits, unsigned nwords, int32_t m, const eoff_t *__restrict__ rowptr,
@@ -1013,6 +1215,11 @@ struct gdn_sssp_plan {
   DevBuf<uint8_t> Wn;      // the same as u8 / u16 (w_bytes 1 / 2)
   int w_bytes = 4;         // 0: all weights equal (w_min), no stream
   int32_t w_min = 0, w_max = 0;
+  // binned relax passes (sssp_bin_*): nbins x SSSP_BIN_SUB lists of bin_cap_each 8-byte entries, their counters, the flag
+  DevBuf<unsigned long long> bin_buf;
+  DevBuf<unsigned> bin_cur, bin_ovf;
+  unsigned bin_nbins = 0, bin_cap_each = 0;
+  int bin_bits = 0;
   DevBuf<unsigned> cand;   // candidate distances, bin-major (u16 or u32 per sweep)
   DevBuf<unsigned> improved;
   DevBuf<unsigned> bad;    // 1 word: a 16-bit candidate overflowed (cannot happen; checked)
@@ -1033,7 +1240,7 @@ struct gdn_sssp_plan {
   double prep_ms = 0;
 };
 
-static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d_weight, bool dense) {
+static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d_weight, bool dense, bool bins = true) {
   HostTimer t;
   t.start();
   p.g = g;
@@ -1114,6 +1321,30 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     }
     p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lg) / 32u);
     GDN_TRY(p.improved.alloc(p.nwords + 64));
+    if (bins && !gdn_option("GDN_SSSP_NO_BINS")) {
+      // lists of the binned relax passes: a pass runs while the improved rows own at most nnz / SSSP_BIN_FRAC out-edges;
+      // room for SSSP_BIN_SLACK times the even share per list (destinations that crowd into few bins overflow a list:
+      // the pass is then repeated as a dense sweep)
+      const uint64_t nb = (((uint64_t)m + (1u << SSSP_BIN_LOGB) - 1) >> SSSP_BIN_LOGB);
+      uint64_t per = (g->nnz / SSSP_BIN_FRAC) * SSSP_BIN_SLACK / (nb * SSSP_BIN_SUB) + 1;
+      per = per < 4096 ? 4096 : per;
+      if (const char *e = gdn_option("GDN_SSSP_BIN_CAP")) per = atoi(e) > 0 ? (uint64_t)atoi(e) : per;  // test knob: short lists overflow
+      per = (per + 15) & ~(uint64_t)15;
+      if (per < 0x7FFFFFFFull && m >= (1 << SSSP_BIN_LOGB)) {
+        GDN_TRY(p.bin_buf.alloc((size_t)(nb * SSSP_BIN_SUB * per)));
+        GDN_TRY(p.bin_cur.alloc((size_t)(nb * SSSP_BIN_SUB * 32)));
+        GDN_HIP(hipMemset(p.bin_cur.p, 0, (size_t)(nb * SSSP_BIN_SUB * 32) * 4));
+        p.bin_nbins = (unsigned)nb;
+        p.bin_cap_each = (unsigned)per;
+        p.bin_bits = 0;
+        while ((1ull << p.bin_bits) < nb) p.bin_bits++;
+        if (hipFuncSetAttribute((const void *)sssp_bin_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                4 << SSSP_BIN_LOGB) != hipSuccess) {
+          gdn_set_error("hipFuncSetAttribute(dynamic LDS, sssp_bin_apply_kernel)");
+          return GDN_ERR_HIP;
+        }
+      }
+    }
     const int lds = (int)((sizeof(unsigned) << lg) + 16);
     const void *fns[] = {(const void *)sssp_pb_expand_kernel<0, uint16_t>, (const void *)sssp_pb_expand_kernel<1, uint16_t>,
                          (const void *)sssp_pb_expand_kernel<2, uint16_t>, (const void *)sssp_pb_expand_kernel<4, uint16_t>,
@@ -1167,7 +1398,8 @@ static void sssp_launch_sweep(gdn_sssp_plan &p, int32_t m, int32_t *d_dist) {
   }
 #undef SSSP_EXPAND
   hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_pb_accumulate_kernel<CT>), dim3(p.pb.nbins), dim3(PB_THREADS), lds, 0, m, p.pb.log_bin,
-                     p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, cand, d_dist, p.improved.p, p.cnt.p);
+                     p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, cand, d_dist, p.improved.p, p.cnt.p,
+                     p.bin_nbins ? p.g->rowptr : nullptr);
 }
 
 static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_dist, gdn_stats *stats) {
@@ -1347,50 +1579,129 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         pre_dense_done = false;
         // ---- heavy frontier: Bellman-Ford sweeps over all edges until few rows still improve
         light_streak = 0;
-        unsigned long long improved = 0;
+        unsigned long long improved = 0, imp_edges = 0;
+        // Between the sweeps and the worklist tail: BINNED passes (sssp_bin_*) while the rows improved by the last step
+        // own at most nnz / SSSP_BIN_FRAC out-edges -- they relax those edges only, still without a random access per edge.
+        // They go on while the improved rows own more than nnz / bin_out edges (GDN_SSSP_BIN_OUT), the sweeps while more
+        // than m / dense_out rows improve.
+        const bool use_bins = p.bin_nbins > 0;
+        unsigned long long bin_out = 64;
+        if (const char *e = gdn_option("GDN_SSSP_BIN_OUT")) bin_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : bin_out;
+        bool have_queue = false;  // near_in holds the rows improved by the last step (n_q of them)
+        unsigned n_q = 0;
+        bool more;
         do {
           ++phases;
-          relaxed_total += g->nnz;
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
           GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
-          // 8- / 16-bit candidates while every finite candidate (a finite distance + a weight) stays below 0xFF / 0xFFFF
-          // (GDN_SSSP_CAND32 / GDN_SSSP_CAND16: test knobs that keep the wider form)
-          const int64_t bound = (int64_t)max_finite + (int64_t)p.w_max;
-          const int cbits = gdn_option("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !gdn_option("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
-          // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
-          // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
-          // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
-          if (cbits == 8) sssp_launch_sweep<uint8_t>(p, m, d_dist);
-          else if (cbits == 16) sssp_launch_sweep<uint16_t>(p, m, d_dist);
-          else sssp_launch_sweep<uint32_t>(p, m, d_dist);
-          GDN_TRY(sssp_read(p, p.cnt.p, h));
+          bool binned = use_bins && have_queue && n_q > 0 && imp_edges * SSSP_BIN_FRAC <= (unsigned long long)g->nnz;
+          int cbits = 0;
+          if (binned) {
+            SsspBinVis bv;
+            bv.colidx = g->colidx;
+            bv.weight = d_weight;
+            bv.dist = d_dist;
+            bv.buf = p.bin_buf.p;
+            bv.cur = p.bin_cur.p;
+            bv.overflow = &p.cnt.p->overflow;
+            bv.cap_each = p.bin_cap_each;
+            bv.sub = 0;
+            bv.bin_bits = p.bin_bits;
+            bv.du = 0;
+            big.count = &p.cnt.p->big_count;
+            big.overflow = &p.cnt.p->overflow;
+            big.min_deg = (unsigned)EXP_BIG;
+            hipLaunchKernelGGL(sssp_bin_kernel, dim3(gdn_nblocks(n_q)), dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in, n_q, big, bv);
+            hipLaunchKernelGGL(sssp_bin_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, bv);
+            hipLaunchKernelGGL(sssp_bin_apply_kernel, dim3(p.bin_nbins), dim3(SSSP_BIN_THREADS), (size_t)4 << SSSP_BIN_LOGB, 0,
+                               p.bin_buf.p, p.bin_cur.p, &p.cnt.p->overflow, p.bin_cap_each, m, d_dist, p.improved.p, g->rowptr,
+                               p.cnt.p, near_out, cap);
+            GDN_TRY(sssp_read(p, p.cnt.p, h));
+            if (h.overflow) {  // a list was too short (or the item list): nothing was applied, the step is a sweep instead
+              if (trace) fprintf(stderr, "[sssp] %7.1f us phase %d binned pass overflowed its lists: repeated as a sweep\n", lap(), phases);
+              binned = false;
+              memset(&h, 0, sizeof(h));
+              h.min_far = GDN_DIST_INF;
+              GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+            } else {
+              relaxed_total += imp_edges;
+              vid_t *t = near_in;
+              near_in = near_out;
+              near_out = t;
+              n_q = h.near_count;
+              have_queue = true;
+            }
+          }
+          if (!binned) {
+            relaxed_total += g->nnz;
+            // 8- / 16-bit candidates while every finite candidate (a finite distance + a weight) stays below 0xFF / 0xFFFF
+            // (GDN_SSSP_CAND32 / GDN_SSSP_CAND16: test knobs that keep the wider form)
+            const int64_t bound = (int64_t)max_finite + (int64_t)p.w_max;
+            cbits = gdn_option("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !gdn_option("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
+            // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
+            // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
+            // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
+            if (cbits == 8) sssp_launch_sweep<uint8_t>(p, m, d_dist);
+            else if (cbits == 16) sssp_launch_sweep<uint16_t>(p, m, d_dist);
+            else sssp_launch_sweep<uint32_t>(p, m, d_dist);
+            GDN_TRY(sssp_read(p, p.cnt.p, h));
+            have_queue = false;
+          }
           improved = h.relaxed;
+          imp_edges = h.improved_edges;
           max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
           if (trace) {
             const double us = lap();
-            unsigned long long ie = 0;  // (trace only) the out-edges of the improved rows
-            DevBuf<unsigned long long> d_ie;
-            if (d_ie.alloc(1) == GDN_OK && hipMemset(d_ie.p, 0, 8) == hipSuccess) {
-              hipLaunchKernelGGL(sssp_bitmap_edges_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, p.improved.p, p.nwords, m, g->rowptr, d_ie.p);
-              (void)hipMemcpy(&ie, d_ie.p, 8, hipMemcpyDeviceToHost);
+            if (binned)
+              fprintf(stderr, "[sssp] %7.1f us phase %d binned pass: %llu rows improved (%llu out-edges = %.1f %% of the graph), max distance %d\n",
+                      us, phases, improved, imp_edges, 100.0 * (double)imp_edges / (double)(g->nnz ? g->nnz : 1), max_finite);
+            else {
+              unsigned long long ie = imp_edges;
+              if (!use_bins) {  // (trace only) the out-edges of the improved rows
+                DevBuf<unsigned long long> d_ie;
+                if (d_ie.alloc(1) == GDN_OK && hipMemset(d_ie.p, 0, 8) == hipSuccess) {
+                  hipLaunchKernelGGL(sssp_bitmap_edges_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, p.improved.p, p.nwords, m, g->rowptr, d_ie.p);
+                  (void)hipMemcpy(&ie, d_ie.p, 8, hipMemcpyDeviceToHost);
+                }
+              }
+              fprintf(stderr, "[sssp] %7.1f us phase %d dense sweep (%d-byte weights, %d-bit candidates): %llu rows improved (%llu out-edges = %.1f %% of the graph), max distance %d\n",
+                      us, phases, p.w_bytes, cbits, improved, ie, 100.0 * (double)ie / (double)(g->nnz ? g->nnz : 1), max_finite);
             }
-            fprintf(stderr, "[sssp] %7.1f us phase %d dense sweep (%d-byte weights, %d-bit candidates): %llu rows improved (%llu out-edges = %.1f %% of the graph), max distance %d\n",
-                    us, phases, p.w_bytes, cbits, improved, ie, 100.0 * (double)ie / (double)(g->nnz ? g->nnz : 1), max_finite);
             (void)lap();
           }
-        } while (improved * dense_out > (unsigned long long)m);
-        // the rows improved by the LAST sweep are the only ones with unpropagated distances: they
+          more = improved * dense_out > (unsigned long long)m ||
+                 (use_bins && improved > 0 && imp_edges * bin_out > (unsigned long long)g->nnz && imp_edges * SSSP_BIN_FRAC <= (unsigned long long)g->nnz);
+          if (more && use_bins && !have_queue && imp_edges * SSSP_BIN_FRAC <= (unsigned long long)g->nnz) {
+            // the next step is a binned pass: it needs the improved rows as a list
+            memset(&h, 0, sizeof(h));
+            h.min_far = GDN_DIST_INF;
+            GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+            hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p, p.nwords, m, near_in,
+                               p.cnt.p, cap, g->rowptr);
+            GDN_TRY(sssp_read(p, p.cnt.p, h));
+            n_q = h.near_count;
+            have_queue = true;
+            if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> list of %u (%llu edges) for a binned pass\n", lap(), n_q, h.relaxed);
+          }
+        } while (more);
+        // the rows improved by the LAST step are the only ones with unpropagated distances: they
         // become a plain Bellman-Ford worklist (one infinite bucket); the parked FAR list is
         // covered by the sweeps and dropped
-        memset(&h, 0, sizeof(h));
-        h.min_far = GDN_DIST_INF;
-        GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
         GDN_HIP(hipMemsetAsync(p.in_far.p, 0, (size_t)m * 4, 0));
-        hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p,
-                           p.nwords, m, near_in, p.cnt.p, cap, g->rowptr);
-        GDN_TRY(sssp_read(p, p.cnt.p, h));
-        if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> queue of %u (%llu edges)\n", lap(), h.near_count, h.relaxed);
+        if (have_queue) {  // the last binned pass left them in near_in already
+          h.near_count = n_q;
+          h.relaxed = imp_edges;
+          if (trace) fprintf(stderr, "[sssp] %7.1f us worklist tail from the list of %u (%llu edges)\n", lap(), n_q, imp_edges);
+        } else {
+          memset(&h, 0, sizeof(h));
+          h.min_far = GDN_DIST_INF;
+          GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+          hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p,
+                             p.nwords, m, near_in, p.cnt.p, cap, g->rowptr);
+          GDN_TRY(sssp_read(p, p.cnt.p, h));
+          if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> queue of %u (%llu edges)\n", lap(), h.near_count, h.relaxed);
+        }
         n_near = h.near_count;
         n_far = 0;
         near_edges = h.relaxed;  // out-degree sum of the queue (counted by the conversion)
@@ -1560,7 +1871,8 @@ int gdn_sssp_dev(const gdn_graph *g, const int32_t *d_weight, int32_t source, in
   unsigned long long dense_min = 1ull << 24;
   if (const char *e = gdn_option("GDN_SSSP_ONESHOT_DENSE_MIN")) dense_min = strtoull(e, nullptr, 10);
   gdn_sssp_plan p;
-  GDN_TRY(sssp_plan_init(p, g, d_weight, /*dense=*/dense_min != 0 && g->nnz >= dense_min));
+  // (no lists for the binned passes here: allocating them costs more than they save in ONE solve)
+  GDN_TRY(sssp_plan_init(p, g, d_weight, /*dense=*/dense_min != 0 && g->nnz >= dense_min, /*bins=*/false));
   return sssp_run(p, source, delta, d_dist, stats);
 }
 

@@ -904,6 +904,28 @@ def test_sssp_resident_dense_sweeps(orc, scale, ef, seed, wmax):
     sp.close()
 
 
+@pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_BIN_OUT": "100000000"}, {"GDN_SSSP_BIN_CAP": "64"}, {"GDN_SSSP_NO_BINS": "1"},
+                                   {"GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_BIN_OUT": "100000000"}])
+@pytest.mark.parametrize("wmax", [1, 255])
+def test_sssp_binned_relax_passes(orc, monkeypatch, knobs, wmax):
+    """Between the dense sweeps and the worklist tail the plan relaxes the out-edges of the rows the last step improved
+    through per-bin lists (sssp_bin_*: propagation blocking made on the fly).  Exact distances with the passes taken as
+    long as anything improves (BIN_OUT huge), with lists far too short (every pass overflows and is repeated as a sweep),
+    without them, and entered from the first heavy phase on."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    g = graphio.rmat_graph(18, 16, seed=83)
+    rng = np.random.default_rng(83)
+    wt = rng.integers(1, wmax + 1, size=g.nnz).astype(np.int32)
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    for s, delta in ((graphio.first_nonisolated(g), 16), (int(np.argmax(g.degrees())), 1)):
+        want = orc.sssp_dijkstra(g, wt, s)
+        dist, st = sp.run(s, delta)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+        assert st["last_error"] >= st["edges_traversed"]  # edges relaxed >= edges of the reached rows
+    sp.close()
+
+
 @pytest.mark.parametrize("wlo,whi,delta", [(7, 7, 3), (1, 255, 16), (200, 60000, 5000), (1, 1 << 20, 1 << 18), (0, 3, 1),
                                            (1, 3000, 64)])
 @pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_SMALL": "0"}, {"GDN_SSSP_SMALL": "2"}, {"GDN_SSSP_CAND32": "1"},

