@@ -414,12 +414,55 @@ def main():
             out["traversal"] = bench_traversal(L, _cabi, graphio, torch, np, device, args)
         except Exception as e:
             log(f"[bench] traversal block skipped: {e}")
+        try:
+            out["pr_oneshot"] = bench_pr_oneshot(L, _cabi, graphio, np, args)
+        except Exception as e:
+            log(f"[bench] pr_oneshot block skipped: {e}")
 
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_pr_oneshot(L, _cabi, graphio, np, args):
+    """The PRSolver drop-in (gdn_pr: host arrays in, one call) on an LJ-sized graph (RMAT-22, BASELINE config 2's
+    stand-in): time to convergence WITH the layout the call builds, for the merge-path and the blocked layout and for
+    what the call picks on its own (by predicted wall time, gdn_pr.hip)."""
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(22, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+    m, nnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(gi, C.byref(m), C.byref(nnz), None, None))
+    m, nnz = m.value, nnz.value
+    rp, ci = np.empty(m + 1, np.uint64), np.empty(nnz, np.int32)
+    _cabi.check(L.gdn_graph_download(gi, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+    orp = np.empty(m + 1, np.uint64)
+    oci = np.empty(nnz, np.int32)
+    _cabi.check(L.gdn_graph_download(go, orp.ctypes.data_as(C.c_void_p), oci.ctypes.data_as(C.c_void_p)))
+    deg = np.diff(orp.astype(np.int64)).astype(np.int32)
+    del oci, orp
+    L.gdn_graph_free(go)
+    L.gdn_graph_free(gi)
+    rec = {"workload": "gdn_pr (PRSolver drop-in, one call on host arrays) to epsilon 1e-4, R-MAT scale 22 avg degree 16",
+           "vertices": m, "edges": nnz}
+    for name, lay in (("csr", b"csr"), ("pb", b"pb"), ("auto", None)):
+        _cabi.check(L.gdn_option_set(b"GDN_PR_LAYOUT", lay))
+        best = None
+        for _ in range(3):
+            scores = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_pr(m, nnz, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), deg.ctypes.data_as(C.c_void_p),
+                                 scores.ctypes.data_as(C.c_void_p), C.c_float(0.85), C.c_double(1e-4), 100, C.byref(st)))
+            cur = {"iterations": st.iterations, "solve_ms": st.solve_ms, "prep_ms": st.prep_ms, "h2d_ms": st.h2d_ms,
+                   "solve_plus_prep_ms": st.solve_ms + st.prep_ms}
+            if best is None or cur["solve_plus_prep_ms"] < best["solve_plus_prep_ms"]:
+                best = cur
+        rec[name] = best
+    L.gdn_option_set(b"GDN_PR_LAYOUT", None)
+    rec["auto_picked"] = "csr" if abs(rec["auto"]["prep_ms"] - rec["csr"]["prep_ms"]) < abs(rec["auto"]["prep_ms"] - rec["pb"]["prep_ms"]) else "pb"
+    log(f"[bench] pr_oneshot: {rec}")
+    return rec
 
 
 def bench_spmv(L, _cabi, graphio, torch, np, device, args):

@@ -777,6 +777,14 @@ struct PbTracksLossy<T, decltype((void)T::kTrackLossy)> {
 };
 #define PB_LOSSY_MIN_SUM (1ull << 32)  // units: below this a row with a lossy product is recomputed
 
+// The timing-only ablations of phase B (GDN_PB_DBG bits: 1 no LDS atomics, 2 no epilogue, 4 scalar epilogue, 8 no record
+// tiers, 32 no main stream -- WRONG results by construction) exist in GDN_EXPERIMENTS builds only (make EXPERIMENTS=1,
+// tools/build_variant.sh): the shipped kernel has no such branch, the `dbg` argument is dead there.
+#ifdef GDN_EXPERIMENTS
+#define PB_DBG(bits) ((dbg & (bits)) != 0)
+#else
+#define PB_DBG(bits) false
+#endif
 // phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then the fused epilogue of the rows (op).
 template <class Op>
 __global__ void __launch_bounds__(PB_THREADS)
@@ -784,7 +792,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
                      const float *__restrict__ vals, double *__restrict__ partial, unsigned *__restrict__ errflag,
                      const uint32_t *__restrict__ dst_bits, const uint32_t *__restrict__ bin_lo, Op op,
-                     int dbg = 0,  // dbg: timing-only experiments (bit0 no LDS atomics, bit1 no epilogue)
+                     int dbg = 0,  // GDN_EXPERIMENTS builds only (PB_DBG above); ignored otherwise
                      unsigned bin_begin = 0,  // bin_order == nullptr: bins bin_begin + blockIdx.x (partial launches)
                      // hub tier (nullable): per bin a second stream of (hub index, row) pairs, sorted by hub, whose
                      // values are read from the small per-iteration table hub_val instead of travelling through vals
@@ -894,7 +902,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   // edges of one tile are sorted by destination row: fold equal neighbours in the lane first (a hub row receives
   // hundreds of consecutive edges per tile)
   auto fold = [&](const pb_f32x4 &x, const pb_u16x4 &v) {
-    if (dbg & 1) {
+    if (PB_DBG(1)) {
       bad |= (unsigned)(x.x + x.y + x.z + x.w == 123.456f) + (unsigned)(v.x + v.w == 77777u);
       return;
     }
@@ -920,7 +928,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   };
   constexpr unsigned STEPU = (unsigned)UNR * PB_THREADS;
   unsigned sb = 0;  // first quad of the current step (wave-uniform)
-  if (dbg & 32) sb = nq;  // timing-only ablation: no main stream
+  if (PB_DBG(32)) sb = nq;  // timing-only ablation: no main stream
   else if (nq >= STEPU) {
     // software pipeline over the full steps: the loads of step k+1 are in flight while step k is folded into LDS
 #pragma unroll
@@ -961,7 +969,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
     if (i < nq) fold(xs[r], vs[r]);
   }
-  if (hub_ptr && !(dbg & 16)) {
+  if (hub_ptr && !PB_DBG(16)) {
     // edges of hub sources: 4 B per edge (u16 hub index + u16 row), 8 edges per lane and step with 16-byte loads;
     // the values come from a table that stays in L2: one 4-byte gather per DISTINCT hub of the lane's run (the
     // stream is sorted by hub, so a run of 8 edges holds 1-4 hubs)
@@ -1018,7 +1026,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       }
     }
   }
-  for (int t = 0; t < ((dbg & 8) ? 0 : mid.n); t++) {
+  for (int t = 0; t < (PB_DBG(8) ? 0 : mid.n); t++) {
     // record streams, sorted by source.  Two forms (PbMidArgs::form):
     //  0  one record per lane and load (mid tiers): the 64 table reads of a wave instruction fall into a few
     //     consecutive lines -- near-coalesced L2 hits, not a divergent gather
@@ -1106,7 +1114,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   }
   __syncthreads();
   double dsum = 0.0;
-  if (!(dbg & 2)) {
+  if (!PB_DBG(2)) {
     // compacted bin: its original row range (rows without in-edges get sum 0); plain bin: its 2^log_bin rows
     const size_t row0 = (size_t)b << log_bin;
     const unsigned lo = dst_bits ? bin_lo[b] : (unsigned)row0;
@@ -1123,7 +1131,7 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       }
       return op.from_fixed(a, bad);
     };
-    if (op.vec_ok && !(dbg & 4)) dsum = pb_epilogue4(dst_bits, lo, hi, s_bits, s_pref, s_scr, op, row_sum);
+    if (op.vec_ok && !PB_DBG(4)) dsum = pb_epilogue4(dst_bits, lo, hi, s_bits, s_pref, s_scr, op, row_sum);
     else dsum = pb_epilogue(dst_bits, lo, hi, s_bits, s_pref, s_scr, op, row_sum);
   }
   if (bad) *errflag = 1u;

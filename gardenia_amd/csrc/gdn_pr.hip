@@ -15,6 +15,8 @@
 #include <stdlib.h>
 
 #include "gdn_mergepath.hpp"
+#include <math.h>
+
 #include "gdn_pb.hpp"
 
 struct gdn_pr_plan {
@@ -1245,8 +1247,26 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     int32_t layout = GDN_LAYOUT_AUTO;
     {
       const char *env = gdn_option("GDN_PR_LAYOUT"), *sq = gdn_option("GDN_PR_SQUISH");
-      const bool pb = (env && env[0] == 'p') || (!(env && env[0] == 'c') && nnz >= (1ull << 22));
+      // One call pays the layout it builds (the reference's blocked solvers do theirs before t.Start(),
+      // src/pr/push_pb.cu:271,339 -- it is in prep_ms here, not in solve_ms, but it is wall time all the same).  Without a
+      // forced layout the call picks by PREDICTED WALL TIME: iterations to epsilon ~ 24 at 1e-4 on power-law graphs (15 on
+      // test/graphs/pr.mtx, 22 on RMAT-22), scaled with log(epsilon), capped by max_iter; per edge and iteration the
+      // merge-path layout costs ~10 ps (18 ps from 2^28 edges on: the contribution vector no longer fits the Infinity
+      // Cache), the blocked one 2.3 ps, and the blocked layout costs ~480 ps per edge to build (tools/pr_oneshot.py,
+      // bench.py `pr_oneshot`).  GDN_PR_ONESHOT=solve restores "blocked from 2^22 edges on" (best solve_ms, the number the
+      // reference's Timer prints); callers that iterate or solve repeatedly hold a plan (gdn_pr_plan_create).
+      const char *os_ = gdn_option("GDN_PR_ONESHOT");
+      bool pb = nnz >= (1ull << 22);
+      if (pb && !(os_ && os_[0] == 's')) {
+        double iters = 24.0;
+        if (epsilon > 0.0 && epsilon < 1.0) iters = 24.0 * log(epsilon) / log(1e-4);
+        if (!(epsilon > 0.0) || iters > (double)max_iter) iters = (double)max_iter;
+        const double csr_ps = nnz >= (1ull << 28) ? 18.0 : 10.0, pb_ps = 2.3, build_ps = 480.0;
+        pb = iters * (csr_ps - pb_ps) > build_ps;
+      }
+      if (env) pb = env[0] == 'p';
       if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
+      else if (!pb) layout = GDN_LAYOUT_CSR;
     }
     if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, layout, &plan))) break;
     int32_t ms = m;

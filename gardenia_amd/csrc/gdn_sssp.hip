@@ -1321,7 +1321,15 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     }
     p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lg) / 32u);
     GDN_TRY(p.improved.alloc(p.nwords + 64));
-    if (bins && !gdn_option("GDN_SSSP_NO_BINS")) {
+    // OFF by default (GDN_SSSP_BINS=1 builds the lists and takes the passes): measured on RMAT-24, U[1,255], delta 16
+    // (profiles/r03_sssp_binned_passes.txt) a binned pass costs ~0.19 ms + 39 ps per list edge -- 2.36 ms for the 55 M
+    // out-edges of the 3.6 M rows the third sweep improved, where the fourth SWEEP takes 0.61 ms for all 263 M edges, and
+    // no better than the worklist pass with its global atomicMin per edge (31 ps).  With 512 bins a wave step's 64
+    // destinations fall into ~60 different bins: one list reservation PER EDGE, each a dependent round trip through the
+    // L2 in front of the store -- the binned BFS level got its 6 ps per edge from hub rows walked 256 edges at a time
+    // with four reservations in flight, and a low-degree list has none of that.  3.65 -> 5.9 ms with the passes on.
+    const char *be = gdn_option("GDN_SSSP_BINS");
+    if (bins && be && be[0] == '1') {
       // lists of the binned relax passes: a pass runs while the improved rows own at most nnz / SSSP_BIN_FRAC out-edges;
       // room for SSSP_BIN_SLACK times the even share per list (destinations that crowd into few bins overflow a list:
       // the pass is then repeated as a dense sweep)

@@ -57,6 +57,27 @@ def test_pr_multi_default_layout_vs_oracle(orc, ranks):
     assert orc.pr_verify_error(g, scores) < 1e-4
 
 
+def test_pr_multi_max_iter_limited_reports_like_gdn_pr(monkeypatch):
+    """A solve cut off by max_iter reports MAX_ITER + 1 iterations whatever GDN_NUM_GPUS is, like the reference prints
+    iter + 1 after the loop (src/pr/omp_base.cc:39); a malformed GDN_MULTI_DEVICES is an error, not a hang."""
+    g, gi = _pr_graph(13, 16, 46, 3)
+    G = solvers.Graph(csr=g, in_csr=gi)
+    a = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    b = a.copy()
+    st1 = solvers.PRSolver(G, a, max_iter=3)
+    st2 = solvers.PRSolver(G, b, max_iter=3, devices=[0, 0])
+    assert st1["iterations"] == st2["iterations"] == 4
+    np.testing.assert_allclose(a, b, rtol=1e-6)
+    for bad in ("0;0", "0,x", "0,0\n1"):
+        monkeypatch.setenv("GDN_MULTI_DEVICES", bad)
+        with pytest.raises(_cabi.GardeniaError) as ei:
+            solvers.PRSolver(G, b, ngpus=2)
+        assert ei.value.status == _cabi.GDN_ERR_INVALID and "GDN_MULTI_DEVICES" in str(ei.value)
+    monkeypatch.setenv("GDN_MULTI_DEVICES", "0, 0")
+    st3 = solvers.PRSolver(G, a.copy(), max_iter=3, ngpus=2)
+    assert st3["iterations"] == 4
+
+
 def test_pr_multi_more_ranks_than_rows_and_bad_device():
     g = graphio.build_csr(3, np.array([0, 1, 2]), np.array([1, 2, 0]))
     gi = graphio.transpose(g)

@@ -904,14 +904,15 @@ def test_sssp_resident_dense_sweeps(orc, scale, ef, seed, wmax):
     sp.close()
 
 
-@pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_BIN_OUT": "100000000"}, {"GDN_SSSP_BIN_CAP": "64"}, {"GDN_SSSP_NO_BINS": "1"},
-                                   {"GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_BIN_OUT": "100000000"}])
+@pytest.mark.parametrize("knobs", [{"GDN_SSSP_BINS": "1"}, {"GDN_SSSP_BINS": "1", "GDN_SSSP_BIN_OUT": "100000000"},
+                                   {"GDN_SSSP_BINS": "1", "GDN_SSSP_BIN_CAP": "64"},
+                                   {"GDN_SSSP_BINS": "1", "GDN_SSSP_DENSE_IN": "100000", "GDN_SSSP_BIN_OUT": "100000000"}])
 @pytest.mark.parametrize("wmax", [1, 255])
 def test_sssp_binned_relax_passes(orc, monkeypatch, knobs, wmax):
-    """Between the dense sweeps and the worklist tail the plan relaxes the out-edges of the rows the last step improved
-    through per-bin lists (sssp_bin_*: propagation blocking made on the fly).  Exact distances with the passes taken as
-    long as anything improves (BIN_OUT huge), with lists far too short (every pass overflows and is repeated as a sweep),
-    without them, and entered from the first heavy phase on."""
+    """GDN_SSSP_BINS=1 (off by default: measured slower): between the dense sweeps and the worklist tail the plan
+    relaxes the out-edges of the rows the last step improved through per-bin lists (sssp_bin_*: propagation blocking made
+    on the fly).  Exact distances with the passes taken as long as anything improves (BIN_OUT huge), with lists far too
+    short (every pass overflows and is repeated as a sweep), and entered from the first heavy phase on."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     g = graphio.rmat_graph(18, 16, seed=83)
