@@ -744,6 +744,13 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
         if (c <= want) break;
       }
       if (thr >= top || acc == 0) break;
+      // a tier of a few thousand sources (a graph without skew: the tail of a Poisson degree distribution) costs every
+      // bin a stream and a table for a fraction of a percent of the edges: a tier has to stand for >= 1/64 of them
+      {
+        unsigned long long est = 0;  // a sampled count of c ~ 16 c out-edges
+        for (uint64_t c = thr; c < (top < PB_LIN_BINS ? top : PB_LIN_BINS); c++) est += 16ull * c * hl[c];
+        if (est * 64ull < g->nnz) break;
+      }
       ta.thr[1 + t] = (unsigned)thr;
       ta.cap[1 + t] = PB_MID_MAX;
       ta.ntiers = 2 + t;

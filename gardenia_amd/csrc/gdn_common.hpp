@@ -9,6 +9,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/gardenia_hip.h"
 
@@ -90,6 +91,83 @@ struct DevBuf {
       return GDN_ERR_OOM;
     }
     p = reinterpret_cast<T *>(static_cast<char *>(base) + off);
+    return GDN_OK;
+  }
+  // move the contents into an allocation made with hipExtMallocWithFlags(flags) (A/B knob: hipDeviceMallocUncached keeps a
+  // read-once stream out of the XCD L2s)
+  int rehome(unsigned flags) {
+    if (!p || n == 0) return GDN_OK;
+    void *nb = nullptr;
+    hipError_t e = hipExtMallocWithFlags(&nb, n * sizeof(T), flags);
+    if (e != hipSuccess) {
+      gdn_set_error("hipExtMallocWithFlags(%zu bytes, %u) -> %s", n * sizeof(T), flags, hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+    e = hipMemcpy(nb, p, n * sizeof(T), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(nb);
+      gdn_set_error("rehome copy -> %s", hipGetErrorString(e));
+      return GDN_ERR_HIP;
+    }
+    (void)hipFree(base);
+    base = nb;
+    p = static_cast<T *>(nb);
+    return GDN_OK;
+  }
+  // move the contents into ONE virtual range backed by physical chunks of `chunk` bytes mapped in a shuffled order
+  // (hipMemCreate / hipMemMap; A/B knob of the placement spread).  The range is never unmapped: measurement
+  // processes only (GDN_EXPERIMENTS builds).
+  int rehome_shuffled(size_t chunk, unsigned seed) {
+    if (!p || n == 0) return GDN_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) gran = 2u << 20;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t bytes = n * sizeof(T), nch = (bytes + chunk - 1) / chunk, total = nch * chunk;
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, total, chunk, nullptr, 0) != hipSuccess) {
+      gdn_set_error("hipMemAddressReserve(%zu) failed", total);
+      return GDN_ERR_OOM;
+    }
+    std::vector<size_t> perm(nch);
+    for (size_t i = 0; i < nch; i++) perm[i] = i;
+    unsigned long long x = 0x9E3779B97F4A7C15ull * (seed + 1);
+    for (size_t i = nch; i > 1; i--) {  // Fisher-Yates with a xorshift
+      x ^= x << 13;
+      x ^= x >> 7;
+      x ^= x << 17;
+      const size_t j = (size_t)(x % i);
+      const size_t t = perm[i - 1];
+      perm[i - 1] = perm[j];
+      perm[j] = t;
+    }
+    for (size_t i = 0; i < nch; i++) {  // physical chunks are created in order and land at shuffled virtual offsets
+      hipMemGenericAllocationHandle_t h;
+      if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess ||
+          hipMemMap(static_cast<char *>(va) + perm[i] * chunk, chunk, 0, h, 0) != hipSuccess) {
+        gdn_set_error("hipMemCreate / hipMemMap of chunk %zu failed", i);
+        return GDN_ERR_OOM;
+      }
+    }
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, total, &acc, 1) != hipSuccess) {
+      gdn_set_error("hipMemSetAccess failed");
+      return GDN_ERR_HIP;
+    }
+    if (hipMemcpy(va, p, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+      gdn_set_error("rehome_shuffled copy failed");
+      return GDN_ERR_HIP;
+    }
+    (void)hipFree(base);
+    base = nullptr;  // (leaked on purpose: see above)
+    p = static_cast<T *>(va);
     return GDN_OK;
   }
   void take(DevBuf &o) {  // this buffer takes o's memory over

@@ -159,6 +159,46 @@ pr_count_sources_kernel(const int32_t *__restrict__ deg, int32_t m, unsigned lon
   if (gdn_lane() == 0 && n) atomicAdd(out, n);
 }
 
+// How local is the gather of a pull over this in-CSR?  One wave per 16th row counts its edges and those whose source
+// lies within 2^16 ids of the row: on a lattice / banded / ring-like graph nearly all of them do, consecutive rows then
+// read the same few lines of the contribution vector out of L1 / L2, and the merge-path layout beats the blocked one,
+// which pays 12 B per edge whatever the structure (4096 x 4096 lattice: 0.62 against 0.53 of the roofline, small world
+// 0.53 against 0.46; uniform random: 0.08 against 0.46 -- profiles/r03_shapes_layout_ab.json).
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_locality_sample_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int32_t row_base,
+                          unsigned long long *__restrict__ out /* [0] edges sampled, [1] local ones */) {
+  const unsigned wid = (blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  const uint64_t row = (uint64_t)wid << 4;
+  if (row >= (uint64_t)m) return;
+  const eoff_t b = rowptr[row], e = rowptr[row + 1];
+  const long long me = (long long)row + row_base;
+  unsigned long long n = 0, loc = 0;
+  for (eoff_t k = b + gdn_lane(); k < e; k += 64) {
+    const long long d = (long long)colidx[k] - me;
+    n++;
+    loc += (d < 65536 && d > -65536) ? 1u : 0u;
+  }
+  n = gdn_wave_sum(n);
+  loc = gdn_wave_sum(loc);
+  if (gdn_lane() == 0 && n) {
+    atomicAdd(out, n);
+    atomicAdd(out + 1, loc);
+  }
+}
+
+// true: at least 85 % of the sampled edges are local (the automatic layout choice then takes the merge-path layout)
+static bool pr_gather_is_local(const gdn_graph *g, int32_t row_base) {
+  if (g->nnz == 0 || g->m < 16) return false;
+  DevBuf<unsigned long long> acc;
+  if (acc.alloc(2) != GDN_OK || hipMemset(acc.p, 0, 16) != hipSuccess) return false;
+  const uint64_t sampled = ((uint64_t)g->m + 15) >> 4;
+  hipLaunchKernelGGL(pr_locality_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, g->m,
+                     row_base, acc.p);
+  unsigned long long h[2] = {0, 0};
+  if (hipMemcpy(h, acc.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  return h[0] > 0 && (double)h[1] >= 0.85 * (double)h[0];
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_contrib_kernel(const float *__restrict__ scores, const int32_t *__restrict__ out_degree, int32_t m,
                   float *__restrict__ contrib) {
@@ -542,7 +582,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     const char *env = gdn_option("GDN_PR_LAYOUT");
     if (env && env[0] == 'c') layout = GDN_LAYOUT_CSR;
     else if (env && env[0] == 'p') layout = GDN_LAYOUT_PB;
-    else layout = in_csr->nnz >= (1ull << 22) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
+    else layout = (in_csr->nnz >= (1ull << 22) && !pr_gather_is_local(in_csr, row_base)) ? GDN_LAYOUT_PB : GDN_LAYOUT_CSR;
   }
   gdn_pr_plan *p = new gdn_pr_plan();
   p->layout = layout;
@@ -782,6 +822,48 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     delete p;
     return st;
   }
+#ifdef GDN_EXPERIMENTS  // GDN_PB_UNCACHED (A/B): bit0 record streams, bit1 V, bit2 vals, bit3 U + G in uncached memory
+  if (const char *e = gdn_option("GDN_PB_UNCACHED")) {
+    const int mask = atoi(e);
+    int rc2 = GDN_OK;
+    if (layout != GDN_LAYOUT_CSR) {
+      if (mask & 1) {
+        if (p->has_hub) rc2 = p->hub_rec.rehome(hipDeviceMallocUncached);
+        for (int t = 0; t < p->n_mid_tiers && rc2 == GDN_OK; t++) rc2 = p->mid[t].rec.rehome(hipDeviceMallocUncached);
+      }
+      if ((mask & 2) && rc2 == GDN_OK) rc2 = p->pb.V.rehome(hipDeviceMallocUncached);
+      if ((mask & 4) && rc2 == GDN_OK) rc2 = p->pb.vals.rehome(hipDeviceMallocUncached);
+      if ((mask & 8) && rc2 == GDN_OK) rc2 = p->pb.U.rehome(hipDeviceMallocUncached);
+      if ((mask & 8) && rc2 == GDN_OK) rc2 = p->pb.G.rehome(hipDeviceMallocUncached);
+    }
+    if (rc2 != GDN_OK) {
+      delete p;
+      return rc2;
+    }
+  }
+  // GDN_PB_VMM=<MiB>: vals (bit0 of GDN_PB_VMM_WHAT, default), U + G (bit1), V (bit2), record streams (bit3) re-homed into
+  // ranges of shuffled physical chunks of that size
+  if (const char *e = gdn_option("GDN_PB_VMM")) {
+    const size_t chunk = (size_t)atoi(e) << 20;
+    const char *w = gdn_option("GDN_PB_VMM_WHAT");
+    const int what = w ? atoi(w) : 1;
+    int rc2 = GDN_OK;
+    if (chunk && layout != GDN_LAYOUT_CSR) {
+      if (what & 1) rc2 = p->pb.vals.rehome_shuffled(chunk, 1);
+      if ((what & 2) && rc2 == GDN_OK) rc2 = p->pb.U.rehome_shuffled(chunk, 2);
+      if ((what & 2) && rc2 == GDN_OK) rc2 = p->pb.G.rehome_shuffled(chunk, 3);
+      if ((what & 4) && rc2 == GDN_OK) rc2 = p->pb.V.rehome_shuffled(chunk, 4);
+      if ((what & 8) && rc2 == GDN_OK) {
+        if (p->has_hub) rc2 = p->hub_rec.rehome_shuffled(chunk, 5);
+        for (int t = 0; t < p->n_mid_tiers && rc2 == GDN_OK; t++) rc2 = p->mid[t].rec.rehome_shuffled(chunk, 6 + t);
+      }
+    }
+    if (rc2 != GDN_OK) {
+      delete p;
+      return rc2;
+    }
+  }
+#endif
   if (p->squished) {  // the PB layouts hold every edge: the relabelled CSR is not read again
     p->sq_colidx.release();
     p->sq_rowptr.release();
@@ -1264,6 +1346,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
         const double csr_ps = nnz >= (1ull << 28) ? 18.0 : 10.0, pb_ps = 2.3, build_ps = 480.0;
         pb = iters * (csr_ps - pb_ps) > build_ps;
       }
+      if (pb && !env && pr_gather_is_local(g, 0)) pb = false;  // lattice-like graphs: the merge-path layout is the faster one anyway
       if (env) pb = env[0] == 'p';
       if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
       else if (!pb) layout = GDN_LAYOUT_CSR;

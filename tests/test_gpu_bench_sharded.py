@@ -96,4 +96,13 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     tr = r["traversal"]
     for k in ("sssp_unit", "sssp_u1_255_delta16"):
         assert tr[k]["ms"]["n"] >= 10 and tr[k]["edges_traversed"] > 0 and 0 < tr[k]["roofline"]["frac"] < 1
+        assert tr[k]["edges_relaxed"] >= tr[k]["edges_traversed"] and tr[k]["roofline"]["frac_on_relaxed_edges"] >= tr[k]["roofline"]["frac"]
+        assert len(tr[k]["oneshot_gdn_sssp_dev"]) == 3 and tr[k]["oneshot_gdn_sssp_dev"][0]["solve_ms"] > 0
     assert tr["cc_with_reverse_graph"]["components"] == tr["cc_out_edges_only"]["components"] > 0
+    for k in ("cc_with_reverse_graph", "cc_out_edges_only"):
+        assert 0 < tr[k]["roofline"]["frac_one_pass"] <= tr[k]["roofline"]["frac"]
+    # round 3: the median BFS run leads, TC carries its own list-read rate and the binary-search A/B, one-shot PageRank block
+    assert r["gteps_bfs"] == r["bfs"]["gteps_median"] <= r["gteps_bfs_best"]
+    assert tc["roofline"]["kernel_list_read_gbs"] > 0 and tc["ab_binary_search_intersect"]["same_count"] is True
+    po = r["pr_oneshot"]
+    assert po["csr"]["iterations"] == po["pb"]["iterations"] == po["auto"]["iterations"] > 1 and po["auto_picked"] in ("csr", "pb")

@@ -14,9 +14,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02_pb"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03_pb"
 out = os.path.join(ROOT, "profiles")
-SRC = "gpurun_out/r02"  # written by tools/profile_r02.sh (one session, one box)
+SRC = "gpurun_out/" + tag.split("_")[0]  # written by tools/profile_<round>.sh (one session, one box)
 
 
 def newest(pat):
@@ -39,7 +39,7 @@ shutil.copyfile(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extras  (RMAT-27, PB layout)\n\n")
-    f.write("Session (one box, tools/profile_r02.sh): %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n\n" % (session, tag))
+    f.write("Session (one box, tools/profile_%s.sh)" % tag.split("_")[0] + ": %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n\n" % (session, tag))
     f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
     for r in rows[:18]:
         f.write(f"| `{r['Name'].split('(')[0][:80]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | "
