@@ -567,12 +567,17 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
     nbytes = C.c_uint64(0)
     _cabi.check(L.gdn_tc_model_bytes(dag, C.byref(nbytes)))
     total, ms = C.c_uint64(0), []
+    t0 = time.time()
+    tplan = C.c_void_p()
+    _cabi.check(L.gdn_tc_plan_create(dag, 1, C.byref(tplan)))  # what the reference does while loading (src/tc/main.cc:12)
+    t_tplan = time.time() - t0
     for i in range(max(args.reps, 10) + 1):
         st = _cabi.GdnStats()
-        _cabi.check(L.gdn_tc_dev(dag, 1, C.byref(total), C.byref(st)))
+        _cabi.check(L.gdn_tc_plan_count(tplan, C.byref(total), C.byref(st)))
         if i:
             ms.append(st.solve_ms)
-    form = {0: "u-centric", 1: "v-centric", 2: "binary search"}.get(st.reserved, "?")
+    L.gdn_tc_plan_free(tplan)
+    form = {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward (rank-ordered DAG, walks start behind v)"}.get(st.reserved, "?")
     mm = med_min(ms)
     gbs = nbytes.value / (mm["median"] * 1e-3) / 1e9
     # what the kernel itself reads: ONE list per DAG edge (4 B x the probes of the formulation that ran) + the row's own
@@ -583,29 +588,56 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
     list_gbs = None
     if hasattr(L, "gdn_tc_probe_counts"):
         _cabi.check(L.gdn_tc_probe_counts(dag, pr_))
-        read_b = 4 * (pr_[1] if st.reserved == 1 else pr_[0]) + 8 * nnz.value + 16 * (m.value + 1)
+        # forward form: SUM_u C(d+(u), 2) = (SUM_u d+(u)^2 - nnz) / 2 list elements (the out-degrees do not depend on the labelling)
+        walked = (pr_[1] - nnz.value) // 2 if st.reserved == 3 else (pr_[1] if st.reserved == 1 else pr_[0])
+        read_b = 4 * walked + 12 * nnz.value + 16 * (m.value + 1)
         list_gbs = read_b / (mm["median"] * 1e-3) / 1e9
     rec = {"workload": "triangle count, %s, DAG orientation by degree (src/common/graph.cc:67)" % what,
            "vertices": m.value, "undirected_csr_entries": snnz.value, "dag_edges": nnz.value, "triangles": total.value,
-           "orient_s": t_orient, "ms": mm, "gteps": nnz.value / (mm["median"] * 1e-3) / 1e9, "formulation": form,
+           "orient_s": t_orient, "plan_build_s": t_tplan, "ms": mm, "gteps": nnz.value / (mm["median"] * 1e-3) / 1e9, "formulation": form,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes.value,
                         "model": "4 SUM_(u,v) (d+(u) + d+(v)) + 8 nnz_dag + 8(m+1) (SURVEY 8d, merge-equivalent)",
                         "kernel": "tc_count_kernel",
+                        "note": "the model counts what a MERGE intersect reads (both lists of every DAG edge, whole); the forward "
+                                "count walks one list per edge from behind v on -- a quarter of those elements -- so this "
+                                "fraction is a speed relative to the merge formulation and can exceed 1; the physical rate is "
+                                "kernel_list_read_frac",
                         "kernel_list_read_gbs": list_gbs,
                         "kernel_list_read_frac": list_gbs / HBM_PEAK_GBS if list_gbs else None,
                         "kernel_list_read_model": "4 B x the list elements the formulation that ran walks (one list per DAG "
-                                                  "edge) + 8 nnz_dag + 16(m+1): what the kernel requests, not what the model "
-                                                  "credits; counters of the shipped kernel: profiles/r03_tc_pmc.md"}}
+                                                  "edge, from behind v in the forward form) + 12 nnz_dag + 16(m+1): what the "
+                                                  "kernel requests, not what the model credits; counters: profiles/r03_tc_pmc.md"}}
+    # A/B: round 2's default (hash set, u- or v-centric on the reference's orientation, whichever probes less)
+    try:
+        _cabi.check(L.gdn_option_set(b"GDN_TC_FORM", b"a"))
+        ta, msa = C.c_uint64(0), []
+        pa_ = C.c_void_p()
+        _cabi.check(L.gdn_tc_plan_create(dag, 1, C.byref(pa_)))
+        for i in range(4):
+            sa = _cabi.GdnStats()
+            _cabi.check(L.gdn_tc_plan_count(pa_, C.byref(ta), C.byref(sa)))
+            if i:
+                msa.append(sa.solve_ms)
+        L.gdn_tc_plan_free(pa_)
+        rec["ab_hash_set_unpruned"] = {"ms": med_min(msa), "same_count": ta.value == total.value,
+                                       "formulation": {0: "u-centric", 1: "v-centric"}.get(sa.reserved, "?")}
+    except Exception as e:
+        log(f"[bench] tc unpruned A/B skipped: {e}")
+    finally:
+        L.gdn_option_set(b"GDN_TC_FORM", None)
     # A/B: the north star's wave-per-edge binary-search intersect (GDN_TC_FORM=bs) on the same DAG, same count
     try:
         _cabi.check(L.gdn_option_set(b"GDN_TC_FORM", b"bs"))
         tb, msb = C.c_uint64(0), []
+        pb_ = C.c_void_p()
+        _cabi.check(L.gdn_tc_plan_create(dag, 1, C.byref(pb_)))
         for i in range(3):
             sb = _cabi.GdnStats()
-            _cabi.check(L.gdn_tc_dev(dag, 1, C.byref(tb), C.byref(sb)))
+            _cabi.check(L.gdn_tc_plan_count(pb_, C.byref(tb), C.byref(sb)))
             if i:
                 msb.append(sb.solve_ms)
+        L.gdn_tc_plan_free(pb_)
         rec["ab_binary_search_intersect"] = {"ms": med_min(msb), "same_count": tb.value == total.value,
                                              "gteps": nnz.value / (med_min(msb)["median"] * 1e-3) / 1e9,
                                              "kernel": "tc_bs_count_kernel (one wavefront per DAG edge, 64 LDS pivots; "

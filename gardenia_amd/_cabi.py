@@ -135,6 +135,9 @@ PROTOTYPES = {
     "gdn_graph_orient": (C.c_int, [_vp, _pp]),
     "gdn_tc_model_bytes": (C.c_int, [_vp, C.POINTER(_u64)]),
     "gdn_tc_probe_counts": (C.c_int, [_vp, C.POINTER(_u64)]),
+    "gdn_tc_plan_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "gdn_tc_plan_count": (C.c_int, [_vp, C.POINTER(_u64), _st]),
+    "gdn_tc_plan_free": (C.c_int, [_vp]),
     "gdn_tc_rows_dev": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64), _st]),
 }
 

@@ -183,6 +183,13 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
   return GDN_OK;
 }
 
+// sorted-or-not 64-bit keys (row << 32 | col) of a graph on m vertices -> owned CSR (self loops and duplicates dropped, rows
+// ascending); the key buffers are consumed.  For builders in other translation units (gdn_tc.hip's rank-ordered DAG).
+int gdn_build_csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n, int32_t m,
+                            gdn_graph **out) {
+  return csr_from_keys(ka, kb, n, m, bits_for(m), out);
+}
+
 struct KeyVis {
   const vid_t *__restrict__ colidx;
   unsigned long long *__restrict__ keys;

@@ -295,9 +295,12 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
 // ids at a time (one pass for all but a few hub rows; every pass walks all the lists of the slice).
 // ncol: the array the neighbours [vlo,vhi) are read from -- colidx itself (the row's own list: "for u, for v in N+(u)") or
 // the in-CSR's column ids (the v-centric count: the set is N+(v), the neighbours are the u with u -> v, see tc_count_kernel).
+// nstart (nullable, parallel to ncol): neighbour i's list is walked from its element nstart[i] on (the FORWARD form: ids are
+// degree ranks, the set is N+(v), and the elements of N+(u) up to and including v itself cannot be in it)
 __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
                                                            const vid_t *__restrict__ ncol, eoff_t ub, eoff_t ue, eoff_t vlo,
-                                                           eoff_t vhi, vid_t *s_tab, unsigned char *s_own) {
+                                                           eoff_t vhi, vid_t *s_tab, unsigned char *s_own,
+                                                           const unsigned *__restrict__ nstart = nullptr) {
   const unsigned lane = gdn_lane();
   const int du = (int)(ue - ub);
   unsigned long long count = 0;
@@ -325,6 +328,7 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
         const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
         vb = rowptr[v];
         ve = rowptr[v + 1];
+        if (nstart) vb += nstart[i];
       }
 #if defined(TC_ABL) && TC_ABL == 7  // timing-only ablation: neighbour ids + bounds loaded, lists not walked
       count += (unsigned long long)((ve - vb) & 1);
@@ -388,7 +392,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
                 const vid_t *__restrict__ ncolidx, int32_t m,
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
                 unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
-                unsigned long long *__restrict__ total, unsigned light) {
+                unsigned long long *__restrict__ total, unsigned light, const unsigned *__restrict__ nstart = nullptr) {
   __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
@@ -414,7 +418,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     const eoff_t nb0 = nrowptr[u], ne0 = nrowptr[u + 1];
     const eoff_t vlo = nb0 + (eoff_t)c * TC_SLICE;
     const eoff_t vhi = vlo + TC_SLICE < ne0 ? vlo + TC_SLICE : ne0;
-    count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w]);
+    count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w], nstart);
   }
   // ---- light rows: 16 consecutive vertices per grab (one atomic per 16 rows)
   for (;;) {
@@ -438,7 +442,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       // nothing to close without a set or a neighbour; heavy rows are done
       if (ue == ub || dn == 0 || dn > light) continue;
       if (nrowptr == rowptr && dn < 2) continue;  // u-centric: a single out-neighbour closes no triangle
-      count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w]);
+      count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w], nstart);
     }
   }
   count = gdn_block_sum(count, s_red);
@@ -598,6 +602,190 @@ static int tc_orient(const gdn_graph *g, gdn_graph **out) {
   return GDN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The FORWARD form (default): vertices are relabelled by DEGREE RANK -- the order (degree, id) the orientation rule of
+// src/common/graph.cc:80-81 compares by -- so that the DAG is simply "edges to higher ids" and every list is sorted by rank.
+// For a DAG edge u -> v and the set N+(v), the elements of N+(u) that can be in the set are the ones BEHIND v in u's list (a
+// member of N+(v) outranks v): the walk of N+(u) starts there.  Look-ups: SUM_u C(d+(u), 2) instead of SUM_u d+(u)^2 -- half
+// of the v-centric count's, the "forward" algorithm.  The triangle count does not depend on the labelling.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_indeg_kernel(const vid_t *__restrict__ colidx, uint64_t nnz, int32_t *__restrict__ deg) {
+  for (size_t k = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; k < nnz; k += (size_t)gridDim.x * GDN_BLOCK) atomicAdd(&deg[colidx[k]], 1);
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_rank_keys_kernel(const int32_t *__restrict__ deg, int32_t m, unsigned long long *__restrict__ keys) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (unsigned)m) keys[v] = ((unsigned long long)(unsigned)deg[v] << 32) | v;
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_newid_kernel(const unsigned long long *__restrict__ sorted, int32_t m, vid_t *__restrict__ newid) {
+  const unsigned r = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (r < (unsigned)m) newid[(unsigned)(sorted[r] & 0xFFFFFFFFull)] = (vid_t)r;
+}
+struct TcRelabelVis {
+  const vid_t *__restrict__ colidx;
+  const vid_t *__restrict__ newid;
+  unsigned long long *__restrict__ keys;  // one per CSR entry: (low rank << 32 | high rank), a self loop where nothing is kept
+  int both;  // the input lists every edge in both directions (symmetric graph): keep the entry with rank(src) < rank(dst)
+  int32_t v;
+  __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t src = __shfl(v, owner, 64);
+    if (valid) {
+      const unsigned a = (unsigned)newid[src], b = (unsigned)newid[colidx[k]];
+      unsigned long long key;
+      if (both) key = a < b ? (((unsigned long long)a << 32) | b) : (((unsigned long long)a << 32) | a);  // self loop = dropped
+      else key = a < b ? (((unsigned long long)a << 32) | b) : (((unsigned long long)b << 32) | a);
+      keys[k] = key;
+    }
+  }
+};
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_relabel_kernel(const eoff_t *__restrict__ rowptr, int32_t m, ExpBigList big, TcRelabelVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_relabel_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, TcRelabelVis vis) {
+  vis.v = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+// nstart[j] for the in-edge slot j = (v <- u): 1 + the position of v in N+(u) (binary search; every list is ascending)
+struct TcStartVis {
+  const eoff_t *__restrict__ rowptr;   // the DAG
+  const vid_t *__restrict__ colidx;
+  const vid_t *__restrict__ in_col;    // its transpose
+  unsigned *__restrict__ nstart;
+  int32_t v;
+  __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
+  __device__ __forceinline__ void edge(int owner, eoff_t j, bool valid) {
+    const int32_t row = __shfl(v, owner, 64);
+    if (valid) {
+      const vid_t u = in_col[j];
+      const eoff_t b = rowptr[u];
+      unsigned lo = 0, hi = (unsigned)(rowptr[u + 1] - b);
+      while (lo < hi) {  // first position with an id > row
+        const unsigned mid = (lo + hi) >> 1;
+        if (colidx[b + mid] <= row) lo = mid + 1;
+        else hi = mid;
+      }
+      nstart[j] = lo;
+    }
+  }
+};
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_start_kernel(const eoff_t *__restrict__ in_rowptr, int32_t m, ExpBigList big, TcStartVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  if (v < (unsigned)m) {
+    b = in_rowptr[v];
+    e = in_rowptr[v + 1];
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_start_big_kernel(const eoff_t *__restrict__ in_rowptr, ExpBigList big, TcStartVis vis) {
+  vis.v = 0;
+  gdn_expand_big_items(in_rowptr, big, vis);
+}
+
+int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
+                       const unsigned long long **sorted);
+int gdn_build_csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n, int32_t m,
+                            gdn_graph **out);
+
+// g: a symmetric graph (oriented == false) or any acyclic orientation of one (oriented == true) -> the rank-ordered DAG, its
+// transpose and the walk starts of the forward count
+static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_out, gdn_graph **in_out, DevBuf<unsigned> &nstart) {
+  const int32_t m = g->m;
+  DevBuf<int32_t> deg;
+  DevBuf<vid_t> newid;
+  DevBuf<unsigned long long> ra, rb, ka, kb, bigitems;
+  DevBuf<unsigned> cnt;
+  GDN_TRY(deg.alloc(m));
+  GDN_TRY(newid.alloc(m));
+  GDN_TRY(ra.alloc(m));
+  GDN_TRY(rb.alloc(m));
+  GDN_TRY(gdn_graph_degrees_dev(g, deg.p, nullptr));
+  if (oriented && g->nnz)  // undirected degree = out + in
+    hipLaunchKernelGGL(tc_indeg_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, g->colidx, g->nnz, deg.p);
+  hipLaunchKernelGGL(tc_rank_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, deg.p, m, ra.p);
+  GDN_HIP(hipGetLastError());
+  const unsigned long long *sorted = nullptr;
+  GDN_TRY(gdn_radix_sort_u64(ra.p, rb.p, (unsigned long long)m, 32u, 64u, &sorted));  // stable: ties keep the id order
+  hipLaunchKernelGGL(tc_newid_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, sorted, m, newid.p);
+  GDN_HIP(hipGetLastError());
+  const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
+  const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
+  GDN_TRY(ka.alloc(g->nnz));
+  GDN_TRY(kb.alloc(g->nnz));
+  GDN_TRY(bigitems.alloc(bigcap));
+  GDN_TRY(cnt.alloc(2));
+  GDN_HIP(hipMemset(cnt.p, 0, 8));
+  ExpBigList big;
+  big.items = bigitems.p;
+  big.capacity = bigcap;
+  big.count = cnt.p;
+  big.overflow = cnt.p + 1;
+  TcRelabelVis rv;
+  rv.colidx = g->colidx;
+  rv.newid = newid.p;
+  rv.keys = ka.p;
+  rv.both = oriented ? 0 : 1;
+  rv.v = 0;
+  hipLaunchKernelGGL(tc_relabel_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, rv);
+  hipLaunchKernelGGL(tc_relabel_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, rv);
+  GDN_HIP(hipGetLastError());
+  unsigned ovf[2];
+  GDN_HIP(hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost));
+  if (ovf[1]) {
+    gdn_set_error("gdn_tc: device worklist overflow");
+    return GDN_ERR_OVERFLOW;
+  }
+  deg.release();
+  ra.release();
+  rb.release();
+  gdn_graph *dag = nullptr, *din = nullptr;
+  GDN_TRY(gdn_build_csr_from_keys(ka, kb, g->nnz, m, &dag));
+  int rc = dag->nnz ? gdn_graph_transpose(dag, &din) : GDN_OK;
+  if (rc == GDN_OK && din) {
+    rc = nstart.alloc(din->nnz);
+    if (rc == GDN_OK) {
+      GDN_HIP(hipMemset(cnt.p, 0, 8));
+      TcStartVis sv;
+      sv.rowptr = dag->rowptr;
+      sv.colidx = dag->colidx;
+      sv.in_col = din->colidx;
+      sv.nstart = nstart.p;
+      sv.v = 0;
+      hipLaunchKernelGGL(tc_start_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, din->rowptr, m, big, sv);
+      hipLaunchKernelGGL(tc_start_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, din->rowptr, big, sv);
+      if (hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost) != hipSuccess || ovf[1]) {
+        gdn_set_error("gdn_tc: start kernel failed or work list overflow");
+        rc = GDN_ERR_OVERFLOW;
+      }
+    }
+  }
+  if (rc != GDN_OK) {
+    if (din) gdn_graph_free(din);
+    gdn_graph_free(dag);
+    return rc;
+  }
+  *dag_out = dag;
+  *in_out = din;
+  return GDN_OK;
+}
+
 // SURVEY 8d's merge-equivalent traffic of a count: SUM over DAG edges (u,v) of d+(u) + d+(v) (a merge intersect reads both lists)
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_model_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned long long *__restrict__ out) {
@@ -663,7 +851,7 @@ int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes) {
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
 // dag_in != nullptr: the v-centric count over the rows [row_lo, row_hi) of the TRANSPOSED DAG's row space (same vertices)
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
-                         const gdn_graph *dag_in = nullptr, bool binary_search = false) {
+                         const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr) {
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
@@ -703,7 +891,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
-                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light);
+                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart);
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -721,37 +909,103 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   return GDN_OK;
 }
 
-int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats *stats) {
-  GDN_REQUIRE(g != nullptr && total != nullptr, "graph / total");
+struct gdn_tc_plan {
+  gdn_graph *dag = nullptr;     // the DAG the count runs on (owned): rank-ordered (forward) or the reference's orientation
+  gdn_graph *dag_in = nullptr;  // its transpose (forward / v-centric), owned
+  DevBuf<unsigned> nstart;      // forward: walk starts, parallel to dag_in->colidx
+  int form = 0;                 // 0 u-centric, 1 v-centric, 2 binary search, 3 forward
+  double prep_ms = 0;
+  ~gdn_tc_plan() {
+    if (dag_in) gdn_graph_free(dag_in);
+    if (dag) gdn_graph_free(dag);
+  }
+};
+
+static int tc_copy_graph(const gdn_graph *g, gdn_graph **out) {  // an owned copy (the plan outlives the caller's handle)
+  gdn_graph *d = new gdn_graph();
+  d->m = g->m;
+  d->nnz = g->nnz;
+  d->owned = true;
+  hipError_t e = hipMalloc((void **)&d->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = hipMalloc((void **)&d->colidx, (g->nnz ? g->nnz : 1) * sizeof(vid_t));
+  if (e == hipSuccess) e = hipMemcpy(d->rowptr, g->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t), hipMemcpyDeviceToDevice);
+  if (e == hipSuccess && g->nnz) e = hipMemcpy(d->colidx, g->colidx, g->nnz * sizeof(vid_t), hipMemcpyDeviceToDevice);
+  if (e != hipSuccess) {
+    gdn_set_error("gdn_tc_plan_create: %s", hipGetErrorString(e));
+    gdn_graph_free(d);
+    return GDN_ERR_OOM;
+  }
+  *out = d;
+  return GDN_OK;
+}
+
+int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan) {
+  GDN_REQUIRE(g != nullptr && plan != nullptr, "graph / plan");
+  *plan = nullptr;
+  HostTimer tprep;
+  tprep.start();
+  // GDN_TC_FORM: f the forward count on the rank-ordered DAG (default from 2^24 DAG edges on: RMAT-23 38 ms against 66,
+  // RMAT-21 8.6 against 9.8, RMAT-19 2.0 against 1.9 -- profiles/r03_tc_forward_ab.txt; its preparation re-ranks and
+  // rebuilds the DAG); a the hash-set count on the reference's orientation, u- or v-centric, whichever probes less (default
+  // below that); u / v one of the two; bs the wave-per-edge binary-search intersect
+  const char *e = gdn_option("GDN_TC_FORM");
+  const uint64_t dag_edges = oriented ? g->nnz : g->nnz / 2;
+  const char form = e ? e[0] : (dag_edges >= (1ull << 24) ? 'f' : 'a');
+  gdn_tc_plan *p = new gdn_tc_plan();
+  int rc = GDN_OK;
+  if (form == 'f') {
+    rc = tc_forward_build(g, oriented != 0, &p->dag, &p->dag_in, p->nstart);
+    p->form = 3;
+  } else {
+    rc = oriented ? tc_copy_graph(g, &p->dag) : tc_orient(g, &p->dag);
+    if (rc == GDN_OK) {
+      // which formulation probes less (tc_count_kernel): the v-centric one needs the transposed DAG
+      unsigned long long probes[2] = {0, 0};
+      const bool bs = form == 'b';
+      rc = tc_probe_counts(p->dag, probes);
+      const bool vform = form == 'v' || (form != 'u' && !bs && (double)probes[1] < 0.85 * (double)probes[0]);
+      if (rc == GDN_OK && vform && p->dag->nnz) rc = gdn_graph_transpose(p->dag, &p->dag_in);
+      p->form = bs ? 2 : p->dag_in ? 1 : 0;
+    }
+  }
+  if (rc != GDN_OK) {
+    delete p;
+    return rc;
+  }
+  p->prep_ms = tprep.stop_ms();
+  *plan = p;
+  return GDN_OK;
+}
+
+int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats) {
+  GDN_REQUIRE(plan != nullptr && total != nullptr, "plan / total");
   gdn_stats st;
   memset(&st, 0, sizeof(st));
-  HostTimer tprep;
-  const gdn_graph *dag = g;
-  gdn_graph *own = nullptr;
-  tprep.start();
-  if (!oriented) {
-    GDN_TRY(tc_orient(g, &own));
-    dag = own;
+  int rc = GDN_OK;
+  *total = 0;
+  if (plan->form == 3) {
+    if (plan->dag_in) rc = tc_count_rows(plan->dag, 0, plan->dag->m, total, st, plan->dag_in, false, plan->nstart.p);
+  } else {
+    rc = tc_count_rows(plan->dag, 0, plan->dag->m, total, st, plan->dag_in, plan->form == 2);
   }
-  // which formulation probes less (tc_count_kernel): the v-centric one needs the transposed DAG (built here, part of the
-  // preparation like the orientation: the reference orients while loading, src/tc/main.cc:12); GDN_TC_FORM=u|v forces one
-  unsigned long long probes[2] = {0, 0};
-  gdn_graph *dag_in = nullptr;
-  bool bs = false;
-  int rc = tc_probe_counts(dag, probes);
-  if (rc == GDN_OK) {
-    const char *e = gdn_option("GDN_TC_FORM");
-    bs = e && e[0] == 'b';
-    const bool vform = e ? e[0] == 'v' : (double)probes[1] < 0.85 * (double)probes[0];
-    if (vform && dag->nnz) rc = gdn_graph_transpose(dag, &dag_in);
-  }
-  st.prep_ms = tprep.stop_ms();
-  if (rc == GDN_OK) rc = tc_count_rows(dag, 0, dag->m, total, st, dag_in, bs);
-  st.edges_traversed = dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
-  st.reserved = bs ? 2 : dag_in ? 1 : 0;  // 1: the v-centric formulation ran, 2: the binary-search intersect
-  if (dag_in) gdn_graph_free(dag_in);
-  if (own) gdn_graph_free(own);
+  st.prep_ms += plan->prep_ms;
+  st.edges_traversed = plan->dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
+  st.reserved = plan->form;
   if (stats) *stats = st;
+  return rc;
+}
+
+int gdn_tc_plan_free(gdn_tc_plan *plan) {
+  delete plan;
+  return GDN_OK;
+}
+
+int gdn_tc_dev(const gdn_graph *g, int32_t oriented, uint64_t *total, gdn_stats *stats) {
+  GDN_REQUIRE(g != nullptr && total != nullptr, "graph / total");
+  gdn_tc_plan *plan = nullptr;
+  GDN_TRY(gdn_tc_plan_create(g, oriented, &plan));
+  const int rc = gdn_tc_plan_count(plan, total, stats);
+  gdn_tc_plan_free(plan);
   return rc;
 }
 

@@ -400,6 +400,19 @@ int gdn_sssp_run(gdn_sssp_plan *plan, int32_t source, int32_t delta, int32_t *d_
 int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,
                gdn_stats *stats);
 int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stats *stats);
+/* Reusable triangle-count state: what TCSolver's caller does ONCE while loading (`Graph g(prefix, USE_DAG)`,
+ * src/tc/main.cc:12 -> src/common/graph.cc:67-113) kept apart from the count the reference's Timer brackets
+ * (src/tc/gpu_base.cu:52-58).  gdn_tc_plan_create prepares the formulation the count will run (stats of a count:
+ * `reserved` 3 = the FORWARD count -- vertices relabelled by degree rank, the DAG = edges to higher ranks, its transpose
+ * and, per DAG edge u -> v, where the walk of N+(u) starts (behind v: a member of N+(v) outranks v), which halves the
+ * look-ups; taken from 2^24 DAG edges on -- 0 / 1 = the hash-set count on the reference's orientation, u- / v-centric;
+ * 2 = the wave-per-edge binary-search intersect; GDN_TC_FORM = f | a | u | v | bs forces one).  `csr` is a symmetric graph
+ * (oriented == 0) or ANY acyclic orientation of one (oriented != 0); it is not referenced after the call.
+ * gdn_tc_dev == create + count + free, the preparation in stats.prep_ms. */
+typedef struct gdn_tc_plan gdn_tc_plan;
+int gdn_tc_plan_create(const gdn_graph *csr, int32_t oriented, gdn_tc_plan **plan);
+int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats);
+int gdn_tc_plan_free(gdn_tc_plan *plan);
 /* The DAG orientation alone (src/common/graph.cc:67-113, what `Graph g(prefix, USE_DAG)` hands to TCSolver), and the count
  * over the source rows [row_lo, row_hi) of an ORIENTED graph: the shard of a multi-GPU count -- every rank holds the DAG,
  * the ranges partition its rows (by DAG-edge count), the partial counts add up (gardenia_amd.sharded.ShardedTC).
@@ -410,8 +423,8 @@ int gdn_graph_orient(const gdn_graph *csr, gdn_graph **dag);
 int gdn_tc_model_bytes(const gdn_graph *dag, uint64_t *bytes);
 /* the list elements a count on `dag` walks: probes[0] the u-centric form (SUM over edges of d+(v); the reference's loop,
  * src/tc/omp_base.cc:16-22), probes[1] the v-centric one (SUM of d+(u)).  gdn_tc_dev runs the cheaper one
- * (GDN_TC_FORM=u|v forces one; GDN_TC_FORM=bs runs the wave-per-edge binary-search intersect of src/tc/gpu_base.cu:11-23
- * instead; stats.reserved says which ran: 0 / 1 / 2).  4 B x probes = what the kernel requests from memory. */
+ * on small graphs, the forward count (half of probes[1] - nnz) on large ones; stats.reserved says which ran, see
+ * gdn_tc_plan_create).  4 B x probes = what the kernel requests from memory. */
 int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes);
 int gdn_tc_rows_dev(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats *stats);
 

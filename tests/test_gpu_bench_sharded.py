@@ -104,5 +104,6 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     # round 3: the median BFS run leads, TC carries its own list-read rate and the binary-search A/B, one-shot PageRank block
     assert r["gteps_bfs"] == r["bfs"]["gteps_median"] <= r["gteps_bfs_best"]
     assert tc["roofline"]["kernel_list_read_gbs"] > 0 and tc["ab_binary_search_intersect"]["same_count"] is True
+    assert tc["ab_hash_set_unpruned"]["same_count"] is True and tc["plan_build_s"] > 0
     po = r["pr_oneshot"]
     assert po["csr"]["iterations"] == po["pb"]["iterations"] == po["auto"]["iterations"] > 1 and po["auto_picked"] in ("csr", "pb")

@@ -1072,11 +1072,12 @@ def test_cc_directed_without_reverse_links_every_out_edge(orc):
 
 
 # ------------------------------------------------------------------ TC
-@pytest.mark.parametrize("form", ["u", "v", "bs"])
+@pytest.mark.parametrize("form", ["f", "a", "u", "v", "bs"])
 @pytest.mark.parametrize("case", ["chesapeake_sym", "rmat10_sym"])
 def test_tc_golden(case, form, monkeypatch):
-    """Every formulation of the count -- the LDS hash set walked u- or v-centric, and the north star's wave-per-edge
-    binary-search intersect (GDN_TC_FORM=bs: src/tc/gpu_base.cu:11-23 re-cut for wave64) -- gives the reference's total."""
+    """Every formulation of the count -- the forward count on the rank-ordered DAG (default), the LDS hash set walked u- or
+    v-centric on the reference's orientation, and the north star's wave-per-edge binary-search intersect (GDN_TC_FORM=bs:
+    src/tc/gpu_base.cu:11-23 re-cut for wave64) -- gives the reference's total."""
     monkeypatch.setenv("GDN_TC_FORM", form)
     d = golden("tc_" + case)
     total, st = solvers.TCSolver(solvers.Graph(csr=csr_from(d, "sym_"), symmetrize=True))
@@ -1090,11 +1091,41 @@ def test_tc_golden(case, form, monkeypatch):
 def test_tc_vs_oracle_rmat(orc, scale, ef, seed, monkeypatch):
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
     want = orc.tc(orc.tc_orient(g))
-    total, _ = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want and st["reserved"] in (0, 1)  # below 2^24 DAG edges: the hash-set count on the reference's orientation
+    monkeypatch.setenv("GDN_TC_FORM", "f")  # the forward count (the default from 2^24 DAG edges on)
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want and st["reserved"] == 3
+    dag = orc.tc_orient(g)
+    total, st = solvers.TCSolver(solvers.Graph(csr=dag), oriented=True)  # handed a DAG: re-ranked from in + out degrees
+    assert total == want and st["edges_traversed"] == dag.nnz
+    src, dst = graphio.csr_to_coo(g)  # ANY acyclic orientation may be handed over: here "towards the higher id"
+    by_id = graphio.build_csr(g.m, src[dst > src], dst[dst > src])
+    total, _ = solvers.TCSolver(solvers.Graph(csr=by_id), oriented=True)
     assert total == want
+    for form in ("u", "v"):
+        monkeypatch.setenv("GDN_TC_FORM", form)
+        total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+        assert total == want and st["reserved"] == (1 if form == "v" else 0)
     monkeypatch.setenv("GDN_TC_FORM", "bs")  # the binary-search intersect: lists from 0 to ~10^3 ids, pivots + segments
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
     assert total == want and st["reserved"] == 2
+    # the plan API: prepared once (the preparation the reference does while loading), counted twice
+    import ctypes as C
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    for form in ("f", "a"):
+        monkeypatch.setenv("GDN_TC_FORM", form)
+        h, plan = C.c_void_p(), C.c_void_p()
+        rp, ci = np.ascontiguousarray(g.rowptr, np.uint64), np.ascontiguousarray(g.colidx, np.int32)
+        _cabi.check(L.gdn_graph_upload(g.m, g.nnz, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), C.byref(h)))
+        _cabi.check(L.gdn_tc_plan_create(h, 0, C.byref(plan)))
+        L.gdn_graph_free(h)  # the plan keeps nothing of the caller's graph
+        for _ in range(2):
+            t, ps = C.c_uint64(0), _cabi.GdnStats()
+            _cabi.check(L.gdn_tc_plan_count(plan, C.byref(t), C.byref(ps)))
+            assert t.value == want and ps.edges_traversed == dag.nnz and ps.solve_ms > 0
+        L.gdn_tc_plan_free(plan)
 
 
 # ------------------------------------------------------------------ device graph builder
