@@ -94,7 +94,11 @@ typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
 #define TC_BUCKETS (TC_HASH / 4)
 // (a 24-bit multiply -- v_mul_u32_u24 is full rate where v_mul_lo_u32 is quarter rate -- of the id folded onto itself was
 // measured: 3 % SLOWER on RMAT-21 / 23, it spreads the ids less evenly over the buckets)
+#ifdef TC_HASH_XOR  // A/B (tools/build_variant.sh): two full-rate instructions instead of the quarter-rate 32-bit multiply
+__device__ __forceinline__ unsigned tc_bucket(vid_t w) { return (((unsigned)w >> 9) ^ (unsigned)w) & (TC_BUCKETS - 1u); }
+#else
 __device__ __forceinline__ unsigned tc_bucket(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - (TC_HASH_BITS - 2)); }
+#endif
 
 struct TcSet {
   const vid_t *table;  // 16-byte aligned
@@ -117,7 +121,10 @@ struct TcSet {
     unsigned long long any = 0ull;
 #pragma unroll
     for (int r = 0; r < N; r++) {
-      const unsigned long long hit = __ballot((b[r].x == w[r]) | (b[r].y == w[r]) | (b[r].z == w[r]) | (b[r].w == w[r])) & vm[r];
+      // four ballots of plain compares OR-ed on the scalar unit (a ballot of the OR-ed condition makes the compiler
+      // materialise the mask in a vector register and compare it again: two more VALU instructions per chunk)
+      const unsigned long long hit = (__ballot(b[r].x == w[r]) | __ballot(b[r].y == w[r]) | __ballot(b[r].z == w[r]) |
+                                      __ballot(b[r].w == w[r])) & vm[r];
       c += (unsigned)__popcll(hit);
       pend[r] = __ballot(b[r].w != TC_EMPTY) & vm[r] & ~hit;  // bucket full and not found: look in the next one
       any |= pend[r];
@@ -129,7 +136,8 @@ struct TcSet {
         if (pend[r]) {  // uniform
           hb[r] = (hb[r] + 1u) & (TC_BUCKETS - 1);
           b[r] = *reinterpret_cast<const tc_i32x4 *>(table + 4u * hb[r]);
-          const unsigned long long hit = __ballot((b[r].x == w[r]) | (b[r].y == w[r]) | (b[r].z == w[r]) | (b[r].w == w[r])) & pend[r];
+          const unsigned long long hit = (__ballot(b[r].x == w[r]) | __ballot(b[r].y == w[r]) | __ballot(b[r].z == w[r]) |
+                                          __ballot(b[r].w == w[r])) & pend[r];
           c += (unsigned)__popcll(hit);
           pend[r] = __ballot(b[r].w != TC_EMPTY) & pend[r] & ~hit;
           any |= pend[r];
@@ -193,38 +201,47 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
      // its base pointer is scalar, positions are 32-bit offsets, loads are unpredicated (a position past the end reads the
      // list's last element and is masked in `valid`).
     const unsigned nch = deg >= (unsigned)TC_LONG ? (deg + 63u) >> 6 : 0u;
-    const unsigned incl = gdn_wave_incl_scan(nch);
-    const unsigned total = __shfl(incl, 63, 64);
-    const unsigned excl = incl - nch;
+    const unsigned total = gdn_wave_sum(nch);
     const unsigned total_s = (unsigned)__builtin_amdgcn_readfirstlane((int)total);  // scalar copy: uniform branches
-    // the TC_UNR chunks from q0 on: every load is ISSUED (a chunk past the end re-reads the last chunk and gets an empty
-    // lane mask), so that the compiler can count the outstanding loads and wait for one step's only
-    auto load_step = [&](unsigned q0, vid_t (&w)[TC_UNR], unsigned long long (&vm)[TC_UNR]) {
-#pragma unroll
-      for (int r = 0; r < TC_UNR; r++) {
-        const unsigned qr = q0 + (unsigned)r;                       // scalar
-        const unsigned q = qr < total_s ? qr : total_s - 1u;        // scalar
-        const unsigned long long m = __ballot(nch > 0u && excl <= q);  // the last lane that owns chunks and starts at or before q
-        const int owner = 63 - __clzll((long long)m);
+    // The chunk stream as a SCALAR iterator (round 3): which list a chunk belongs to, its base pointer, its length and the
+    // position reached are wave-uniform, so they live in scalar registers and advance with a handful of scalar
+    // instructions per chunk -- the first form found every chunk's list again (ballot of "owns chunks and starts at or
+    // before q", four readlanes, 64-bit address arithmetic per lane: ~12 VALU + ~15 SALU per chunk, more than the look-up
+    // itself; profiles/r03_tc_pmc.md: VALU issue was half of the kernel).  Per chunk now: lane offset, clamp, shift, load.
+    // Every call ISSUES its load (past the end: the last element again, empty lane mask), so that the compiler can count
+    // the outstanding loads and wait for one step's only.
+    unsigned long long rem = __ballot(nch > 0u);  // lists not started yet (scalar)
+    const vid_t *s_base = colidx;                 // current list (scalar)
+    unsigned s_len = 1u, s_off = 1u;              // its length and the position of the next chunk (s_off >= s_len: finished)
+    auto next_chunk = [&](vid_t &w, unsigned long long &vm) {
+      if (s_off >= s_len && rem) {  // uniform: the next list
+        const int owner = __ffsll((long long)rem) - 1;
+        rem &= rem - 1ull;
         const eoff_t ob = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(vb >> 32), owner) << 32) |
                           (unsigned)__builtin_amdgcn_readlane((int)vb, owner);
-        const unsigned len = (unsigned)__builtin_amdgcn_readlane((int)deg, owner);
-        const unsigned oex = (unsigned)__builtin_amdgcn_readlane((int)excl, owner);
-        const unsigned o = ((q - oex) << 6) + lane;
-        const bool ok = o < len;
-        vm[r] = qr < total_s ? __ballot(ok) : 0ull;
-        w[r] = (colidx + ob)[ok ? o : len - 1u];
+        s_base = colidx + ob;
+        s_len = (unsigned)__builtin_amdgcn_readlane((int)deg, owner);
+        s_off = 0u;
       }
+      const unsigned left = s_off < s_len ? s_len - s_off : 0u;  // scalar
+      vm = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
+      const unsigned o = s_off + lane;
+      w = s_base[o < s_len ? o : s_len - 1u];
+      s_off = left ? s_off + 64u : s_off;
+    };
+    auto load_step = [&](vid_t (&w)[TC_UNR], unsigned long long (&vm)[TC_UNR]) {
+#pragma unroll
+      for (int r = 0; r < TC_UNR; r++) next_chunk(w[r], vm[r]);
     };
     if (total_s) {
       vid_t w0[TC_UNR], w1[TC_UNR];
       unsigned long long m0[TC_UNR], m1[TC_UNR];
       unsigned cw = 0;  // wave total
-      load_step(0u, w0, m0);
+      load_step(w0, m0);
       for (unsigned q0 = 0; q0 < total_s; q0 += 2 * TC_UNR) {
-        load_step(q0 + TC_UNR, w1, m1);
+        load_step(w1, m1);
         cw += set.count(w0, m0);
-        load_step(q0 + 2 * TC_UNR, w0, m0);
+        load_step(w0, m0);
         cw += set.count(w1, m1);
       }
       if (lane == 0) count += cw;
