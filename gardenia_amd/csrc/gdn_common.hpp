@@ -93,6 +93,7 @@ struct DevBuf {
     p = reinterpret_cast<T *>(static_cast<char *>(base) + off);
     return GDN_OK;
   }
+#ifdef GDN_EXPERIMENTS  // placement A/B knobs of measurement builds only (make EXPERIMENTS=1, tools/build_variant.sh)
   // move the contents into an allocation made with hipExtMallocWithFlags(flags) (A/B knob: hipDeviceMallocUncached keeps a
   // read-once stream out of the XCD L2s)
   int rehome(unsigned flags) {
@@ -170,6 +171,7 @@ struct DevBuf {
     p = static_cast<T *>(va);
     return GDN_OK;
   }
+#endif
   void take(DevBuf &o) {  // this buffer takes o's memory over
     release();
     p = o.p;

@@ -777,8 +777,11 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   int rc = dag->nnz ? gdn_graph_transpose(dag, &din) : GDN_OK;
   if (rc == GDN_OK && din) {
     rc = nstart.alloc(din->nnz);
+    if (rc == GDN_OK && hipMemset(cnt.p, 0, 8) != hipSuccess) {
+      gdn_set_error("gdn_tc: hipMemset failed");
+      rc = GDN_ERR_HIP;
+    }
     if (rc == GDN_OK) {
-      GDN_HIP(hipMemset(cnt.p, 0, 8));
       TcStartVis sv;
       sv.rowptr = dag->rowptr;
       sv.colidx = dag->colidx;
