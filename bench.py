@@ -352,7 +352,12 @@ def main():
                                   roofline={"bound": "hbm", "achieved": med["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": med["gbs"] / HBM_PEAK_GBS, "frac_best_run": best["gbs"] / HBM_PEAK_GBS,
                                             "algorithmic_bytes": med["bytes"],
-                                            "model": "SUM_reached (16 + 8 outdeg) + 4 m (SURVEY 8d)"})
+                                            "model": "SUM_reached (16 + 8 outdeg) + 4 m (SURVEY 8d)",
+                                            "note": "the model charges every out-edge of the reached part (a top-down "
+                                                    "search); the direction-optimizing search skips most of them in "
+                                                    "its bottom-up levels, so frac can exceed 1 -- it compares with a "
+                                                    "search that walks all edges, it is not an HBM utilisation "
+                                                    "(per-level figures: profiles/r03_bfs_bottom_up.txt)"})
                 out["gteps_bfs"] = med["gteps"]
                 out["gteps_bfs_best"] = best["gteps"]
         except Exception as e:  # BFS is an extra; never lose the PR line

@@ -28,6 +28,8 @@ struct BfsCounters {  // device, zeroed per level by the host-side memset
   alignas(128) unsigned long long scout;  // sum of out-degrees of the vertices discovered this level
   alignas(128) unsigned long long awake;  // vertices discovered by a bottom-up step
   alignas(128) unsigned overflow;
+  alignas(128) unsigned long long bu_by_head;  // bottom-up: rows discovered through their hub head ...
+  unsigned long long bu_probes;                //            ... and in-neighbours probed for the others (GDN_BFS_TRACE)
 };
 
 struct BfsTdVis {
@@ -300,11 +302,118 @@ bfs_td_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
   }
 }
 
-// Bottom-up step: one thread per vertex, early exit on the first parent found in the frontier
-// bitmap (omp_beamer.cc:13-31).  A wave owns two bitmap words, so next/visited words are
-// written whole, without atomics.  Persistent grid: the awake / scout totals are kept in registers and added
-// to the level counters ONCE per workgroup (one atomicAdd per wave serialised on the hot counter at ~12 ns each:
-// 2 M of them made a cheap late level cost 21 ms on RMAT-27).
+// ---- hub heads of the bottom-up step (see bfs_bu_kernel)
+#ifndef BFS_HUBS
+#define BFS_HUBS (1u << 17)      // hubs tracked: their frontier bits are 16 KB of LDS per workgroup
+#endif
+#define BFS_NO_HUB 0xFFFFFFFFu
+// keys (out-degree << 32 | vertex) of every vertex, for the sort that ranks them
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_hub_keys_kernel(const eoff_t *__restrict__ out_rowptr, int32_t m, unsigned long long *__restrict__ keys) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (unsigned)m) {
+    const eoff_t d = out_rowptr[v + 1] - out_rowptr[v];
+    keys[v] = ((unsigned long long)(d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d) << 32) | v;
+  }
+}
+// rank[vertex] = its position in the descending order of out-degrees (the END of the ascending sort is rank 0; no
+// out-edge: BFS_NO_HUB, never in a frontier that matters); hub_id[k] = the vertex of rank k < n_hubs
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_hub_rank_kernel(const unsigned long long *__restrict__ sorted, int32_t m, unsigned n_hubs, vid_t *__restrict__ hub_id,
+                    unsigned *__restrict__ rank) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k >= (unsigned)m) {
+    if (k < n_hubs) hub_id[k] = -1;  // fewer vertices than slots
+    return;
+  }
+  const unsigned long long key = sorted[(size_t)m - 1 - k];
+  const unsigned v = (unsigned)(key & 0xFFFFFFFFull);
+  const bool any = (key >> 32) != 0ull;
+  rank[v] = any ? k : BFS_NO_HUB;
+  if (k < n_hubs) hub_id[k] = any ? (vid_t)v : -1;
+}
+// rec[v] = out-degree of v << 32 | HEAD of v: its in-neighbour of highest out-degree -- as the hub index when that is one
+// of the BFS_HUBS largest (tested against LDS bits), else as 2^31 | vertex (tested against the frontier bitmap), BFS_NO_HUB
+// without in-edges.  One wave per row, over at most BFS_HEAD_SCAN of its in-edges: ANY in-neighbour is a valid head, the
+// best one only raises the hit rate, and the rows beyond (0.01 % of RMAT-27's) are hubs themselves, discovered top-down --
+// walked whole, the few rows of millions of in-edges made the plan build 2.8 s longer.  (Measured and dropped: the three best hubs, 16 bits each, tested together -- with
+// 2^16 hub slots the heavy level of RMAT-27 1.26 -> 1.60 ms, profiles/r03_bfs_hub_heads.txt.)
+#define BFS_HEAD_VERTEX 0x80000000u
+#define BFS_HEAD_SCAN 8192
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
+                    const eoff_t *__restrict__ out_rowptr, int32_t m, const unsigned *__restrict__ rank,
+                    const unsigned long long *__restrict__ sorted, unsigned long long *__restrict__ rec) {
+  const unsigned lane = gdn_lane();
+  const size_t nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
+  for (size_t v = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; v < (size_t)m; v += nwaves) {
+    const eoff_t b = in_rowptr[v];
+    eoff_t e = in_rowptr[v + 1];
+    if (e - b > BFS_HEAD_SCAN) e = b + BFS_HEAD_SCAN;
+    unsigned best = BFS_NO_HUB;
+    for (eoff_t k = b + lane; k < e; k += 64) {
+      const unsigned h = rank[in_colidx[k]];
+      best = h < best ? h : best;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned t = (unsigned)__shfl_xor((int)best, o, 64);
+      best = t < best ? t : best;
+    }
+    if (lane == 0) {
+      unsigned code = best;
+      if (best != BFS_NO_HUB && best >= BFS_HUBS) code = BFS_HEAD_VERTEX | (unsigned)(sorted[(size_t)m - 1 - best] & 0x7FFFFFFFull);
+      const eoff_t d = out_rowptr[v + 1] - out_rowptr[v];
+      rec[v] = ((unsigned long long)d << 32) | code;
+    }
+  }
+}
+// this level's frontier bits of the hubs
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_hub_front_kernel(const vid_t *__restrict__ hub_id, const unsigned *__restrict__ front, unsigned *__restrict__ hub_front) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;  // grid covers BFS_HUBS exactly
+  const vid_t u = hub_id[k];
+  const bool in = u >= 0 && ((front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u);
+  const unsigned long long mask = __ballot(in);
+  if ((gdn_lane() & 31u) == 0) hub_front[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
+  // word BFS_HUBS / 32 (zeroed by the host before): how many hubs the frontier holds -- the bottom-up step reads the
+  // heads only when that is worth 4 bytes per open row
+  if (gdn_lane() == 0 && mask) atomicAdd(&hub_front[BFS_HUBS / 32], (unsigned)__popcll(mask));
+}
+
+// Bottom-up step (omp_beamer.cc:13-31): a row not yet visited is discovered if one of its in-neighbours is in the frontier.
+// Round 3 form -- the first one walked the vertices one per thread and iteration, every iteration a chain of dependent
+// reads (visited word -> row offsets -> neighbour -> frontier word), 256 iterations per thread at RMAT-27: latency bound at
+// 1.4-1.7 ms for the heavy level, and in the late levels three lanes of a wave scanned while 61 idled (0.3 ms for a level
+// that discovers 20 000 rows).  A workgroup now takes windows of BFS_BU_STEP consecutive rows:
+//   stage 0, one bitmap word per thread (visited | no-in-edges, fetched one step ahead): the OPEN rows of the window are
+//            listed in LDS (a block scan of the pop-counts) -- a late level is nothing but this;
+//   stage 1, the listed rows, one per thread and dense: HEADS.  rec[v] (8 bytes, bfs_hub_head_kernel) names the
+//            in-neighbour of v with the highest out-degree -- by hub index when it is one of the BFS_HUBS largest (this
+//            level's frontier bits of the hubs sit in LDS: hub_front), by vertex id else (one read of the frontier bitmap)
+//            -- and carries v's out-degree: a row whose head is in the frontier is discovered from ONE 8-byte read, the
+//            frontier's out-degree sum comes with it.  RMAT-27, the heavy level: 43.8 M of 44.1 M discoveries (with hub
+//            indices alone 35.3 M; the 12 M others then cost 0.57 ms of row-offset / neighbour / frontier gathers at the
+//            ~55 G/s gather wall); the rows still open go into an LDS queue that spans up to BFS_BU_WIN windows;
+//   stage 2, when the queue is full or BFS_BU_WIN windows wait: every thread takes queued rows and scans their
+//            in-neighbours (dense lanes whatever the level); then the windows' next / visited words are written whole --
+//            every word belongs to one workgroup and is written once, no atomics on global memory.
+// Measured (profiles/r03_bfs_bottom_up.txt): heavy level 1.72 -> 1.03 ms, the level after 0.85 -> 0.37, a late level
+// 0.31 -> 0.17; compile-time knobs (windows 16, grid 1024 / 4096, 2 / 8 rows side by side) within 3 %, 2^15 / 2^16 hubs
+// 14 % / 8 % slower on the heavy level.
+// Persistent grid: the awake / scout totals are kept in registers and added to the level counters ONCE per workgroup.
+#define BFS_BU_WORDS 128                                  // bitmap words per window (threads 0..127 fetch one each)
+#define BFS_BU_STEP (BFS_BU_WORDS * 32)                   // rows per window
+#ifndef BFS_BU_WIN
+#define BFS_BU_WIN 8                                      // windows whose open rows may wait together
+#endif
+#define BFS_BU_Q 4096                                     // queue entries (u16: window << 12 | row in window)
+#ifndef BFS_BU_UNR
+#define BFS_BU_UNR 4                                      // listed rows per thread whose loads are issued side by side
+#endif
+#ifndef BFS_BU_GRID
+#define BFS_BU_GRID (256 * 8)
+#endif
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
               const eoff_t *__restrict__ out_rowptr, int32_t m, unsigned m_pad, const unsigned *__restrict__ front,
@@ -312,55 +421,191 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
               int32_t next_level, BfsCounters *cnt,
               // nullable: bitmap of the rows WITHOUT in-edges (never discoverable): skipped without touching their row
               // offsets -- 61 % of RMAT-27's rows, 16 B of in_rowptr each otherwise
-              const unsigned *__restrict__ noin = nullptr) {
-  __shared__ unsigned long long s_red[2 * GDN_WAVES_PER_BLOCK];
-  const unsigned lane = gdn_lane();
+              const unsigned *__restrict__ noin = nullptr,
+              // hub heads (nullable, see above)
+              const unsigned long long *__restrict__ rec = nullptr, const unsigned *__restrict__ hub_front = nullptr,
+              unsigned min_hubs = 0, bool trace = false) {
+  static_assert(BFS_BU_STEP == 4096 && BFS_BU_WIN <= 16 && BFS_BU_Q >= BFS_BU_STEP && BFS_BU_WORDS <= GDN_BLOCK,
+                "queue entries keep the row in 12 bits, the window in 4; one window's open rows must fit the empty queue");
+  __shared__ unsigned long long s_red[4 * GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned s_hf[BFS_HUBS / 32];
+  __shared__ unsigned short s_list[BFS_BU_STEP];       // open rows of the current window, ascending
+  __shared__ unsigned short s_q[BFS_BU_Q];             // rows waiting for their in-neighbour scan
+  __shared__ unsigned s_bits[BFS_BU_WIN][BFS_BU_WORDS];  // discoveries of the windows that wait, 1 bit per row
+  __shared__ unsigned s_wbase[BFS_BU_WIN];              // first row of every waiting window
+  __shared__ unsigned s_wsum[GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned s_qn;
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
+  const bool hubs = rec && hub_front[BFS_HUBS / 32] >= min_hubs;  // else: too few hubs in this frontier (uniform)
+  if (hubs)
+    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += GDN_BLOCK) s_hf[i] = hub_front[i];
+  if (threadIdx.x == 0) s_qn = 0u;
+  __syncthreads();
   unsigned long long awake = 0, scout = 0;
-  for (unsigned base = blockIdx.x * GDN_BLOCK; base < m_pad; base += gridDim.x * GDN_BLOCK) {
-    const unsigned v = base + threadIdx.x;
-    bool found = false;
-    if (v < (unsigned)m) {
-      const unsigned vw = visited[v >> 5] | (noin ? noin[v >> 5] : 0u);
-      if (!((vw >> (v & 31)) & 1u)) {
-        const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
-        for (eoff_t k = rb; k < re; k++) {
-          const vid_t u = in_colidx[k];
-          if ((front[u >> 5] >> (u & 31)) & 1u) {
-            found = true;
-            break;
-          }
+  unsigned by_head = 0, probes = 0;
+  unsigned nwin = 0;  // windows waiting (block-uniform)
+  // stage 2a: the queued rows, one per thread
+  auto scan_queue = [&]() {
+    __syncthreads();
+    const unsigned n = s_qn;
+    // (four queued rows side by side per thread -- offsets, first neighbours, frontier words as rounds of independent
+    // loads -- measured no faster: the scans run at the gather wall, not at a latency chain)
+    for (unsigned i = threadIdx.x; i < n; i += GDN_BLOCK) {
+      const unsigned e = s_q[i], wi = e >> 12, rl = e & 4095u;
+      const unsigned v = s_wbase[wi] + rl;
+      const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
+      bool found = false;
+      for (eoff_t k = rb; k < re; k++) {
+        const vid_t u = in_colidx[k];
+        probes++;
+        if ((front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u) {
+          found = true;
+          break;
+        }
+      }
+      if (found) {
+        depth[v] = next_level;
+        atomicOr(&s_bits[wi][rl >> 5], 1u << (rl & 31u));
+        awake++;
+        scout += rec ? (eoff_t)(rec[v] >> 32) : out_rowptr[v + 1] - out_rowptr[v];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_qn = 0u;
+    __syncthreads();
+  };
+  // stage 2b: the waiting windows' words go out
+  auto flush = [&]() {
+    scan_queue();
+    for (unsigned i = threadIdx.x; i < nwin * BFS_BU_WORDS; i += GDN_BLOCK) {
+      const unsigned wi = i / BFS_BU_WORDS, j = i % BFS_BU_WORDS;
+      const unsigned word = (s_wbase[wi] >> 5) + j;
+      if ((word << 5) < m_pad) {
+        const unsigned bits = s_bits[wi][j];
+        next[word] = bits;
+        if (bits) visited[word] |= bits;
+      }
+    }
+    nwin = 0;
+    __syncthreads();
+  };
+  // the bitmap word of a thread, fetched one window ahead (another workgroup's words never change under this one)
+  auto fetch = [&](unsigned base) -> unsigned {
+    const unsigned x = base + threadIdx.x * 32u;  // first row of the word
+    unsigned w = ~0u;
+    if (threadIdx.x < BFS_BU_WORDS && base < m_pad && x < (unsigned)m) {
+      w = visited[x >> 5] | (noin ? noin[x >> 5] : 0u);
+      if ((unsigned)m - x < 32u) w |= ~0u << ((unsigned)m - x);  // rows past the last one
+    }
+    return w;
+  };
+  unsigned w_next = fetch(blockIdx.x * BFS_BU_STEP);
+  for (unsigned base = blockIdx.x * BFS_BU_STEP; base < m_pad; base += gridDim.x * BFS_BU_STEP) {  // block-uniform trip count
+    // ---- stage 0
+    unsigned open = ~w_next;
+    w_next = fetch(base + gridDim.x * BFS_BU_STEP);
+    const unsigned cnt_open = (unsigned)__popc(open);
+    const unsigned incl = gdn_wave_incl_scan(cnt_open);
+    if (lane == 63) s_wsum[wave] = incl;
+    if (threadIdx.x < BFS_BU_WORDS) s_bits[nwin][threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_wbase[nwin] = base;
+    __syncthreads();
+    unsigned off = incl - cnt_open, n = 0;
+#pragma unroll
+    for (unsigned i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
+      const unsigned t = s_wsum[i];
+      if (i < wave) off += t;
+      n += t;
+    }
+    if (n == 0) {  // nothing open in the window (uniform): its words are zero, and they still have to go out
+      nwin++;
+      if (nwin == BFS_BU_WIN) flush();
+      else __syncthreads();
+      continue;
+    }
+    while (open) {
+      const unsigned b = (unsigned)__ffs((int)open) - 1u;
+      open &= open - 1u;
+      s_list[off++] = (unsigned short)(threadIdx.x * 32u + b);
+    }
+    if (s_qn + n > BFS_BU_Q) scan_queue();  // uniform; leaves room for every row of this window
+    else __syncthreads();
+    // ---- stage 1
+    for (unsigned i0 = 0; i0 < n; i0 += BFS_BU_UNR * GDN_BLOCK) {
+      unsigned rl[BFS_BU_UNR], code[BFS_BU_UNR], fw[BFS_BU_UNR];
+      unsigned long long rc[BFS_BU_UNR];
+      bool on[BFS_BU_UNR], found[BFS_BU_UNR];
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {
+        const unsigned i = i0 + (unsigned)r * GDN_BLOCK + threadIdx.x;
+        on[r] = i < n;
+        rl[r] = on[r] ? s_list[i] : 0u;
+        rc[r] = BFS_NO_HUB;
+        if (on[r] && rec) rc[r] = rec[base + rl[r]];
+        code[r] = (unsigned)rc[r];
+      }
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {  // heads outside the hub set: their frontier word
+        fw[r] = 0u;
+        if (code[r] != BFS_NO_HUB && (code[r] & BFS_HEAD_VERTEX)) fw[r] = front[(code[r] & ~BFS_HEAD_VERTEX) >> 5];
+      }
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {
+        found[r] = code[r] < BFS_HUBS ? (hubs && ((s_hf[code[r] >> 5] >> (code[r] & 31u)) & 1u)) : (bool)((fw[r] >> (code[r] & 31u)) & 1u);
+        if (found[r]) {
+          depth[base + rl[r]] = next_level;
+          scout += rc[r] >> 32;
+          atomicOr(&s_bits[nwin][rl[r] >> 5], 1u << (rl[r] & 31u));
+          by_head++;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {
+        const bool wait = on[r] && !found[r];  // into the queue (one LDS reservation per wave)
+        const unsigned long long om = __ballot(wait);
+        if (om) {
+          const int first = __ffsll((long long)om) - 1;
+          unsigned pos = 0;
+          if (lane == (unsigned)first) pos = atomicAdd(&s_qn, (unsigned)__popcll(om));
+          pos = __shfl(pos, first, 64);
+          if (wait) s_q[pos + (unsigned)__popcll(om & gdn_lanemask_lt())] = (unsigned short)((nwin << 12) | rl[r]);
         }
       }
     }
-    if (found) {
-      depth[v] = next_level;
-      awake++;
-      scout += out_rowptr[v + 1] - out_rowptr[v];
-    }
-    const unsigned long long mask = __ballot(found);
-    if ((lane & 31u) == 0 && v < m_pad) {
-      const unsigned bits = (unsigned)(mask >> (lane & 32u));
-      next[v >> 5] = bits;
-      if (bits) visited[v >> 5] |= bits;
-    }
+    nwin++;
+    if (nwin == BFS_BU_WIN) flush();  // uniform
+    else __syncthreads();
   }
+  if (nwin) flush();
+  awake += by_head;
   awake = gdn_wave_sum(awake);
   scout = gdn_wave_sum(scout);
+  // (the two trace counters: per workgroup like the others -- added per WAVE, 16 K atomics on one line cost a level 0.25 ms)
+  const unsigned long long bh = trace ? gdn_wave_sum((unsigned long long)by_head) : 0ull;
+  const unsigned long long pr = trace ? gdn_wave_sum((unsigned long long)probes) : 0ull;
   const unsigned w = threadIdx.x >> 6;
   if (lane == 0) {
     s_red[w] = awake;
     s_red[GDN_WAVES_PER_BLOCK + w] = scout;
+    s_red[2 * GDN_WAVES_PER_BLOCK + w] = bh;
+    s_red[3 * GDN_WAVES_PER_BLOCK + w] = pr;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    unsigned long long a = 0, sc = 0;
+    unsigned long long a = 0, sc = 0, b = 0, c = 0;
     for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
       a += s_red[i];
       sc += s_red[GDN_WAVES_PER_BLOCK + i];
+      b += s_red[2 * GDN_WAVES_PER_BLOCK + i];
+      c += s_red[3 * GDN_WAVES_PER_BLOCK + i];
     }
     if (a) {
       atomicAdd(&cnt->awake, a);
       atomicAdd(&cnt->scout, sc);
+    }
+    if (b | c) {
+      atomicAdd(&cnt->bu_by_head, b);
+      atomicAdd(&cnt->bu_probes, c);
     }
   }
 }
@@ -837,6 +1082,9 @@ bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigne
   }
 }
 
+int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
+                       const unsigned long long **sorted);
+
 struct gdn_bfs_plan {
   const gdn_graph *g = nullptr, *gin = nullptr;
   bool dense = false;
@@ -857,6 +1105,9 @@ struct gdn_bfs_plan {
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
+  DevBuf<vid_t> hub_id;                // hub heads of the bottom-up step (bfs_bu_kernel): the BFS_HUBS vertices of highest
+  DevBuf<unsigned long long> head;     //   out-degree, every row's out-degree | head (bfs_hub_head_kernel),
+  DevBuf<unsigned> hub_front;          //   the hubs' frontier bits per level
   // binned top-down levels (bfs_btd_*): nbins x BFS_BTD_SUB id lists of btd_cap_each entries, their counters, the flag
   DevBuf<vid_t> btd_buf;
   DevBuf<unsigned> btd_cur, btd_flag;
@@ -982,6 +1233,33 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     GDN_TRY(p.noin.alloc(p.nwords_pad));
     hipLaunchKernelGGL(bfs_noin_kernel, dim3(gdn_nblocks(p.nwords_pad)), dim3(GDN_BLOCK), 0, 0, gin->rowptr, m, p.nwords_pad,
                        p.noin.p);
+    // hub heads: from 2^24 edges on (below, a level is a few hundred microseconds and the plan build should stay short);
+    // GDN_BFS_HUB_HEADS=0 switches them off (A/B)
+    const char *hh = gdn_option("GDN_BFS_HUB_HEADS");
+    if (dense && g->nnz >= (1ull << 24) && (unsigned)m >= 4u * BFS_HUBS && !(hh && hh[0] == '0')) {
+      HostTimer th;
+      GDN_HIP(hipDeviceSynchronize());
+      th.start();
+      DevBuf<unsigned long long> ka, kb;
+      DevBuf<unsigned> hub_idx;
+      GDN_TRY(ka.alloc((size_t)m));
+      GDN_TRY(kb.alloc((size_t)m));
+      GDN_TRY(hub_idx.alloc((size_t)m));
+      GDN_TRY(p.hub_id.alloc(BFS_HUBS));
+      GDN_TRY(p.head.alloc((size_t)m));
+      GDN_TRY(p.hub_front.alloc(BFS_HUBS / 32 + 1));  // + the count of hubs in the frontier
+      hipLaunchKernelGGL(bfs_hub_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, ka.p);
+      GDN_HIP(hipGetLastError());
+      const unsigned long long *sorted = nullptr;
+      GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m, 32u, 64u, &sorted));
+      hipLaunchKernelGGL(bfs_hub_rank_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, sorted, m, BFS_HUBS, p.hub_id.p,
+                         hub_idx.p);
+      hipLaunchKernelGGL(bfs_hub_head_kernel, dim3(256 * 16), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
+                         hub_idx.p, sorted, p.head.p);
+      GDN_HIP(hipGetLastError());
+      GDN_HIP(hipDeviceSynchronize());
+      if (gdn_option("GDN_BFS_TRACE")) fprintf(stderr, "[bfs] plan: heads of the bottom-up step %.1f ms\n", th.stop_ms());
+    }
   }
   GDN_HIP(hipDeviceSynchronize());
   p.prep_ms = t.stop_ms();
@@ -1035,6 +1313,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   if (const char *e = gdn_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
   int64_t bu_stay = 256;
   if (const char *e = gdn_option("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
+  unsigned hub_min = BFS_HUBS / 8;  // hubs a frontier must hold for the bottom-up step to read the heads
+  if (const char *e = gdn_option("GDN_BFS_HUB_MIN")) hub_min = (unsigned)atoi(e);  // tuning knob
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
   // (measured: 1024 / 16384 made RMAT-20..24 searches 5-15 % slower -- 16 K edges on ONE CU are no faster than a launch
   // over all of them --, a 100 000-vertex chain 4.6x faster; the smaller limits keep the second without the first)
@@ -1141,8 +1421,13 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         }
         if (btd) {
         } else if (bottom_up) {
-          hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
-                             p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
+          if (p.head.p) {
+            GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, sizeof(unsigned), 0));
+            hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(BFS_HUBS / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p);
+          }
+          hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
+                             p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
+                             p.hub_front.p, hub_min, trace);
         } else {
           hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
                              p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
@@ -1163,6 +1448,13 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         nx = t;
         level++;
         have_queue = false;
+        if (trace && bottom_up && !btd)
+        {
+          unsigned nh = 0;
+          if (p.head.p) (void)hipMemcpy(&nh, p.hub_front.p + BFS_HUBS / 32, sizeof(nh), hipMemcpyDeviceToHost);
+          fprintf(stderr, "[bfs]   bottom-up: %u hubs in the frontier, %llu rows by their hub head, %llu in-neighbours probed for the others\n",
+                  nh, h.bu_by_head, h.bu_probes);
+        }
         lap(engine, awake, scout_count);
         // stay on bitmaps while the frontier is heavy, or while the cheap bottom-up engine beats a top-down
         // step over scout_count edges (a late level with millions of frontier vertices but few discoveries)
@@ -1192,7 +1484,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         ++iter;
         old_awake = awake;
         GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
-        hipLaunchKernelGGL(bfs_bu_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
+        hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                            p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
         GDN_TRY(bfs_read_counters(p, h));
         awake = (int64_t)h.awake;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # build_variant.sh <name> <extra hipcc flags...>: a second build of libgardenia_hip.so with other compile-time
-# knobs into gardenia_amd/lib/var_<name>/ (select it with GARDENIA_HIP_LIB=...); measurement scaffolding.
+# knobs (VARIANT_FILE=gdn_bfs: the source the knobs are in, default gdn_tc) into gardenia_amd/lib/var_<name>/ (select it with GARDENIA_HIP_LIB=...); measurement scaffolding.
 set -e
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
@@ -8,7 +8,7 @@ out=$HERE/gardenia_amd/lib/var_$name
 mkdir -p $out/obj
 for f in $HERE/gardenia_amd/csrc/*.hip; do
   b=$(basename $f .hip)
-  if [ "$b" = "gdn_tc" ] || [ ! -f $out/obj/$b.o ]; then
+  if [ "$b" = "${VARIANT_FILE:-gdn_tc}" ] || [ ! -f $out/obj/$b.o ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$HERE/include "$@" -c $f -o $out/obj/$b.o &
   fi
 done
