@@ -95,6 +95,7 @@ PROTOTYPES = {
     "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
     "gdn_pr_plan_mid": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_u64)]),
+    "gdn_pr_plan_move": (C.c_int, [_vp, C.c_uint32]),
     "gdn_pr_plan_state_size": (C.c_int, [_vp, C.POINTER(_i32)]),
     "gdn_pr_plan_bins": (C.c_int, [_vp, C.POINTER(_i32)]),
     "gdn_pr_import_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),

@@ -93,6 +93,41 @@ struct DevBuf {
     p = reinterpret_cast<T *>(static_cast<char *>(base) + off);
     return GDN_OK;
   }
+  // the same contents in a FRESH allocation (made while the old one is still held, so it is other memory); `keep` gets the
+  // old allocation instead of hipFree when the caller may want to go back (gdn_pr_plan_place: where hipMalloc puts a
+  // streamed array moves a PageRank iteration by up to 8 %)
+  int move(DevBuf<T> *keep = nullptr) {
+    if (!p || n == 0) return GDN_OK;
+    void *nb = nullptr;
+    hipError_t e = hipMalloc(&nb, n * sizeof(T));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      gdn_set_error("hipMalloc(%zu bytes) -> %s", n * sizeof(T), hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+    e = hipMemcpy(nb, p, n * sizeof(T), hipMemcpyDeviceToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(nb);
+      gdn_set_error("move copy -> %s", hipGetErrorString(e));
+      return GDN_ERR_HIP;
+    }
+    if (keep) {
+      keep->release();
+      keep->base = base;
+      keep->p = p;
+      keep->n = n;
+    } else {
+      (void)hipFree(base);
+    }
+    base = nb;
+    p = static_cast<T *>(nb);
+    return GDN_OK;
+  }
+  void swap(DevBuf<T> &o) {
+    T *tp = p; p = o.p; o.p = tp;
+    size_t tn = n; n = o.n; o.n = tn;
+    void *tb = base; base = o.base; o.base = tb;
+  }
 #ifdef GDN_EXPERIMENTS  // placement A/B knobs of measurement builds only (make EXPERIMENTS=1, tools/build_variant.sh)
   // move the contents into an allocation made with hipExtMallocWithFlags(flags) (A/B knob: hipDeviceMallocUncached keeps a
   // read-once stream out of the XCD L2s)

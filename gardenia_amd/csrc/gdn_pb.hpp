@@ -39,6 +39,7 @@
 // truncated at 2^-62 = 2.2e-19 absolute.  That is MORE accurate than the reference's
 // sequential fp32 accumulation.  Out-of-range inputs raise an error flag instead of wrapping.
 #pragma once
+#include <functional>
 #include <vector>
 
 #include "gdn_common.hpp"
@@ -96,6 +97,60 @@ struct PbPlan {
 // costs ~1 s at RMAT-27 (page mapping), and a PageRank plan builds four layouts.
 struct PbScratch {
   DevBuf<unsigned long long> ka, kb;
+};
+
+// PLACEMENT SEARCH of a plan's streamed arrays.  Where hipMalloc puts them moves a sweep by up to 9 % (PageRank, RMAT-27:
+// 3.77 .. 4.15 ms between plans of ONE process that differ in nothing else; phase A follows `vals` (1.04 .. 1.23 ms) and a
+// little `U`, phase B follows `V` and the record streams, 0.03 .. 0.1 ms each -- tools/pr_place_probe.py,
+// profiles/r03_pb_placement.txt).  Physical addresses are not visible to an unprivileged process, and neither staggered bases
+// nor shuffled 2 MiB chunks changed the spread.  So a plan measures: array by array, up to `tries` fresh
+// allocations are timed on scratch vectors (`timed`: the mean of a few sweeps), the fastest one stays; a rejected allocation is
+// held until the array is done, else hipMalloc would hand the same block out again.  Values do not matter to the timing, and
+// no result depends on where an array lives.  Bounded by budget_ms (a fresh allocation costs ~50 ms per GB of page mapping
+// once the blocks the plan build freed are used up).  What does NOT explore the spread: offsets inside one allocation (16
+// random 4 KiB multiples inside a 64 MiB slack: all within 0.5 % of each other, the other arena 2 % away) -- it is the
+// physical region, not the alignment.
+struct PbPlacer {
+  int tries = 0;
+  double budget_ms = 0;
+  const char *tag = "";
+  bool trace = false;
+  size_t min_bytes = (size_t)64 << 20;  // smaller arrays live in the caches (GDN_PLACE_MIN_BYTES: tests force the search)
+  std::function<int(double *)> timed;
+  HostTimer wall;
+  double best = 0, first = 0;
+  int begin() {
+    if (const char *e = gdn_option("GDN_PLACE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);
+    GDN_HIP(hipDeviceSynchronize());
+    wall.start();
+    GDN_TRY(timed(&best));  // (the first one also loads code objects in a fresh process)
+    GDN_TRY(timed(&best));
+    first = best;
+    return GDN_OK;
+  }
+  template <typename T>
+  int search(DevBuf<T> &buf, const char *name, int mult = 1) {
+    if (!buf.p || buf.n * sizeof(T) < min_bytes) return GDN_OK;
+    std::vector<DevBuf<T> *> held;
+    int rc = GDN_OK;
+    for (int k = 0; k < tries * mult && rc == GDN_OK; k++) {
+      if (wall.stop_ms() > budget_ms) break;
+      DevBuf<T> *old = new DevBuf<T>();
+      held.push_back(old);
+      if (buf.move(old) != GDN_OK) break;  // no memory for a second copy: the array stays where it is
+      double cur = 0;
+      if ((rc = timed(&cur)) != GDN_OK) break;
+      if (trace) fprintf(stderr, "[%s place] %-12s try %d: %.3f ms (best %.3f) at %p (was %p)\n", tag, name, k, cur, best, (void *)buf.p, (void *)old->p);
+      if (cur < best * 0.997) best = cur;
+      else buf.swap(*old);  // back to the faster allocation; the new one is held until the array is done, then freed
+    }
+    for (DevBuf<T> *h : held) delete h;
+    return rc;
+  }
+  void end() {
+    (void)hipDeviceSynchronize();
+    if (trace) fprintf(stderr, "[%s place] %.3f -> %.3f ms per sweep, %.0f ms spent\n", tag, first, best, wall.stop_ms());
+  }
 };
 
 // implemented in gdn_build.hip (uses the radix sort)

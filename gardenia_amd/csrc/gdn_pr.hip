@@ -568,6 +568,9 @@ static int pb_pick_log(int64_t n, int max_log, int slices_log) {
   return lg;
 }
 
+static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms);
+static thread_local bool g_pr_no_place = false;  // set by gdn_pr around its own plan: one solve does not pay for a search
+
 int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
                        int32_t row_base, int32_t layout, gdn_pr_plan **plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
@@ -867,6 +870,21 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   if (p->squished) {  // the PB layouts hold every edge: the relabelled CSR is not read again
     p->sq_colidx.release();
     p->sq_rowptr.release();
+  }
+  // placement search (pr_plan_place): from 2^28 edges on -- below, the streams are a few hundred MB and an iteration a few
+  // hundred microseconds.  GDN_PR_PLACE=<tries per array> (0 = off)
+  unsigned long long place_from = 1ull << 28;
+  if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
+  if (p->layout != GDN_LAYOUT_CSR && p->nnz >= place_from && !g_pr_no_place) {
+    int tries = 3;
+    if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
+    if (tries > 0) {
+      const int rcp = pr_plan_place(p, tries, 1000.0);
+      if (rcp != GDN_OK) {
+        delete p;
+        return rcp;
+      }
+    }
   }
   *plan = p;
   return GDN_OK;
@@ -1229,6 +1247,73 @@ int gdn_pr_plan_kernel_time(gdn_pr_plan *plan, int32_t reset, int32_t max_launch
   return GDN_OK;
 }
 
+// Placement: the arrays named in `what` (1 vals, 2 U, 4 G, 8 V, 16 hub records, 32 mid-tier records,
+// 64 per-iteration tables) move into fresh allocations.
+int gdn_pr_plan_move(gdn_pr_plan *plan, uint32_t what) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (plan->layout == GDN_LAYOUT_CSR) return GDN_OK;
+  GDN_HIP(hipDeviceSynchronize());
+  if (what & 1u) GDN_TRY(plan->pb.vals.move());
+  if (what & 2u) GDN_TRY(plan->pb.U.move());
+  if (what & 4u) GDN_TRY(plan->pb.G.move());
+  if (what & 8u) GDN_TRY(plan->pb.V.move());
+  if ((what & 16u) && plan->has_hub) GDN_TRY(plan->hub_rec.move());
+  if (what & 32u)
+    for (int t = 0; t < plan->n_mid_tiers; t++) GDN_TRY(plan->mid[t].rec.move());
+  if (what & 64u) {
+    if (plan->has_hub) GDN_TRY(plan->hub_val.move());
+    for (int t = 0; t < plan->n_mid_tiers; t++) GDN_TRY(plan->mid[t].val.move());
+  }
+  return GDN_OK;
+}
+
+// Placement search (PbPlacer, gdn_pb.hpp) of a blocked PageRank plan: three iterations on scratch vectors per candidate.
+static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
+  const int32_t ms = p->squished ? (int32_t)p->sq_ids.n : p->m_local;
+  const int32_t mg = p->squished ? ms : p->m_global;
+  if (ms <= 0 || mg <= 0) return GDN_OK;
+  DevBuf<float> sc, c0, c1;
+  DevBuf<double> diff;
+  GDN_TRY(sc.alloc((size_t)ms));
+  GDN_TRY(c0.alloc((size_t)mg));
+  GDN_TRY(c1.alloc((size_t)mg));
+  GDN_TRY(diff.alloc(1));
+  const float v = 1.0f / (float)mg, c = v / 16.0f;
+  GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(sc.p), __builtin_bit_cast(int32_t, v), (size_t)ms, 0));
+  GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(c0.p), __builtin_bit_cast(int32_t, c), (size_t)mg, 0));
+  GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(c1.p), __builtin_bit_cast(int32_t, c), (size_t)mg, 0));
+  HostTimer t;
+  int it = 0;
+  auto pull = [&]() {
+    float *in = (it & 1) ? c1.p : c0.p, *out = (it & 1) ? c0.p : c1.p;
+    it++;
+    return gdn_pr_pull_dev(p, in, sc.p, out, diff.p, 0.85f, nullptr);
+  };
+  PbPlacer pl;
+  pl.tries = tries;
+  pl.budget_ms = budget_ms;
+  pl.tag = "pr";
+  pl.trace = gdn_option("GDN_PR_PLACE_TRACE") != nullptr;
+  pl.timed = [&](double *out_ms) -> int {
+    GDN_TRY(pull());
+    GDN_HIP(hipDeviceSynchronize());
+    t.start();
+    for (int k = 0; k < 3; k++) GDN_TRY(pull());
+    *out_ms = t.stop_ms() / 3.0;
+    return GDN_OK;
+  };
+  GDN_TRY(pl.begin());
+  int rc = pl.search(p->pb.vals, "vals", 2);  // the array that matters most (phase A 1.04 .. 1.23 ms)
+  if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
+  for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) rc = pl.search(p->mid[k].rec, "mid records");
+  if (rc == GDN_OK && p->has_hub) rc = pl.search(p->hub_rec, "hub records");
+  if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
+  pl.end();
+  unsigned zero = 0;  // the scratch iterations must not leave a range flag behind
+  GDN_HIP(hipMemcpy(p->pb.errflag.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
+  return rc;
+}
+
 int gdn_pr_plan_check(gdn_pr_plan *plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
   if (plan->layout != GDN_LAYOUT_PB) return GDN_OK;
@@ -1351,7 +1436,10 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
       else if (!pb) layout = GDN_LAYOUT_CSR;
     }
-    if ((rc = gdn_pr_plan_create(g, d_deg.p, m, 0, layout, &plan))) break;
+    g_pr_no_place = true;
+    rc = gdn_pr_plan_create(g, d_deg.p, m, 0, layout, &plan);
+    g_pr_no_place = false;
+    if (rc) break;
     int32_t ms = m;
     if ((rc = gdn_pr_plan_state_size(plan, &ms))) break;
     if ((rc = d_state.alloc(ms)) || (rc = d_c0.alloc(ms)) || (rc = d_c1.alloc(ms))) break;

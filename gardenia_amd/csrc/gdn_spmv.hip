@@ -197,6 +197,8 @@ static int spmv_pick_log(int64_t n, int max_log, int slices_log) {
   return lg;
 }
 
+static int spmv_plan_place(gdn_spmv_plan *p, const float *d_Ax, int tries, double budget_ms);
+
 int gdn_spmv_plan_create(const gdn_graph *csr, const float *d_Ax, int32_t layout, gdn_spmv_plan **plan) {
   GDN_REQUIRE(csr != nullptr, "csr");
   return gdn_spmv_plan_create_cols(csr, d_Ax, csr->m, layout, plan);
@@ -314,12 +316,59 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     gdn_set_error("gdn_spmv_plan_create: layout kernels failed: %s", hipGetErrorString(hipGetLastError()));
     st = GDN_ERR_HIP;
   }
+  // placement search (PbPlacer, gdn_pb.hpp) from 2^28 non-zeros on: three multiplies on scratch vectors per candidate.
+  // GDN_SPMV_PLACE=<tries per array> (0 = off)
+  unsigned long long place_from = 1ull << 28;
+  if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
+  if (st == GDN_OK && p->layout == GDN_LAYOUT_PB && csr->nnz >= place_from) {
+    int tries = 3;
+    if (const char *e = gdn_option("GDN_SPMV_PLACE")) tries = atoi(e);
+    if (tries > 0) st = spmv_plan_place(p, d_Ax, tries, 1000.0);
+  }
   if (st != GDN_OK) {
     delete p;
     return st;
   }
   *plan = p;
   return GDN_OK;
+}
+
+static int spmv_plan_place(gdn_spmv_plan *p, const float *d_Ax, int tries, double budget_ms) {
+  DevBuf<float> x, y;
+  GDN_TRY(x.alloc((size_t)p->n_cols));
+  GDN_TRY(y.alloc((size_t)p->m));
+  const float half = 0.5f;
+  GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(x.p), __builtin_bit_cast(int32_t, half), (size_t)p->n_cols, 0));
+  GDN_HIP(hipMemset(y.p, 0, (size_t)p->m * sizeof(float)));
+  HostTimer t;
+  PbPlacer pl;
+  pl.tries = tries;
+  pl.budget_ms = budget_ms;
+  pl.tag = "spmv";
+  pl.trace = gdn_option("GDN_SPMV_PLACE_TRACE") != nullptr;
+  pl.timed = [&](double *out_ms) -> int {
+    GDN_TRY(gdn_spmv_dev(p, d_Ax, x.p, y.p, nullptr));
+    GDN_HIP(hipDeviceSynchronize());
+    t.start();
+    for (int k = 0; k < 3; k++) GDN_TRY(gdn_spmv_dev(p, d_Ax, x.p, y.p, nullptr));
+    *out_ms = t.stop_ms() / 3.0;
+    return GDN_OK;
+  };
+  GDN_TRY(pl.begin());
+  int rc = pl.search(p->pb.vals, "vals", 2);
+  if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
+  if (rc == GDN_OK) rc = pl.search(p->Axp, "Ax");
+  for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) {
+    rc = pl.search(p->mid[k].rec, "mid records");
+    if (rc == GDN_OK) rc = pl.search(p->mid[k].Ax, "mid Ax");
+  }
+  if (rc == GDN_OK && p->has_hub) {
+    rc = pl.search(p->hub_rec, "hub records");
+    if (rc == GDN_OK) rc = pl.search(p->hub_Ax, "hub Ax");
+  }
+  if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
+  pl.end();
+  return rc;
 }
 
 int gdn_spmv_plan_free(gdn_spmv_plan *plan) {

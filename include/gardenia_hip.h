@@ -263,6 +263,10 @@ int gdn_pr_plan_hubs(const gdn_pr_plan *plan, int32_t *n_hubs, uint64_t *hub_edg
 /* mid tiers of the PB layout (the degree levels below the hubs, read by phase B as 32-bit (source, row) records):
  * number of tiers, their sources and their edges (0 / 0 / 0 when the plan has none) */
 int gdn_pr_plan_mid(const gdn_pr_plan *plan, int32_t *n_tiers, int32_t *n_sources, uint64_t *n_edges);
+/* Placement of a blocked plan's streamed arrays: those named in `what` (1 vals, 2 U, 4 G, 8 V, 16 hub records, 32 mid-tier
+ * records, 64 per-iteration tables) are copied into fresh allocations.  Measurement hook of DESIGN.md 4.1 (where hipMalloc
+ * puts these arrays moves an iteration by up to 8 %). */
+int gdn_pr_plan_move(gdn_pr_plan *plan, uint32_t what);
 /* destination bins of the PB layout = workgroups of the accumulate phase (0 for the CSR layout): a driver that cuts an
  * iteration into row-range parts (gdn_pr_pull_rows_dev) keeps every part at a whole wave of workgroups or more */
 int gdn_pr_plan_bins(const gdn_pr_plan *plan, int32_t *n_bins);

@@ -328,6 +328,69 @@ def test_pr_mid_tiers_are_bitwise_neutral(orc, monkeypatch, world, parts):
     assert abs(res[2][2] - trace[-1]) < 1e-6
 
 
+@pytest.mark.parametrize("world,parts", [(1, 1), (2, 3)])
+def test_pr_placement_search_is_bitwise_neutral(orc, monkeypatch, capfd, world, parts):
+    """gdn_pr_plan_create times fresh allocations of a blocked plan's streamed arrays and keeps the fastest ones
+    (PbPlacer, DESIGN 4.1: from 2^28 edges on; forced here on every array of a small plan, tiers on).  A result must not
+    depend on where an array lives: same bits, iteration count and final error as the plan left where hipMalloc put it,
+    on whole graphs and on row shards; and gdn_pr_plan_move (the measurement hook) moves a live plan's arrays between
+    two solves without changing a bit."""
+    from gardenia_amd import _cabi
+    g = graphio.rmat_graph(17, 16, seed=43)
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    for k, v in TIER_ENV.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("GDN_PLACE_MIN_EDGES", "1")
+    monkeypatch.setenv("GDN_PLACE_MIN_BYTES", "1")
+    monkeypatch.setenv("GDN_PR_PLACE_TRACE", "1")
+    res = []
+    for tries in ("0", "2", "hook"):
+        monkeypatch.setenv("GDN_PR_PLACE", "0" if tries == "hook" else tries)
+        capfd.readouterr()
+        sh = solvers.ResidentPageRankShards(G, world, 1, parts=parts)
+        log = capfd.readouterr().err
+        assert ("[pr place]" in log) == (tries == "2"), log[-400:]
+        if tries == "2":
+            for name in ("vals", "V", "mid records", "hub records", "U"):
+                assert "[pr place] %-12s try" % name in log, name
+        if tries == "hook":  # every array group of the finished plan into a fresh allocation
+            for r in sh.ranks:
+                if r["plan"]:
+                    _cabi.check(_cabi.lib().gdn_pr_plan_move(r["plan"], 127))
+        res.append(sh.solve())
+        sh.close()
+    for scores, it2, err in res:
+        assert it2 == it and np.array_equal(scores, res[0][0]) and err == res[0][2]
+    np.testing.assert_allclose(res[0][0], want, rtol=REL_TOL, atol=0)
+
+
+def test_spmv_placement_search_is_bitwise_neutral(orc, monkeypatch, capfd):
+    """The same search in gdn_spmv_plan_create (blocked layout with tiers, forced on a small matrix)."""
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    monkeypatch.setenv("GDN_PLACE_MIN_EDGES", "1")
+    monkeypatch.setenv("GDN_PLACE_MIN_BYTES", "1")
+    monkeypatch.setenv("GDN_SPMV_PLACE_TRACE", "1")
+    g = graphio.rmat_graph(16, 16, seed=47)
+    gi = graphio.transpose(g)
+    rng = np.random.default_rng(47)
+    Ax, x = rng.random(gi.nnz, dtype=np.float32), rng.random(gi.m, dtype=np.float32)
+    y0 = rng.random(gi.m, dtype=np.float32)
+    got = []
+    for tries in ("0", "2"):
+        monkeypatch.setenv("GDN_SPMV_PLACE", tries)
+        capfd.readouterr()
+        sp = solvers.ResidentSpMV(solvers.Graph(csr=g, in_csr=gi), Ax, layout=1)
+        log = capfd.readouterr().err
+        assert ("[spmv place]" in log) == (tries != "0"), log[-400:]
+        got.append(sp.multiply(x, y0))
+        sp.close()
+    assert np.array_equal(got[0], got[1])
+    want = orc.spmv(gi, Ax, x, y0)
+    np.testing.assert_allclose(got[1], want, rtol=REL_TOL, atol=0)
+
+
 @pytest.mark.parametrize("tiers", [False, True])
 def test_pr_squished_vertex_space_is_bitwise_neutral(orc, monkeypatch, tiers):
     """GDN_LAYOUT_PB_SQUISHED: the plan's per-iteration state leaves out the vertices without any edge (they keep the base
