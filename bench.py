@@ -306,7 +306,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "mp_tile_kernel<PrOp>" if be.layout == 0 else
-                     "pb_expand_kernel + pb_accumulate_kernel<PrOp> (one iteration = both)",
+                     "pb_expand_kernel<0> + pb_accumulate_kernel<PrOp, 0> (one iteration = both; <1> = the plan's placement search)",
                      "kernel_ms": k_avg_ms, "launches": klaunches,
                      "kernel_ms_parts": [kA_ms / max(klaunches, 1), kB_ms / max(klaunches, 1)],
                      "algorithmic_bytes_per_launch": iter_bytes},

@@ -818,7 +818,7 @@ static int bc_pb_sweep_fwd(gdn_bc_plan &p, int32_t level) {
   hipLaunchKernelGGL(bc_x_fwd_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, p.depth.p, p.pc.p, m, level, p.x.p);
   const size_t lds_a = sizeof(float) * (pb.chunk_slots + 4);
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
-  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
+  hipLaunchKernelGGL(pb_expand_kernel<0>, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
                      pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p, pb.src_bits.p, pb.chunk_lo.p, 1u, pb.log_group, /*raw*/ 8,
                      nullptr, nullptr, nullptr, 0u, nullptr, pb.errflag.p, pb.chunk_slots);
   BcPcOp op;
@@ -860,7 +860,7 @@ static int bc_pb_sweep_back(gdn_bc_plan &p, int32_t level, float *d_scores, bool
   if (h[1]) return GDN_OK;  // inf / nan among the terms: not for the fixed-point sweep
   const size_t lds_a = sizeof(float) * (pb.chunk_slots + 4);
   const size_t lds_b = sizeof(unsigned long long) << pb.log_bin;
-  hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
+  hipLaunchKernelGGL(pb_expand_kernel<0>, dim3(pb.nchunks), dim3(PB_THREADS), lds_a, 0, p.x.p, pb.m_global, pb.log_chunk, pb.chunk_ptr.p,
                      pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p, pb.src_bits.p, pb.chunk_lo.p, 1u, pb.log_group, 0, nullptr,
                      nullptr, nullptr, 0u, nullptr, pb.errflag.p, pb.chunk_slots);
   BcBackOp op;
@@ -928,7 +928,7 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     p->max_deg = h_md ? h_md : 1;
     const int lds_a = (int)(sizeof(float) * ((p->fwd.chunk_slots > p->back.chunk_slots ? p->fwd.chunk_slots : p->back.chunk_slots) + 4));
     const int lds_b = (int)(sizeof(unsigned long long) << lb);
-    hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+    hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
     if (e == hipSuccess)
       e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<BcPcOp>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_b);
     if (e == hipSuccess)

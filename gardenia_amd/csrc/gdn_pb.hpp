@@ -526,7 +526,8 @@ __device__ __forceinline__ unsigned long long pb_decode(uint32_t enc) {
   return ((unsigned long long)(enc << 8) << 32) >> (enc >> 24);  // mantissa * 2^40 >> (shift + 1)
 }
 
-// phase A: vals[group(G[g]) + i] = x[chunk*CH + U[...]]
+// phase A: vals[group(G[g]) + i] = x[chunk*CH + U[...]]   (TAG: see pb_accumulate_kernel)
+template <int TAG = 0>
 static __global__ void __launch_bounds__(PB_THREADS)
 pb_expand_kernel(const float *__restrict__ x, int32_t m_global, int log_chunk, const eoff_t *__restrict__ chunk_ptr,
                  const uint32_t *__restrict__ chunk_order, const uint16_t *__restrict__ U,
@@ -841,7 +842,9 @@ struct PbTracksLossy<T, decltype((void)T::kTrackLossy)> {
 #define PB_DBG(bits) false
 #endif
 // phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then the fused epilogue of the rows (op).
-template <class Op>
+// TAG: 1 = the launches of a plan's placement search (PbPlacer) -- the same code under another name, so that a profiler's
+// per-kernel statistics of the iterations proper do not average in sweeps timed on allocations that were then dropped
+template <class Op, int TAG = 0>
 __global__ void __launch_bounds__(PB_THREADS)
 pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bin_ptr,
                      const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,

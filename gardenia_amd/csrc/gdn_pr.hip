@@ -20,6 +20,7 @@
 #include "gdn_pb.hpp"
 
 struct gdn_pr_plan {
+  bool placing = false;  // the placement search is running: its sweeps are launched under tagged kernel names
   const unsigned *skip_flag = nullptr;  // device word (gdn_pr's batched loop): non-zero = the pull launches do nothing
   int layout = GDN_LAYOUT_CSR;
   MpPlan mp;  // GDN_LAYOUT_CSR
@@ -807,9 +808,14 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (st == GDN_OK) {
       const int lds_a = (int)(sizeof(float) * (p->pb.chunk_slots + 4) + (p->has_hr ? 8 * p->n_hr : 0));
       const int lds_b = (int)(sizeof(unsigned long long) << p->pb.log_bin);
-      hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+      hipError_t e = hipFuncSetAttribute((const void *)pb_expand_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)pb_expand_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_a);
       if (e == hipSuccess)
         e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<PrOp>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_b);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void *)pb_accumulate_kernel<PrOp, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_b);
       if (e != hipSuccess) {
         gdn_set_error("hipFuncSetAttribute(dynamic LDS %d/%d): %s", lds_a, lds_b, hipGetErrorString(e));
@@ -879,7 +885,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int tries = 3;
     if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
     if (tries > 0) {
-      const int rcp = pr_plan_place(p, tries, 1000.0);
+      const int rcp = pr_plan_place(p, tries, 2500.0);
       if (rcp != GDN_OK) {
         delete p;
         return rcp;
@@ -1127,7 +1133,8 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
       tr.n[tr.ntiers] = plan->mid[t].n;
       tr.slots[tr.ntiers++] = plan->mid[t].n + 4u;
     }
-    hipLaunchKernelGGL(pb_expand_kernel, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
+    auto *const kern_a = plan->placing ? &pb_expand_kernel<1> : &pb_expand_kernel<0>;
+    hipLaunchKernelGGL(kern_a, dim3(pb.nchunks * split), dim3(PB_THREADS), lds_a, s, d_contrib_in, pb.m_global,
                        pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                        pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
@@ -1168,8 +1175,9 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   const bool whole = first && last;
   const unsigned b0 = whole ? 0u : pb_first_bin_at(pb, row_begin);
   const unsigned b1 = whole ? pb.nbins : (last ? pb.nbins : pb_first_bin_at(pb, row_end));
+  auto *const kern_b = plan->placing ? &pb_accumulate_kernel<PrOp, 1> : &pb_accumulate_kernel<PrOp, 0>;
   if (b1 > b0)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<PrOp>), dim3(b1 - b0), dim3(PB_THREADS), lds_b, s, pb.m_local,
+    hipLaunchKernelGGL(kern_b, dim3(b1 - b0), dim3(PB_THREADS), lds_b, s, pb.m_local,
                        pb.log_bin, pb.bin_ptr.p, whole ? pb.bin_order.p : nullptr, pb.V.p, pb.vals.p, pb.partial.p,
                        pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
@@ -1302,13 +1310,18 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
     *out_ms = t.stop_ms() / 3.0;
     return GDN_OK;
   };
-  GDN_TRY(pl.begin());
-  int rc = pl.search(p->pb.vals, "vals", 2);  // the array that matters most (phase A 1.04 .. 1.23 ms)
-  if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
+  p->placing = true;
+  int rc = pl.begin();
+  // cheapest first (a fresh allocation costs ~60 ms per GB in a process that has not touched the memory before): the record
+  // streams (~1 GB each, 0.03-0.1 ms of phase B each), then vals (4.4 GB, up to 0.19 ms of phase A), V, U
   for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) rc = pl.search(p->mid[k].rec, "mid records");
   if (rc == GDN_OK && p->has_hub) rc = pl.search(p->hub_rec, "hub records");
+  if (rc == GDN_OK) rc = pl.search(p->pb.vals, "vals", 2);
+  if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
   if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
   pl.end();
+  p->placing = false;
+  if (rc != GDN_OK) return rc;
   unsigned zero = 0;  // the scratch iterations must not leave a range flag behind
   GDN_HIP(hipMemcpy(p->pb.errflag.p, &zero, sizeof(zero), hipMemcpyHostToDevice));
   return rc;

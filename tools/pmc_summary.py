@@ -41,25 +41,33 @@ with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extras  (RMAT-27, PB layout)\n\n")
     f.write("Session (one box, tools/profile_%s.sh)" % tag.split("_")[0] + ": %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n\n" % (session, tag))
     f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
-    for r in rows[:18]:
+    for r in rows[:22]:
         f.write(f"| `{r['Name'].split('(')[0][:80]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | "
                 f"{float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |\n")
 fetch = counters(SRC + "/fetch/*/*_counter_collection.csv")
 write = counters(SRC + "/write/*/*_counter_collection.csv")
 kern = {}
 total = 0.0
-for k in ("pb_expand_kernel", "void pb_accumulate_kernel<PrOp>"):
-    fk = sum(fetch[k]) / len(fetch[k]) * 1024.0
-    wk = sum(write[k]) / len(write[k]) * 1024.0
+def pick(agg, name):
+    """the iterations proper: the TAG 0 instantiation (TAG 1 = the sweeps of the plan's placement search, gdn_pb.hpp)"""
+    ks = [k for k in agg if name in k]
+    assert len(ks) == 1, (name, list(agg))
+    return agg[ks[0]]
+
+
+for k, name in (("pb_expand_kernel<0>", "pb_expand_kernel<0>"), ("pb_accumulate_kernel<PrOp, 0>", "pb_accumulate_kernel<PrOp, 0>")):
+    fk = sum(pick(fetch, name)) / len(pick(fetch, name)) * 1024.0
+    wk = sum(pick(write, name)) / len(pick(write, name)) * 1024.0
     kern[k] = {"FETCH_SIZE_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "WRITE_SIZE_bytes": wk,
-               "hbm_bytes": 2 * fk + wk, "dispatches": len(fetch[k])}
+               "hbm_bytes": 2 * fk + wk, "dispatches": len(pick(fetch, name))}
     total += 2 * fk + wk
 bench = json.load(open(os.path.join(ROOT, SRC, "bench_under_rocprof.json")))
 plain = json.load(open(os.path.join(ROOT, SRC, "bench.json")))
 res = {"scale": 27, "n_gpus": 1, "session": session, "layout": bench["config"]["layout"], "hbm_bytes_per_launch": total,
        "unprofiled_same_session": {"ms_per_step": plain["ms_per_step"], "kernel_ms": plain["roofline"]["kernel_ms"],
                                    "frac": plain["roofline"]["frac"], "step_ms": plain.get("step_ms")},
-       "note": "one launch = one PageRank iteration = pb_expand_kernel + pb_accumulate_kernel<PrOp>; "
+       "note": "one launch = one PageRank iteration = pb_expand_kernel<0> + pb_accumulate_kernel<PrOp, 0> (the <1> / <PrOp, 1> "
+               "rows of the kernel statistics are the sweeps of the plan's placement search, not iterations); "
                "FETCH_SIZE (KB) doubled per MI355X_MICROARCH.md, WRITE_SIZE (KB) as is; separate --pmc passes",
        "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"], "kernels": kern,
        "kernel_ms_under_rocprof": bench["roofline"]["kernel_ms"]}
