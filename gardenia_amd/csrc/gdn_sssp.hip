@@ -1278,7 +1278,9 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
     // would cost more than the partial lines
     const double avg_tile = (double)g->nnz / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lg) + 1));
-    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 512.0 ? 64u : 32u;
+    // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
+    // profiles/r03_sssp_layout_knobs.txt)
+    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
     if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
     GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
                      /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3));
