@@ -1111,10 +1111,7 @@ struct gdn_bfs_plan {
   DevBuf<unsigned> coop_bar;    // its grid barrier (gdn_grid_barrier, gdn_common.hpp)
   int coop_blocks = 0;          // 0: cooperative launches unavailable
   DevBuf<BfsSmallOut> small_out;
-  BfsCounters *h_cnt = nullptr;  // pinned host copy of the level counters (one 32-byte read back per level)
-  ~gdn_bfs_plan() {
-    if (h_cnt) (void)hipHostFree(h_cnt);
-  }
+  GdnMailbox mail;  // the per-level read back of the counters (gdn_common.hpp)
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
@@ -1151,17 +1148,8 @@ bfs_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned lon
   if (gdn_lane() == 0 && n) atomicAdd(out, n);
 }
 
-// the per-level read back of the counters: into pinned memory (no staging copy in the runtime), then one stream sync
-static int bfs_read_counters(gdn_bfs_plan &p, BfsCounters &h) {
-  if (!p.h_cnt) {
-    GDN_HIP(hipMemcpy(&h, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost));
-    return GDN_OK;
-  }
-  GDN_HIP(hipMemcpyAsync(p.h_cnt, p.cnt.p, sizeof(h), hipMemcpyDeviceToHost, 0));
-  GDN_HIP(hipStreamSynchronize(0));
-  h = *p.h_cnt;
-  return GDN_OK;
-}
+// the per-level read back of the counters
+static int bfs_read_counters(gdn_bfs_plan &p, BfsCounters &h) { return p.mail.read(p.cnt.p, h); }
 
 static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *gin, bool dense) {
   HostTimer t;
@@ -1239,7 +1227,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     }
     (void)hipGetLastError();
   }
-  if (hipHostMalloc((void **)&p.h_cnt, sizeof(BfsCounters) > 64 ? sizeof(BfsCounters) : 64 /* BfsCounters or BfsSmallOut */, hipHostMallocDefault) != hipSuccess) p.h_cnt = nullptr;
+  p.mail.init();
   if (gin) {
     GDN_TRY(p.front.alloc(p.nwords_pad));
     GDN_TRY(p.next.alloc(p.nwords_pad));
@@ -1529,13 +1517,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                            p.q0.p, p.q1.p, qin == p.q1.p ? 1u : 0u, nf, p.qcap, level, (unsigned long long)scout_count, small_nf,
                            small_scout, 1u << 30, p.small_out.p);
         BfsSmallOut so;
-        if (p.h_cnt) {  // pinned staging (sizeof(BfsSmallOut) <= the pinned block)
-          GDN_HIP(hipMemcpyAsync(p.h_cnt, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost, 0));
-          GDN_HIP(hipStreamSynchronize(0));
-          memcpy(&so, p.h_cnt, sizeof(so));
-        } else {
-          GDN_HIP(hipMemcpy(&so, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost));
-        }
+        GDN_TRY(p.mail.read(p.small_out.p, so));
         if (so.overflow) {
           gdn_set_error("gdn_bfs: device worklist overflow");
           return GDN_ERR_OVERFLOW;
@@ -1573,13 +1555,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         GDN_HIP(hipLaunchCooperativeKernel((const void *)bfs_td_coop_kernel, dim3((unsigned)p.coop_blocks), dim3(BFS_COOP_THREADS), args,
                                            0, 0));
         BfsSmallOut so;
-        if (p.h_cnt) {
-          GDN_HIP(hipMemcpyAsync(p.h_cnt, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost, 0));
-          GDN_HIP(hipStreamSynchronize(0));
-          memcpy(&so, p.h_cnt, sizeof(so));
-        } else {
-          GDN_HIP(hipMemcpy(&so, p.small_out.p, sizeof(so), hipMemcpyDeviceToHost));
-        }
+        GDN_TRY(p.mail.read(p.small_out.p, so));
         if (so.overflow) {
           gdn_set_error("gdn_bfs: device worklist overflow");
           return GDN_ERR_OVERFLOW;

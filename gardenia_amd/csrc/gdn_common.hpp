@@ -6,6 +6,7 @@
 // src/tc/gpu_base.cu:22) and the Worklist2 push (include/worklistc.h:66-113).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -215,6 +216,83 @@ struct DevBuf {
     o.p = nullptr;
     o.base = nullptr;
     o.n = 0;
+  }
+};
+
+// ---- GdnMailbox: a small device struct read back by the host WITHOUT a stream synchronisation.  A level-synchronous
+// solver reads a few counters per level; hipMemcpyAsync + hipStreamSynchronize costs 16-18 us of idle GPU per level
+// (rocprofv3 --kernel-trace of a search, profiles/r03_bfs_bottom_up.txt).  Here a one-wave kernel, queued behind the level's
+// kernels, copies the struct into pinned host memory and then publishes a sequence number with system scope; the host spins
+// on the number.  GDN_MAILBOX=0 (or no pinned memory) falls back to the copy; a spin of more than two seconds falls back to
+// the synchronisation too, which then reports what went wrong.
+static __global__ void gdn_mailbox_kernel(const unsigned *__restrict__ src, unsigned nwords, unsigned *dst, unsigned seq) {
+  for (unsigned i = threadIdx.x; i < nwords; i += 64) __hip_atomic_store(dst + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+struct GdnMailbox {
+  static constexpr size_t kPayload = 1024;  // bytes
+  unsigned *host = nullptr;  // pinned: [0] sequence number, [1 ..] payload
+  unsigned *dev = nullptr;   // the same memory as the device sees it
+  unsigned seq = 0;
+  bool spin = true;
+  ~GdnMailbox() {
+    if (host) (void)hipHostFree(host);
+  }
+  void init() {
+    if (host) return;
+    const char *e = gdn_option("GDN_MAILBOX");
+    spin = !(e && e[0] == '0');
+    void *h = nullptr;
+    if (hipHostMalloc(&h, kPayload + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+      (void)hipGetLastError();
+      return;
+    }
+    void *d = nullptr;
+    if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      (void)hipHostFree(h);
+      return;
+    }
+    host = static_cast<unsigned *>(h);
+    dev = static_cast<unsigned *>(d);
+    host[0] = 0;
+  }
+  template <typename T>
+  int read(const T *d_src, T &out, hipStream_t s = 0) {
+    static_assert(sizeof(T) <= kPayload && sizeof(T) % 4 == 0, "mailbox payload");
+    if (!host) {
+      GDN_HIP(hipMemcpy(&out, d_src, sizeof(T), hipMemcpyDeviceToHost));
+      return GDN_OK;
+    }
+    if (!spin) {
+      GDN_HIP(hipMemcpyAsync(host + 1, d_src, sizeof(T), hipMemcpyDeviceToHost, s));
+      GDN_HIP(hipStreamSynchronize(s));
+      memcpy(&out, host + 1, sizeof(T));
+      return GDN_OK;
+    }
+    ++seq;
+    if (seq == 0) ++seq;
+    hipLaunchKernelGGL(gdn_mailbox_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned *>(d_src),
+                       (unsigned)(sizeof(T) / 4), dev, seq);
+    GDN_HIP(hipGetLastError());
+    const volatile unsigned *flag = host;
+    unsigned long long spins = 0;
+    auto t0 = std::chrono::steady_clock::now();
+    while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+      if ((++spins & 0xFFFFu) == 0 &&
+          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {
+        GDN_HIP(hipStreamSynchronize(s));  // reports a failed kernel; else the number is there now
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+          gdn_set_error("mailbox: the sequence number never arrived");
+          return GDN_ERR_HIP;
+        }
+        break;
+      }
+    }
+    memcpy(&out, const_cast<const unsigned *>(host + 1), sizeof(T));
+    return GDN_OK;
   }
 };
 

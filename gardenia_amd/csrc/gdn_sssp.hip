@@ -1227,10 +1227,7 @@ struct gdn_sssp_plan {
   DevBuf<SsspCoopCnt> coop_cnt;  // 3 rotating counter sets of sssp_coop_kernel
   DevBuf<unsigned> coop_bar;     // its grid barrier
   int coop_blocks = 0;           // 0: no cooperative launches
-  void *h_pin = nullptr;   // pinned staging for the counter read-backs
-  ~gdn_sssp_plan() {
-    if (h_pin) (void)hipHostFree(h_pin);
-  }
+  GdnMailbox mail;               // the per-phase read back of the counters
   DevBuf<vid_t> near0, near1, far0, far1;
   DevBuf<int32_t> stamp;
   DevBuf<unsigned> in_far;
@@ -1269,7 +1266,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     }
     (void)hipGetLastError();
   }
-  if (hipHostMalloc(&p.h_pin, 1024, hipHostMallocDefault) != hipSuccess) p.h_pin = nullptr;  // falls back to pageable copies
+  p.mail.init();
   if (dense && g->nnz > 0) {
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
@@ -1379,16 +1376,22 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
 }
 
 // blocking read of a small device struct through the plan's pinned block (a pageable hipMemcpy costs ~2x the latency)
+// a small host struct into device memory as the ARGUMENT of a one-wave kernel: hipMemcpyAsync from pageable memory is
+// staged through the runtime (a host-side copy and a DMA packet per phase), a kernel argument rides in the dispatch packet
+template <typename T>
+__global__ void sssp_put_kernel(T *dst, const T v) {
+  const unsigned *src = reinterpret_cast<const unsigned *>(&v);
+  for (unsigned i = threadIdx.x; i < sizeof(T) / 4; i += 64) reinterpret_cast<unsigned *>(dst)[i] = src[i];
+}
+template <typename T>
+static void sssp_put(T *d_dst, const T &v) {
+  static_assert(sizeof(T) % 4 == 0 && sizeof(T) <= 2048, "kernel-argument copy");
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_put_kernel<T>), dim3(1), dim3(64), 0, 0, d_dst, v);
+}
+
 template <typename T>
 static int sssp_read(gdn_sssp_plan &p, const T *d_src, T &out) {
-  if (p.h_pin && sizeof(T) <= 1024) {
-    GDN_HIP(hipMemcpyAsync(p.h_pin, d_src, sizeof(T), hipMemcpyDeviceToHost, 0));
-    GDN_HIP(hipStreamSynchronize(0));
-    memcpy(&out, p.h_pin, sizeof(T));
-  } else {
-    GDN_HIP(hipMemcpy(&out, d_src, sizeof(T), hipMemcpyDeviceToHost));
-  }
-  return GDN_OK;
+  return p.mail.read(d_src, out);  // (GdnMailbox, gdn_common.hpp: no stream synchronisation per phase)
 }
 
 template <typename CT>
@@ -1496,7 +1499,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         ss.pass = pass;
         ss.near_sel = near_in == p.near1.p ? 1u : 0u;
         ss.far_sel = far_cur == p.far1.p ? 1u : 0u;
-        GDN_HIP(hipMemcpyAsync(p.small.p, &ss, sizeof(ss), hipMemcpyHostToDevice, 0));
+        sssp_put(p.small.p, ss);
         hipLaunchKernelGGL(sssp_small_kernel, dim3(1), dim3(SSSP_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, d_weight, d_dist,
                            p.stamp.p, p.in_far.p, p.near0.p, p.near1.p, p.far0.p, p.far1.p, cap, delta, small_v, small_e,
                            small_far, p.small.p);
@@ -1541,7 +1544,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       SsspCoopCnt init[3];
       memset(init, 0, sizeof(init));
       for (int k = 0; k < 3; k++) init[k].min_far = GDN_DIST_INF;
-      GDN_HIP(hipMemcpyAsync(p.small.p, &ss, sizeof(ss), hipMemcpyHostToDevice, 0));
+      sssp_put(p.small.p, ss);
       GDN_HIP(hipMemcpyAsync(p.coop_cnt.p, init, sizeof(init), hipMemcpyHostToDevice, 0));
       GDN_HIP(hipMemsetAsync(p.coop_bar.p, 0, GDN_GBAR_WORDS * sizeof(unsigned), 0));
       const eoff_t *a_rowptr = g->rowptr;
@@ -1604,7 +1607,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
           ++phases;
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
-          GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+          sssp_put(p.cnt.p, h);
           bool binned = use_bins && have_queue && n_q > 0 && imp_edges * SSSP_BIN_FRAC <= (unsigned long long)g->nnz;
           int cbits = 0;
           if (binned) {
@@ -1633,7 +1636,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
               binned = false;
               memset(&h, 0, sizeof(h));
               h.min_far = GDN_DIST_INF;
-              GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+              sssp_put(p.cnt.p, h);
             } else {
               relaxed_total += imp_edges;
               vid_t *t = near_in;
@@ -1686,7 +1689,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
             // the next step is a binned pass: it needs the improved rows as a list
             memset(&h, 0, sizeof(h));
             h.min_far = GDN_DIST_INF;
-            GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+            sssp_put(p.cnt.p, h);
             hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p, p.nwords, m, near_in,
                                p.cnt.p, cap, g->rowptr);
             GDN_TRY(sssp_read(p, p.cnt.p, h));
@@ -1706,7 +1709,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         } else {
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
-          GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+          sssp_put(p.cnt.p, h);
           hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p,
                              p.nwords, m, near_in, p.cnt.p, cap, g->rowptr);
           GDN_TRY(sssp_read(p, p.cnt.p, h));
@@ -1734,7 +1737,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       h.min_far = GDN_DIST_INF;
       h.max_dist = 0;
       h.relaxed = 0;
-      GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+      sssp_put(p.cnt.p, h);
       SsspVis vis;
       vis.rowptr = g->rowptr;
       vis.near_edges = 0;
@@ -1793,7 +1796,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
     h.min_far = GDN_DIST_INF;
     h.max_dist = 0;
     h.relaxed = 0;
-    GDN_HIP(hipMemcpyAsync(p.cnt.p, &h, sizeof(h), hipMemcpyHostToDevice, 0));
+    sssp_put(p.cnt.p, h);
     hipLaunchKernelGGL(sssp_far_min_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
                        far_cur, n_far, d_dist,
                        clamp(thr_hi), p.cnt.p);
