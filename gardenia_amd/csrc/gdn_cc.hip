@@ -117,14 +117,49 @@ __device__ __forceinline__ void cc_link(int32_t u, int32_t v, int32_t *comp) {  
   }
 }
 
+// cc_link for every lane of a wave at once (has = this lane holds an edge).  Once trees are few and large (R-MAT after the
+// first sampling round: stars around the lowest ids) the links that still join two of them are the SAME (root, root) pair in
+// thousands of lanes at a time -- every one a compare-and-swap on one address, served one after the other (RMAT-24: sampling
+// round 1 took 1.16 ms against round 0's 0.25).  One lane per distinct pair of a wave issues it; the others find the link made
+// when they walk cc_link's loop afterwards.  Labels do not depend on who wins a link (the final labels are the minimum ids).
+__device__ __forceinline__ void cc_link_wave(bool has, int32_t u, int32_t w, int32_t *comp) {
+  int32_t p1 = 0, p2 = 0;
+  if (has) {
+    p1 = cc_ld(comp + u);
+    p2 = cc_ld(comp + w);
+  }
+  const bool need = has && p1 != p2;
+  const int32_t high = p1 > p2 ? p1 : p2, low = p1 + (p2 - high);
+  const bool want = need && cc_ld(comp + high) == high;
+  unsigned long long wm = __ballot(want);
+  const unsigned lane = gdn_lane();
+  while (wm) {
+    const int leader = __ffsll((long long)wm) - 1;
+    const int32_t h = __shfl(high, leader, 64), l = __shfl(low, leader, 64);
+    const unsigned long long grp = __ballot(want && high == h && low == l);
+    if (lane == (unsigned)leader) atomicCAS(comp + h, h, l);
+    wm &= ~grp;
+  }
+  if (need) cc_link(u, w, comp);
+}
+
 // sampling round r: link v with its r-th out-neighbour (omp_afforest.cc:40-46)
 __global__ void __launch_bounds__(GDN_BLOCK)
 cc_sample_link_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int r,
-                      int32_t *__restrict__ comp) {
-  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (v >= (unsigned)m) return;
-  const eoff_t b = rowptr[v], e = rowptr[v + 1];
-  if (b + (eoff_t)r < e) cc_link((int32_t)v, colidx[b + r], comp);
+                      int32_t *__restrict__ comp, unsigned v0 = 0) {
+  const unsigned v = v0 + blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+  }
+  const bool has = b + (eoff_t)r < e;
+  const int32_t w = has ? colidx[b + r] : 0;
+  if (r == 0) {
+    if (has) cc_link((int32_t)v, w, comp);
+    return;
+  }
+  cc_link_wave(has, (int32_t)v, w, comp);
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -145,7 +180,7 @@ struct CcLinkVis {
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
     const int32_t src = __shfl(v, owner, 64);
-    if (valid) cc_link(src, colidx[k], comp);
+    cc_link_wave(valid, src, valid ? colidx[k] : 0, comp);
   }
 };
 
@@ -268,7 +303,20 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   hipLaunchKernelGGL(cc_init_kernel, grid_m, blk, 0, 0, d_comp, m);
   const int neighbor_rounds = 2;  // omp_afforest.cc:37
   for (int r = 0; r < neighbor_rounds; r++) {
-    hipLaunchKernelGGL(cc_sample_link_kernel, grid_m, blk, 0, 0, g->rowptr, g->colidx, m, r, d_comp);
+    // rounds after the first in two launches: a small head of the vertex range joins the few large trees round 0 left
+    // (their roots are what thousands of waves would otherwise compare-and-swap at the same time, see cc_link_wave); the
+    // rest then finds them joined.  RMAT-24, the whole solve: 1.48 -> 1.02 ms with a head of 2^10 .. 2^14 vertices (2^18: 1.19, 2^20: 1.48)
+    unsigned head = 0;
+    if (r > 0 && (unsigned)m > (1u << 18)) {
+      head = 1u << 14;
+      if (const char *e = gdn_option("GDN_CC_HEAD")) head = (unsigned)atoi(e) & ~(unsigned)(GDN_BLOCK - 1);  // tuning knob
+    }
+    if (head) {
+      hipLaunchKernelGGL(cc_sample_link_kernel, dim3(head / GDN_BLOCK), blk, 0, 0, g->rowptr, g->colidx, (int32_t)head, r, d_comp, 0u);
+      hipLaunchKernelGGL(cc_sample_link_kernel, dim3(gdn_nblocks((uint64_t)m - head)), blk, 0, 0, g->rowptr, g->colidx, m, r, d_comp, head);
+    } else {
+      hipLaunchKernelGGL(cc_sample_link_kernel, grid_m, blk, 0, 0, g->rowptr, g->colidx, m, r, d_comp, 0u);
+    }
     hipLaunchKernelGGL(cc_shortcut_kernel, grid_m, blk, 0, 0, d_comp, m);
   }
   // most frequent label of the sample = the giant intermediate component
