@@ -554,9 +554,8 @@ bc_max_kernel(const float *__restrict__ scores, int32_t m, unsigned *__restrict_
   float mx = 0.0f;
   for (size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (size_t)m; i += (size_t)gridDim.x * GDN_BLOCK)
     mx = fmaxf(mx, scores[i]);  // max(biggest, score) with biggest starting at 0 (src/bc/omp_base.cc:96-99)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (gdn_lane() == 0 && mx > 0.0f) atomicMax(out, __float_as_uint(mx));
+  // (non-negative floats order like their bits; one atomic per workgroup -- per wave, 8192 of them on one word took 0.1 ms)
+  gdn_block_max_u32(mx > 0.0f ? __float_as_uint(mx) : 0u, out);
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -728,9 +727,7 @@ bc_w_max_kernel(const bc_i32x4 *__restrict__ rec, int32_t m, int32_t next_level,
       if (w > mx && w < 3.0e38f) mx = w;  // inf / nan (a wrapped path count of 0) do not take part in the sweep
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  if (gdn_lane() == 0 && mx > 0.0f) atomicMax(out, __float_as_uint(mx));
+  gdn_block_max_u32(mx > 0.0f ? __float_as_uint(mx) : 0u, out);
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)

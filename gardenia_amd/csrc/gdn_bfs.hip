@@ -62,10 +62,11 @@ struct BfsTdVis {
     }
     gdn_wl_push_staged(stage, outq, &cnt->next_count, cap, claim, dst, &cnt->overflow);
   }
-  __device__ __forceinline__ void finish() {
-    gdn_wl_flush(stage, outq, &cnt->next_count, cap, &cnt->overflow);
-    const unsigned long long s = gdn_wave_sum(scout_local);
-    if (gdn_lane() == 0 && s) atomicAdd(&cnt->scout, s);
+  // by the whole workgroup at the end of the kernel: one queue reservation and one counter add per WORKGROUP (per wave, the
+  // 8192 waves of the big-row kernel put 16 K atomics on two addresses behind a level that discovers 3 M vertices)
+  __device__ __forceinline__ void finish(unsigned *s_tmp, unsigned long long *s_tmp64) {
+    gdn_wl_flush_block(stage, outq, &cnt->next_count, cap, &cnt->overflow, s_tmp);
+    gdn_block_add_u64(scout_local, &cnt->scout, s_tmp64);
   }
 };
 
@@ -86,17 +87,21 @@ bfs_td_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ inq, 
   vis.stage.strip = s_stage[threadIdx.x >> 6];
   vis.stage.n = 0;
   gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
-  vis.finish();
+  __shared__ unsigned s_tmp[GDN_WAVES_PER_BLOCK + 1];
+  __shared__ unsigned long long s_tmp64[GDN_WAVES_PER_BLOCK];
+  vis.finish(s_tmp, s_tmp64);
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_td_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsTdVis vis) {
   __shared__ vid_t s_stage[GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
+  __shared__ unsigned s_tmp[GDN_WAVES_PER_BLOCK + 1];
+  __shared__ unsigned long long s_tmp64[GDN_WAVES_PER_BLOCK];
   vis.stage.strip = s_stage[threadIdx.x >> 6];
   vis.stage.n = 0;
   vis.scout_local = 0;
   gdn_expand_big_items(rowptr, big, vis);
-  vis.finish();
+  vis.finish(s_tmp, s_tmp64);
 }
 
 // ---- fused light levels (the "fusion" variant of the reference, src/bfs/fusion.cu, without its grid barrier): ONE
@@ -378,7 +383,8 @@ bfs_hub_front_kernel(const vid_t *__restrict__ hub_id, const unsigned *__restric
   if ((gdn_lane() & 31u) == 0) hub_front[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
   // word BFS_HUBS / 32 (zeroed by the host before): how many hubs the frontier holds -- the bottom-up step reads the
   // heads only when that is worth 4 bytes per open row
-  if (gdn_lane() == 0 && mask) atomicAdd(&hub_front[BFS_HUBS / 32], (unsigned)__popcll(mask));
+  __shared__ unsigned long long s_cnt[GDN_WAVES_PER_BLOCK];
+  gdn_block_add_u64(in ? 1ull : 0ull, reinterpret_cast<unsigned long long *>(hub_front + BFS_HUBS / 32), s_cnt);
 }
 
 // Bottom-up step (omp_beamer.cc:13-31): a row not yet visited is discovered if one of its in-neighbours is in the frontier.
@@ -1249,7 +1255,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_TRY(hub_idx.alloc((size_t)m));
       GDN_TRY(p.hub_id.alloc(BFS_HUBS));
       GDN_TRY(p.head.alloc((size_t)m));
-      GDN_TRY(p.hub_front.alloc(BFS_HUBS / 32 + 1));  // + the count of hubs in the frontier
+      GDN_TRY(p.hub_front.alloc(BFS_HUBS / 32 + 2));  // + the count of hubs in the frontier (64 bits)
       hipLaunchKernelGGL(bfs_hub_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, ka.p);
       GDN_HIP(hipGetLastError());
       const unsigned long long *sorted = nullptr;
@@ -1433,7 +1439,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         if (btd) {
         } else if (bottom_up) {
           if (p.head.p) {
-            GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, sizeof(unsigned), 0));
+            GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, 2 * sizeof(unsigned), 0));
             hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(BFS_HUBS / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p);
           }
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,

@@ -533,6 +533,61 @@ __device__ __forceinline__ void gdn_wl_flush(GdnWlStage &st, vid_t *queue, unsig
   st.n = 0;
 }
 
+// The LAST flush of a kernel, by the whole workgroup (every thread calls it at the end, after its pushes): the strips of the
+// workgroup's waves go out behind ONE reservation.  A persistent grid of 2048 workgroups otherwise ends with 8192 partial
+// flushes on one counter (~12-25 ns each, one after the other: 0.1-0.2 ms whatever the kernel did before).
+// s_tmp: GDN_WAVES_PER_BLOCK + 1 unsigned of LDS.
+__device__ __forceinline__ void gdn_wl_flush_block(GdnWlStage &st, vid_t *queue, unsigned *count, unsigned capacity,
+                                                   unsigned *overflow, unsigned *s_tmp) {
+  const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
+  __syncthreads();  // (s_tmp may have held something else; the strips are complete)
+  if (lane == 0) s_tmp[w] = st.n;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned total = 0;
+    for (unsigned i = 0; i < GDN_WAVES_PER_BLOCK; i++) total += s_tmp[i];
+    s_tmp[GDN_WAVES_PER_BLOCK] = total ? atomicAdd(count, total) : 0u;
+  }
+  __syncthreads();
+  unsigned base = s_tmp[GDN_WAVES_PER_BLOCK];
+  for (unsigned i = 0; i < w; i++) base += s_tmp[i];
+  for (unsigned i = lane; i < st.n; i += 64) {
+    if (base + i < capacity) queue[base + i] = st.strip[i];
+    else *overflow = 1u;
+  }
+  st.n = 0;
+  __syncthreads();
+}
+
+// sum of a per-thread value over the workgroup, added to a global counter by ONE thread (s_tmp: GDN_WAVES_PER_BLOCK u64)
+__device__ __forceinline__ void gdn_block_add_u64(unsigned long long v, unsigned long long *counter, unsigned long long *s_tmp) {
+  v = gdn_wave_sum(v);
+  __syncthreads();
+  if (gdn_lane() == 0) s_tmp[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (unsigned i = 0; i < GDN_WAVES_PER_BLOCK; i++) t += s_tmp[i];
+    if (t) atomicAdd(counter, t);
+  }
+}
+
+// maximum of a per-thread unsigned over the workgroup, atomicMax-ed into a global word by ONE thread
+__device__ __forceinline__ void gdn_block_max_u32(unsigned v, unsigned *out) {
+  __shared__ unsigned s_mx[GDN_WAVES_PER_BLOCK];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)v, o, 64);
+    v = t > v ? t : v;
+  }
+  if (gdn_lane() == 0) s_mx[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (unsigned i = 1; i < GDN_WAVES_PER_BLOCK; i++) v = s_mx[i] > v ? s_mx[i] : v;
+    if (v) atomicMax(out, v);
+  }
+}
+
 // must be called by every active lane of the wave (convergent), like gdn_wl_push
 __device__ __forceinline__ void gdn_wl_push_staged(GdnWlStage &st, vid_t *queue, unsigned *count, unsigned capacity,
                                                    bool pred, vid_t item, unsigned *overflow) {

@@ -79,11 +79,12 @@ struct SsspVis {
     gdn_wl_push_staged(near_st, near_out, &cnt->near_count, cap, push_near, dst, &cnt->overflow);
     gdn_wl_push_staged(far_st, far_out, &cnt->far_count, cap, push_far, dst, &cnt->overflow);
   }
-  __device__ __forceinline__ void finish() {
-    gdn_wl_flush(near_st, near_out, &cnt->near_count, cap, &cnt->overflow);
-    gdn_wl_flush(far_st, far_out, &cnt->far_count, cap, &cnt->overflow);
-    const unsigned long long s = gdn_wave_sum(near_edges);
-    if (gdn_lane() == 0 && s) atomicAdd(&cnt->relaxed, s);
+  // by the whole workgroup at the end of the kernel: one reservation per list and one add per counter and WORKGROUP (per
+  // wave, a pass over 1.2 M rows put 19 K atomics on each of three addresses: 0.28 ms of its 0.34)
+  __device__ __forceinline__ void finish(unsigned *s_tmp, unsigned long long *s_tmp64) {
+    gdn_wl_flush_block(near_st, near_out, &cnt->near_count, cap, &cnt->overflow, s_tmp);
+    gdn_wl_flush_block(far_st, far_out, &cnt->far_count, cap, &cnt->overflow, s_tmp);
+    gdn_block_add_u64(near_edges, &cnt->relaxed, s_tmp64);
     int32_t mx = max_d;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -95,6 +96,7 @@ struct SsspVis {
   }
 };
 
+#define SSSP_RELAX_GRID 2048u  // 8 workgroups per CU: every wave slot taken, and at most 2048 closing reservations per list
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ near_in, unsigned n,
                   int32_t thr_lo, ExpBigList big, SsspVis vis) {
@@ -104,22 +106,27 @@ sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ n
   vis.far_st.strip = s_stage[1][threadIdx.x >> 6];
   vis.near_st.n = vis.far_st.n = 0;
   vis.max_d = 0;
-  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  eoff_t b = 0, e = 0;
-  vid_t v = 0;
-  vis.du = 0;
-  if (i < n) {
-    v = near_in[i];
-    vis.du = vis.dist[v];
-    // omp_base.cc:40: entries whose distance fell below the bucket were settled earlier
-    if (vis.du >= thr_lo) {
-      b = rowptr[v];
-      e = rowptr[v + 1];
-    }
-  }
+  __shared__ unsigned s_tmp[GDN_WAVES_PER_BLOCK + 1];
+  __shared__ unsigned long long s_tmp64[GDN_WAVES_PER_BLOCK];
   vis.near_edges = 0;
-  gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
-  vis.finish();
+  // persistent grid (<= SSSP_RELAX_GRID workgroups): the strips fill across the batches of a workgroup
+  for (unsigned i0 = blockIdx.x * GDN_BLOCK; i0 < n; i0 += gridDim.x * GDN_BLOCK) {  // block-uniform trip count
+    const unsigned i = i0 + threadIdx.x;
+    eoff_t b = 0, e = 0;
+    vid_t v = 0;
+    vis.du = 0;
+    if (i < n) {
+      v = near_in[i];
+      vis.du = vis.dist[v];
+      // omp_base.cc:40: entries whose distance fell below the bucket were settled earlier
+      if (vis.du >= thr_lo) {
+        b = rowptr[v];
+        e = rowptr[v + 1];
+      }
+    }
+    gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
+  }
+  vis.finish(s_tmp, s_tmp64);
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -131,8 +138,10 @@ sssp_relax_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, SsspVis
   vis.du = 0;
   vis.max_d = 0;
   vis.near_edges = 0;
+  __shared__ unsigned s_tmp[GDN_WAVES_PER_BLOCK + 1];
+  __shared__ unsigned long long s_tmp64[GDN_WAVES_PER_BLOCK];
   gdn_expand_big_items(rowptr, big, vis);
-  vis.finish();
+  vis.finish(s_tmp, s_tmp64);
 }
 
 // smallest distance parked in FAR that is still >= thr_hi (stale entries are ignored)
@@ -1762,7 +1771,8 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       big.min_deg = ((uint64_t)n_near < 65536u && (uint64_t)n_near + near_edges / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
                         ? 64u : (unsigned)EXP_BIG;  // (on a 228 K-vertex list the item detour cost 0.42 ms instead of 0.28)
       if (const char *e = gdn_option("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
-      hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near)), dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
+      hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near) < SSSP_RELAX_GRID ? gdn_nblocks(n_near) : SSSP_RELAX_GRID),
+                         dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
                          n_near, clamp(thr_lo), big, vis);
       hipLaunchKernelGGL(sssp_relax_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
       GDN_TRY(sssp_read(p, p.cnt.p, h));
