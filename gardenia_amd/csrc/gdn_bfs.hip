@@ -1244,7 +1244,9 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     // hub heads: from 2^24 edges on (below, a level is a few hundred microseconds and the plan build should stay short);
     // GDN_BFS_HUB_HEADS=0 switches them off (A/B)
     const char *hh = gdn_option("GDN_BFS_HUB_HEADS");
-    if (dense && g->nnz >= (1ull << 24) && (unsigned)m >= 4u * BFS_HUBS && !(hh && hh[0] == '0')) {
+    unsigned long long heads_from = 1ull << 24;
+    if (const char *e = gdn_option("GDN_BFS_HEADS_MIN_NNZ")) heads_from = strtoull(e, nullptr, 10);  // (tests)
+    if (dense && g->nnz >= heads_from && (unsigned)m >= 4u * BFS_HUBS && !(hh && hh[0] == '0')) {
       HostTimer th;
       GDN_HIP(hipDeviceSynchronize());
       th.start();

@@ -61,6 +61,36 @@ def test_bfs_resident_dense_levels(orc, scale, ef, seed):
     bfs.close()
 
 
+@pytest.mark.parametrize("scale,ef,seed,hub_min", [(19, 16, 8, None), (19, 48, 9, "0"), (20, 8, 10, "100000")])
+def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed, hub_min):
+    """The bottom-up step's HEAD records (bfs_hub_head_kernel: every row's in-neighbour of highest out-degree, as a hub index
+    tested against LDS bits or as a vertex id tested against the frontier bitmap, + the row's out-degree) exist from 2^24
+    edges on; forced here at sizes the serial oracle walks, with the hub test always on / gated off / at its default: depths
+    and the traversed-edge count equal the oracle's from hub, leaf and late sources, and the trace shows the heads at work."""
+    monkeypatch.setenv("GDN_BFS_HEADS_MIN_NNZ", "1")
+    monkeypatch.setenv("GDN_BFS_TRACE", "1")
+    if hub_min is not None:
+        monkeypatch.setenv("GDN_BFS_HUB_MIN", hub_min)
+    g = graphio.rmat_graph(scale, ef, seed=seed)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    capfd.readouterr()
+    bfs = solvers.ResidentBFS(G, dense=True)
+    assert "heads of the bottom-up step" in capfd.readouterr().err
+    deg = g.degrees()
+    sources = [graphio.first_nonisolated(g), int(np.argmax(deg)), int(np.nonzero(deg)[0][-1]), int(np.nonzero(deg == 1)[0][0])]
+    by_head = 0
+    for s in sources:
+        dist, st = bfs.run(s)
+        log = capfd.readouterr().err
+        import re
+        by_head += sum(int(x) for x in re.findall(r"(\d+) rows by their hub head", log))
+        want = orc.bfs_serial(g, s)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+        assert st["edges_traversed"] == int(deg[want != solvers.MYINFINITY].astype(np.int64).sum())
+    bfs.close()
+    assert by_head > 0
+
+
 def test_bfs_star_and_chain(orc):
     # a hub with 20000 out-neighbours (big-row path) feeding a chain (many tiny levels)
     n = 20001 + 300
