@@ -1246,7 +1246,9 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     const char *hh = gdn_option("GDN_BFS_HUB_HEADS");
     unsigned long long heads_from = 1ull << 24;
     if (const char *e = gdn_option("GDN_BFS_HEADS_MIN_NNZ")) heads_from = strtoull(e, nullptr, 10);  // (tests)
-    if (dense && g->nnz >= heads_from && (unsigned)m >= 4u * BFS_HUBS && !(hh && hh[0] == '0')) {
+    // (a graph with fewer vertices than a few times the hub slots gains nothing; the test knob lifts that too)
+    const bool enough = (unsigned)m >= 4u * BFS_HUBS || gdn_option("GDN_BFS_HEADS_MIN_NNZ") != nullptr;
+    if (dense && g->nnz >= heads_from && enough && m >= 2 && !(hh && hh[0] == '0')) {
       HostTimer th;
       GDN_HIP(hipDeviceSynchronize());
       th.start();
@@ -1262,7 +1264,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_HIP(hipGetLastError());
       const unsigned long long *sorted = nullptr;
       GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m, 32u, 64u, &sorted));
-      hipLaunchKernelGGL(bfs_hub_rank_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, sorted, m, BFS_HUBS, p.hub_id.p,
+      hipLaunchKernelGGL(bfs_hub_rank_kernel, dim3(gdn_nblocks((uint64_t)m > BFS_HUBS ? (uint64_t)m : (uint64_t)BFS_HUBS)), dim3(GDN_BLOCK), 0, 0, sorted, m, BFS_HUBS, p.hub_id.p,
                          hub_idx.p);
       hipLaunchKernelGGL(bfs_hub_head_kernel, dim3(256 * 16), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                          hub_idx.p, sorted, p.head.p);

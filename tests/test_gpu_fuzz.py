@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("first_seed,blocked", [(1, False), (100001, False), (200001, True), (300001, "plans"),
-                                                (700001, "fused")])
+                                                (700001, "fused"), (800001, "heads")])
 def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
     env = dict(os.environ, OMP_NUM_THREADS="4")
     if blocked == "fused":  # every BFS level, every forward and every backward level of BC that fits, and PageRank's
@@ -21,6 +21,11 @@ def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
         env.update(GDN_BFS_SMALL_NF="100000", GDN_BFS_SMALL_SCOUT="1000000000", GDN_BC_SMALL_NF="1000000",
                    GDN_BC_SMALL_SCOUT="1000000000000", GDN_BC_BACK_NF="1024", GDN_BC_BACK_SCOUT="1000000000000",
                    GDN_PR_FUSED="1", GDN_PR_SMALL_M="16384", FUZZ_PLANS="1")
+        blocked = False
+    if blocked == "heads":  # the resident plans with every heavy BFS level on the bottom-up step and its head records
+        # (normally from 2^24 edges on; hub test always on)
+        env.update(FUZZ_PLANS="1", GDN_BFS_HEADS_MIN_NNZ="1", GDN_BFS_HUB_MIN="0", GDN_BFS_BU_EDGE_DIV="1000000000",
+                   GDN_BFS_BTD="0")
         blocked = False
     if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels -- with the binned
         # top-down level forced onto every heavy BFS level below a third of the edges
