@@ -310,6 +310,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
     if (r > 0 && (unsigned)m > (1u << 18)) {
       head = 1u << 14;
       if (const char *e = gdn_option("GDN_CC_HEAD")) head = (unsigned)atoi(e) & ~(unsigned)(GDN_BLOCK - 1);  // tuning knob
+      if (head >= (unsigned)m) head = 0;
     }
     if (head) {
       hipLaunchKernelGGL(cc_sample_link_kernel, dim3(head / GDN_BLOCK), blk, 0, 0, g->rowptr, g->colidx, (int32_t)head, r, d_comp, 0u);
