@@ -897,6 +897,8 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     int lc = 10, lb = 10;
     while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 9)) < (int64_t)m) lc++;  // slice sizes as for PageRank (pb_pick_log)
     while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 9)) < (int64_t)m) lb++;
+    if (const char *e = gdn_option("GDN_BC_LOG_CHUNK")) lc = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_CHUNK ? atoi(e) : lc;  // tuning knobs
+    if (const char *e = gdn_option("GDN_BC_LOG_BIN")) lb = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_BIN ? atoi(e) : lb;
     // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
     PbScratch scratch;
     if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
