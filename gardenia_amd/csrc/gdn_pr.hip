@@ -877,9 +877,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     p->sq_colidx.release();
     p->sq_rowptr.release();
   }
-  // placement search (pr_plan_place): from 2^28 edges on -- below, the streams are a few hundred MB and an iteration a few
-  // hundred microseconds.  GDN_PR_PLACE=<tries per array> (0 = off)
-  unsigned long long place_from = 1ull << 28;
+  // placement search (pr_plan_place).  GDN_PR_PLACE=<tries per array> (0 = off)
+  // from 3 x 2^28 edges on: RMAT-26 (1.06 G edges) gains 4 % (1.93 -> 1.85 ms), RMAT-25 and RMAT-24 plans show no spread at all
+  // (0.93 / 0.45 ms wherever they lie, profiles/r03_pb_placement.txt) -- it comes with allocations of several GB
+  unsigned long long place_from = 3ull << 28;
   if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
   if (p->layout != GDN_LAYOUT_CSR && p->nnz >= place_from && !g_pr_no_place) {
     int tries = 3;

@@ -316,9 +316,9 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     gdn_set_error("gdn_spmv_plan_create: layout kernels failed: %s", hipGetErrorString(hipGetLastError()));
     st = GDN_ERR_HIP;
   }
-  // placement search (PbPlacer, gdn_pb.hpp) from 2^28 non-zeros on: three multiplies on scratch vectors per candidate.
+  // placement search (PbPlacer, gdn_pb.hpp) from 3 x 2^28 non-zeros on: three multiplies on scratch vectors per candidate.
   // GDN_SPMV_PLACE=<tries per array> (0 = off)
-  unsigned long long place_from = 1ull << 28;
+  unsigned long long place_from = 3ull << 28;  // (as for PageRank, gdn_pr.hip: below, plans show no placement spread)
   if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
   if (st == GDN_OK && p->layout == GDN_LAYOUT_PB && csr->nnz >= place_from) {
     int tries = 3;

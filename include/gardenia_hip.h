@@ -252,7 +252,7 @@ typedef struct gdn_pr_plan gdn_pr_plan;
  *                   between the caller's m-entry score vector and the state at the boundary of a solve.  Same bits
  *                   as GDN_LAYOUT_PB for every vertex. */
 enum { GDN_LAYOUT_AUTO = -1, GDN_LAYOUT_CSR = 0, GDN_LAYOUT_PB = 1, GDN_LAYOUT_PB_SQUISHED = 2 };
-/* From 2^28 edges on, creating a PB plan ends with a PLACEMENT SEARCH: fresh allocations of the streamed
+/* From 3 x 2^28 edges on, creating a PB plan ends with a PLACEMENT SEARCH: fresh allocations of the streamed
  * arrays are timed on scratch vectors and the fastest ones kept -- 0.4-2.5 s more plan build for up to 9 % faster
  * iterations, same results.  Option GDN_PR_PLACE=<tries per array> (default 3, 0 = off); the one-shot gdn_pr never runs it.
  * gdn_spmv_plan_create does the same (GDN_SPMV_PLACE). */
