@@ -342,7 +342,7 @@ bfs_hub_rank_kernel(const unsigned long long *__restrict__ sorted, int32_t m, un
 // without in-edges.  One wave per row, over at most BFS_HEAD_SCAN of its in-edges: ANY in-neighbour is a valid head, the
 // best one only raises the hit rate, and the rows beyond (0.01 % of RMAT-27's) are hubs themselves, discovered top-down --
 // walked whole, the few rows of millions of in-edges made the plan build 2.8 s longer.  (Measured and dropped: the three best hubs, 16 bits each, tested together -- with
-// 2^16 hub slots the heavy level of RMAT-27 1.26 -> 1.60 ms, profiles/r03_bfs_hub_heads.txt.)
+// 2^16 hub slots the heavy level of RMAT-27 1.26 -> 1.60 ms, profiles/r03_bfs_bottom_up.txt.)
 #define BFS_HEAD_VERTEX 0x80000000u
 #define BFS_HEAD_SCAN 8192
 __global__ void __launch_bounds__(GDN_BLOCK)
