@@ -173,6 +173,35 @@ cc_sample_labels_kernel(const int32_t *__restrict__ comp, int32_t m, int32_t *__
   out[i] = comp[z % (unsigned long long)m];
 }
 
+// the most frequent label of the sample (ties: the smallest label, like a scan of the sorted sample keeping the first
+// maximum) -> *out, on the device: the closing passes read it from there, no copy back and host sort in between (50 us of a
+// 1 ms solve)
+__global__ void __launch_bounds__(1024) cc_sample_mode_kernel(const int32_t *__restrict__ sample, int n, int32_t *__restrict__ out) {
+  __shared__ int32_t s_lab[1024];
+  __shared__ unsigned long long s_best[16];
+  const int i = (int)threadIdx.x;
+  s_lab[i] = i < n ? sample[i] : -1;
+  __syncthreads();
+  unsigned long long key = 0ull;
+  if (i < n) {
+    const int32_t mine = s_lab[i];
+    unsigned cnt = 0;
+    for (int j = 0; j < n; j++) cnt += s_lab[j] == mine ? 1u : 0u;
+    key = ((unsigned long long)cnt << 32) | (unsigned)(0x7FFFFFFF - mine);  // more often first, then the smaller label
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(key, o, 64);
+    key = t > key ? t : key;
+  }
+  if ((i & 63) == 0) s_best[i >> 6] = key;
+  __syncthreads();
+  if (i == 0) {
+    for (int w = 1; w < 16; w++) key = s_best[w] > key ? s_best[w] : key;
+    *out = 0x7FFFFFFF - (int32_t)(unsigned)(key & 0xFFFFFFFFull);
+  }
+}
+
 struct CcLinkVis {
   const vid_t *__restrict__ colidx;
   int32_t *__restrict__ comp;
@@ -187,7 +216,9 @@ struct CcLinkVis {
 // remaining edges of the vertices outside the giant component c (omp_afforest.cc:56-76);
 // skip = neighbours already used by the sampling rounds (out-CSR) or 0 (in-CSR)
 __global__ void __launch_bounds__(GDN_BLOCK)
-cc_finish_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int32_t c, int skip, ExpBigList big, CcLinkVis vis) {
+cc_finish_kernel(const eoff_t *__restrict__ rowptr, int32_t m, const int32_t *__restrict__ c_ptr, int skip, ExpBigList big,
+                 CcLinkVis vis) {
+  const int32_t c = c_ptr ? *c_ptr : -1;  // label of the giant component (nullptr: nobody is skipped)
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
   const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
   eoff_t b = 0, e = 0;
@@ -295,7 +326,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
   GDN_TRY(bigitems.alloc(bigcap));
   GDN_TRY(cnt.alloc(1));
-  GDN_TRY(d_sample.alloc(nsample));
+  GDN_TRY(d_sample.alloc(nsample + 1));  // + the label of the giant component
   st.prep_ms = tprep.stop_ms();
 
   tsolve.start();
@@ -322,20 +353,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   }
   // most frequent label of the sample = the giant intermediate component
   hipLaunchKernelGGL(cc_sample_labels_kernel, dim3(gdn_nblocks(nsample)), blk, 0, 0, d_comp, m, d_sample.p, nsample);
-  int32_t h_sample[1024];
-  GDN_HIP(hipMemcpy(h_sample, d_sample.p, sizeof(h_sample), hipMemcpyDeviceToHost));
-  std::sort(h_sample, h_sample + nsample);
-  int32_t c = h_sample[0];
-  int best = 0;
-  for (int i = 0; i < nsample;) {
-    int j = i;
-    while (j < nsample && h_sample[j] == h_sample[i]) j++;
-    if (j - i > best) {
-      best = j - i;
-      c = h_sample[i];
-    }
-    i = j;
-  }
+  hipLaunchKernelGGL(cc_sample_mode_kernel, dim3(1), dim3(1024), 0, 0, d_sample.p, nsample, d_sample.p + nsample);
   GDN_HIP(hipMemsetAsync(cnt.p, 0, sizeof(CcCounters), 0));
   ExpBigList big;
   big.items = bigitems.p;
@@ -347,12 +365,12 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   vis.v = 0;
   vis.colidx = g->colidx;
   // gin == nullptr (out-edges only): nobody is skipped (label -1 matches no vertex)
-  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, gin ? c : -1, neighbor_rounds, big, vis);
+  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, gin ? d_sample.p + nsample : nullptr, neighbor_rounds, big, vis);
   hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, vis);
   if (gin && gin != g) {  // directed: the in-edges too (omp_afforest.cc:72-74)
     GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
     vis.colidx = gin->colidx;
-    hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, gin->rowptr, m, c, 0, big, vis);
+    hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, gin->rowptr, m, d_sample.p + nsample, 0, big, vis);
     hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, gin->rowptr, big, vis);
   }
   hipLaunchKernelGGL(cc_shortcut_kernel, grid_m, blk, 0, 0, d_comp, m);
