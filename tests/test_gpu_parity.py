@@ -1102,7 +1102,8 @@ def test_cc_golden(orc, case):
         assert orc.cc_verify(csr_from(d), comp)  # CCVerifier criterion
 
 
-@pytest.mark.parametrize("scale,ef,seed", [(14, 4, 31), (16, 16, 32), (18, 2, 33)])
+# (scale 20: more than 2^18 vertices -- the sampling rounds after the first then run in two launches, gdn_cc.hip)
+@pytest.mark.parametrize("scale,ef,seed", [(14, 4, 31), (16, 16, 32), (18, 2, 33), (20, 6, 34)])
 @pytest.mark.parametrize("variant", ["afforest_sym", "afforest_directed", "sv_no_reverse"])
 def test_cc_vs_oracle_rmat(orc, scale, ef, seed, variant):
     d = graphio.rmat_graph(scale, ef, seed=seed)
