@@ -7,6 +7,8 @@ properties -- the oracle cannot run at this size inside a test:
   BFS       the resident dense-sweep plan and the plan-less Beamer search give identical depths; every
             edge (u,v) with u reached has depth[v] <= depth[u]+1; every reached v != source has
             depth >= 1; TEPS numerator = sum of out-degrees of the reached vertices
+  CC        Afforest with / without the reverse graph agree; labels are minimum ids, equal across sampled edges and over
+            everything a BFS reaches
   SSSP      unit weights: distances == BFS depths (R-MAT scale 25)
   delta PR  pull-only iterates equal the plain solver's iterates, the L1 trace equals a torch recomputation, runs repeat
             bit for bit, the converged vector stays within the variant's stop of the plain solver's (R-MAT scale 27)
@@ -125,6 +127,34 @@ def test_bfs_plans_agree_and_depths_are_consistent(big):
     du, dv = d2[u].to(torch.int64), d2[ci[idx].to(torch.int64)].to(torch.int64)
     ok = (du == INF) | (dv <= du + 1)
     assert bool(ok.all())
+
+
+def test_cc_labels_at_full_size(big):
+    """Afforest with the reverse graph, without it, and the Shiloach-Vishkin rounds give the same labels on the full graph;
+    a label is the smallest id of its component (comp[comp] == comp, comp <= id), both ends of 64 M sampled edges carry the
+    same label, and the vertices the BFS from the first source reaches all carry the source's label."""
+    torch, L, cabi, dev, m, nnz = big["torch"], big["L"], big["cabi"], big["dev"], big["m"], big["nnz"]
+    p = lambda t: C.c_void_p(t.data_ptr())
+    labels = []
+    for rev in (big["gi"], None):
+        comp = torch.empty(m, dtype=torch.int32, device=dev)
+        st = cabi.GdnStats()
+        cabi.check(L.gdn_cc_dev(big["go"], rev, p(comp), C.byref(st)))
+        labels.append(comp)
+    a = labels[0]
+    assert bool((a == labels[1]).all())
+    ids = torch.arange(m, dtype=torch.int32, device=dev)
+    assert bool((a <= ids).all()) and bool((a[a.to(torch.int64)] == a).all())
+    rp = _view(torch, big["out_rowptr"], m + 1, torch.int64, dev)
+    ci = _view(torch, big["out_colidx"], nnz, torch.int32, dev)
+    idx = torch.randint(0, nnz, (1 << 26,), device=dev)
+    u = torch.searchsorted(rp, idx, right=True) - 1
+    assert bool((a[u] == a[ci[idx].to(torch.int64)]).all())
+    src = int(torch.nonzero(big["deg"][:1 << 16] > 0)[0])
+    d = torch.empty(m, dtype=torch.int32, device=dev)
+    st = cabi.GdnStats()
+    cabi.check(L.gdn_bfs_dev(big["go"], big["gi"], src, p(d), C.byref(st)))
+    assert bool((a[d != 1000000000] == a[src]).all())
 
 
 def test_sssp_unit_weights_equal_bfs_depths():
