@@ -9,7 +9,8 @@ properties -- the oracle cannot run at this size inside a test:
             depth >= 1; TEPS numerator = sum of out-degrees of the reached vertices
   CC        Afforest with / without the reverse graph agree; labels are minimum ids, equal across sampled edges and over
             everything a BFS reaches
-  SSSP      unit weights: distances == BFS depths (R-MAT scale 25)
+  SSSP      unit weights: distances == BFS depths (R-MAT scale 25); weights U[1,255]: the same distances for three deltas and
+            both plans, no sampled edge left to relax
   delta PR  pull-only iterates equal the plain solver's iterates, the L1 trace equals a torch recomputation, runs repeat
             bit for bit, the converged vector stays within the variant's stop of the plain solver's (R-MAT scale 27)
   BC        the resident plan (BFS depths + propagation-blocked heavy levels) and the queue-based path agree within the
@@ -184,6 +185,53 @@ def test_sssp_unit_weights_equal_bfs_depths():
     assert bool((dist == depth).all())
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
+
+
+def test_sssp_random_weights_at_full_size():
+    """R-MAT scale 25 (529 M edges), weights U[1,255]: the distances do not depend on delta (16 / 64 / 2^20: three different
+    orders of buckets, sweeps and worklist passes) nor on the plan (the worklist-only plan gives the same), dist[source] = 0,
+    no sampled edge can still be relaxed (dist[v] <= dist[u] + w), and every reached vertex other than the source is at
+    least one smallest weight away."""
+    torch = pytest.importorskip("torch")
+    from gardenia_amd import _cabi, graphio
+    L = _cabi.lib()
+    dev = torch.device("cuda", 0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    go = C.c_void_p()
+    _cabi.check(L.gdn_rmat_build(25, 16, graphio.K_RAND_SEED, 1, C.byref(go), None))
+    m, nnz = C.c_int32(), C.c_uint64()
+    rp, ci = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), C.byref(rp), C.byref(ci)))
+    m, nnz = m.value, nnz.value
+    deg = torch.empty(m, dtype=torch.int32, device=dev)
+    _cabi.check(L.gdn_graph_degrees_dev(go, p(deg), None))
+    src = int(torch.nonzero(deg[:1 << 16] > 0)[0])
+    torch.manual_seed(11)
+    w = torch.randint(1, 256, (nnz,), dtype=torch.int32, device=dev)
+    res = []
+    for dense, delta in ((1, 16), (1, 64), (1, 1 << 20), (0, 16)):
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_sssp_plan_create(go, p(w), dense, C.byref(plan)))
+        dist = torch.empty(m, dtype=torch.int32, device=dev)
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_sssp_run(plan, src, delta, p(dist), C.byref(st)))
+        L.gdn_sssp_plan_free(plan)
+        res.append(dist)
+    for d in res[1:]:
+        assert bool((d == res[0]).all())
+    dist = res[0].to(torch.int64)
+    INF = 2147483647
+    assert int(dist[src]) == 0
+    reached = dist != INF
+    assert int((dist[reached] == 0).sum()) == 1 and int(dist[reached].min()) == 0
+    rpt = _view(torch, rp.value, m + 1, torch.int64, dev)
+    cit = _view(torch, ci.value, nnz, torch.int32, dev)
+    idx = torch.randint(0, nnz, (1 << 26,), device=dev)
+    u = torch.searchsorted(rpt, idx, right=True) - 1
+    du, dv = dist[u], dist[cit[idx].to(torch.int64)]
+    ok = (du == INF) | (dv <= du + w[idx].to(torch.int64))
+    assert bool(ok.all())
+    L.gdn_graph_free(go)
 
 
 def test_bc_plan_equals_queue_path_at_full_size(big):
