@@ -980,7 +980,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
              PbScratch *scratch) {
   GDN_REQUIRE(log_chunk >= 8 && log_chunk <= 15, "log_chunk");
   GDN_REQUIRE(!v_delta || (pad >= 32 && !src_major && !rows_are_sources), "delta-coded rows: tiles of whole 32-edge groups, sorted by row");
-  GDN_REQUIRE(!(src_class && rows_are_sources), "source classes: in-CSR only");
+  // (source classes on an out-CSR -- SSSP's sweeps -- index the CSR's ROWS: the key visitor swaps row and column first;
+  // what an out-CSR cannot have is the compaction, see below)
   GDN_REQUIRE(log_group >= 3 && log_group <= 7 && pad >= (1u << log_group) && pad <= 128 && (pad & (pad - 1)) == 0,
               "pad / log_group");
   const auto t_begin = std::chrono::steady_clock::now();

@@ -34,6 +34,23 @@ struct SsspCounters {
   alignas(128) unsigned long long improved_edges;  // binned relax pass: out-edges of the rows it improved
 };
 
+// record tiers of the dense sweeps (sssp_build_tiers below)
+#define SSSP_MAX_TIERS 4
+#define SSSP_TIER_ROW_BITS 15               // a record keeps the row of its bin in 15 bits (bins of up to 2^15 rows, as without tiers:
+                                            // with 14 bits and 2^14-row bins RMAT-25 / 26 lost 1-3 % where RMAT-24 gained 8 %)
+#define SSSP_TIER0 (1u << 15)               // sources of the first tier (a 128 KB table)
+#define SSSP_TIER_N (1u << 17)              // of every further one (32 - 15 index bits: 512 KB tables)
+struct SsspTierArgs {  // what phase B needs (by value)
+  int n = 0;
+  unsigned nbins = 0;
+  const uint32_t *rec = nullptr;
+  const uint8_t *w = nullptr;  // nullptr: every weight is w_uniform
+  const eoff_t *ptr = nullptr;
+  const unsigned *tab = nullptr;
+  unsigned off[SSSP_MAX_TIERS] = {};
+  unsigned w_uniform = 0;
+};
+
 struct SsspVis {
   const eoff_t *__restrict__ rowptr;
   unsigned long long near_edges;  // per-lane: out-degree sum of the vertices this lane pushed to NEAR
@@ -352,12 +369,15 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
                           const uint32_t *__restrict__ bin_order, const uint16_t *__restrict__ V,
                           const CT *__restrict__ cand, int32_t *__restrict__ dist,
                           unsigned *__restrict__ improved_bits, SsspCounters *cnt,
-                          const eoff_t *__restrict__ out_rowptr = nullptr) {  // nullable: count the improved rows' out-edges
+                          const eoff_t *__restrict__ out_rowptr,  // nullable: count the improved rows' out-edges
+                          const SsspTierArgs ta) {
   extern __shared__ __attribute__((aligned(16))) unsigned s_min[];
   __shared__ unsigned long long s_red[2 * PB_WAVES];
   __shared__ int s_max[PB_WAVES];
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order[blockIdx.x];
+  // (measured and dropped: the fold started from the rows' current distances with an LDS read in front of every atomic -- most
+  // candidates lose from the second sweep on -- 383 -> 400 us: a read meets the same bank conflicts as the atomic)
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_min[i] = (unsigned)GDN_DIST_INF;
   __syncthreads();
   const eoff_t q0 = bin_ptr[b] >> 3, q1 = bin_ptr[b + 1] >> 3;
@@ -396,6 +416,40 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
           const unsigned v = (vs[r][k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
           if (x != CINF) atomicMin(&s_min[v], x);
         }
+      }
+    }
+  }
+  // the record tiers: ONE record per lane and load, eight loads in flight (records are sorted by source inside a bin: the 64
+  // table reads of a wave instruction then fall into a few consecutive lines -- near-coalesced L2 hits; four consecutive
+  // records per lane spread them over four times as many lines and cost the sweep 0.66 instead of 0.6 ms)
+  for (int t = 0; t < ta.n; t++) {
+    const eoff_t j0 = ta.ptr[(size_t)t * ta.nbins + b];
+    const unsigned nr = (unsigned)(ta.ptr[(size_t)t * ta.nbins + b + 1] - j0);
+    const unsigned *__restrict__ tab = ta.tab + ta.off[t];
+    const uint32_t *__restrict__ R = ta.rec + j0;
+    const uint8_t *__restrict__ W = ta.w ? ta.w + j0 : nullptr;
+    constexpr int TU = 8;
+    constexpr unsigned RMASK = (1u << SSSP_TIER_ROW_BITS) - 1u;
+    for (unsigned i0 = threadIdx.x; i0 < nr; i0 += (unsigned)TU * PB_THREADS) {
+      unsigned rc[TU], wv[TU], d[TU];
+      bool on[TU];
+#pragma unroll
+      for (int r = 0; r < TU; r++) {
+        const unsigned i = i0 + (unsigned)r * PB_THREADS;
+        on[r] = i < nr;
+        rc[r] = 0u;
+        wv[r] = ta.w_uniform;
+        if (on[r]) {
+          rc[r] = __builtin_nontemporal_load(R + i);
+          if (W) wv[r] = W[i];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < TU; r++) d[r] = on[r] ? tab[rc[r] >> SSSP_TIER_ROW_BITS] : (unsigned)GDN_DIST_INF;
+#pragma unroll
+      for (int r = 0; r < TU; r++) {
+        const unsigned nd = d[r] + wv[r];
+        if (d[r] < (unsigned)GDN_DIST_INF && nd < (unsigned)GDN_DIST_INF) atomicMin(&s_min[rc[r] & RMASK], nd);
       }
     }
   }
@@ -1229,6 +1283,17 @@ struct gdn_sssp_plan {
   DevBuf<unsigned> bin_cur, bin_ovf;
   unsigned bin_nbins = 0, bin_cap_each = 0;
   int bin_bits = 0;
+  // RECORD TIERS of the sweeps (sssp_build_tiers): the out-edges of the sources of highest out-degree leave the blocked
+  // layout; phase B reads them as 4-byte (source index << 14 | row) records + a 1-byte weight, the source's distance comes
+  // from a per-sweep table (tier_tab, L2 resident) -- 5 B per edge instead of the 9.5 B of an edge that travels through cand
+  int n_tiers = 0;
+  unsigned tier_off[SSSP_MAX_TIERS + 1] = {};  // first source of tier t in tier_ids / tier_tab
+  DevBuf<uint32_t> tier_ids;                   // the tier sources (descending out-degree)
+  DevBuf<unsigned> tier_tab;                   // their distances, refreshed per sweep
+  DevBuf<uint32_t> tier_rec;                   // records, tier-major then bin-major
+  DevBuf<uint8_t> tier_w;                      // their weights (w_bytes 1; none when all weights are equal)
+  DevBuf<eoff_t> tier_ptr;                     // n_tiers x nbins + 1 offsets into tier_rec
+  unsigned long long tier_edges = 0;
   DevBuf<unsigned> cand;   // candidate distances, bin-major (u16 or u32 per sweep)
   DevBuf<unsigned> improved;
   DevBuf<unsigned> bad;    // 1 word: a 16-bit candidate overflowed (cannot happen; checked)
@@ -1245,6 +1310,169 @@ struct gdn_sssp_plan {
   unsigned cap = 0, bigcap = 0, nwords = 0;
   double prep_ms = 0;
 };
+
+// ------------------------------------------------------------------------------------------
+// RECORD TIERS of the dense sweeps.  PageRank's record tiers (gdn_pb.hpp) for a min-plus sweep: an edge of the blocked layout
+// costs 9.5 B per sweep (U 2 + G 0.5 + weight 1 + candidate 2 written, candidate 2 + V 2 read); an edge that leaves a source
+// of high out-degree is instead kept as a RECORD in the order phase B wants it (bin-major): 4 bytes (source index << 14 | row
+// in the bin) + 1 byte of weight, and the source's distance is looked up in a table refreshed per sweep (32 K entries for the
+// first tier, up to 256 K for the others: L2 resident).  Sources are ranked by out-degree; those with at least 1/16 edge per
+// bin (and 8) go into up to SSSP_MAX_TIERS tiers.  Needs weights of at most 8 bits (or all equal) and bins of 2^14 rows.
+// ------------------------------------------------------------------------------------------
+int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
+                       const unsigned long long **sorted);
+
+static inline unsigned sssp_tier_first_host(unsigned t) { return t == 0 ? 0u : SSSP_TIER0 + (t - 1u) * SSSP_TIER_N; }
+__device__ __forceinline__ unsigned sssp_tier_of(unsigned r) { return r < SSSP_TIER0 ? 0u : 1u + (r - SSSP_TIER0) / SSSP_TIER_N; }
+__device__ __forceinline__ unsigned sssp_tier_first(unsigned t) { return t == 0 ? 0u : SSSP_TIER0 + (t - 1u) * SSSP_TIER_N; }
+
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_tier_degkeys_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long long *__restrict__ keys) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (unsigned)m) {
+    const eoff_t d = rowptr[v + 1] - rowptr[v];
+    keys[v] = ((unsigned long long)(d > 0xFFFFFFFFull ? 0xFFFFFFFFull : d) << 32) | v;
+  }
+}
+// number of keys (ascending by degree) whose degree is >= min_deg
+__global__ void sssp_tier_count_kernel(const unsigned long long *__restrict__ sorted, int32_t m, unsigned min_deg, unsigned *out) {
+  if (threadIdx.x || blockIdx.x) return;
+  size_t lo = 0, hi = (size_t)m;  // first index with degree >= min_deg
+  while (lo < hi) {
+    const size_t mid = (lo + hi) >> 1;
+    if ((unsigned)(sorted[mid] >> 32) < min_deg) lo = mid + 1;
+    else hi = mid;
+  }
+  *out = (unsigned)((size_t)m - lo);
+}
+// rank r (0 = the largest out-degree) -> ids[r], degs[r], cls[id] = 1 + its tier
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_tier_assign_kernel(const unsigned long long *__restrict__ sorted, int32_t m, unsigned n_ts, uint8_t *__restrict__ cls,
+                        uint32_t *__restrict__ ids, uint32_t *__restrict__ degs) {
+  const unsigned r = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (r >= n_ts) return;
+  const unsigned long long key = sorted[(size_t)m - 1 - r];
+  const unsigned id = (unsigned)(key & 0xFFFFFFFFull);
+  ids[r] = id;
+  degs[r] = (unsigned)(key >> 32);
+  cls[id] = (uint8_t)(1u + sssp_tier_of(r));
+}
+// one wave per tier source: its out-edges as keys  (tier * nbins + bin) << 40 | record << 8 | weight
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_tier_keys_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const int32_t *__restrict__ weight,
+                      const uint32_t *__restrict__ ids, const eoff_t *__restrict__ offs, unsigned n_ts, unsigned nbins, int lb,
+                      unsigned long long *__restrict__ keys) {
+  const unsigned lane = gdn_lane();
+  const size_t nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
+  for (size_t r = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; r < (size_t)n_ts; r += nwaves) {
+    const unsigned id = ids[r], t = sssp_tier_of((unsigned)r), idx = (unsigned)r - sssp_tier_first(t);
+    const eoff_t b = rowptr[id], e = rowptr[id + 1], o = offs[r];
+    for (eoff_t k = b + lane; k < e; k += 64) {
+      const unsigned dst = (unsigned)colidx[k];
+      const unsigned long long tb = (unsigned long long)t * nbins + (dst >> lb);
+      const unsigned rec = (idx << SSSP_TIER_ROW_BITS) | (dst & ((1u << lb) - 1u));
+      keys[o + (k - b)] = (tb << 40) | ((unsigned long long)rec << 8) | ((unsigned)weight[k] & 0xFFu);
+    }
+  }
+}
+// sorted keys -> records, weights, and ptr[x] = first position whose (tier, bin) index is >= x (ptr[n_tb] = n)
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_tier_split_kernel(const unsigned long long *__restrict__ sorted, unsigned long long n, unsigned n_tb,
+                       uint32_t *__restrict__ rec, uint8_t *__restrict__ w8, eoff_t *__restrict__ ptr) {
+  const unsigned long long j = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (j >= n) return;
+  const unsigned long long key = sorted[j];
+  rec[j] = (uint32_t)(key >> 8);
+  if (w8) w8[j] = (uint8_t)(key & 0xFFull);
+  const long long tb = (long long)(key >> 40), prev = j ? (long long)(sorted[j - 1] >> 40) : -1ll;
+  for (long long x = prev + 1; x <= tb; x++) ptr[x] = j;
+  if (j == n - 1)
+    for (long long x = tb + 1; x <= (long long)n_tb; x++) ptr[x] = n;
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_tier_gather_kernel(const int32_t *__restrict__ dist, const uint32_t *__restrict__ ids, unsigned n, unsigned *__restrict__ tab) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (k < n) tab[k] = (unsigned)dist[ids[k]];
+}
+
+// picks the tier sources and builds their record streams; cls (one byte per source: 0 = stays in the blocked layout) is what
+// pb_build filters the blocked layout with.  No tiers (n_tiers = 0, cls empty) when nothing qualifies.
+static int sssp_build_tiers(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d_weight, int lb, DevBuf<uint8_t> &cls) {
+  const int32_t m = g->m;
+  const unsigned nbins = (unsigned)(((uint64_t)m + (1u << lb) - 1) >> lb);  // the bins of the blocked layout (lb <= 14)
+  // floor: a quarter of an edge per bin (RMAT-24, 1024 bins: 256 out-edges -> two tiers, 64.5 % of the edges, 3.47 -> 3.15 ms;
+  // 64: three tiers, 80 %, 3.33 -- phase B's LDS atomics bound the sweep then, not its bytes; profiles/r03_sssp_tiers.txt)
+  unsigned min_deg = nbins / 4u < 8u ? 8u : nbins / 4u;
+  if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;  // test / tuning knob
+  int max_tiers = SSSP_MAX_TIERS;
+  if (const char *e = gdn_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
+  if (max_tiers <= 0 || m < 2) return GDN_OK;
+  DevBuf<unsigned long long> ka, kb;
+  GDN_TRY(ka.alloc((size_t)m));
+  GDN_TRY(kb.alloc((size_t)m));
+  hipLaunchKernelGGL(sssp_tier_degkeys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, ka.p);
+  const unsigned long long *sorted = nullptr;
+  GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m, 32u, 64u, &sorted));
+  DevBuf<unsigned> cntb;
+  GDN_TRY(cntb.alloc(1));
+  hipLaunchKernelGGL(sssp_tier_count_kernel, dim3(1), dim3(64), 0, 0, sorted, m, min_deg, cntb.p);
+  unsigned n_ts = 0;
+  GDN_HIP(hipMemcpy(&n_ts, cntb.p, 4, hipMemcpyDeviceToHost));
+  const unsigned cap = SSSP_TIER0 + (unsigned)(max_tiers - 1) * SSSP_TIER_N;
+  if (n_ts > cap) n_ts = cap;
+  if (n_ts == 0) return GDN_OK;
+  int nt = 1;
+  while (nt < max_tiers && sssp_tier_first_host((unsigned)nt) < n_ts) nt++;
+  GDN_TRY(cls.alloc((size_t)m));
+  GDN_HIP(hipMemset(cls.p, 0, (size_t)m));
+  DevBuf<uint32_t> degs;
+  DevBuf<eoff_t> offs;
+  GDN_TRY(p.tier_ids.alloc(n_ts));
+  GDN_TRY(degs.alloc((size_t)n_ts + 1));
+  GDN_TRY(offs.alloc((size_t)n_ts + 1));
+  GDN_HIP(hipMemset(degs.p, 0, ((size_t)n_ts + 1) * 4));
+  hipLaunchKernelGGL(sssp_tier_assign_kernel, dim3(gdn_nblocks(n_ts)), dim3(GDN_BLOCK), 0, 0, sorted, m, n_ts, cls.p, p.tier_ids.p,
+                     degs.p);
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(degs.p, offs.p, (size_t)n_ts + 1, 0));
+  eoff_t n_e = 0;
+  GDN_HIP(hipMemcpy(&n_e, offs.p + n_ts, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  if (n_e == 0) {
+    cls.release();
+    p.tier_ids.release();
+    return GDN_OK;
+  }
+  ka.release();  // (sorted may live in either buffer: the assign kernel is done with it)
+  GDN_HIP(hipDeviceSynchronize());
+  kb.release();
+  DevBuf<unsigned long long> ea, eb;
+  GDN_TRY(ea.alloc((size_t)n_e));
+  GDN_TRY(eb.alloc((size_t)n_e));
+  hipLaunchKernelGGL(sssp_tier_keys_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, d_weight, p.tier_ids.p, offs.p, n_ts,
+                     nbins, lb, ea.p);
+  const unsigned n_tb = (unsigned)nt * nbins;
+  unsigned tb_bits = 1;
+  while ((1ull << tb_bits) < n_tb) tb_bits++;
+  const unsigned long long *es = nullptr;
+  GDN_TRY(gdn_radix_sort_u64(ea.p, eb.p, n_e, 40u, 40u + tb_bits, &es));
+  GDN_TRY(p.tier_rec.alloc((size_t)n_e + 16));
+  if (p.w_bytes == 1) GDN_TRY(p.tier_w.alloc((size_t)n_e + 16));
+  GDN_TRY(p.tier_ptr.alloc((size_t)n_tb + 1));
+  hipLaunchKernelGGL(sssp_tier_split_kernel, dim3(gdn_nblocks(n_e)), dim3(GDN_BLOCK), 0, 0, es, n_e, n_tb, p.tier_rec.p,
+                     p.w_bytes == 1 ? p.tier_w.p : nullptr, p.tier_ptr.p);
+  GDN_TRY(p.tier_tab.alloc(n_ts));
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipDeviceSynchronize());
+  p.n_tiers = nt;
+  for (int t = 0; t <= nt; t++) {
+    const unsigned f = sssp_tier_first_host((unsigned)t);
+    p.tier_off[t] = f < n_ts ? f : n_ts;
+  }
+  p.tier_edges = n_e;
+  if (gdn_option("GDN_SSSP_TRACE"))
+    fprintf(stderr, "[sssp] plan: %d record tiers, %u sources of >= %u out-edges, %llu edges (%.1f %% of the graph)\n", nt, n_ts, min_deg,
+            (unsigned long long)n_e, 100.0 * (double)n_e / (double)(g->nnz ? g->nnz : 1));
+  return GDN_OK;
+}
 
 static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d_weight, bool dense, bool bins = true) {
   HostTimer t;
@@ -1283,20 +1511,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     // tiles padded so that a tile's candidates are whole 128-byte lines (a line shared by two tiles is written by two
     // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
     // would cost more than the partial lines
-    const double avg_tile = (double)g->nnz / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lg) + 1));
-    // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
-    // profiles/r03_sssp_layout_knobs.txt)
-    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
-    if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
-    GDN_TRY(pb_build(g, m, lg, lg, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
-                     /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3));
-    GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
-    GDN_TRY(p.bad.alloc(1));
-    GDN_HIP(hipMemset(p.bad.p, 0, 4));
-    // slots in the alignment gaps of the layout are never written by phase A: keep them neutral (all ones = INF of both
-    // candidate widths)
-    GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), -1, (size_t)p.pb.n_pad + 8, 0));
-    // the weight stream as narrow as the weights allow
+    // the weight range first: the record tiers keep a weight in 8 bits
     {
       DevBuf<int32_t> rng;
       GDN_TRY(rng.alloc(2));
@@ -1309,12 +1524,40 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       p.w_max = h[1];
       const char *e = gdn_option("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
       const int force = e ? atoi(e) : -1;
-      const size_t n = (size_t)p.pb.n_pad;
       if (p.w_min < 0) p.w_bytes = 4;  // negative weights: not narrowed (the solvers assume none, like the reference)
       else if (p.w_min == p.w_max && force < 0) p.w_bytes = 0;
       else if (p.w_max < 256 && (force < 0 || force == 1)) p.w_bytes = 1;
       else if (p.w_max < 65536 && (force < 0 || force == 2)) p.w_bytes = 2;
       else p.w_bytes = 4;
+    }
+    // record tiers (sssp_build_tiers): from 2^22 edges on, weights of at most 8 bits; bins of 2^14 rows then
+    DevBuf<uint8_t> cls;
+    int lb = lg;
+    {
+      unsigned long long tiers_from = 1ull << 22;
+      if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_NNZ")) tiers_from = strtoull(e, nullptr, 10);  // (tests)
+      if (p.w_bytes <= 1 && p.w_min >= 0 && g->nnz >= tiers_from) {
+        const int lbt = lg < SSSP_TIER_ROW_BITS ? lg : SSSP_TIER_ROW_BITS;  // a record keeps its row in 14 bits
+        GDN_TRY(sssp_build_tiers(p, g, d_weight, lbt, cls));
+        if (p.n_tiers) lb = lbt;
+      }
+    }
+    const double avg_tile = (double)(g->nnz - p.tier_edges) / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lb) + 1));
+    // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
+    // profiles/r03_sssp_layout_knobs.txt)
+    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
+    if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
+    GDN_TRY(pb_build(g, m, lg, lb, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
+                     /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3, p.n_tiers ? cls.p : nullptr, 0));
+    GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
+    GDN_TRY(p.bad.alloc(1));
+    GDN_HIP(hipMemset(p.bad.p, 0, 4));
+    // slots in the alignment gaps of the layout are never written by phase A: keep them neutral (all ones = INF of both
+    // candidate widths)
+    GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), -1, (size_t)p.pb.n_pad + 8, 0));
+    // the weight stream as narrow as the weights allow
+    {
+      const size_t n = (size_t)p.pb.n_pad;
       if (p.w_bytes == 1 || p.w_bytes == 2) {
         GDN_TRY(p.Wn.alloc(n * (size_t)p.w_bytes + 64));
         if (p.w_bytes == 1)
@@ -1327,7 +1570,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       }
       if (p.w_bytes != 4) p.Wp.release();
     }
-    p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lg) / 32u);
+    p.nwords = (unsigned)(((uint64_t)p.pb.nbins << lb) / 32u);
     GDN_TRY(p.improved.alloc(p.nwords + 64));
     // OFF by default (GDN_SSSP_BINS=1 builds the lists and takes the passes): measured on RMAT-24, U[1,255], delta 16
     // (profiles/r03_sssp_binned_passes.txt) a binned pass costs ~0.19 ms + 39 ps per list edge -- 2.36 ms for the 55 M
@@ -1419,9 +1662,22 @@ static void sssp_launch_sweep(gdn_sssp_plan &p, int32_t m, int32_t *d_dist) {
     default: SSSP_EXPAND(4); break;
   }
 #undef SSSP_EXPAND
+  SsspTierArgs ta;
+  if (p.n_tiers) {
+    const unsigned n_ts = p.tier_off[p.n_tiers];
+    hipLaunchKernelGGL(sssp_tier_gather_kernel, dim3(gdn_nblocks(n_ts)), dim3(GDN_BLOCK), 0, 0, d_dist, p.tier_ids.p, n_ts, p.tier_tab.p);
+    ta.n = p.n_tiers;
+    ta.nbins = p.pb.nbins;
+    ta.rec = p.tier_rec.p;
+    ta.w = p.w_bytes == 1 ? p.tier_w.p : nullptr;
+    ta.ptr = p.tier_ptr.p;
+    ta.tab = p.tier_tab.p;
+    for (int t = 0; t < p.n_tiers; t++) ta.off[t] = p.tier_off[t];
+    ta.w_uniform = p.w_bytes == 0 ? (unsigned)p.w_min : 0u;
+  }
   hipLaunchKernelGGL(HIP_KERNEL_NAME(sssp_pb_accumulate_kernel<CT>), dim3(p.pb.nbins), dim3(PB_THREADS), lds, 0, m, p.pb.log_bin,
                      p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, cand, d_dist, p.improved.p, p.cnt.p,
-                     p.bin_nbins ? p.g->rowptr : nullptr);
+                     p.bin_nbins ? p.g->rowptr : nullptr, ta);
 }
 
 static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_dist, gdn_stats *stats) {

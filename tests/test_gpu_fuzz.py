@@ -23,9 +23,9 @@ def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
                    GDN_PR_FUSED="1", GDN_PR_SMALL_M="16384", FUZZ_PLANS="1")
         blocked = False
     if blocked == "heads":  # the resident plans with every heavy BFS level on the bottom-up step and its head records
-        # (normally from 2^24 edges on; hub test always on)
+        # (normally from 2^24 edges on; hub test always on), and SSSP's sweeps with their record tiers (from 2^22 edges on)
         env.update(FUZZ_PLANS="1", GDN_BFS_HEADS_MIN_NNZ="1", GDN_BFS_HUB_MIN="0", GDN_BFS_BU_EDGE_DIV="1000000000",
-                   GDN_BFS_BTD="0")
+                   GDN_BFS_BTD="0", GDN_SSSP_TIER_MIN_NNZ="1", GDN_SSSP_TIER_MIN_DEG="2", GDN_SSSP_DENSE_IN="100000")
         blocked = False
     if blocked == "plans":  # also the resident plans: dense BFS / SSSP sweeps, BC's blocked levels -- with the binned
         # top-down level forced onto every heavy BFS level below a third of the edges

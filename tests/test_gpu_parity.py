@@ -1020,6 +1020,54 @@ def test_sssp_binned_relax_passes(orc, monkeypatch, knobs, wmax):
     sp.close()
 
 
+@pytest.mark.parametrize("scale,ef,floor,tiers", [(15, 16, "4", None), (17, 8, "2", None), (17, 8, "2", "1"), (16, 32, "64", "3")])
+@pytest.mark.parametrize("wlo,whi", [(1, 255), (3, 3), (0, 2)])
+def test_sssp_record_tiers_vs_oracle(orc, monkeypatch, capfd, scale, ef, floor, tiers, wlo, whi):
+    """The record tiers of the dense sweeps (sssp_build_tiers: the out-edges of the sources of highest out-degree leave the
+    blocked layout and are read by phase B as (source index, row) records + 8-bit weights, the source's distance from a
+    per-sweep table; from 2^22 edges on) forced onto small graphs: floors of 2 / 4 / 64 out-edges, one tier, and -- scale 17
+    with a floor of 2 -- more sources than the first tier holds; weights in 8 bits and all equal (no weight stream), zero
+    weights included.  Exact distances for hub, leaf and first sources and two deltas; the sweeps are entered early."""
+    monkeypatch.setenv("GDN_SSSP_TIER_MIN_NNZ", "1")
+    monkeypatch.setenv("GDN_SSSP_TIER_MIN_DEG", floor)
+    monkeypatch.setenv("GDN_SSSP_DENSE_IN", "100000")
+    monkeypatch.setenv("GDN_SSSP_TRACE", "1")
+    if tiers:
+        monkeypatch.setenv("GDN_SSSP_TIERS", tiers)
+    g = graphio.rmat_graph(scale, ef, seed=91)
+    rng = np.random.default_rng(91)
+    wt = rng.integers(wlo, whi + 1, size=g.nnz).astype(np.int32)
+    capfd.readouterr()
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    log = capfd.readouterr().err
+    assert "record tiers" in log, log[-300:]
+    if scale == 17 and not tiers:
+        assert "[sssp] plan: 2 record tiers" in log or "[sssp] plan: 3 record tiers" in log, log[-300:]
+    deg = g.degrees()
+    for s, delta in ((graphio.first_nonisolated(g), 16), (int(np.argmax(deg)), 1), (int(np.nonzero(deg == 1)[0][0]), 64)):
+        want = orc.sssp_dijkstra(g, wt, s)
+        dist, st = sp.run(s, delta)
+        assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+    sp.close()
+
+
+def test_sssp_wide_weights_keep_the_blocked_layout(orc, monkeypatch, capfd):
+    """Weights beyond 8 bits do not fit a record: the plan builds no tiers and every edge stays in the blocked layout."""
+    monkeypatch.setenv("GDN_SSSP_TIER_MIN_NNZ", "1")
+    monkeypatch.setenv("GDN_SSSP_TIER_MIN_DEG", "2")
+    monkeypatch.setenv("GDN_SSSP_DENSE_IN", "100000")
+    monkeypatch.setenv("GDN_SSSP_TRACE", "1")
+    g = graphio.rmat_graph(14, 16, seed=93)
+    wt = np.random.default_rng(93).integers(1, 1000, size=g.nnz).astype(np.int32)
+    capfd.readouterr()
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    assert "record tiers" not in capfd.readouterr().err
+    s = graphio.first_nonisolated(g)
+    dist, _ = sp.run(s, 64)
+    assert np.array_equal(dist, orc.sssp_dijkstra(g, wt, s))
+    sp.close()
+
+
 @pytest.mark.parametrize("wlo,whi,delta", [(7, 7, 3), (1, 255, 16), (200, 60000, 5000), (1, 1 << 20, 1 << 18), (0, 3, 1),
                                            (1, 3000, 64)])
 @pytest.mark.parametrize("knobs", [{}, {"GDN_SSSP_SMALL": "0"}, {"GDN_SSSP_SMALL": "2"}, {"GDN_SSSP_CAND32": "1"},
