@@ -377,7 +377,7 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
   const unsigned bn = 1u << log_bin;
   const unsigned b = bin_order[blockIdx.x];
   // (measured and dropped: the fold started from the rows' current distances with an LDS read in front of every atomic -- most
-  // candidates lose from the second sweep on -- 383 -> 400 us: a read meets the same bank conflicts as the atomic)
+  // candidates lose from the second sweep on -- 383 -> 400 us)
   for (unsigned i = threadIdx.x; i < bn; i += PB_THREADS) s_min[i] = (unsigned)GDN_DIST_INF;
   __syncthreads();
   const eoff_t q0 = bin_ptr[b] >> 3, q1 = bin_ptr[b + 1] >> 3;
@@ -1401,7 +1401,8 @@ static int sssp_build_tiers(gdn_sssp_plan &p, const gdn_graph *g, const int32_t 
   const int32_t m = g->m;
   const unsigned nbins = (unsigned)(((uint64_t)m + (1u << lb) - 1) >> lb);  // the bins of the blocked layout (lb <= 14)
   // floor: a quarter of an edge per bin (RMAT-24, 1024 bins: 256 out-edges -> two tiers, 64.5 % of the edges, 3.47 -> 3.15 ms;
-  // 64: three tiers, 80 %, 3.33 -- phase B's LDS atomics bound the sweep then, not its bytes; profiles/r03_sssp_tiers.txt)
+  // 64: three tiers, 80 %, 3.33 -- phase B is bound by the issue side of the memory pipeline then, not by bytes;
+  // profiles/r03_sssp_tiers.txt)
   unsigned min_deg = nbins / 4u < 8u ? 8u : nbins / 4u;
   if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;  // test / tuning knob
   int max_tiers = SSSP_MAX_TIERS;
