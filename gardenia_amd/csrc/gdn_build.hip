@@ -666,6 +666,84 @@ pb_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long
 // cls gets one byte per source id (0 main, 1 hub, 2.. mid tiers), hub_ids / mid_ids[t] the ascending ids.
 #define PB_HUB_MIN_PER_BIN 2
 #define PB_MID_MIN_PER_BIN16 4
+// Host part of the tier choice: thresholds in SAMPLED-count units (a sampled count of c stands for about 16 c out-edges)
+// from the quarter-octave histogram h[PB_HUB_BUCKETS] and the linear histogram hl[PB_LIN_BINS] (nullable: no mid tiers)
+// of the per-source counts.  thr[0] = hubs (0xFFFFFFFF: none qualifies; the slot is kept so that the classes keep
+// their numbers), thr[1 + t] = mid tier t; *ntiers = classes in use, the hub class included.
+void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint64_t nnz, int max_mid, unsigned min16,
+                     unsigned *thr_out, int *ntiers_out) {
+  struct {
+    unsigned thr[1 + PB_MAX_MID];
+    int ntiers;
+  } ta;
+  memset(&ta, 0, sizeof(ta));
+  if (max_mid > PB_MAX_MID) max_mid = PB_MAX_MID;
+  if (!hl) max_mid = 0;
+  // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
+  uint64_t per_bin = PB_HUB_MIN_PER_BIN;
+  if (const char *e = gdn_option("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
+  // smallest bucket >= the bucket of `want` whose sources, up to (not including) bucket `top`, number at most `cap`;
+  // PB_HUB_BUCKETS = none
+  auto pick = [&](uint64_t want, unsigned top, uint64_t cap) -> unsigned {
+    if (want < 4) want = 4;
+    if (want > 0x40000000ull) return PB_HUB_BUCKETS;
+    unsigned bk = pb_hub_bucket((unsigned)want);
+    if (pb_hub_bucket_floor(bk) < want) bk++;
+    for (; bk < top; bk++) {
+      uint64_t above = 0;
+      for (unsigned j = bk; j < top; j++) above += h[j];
+      if (above == 0) return PB_HUB_BUCKETS;
+      if (above <= cap) return bk;
+    }
+    return PB_HUB_BUCKETS;
+  };
+  // tier 0 = hubs (the slot keeps an unreachable threshold when no source qualifies, so the classes keep their numbers)
+  const unsigned bk0 = pick((nbins * per_bin) >> PB_HUB_SAMPLE_LOG, PB_HUB_BUCKETS, 1u << PB_HUB_LOG);
+  ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
+  ta.ntiers = 1;
+  uint64_t mid16 = min16 ? min16 : PB_MID_MIN_PER_BIN16;
+  if (const char *e = gdn_option("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
+  uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
+  if (const char *e = gdn_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
+  if (max_mid > 0) {
+    // mid tiers: consecutive count ranges [thr[t], thr[t-1]) below the hubs, each filled up to mid_cap sources, down
+    // to the count that stands for mid16 / 16 edges per average bin
+    uint64_t n_hub_src = 0;
+    for (unsigned j = bk0; j < PB_HUB_BUCKETS; j++) n_hub_src += h[j];
+    // sources with a count in [c, top): the last linear bin also holds everything beyond it, the hubs included
+    uint64_t top = bk0 < PB_HUB_BUCKETS ? ta.thr[0] : 0xFFFFFFFFull;
+    uint64_t want = (nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4);
+    if (want < 4) want = 4;
+    for (int t = 0; t < max_mid && top > want; t++) {
+      uint64_t acc = 0, thr = top;
+      for (uint64_t c = (top < PB_LIN_BINS ? top : PB_LIN_BINS) - 1;; c--) {
+        uint64_t here = hl[c];
+        if (c == PB_LIN_BINS - 1) {  // the open-ended bin: not cut inside; take it whole or not at all
+          if (top <= c) here = 0;
+          else here -= (here >= n_hub_src ? n_hub_src : here);
+        }
+        if (acc + here > mid_cap) break;
+        acc += here;
+        thr = c;
+        if (c <= want) break;
+      }
+      if (thr >= top || acc == 0) break;
+      // a tier of a few thousand sources (a graph without skew: the tail of a Poisson degree distribution) costs every
+      // bin a stream and a table for a fraction of a percent of the edges: a tier has to stand for >= 1/64 of them
+      {
+        unsigned long long est = 0;  // a sampled count of c ~ 16 c out-edges
+        for (uint64_t c = thr; c < (top < PB_LIN_BINS ? top : PB_LIN_BINS); c++) est += 16ull * c * hl[c];
+        if (est * 64ull < nnz) break;
+      }
+      ta.thr[1 + t] = (unsigned)thr;
+      ta.ntiers = 2 + t;
+      top = thr;
+    }
+  }
+  for (int t = 0; t < 1 + PB_MAX_MID; t++) thr_out[t] = ta.thr[t];
+  *ntiers_out = ta.ntiers;
+}
+
 int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint8_t> &cls, DevBuf<uint32_t> &hub_ids,
                   unsigned *n_hubs, int max_mid, DevBuf<uint32_t> *mid_ids, unsigned *n_mid, unsigned min16) {
   *n_hubs = 0;
@@ -692,79 +770,23 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
   GDN_HIP(hipMemcpy(h, hist.p, sizeof(h), hipMemcpyDeviceToHost));
   GDN_HIP(hipMemcpy(&active_rows, nrows.p, 8, hipMemcpyDeviceToHost));
   const uint64_t nbins = ((active_rows + (1ull << log_bin) - 1) >> log_bin) + 1;
-  // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
-  uint64_t per_bin = PB_HUB_MIN_PER_BIN;
-  if (const char *e = gdn_option("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
-  // smallest bucket >= the bucket of `want` whose sources, up to (not including) bucket `top`, number at most `cap`;
-  // PB_HUB_BUCKETS = none
-  auto pick = [&](uint64_t want, unsigned top, uint64_t cap) -> unsigned {
-    if (want < 4) want = 4;
-    if (want > 0x40000000ull) return PB_HUB_BUCKETS;
-    unsigned bk = pb_hub_bucket((unsigned)want);
-    if (pb_hub_bucket_floor(bk) < want) bk++;
-    for (; bk < top; bk++) {
-      uint64_t above = 0;
-      for (unsigned j = bk; j < top; j++) above += h[j];
-      if (above == 0) return PB_HUB_BUCKETS;
-      if (above <= cap) return bk;
-    }
-    return PB_HUB_BUCKETS;
-  };
   PbTierArgs ta;
   memset(&ta, 0, sizeof(ta));
-  // tier 0 = hubs (the slot keeps an unreachable threshold when no source qualifies, so the classes keep their numbers)
-  const unsigned bk0 = pick((nbins * per_bin) >> PB_HUB_SAMPLE_LOG, PB_HUB_BUCKETS, 1u << PB_HUB_LOG);
-  ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
-  ta.cap[0] = 1u << PB_HUB_LOG;
-  ta.ntiers = 1;
-  uint64_t mid16 = min16 ? min16 : PB_MID_MIN_PER_BIN16;
-  if (const char *e = gdn_option("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
-  uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
-  if (const char *e = gdn_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
+  std::vector<unsigned> hl;
   if (max_mid > 0) {
-    // mid tiers: consecutive count ranges [thr[t], thr[t-1]) below the hubs, each filled up to mid_cap sources, down
-    // to the count that stands for mid16 / 16 edges per average bin
     DevBuf<unsigned> lin;
     GDN_TRY(lin.alloc(PB_LIN_BINS));
     GDN_HIP(hipMemset(lin.p, 0, PB_LIN_BINS * 4));
     hipLaunchKernelGGL(pb_hub_hist_lin_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, cnt.p, (size_t)m_global, lin.p);
     GDN_HIP(hipGetLastError());
-    std::vector<unsigned> hl(PB_LIN_BINS);
+    hl.resize(PB_LIN_BINS);
     GDN_HIP(hipMemcpy(hl.data(), lin.p, PB_LIN_BINS * 4, hipMemcpyDeviceToHost));
-    uint64_t n_hub_src = 0;
-    for (unsigned j = bk0; j < PB_HUB_BUCKETS; j++) n_hub_src += h[j];
-    // sources with a count in [c, top): the last linear bin also holds everything beyond it, the hubs included
-    uint64_t top = bk0 < PB_HUB_BUCKETS ? ta.thr[0] : 0xFFFFFFFFull;
-    uint64_t want = (nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4);
-    if (want < 4) want = 4;
-    for (int t = 0; t < max_mid && top > want; t++) {
-      uint64_t acc = 0, thr = top;
-      for (uint64_t c = (top < PB_LIN_BINS ? top : PB_LIN_BINS) - 1;; c--) {
-        uint64_t here = hl[c];
-        if (c == PB_LIN_BINS - 1) {  // the open-ended bin: not cut inside; take it whole or not at all
-          if (top <= c) here = 0;
-          else here -= (here >= n_hub_src ? n_hub_src : here);
-        }
-        if (acc + here > mid_cap) break;
-        acc += here;
-        thr = c;
-        if (c <= want) break;
-      }
-      if (thr >= top || acc == 0) break;
-      // a tier of a few thousand sources (a graph without skew: the tail of a Poisson degree distribution) costs every
-      // bin a stream and a table for a fraction of a percent of the edges: a tier has to stand for >= 1/64 of them
-      {
-        unsigned long long est = 0;  // a sampled count of c ~ 16 c out-edges
-        for (uint64_t c = thr; c < (top < PB_LIN_BINS ? top : PB_LIN_BINS); c++) est += 16ull * c * hl[c];
-        if (est * 64ull < g->nnz) break;
-      }
-      ta.thr[1 + t] = (unsigned)thr;
-      ta.cap[1 + t] = PB_MID_MAX;
-      ta.ntiers = 2 + t;
-      top = thr;
-    }
   }
-  if (bk0 >= PB_HUB_BUCKETS && ta.ntiers == 1) return GDN_OK;
+  pb_choose_tiers(h, max_mid > 0 ? hl.data() : nullptr, nbins, g->nnz, max_mid, min16, ta.thr, &ta.ntiers);
+  ta.cap[0] = 1u << PB_HUB_LOG;
+  for (int t = 1; t < ta.ntiers; t++) ta.cap[t] = PB_MID_MAX;
+  const bool no_hubs = ta.thr[0] == 0xFFFFFFFFu;
+  if (no_hubs && ta.ntiers == 1) return GDN_OK;
   GDN_TRY(cls.alloc((size_t)m_global));
   GDN_TRY(hub_ids.alloc(1u << PB_HUB_LOG));
   ta.ids[0] = hub_ids.p;
@@ -1367,6 +1389,11 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return GDN_OK;
 }
+
+#include "gdn_pbtier.hpp"
+
+// the builder above behind a linkable name (gdn_pr.hip, gdn_spmv.hip); see PbTieredArgs
+int pb_build_tiered_run(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) { return pb_build_tiered(a, p, ts); }
 
 extern "C" {
 

@@ -138,6 +138,21 @@ int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n,
   return GDN_OK;
 }
 
+// the same scan with caller-provided scratch (ws: ceil(n / SCAN_TILE) + 1 u64), no allocation and no synchronisation:
+// the layout builder runs a dozen of them back to back (a hipMalloc / hipFree pair costs 0.2 ms)
+int gdn_exclusive_scan_u32_to_u64_ws(const uint32_t *d_in, eoff_t *d_out, size_t n, eoff_t *ws, hipStream_t s) {
+  if (n == 0) {
+    GDN_HIP(hipMemsetAsync(d_out, 0, sizeof(eoff_t), s));
+    return GDN_OK;
+  }
+  const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, ws);
+  hipLaunchKernelGGL(scan_single_block, dim3(1), dim3(GDN_BLOCK), 0, s, ws, nb);
+  hipLaunchKernelGGL(scan_downsweep, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, ws, d_out, d_out + n);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK) fill_i32_kernel(int32_t *d, int32_t v, size_t n) {
   size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * GDN_BLOCK;

@@ -223,6 +223,42 @@ int pb_mid_finish(PbPlan &layout, unsigned n_src, DevBuf<uint32_t> &rec, DevBuf<
 int pb_order_bins_by_work(PbPlan &main, int n_tiers, const eoff_t *const *tier_bin_ptr, double main_bytes_per_edge,
                           double rec_bytes, double row_bytes);
 
+// ---- round 4: the main layout AND its record tiers from one gather pass over the edges (gdn_pbtier.hpp, built into
+// gdn_build.hip).  Replaces pb_pick_tiers + one pb_build per layout + pb_mid_finish for in-CSR plans.
+struct PbTierSet {
+  int n = 0;
+  struct Tier {
+    unsigned n_src = 0;
+    uint64_t nnz = 0;
+    DevBuf<uint32_t> ids;     // original (label) id of source k, ascending
+    DevBuf<uint32_t> rec;     // bin-major records (source index << 14 | row), pad records = n_src << 14
+    DevBuf<eoff_t> bin_ptr;   // nbins + 1 record offsets (multiples of 16)
+  } t[PB_MAX_REC_TIERS];
+  bool first_is_hub = false;  // t[0] is the hub tier (<= 2^15 sources), else the mid tiers start at t[0]
+};
+
+struct PbTieredArgs {
+  const eoff_t *rowptr = nullptr;   // m_rows + 1, rows in the layout's vertex space
+  const vid_t *colidx = nullptr;    // caller's column ids ...
+  const eoff_t *colmap = nullptr;   // ... and (nullable) their map into the layout's vertex space: m_raw + 1 entries, the
+  int32_t m_raw = 0;                //     exclusive scan of the live flags (needs src_count)
+  int32_t m_rows = 0, m_global = 0;
+  uint64_t nnz = 0;
+  const int32_t *src_count = nullptr;  // nullable, m_global: out-edge count of every source (> 0 for every column that occurs)
+  int log_chunk = 15, log_bin = 14;
+  unsigned pad = 32;
+  int log_group = 5;
+  bool tiers = true;
+  int max_mid = PB_MAX_MID;
+  unsigned min16 = 1;
+  int bin_balance_log = PB_MAX_LOG_BIN;
+  bool alloc_vals = true;
+};
+
+// GDN_OK; 1 = shape outside the builder's limits (nothing built: use pb_build); 2 = a column occurs whose src_count is 0
+// (repeat with src_count = nullptr); < 0 error
+int pb_build_tiered_run(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts);
+
 // the rows with the most in-edges (gdn_build.hip): at most max_rows rows with >= min_deg in-edges each
 uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full);  // vertices per slice after round balancing
 int pb_pick_hub_rows(const gdn_graph *in_csr, unsigned max_rows, uint64_t min_deg, DevBuf<uint8_t> &dcls,

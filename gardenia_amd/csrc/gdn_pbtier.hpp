@@ -1,0 +1,1134 @@
+// gdn_pbtier.hpp -- the propagation-blocked layout of gdn_pb.hpp AND its record tiers from ONE gather pass over the edges
+// (round 4).  Included by gdn_build.hip (shares its histogram / sampling kernels); nothing here is on a solver's hot path.
+//
+// Why: pb_build (gdn_build.hip) makes one layout per call -- mark pass, key pass, global 8-byte-key radix sort -- and a
+// PageRank plan is six layouts (main + hubs + four mid tiers): ~480 ps per edge, 50 passes over the edges, so the
+// one-call drop-ins (gdn_pr = PRSolver, src/pr/main.cc:19) never got the blocked layout the reference builds inside its
+// solver (src/pr/push_pb.cu:271, include/prop_blocking.h:29-65).  Here the work is what it has to be:
+//
+//   vertex phase   per source: class (0 main, 1 hubs, 2.. mid tiers) and index inside the class, all classes ranked by
+//                  ONE two-level scan (block counts, scan of the block counts, in-block ranks); per row: compact index,
+//                  bin, row-in-bin; a bitmap with one bit per edge marks the first edge of every row.
+//                  smap[source id] = class << 29 | index -- the only table the edges gather from.
+//   pt_keygen      ONE pass over the edges in CSR order, a workgroup per destination bin (bins are contiguous edge
+//                  ranges of an in-CSR), 64 consecutive edges per wave step: code S[e] = smap[col[e]] (THE divergent
+//                  gather of the build: ~18 ps per edge at RMAT-27, everything else streams), row-in-bin R[e] from the
+//                  popcount of the row-start bitmap, tile counts (bin x chunk) and tier counts in LDS.
+//   (scans: padded tile offsets in chunk-major and bin-major order, segment offsets, tier bin offsets)
+//   pt_split       stable partition of every bin's edges by (chunk >> 3 | tier): a workgroup walks its bin in steps of
+//                  16 K edges, ranks them per wave by ballot matching, puts the step in digit order in LDS and writes
+//                  runs.  Main-layout edges become 32-bit items (slot, row, chunk & 7), tier edges their final records.
+//   pt_tiles       a wave per (bin, 8 chunks) segment: stable split by the last 3 chunk bits straight into V (contiguous)
+//                  and U (one run per tile).
+//   pt_radix       the records of a (bin, tier) sorted by source: two stable passes of <= 10 bits with the same LDS staging
+//                  (CSR order is (row, source); phase B wants (source, row) so that its table reads fall into few lines).
+//
+// Order inside a tile is (row, source) as pb_build makes it, inside a bin's record stream (source, row): the layout
+// is deterministic, and no result depends on it anyway (integer accumulation, gdn_pb.hpp).
+// Limits (the caller falls back to pb_build): <= 8192 source chunks, bins of <= 2^14 rows, in-CSR orientation.
+#pragma once
+
+#define PT_THREADS 1024
+#define PT_WAVES (PT_THREADS / 64)
+#define PT_IPT 16
+#define PT_STEP (PT_THREADS * PT_IPT)  // 16384 edges per step of a partition
+#define PT_MAX_DIGITS 1024
+#define PT_LOW_BITS 3                  // chunk bits left to pt_tiles (slot 15 + row 14 + 3 = one 32-bit item)
+#define PT_INACTIVE 0xFFFFFFFFu
+#define PT_CLASS_SHIFT 29
+#define PT_IDX_MASK 0x1FFFFFFFu
+#define PT_MAX_CHUNKS 8192u
+#define PT_VTILE 2048                  // vertices per workgroup of the vertex-phase kernels (256 threads x 8)
+#define PT_NCLS (1 + PB_MAX_REC_TIERS) // class 0 + record tiers
+static_assert(PT_NCLS <= 6, "pt_src_assign_kernel packs the class counts of a thread into two u64 of three 16-bit fields");
+
+// ---- scratch: ONE device block per phase, bump-allocated (a hipFree costs 0.16 ms whatever the size, a 16 GB hipMalloc
+// 0.8 s -- the stream-ordered pool 6 ms: profiles/r04_malloc_probe.txt)
+struct PtArena {
+  char *base = nullptr;
+  size_t cap = 0, used = 0;
+  bool pooled = false;
+  int init(size_t bytes) {
+    release();
+    bytes += 4096;
+    hipError_t e;
+    pooled = bytes >= ((size_t)3 << 30);
+    if (pooled) e = hipMallocAsync((void **)&base, bytes, 0);
+    else e = hipMalloc((void **)&base, bytes);
+    if (e != hipSuccess) {
+      base = nullptr;
+      (void)hipGetLastError();
+      gdn_set_error("layout build: %zu bytes of scratch -> %s", bytes, hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+    cap = bytes;
+    used = 0;
+    return GDN_OK;
+  }
+  template <class T>
+  T *get(size_t n) {
+    const size_t at = (used + 255) & ~(size_t)255;
+    const size_t need = (n ? n : 1) * sizeof(T);
+    if (at + need > cap) return nullptr;
+    used = at + need;
+    return reinterpret_cast<T *>(base + at);
+  }
+  void release() {
+    if (base) {
+      if (pooled) (void)hipFreeAsync(base, 0);
+      else (void)hipFree(base);
+    }
+    base = nullptr;
+    cap = used = 0;
+  }
+  ~PtArena() { release(); }
+};
+static inline size_t pt_pad256(size_t bytes) { return (bytes + 511) & ~(size_t)255; }
+
+// ---- device-wide scans without allocation or synchronisation: rows of u32 block counts scanned by one workgroup per row
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_scan_rows_kernel(uint32_t *__restrict__ data, unsigned n, uint32_t *__restrict__ totals) {
+  __shared__ uint32_t s[GDN_WAVES_PER_BLOCK];
+  uint32_t *row = data + (size_t)blockIdx.x * n;
+  uint32_t carry = 0;
+  for (unsigned base = 0; base < n; base += GDN_BLOCK) {
+    const unsigned i = base + threadIdx.x;
+    const uint32_t v = i < n ? row[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = gdn_block_excl_scan(v, s, &total);
+    if (i < n) row[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+// u32 -> u64 exclusive scan, out[n] = total; ws: ceil(n / 2048) + 1 u64.  Three launches on the null stream.
+int gdn_exclusive_scan_u32_to_u64_ws(const uint32_t *d_in, eoff_t *d_out, size_t n, eoff_t *ws, hipStream_t s);
+
+// ---- vertex phase ---------------------------------------------------------------------------------------------------
+struct PtSrcArgs {
+  const int32_t *src_count;  // exact out-edge counts (trusted superset of "occurs as a column"), or nullptr:
+  const uint32_t *cnt16;     //   sampled counts (pb_hub_sample_kernel) ...
+  const uint32_t *mark;      //   ... and exact marks
+  unsigned thr[PB_MAX_REC_TIERS];  // sampled-count units, descending; tier t: count >= thr[t]
+  int ntiers;
+  unsigned n;  // sources
+};
+// class of source s: 0 main, 1 + t record tier t, PT_NCLS = inactive
+__device__ __forceinline__ int pt_class_of(const PtSrcArgs &a, unsigned s) {
+  unsigned c16;
+  bool act;
+  if (a.src_count) {
+    const int32_t d = a.src_count[s];
+    act = d > 0;
+    c16 = act ? (unsigned)d >> PB_HUB_SAMPLE_LOG : 0u;
+  } else {
+    act = a.mark[s] != 0u;
+    c16 = a.cnt16[s];
+  }
+  if (!act) return PT_NCLS;
+  int k = 0;
+  for (int t = a.ntiers - 1; t >= 0; t--)
+    if (c16 >= a.thr[t]) k = t + 1;
+  return k;
+}
+
+// block counts per class: bc[k * nb + block]
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_src_count_kernel(PtSrcArgs a, unsigned nb, uint32_t *__restrict__ bc) {
+  __shared__ unsigned s_n[PT_NCLS];
+  if (threadIdx.x < PT_NCLS) s_n[threadIdx.x] = 0u;
+  __syncthreads();
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  unsigned cnt[PT_NCLS];
+#pragma unroll
+  for (int k = 0; k < PT_NCLS; k++) cnt[k] = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned s = base + (unsigned)i;
+    if (s < a.n) {
+      const int k = pt_class_of(a, s);
+#pragma unroll
+      for (int q = 0; q < PT_NCLS; q++) cnt[q] += (k == q) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PT_NCLS; k++) {
+    const unsigned t = gdn_wave_sum(cnt[k]);
+    if (gdn_lane() == 0 && t) atomicAdd(&s_n[k], t);
+  }
+  __syncthreads();
+  if (threadIdx.x < PT_NCLS) bc[(size_t)threadIdx.x * nb + blockIdx.x] = s_n[threadIdx.x];
+}
+
+// ranks: smap[s] = class << 29 | index (class 0: chunk << log_chunk | slot), the ascending id list of every tier, the
+// activity bitmap of the main layout's sources and the first id of every chunk
+struct PtSrcOut {
+  uint32_t *smap;
+  uint32_t *ids[PB_MAX_REC_TIERS];
+  uint8_t *src_bits8;  // byte view of the bitmap (bit i of word w <-> id 32 w + i, little endian)
+  uint32_t *chunk_lo;
+  unsigned per_c;
+  int log_chunk;
+};
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_src_assign_kernel(PtSrcArgs a, unsigned nb, const uint32_t *__restrict__ bc, PtSrcOut o) {
+  __shared__ unsigned long long s_scan[GDN_WAVES_PER_BLOCK];
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  int cls[8];
+  // in-thread counts, packed 16 bits per class: A = classes 0..2, B = classes 3..5
+  unsigned long long pa = 0ull, pb = 0ull;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned s = base + (unsigned)i;
+    cls[i] = s < a.n ? pt_class_of(a, s) : PT_NCLS;
+    if (cls[i] < 3) pa += 1ull << (16 * cls[i]);
+    else if (cls[i] < PT_NCLS) pb += 1ull << (16 * (cls[i] - 3));
+  }
+  unsigned long long ta, tb;
+  const unsigned long long ea = gdn_block_excl_scan(pa, s_scan, &ta);
+  __syncthreads();
+  const unsigned long long eb = gdn_block_excl_scan(pb, s_scan, &tb);
+  unsigned run[PT_NCLS];
+#pragma unroll
+  for (int k = 0; k < PT_NCLS; k++) {
+    const unsigned long long e = k < 3 ? ea : eb;
+    run[k] = bc[(size_t)k * nb + blockIdx.x] + (unsigned)((e >> (16 * (k % 3))) & 0xFFFFull);
+  }
+  unsigned bits = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned s = base + (unsigned)i;
+    if (s >= a.n) continue;
+    const int k = cls[i];
+    unsigned code = PT_INACTIVE;
+    if (k == 0) {
+      const unsigned r = run[0]++;
+      const unsigned c = r / o.per_c, sl = r - c * o.per_c;
+      code = (c << o.log_chunk) | sl;
+      if (sl == 0u) o.chunk_lo[c] = c ? s : 0u;  // chunk 0 also owns the inactive ids in front of its first source
+      bits |= 1u << i;
+    } else if (k < PT_NCLS) {
+      unsigned r = 0;
+#pragma unroll
+      for (int q = 1; q < PT_NCLS; q++)
+        if (k == q) r = run[q]++;
+      code = ((unsigned)k << PT_CLASS_SHIFT) | r;
+      o.ids[k - 1][r] = s;
+    }
+    o.smap[s] = code;
+  }
+  if (base < a.n) o.src_bits8[base >> 3] = (uint8_t)bits;
+}
+
+// smap over the caller's (raw) column ids when the layout works in a relabelled vertex space (squished PageRank plan):
+// colmap = exclusive scan of the live flags, so id c is live iff colmap[c + 1] > colmap[c]
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_smap_raw_kernel(const eoff_t *__restrict__ colmap, unsigned m_raw, const uint32_t *__restrict__ smap_l,
+                   uint32_t *__restrict__ smap_raw) {
+  const unsigned c = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (c >= m_raw) return;
+  const eoff_t a = colmap[c], b = colmap[c + 1];
+  smap_raw[c] = b > a ? smap_l[a] : PT_INACTIVE;
+}
+
+// rows: block counts of the rows that have entries
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_row_count_kernel(const eoff_t *__restrict__ rowptr, unsigned m, uint32_t *__restrict__ bc) {
+  __shared__ unsigned s_n;
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  unsigned c = 0;
+  if (base < m) {
+    eoff_t prev = rowptr[base];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const unsigned r = base + (unsigned)i;
+      if (r < m) {
+        const eoff_t nx = rowptr[r + 1];
+        c += nx > prev ? 1u : 0u;
+        prev = nx;
+      }
+    }
+  }
+  const unsigned t = gdn_wave_sum(c);
+  if (gdn_lane() == 0 && t) atomicAdd(&s_n, t);
+  __syncthreads();
+  if (threadIdx.x == 0) bc[blockIdx.x] = s_n;
+}
+
+struct PtRowOut {
+  eoff_t *crp;         // n_dst + 1: first edge of the k-th row with entries
+  eoff_t *bin_e;       // nbins + 1: first edge of every bin
+  uint32_t *bin_lo;    // nbins + 1: first row id of every bin
+  uint8_t *dst_bits8;
+  uint32_t *rowstart;  // one bit per edge: set at the first edge of every row with entries
+  unsigned per_b;
+};
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_row_assign_kernel(const eoff_t *__restrict__ rowptr, unsigned m, const uint32_t *__restrict__ bc, PtRowOut o) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK];
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  eoff_t st[9];
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const unsigned r = base + (unsigned)i;
+    st[i] = r <= m ? rowptr[r] : 0;
+  }
+  unsigned act = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (base + (unsigned)i < m && st[i + 1] > st[i]) {
+      act |= 1u << i;
+      c++;
+    }
+  unsigned total;
+  unsigned k = bc[blockIdx.x] + gdn_block_excl_scan(c, s_scan, &total);
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (!((act >> i) & 1u)) continue;
+    const unsigned r = base + (unsigned)i;
+    o.crp[k] = st[i];
+    const unsigned b = k / o.per_b;
+    if (k - b * o.per_b == 0u) {
+      o.bin_lo[b] = b ? r : 0u;
+      o.bin_e[b] = st[i];
+    }
+    atomicOr(&o.rowstart[st[i] >> 5], 1u << (st[i] & 31u));
+    k++;
+  }
+  if (base < m) o.dst_bits8[base >> 3] = (uint8_t)act;
+}
+
+static __global__ void pt_ends_kernel(uint32_t *chunk_lo, unsigned nchunks, unsigned n_src_ids, uint32_t *bin_lo, unsigned nbins,
+                                      unsigned m_rows, eoff_t *bin_e, eoff_t *crp, eoff_t n_dst, eoff_t nnz, int have_src, int have_rows) {
+  if (threadIdx.x == 0) {
+    chunk_lo[nchunks] = n_src_ids;
+    if (!have_src) chunk_lo[0] = 0u;
+    bin_lo[nbins] = m_rows;
+    bin_e[nbins] = nnz;
+    crp[n_dst] = nnz;
+    if (!have_rows) {
+      bin_lo[0] = 0u;
+      bin_e[0] = 0;
+    }
+  }
+}
+
+// exact marks of the columns that occur (only without trusted counts)
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_mark_kernel(const vid_t *__restrict__ colidx, eoff_t nnz, uint32_t *__restrict__ mark) {
+  for (eoff_t e = (eoff_t)blockIdx.x * GDN_BLOCK + threadIdx.x; e < nnz; e += (eoff_t)gridDim.x * GDN_BLOCK)
+    mark[__builtin_nontemporal_load(colidx + e)] = 1u;  // benign race: everybody stores 1
+}
+// src_count >> 4 as the "sampled" count of the histogram kernels
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_count16_kernel(const int32_t *__restrict__ deg, unsigned n, uint32_t *__restrict__ out) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) out[i] = deg[i] > 0 ? (uint32_t)deg[i] >> PB_HUB_SAMPLE_LOG : 0u;
+}
+
+// ---- pt_keygen: the ONE gather pass ---------------------------------------------------------------------------------
+struct PtKeyArgs {
+  const vid_t *colidx;
+  const uint32_t *smap;           // over the column ids of colidx
+  const unsigned long long *rowstart;  // 64-bit view of the row-start bitmap
+  const eoff_t *bin_e, *crp;
+  eoff_t n_dst;
+  unsigned per_b, nchunks;
+  int log_chunk, ntiers;
+  uint32_t *S;
+  uint16_t *R;
+  uint32_t *tile_cnt;   // nbins x nchunks
+  uint32_t *tier_cnt;   // nbins x 8
+  unsigned *errflag;
+};
+static __global__ void __launch_bounds__(PT_THREADS)
+pt_keygen_kernel(PtKeyArgs a) {
+  extern __shared__ unsigned s_tile[];
+  __shared__ unsigned s_tier[8];
+  const unsigned b = blockIdx.x;
+  for (unsigned i = threadIdx.x; i < a.nchunks; i += PT_THREADS) s_tile[i] = 0u;
+  if (threadIdx.x < 8) s_tier[threadIdx.x] = 0u;
+  __syncthreads();
+  const eoff_t E0 = a.bin_e[b], E1 = a.bin_e[b + 1];
+  const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
+  unsigned bad = 0u;
+  if (E1 > E0) {
+    const eoff_t w0 = E0 >> 6, w1 = (E1 - 1) >> 6;  // 64-edge words of the bin, inclusive
+    const eoff_t per = (w1 - w0 + PT_WAVES) / PT_WAVES;
+    const eoff_t wa = w0 + (eoff_t)w * per, wb = wa + per < w1 + 1 ? wa + per : w1 + 1;
+    if (wa < wb) {
+      const eoff_t kb0 = (eoff_t)b * a.per_b, kb1 = kb0 + a.per_b < a.n_dst ? kb0 + a.per_b : a.n_dst;
+      // rows of this bin that start in front of the wave's first edge
+      eoff_t x = wa << 6;
+      if (x < E0) x = E0;
+      eoff_t lo = kb0, hi = kb1;
+      while (lo < hi) {
+        const eoff_t mid = lo + ((hi - lo) >> 1);
+        if (a.crp[mid] < x) lo = mid + 1;
+        else hi = mid;
+      }
+      eoff_t rb = lo;
+      const unsigned long long le = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);
+      const unsigned long long lt = gdn_lanemask_lt();
+      unsigned tcnt[PB_MAX_REC_TIERS];
+#pragma unroll
+      for (int t = 0; t < PB_MAX_REC_TIERS; t++) tcnt[t] = 0u;
+      constexpr int UNR = 4;
+      for (eoff_t wi = wa; wi < wb; wi += UNR) {
+        unsigned long long bits[UNR];
+        vid_t col[UNR];
+        uint32_t code[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+          const eoff_t wj = wi + r, e = (wj << 6) + lane;
+          ok[r] = wj < wb && e >= E0 && e < E1;
+          bits[r] = wj < wb ? a.rowstart[wj] : 0ull;
+          col[r] = ok[r] ? __builtin_nontemporal_load(a.colidx + e) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; r++) code[r] = ok[r] ? a.smap[col[r]] : 0u;
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+          const eoff_t wj = wi + r;
+          if (wj >= wb) break;  // wave-uniform
+          unsigned long long bt = bits[r];
+          if ((wj << 6) < E0) bt &= ~0ull << (E0 & 63u);
+          if (((wj + 1) << 6) > E1) bt &= ~0ull >> (64u - (unsigned)(E1 & 63u));
+          const unsigned rib = (unsigned)(rb + (eoff_t)__popcll(bt & le) - 1 - kb0);
+          rb += (eoff_t)__popcll(bt);
+          const eoff_t e = (wj << 6) + lane;
+          const uint32_t c = code[r];
+          const unsigned k = c >> PT_CLASS_SHIFT;
+          if (ok[r]) {
+            a.S[e] = c;
+            a.R[e] = (uint16_t)rib;
+            if (c == PT_INACTIVE) bad = 1u;
+          }
+          // tile counts: ONE LDS atomic per run of equal chunks in the wave (a hub row is hundreds of consecutive
+          // edges into one chunk: 64 lanes on one counter serialise)
+          const unsigned key = (ok[r] && k == 0u) ? (c >> a.log_chunk) : 0xFFFFFFFFu;
+          const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+          const bool head = lane == 0u || prev != key;
+          const unsigned long long heads = __ballot(head);
+          if (head && key != 0xFFFFFFFFu) {
+            const unsigned long long after = lane == 63u ? 0ull : heads >> (lane + 1u);
+            const unsigned len = after ? (unsigned)__ffsll((long long)after) : 64u - lane;
+            atomicAdd(&s_tile[key], len);
+          }
+#pragma unroll
+          for (int t = 0; t < PB_MAX_REC_TIERS; t++)
+            if (t < a.ntiers) tcnt[t] += (unsigned)__popcll(__ballot(ok[r] && c != PT_INACTIVE && k == (unsigned)(t + 1)));
+          (void)lt;
+        }
+      }
+      if (lane == 0u) {
+#pragma unroll
+        for (int t = 0; t < PB_MAX_REC_TIERS; t++)
+          if (t < a.ntiers && tcnt[t]) atomicAdd(&s_tier[t], tcnt[t]);
+      }
+    }
+  }
+  if (bad) *a.errflag = 1u;
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < a.nchunks; i += PT_THREADS) a.tile_cnt[(size_t)b * a.nchunks + i] = s_tile[i];
+  if (threadIdx.x < 8) a.tier_cnt[(size_t)b * 8 + threadIdx.x] = s_tier[threadIdx.x];
+}
+
+// ---- offsets --------------------------------------------------------------------------------------------------------
+// padded tile sizes in both tile orders + the (unpadded) sizes of the (bin, 8 chunks) segments of pt_split's output
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_tile_sizes_kernel(const uint32_t *__restrict__ tile_cnt, unsigned nchunks, unsigned nbins, unsigned pad, unsigned d1,
+                     uint32_t *__restrict__ psz_c, uint32_t *__restrict__ psz_b, uint32_t *__restrict__ segsz) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;  // bin-major tile index
+  if (t < (unsigned long long)nchunks * nbins) {
+    const unsigned b = (unsigned)(t / nchunks), c = (unsigned)(t % nchunks);
+    const uint32_t sz = (tile_cnt[t] + (pad - 1u)) & ~(pad - 1u);
+    psz_b[t] = sz;
+    psz_c[(unsigned long long)c * nbins + b] = sz;
+  }
+  if (t < (unsigned long long)d1 * nbins) {
+    const unsigned b = (unsigned)(t / d1), d = (unsigned)(t % d1);
+    uint32_t s = 0;
+    for (unsigned k = 0; k < (1u << PT_LOW_BITS); k++) {
+      const unsigned c = (d << PT_LOW_BITS) + k;
+      if (c < nchunks) s += tile_cnt[(unsigned long long)b * nchunks + c];
+    }
+    segsz[t] = s;
+  }
+}
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_tier_sizes_kernel(const uint32_t *__restrict__ tier_cnt, unsigned nbins, int ntiers, uint32_t *__restrict__ tsz /*ntiers x nbins*/) {
+  const unsigned b = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (b >= nbins) return;
+  for (int t = 0; t < ntiers; t++) tsz[(size_t)t * nbins + b] = (tier_cnt[(size_t)b * 8 + t] + 15u) & ~15u;
+}
+
+// ---- stable partition of a range of items by a digit, staged through LDS ---------------------------------------------
+// lanes of the wave whose (valid) digit equals mine
+__device__ __forceinline__ unsigned long long pt_match(unsigned d, bool valid, int bits) {
+  unsigned long long peers = __ballot(valid);
+  for (int b = 0; b < bits; b++) {
+    const bool one = (d >> b) & 1u;
+    const unsigned long long m = __ballot(one && valid);
+    peers &= one ? m : ~m;
+  }
+  return peers;
+}
+struct PtStage {
+  uint32_t *stage;           // PT_STEP items in digit order
+  unsigned short *dig;       // their digits
+  unsigned short *wc;        // PT_WAVES x nd: per wave and digit, count -> exclusive prefix over the waves
+  unsigned *start, *tot;     // nd: first position of a digit in the staged order, its count in this step
+  unsigned long long *goff;  // nd: where the digit's next item goes in `out`
+  unsigned *scr;             // PB_WAVES + 1 (pb_block_excl_scan)
+};
+__device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned nd) {
+  PtStage s;
+  s.stage = reinterpret_cast<uint32_t *>(lds);
+  s.goff = reinterpret_cast<unsigned long long *>(lds + (size_t)PT_STEP * 4);
+  s.start = reinterpret_cast<unsigned *>(s.goff + nd);
+  s.tot = s.start + nd;
+  s.scr = s.tot + nd;
+  s.dig = reinterpret_cast<unsigned short *>(s.scr + PT_WAVES + 2);
+  s.wc = s.dig + PT_STEP;
+  return s;
+}
+static inline size_t pt_stage_bytes(unsigned nd) {
+  return (size_t)PT_STEP * 4 + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_STEP * 2 + (size_t)PT_WAVES * nd * 2 + 64;
+}
+// Walks items [0, n) in steps of PT_STEP.  load(i, item, digit) for i < n.  The caller has set st.goff[d] (behind a
+// barrier) and zeroed st.wc.  Every thread of the workgroup must call.
+template <class Load>
+__device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, int dbits, uint32_t *__restrict__ out,
+                                             const PtStage &st, Load load) {
+  const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
+  const unsigned long long lt = gdn_lanemask_lt();
+  unsigned short *wcw = st.wc + (size_t)w * nd;
+  for (unsigned long long base = 0; base < n; base += PT_STEP) {
+    const unsigned cnt = (unsigned)(n - base < (unsigned long long)PT_STEP ? n - base : (unsigned long long)PT_STEP);
+    uint32_t it[PT_IPT];
+    unsigned short dg[PT_IPT], rk[PT_IPT];
+#pragma unroll
+    for (int j = 0; j < PT_IPT; j++) {
+      const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;  // a wave owns 1024 consecutive items of the step
+      it[j] = 0u;
+      unsigned d = 0u;
+      if (i < cnt) load(base + i, it[j], d);
+      dg[j] = (unsigned short)d;
+    }
+#pragma unroll
+    for (int j = 0; j < PT_IPT; j++) {
+      const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;
+      const bool valid = i < cnt;
+      const unsigned d = dg[j];
+      const unsigned long long peers = pt_match(d, valid, dbits);
+      const unsigned r = (unsigned)__popcll(peers & lt);
+      unsigned old = 0u;
+      if (valid && r == 0u) {
+        old = wcw[d];
+        wcw[d] = (unsigned short)(old + (unsigned)__popcll(peers));
+      }
+      const int leader = valid ? __ffsll((long long)peers) - 1 : (int)lane;
+      old = (unsigned)__shfl((int)old, leader, 64);
+      rk[j] = (unsigned short)(old + r);
+    }
+    __syncthreads();
+    // per digit: counts of the waves -> exclusive prefix over the waves, total of the step
+    unsigned mine = 0u;
+    if (threadIdx.x < nd) {
+      unsigned acc = 0u;
+#pragma unroll
+      for (int ww = 0; ww < PT_WAVES; ww++) {
+        const unsigned c = st.wc[(size_t)ww * nd + threadIdx.x];
+        st.wc[(size_t)ww * nd + threadIdx.x] = (unsigned short)acc;
+        acc += c;
+      }
+      mine = acc;
+      st.tot[threadIdx.x] = acc;
+    }
+    unsigned total;
+    const unsigned ex = pb_block_excl_scan(mine, st.scr, &total);
+    if (threadIdx.x < nd) st.start[threadIdx.x] = ex;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT_IPT; j++) {
+      const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;
+      if (i < cnt) {
+        const unsigned d = dg[j];
+        const unsigned pos = st.start[d] + wcw[d] + rk[j];
+        st.stage[pos] = it[j];
+        st.dig[pos] = (unsigned short)d;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PT_IPT; j++) {
+      const unsigned pos = (unsigned)j * PT_THREADS + threadIdx.x;
+      if (pos < cnt) {
+        const unsigned d = st.dig[pos];
+        out[st.goff[d] + (pos - st.start[d])] = st.stage[pos];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < nd) {
+      st.goff[threadIdx.x] += st.tot[threadIdx.x];
+#pragma unroll
+      for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// pt_split: a bin's edges -> main-layout items by (chunk >> 3) and tier records by tier, all into X
+struct PtSplitArgs {
+  const uint32_t *S;
+  const uint16_t *R;
+  const eoff_t *bin_e;
+  const eoff_t *segoff;                   // nbins x d1 (+1): item offsets of the (bin, digit) segments in X
+  const eoff_t *tier_ptr[PB_MAX_REC_TIERS];  // nbins + 1 record offsets (multiples of 16) per tier
+  eoff_t tier_base[PB_MAX_REC_TIERS];     // where tier t's records start in X
+  const uint32_t *order;                  // bins, largest first
+  uint32_t *X;
+  unsigned d1;
+  int ntiers, log_chunk, dbits;
+};
+static __global__ void __launch_bounds__(PT_THREADS)
+pt_split_kernel(PtSplitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const unsigned nd = a.d1 + (unsigned)a.ntiers;
+  const PtStage st = pt_stage_carve(s_raw, nd);
+  const unsigned b = a.order[blockIdx.x];
+  if (threadIdx.x < nd) {
+    st.goff[threadIdx.x] = threadIdx.x < a.d1 ? a.segoff[(size_t)b * a.d1 + threadIdx.x]
+                                               : a.tier_base[threadIdx.x - a.d1] + a.tier_ptr[threadIdx.x - a.d1][b];
+#pragma unroll
+    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+  }
+  __syncthreads();
+  const eoff_t E0 = a.bin_e[b], E1 = a.bin_e[b + 1];
+  const uint32_t *S = a.S + E0;
+  const uint16_t *R = a.R + E0;
+  const unsigned slot_mask = (1u << a.log_chunk) - 1u;
+  const int lc = a.log_chunk;
+  const unsigned d1 = a.d1;
+  pt_partition(E1 - E0, nd, a.dbits, a.X, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+    const uint32_t c = __builtin_nontemporal_load(S + i);
+    const unsigned row = __builtin_nontemporal_load(R + i);
+    const unsigned k = c >> PT_CLASS_SHIFT;
+    if (k == 0u) {
+      const unsigned chunk = c >> lc;
+      d = chunk >> PT_LOW_BITS;
+      item = ((c & slot_mask) << 17) | (row << PT_LOW_BITS) | (chunk & ((1u << PT_LOW_BITS) - 1u));
+    } else {
+      d = d1 + k - 1u;
+      item = ((c & PT_IDX_MASK) << PB_MID_ROW_BITS) | row;
+    }
+  });
+}
+
+// pt_tiles: a wave per (bin, 8 chunks) segment of X -> V (bin-major) and U (chunk-major)
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segoff, unsigned d1, unsigned nbins,
+                unsigned nchunks, const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
+                uint16_t *__restrict__ V) {
+  const unsigned long long seg = ((unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  if (seg >= (unsigned long long)d1 * nbins) return;
+  const unsigned b = (unsigned)(seg / d1), d = (unsigned)(seg % d1), lane = gdn_lane();
+  const eoff_t s0 = segoff[seg], s1 = segoff[seg + 1];
+  if (s1 == s0) return;
+  // lane k < 8 holds the tile offsets of chunk 8 d + k
+  eoff_t offu = 0, offv = 0;
+  const unsigned cl = (d << PT_LOW_BITS) + (lane & 7u);
+  if (cl < nchunks) {
+    offu = pu[(unsigned long long)cl * nbins + b];
+    offv = pv[(unsigned long long)b * nchunks + cl];
+  }
+  const unsigned long long lt = gdn_lanemask_lt();
+  unsigned basek[1 << PT_LOW_BITS];
+#pragma unroll
+  for (int k = 0; k < (1 << PT_LOW_BITS); k++) basek[k] = 0u;
+  for (eoff_t i0 = s0; i0 < s1; i0 += 64) {
+    const eoff_t i = i0 + lane;
+    const bool valid = i < s1;
+    const uint32_t item = valid ? __builtin_nontemporal_load(X + i) : 0u;
+    const unsigned low = item & ((1u << PT_LOW_BITS) - 1u);
+    unsigned rank = 0u;
+#pragma unroll
+    for (int k = 0; k < (1 << PT_LOW_BITS); k++) {
+      const unsigned long long mk = __ballot(valid && low == (unsigned)k);
+      if (low == (unsigned)k) rank = basek[k] + (unsigned)__popcll(mk & lt);
+      basek[k] += (unsigned)__popcll(mk);
+    }
+    const eoff_t ou = (eoff_t)__shfl((long long)offu, (int)low, 64), ov = (eoff_t)__shfl((long long)offv, (int)low, 64);
+    if (valid) {
+      U[ou + rank] = (uint16_t)(item >> 17);
+      V[ov + rank] = (uint16_t)((item >> PT_LOW_BITS) & ((1u << PB_MID_ROW_BITS) - 1u));
+    }
+  }
+}
+
+// pt_radix: one stable pass over the records of every (bin) segment of ONE tier by bits [shift, shift + bits) of the record
+struct PtRadixArgs {
+  const uint32_t *in;
+  uint32_t *out;
+  const eoff_t *ptr;          // nbins + 1 record offsets (the same in `in` and `out`)
+  const uint32_t *tier_cnt;   // nbins x 8
+  const uint32_t *order;
+  int tier, shift, bits;
+  int last;                   // final pass: pad records behind the segment
+  uint32_t zrec;
+};
+static __global__ void __launch_bounds__(PT_THREADS)
+pt_radix_kernel(PtRadixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const unsigned nd = 1u << a.bits;
+  const PtStage st = pt_stage_carve(s_raw, nd);
+  const unsigned b = a.order[blockIdx.x];
+  const eoff_t p0 = a.ptr[b];
+  const unsigned n = a.tier_cnt[(size_t)b * 8 + a.tier];
+  const uint32_t *in = a.in + p0;
+  const unsigned mask = nd - 1u;
+  // histogram of the segment (st.tot doubles as the counter array)
+  if (threadIdx.x < nd) {
+    st.tot[threadIdx.x] = 0u;
+#pragma unroll
+    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < n; i += PT_THREADS) atomicAdd(&st.tot[(in[i] >> a.shift) & mask], 1u);
+  __syncthreads();
+  unsigned total;
+  const unsigned mine = threadIdx.x < nd ? st.tot[threadIdx.x] : 0u;
+  const unsigned ex = pb_block_excl_scan(mine, st.scr, &total);
+  if (threadIdx.x < nd) st.goff[threadIdx.x] = p0 + ex;
+  __syncthreads();
+  const int shift = a.shift;
+  pt_partition(n, nd, a.bits, a.out, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+    item = in[i];
+    d = (item >> shift) & mask;
+  });
+  if (a.last) {
+    const unsigned npad = (n + 15u) & ~15u;
+    for (unsigned i = n + threadIdx.x; i < npad; i += PT_THREADS) a.out[p0 + i] = a.zrec;
+  }
+}
+
+// ---- small kernels of the offsets phase (the forms of gdn_build.hip's pb_build on counts instead of sorted keys)
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_sizes_from_ptr_kernel(const eoff_t *__restrict__ ptr, unsigned n, eoff_t *__restrict__ sz) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) sz[i] = ptr[i + 1] - ptr[i];
+}
+
+#define PT_CHECK_PTR(p)                                              \
+  do {                                                               \
+    if (!(p)) {                                                      \
+      gdn_set_error("layout build: scratch arena too small (%s:%d)", __FILE__, __LINE__); \
+      return GDN_ERR_INVALID;                                        \
+    }                                                                \
+  } while (0)
+
+// GDN_ERR_UNSUPPORTED-like: returns 1 (positive) when the shape is outside the limits above and nothing was built
+static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
+  GDN_REQUIRE(a.rowptr && (a.colidx || a.nnz == 0) && a.m_rows >= 0 && a.m_global > 0, "layout build: arguments");
+  GDN_REQUIRE(!a.colmap || a.src_count, "layout build: a column map needs source counts");
+  const int lc = a.log_chunk, lb = a.log_bin;
+  GDN_REQUIRE(lc >= 8 && lc <= 15 && lb >= 8 && lb <= PB_MID_ROW_BITS, "layout build: log_chunk / log_bin");
+  GDN_REQUIRE(a.pad >= (1u << a.log_group) && a.pad <= 128 && (a.pad & (a.pad - 1)) == 0 && a.log_group >= 3, "pad / log_group");
+  const unsigned mL = (unsigned)a.m_global, mR = (unsigned)a.m_rows;
+  const unsigned m_raw = a.colmap ? (unsigned)a.m_raw : mL;
+  const unsigned long long n = a.nnz;
+  if ((uint64_t)((mL + (1u << lc) - 1) >> lc) > PT_MAX_CHUNKS) return 1;
+  const unsigned grp = 1u << a.log_group;
+  const unsigned nbS = (mL + PT_VTILE - 1) / PT_VTILE, nbR = (mR + PT_VTILE - 1) / PT_VTILE;
+  ts.n = 0;
+  // ---- arena 1: vertex phase + the per-edge codes
+  PtArena A1;
+  {
+    size_t bytes = 0;
+    bytes += pt_pad256((size_t)mL * 4) * 3;                  // cnt16, mark, smap_l
+    bytes += a.colmap ? pt_pad256((size_t)m_raw * 4) : 0;    // smap_raw
+    bytes += pt_pad256((size_t)PT_NCLS * nbS * 4) + pt_pad256((size_t)nbR * 4) + 4096;
+    bytes += pt_pad256(((size_t)mR + 2) * 8);                // crp
+    bytes += pt_pad256(((size_t)(n >> 5) + 4) * 4);          // rowstart
+    bytes += pt_pad256((size_t)n * 4) + pt_pad256((size_t)n * 2);  // S, R
+    bytes += pt_pad256((PB_HUB_BUCKETS + PB_LIN_BINS + 64) * 4);
+    GDN_TRY(A1.init(bytes));
+  }
+  uint32_t *cnt16 = A1.get<uint32_t>(mL), *mark = A1.get<uint32_t>(mL), *smap_l = A1.get<uint32_t>(mL);
+  uint32_t *smap_raw = a.colmap ? A1.get<uint32_t>(m_raw) : smap_l;
+  uint32_t *bcS = A1.get<uint32_t>((size_t)PT_NCLS * nbS), *bcR = A1.get<uint32_t>(nbR);
+  uint32_t *totals = A1.get<uint32_t>(16);
+  unsigned *hist = A1.get<unsigned>(PB_HUB_BUCKETS + PB_LIN_BINS);
+  unsigned *errflag = A1.get<unsigned>(4);
+  eoff_t *crp = A1.get<eoff_t>((size_t)mR + 2);
+  uint32_t *rowstart = A1.get<uint32_t>((size_t)(n >> 5) + 4);
+  uint32_t *S = A1.get<uint32_t>(n);
+  uint16_t *R = A1.get<uint16_t>(n);
+  PT_CHECK_PTR(R);
+  PT_CHECK_PTR(S);
+  GDN_HIP(hipMemsetAsync(hist, 0, (PB_HUB_BUCKETS + PB_LIN_BINS) * 4, 0));
+  GDN_HIP(hipMemsetAsync(errflag, 0, 16, 0));
+  GDN_HIP(hipMemsetAsync(rowstart, 0, ((size_t)(n >> 5) + 4) * 4, 0));
+  // ---- source counts (sampled units) and their histograms; active rows
+  const bool want_tiers = a.tiers && lb <= PB_MID_ROW_BITS;
+  if (a.src_count) {
+    if (want_tiers) hipLaunchKernelGGL(pt_count16_kernel, dim3(gdn_nblocks(mL)), dim3(GDN_BLOCK), 0, 0, a.src_count, mL, cnt16);
+  } else {
+    GDN_HIP(hipMemsetAsync(mark, 0, (size_t)mL * 4, 0));
+    GDN_HIP(hipMemsetAsync(cnt16, 0, (size_t)mL * 4, 0));
+    if (n) {
+      const unsigned long long gb = (n + GDN_BLOCK * 8ull - 1) / (GDN_BLOCK * 8ull);
+      hipLaunchKernelGGL(pt_mark_kernel, dim3((unsigned)(gb > 262144ull ? 262144ull : gb)), dim3(GDN_BLOCK), 0, 0, a.colidx, (eoff_t)n, mark);
+      if (want_tiers) {
+        const uint64_t sampled = ((uint64_t)mR + (1u << PB_HUB_SAMPLE_LOG) - 1) >> PB_HUB_SAMPLE_LOG;
+        hipLaunchKernelGGL(pb_hub_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, a.rowptr, a.colidx, (int32_t)mR, cnt16);
+      }
+    }
+  }
+  if (want_tiers) {
+    hipLaunchKernelGGL(pb_hub_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, cnt16, (size_t)mL, hist);
+    if (a.max_mid > 0) hipLaunchKernelGGL(pb_hub_hist_lin_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, cnt16, (size_t)mL, hist + PB_HUB_BUCKETS);
+  }
+  hipLaunchKernelGGL(pt_row_count_kernel, dim3(nbR ? nbR : 1), dim3(GDN_BLOCK), 0, 0, a.rowptr, mR, bcR);
+  hipLaunchKernelGGL(pt_scan_rows_kernel, dim3(1), dim3(GDN_BLOCK), 0, 0, bcR, nbR, totals + 8);
+  GDN_HIP(hipGetLastError());
+  std::vector<unsigned> h_hist(PB_HUB_BUCKETS + PB_LIN_BINS);
+  unsigned h_tot[16];
+  GDN_HIP(hipMemcpy(h_hist.data(), hist, h_hist.size() * 4, hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(h_tot + 8, totals + 8, 4, hipMemcpyDeviceToHost));
+  const uint64_t n_dst = h_tot[8];
+  PtSrcArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.src_count = a.src_count;
+  sa.cnt16 = cnt16;
+  sa.mark = mark;
+  sa.n = mL;
+  sa.ntiers = 0;
+  bool has_hub = false;
+  if (want_tiers) {
+    unsigned thr[1 + PB_MAX_MID];
+    int nt = 0;
+    const uint64_t nbins_est = ((n_dst + (1ull << lb) - 1) >> lb) + 1;
+    pb_choose_tiers(h_hist.data(), a.max_mid > 0 ? h_hist.data() + PB_HUB_BUCKETS : nullptr, nbins_est, n, a.max_mid, a.min16, thr, &nt);
+    has_hub = thr[0] != 0xFFFFFFFFu;
+    // classes in use, in descending threshold order (a missing hub class is dropped: the tiers are numbered 1.. here)
+    for (int t = has_hub ? 0 : 1; t < nt; t++) sa.thr[sa.ntiers++] = thr[t];
+  }
+  hipLaunchKernelGGL(pt_src_count_kernel, dim3(nbS), dim3(GDN_BLOCK), 0, 0, sa, nbS, bcS);
+  hipLaunchKernelGGL(pt_scan_rows_kernel, dim3(PT_NCLS), dim3(GDN_BLOCK), 0, 0, bcS, nbS, totals);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipMemcpy(h_tot, totals, PT_NCLS * 4, hipMemcpyDeviceToHost));
+  const uint64_t n_src0 = h_tot[0];
+  // tiers that came out empty are dropped from the back (the histogram counted them, so only when nothing qualifies)
+  while (sa.ntiers > 0 && h_tot[sa.ntiers] == 0) sa.ntiers--;
+  for (int t = 0; t < sa.ntiers; t++) {
+    const unsigned cap = (t == 0 && has_hub) ? (1u << PB_HUB_LOG) : PB_MID_MAX;
+    if (h_tot[1 + t] > cap || h_tot[1 + t] == 0) {  // cannot happen: the histograms counted them
+      gdn_set_error("layout build: tier %d holds %u sources (cap %u)", t, h_tot[1 + t], cap);
+      return GDN_ERR_INVALID;
+    }
+  }
+  const int ntiers = sa.ntiers;
+  // ---- slices (whole rounds of workgroups, see pb_build)
+  const uint64_t per_c = pb_slots_per_slice(n_src0, lc, PB_MAX_LOG_CHUNK), per_b = pb_slots_per_slice(n_dst, lb, a.bin_balance_log);
+  unsigned nchunks = (unsigned)((n_src0 + per_c - 1) / per_c), nbins = (unsigned)((n_dst + per_b - 1) / per_b);
+  if (nchunks == 0) nchunks = 1;
+  if (nbins == 0) nbins = 1;
+  if (nchunks > PT_MAX_CHUNKS) return 1;
+  const unsigned d1 = (nchunks + (1u << PT_LOW_BITS) - 1) >> PT_LOW_BITS;
+  const unsigned nd_split = d1 + (unsigned)ntiers;
+  if (nd_split > PT_MAX_DIGITS) return 1;
+  p.m_local = a.m_rows;
+  p.m_global = a.m_global;
+  p.log_chunk = lc;
+  p.log_bin = lb;
+  p.compact = true;
+  p.chunk_slots = (unsigned)per_c;
+  p.log_group = a.log_group;
+  p.nchunks = nchunks;
+  p.nbins = nbins;
+  const unsigned long long ntiles = (unsigned long long)nchunks * nbins;
+  GDN_TRY(p.src_bits.alloc(((size_t)mL + 31) / 32 + 1));
+  GDN_TRY(p.dst_bits.alloc(((size_t)mR + 31) / 32 + 1));
+  GDN_TRY(p.chunk_lo.alloc((size_t)nchunks + 1));
+  GDN_TRY(p.bin_lo.alloc((size_t)nbins + 1));
+  GDN_TRY(p.chunk_ptr.alloc((size_t)nchunks + 1));
+  GDN_TRY(p.bin_ptr.alloc((size_t)nbins + 1));
+  GDN_TRY(p.errflag.alloc(1));
+  GDN_HIP(hipMemsetAsync(p.errflag.p, 0, sizeof(unsigned), 0));
+  GDN_HIP(hipMemsetAsync(p.src_bits.p, 0, (((size_t)mL + 31) / 32 + 1) * 4, 0));
+  GDN_HIP(hipMemsetAsync(p.dst_bits.p, 0, (((size_t)mR + 31) / 32 + 1) * 4, 0));
+  GDN_HIP(hipMemsetAsync(p.chunk_lo.p, 0, ((size_t)nchunks + 1) * 4, 0));
+  GDN_HIP(hipMemsetAsync(p.bin_lo.p, 0, ((size_t)nbins + 1) * 4, 0));
+  for (int t = 0; t < ntiers; t++) {
+    ts.t[t].n_src = h_tot[1 + t];
+    GDN_TRY(ts.t[t].ids.alloc(h_tot[1 + t]));
+    GDN_TRY(ts.t[t].bin_ptr.alloc((size_t)nbins + 1));
+  }
+  // ---- arena 2: tile tables
+  PtArena A2;
+  {
+    size_t bytes = 0;
+    bytes += pt_pad256(ntiles * 4) * 3;                                  // tile_cnt, psz_c, psz_b
+    bytes += pt_pad256((ntiles + 1) * 8) * 2;                            // pu, pv
+    bytes += pt_pad256((size_t)d1 * nbins * 4) + pt_pad256(((size_t)d1 * nbins + 1) * 8);  // segsz, segoff
+    bytes += pt_pad256((size_t)nbins * 8 * 4) + pt_pad256((size_t)PB_MAX_REC_TIERS * nbins * 4);
+    bytes += pt_pad256(((size_t)nbins + 2) * 8) * 3 + pt_pad256((size_t)nbins * 4) + pt_pad256(((size_t)nchunks + 1) * 8);
+    bytes += pt_pad256((ntiles / 2048 + 16) * 8) * 2;
+    GDN_TRY(A2.init(bytes));
+  }
+  uint32_t *tile_cnt = A2.get<uint32_t>(ntiles), *psz_c = A2.get<uint32_t>(ntiles), *psz_b = A2.get<uint32_t>(ntiles);
+  eoff_t *pu = A2.get<eoff_t>(ntiles + 1), *pv = A2.get<eoff_t>(ntiles + 1);
+  uint32_t *segsz = A2.get<uint32_t>((size_t)d1 * nbins);
+  eoff_t *segoff = A2.get<eoff_t>((size_t)d1 * nbins + 1);
+  uint32_t *tier_cnt = A2.get<uint32_t>((size_t)nbins * 8), *tsz = A2.get<uint32_t>((size_t)PB_MAX_REC_TIERS * nbins);
+  eoff_t *bin_e = A2.get<eoff_t>((size_t)nbins + 2), *d_du = A2.get<eoff_t>((size_t)nchunks + 1), *d_dv = A2.get<eoff_t>((size_t)nbins + 2);
+  eoff_t *bin_sz = A2.get<eoff_t>((size_t)nbins + 2);
+  uint32_t *order = A2.get<uint32_t>(nbins);
+  eoff_t *ws = A2.get<eoff_t>(ntiles / 2048 + 16);
+  PT_CHECK_PTR(ws);
+  GDN_HIP(hipMemsetAsync(bin_e, 0, ((size_t)nbins + 2) * 8, 0));
+  // ---- ranks
+  {
+    PtSrcOut so;
+    memset(&so, 0, sizeof(so));
+    so.smap = smap_l;
+    for (int t = 0; t < ntiers; t++) so.ids[t] = ts.t[t].ids.p;
+    so.src_bits8 = reinterpret_cast<uint8_t *>(p.src_bits.p);
+    so.chunk_lo = p.chunk_lo.p;
+    so.per_c = (unsigned)per_c;
+    so.log_chunk = lc;
+    hipLaunchKernelGGL(pt_src_assign_kernel, dim3(nbS), dim3(GDN_BLOCK), 0, 0, sa, nbS, bcS, so);
+    if (a.colmap) hipLaunchKernelGGL(pt_smap_raw_kernel, dim3(gdn_nblocks(m_raw)), dim3(GDN_BLOCK), 0, 0, a.colmap, m_raw, smap_l, smap_raw);
+    PtRowOut ro;
+    ro.crp = crp;
+    ro.bin_e = bin_e;
+    ro.bin_lo = p.bin_lo.p;
+    ro.dst_bits8 = reinterpret_cast<uint8_t *>(p.dst_bits.p);
+    ro.rowstart = rowstart;
+    ro.per_b = (unsigned)per_b;
+    if (nbR) hipLaunchKernelGGL(pt_row_assign_kernel, dim3(nbR), dim3(GDN_BLOCK), 0, 0, a.rowptr, mR, bcR, ro);
+    hipLaunchKernelGGL(pt_ends_kernel, dim3(1), dim3(64), 0, 0, p.chunk_lo.p, nchunks, mL, p.bin_lo.p, nbins, mR, bin_e, crp,
+                       (eoff_t)n_dst, (eoff_t)n, n_src0 ? 1 : 0, n_dst ? 1 : 0);
+    GDN_HIP(hipGetLastError());
+  }
+  // ---- the gather pass
+  {
+    PtKeyArgs ka;
+    ka.colidx = a.colidx;
+    ka.smap = smap_raw;
+    ka.rowstart = reinterpret_cast<const unsigned long long *>(rowstart);
+    ka.bin_e = bin_e;
+    ka.crp = crp;
+    ka.n_dst = (eoff_t)n_dst;
+    ka.per_b = (unsigned)per_b;
+    ka.nchunks = nchunks;
+    ka.log_chunk = lc;
+    ka.ntiers = ntiers;
+    ka.S = S;
+    ka.R = R;
+    ka.tile_cnt = tile_cnt;
+    ka.tier_cnt = tier_cnt;
+    ka.errflag = errflag;
+    hipLaunchKernelGGL(pt_keygen_kernel, dim3(nbins), dim3(PT_THREADS), (size_t)nchunks * 4, 0, ka);
+    GDN_HIP(hipGetLastError());
+  }
+  // ---- offsets
+  {
+    const unsigned long long tt = ntiles > (unsigned long long)d1 * nbins ? ntiles : (unsigned long long)d1 * nbins;
+    hipLaunchKernelGGL(pt_tile_sizes_kernel, dim3(gdn_nblocks(tt)), dim3(GDN_BLOCK), 0, 0, tile_cnt, nchunks, nbins, a.pad, d1, psz_c, psz_b, segsz);
+    GDN_HIP(hipGetLastError());
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(psz_c, pu, (size_t)ntiles, ws, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(psz_b, pv, (size_t)ntiles, ws, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(segsz, segoff, (size_t)d1 * nbins, ws, 0));
+    hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(nchunks > nbins ? nchunks : nbins) + 1)), dim3(GDN_BLOCK), 0, 0, pu,
+                       pv, nchunks, nbins, p.chunk_ptr.p, p.bin_ptr.p);
+    if (ntiers) {
+      hipLaunchKernelGGL(pt_tier_sizes_kernel, dim3(gdn_nblocks(nbins)), dim3(GDN_BLOCK), 0, 0, tier_cnt, nbins, ntiers, tsz);
+      for (int t = 0; t < ntiers; t++) GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(tsz + (size_t)t * nbins, ts.t[t].bin_ptr.p, nbins, ws, 0));
+    }
+    hipLaunchKernelGGL(pt_sizes_from_ptr_kernel, dim3(gdn_nblocks(nbins)), dim3(GDN_BLOCK), 0, 0, bin_e, nbins, bin_sz);
+    GDN_HIP(hipGetLastError());
+  }
+  std::vector<eoff_t> cs((size_t)nchunks + 1), bs((size_t)nbins + 1), h_binsz(nbins);
+  std::vector<uint32_t> h_tier_cnt((size_t)nbins * 8);
+  eoff_t n0 = 0, tier_pad[PB_MAX_REC_TIERS] = {};
+  unsigned h_err = 0;
+  GDN_HIP(hipMemcpy(cs.data(), p.chunk_ptr.p, cs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(bs.data(), p.bin_ptr.p, bs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(h_binsz.data(), bin_sz, (size_t)nbins * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&n0, segoff + (size_t)d1 * nbins, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&h_err, errflag, 4, hipMemcpyDeviceToHost));
+  if (ntiers) GDN_HIP(hipMemcpy(h_tier_cnt.data(), tier_cnt, h_tier_cnt.size() * 4, hipMemcpyDeviceToHost));
+  for (int t = 0; t < ntiers; t++)
+    GDN_HIP(hipMemcpy(&tier_pad[t], ts.t[t].bin_ptr.p + nbins, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  if (h_err) {
+    gdn_set_error("layout build: a column id occurs whose source count is 0 (counts do not match the graph)");
+    return 2;  // the caller repeats the build with exact marks
+  }
+  for (int t = 0; t < ntiers; t++) {
+    uint64_t s = 0;
+    for (unsigned b = 0; b < nbins; b++) s += h_tier_cnt[(size_t)b * 8 + t];
+    ts.t[t].nnz = s;
+  }
+  p.nnz = n0;
+  // slice starts on aligned boundaries (see pb_build)
+  eoff_t n_pad = 0;
+  std::vector<eoff_t> ca((size_t)nchunks + 1, 0), ba((size_t)nbins + 1, 0);
+  {
+    std::vector<eoff_t> du(nchunks), dv(nbins);
+    auto pick_align = [](eoff_t total, unsigned parts) {
+      eoff_t al = 16;
+      while (al < 16384 && al * 32 <= total / (parts ? parts : 1)) al <<= 1;
+      return al;
+    };
+    const eoff_t al_c = pick_align(cs[nchunks], nchunks), al_b = pick_align(bs[nbins], nbins);
+    for (unsigned c = 0; c < nchunks; c++) {
+      du[c] = ca[c] - cs[c];
+      ca[c + 1] = (ca[c] + (cs[c + 1] - cs[c]) + al_c - 1) & ~(al_c - 1);
+    }
+    for (unsigned b = 0; b < nbins; b++) {
+      dv[b] = ba[b] - bs[b];
+      ba[b + 1] = (ba[b] + (bs[b + 1] - bs[b]) + al_b - 1) & ~(al_b - 1);
+    }
+    n_pad = ca[nchunks] > ba[nbins] ? ca[nchunks] : ba[nbins];
+    GDN_HIP(hipMemcpyAsync(d_du, du.data(), du.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(d_dv, dv.data(), dv.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    hipLaunchKernelGGL(pb_shift_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu, pv, d_du, d_dv, nchunks, nbins);
+    GDN_HIP(hipMemcpyAsync(p.chunk_ptr.p, ca.data(), ca.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(p.bin_ptr.p, ba.data(), ba.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipStreamSynchronize(0));  // du / dv are host vectors of this scope
+  }
+  p.n_pad = n_pad;
+  if ((n_pad >> a.log_group) + 1 > 0xFFFFFFFFull) {
+    gdn_set_error("layout build: more than 2^35 padded edges");
+    return GDN_ERR_INVALID;
+  }
+  // bins by descending edge count: the launch order of the per-bin kernels
+  {
+    std::vector<uint32_t> bo(nbins);
+    for (unsigned b = 0; b < nbins; b++) bo[b] = b;
+    std::stable_sort(bo.begin(), bo.end(), [&](uint32_t x, uint32_t y) { return h_binsz[x] > h_binsz[y]; });
+    GDN_HIP(hipMemcpy(order, bo.data(), (size_t)nbins * 4, hipMemcpyHostToDevice));
+  }
+  // ---- arena 3: X = main-layout items + the tiers' records in CSR order; the radix passes ping-pong with S's memory
+  eoff_t tier_base[PB_MAX_REC_TIERS], xlen = n0;
+  for (int t = 0; t < ntiers; t++) {
+    tier_base[t] = xlen;
+    xlen += tier_pad[t];
+  }
+  PtArena A3;
+  GDN_TRY(A3.init(pt_pad256((size_t)xlen * 4) + pt_pad256((size_t)(xlen - n0) * 4) + 4096));
+  uint32_t *X = A3.get<uint32_t>(xlen);
+  uint32_t *TMP = A3.get<uint32_t>(xlen - n0);  // second buffer of the tiers' radix passes (laid out like X's tier part)
+  PT_CHECK_PTR(X);
+  PT_CHECK_PTR(TMP);
+  GDN_TRY(p.U.alloc(n_pad + grp));
+  GDN_TRY(p.V.alloc(n_pad + grp));
+  GDN_TRY(p.G.alloc((n_pad >> a.log_group) + 1));
+  for (int t = 0; t < ntiers; t++) GDN_TRY(ts.t[t].rec.alloc(tier_pad[t] + 16));
+  {
+    const unsigned long long fb = (n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p, n_pad + grp,
+                       (uint16_t)p.chunk_slots);
+    GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + grp) * sizeof(uint16_t), 0));
+    const unsigned long long ng = (n_pad >> a.log_group) + 1;
+    const unsigned long long fbg = (ng + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fbg > 262144ull ? 262144ull : fbg)), dim3(GDN_BLOCK), 0, 0, p.G.p, ng,
+                       (uint32_t)(n_pad >> a.log_group));
+  }
+  int dbits = 1;
+  while ((1u << dbits) < nd_split) dbits++;
+  {
+    PtSplitArgs sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.S = S;
+    sp.R = R;
+    sp.bin_e = bin_e;
+    sp.segoff = segoff;
+    for (int t = 0; t < ntiers; t++) {
+      sp.tier_ptr[t] = ts.t[t].bin_ptr.p;
+      sp.tier_base[t] = tier_base[t];
+    }
+    sp.order = order;
+    sp.X = X;
+    sp.d1 = d1;
+    sp.ntiers = ntiers;
+    sp.log_chunk = lc;
+    sp.dbits = dbits;
+    const size_t lds = pt_stage_bytes(nd_split);
+    GDN_HIP(hipFuncSetAttribute((const void *)pt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (n) hipLaunchKernelGGL(pt_split_kernel, dim3(nbins), dim3(PT_THREADS), lds, 0, sp);
+    GDN_HIP(hipGetLastError());
+  }
+  if (n0) {
+    const unsigned long long nseg = (unsigned long long)d1 * nbins;
+    hipLaunchKernelGGL(pt_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, X, segoff, d1, nbins, nchunks, pu, pv, p.U.p, p.V.p);
+    GDN_HIP(hipGetLastError());
+  }
+  // record tiers: (row, source) -> (source, row) inside every bin
+  if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)pt_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS)));
+  for (int t = 0; t < ntiers; t++) {
+    int nbits = 1;
+    while ((1u << nbits) < ts.t[t].n_src) nbits++;
+    const int passes = nbits > 10 ? 2 : 1;
+    const int b1 = passes == 2 ? (nbits + 1) / 2 : nbits;
+    uint32_t *tmp = TMP + (tier_base[t] - n0);
+    PtRadixArgs ra;
+    ra.ptr = ts.t[t].bin_ptr.p;
+    ra.tier_cnt = tier_cnt;
+    ra.order = order;
+    ra.tier = t;
+    ra.zrec = ts.t[t].n_src << PB_MID_ROW_BITS;
+    for (int ps = 0; ps < passes; ps++) {
+      ra.in = ps == 0 ? X + tier_base[t] : tmp;
+      ra.out = ps == passes - 1 ? ts.t[t].rec.p : tmp;
+      ra.shift = PB_MID_ROW_BITS + (ps == 0 ? 0 : b1);
+      ra.bits = ps == 0 ? b1 : nbits - b1;
+      ra.last = ps == passes - 1 ? 1 : 0;
+      const size_t lds = pt_stage_bytes(1u << ra.bits);
+      hipLaunchKernelGGL(pt_radix_kernel, dim3(nbins), dim3(PT_THREADS), lds, 0, ra);
+    }
+    GDN_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu, pv, psz_c, nchunks, nbins, p.G.p, 0, a.log_group);
+  GDN_HIP(hipGetLastError());
+  {  // largest-first launch order of both phases
+    std::vector<uint32_t> co(nchunks), bo(nbins);
+    for (unsigned i = 0; i < nchunks; i++) co[i] = i;
+    for (unsigned i = 0; i < nbins; i++) bo[i] = i;
+    std::stable_sort(co.begin(), co.end(), [&](uint32_t x, uint32_t y) { return ca[x + 1] - ca[x] > ca[y + 1] - ca[y]; });
+    std::stable_sort(bo.begin(), bo.end(), [&](uint32_t x, uint32_t y) { return ba[x + 1] - ba[x] > ba[y + 1] - ba[y]; });
+    GDN_TRY(p.chunk_order.alloc(nchunks));
+    GDN_TRY(p.bin_order.alloc(nbins));
+    GDN_HIP(hipMemcpyAsync(p.chunk_order.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipStreamSynchronize(0));
+  }
+  if (a.alloc_vals) {
+    GDN_TRY(p.vals.alloc(n_pad + grp));
+    GDN_HIP(hipMemsetAsync(p.vals.p, 0, (n_pad + grp) * sizeof(float), 0));
+  }
+  GDN_TRY(p.partial.alloc(nbins));
+  GDN_TRY(p.red_scratch.alloc(2 * ((size_t)nbins / 4096 + 2)));
+  ts.n = ntiers;
+  ts.first_is_hub = has_hub && ntiers > 0;
+  GDN_HIP(hipDeviceSynchronize());
+  if (trace) {
+    fprintf(stderr, "[pb_build_tiered] edges %llu: main %llu padded %llu (%.3f x) chunks %u (%llu slots) bins %u", n,
+            (unsigned long long)n0, (unsigned long long)n_pad, n0 ? (double)n_pad / (double)n0 : 0.0, nchunks,
+            (unsigned long long)per_c, nbins);
+    for (int t = 0; t < ntiers; t++) fprintf(stderr, ", tier %d: %u sources %llu edges", t, ts.t[t].n_src, (unsigned long long)ts.t[t].nnz);
+    fprintf(stderr, "; %.2f ms wall\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  }
+  return GDN_OK;
+}

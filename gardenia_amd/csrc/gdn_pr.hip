@@ -599,11 +599,20 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   p->nnz = in_csr->nnz;
   int st;
   gdn_graph sq_graph;  // the relabelled in-CSR of a squished plan (arrays owned by the plan)
+  // Round 4: main layout + record tiers from ONE gather pass (pb_build_tiered_run, gdn_pbtier.hpp).  GDN_PB_BUILDER=old
+  // and the knobs the new builder does not serve (8-bit rows, hub rows, no compaction) take one pb_build per layout.
+  bool tiered_builder = true;
+  {
+    const char *be = gdn_option("GDN_PB_BUILDER"), *ve = gdn_option("GDN_PB_V8"), *re = gdn_option("GDN_PB_HUB_ROWS"),
+               *ce = gdn_option("GDN_PB_COMPACT");
+    if ((be && be[0] == 'o') || (ve && ve[0] == '1') || (re && re[0] == '1') || (ce && ce[0] == '0')) tiered_builder = false;
+  }
+  const gdn_graph *raw_csr = in_csr;  // the caller's graph (a squished plan relabels rows and columns)
+  DevBuf<eoff_t> cmap;                // squished plan: caller's id -> state index (exclusive scan of the live flags)
   if (layout == GDN_LAYOUT_PB_SQUISHED) {
     layout = p->layout = GDN_LAYOUT_PB;
     const int32_t m = in_csr->m;
     DevBuf<uint32_t> flag;
-    DevBuf<eoff_t> cmap;
     st = flag.alloc((size_t)m);
     if (st == GDN_OK) st = cmap.alloc((size_t)m + 1);
     if (st == GDN_OK) {
@@ -617,12 +626,14 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       const uint32_t ms = (uint32_t)n_live;
       if ((st = p->sq_ids.alloc(ms)) == GDN_OK && (st = p->sq_deg.alloc(ms)) == GDN_OK &&
           (st = p->sq_rowptr.alloc((size_t)ms + 1)) == GDN_OK && (st = p->sq_bits.alloc(((size_t)m + 31) / 32 + 1)) == GDN_OK &&
-          (st = p->sq_colidx.alloc((size_t)in_csr->nnz)) == GDN_OK && (st = p->sq_diff.alloc(1)) == GDN_OK) {
+          (tiered_builder || (st = p->sq_colidx.alloc((size_t)in_csr->nnz)) == GDN_OK) && (st = p->sq_diff.alloc(1)) == GDN_OK) {
         (void)hipMemset(p->sq_diff.p, 0, sizeof(double));
         hipLaunchKernelGGL(pr_squish_vertices_kernel, dim3(gdn_nblocks(((uint64_t)m + 31) / 32)), dim3(GDN_BLOCK), 0, 0, flag.p,
                            cmap.p, in_csr->rowptr, d_out_degree, m, in_csr->nnz, ms, p->sq_ids.p, p->sq_deg.p, p->sq_rowptr.p,
                            p->sq_bits.p);
-        if (in_csr->nnz)
+        // (the tiered builder reads the caller's column ids through cmap: the relabelled copy -- a gather pass over the
+        // edges of its own, 40 ms at RMAT-27 -- is only made for pb_build)
+        if (in_csr->nnz && !tiered_builder)
           hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, in_csr->colidx, cmap.p, in_csr->nnz,
                              p->sq_colidx.p);
         if (hipDeviceSynchronize() != hipSuccess) {
@@ -632,7 +643,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
         sq_graph.m = (int32_t)ms;
         sq_graph.nnz = in_csr->nnz;
         sq_graph.rowptr = p->sq_rowptr.p;
-        sq_graph.colidx = p->sq_colidx.p;
+        sq_graph.colidx = tiered_builder ? raw_csr->colidx : p->sq_colidx.p;  // (raw ids: only pb_build_tiered_run may read them)
         sq_graph.owned = false;
         in_csr = &sq_graph;
         d_out_degree = p->sq_deg.p;
@@ -680,12 +691,81 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
     unsigned n_mid[PB_MAX_MID] = {};
-    if (compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
+    const bool want_tiers = compact && in_csr->nnz >= hub_min_nnz && !(he && he[0] == '0');
+    bool built = false;  // by the tiered builder
+    if (tiered_builder && lb <= PB_MID_ROW_BITS) {
+      PbTieredArgs ta;
+      PbTierSet ts;
+      ta.rowptr = in_csr->rowptr;
+      ta.colidx = raw_csr->colidx;
+      ta.colmap = p->squished ? cmap.p : nullptr;
+      ta.m_raw = raw_csr->m;
+      ta.m_rows = in_csr->m;
+      ta.m_global = m_global;
+      ta.nnz = in_csr->nnz;
+      // the out-degrees ARE the column counts when the plan covers the whole graph (a row shard sees a part of every
+      // column: exact marks there); a mismatch is detected by the gather pass (rc 2) and the build repeated without
+      ta.src_count = in_csr->m == m_global ? d_out_degree : nullptr;
+      ta.log_chunk = lc;
+      ta.log_bin = lb;
+      ta.pad = pad;
+      ta.log_group = lg;
+      ta.tiers = want_tiers;
+      ta.max_mid = max_mid;
+      ta.min16 = 1u;
+      int rc = pb_build_tiered_run(ta, p->pb, ts);
+      if (rc == 2 && !ta.colmap) {
+        ta.src_count = nullptr;
+        rc = pb_build_tiered_run(ta, p->pb, ts);
+      }
+      if (rc < 0) st = rc;
+      else if (rc == GDN_OK) {
+        built = true;
+        int k = 0;
+        if (ts.n > 0 && ts.first_is_hub) {
+          p->n_hubs = ts.t[0].n_src;
+          p->hub_ids.take(ts.t[0].ids);
+          p->hub_rec.take(ts.t[0].rec);
+          p->hub.bin_ptr.take(ts.t[0].bin_ptr);
+          p->hub.nnz = ts.t[0].nnz;
+          p->hub.nbins = p->pb.nbins;
+          p->hub.nchunks = 1;
+          st = p->hub_val.alloc(PB_HUB_SLOTS + 3);
+          p->has_hub = true;
+          k = 1;
+        }
+        for (int t = k; t < ts.n && st == GDN_OK; t++) {
+          gdn_pr_plan::MidTier &mt = p->mid[t - k];
+          mt.n = ts.t[t].n_src;
+          mt.ids.take(ts.t[t].ids);
+          mt.rec.take(ts.t[t].rec);
+          mt.layout.bin_ptr.take(ts.t[t].bin_ptr);
+          mt.layout.nnz = ts.t[t].nnz;
+          mt.layout.nbins = p->pb.nbins;
+          st = mt.val.alloc((size_t)mt.n + 4);
+          p->n_mid_tiers = t - k + 1;
+        }
+      } else if (p->squished) {
+        // outside the builder's limits (or counts that do not match the columns): pb_build below needs the relabelled columns
+        if ((st = p->sq_colidx.alloc((size_t)in_csr->nnz)) == GDN_OK && in_csr->nnz) {
+          hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, raw_csr->colidx, cmap.p, in_csr->nnz,
+                             p->sq_colidx.p);
+          sq_graph.colidx = p->sq_colidx.p;
+        }
+      }
+    } else if (p->squished && tiered_builder) {
+      if ((st = p->sq_colidx.alloc((size_t)in_csr->nnz)) == GDN_OK && in_csr->nnz) {
+        hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, raw_csr->colidx, cmap.p, in_csr->nnz,
+                           p->sq_colidx.p);
+        sq_graph.colidx = p->sq_colidx.p;
+      }
+    }
+    if (!built && st == GDN_OK && want_tiers)
       // four mid tiers down to 1/16 edge per source and bin: RMAT-27 62 % of the edges in record tiers, 4.12 -> 3.78 ms
       // per iteration against two tiers down to 1/4 (profiles/r03_pb_tier_sweep_reps.txt; a fifth and sixth tier give it
       // back: their table lines are fetched for one record each)
       st = pb_pick_tiers(in_csr, m_global, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid, 1u);
-    const bool any_class = p->n_hubs || n_mid[0];
+    const bool any_class = !built && (p->n_hubs || n_mid[0]);
     // hub rows: as many as phase A's LDS can hold accumulators for behind the slice (the slice size is known when
     // this plan covers the whole graph: sources = vertices with out-edges; a row shard takes the safe bound)
     DevBuf<uint8_t> dcls;
@@ -712,7 +792,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       const uint64_t nchunks_est = ((uint64_t)m_global >> lc) + 1;
       if (st == GDN_OK) st = pb_pick_hub_rows(in_csr, max_rows, 2 * nchunks_est, dcls, p->hr_ids, &p->n_hr);
     }
-    if (st == GDN_OK)
+    if (st == GDN_OK && !built)
       st = pb_build(in_csr, m_global, lc, lb, p->pb, true, nullptr, nullptr, compact, false, pad, lg,
                     any_class ? cls.p : nullptr, 0, false, v_delta, p->n_hr ? dcls.p : nullptr, 0, false, false,
                     PB_MAX_LOG_BIN, &scratch);
@@ -760,7 +840,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
         p->has_hr = true;
       }
     }
-    if (st == GDN_OK && p->n_hubs) {
+    if (st == GDN_OK && !built && p->n_hubs) {
       st = pb_build(in_csr, m_global, PB_HUB_LOG, lb, p->hub, false, nullptr, nullptr, true, false, 16, 4, cls.p, 1, true, false,
                     nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
@@ -773,7 +853,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       if (st == GDN_OK) st = pb_mid_finish(p->hub, p->n_hubs, p->hub_rec);
       if (st == GDN_OK) p->has_hub = true;
     }
-    for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
+    for (int t = 0; t < PB_MAX_MID && st == GDN_OK && !built && n_mid[t]; t++) {
       gdn_pr_plan::MidTier &mt = p->mid[t];
       st = pb_build(in_csr, m_global, 15, lb, mt.layout, false, nullptr, nullptr, true, false, 16, 4, cls.p, 2 + t, true, false,
                     nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
