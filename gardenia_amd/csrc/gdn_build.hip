@@ -151,8 +151,8 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
   hipError_t e;
   DevBuf<unsigned> flag;
   DevBuf<eoff_t> pos;
-  GDN_TRY(flag.alloc(n));
-  GDN_TRY(pos.alloc(n + 1));
+  GDN_TRY(flag.alloc_scratch(n));
+  GDN_TRY(pos.alloc_scratch(n + 1));
   unsigned nb = (unsigned)((n + GDN_BLOCK - 1) / GDN_BLOCK > 262144ull ? 262144ull : (n + GDN_BLOCK - 1) / GDN_BLOCK);
   if (nb == 0) nb = 1;
   hipLaunchKernelGGL(keys_flag_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, sorted, n, flag.p);
@@ -666,12 +666,12 @@ pb_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long
 // cls gets one byte per source id (0 main, 1 hub, 2.. mid tiers), hub_ids / mid_ids[t] the ascending ids.
 #define PB_HUB_MIN_PER_BIN 2
 #define PB_MID_MIN_PER_BIN16 4
-// Host part of the tier choice: thresholds in SAMPLED-count units (a sampled count of c stands for about 16 c out-edges)
+// Host part of the tier choice: thresholds in count units of 2^sample_log edges (a count of the 1/16 row sample stands for 16)
 // from the quarter-octave histogram h[PB_HUB_BUCKETS] and the linear histogram hl[PB_LIN_BINS] (nullable: no mid tiers)
 // of the per-source counts.  thr[0] = hubs (0xFFFFFFFF: none qualifies; the slot is kept so that the classes keep
 // their numbers), thr[1 + t] = mid tier t; *ntiers = classes in use, the hub class included.
 void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint64_t nnz, int max_mid, unsigned min16,
-                     unsigned *thr_out, int *ntiers_out) {
+                     unsigned *thr_out, int *ntiers_out, int sample_log = PB_HUB_SAMPLE_LOG) {
   struct {
     unsigned thr[1 + PB_MAX_MID];
     int ntiers;
@@ -698,7 +698,7 @@ void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint
     return PB_HUB_BUCKETS;
   };
   // tier 0 = hubs (the slot keeps an unreachable threshold when no source qualifies, so the classes keep their numbers)
-  const unsigned bk0 = pick((nbins * per_bin) >> PB_HUB_SAMPLE_LOG, PB_HUB_BUCKETS, 1u << PB_HUB_LOG);
+  const unsigned bk0 = pick((nbins * per_bin) >> sample_log, PB_HUB_BUCKETS, 1u << PB_HUB_LOG);
   ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
   ta.ntiers = 1;
   uint64_t mid16 = min16 ? min16 : PB_MID_MIN_PER_BIN16;
@@ -712,8 +712,8 @@ void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint
     for (unsigned j = bk0; j < PB_HUB_BUCKETS; j++) n_hub_src += h[j];
     // sources with a count in [c, top): the last linear bin also holds everything beyond it, the hubs included
     uint64_t top = bk0 < PB_HUB_BUCKETS ? ta.thr[0] : 0xFFFFFFFFull;
-    uint64_t want = (nbins * mid16) >> (PB_HUB_SAMPLE_LOG + 4);
-    if (want < 4) want = 4;
+    uint64_t want = (nbins * mid16) >> (sample_log + 4);
+    if (want < (64u >> sample_log)) want = 64u >> sample_log;  // 64 edges (4 sampled): below, a table line is fetched per record
     for (int t = 0; t < max_mid && top > want; t++) {
       uint64_t acc = 0, thr = top;
       for (uint64_t c = (top < PB_LIN_BINS ? top : PB_LIN_BINS) - 1;; c--) {
@@ -732,7 +732,7 @@ void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint
       // bin a stream and a table for a fraction of a percent of the edges: a tier has to stand for >= 1/64 of them
       {
         unsigned long long est = 0;  // a sampled count of c ~ 16 c out-edges
-        for (uint64_t c = thr; c < (top < PB_LIN_BINS ? top : PB_LIN_BINS); c++) est += 16ull * c * hl[c];
+        for (uint64_t c = thr; c < (top < PB_LIN_BINS ? top : PB_LIN_BINS); c++) est += ((unsigned long long)c << sample_log) * hl[c];
         if (est * 64ull < nnz) break;
       }
       ta.thr[1 + t] = (unsigned)thr;
@@ -1147,8 +1147,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     DevBuf<unsigned> cnt;
     const uint64_t bigcap64 = n / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-    if (ka.n < n || !ka.p) GDN_TRY(ka.alloc(n));
-    if (kb.n < n || !kb.p) GDN_TRY(kb.alloc(n));
+    if (ka.n < n || !ka.p) GDN_TRY(ka.alloc_scratch(n));
+    if (kb.n < n || !kb.p) GDN_TRY(kb.alloc_scratch(n));
     GDN_TRY(bigitems.alloc(bigcap));
     GDN_TRY(cnt.alloc(2));
     GDN_TRY(nvalid.alloc(1));
@@ -1405,8 +1405,8 @@ int gdn_graph_transpose(const gdn_graph *g, gdn_graph **out) {
   DevBuf<unsigned> cnt;
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
   const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-  GDN_TRY(ka.alloc(g->nnz));
-  GDN_TRY(kb.alloc(g->nnz));
+  GDN_TRY(ka.alloc_scratch(g->nnz));
+  GDN_TRY(kb.alloc_scratch(g->nnz));
   GDN_TRY(bigitems.alloc(bigcap));
   GDN_TRY(cnt.alloc(2));
   GDN_HIP(hipMemset(cnt.p, 0, 8));
@@ -1462,8 +1462,8 @@ int gdn_graph_from_edges(int32_t m, uint64_t n_edges, const int32_t *src, const 
   const unsigned long long n = n_edges, nk = symmetrize ? 2 * n : n;
   DevBuf<unsigned long long> ka, kb;
   DevBuf<unsigned> bad;
-  GDN_TRY(ka.alloc(nk));
-  GDN_TRY(kb.alloc(nk));
+  GDN_TRY(ka.alloc_scratch(nk));
+  GDN_TRY(kb.alloc_scratch(nk));
   GDN_TRY(bad.alloc(1));
   GDN_HIP(hipMemset(bad.p, 0, sizeof(unsigned)));
   if (n) {
@@ -1496,8 +1496,8 @@ int gdn_graph_symmetrize(const gdn_graph *g, gdn_graph **out) {
   DevBuf<unsigned> cnt;
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
   const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-  GDN_TRY(ka.alloc(2 * g->nnz));
-  GDN_TRY(kb.alloc(2 * g->nnz));
+  GDN_TRY(ka.alloc_scratch(2 * g->nnz));
+  GDN_TRY(kb.alloc_scratch(2 * g->nnz));
   GDN_TRY(bigitems.alloc(bigcap));
   GDN_TRY(cnt.alloc(2));
   GDN_HIP(hipMemset(cnt.p, 0, 8));
@@ -1538,8 +1538,8 @@ int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t pe
     gdn_graph **dst = which == 0 ? out_csr : in_csr;
     if (!dst) continue;
     DevBuf<unsigned long long> ka, kb;
-    GDN_TRY(ka.alloc(n));
-    GDN_TRY(kb.alloc(n));
+    GDN_TRY(ka.alloc_scratch(n));
+    GDN_TRY(kb.alloc_scratch(n));
     unsigned nb = (unsigned)((n + GDN_BLOCK - 1) / GDN_BLOCK > 262144ull ? 262144ull : (n + GDN_BLOCK - 1) / GDN_BLOCK);
     hipLaunchKernelGGL(rmat_keys_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, (int)scale, n, (unsigned long long)seed,
                        (int)permute, which, ka.p);

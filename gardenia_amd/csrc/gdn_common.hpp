@@ -63,21 +63,45 @@ const char *gdn_option(const char *name);
 // walk the memory channels in step).
 size_t gdn_alloc_stagger_next(size_t bytes);
 
+// Short-lived device memory of a build (sort keys, the layout builder's arenas): a process-level cache of hipMalloc blocks
+// (gdn_graph.hip), NOT hipMalloc / hipFree per use.  Measured (profiles/r04_malloc_probe.txt, r04 sessions 3-5): a hipMalloc
+// of 16 GB takes 0.8 - 4.8 s whenever memory of that size was freed shortly before (the driver hands freed pages out again
+// only after wiping them), and hipFree costs 0.16 ms of synchronisation whatever the size.  A freed block may still be in
+// use by work queued on the null stream; its next user queues behind that work.
+int gdn_scratch_malloc(void **p, size_t bytes, int site = 8);  // gdn_graph.hip (site: bit of GDN_SCRATCH_POISON_SITES)
+void gdn_scratch_free(void *p);
+void gdn_scratch_trim();  // the cache goes back to the driver
+
 // RAII device buffer (solver-private scratch)
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
   size_t n = 0;
   void *base = nullptr;  // what hipMalloc returned (p may sit a staggered offset behind it)
+  bool pooled = false;   // base came from gdn_scratch_malloc
   DevBuf() {}
   DevBuf(const DevBuf &) = delete;
   DevBuf &operator=(const DevBuf &) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (base) (void)hipFree(base);
+    if (base) {
+      if (pooled) gdn_scratch_free(base);
+      else (void)hipFree(base);
+    }
     base = nullptr;
     p = nullptr;
     n = 0;
+    pooled = false;
+  }
+  // a temporary of a build (see gdn_scratch_malloc); never one of a plan's long-lived arrays
+  int alloc_scratch(size_t count) {
+    release();
+    n = count;
+    if (count == 0) count = 1;
+    GDN_TRY(gdn_scratch_malloc(&base, count * sizeof(T)));
+    p = static_cast<T *>(base);
+    pooled = true;
+    return GDN_OK;
   }
   int alloc(size_t count) {
     release();
@@ -85,6 +109,11 @@ struct DevBuf {
     if (count == 0) count = 1;
     const size_t off = gdn_alloc_stagger_next(count * sizeof(T));
     hipError_t e = hipMalloc(&base, count * sizeof(T) + off);
+    if (e != hipSuccess) {  // the scratch cache may hold what is missing
+      (void)hipGetLastError();
+      gdn_scratch_trim();
+      e = hipMalloc(&base, count * sizeof(T) + off);
+    }
     if (e != hipSuccess) {
       base = nullptr;
       p = nullptr;
@@ -117,17 +146,22 @@ struct DevBuf {
       keep->base = base;
       keep->p = p;
       keep->n = n;
+      keep->pooled = pooled;
+    } else if (pooled) {
+      gdn_scratch_free(base);
     } else {
       (void)hipFree(base);
     }
     base = nb;
     p = static_cast<T *>(nb);
+    pooled = false;
     return GDN_OK;
   }
   void swap(DevBuf<T> &o) {
     T *tp = p; p = o.p; o.p = tp;
     size_t tn = n; n = o.n; o.n = tn;
     void *tb = base; base = o.base; o.base = tb;
+    bool tq = pooled; pooled = o.pooled; o.pooled = tq;
   }
 #ifdef GDN_EXPERIMENTS  // placement A/B knobs of measurement builds only (make EXPERIMENTS=1, tools/build_variant.sh)
   // move the contents into an allocation made with hipExtMallocWithFlags(flags) (A/B knob: hipDeviceMallocUncached keeps a
@@ -213,9 +247,11 @@ struct DevBuf {
     p = o.p;
     n = o.n;
     base = o.base;
+    pooled = o.pooled;
     o.p = nullptr;
     o.base = nullptr;
     o.n = 0;
+    o.pooled = false;
   }
 };
 

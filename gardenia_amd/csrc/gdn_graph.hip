@@ -14,7 +14,9 @@ static thread_local char g_err[512] = "";
 // ---- options: every tuning / test knob of the library ("GDN_...") is an OPTION that a caller sets through the API
 // (gdn_option_set) and the environment variable of the same name OVERRIDES (so measurements and tests can flip a knob
 // without touching the caller).  Values are strings, parsed where they are used, exactly like the environment's.
+#include <algorithm>
 #include <atomic>
+#include <iterator>
 #include <map>
 #include <mutex>
 static std::mutex g_opt_mu;
@@ -45,6 +47,179 @@ void gdn_set_error(const char *fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
+}
+
+// ---- scratch cache (gdn_common.hpp): freed scratch blocks stay with the process, keyed by device and size, and are handed
+// out again to requests of about their size.  Plain hipMalloc pointers: the stream-ordered pool (hipMallocAsync) was
+// measured first and dropped -- on this runtime (HIP 7.0.51831) a hipMemsetAsync on pool memory is NOT ordered in front of
+// the kernel queued behind it (tools/memset_probe.hip, profiles/r04_memset_probe.txt: 16 896 bytes zeroed AFTER the kernel
+// had set its bits, deterministically; never on hipMalloc memory), and two fuzz sweeps failed on it.
+// GDN_SCRATCH_POOL=0 (read once): plain hipMalloc / hipFree instead (A/B knob)
+static bool gdn_scratch_pooled() {
+  static const bool on = [] {
+    const char *e = gdn_option("GDN_SCRATCH_POOL");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+namespace {
+struct ScratchCache {
+  static constexpr int kDevs = 16;
+  std::mutex mu;
+  std::multimap<size_t, void *> free_[kDevs];  // size -> block
+  std::map<void *, std::pair<int, size_t>> live;  // block -> (device, size)
+  size_t cached[kDevs] = {};
+  size_t keep = 64ull << 30;  // cached bytes per device beyond which the largest blocks go back (GDN_SCRATCH_KEEP_GB)
+  ScratchCache() {
+    if (const char *e = gdn_option("GDN_SCRATCH_KEEP_GB")) keep = (size_t)strtoull(e, nullptr, 10) << 30;
+  }
+};
+ScratchCache &scratch_cache() {
+  static ScratchCache *c = new ScratchCache();  // never destroyed: the HIP runtime may be gone before static destructors run
+  return *c;
+}
+// size classes: eighths of a power of two (at most 12.5 % over the request), never below 4 KB
+size_t scratch_round(size_t bytes) {
+  if (bytes < 4096) return 4096;
+  size_t p2 = 4096;
+  while ((p2 << 1) <= bytes) p2 <<= 1;
+  const size_t g = p2 >> 3;
+  return (bytes + g - 1) / g * g;
+}
+}  // namespace
+
+// everything the cache holds goes back to the driver (an allocation failed, or a caller wants the memory)
+void gdn_scratch_trim() {
+  ScratchCache &c = scratch_cache();
+  std::lock_guard<std::mutex> lk(c.mu);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (int d = 0; d < ScratchCache::kDevs; d++) {
+    if (c.free_[d].empty()) continue;
+    (void)hipSetDevice(d);
+    for (auto &kv : c.free_[d]) (void)hipFree(kv.second);
+    c.free_[d].clear();
+    c.cached[d] = 0;
+  }
+  (void)hipSetDevice(cur);
+}
+
+// GDN_SCRATCH_POISON=1 (read once): every scratch block starts as 0xCD bytes -- finds code that counts on fresh device
+// memory being zero (it is, from hipMalloc; a block of the pool holds whatever its last user left)
+static bool gdn_scratch_poison() {
+  static const bool on = [] {
+    const char *e = gdn_option("GDN_SCRATCH_POISON");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+static int gdn_scratch_malloc_raw(void **p, size_t bytes);
+int gdn_scratch_malloc(void **p, size_t bytes, int site) {
+  GDN_TRY(gdn_scratch_malloc_raw(p, bytes));
+  if (gdn_scratch_poison()) {
+    static const int sites = [] {
+      const char *e = gdn_option("GDN_SCRATCH_POISON_SITES");  // bit mask of the sites to poison (debugging)
+      return e ? atoi(e) : 0xFFFF;
+    }();
+    if (sites & site) {
+      // GDN_SCRATCH_POISON_PART (debugging): "head:N" only the first N bytes, "tail:N" only the last N, "mid:A:B" bytes [A, B)
+      size_t lo = 0, hi = bytes ? bytes : 1;
+      if (const char *e = gdn_option("GDN_SCRATCH_POISON_PART")) {
+        if (!strncmp(e, "head:", 5)) hi = std::min(hi, (size_t)strtoull(e + 5, nullptr, 10));
+        else if (!strncmp(e, "tail:", 5)) lo = hi - std::min(hi, (size_t)strtoull(e + 5, nullptr, 10));
+        else if (!strncmp(e, "mid:", 4)) {
+          char *q = nullptr;
+          lo = std::min(hi, (size_t)strtoull(e + 4, &q, 10));
+          if (q && *q == ':') hi = std::min(hi, (size_t)strtoull(q + 1, nullptr, 10));
+        }
+        fprintf(stderr, "[scratch] %p + %zu: poisoning [%zu, %zu)\n", *p, bytes, lo, hi);
+      }
+      if (hi > lo) GDN_HIP(hipMemsetAsync(static_cast<char *>(*p) + lo, 0xCD, hi - lo, 0));
+    }
+  }
+  return GDN_OK;
+}
+static int gdn_scratch_malloc_raw(void **p, size_t bytes) {
+  *p = nullptr;
+  if (gdn_scratch_pooled()) {
+    ScratchCache &c = scratch_cache();
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const size_t want = scratch_round(bytes);
+    if (dev >= 0 && dev < ScratchCache::kDevs) {
+      {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.free_[dev].lower_bound(want);
+        if (it != c.free_[dev].end() && it->first <= want + want / 4) {  // a cached block of about this size
+          *p = it->second;
+          c.cached[dev] -= it->first;
+          c.live[*p] = std::make_pair(dev, it->first);
+          c.free_[dev].erase(it);
+          return GDN_OK;
+        }
+      }
+      hipError_t e = hipMalloc(p, want);
+      if (e != hipSuccess) {  // give the cache back and try once more
+        (void)hipGetLastError();
+        gdn_scratch_trim();
+        e = hipMalloc(p, want);
+      }
+      if (e == hipSuccess) {
+        std::lock_guard<std::mutex> lk(c.mu);
+        c.live[*p] = std::make_pair(dev, want);
+        return GDN_OK;
+      }
+      (void)hipGetLastError();
+      *p = nullptr;
+      gdn_set_error("scratch allocation of %zu bytes -> %s", want, hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+  }
+  const hipError_t e0 = hipMalloc(p, bytes ? bytes : 1);
+  if (e0 != hipSuccess) {
+    (void)hipGetLastError();
+    *p = nullptr;
+    gdn_set_error("scratch allocation of %zu bytes -> %s", bytes, hipGetErrorString(e0));
+    return GDN_ERR_OOM;
+  }
+  return GDN_OK;
+}
+
+// The block may still be read or written by work queued on the null stream: its next user queues behind that work (every
+// build runs on the null stream; a caller that used another stream synchronises it before the buffer goes out of scope).
+void gdn_scratch_free(void *p) {
+  if (!p) return;
+  ScratchCache &c = scratch_cache();
+  std::vector<void *> evict;
+  int dev = -1;
+  {
+    std::lock_guard<std::mutex> lk(c.mu);
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+      dev = it->second.first;
+      const size_t sz = it->second.second;
+      c.live.erase(it);
+      c.free_[dev].insert(std::make_pair(sz, p));
+      c.cached[dev] += sz;
+      while (c.cached[dev] > c.keep && !c.free_[dev].empty()) {  // over the cap: the largest blocks go back
+        auto last = std::prev(c.free_[dev].end());
+        evict.push_back(last->second);
+        c.cached[dev] -= last->first;
+        c.free_[dev].erase(last);
+      }
+    }
+  }
+  if (dev < 0) {  // not from the cache (GDN_SCRATCH_POOL=0)
+    (void)hipFree(p);
+    return;
+  }
+  if (!evict.empty()) {
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != dev) (void)hipSetDevice(dev);
+    for (void *q : evict) (void)hipFree(q);
+    if (cur != dev) (void)hipSetDevice(cur);
+  }
 }
 
 int gdn_require_device() {
@@ -128,7 +303,7 @@ int gdn_exclusive_scan_u32_to_u64(const uint32_t *d_in, eoff_t *d_out, size_t n,
   }
   const size_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
   DevBuf<eoff_t> sums;
-  GDN_TRY(sums.alloc(nb));
+  GDN_TRY(sums.alloc_scratch(nb));
   hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, sums.p);
   hipLaunchKernelGGL(scan_single_block, dim3(1), dim3(GDN_BLOCK), 0, s, sums.p, nb);
   hipLaunchKernelGGL(scan_downsweep, dim3((unsigned)nb), dim3(GDN_BLOCK), 0, s, d_in, n, sums.p, d_out,

@@ -16,7 +16,7 @@
 //                  popcount of the row-start bitmap, tile counts (bin x chunk) and tier counts in LDS.
 //   (scans: padded tile offsets in chunk-major and bin-major order, segment offsets, tier bin offsets)
 //   pt_split       stable partition of every bin's edges by (chunk >> 3 | tier): a workgroup walks its bin in steps of
-//                  16 K edges, ranks them per wave by ballot matching, puts the step in digit order in LDS and writes
+//                  8 K edges, ranks them per wave by ballot matching, puts the step in digit order in LDS and writes
 //                  runs.  Main-layout edges become 32-bit items (slot, row, chunk & 7), tier edges their final records.
 //   pt_tiles       a wave per (bin, 8 chunks) segment: stable split by the last 3 chunk bits straight into V (contiguous)
 //                  and U (one run per tile).
@@ -28,10 +28,11 @@
 // Limits (the caller falls back to pb_build): <= 8192 source chunks, bins of <= 2^14 rows, in-CSR orientation.
 #pragma once
 
-#define PT_THREADS 1024
-#define PT_WAVES (PT_THREADS / 64)
+#define PT_THREADS 1024                 // pt_keygen
+#define PT_PTHREADS 512                 // the partition kernels: 256 VGPRs per lane (16 items + digits + ranks live at once:
+#define PT_WAVES (PT_PTHREADS / 64)     //   1024 threads spilled 1 KB per lane), two workgroups per CU
 #define PT_IPT 16
-#define PT_STEP (PT_THREADS * PT_IPT)  // 16384 edges per step of a partition
+#define PT_STEP (PT_PTHREADS * PT_IPT)  // 8192 items per step of a partition
 #define PT_MAX_DIGITS 1024
 #define PT_LOW_BITS 3                  // chunk bits left to pt_tiles (slot 15 + row 14 + 3 = one 32-bit item)
 #define PT_INACTIVE 0xFFFFFFFFu
@@ -42,25 +43,16 @@
 #define PT_NCLS (1 + PB_MAX_REC_TIERS) // class 0 + record tiers
 static_assert(PT_NCLS <= 6, "pt_src_assign_kernel packs the class counts of a thread into two u64 of three 16-bit fields");
 
-// ---- scratch: ONE device block per phase, bump-allocated (a hipFree costs 0.16 ms whatever the size, a 16 GB hipMalloc
-// 0.8 s -- the stream-ordered pool 6 ms: profiles/r04_malloc_probe.txt)
+// ---- scratch: ONE block of the scratch pool per phase, bump-allocated (gdn_scratch_malloc, gdn_common.hpp)
 struct PtArena {
   char *base = nullptr;
   size_t cap = 0, used = 0;
-  bool pooled = false;
-  int init(size_t bytes) {
+  int init(size_t bytes, int site = 1) {
     release();
     bytes += 4096;
-    hipError_t e;
-    pooled = bytes >= ((size_t)3 << 30);
-    if (pooled) e = hipMallocAsync((void **)&base, bytes, 0);
-    else e = hipMalloc((void **)&base, bytes);
-    if (e != hipSuccess) {
-      base = nullptr;
-      (void)hipGetLastError();
-      gdn_set_error("layout build: %zu bytes of scratch -> %s", bytes, hipGetErrorString(e));
-      return GDN_ERR_OOM;
-    }
+    void *q = nullptr;
+    GDN_TRY(gdn_scratch_malloc(&q, bytes, site));
+    base = static_cast<char *>(q);
     cap = bytes;
     used = 0;
     return GDN_OK;
@@ -74,16 +66,24 @@ struct PtArena {
     return reinterpret_cast<T *>(base + at);
   }
   void release() {
-    if (base) {
-      if (pooled) (void)hipFreeAsync(base, 0);
-      else (void)hipFree(base);
-    }
+    if (base) gdn_scratch_free(base);
     base = nullptr;
     cap = used = 0;
   }
   ~PtArena() { release(); }
 };
 static inline size_t pt_pad256(size_t bytes) { return (bytes + 511) & ~(size_t)255; }
+// Zeroing inside an arena is done by a kernel, not by hipMemsetAsync: on stream-ordered (hipMallocAsync) memory this runtime
+// runs such a memset BEHIND the kernel queued after it (tools/memset_probe.hip, profiles/r04_memset_probe.txt -- the builder
+// lost its row-start bits that way).  The arenas are hipMalloc blocks of the scratch cache now; the kernel stays.
+static inline int pt_zero(void *p, size_t bytes) {
+  const unsigned long long nw = (bytes + 3) / 4;
+  if (nw == 0) return GDN_OK;
+  const unsigned long long nb = (nw + GDN_BLOCK - 1) / GDN_BLOCK;
+  hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(nb > 65536ull ? 65536ull : nb)), dim3(GDN_BLOCK), 0, 0, static_cast<uint32_t *>(p), nw, 0u);
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
 
 // ---- device-wide scans without allocation or synchronisation: rows of u32 block counts scanned by one workgroup per row
 static __global__ void __launch_bounds__(GDN_BLOCK)
@@ -111,7 +111,7 @@ struct PtSrcArgs {
   const int32_t *src_count;  // exact out-edge counts (trusted superset of "occurs as a column"), or nullptr:
   const uint32_t *cnt16;     //   sampled counts (pb_hub_sample_kernel) ...
   const uint32_t *mark;      //   ... and exact marks
-  unsigned thr[PB_MAX_REC_TIERS];  // sampled-count units, descending; tier t: count >= thr[t]
+  unsigned thr[PB_MAX_REC_TIERS];  // descending; tier t: count >= thr[t] (units: edges with src_count, else 16 edges)
   int ntiers;
   unsigned n;  // sources
 };
@@ -122,7 +122,7 @@ __device__ __forceinline__ int pt_class_of(const PtSrcArgs &a, unsigned s) {
   if (a.src_count) {
     const int32_t d = a.src_count[s];
     act = d > 0;
-    c16 = act ? (unsigned)d >> PB_HUB_SAMPLE_LOG : 0u;
+    c16 = act ? (unsigned)d : 0u;
   } else {
     act = a.mark[s] != 0u;
     c16 = a.cnt16[s];
@@ -324,11 +324,11 @@ pt_mark_kernel(const vid_t *__restrict__ colidx, eoff_t nnz, uint32_t *__restric
   for (eoff_t e = (eoff_t)blockIdx.x * GDN_BLOCK + threadIdx.x; e < nnz; e += (eoff_t)gridDim.x * GDN_BLOCK)
     mark[__builtin_nontemporal_load(colidx + e)] = 1u;  // benign race: everybody stores 1
 }
-// src_count >> 4 as the "sampled" count of the histogram kernels
+// exact counts as the input of the histogram kernels (negative = 0)
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pt_count16_kernel(const int32_t *__restrict__ deg, unsigned n, uint32_t *__restrict__ out) {
   const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
-  if (i < n) out[i] = deg[i] > 0 ? (uint32_t)deg[i] >> PB_HUB_SAMPLE_LOG : 0u;
+  if (i < n) out[i] = deg[i] > 0 ? (uint32_t)deg[i] : 0u;
 }
 
 // ---- pt_keygen: the ONE gather pass ---------------------------------------------------------------------------------
@@ -359,7 +359,8 @@ pt_keygen_kernel(PtKeyArgs a) {
   unsigned bad = 0u;
   if (E1 > E0) {
     const eoff_t w0 = E0 >> 6, w1 = (E1 - 1) >> 6;  // 64-edge words of the bin, inclusive
-    const eoff_t per = (w1 - w0 + PT_WAVES) / PT_WAVES;
+    constexpr unsigned KW = PT_THREADS / 64;
+    const eoff_t per = (w1 - w0 + KW) / KW;
     const eoff_t wa = w0 + (eoff_t)w * per, wb = wa + per < w1 + 1 ? wa + per : w1 + 1;
     if (wa < wb) {
       const eoff_t kb0 = (eoff_t)b * a.per_b, kb1 = kb0 + a.per_b < a.n_dst ? kb0 + a.per_b : a.n_dst;
@@ -480,13 +481,30 @@ __device__ __forceinline__ unsigned long long pt_match(unsigned d, bool valid, i
   }
   return peers;
 }
+// exclusive scan over the PT_PTHREADS threads of a partition workgroup; scratch = PT_WAVES + 1 unsigned
+__device__ __forceinline__ unsigned pt_block_excl_scan(unsigned v, unsigned *scratch, unsigned *total) {
+  const unsigned incl = gdn_wave_incl_scan(v);
+  const unsigned w = threadIdx.x >> 6;
+  __syncthreads();
+  if (gdn_lane() == 63) scratch[w] = incl;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < PT_WAVES; i++) {
+    const unsigned x = scratch[i];
+    if ((unsigned)i < w) base += x;
+    tot += x;
+  }
+  *total = tot;
+  return base + incl - v;
+}
 struct PtStage {
   uint32_t *stage;           // PT_STEP items in digit order
   unsigned short *dig;       // their digits
   unsigned short *wc;        // PT_WAVES x nd: per wave and digit, count -> exclusive prefix over the waves
   unsigned *start, *tot;     // nd: first position of a digit in the staged order, its count in this step
   unsigned long long *goff;  // nd: where the digit's next item goes in `out`
-  unsigned *scr;             // PB_WAVES + 1 (pb_block_excl_scan)
+  unsigned *scr;             // PT_WAVES + 1 (pt_block_excl_scan)
 };
 __device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned nd) {
   PtStage s;
@@ -539,22 +557,27 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
       rk[j] = (unsigned short)(old + r);
     }
     __syncthreads();
-    // per digit: counts of the waves -> exclusive prefix over the waves, total of the step
-    unsigned mine = 0u;
-    if (threadIdx.x < nd) {
-      unsigned acc = 0u;
+    // per digit (two per thread): counts of the waves -> exclusive prefix over the waves, total of the step
+    unsigned mine[2] = {0u, 0u};
 #pragma unroll
-      for (int ww = 0; ww < PT_WAVES; ww++) {
-        const unsigned c = st.wc[(size_t)ww * nd + threadIdx.x];
-        st.wc[(size_t)ww * nd + threadIdx.x] = (unsigned short)acc;
-        acc += c;
+    for (int q = 0; q < 2; q++) {
+      const unsigned d = 2u * threadIdx.x + (unsigned)q;
+      if (d < nd) {
+        unsigned acc = 0u;
+#pragma unroll
+        for (int ww = 0; ww < PT_WAVES; ww++) {
+          const unsigned c = st.wc[(size_t)ww * nd + d];
+          st.wc[(size_t)ww * nd + d] = (unsigned short)acc;
+          acc += c;
+        }
+        mine[q] = acc;
+        st.tot[d] = acc;
       }
-      mine = acc;
-      st.tot[threadIdx.x] = acc;
     }
     unsigned total;
-    const unsigned ex = pb_block_excl_scan(mine, st.scr, &total);
-    if (threadIdx.x < nd) st.start[threadIdx.x] = ex;
+    const unsigned ex = pt_block_excl_scan(mine[0] + mine[1], st.scr, &total);
+    if (2u * threadIdx.x < nd) st.start[2u * threadIdx.x] = ex;
+    if (2u * threadIdx.x + 1u < nd) st.start[2u * threadIdx.x + 1u] = ex + mine[0];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PT_IPT; j++) {
@@ -569,17 +592,17 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < PT_IPT; j++) {
-      const unsigned pos = (unsigned)j * PT_THREADS + threadIdx.x;
+      const unsigned pos = (unsigned)j * PT_PTHREADS + threadIdx.x;
       if (pos < cnt) {
         const unsigned d = st.dig[pos];
         out[st.goff[d] + (pos - st.start[d])] = st.stage[pos];
       }
     }
     __syncthreads();
-    if (threadIdx.x < nd) {
-      st.goff[threadIdx.x] += st.tot[threadIdx.x];
+    for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
+      st.goff[d] += st.tot[d];
 #pragma unroll
-      for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+      for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + d] = 0;
     }
     __syncthreads();
   }
@@ -598,17 +621,16 @@ struct PtSplitArgs {
   unsigned d1;
   int ntiers, log_chunk, dbits;
 };
-static __global__ void __launch_bounds__(PT_THREADS)
+static __global__ void __launch_bounds__(PT_PTHREADS)
 pt_split_kernel(PtSplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = a.d1 + (unsigned)a.ntiers;
   const PtStage st = pt_stage_carve(s_raw, nd);
   const unsigned b = a.order[blockIdx.x];
-  if (threadIdx.x < nd) {
-    st.goff[threadIdx.x] = threadIdx.x < a.d1 ? a.segoff[(size_t)b * a.d1 + threadIdx.x]
-                                               : a.tier_base[threadIdx.x - a.d1] + a.tier_ptr[threadIdx.x - a.d1][b];
+  for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
+    st.goff[d] = d < a.d1 ? a.segoff[(size_t)b * a.d1 + d] : a.tier_base[d - a.d1] + a.tier_ptr[d - a.d1][b];
 #pragma unroll
-    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + d] = 0;
   }
   __syncthreads();
   const eoff_t E0 = a.bin_e[b], E1 = a.bin_e[b + 1];
@@ -684,7 +706,7 @@ struct PtRadixArgs {
   int last;                   // final pass: pad records behind the segment
   uint32_t zrec;
 };
-static __global__ void __launch_bounds__(PT_THREADS)
+static __global__ void __launch_bounds__(PT_PTHREADS)
 pt_radix_kernel(PtRadixArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = 1u << a.bits;
@@ -694,19 +716,33 @@ pt_radix_kernel(PtRadixArgs a) {
   const unsigned n = a.tier_cnt[(size_t)b * 8 + a.tier];
   const uint32_t *in = a.in + p0;
   const unsigned mask = nd - 1u;
-  // histogram of the segment (st.tot doubles as the counter array)
-  if (threadIdx.x < nd) {
-    st.tot[threadIdx.x] = 0u;
+  // histogram of the segment (st.tot doubles as the counter array; eight loads in flight per thread)
+  for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
+    st.tot[d] = 0u;
 #pragma unroll
-    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + threadIdx.x] = 0;
+    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + d] = 0;
   }
   __syncthreads();
-  for (unsigned i = threadIdx.x; i < n; i += PT_THREADS) atomicAdd(&st.tot[(in[i] >> a.shift) & mask], 1u);
+  for (unsigned i0 = threadIdx.x; i0 < n; i0 += 8u * PT_PTHREADS) {
+    uint32_t v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const unsigned i = i0 + (unsigned)r * PT_PTHREADS;
+      v[r] = i < n ? in[i] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      if (i0 + (unsigned)r * PT_PTHREADS < n) atomicAdd(&st.tot[(v[r] >> a.shift) & mask], 1u);
+  }
   __syncthreads();
-  unsigned total;
-  const unsigned mine = threadIdx.x < nd ? st.tot[threadIdx.x] : 0u;
-  const unsigned ex = pb_block_excl_scan(mine, st.scr, &total);
-  if (threadIdx.x < nd) st.goff[threadIdx.x] = p0 + ex;
+  {
+    const unsigned d0 = 2u * threadIdx.x, d1 = d0 + 1u;
+    const unsigned m0 = d0 < nd ? st.tot[d0] : 0u, m1 = d1 < nd ? st.tot[d1] : 0u;
+    unsigned total;
+    const unsigned ex = pt_block_excl_scan(m0 + m1, st.scr, &total);
+    if (d0 < nd) st.goff[d0] = p0 + ex;
+    if (d1 < nd) st.goff[d1] = p0 + ex + m0;
+  }
   __syncthreads();
   const int shift = a.shift;
   pt_partition(n, nd, a.bits, a.out, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
@@ -715,7 +751,7 @@ pt_radix_kernel(PtRadixArgs a) {
   });
   if (a.last) {
     const unsigned npad = (n + 15u) & ~15u;
-    for (unsigned i = n + threadIdx.x; i < npad; i += PT_THREADS) a.out[p0 + i] = a.zrec;
+    for (unsigned i = n + threadIdx.x; i < npad; i += PT_PTHREADS) a.out[p0 + i] = a.zrec;
   }
 }
 
@@ -738,6 +774,14 @@ pt_sizes_from_ptr_kernel(const eoff_t *__restrict__ ptr, unsigned n, eoff_t *__r
 static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   const auto t_begin = std::chrono::steady_clock::now();
   const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
+  auto t_last = t_begin;
+  auto phase = [&](const char *name) {  // GDN_PB_TRACE: wall time of every phase (synchronises: the timings perturb)
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pb_build_tiered]   %-22s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
   GDN_REQUIRE(a.rowptr && (a.colidx || a.nnz == 0) && a.m_rows >= 0 && a.m_global > 0, "layout build: arguments");
   GDN_REQUIRE(!a.colmap || a.src_count, "layout build: a column map needs source counts");
   const int lc = a.log_chunk, lb = a.log_bin;
@@ -775,16 +819,17 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   uint16_t *R = A1.get<uint16_t>(n);
   PT_CHECK_PTR(R);
   PT_CHECK_PTR(S);
-  GDN_HIP(hipMemsetAsync(hist, 0, (PB_HUB_BUCKETS + PB_LIN_BINS) * 4, 0));
-  GDN_HIP(hipMemsetAsync(errflag, 0, 16, 0));
-  GDN_HIP(hipMemsetAsync(rowstart, 0, ((size_t)(n >> 5) + 4) * 4, 0));
+  phase("arena 1");
+  GDN_TRY(pt_zero(hist, (PB_HUB_BUCKETS + PB_LIN_BINS) * 4));
+  GDN_TRY(pt_zero(errflag, 16));
+  GDN_TRY(pt_zero(rowstart, ((size_t)(n >> 5) + 4) * 4));
   // ---- source counts (sampled units) and their histograms; active rows
   const bool want_tiers = a.tiers && lb <= PB_MID_ROW_BITS;
   if (a.src_count) {
     if (want_tiers) hipLaunchKernelGGL(pt_count16_kernel, dim3(gdn_nblocks(mL)), dim3(GDN_BLOCK), 0, 0, a.src_count, mL, cnt16);
   } else {
-    GDN_HIP(hipMemsetAsync(mark, 0, (size_t)mL * 4, 0));
-    GDN_HIP(hipMemsetAsync(cnt16, 0, (size_t)mL * 4, 0));
+    GDN_TRY(pt_zero(mark, (size_t)mL * 4));
+    GDN_TRY(pt_zero(cnt16, (size_t)mL * 4));
     if (n) {
       const unsigned long long gb = (n + GDN_BLOCK * 8ull - 1) / (GDN_BLOCK * 8ull);
       hipLaunchKernelGGL(pt_mark_kernel, dim3((unsigned)(gb > 262144ull ? 262144ull : gb)), dim3(GDN_BLOCK), 0, 0, a.colidx, (eoff_t)n, mark);
@@ -806,6 +851,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   GDN_HIP(hipMemcpy(h_hist.data(), hist, h_hist.size() * 4, hipMemcpyDeviceToHost));
   GDN_HIP(hipMemcpy(h_tot + 8, totals + 8, 4, hipMemcpyDeviceToHost));
   const uint64_t n_dst = h_tot[8];
+  phase("counts + histograms");
   PtSrcArgs sa;
   memset(&sa, 0, sizeof(sa));
   sa.src_count = a.src_count;
@@ -818,7 +864,10 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     unsigned thr[1 + PB_MAX_MID];
     int nt = 0;
     const uint64_t nbins_est = ((n_dst + (1ull << lb) - 1) >> lb) + 1;
-    pb_choose_tiers(h_hist.data(), a.max_mid > 0 ? h_hist.data() + PB_HUB_BUCKETS : nullptr, nbins_est, n, a.max_mid, a.min16, thr, &nt);
+    // exact counts cut the tiers at single degrees (the linear histogram covers degrees < 4095: every mid-tier threshold
+    // of a graph with <= 2^17 bins); sampled ones stand for 16 edges each
+    pb_choose_tiers(h_hist.data(), a.max_mid > 0 ? h_hist.data() + PB_HUB_BUCKETS : nullptr, nbins_est, n, a.max_mid, a.min16, thr, &nt,
+                    a.src_count ? 0 : PB_HUB_SAMPLE_LOG);
     has_hub = thr[0] != 0xFFFFFFFFu;
     // classes in use, in descending threshold order (a missing hub class is dropped: the tiers are numbered 1.. here)
     for (int t = has_hub ? 0 : 1; t < nt; t++) sa.thr[sa.ntiers++] = thr[t];
@@ -828,6 +877,14 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipMemcpy(h_tot, totals, PT_NCLS * 4, hipMemcpyDeviceToHost));
   const uint64_t n_src0 = h_tot[0];
+  phase("class counts");
+  if (trace) {
+    fprintf(stderr, "[pb_build_tiered]   rows with entries %llu, sources per class:", (unsigned long long)n_dst);
+    for (int k = 0; k < PT_NCLS; k++) fprintf(stderr, " %u", h_tot[k]);
+    fprintf(stderr, "; thresholds:");
+    for (int t = 0; t < sa.ntiers; t++) fprintf(stderr, " %u", sa.thr[t]);
+    fprintf(stderr, " (%s counts)\n", a.src_count ? "exact" : "sampled");
+  }
   // tiers that came out empty are dropped from the back (the histogram counted them, so only when nothing qualifies)
   while (sa.ntiers > 0 && h_tot[sa.ntiers] == 0) sa.ntiers--;
   for (int t = 0; t < sa.ntiers; t++) {
@@ -884,7 +941,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     bytes += pt_pad256((size_t)nbins * 8 * 4) + pt_pad256((size_t)PB_MAX_REC_TIERS * nbins * 4);
     bytes += pt_pad256(((size_t)nbins + 2) * 8) * 3 + pt_pad256((size_t)nbins * 4) + pt_pad256(((size_t)nchunks + 1) * 8);
     bytes += pt_pad256((ntiles / 2048 + 16) * 8) * 2;
-    GDN_TRY(A2.init(bytes));
+    GDN_TRY(A2.init(bytes, 2));
   }
   uint32_t *tile_cnt = A2.get<uint32_t>(ntiles), *psz_c = A2.get<uint32_t>(ntiles), *psz_b = A2.get<uint32_t>(ntiles);
   eoff_t *pu = A2.get<eoff_t>(ntiles + 1), *pv = A2.get<eoff_t>(ntiles + 1);
@@ -896,7 +953,8 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   uint32_t *order = A2.get<uint32_t>(nbins);
   eoff_t *ws = A2.get<eoff_t>(ntiles / 2048 + 16);
   PT_CHECK_PTR(ws);
-  GDN_HIP(hipMemsetAsync(bin_e, 0, ((size_t)nbins + 2) * 8, 0));
+  GDN_TRY(pt_zero(bin_e, ((size_t)nbins + 2) * 8));
+  phase("plan arrays + arena 2");
   // ---- ranks
   {
     PtSrcOut so;
@@ -921,6 +979,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
                        (eoff_t)n_dst, (eoff_t)n, n_src0 ? 1 : 0, n_dst ? 1 : 0);
     GDN_HIP(hipGetLastError());
   }
+  phase("ranks");
   // ---- the gather pass
   {
     PtKeyArgs ka;
@@ -942,6 +1001,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     hipLaunchKernelGGL(pt_keygen_kernel, dim3(nbins), dim3(PT_THREADS), (size_t)nchunks * 4, 0, ka);
     GDN_HIP(hipGetLastError());
   }
+  phase("pt_keygen");
   // ---- offsets
   {
     const unsigned long long tt = ntiles > (unsigned long long)d1 * nbins ? ntiles : (unsigned long long)d1 * nbins;
@@ -971,6 +1031,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   if (ntiers) GDN_HIP(hipMemcpy(h_tier_cnt.data(), tier_cnt, h_tier_cnt.size() * 4, hipMemcpyDeviceToHost));
   for (int t = 0; t < ntiers; t++)
     GDN_HIP(hipMemcpy(&tier_pad[t], ts.t[t].bin_ptr.p + nbins, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  if (trace) fprintf(stderr, "[pb_build_tiered]   main edges %llu, mismatch flag %u\n", (unsigned long long)n0, h_err);
   if (h_err) {
     gdn_set_error("layout build: a column id occurs whose source count is 0 (counts do not match the graph)");
     return 2;  // the caller repeats the build with exact marks
@@ -981,6 +1042,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     ts.t[t].nnz = s;
   }
   p.nnz = n0;
+  phase("offsets + readback");
   // slice starts on aligned boundaries (see pb_build)
   eoff_t n_pad = 0;
   std::vector<eoff_t> ca((size_t)nchunks + 1, 0), ba((size_t)nbins + 1, 0);
@@ -1027,7 +1089,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     xlen += tier_pad[t];
   }
   PtArena A3;
-  GDN_TRY(A3.init(pt_pad256((size_t)xlen * 4) + pt_pad256((size_t)(xlen - n0) * 4) + 4096));
+  GDN_TRY(A3.init(pt_pad256((size_t)xlen * 4) + pt_pad256((size_t)(xlen - n0) * 4) + 4096, 4));
   uint32_t *X = A3.get<uint32_t>(xlen);
   uint32_t *TMP = A3.get<uint32_t>(xlen - n0);  // second buffer of the tiers' radix passes (laid out like X's tier part)
   PT_CHECK_PTR(X);
@@ -1046,6 +1108,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fbg > 262144ull ? 262144ull : fbg)), dim3(GDN_BLOCK), 0, 0, p.G.p, ng,
                        (uint32_t)(n_pad >> a.log_group));
   }
+  phase("arena 3 + U V G rec + fills");
   int dbits = 1;
   while ((1u << dbits) < nd_split) dbits++;
   {
@@ -1067,14 +1130,16 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     sp.dbits = dbits;
     const size_t lds = pt_stage_bytes(nd_split);
     GDN_HIP(hipFuncSetAttribute((const void *)pt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (n) hipLaunchKernelGGL(pt_split_kernel, dim3(nbins), dim3(PT_THREADS), lds, 0, sp);
+    if (n) hipLaunchKernelGGL(pt_split_kernel, dim3(nbins), dim3(PT_PTHREADS), lds, 0, sp);
     GDN_HIP(hipGetLastError());
   }
+  phase("pt_split");
   if (n0) {
     const unsigned long long nseg = (unsigned long long)d1 * nbins;
     hipLaunchKernelGGL(pt_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, X, segoff, d1, nbins, nchunks, pu, pv, p.U.p, p.V.p);
     GDN_HIP(hipGetLastError());
   }
+  phase("pt_tiles");
   // record tiers: (row, source) -> (source, row) inside every bin
   if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)pt_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS)));
   for (int t = 0; t < ntiers; t++) {
@@ -1096,10 +1161,11 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
       ra.bits = ps == 0 ? b1 : nbits - b1;
       ra.last = ps == passes - 1 ? 1 : 0;
       const size_t lds = pt_stage_bytes(1u << ra.bits);
-      hipLaunchKernelGGL(pt_radix_kernel, dim3(nbins), dim3(PT_THREADS), lds, 0, ra);
+      hipLaunchKernelGGL(pt_radix_kernel, dim3(nbins), dim3(PT_PTHREADS), lds, 0, ra);
     }
     GDN_HIP(hipGetLastError());
   }
+  phase("pt_radix");
   hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu, pv, psz_c, nchunks, nbins, p.G.p, 0, a.log_group);
   GDN_HIP(hipGetLastError());
   {  // largest-first launch order of both phases
@@ -1123,6 +1189,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   ts.n = ntiers;
   ts.first_is_hub = has_hub && ntiers > 0;
   GDN_HIP(hipDeviceSynchronize());
+  phase("groups + orders + vals");
   if (trace) {
     fprintf(stderr, "[pb_build_tiered] edges %llu: main %llu padded %llu (%.3f x) chunks %u (%llu slots) bins %u", n,
             (unsigned long long)n0, (unsigned long long)n_pad, n0 ? (double)n_pad / (double)n0 : 0.0, nchunks,

@@ -1492,7 +1492,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     // graphs of the CSR regime: the whole solve in one cooperative launch (GDN_PR_FUSED=0: the per-iteration loop)
     {
       const char *env = gdn_option("GDN_PR_LAYOUT"), *fz = gdn_option("GDN_PR_FUSED");
-      const bool want = fz ? fz[0] != '0' : (!env && nnz < (1ull << 18));  // measured: 20 us per iteration against the loop's 27 at 0.23 M edges, 35 against 30 at 1 M
+      const bool want = fz ? fz[0] != '0' : (!(env && (env[0] == 'c' || env[0] == 'p')) && nnz < (1ull << 18));  // measured: 20 us per iteration against the loop's 27 at 0.23 M edges, 35 against 30 at 1 M
       int fused = 0;
       if (want && (rc = pr_solve_fused(g, d_deg.p, d_scores.p, damping, epsilon, max_iter, &st, &fused))) break;
       if (fused) {
@@ -1513,20 +1513,23 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       // forced layout the call picks by PREDICTED WALL TIME: iterations to epsilon ~ 24 at 1e-4 on power-law graphs (15 on
       // test/graphs/pr.mtx, 22 on RMAT-22), scaled with log(epsilon), capped by max_iter; per edge and iteration the
       // merge-path layout costs ~10 ps (18 ps from 2^28 edges on: the contribution vector no longer fits the Infinity
-      // Cache), the blocked one 2.3 ps, and the blocked layout costs ~480 ps per edge to build (tools/pr_oneshot.py,
-      // bench.py `pr_oneshot`).  GDN_PR_ONESHOT=solve restores "blocked from 2^22 edges on" (best solve_ms, the number the
-      // reference's Timer prints); callers that iterate or solve repeatedly hold a plan (gdn_pr_plan_create).
+      // Cache), the blocked one 2.3 ps, and the blocked layout ~100 ps per edge to build with the tiered builder of round 4
+      // (RMAT-22: 6.3 ms of prep for 65 M edges, RMAT-27: 0.15 s for 2.1 G; round 3: 480 ps -- the merge-path layout then won
+      // every single solve at epsilon 1e-4) -- so the blocked layout wins from ~13 iterations on.  GDN_PR_ONESHOT=solve:
+      // "blocked from 2^22 edges on" whatever the iteration count (best solve_ms, the number the reference's Timer prints);
+      // GDN_PR_LAYOUT=c / p force a layout, anything else is this choice.
       const char *os_ = gdn_option("GDN_PR_ONESHOT");
       bool pb = nnz >= (1ull << 22);
       if (pb && !(os_ && os_[0] == 's')) {
         double iters = 24.0;
         if (epsilon > 0.0 && epsilon < 1.0) iters = 24.0 * log(epsilon) / log(1e-4);
         if (!(epsilon > 0.0) || iters > (double)max_iter) iters = (double)max_iter;
-        const double csr_ps = nnz >= (1ull << 28) ? 18.0 : 10.0, pb_ps = 2.3, build_ps = 480.0;
+        const double csr_ps = nnz >= (1ull << 28) ? 18.0 : 10.0, pb_ps = 2.3, build_ps = 100.0;
         pb = iters * (csr_ps - pb_ps) > build_ps;
       }
-      if (pb && !env && pr_gather_is_local(g, 0)) pb = false;  // lattice-like graphs: the merge-path layout is the faster one anyway
-      if (env) pb = env[0] == 'p';
+      const bool forced = env && (env[0] == 'c' || env[0] == 'p');
+      if (pb && !forced && pr_gather_is_local(g, 0)) pb = false;  // lattice-like graphs: the merge-path layout is the faster one anyway
+      if (forced) pb = env[0] == 'p';
       if (pb && !(sq && sq[0] == '0')) layout = GDN_LAYOUT_PB_SQUISHED;
       else if (!pb) layout = GDN_LAYOUT_CSR;
     }

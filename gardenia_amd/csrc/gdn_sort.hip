@@ -159,8 +159,8 @@ int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned lo
   const unsigned span = end_bit - begin_bit, passes = (span + 7) / 8;
   DevBuf<uint32_t> counts;
   DevBuf<eoff_t> offsets;
-  GDN_TRY(counts.alloc((size_t)256 * nblocks));
-  GDN_TRY(offsets.alloc((size_t)256 * nblocks + 1));
+  GDN_TRY(counts.alloc_scratch((size_t)256 * nblocks));
+  GDN_TRY(offsets.alloc_scratch((size_t)256 * nblocks + 1));
   unsigned long long *src = a, *dst = b;
   unsigned bit = begin_bit;
   for (unsigned p = 0; p < passes; p++) {

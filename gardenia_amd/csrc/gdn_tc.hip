@@ -645,6 +645,7 @@ struct TcRelabelVis {
   const vid_t *__restrict__ newid;
   unsigned long long *__restrict__ keys;  // one per CSR entry: (low rank << 32 | high rank), a self loop where nothing is kept
   int both;  // the input lists every edge in both directions (symmetric graph): keep the entry with rank(src) < rank(dst)
+  unsigned *__restrict__ descends;  // oriented input: set when an edge does not ascend in rank (see tc_forward_build)
   int32_t v;
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
@@ -653,7 +654,10 @@ struct TcRelabelVis {
       const unsigned a = (unsigned)newid[src], b = (unsigned)newid[colidx[k]];
       unsigned long long key;
       if (both) key = a < b ? (((unsigned long long)a << 32) | b) : (((unsigned long long)a << 32) | a);  // self loop = dropped
-      else key = a < b ? (((unsigned long long)a << 32) | b) : (((unsigned long long)b << 32) | a);
+      else {
+        key = a < b ? (((unsigned long long)a << 32) | b) : (((unsigned long long)b << 32) | a);
+        if (a >= b) *descends = 1u;
+      }
       keys[k] = key;
     }
   }
@@ -721,8 +725,13 @@ int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned lo
 int gdn_build_csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long long> &kb, unsigned long long n, int32_t m,
                             gdn_graph **out);
 
-// g: a symmetric graph (oriented == false) or any acyclic orientation of one (oriented == true) -> the rank-ordered DAG, its
-// transpose and the walk starts of the forward count
+// g: a symmetric graph (oriented == false) or its orientation by (degree, id) -- what the reference's
+// Graph::orientation (src/common/graph.cc:67-113) hands to TCSolver -- (oriented == true) -> the rank-ordered DAG, its
+// transpose and the walk starts of the forward count.
+// The forward count is the number of triangles of the underlying simple graph; the reference's loop (src/tc/omp_base.cc:16-22)
+// counts, on WHATEVER directed graph it is given, the pairs (u -> v, w in N+(u) and N+(v)).  The two agree when every edge
+// of an oriented input ascends in the (degree, id) order and no entry repeats -- checked here, one flag and one count.
+// Returns 1 (nothing built) when it does not hold: the caller then counts on the caller's orientation as it is.
 static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_out, gdn_graph **in_out, DevBuf<unsigned> &nstart) {
   const int32_t m = g->m;
   DevBuf<int32_t> deg;
@@ -744,11 +753,11 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   GDN_HIP(hipGetLastError());
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
   const unsigned bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
-  GDN_TRY(ka.alloc(g->nnz));
-  GDN_TRY(kb.alloc(g->nnz));
+  GDN_TRY(ka.alloc_scratch(g->nnz));
+  GDN_TRY(kb.alloc_scratch(g->nnz));
   GDN_TRY(bigitems.alloc(bigcap));
-  GDN_TRY(cnt.alloc(2));
-  GDN_HIP(hipMemset(cnt.p, 0, 8));
+  GDN_TRY(cnt.alloc(4));
+  GDN_HIP(hipMemset(cnt.p, 0, 16));
   ExpBigList big;
   big.items = bigitems.p;
   big.capacity = bigcap;
@@ -759,21 +768,27 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   rv.newid = newid.p;
   rv.keys = ka.p;
   rv.both = oriented ? 0 : 1;
+  rv.descends = cnt.p + 2;
   rv.v = 0;
   hipLaunchKernelGGL(tc_relabel_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, big, rv);
   hipLaunchKernelGGL(tc_relabel_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, rv);
   GDN_HIP(hipGetLastError());
-  unsigned ovf[2];
-  GDN_HIP(hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost));
+  unsigned ovf[4];
+  GDN_HIP(hipMemcpy(ovf, cnt.p, 16, hipMemcpyDeviceToHost));
   if (ovf[1]) {
     gdn_set_error("gdn_tc: device worklist overflow");
     return GDN_ERR_OVERFLOW;
   }
+  if (oriented && ovf[2]) return 1;  // not the (degree, id) orientation: count on the input as it is
   deg.release();
   ra.release();
   rb.release();
   gdn_graph *dag = nullptr, *din = nullptr;
   GDN_TRY(gdn_build_csr_from_keys(ka, kb, g->nnz, m, &dag));
+  if (oriented && dag->nnz != g->nnz) {  // repeated entries (or self loops) in an oriented input: the reference counts them
+    gdn_graph_free(dag);
+    return 1;
+  }
   int rc = dag->nnz ? gdn_graph_transpose(dag, &din) : GDN_OK;
   if (rc == GDN_OK && din) {
     rc = nstart.alloc(din->nnz);
@@ -973,10 +988,16 @@ int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan)
   const char form = e ? e[0] : (dag_edges >= (1ull << 24) ? 'f' : 'a');
   gdn_tc_plan *p = new gdn_tc_plan();
   int rc = GDN_OK;
-  if (form == 'f') {
+  bool forward = form == 'f';
+  if (forward) {
     rc = tc_forward_build(g, oriented != 0, &p->dag, &p->dag_in, p->nstart);
     p->form = 3;
-  } else {
+    if (rc == 1) {  // an oriented input that is not the reference's orientation of a simple graph: no re-ranking
+      forward = false;
+      rc = GDN_OK;
+    }
+  }
+  if (!forward) {
     rc = oriented ? tc_copy_graph(g, &p->dag) : tc_orient(g, &p->dag);
     if (rc == GDN_OK) {
       // which formulation probes less (tc_count_kernel): the v-centric one needs the transposed DAG

@@ -1229,6 +1229,26 @@ def test_tc_golden(case, form, monkeypatch):
     assert total2 == int(d["total"])
 
 
+@pytest.mark.parametrize("form", ["", "f"])
+def test_tc_oriented_input_that_is_no_dag_counts_like_the_reference_loop(orc, form, monkeypatch):
+    """with oriented=1 the count runs on the caller's lists AS THEY ARE (src/tc/omp_base.cc:16-22 does not know
+    whether they are an orientation): a directed graph with 2-cycles and cyclic triangles gives the reference loop's total,
+    also when the forward form is asked for (the default from 2^24 DAG edges on) -- its precondition check (every edge
+    ascends in the (degree, id) order, no entry repeats) sends such an input to the count on the given lists."""
+    if form:
+        monkeypatch.setenv("GDN_TC_FORM", form)
+    g = graphio.rmat_graph(12, 12, seed=77)  # directed: both directions of some pairs, cyclic triangles
+    want = orc.tc(g)
+    src, dst = graphio.csr_to_coo(graphio.symmetrize(g))
+    assert want != orc.tc(orc.tc_orient(graphio.symmetrize(g)))  # (not the triangle count of the underlying graph)
+    total, st = solvers.TCSolver(solvers.Graph(csr=g), oriented=True)
+    assert total == want and st["reserved"] in (0, 1)
+    # the reference's own orientation still takes the forward form when asked to
+    dag = orc.tc_orient(graphio.symmetrize(g))
+    total, st = solvers.TCSolver(solvers.Graph(csr=dag), oriented=True)
+    assert total == orc.tc(dag) and st["reserved"] == (3 if form else st["reserved"])
+
+
 @pytest.mark.parametrize("scale,ef,seed", [(13, 16, 41), (16, 8, 42)])
 def test_tc_vs_oracle_rmat(orc, scale, ef, seed, monkeypatch):
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))

@@ -2,7 +2,8 @@ import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np
 from gardenia_amd import graphio, solvers
-for scale in (18, 20, 22):
+scales = [int(x) for x in sys.argv[1:]] or [18, 20, 22]
+for scale in scales:
     g = graphio.rmat_graph(scale, 16, seed=3)
     G = solvers.Graph(csr=g, need_reverse=True)
     for lay in ("csr", "pb"):
