@@ -501,7 +501,7 @@ __device__ __forceinline__ unsigned pt_block_excl_scan(unsigned v, unsigned *scr
 struct PtStage {
   uint32_t *stage;           // PT_STEP items in digit order
   unsigned short *dig;       // their digits
-  unsigned short *wc;        // PT_WAVES x nd: per wave and digit, count -> exclusive prefix over the waves
+  unsigned *wc;              // PT_WAVES x nd: per wave and digit, count -> exclusive prefix over the waves
   unsigned *start, *tot;     // nd: first position of a digit in the staged order, its count in this step
   unsigned long long *goff;  // nd: where the digit's next item goes in `out`
   unsigned *scr;             // PT_WAVES + 1 (pt_block_excl_scan)
@@ -513,21 +513,28 @@ __device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned n
   s.start = reinterpret_cast<unsigned *>(s.goff + nd);
   s.tot = s.start + nd;
   s.scr = s.tot + nd;
-  s.dig = reinterpret_cast<unsigned short *>(s.scr + PT_WAVES + 2);
-  s.wc = s.dig + PT_STEP;
+  s.wc = s.scr + PT_WAVES + 2;
+  s.dig = reinterpret_cast<unsigned short *>(s.wc + (size_t)PT_WAVES * nd);
   return s;
 }
 static inline size_t pt_stage_bytes(unsigned nd) {
-  return (size_t)PT_STEP * 4 + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_STEP * 2 + (size_t)PT_WAVES * nd * 2 + 64;
+  return (size_t)PT_STEP * 4 + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_STEP * 2 + (size_t)PT_WAVES * nd * 4 + 64;
 }
 // Walks items [0, n) in steps of PT_STEP.  load(i, item, digit) for i < n.  The caller has set st.goff[d] (behind a
 // barrier) and zeroed st.wc.  Every thread of the workgroup must call.
-template <class Load>
+// Rank of an item among the items of its digit: a wave owns 1024 consecutive items of a step and counts them in ITS row of
+// st.wc.  STABLE = false (default): one LDS atomic with return per item -- sixteen independent ones in flight per lane;
+// items of one wave instruction that share a digit take their slots in the order the LDS unit serialises the conflict
+// (lane order on this hardware: the partition came out stable in every comparison with the other form, but nothing
+// documents it, and no result depends on the order inside a tile or a record stream).  STABLE = true (GDN_PT_STABLE=1):
+// ballot matching, the leader lane adds the group's count -- stable by construction, ~10 VALU instructions per digit bit
+// and item, and one LDS round trip per item in sequence (RMAT-27: pt_split 23.8 ms, pt_radix 31 ms).
+template <bool STABLE, class Load>
 __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, int dbits, uint32_t *__restrict__ out,
                                              const PtStage &st, Load load) {
   const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
   const unsigned long long lt = gdn_lanemask_lt();
-  unsigned short *wcw = st.wc + (size_t)w * nd;
+  unsigned *wcw = st.wc + (size_t)w * nd;
   for (unsigned long long base = 0; base < n; base += PT_STEP) {
     const unsigned cnt = (unsigned)(n - base < (unsigned long long)PT_STEP ? n - base : (unsigned long long)PT_STEP);
     uint32_t it[PT_IPT];
@@ -540,21 +547,29 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
       if (i < cnt) load(base + i, it[j], d);
       dg[j] = (unsigned short)d;
     }
+    if constexpr (STABLE) {
 #pragma unroll
-    for (int j = 0; j < PT_IPT; j++) {
-      const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;
-      const bool valid = i < cnt;
-      const unsigned d = dg[j];
-      const unsigned long long peers = pt_match(d, valid, dbits);
-      const unsigned r = (unsigned)__popcll(peers & lt);
-      unsigned old = 0u;
-      if (valid && r == 0u) {
-        old = wcw[d];
-        wcw[d] = (unsigned short)(old + (unsigned)__popcll(peers));
+      for (int j = 0; j < PT_IPT; j++) {
+        const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;
+        const bool valid = i < cnt;
+        const unsigned d = dg[j];
+        const unsigned long long peers = pt_match(d, valid, dbits);
+        const unsigned r = (unsigned)__popcll(peers & lt);
+        unsigned old = 0u;
+        if (valid && r == 0u) {
+          old = wcw[d];
+          wcw[d] = old + (unsigned)__popcll(peers);
+        }
+        const int leader = valid ? __ffsll((long long)peers) - 1 : (int)lane;
+        old = (unsigned)__shfl((int)old, leader, 64);
+        rk[j] = (unsigned short)(old + r);
       }
-      const int leader = valid ? __ffsll((long long)peers) - 1 : (int)lane;
-      old = (unsigned)__shfl((int)old, leader, 64);
-      rk[j] = (unsigned short)(old + r);
+    } else {
+#pragma unroll
+      for (int j = 0; j < PT_IPT; j++) {
+        const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;
+        rk[j] = i < cnt ? (unsigned short)atomicAdd(&wcw[dg[j]], 1u) : (unsigned short)0;
+      }
     }
     __syncthreads();
     // per digit (two per thread): counts of the waves -> exclusive prefix over the waves, total of the step
@@ -567,7 +582,7 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
 #pragma unroll
         for (int ww = 0; ww < PT_WAVES; ww++) {
           const unsigned c = st.wc[(size_t)ww * nd + d];
-          st.wc[(size_t)ww * nd + d] = (unsigned short)acc;
+          st.wc[(size_t)ww * nd + d] = acc;
           acc += c;
         }
         mine[q] = acc;
@@ -621,7 +636,8 @@ struct PtSplitArgs {
   unsigned d1;
   int ntiers, log_chunk, dbits;
 };
-static __global__ void __launch_bounds__(PT_PTHREADS)
+template <bool STABLE>
+static __global__ void __launch_bounds__(PT_PTHREADS, 4)
 pt_split_kernel(PtSplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = a.d1 + (unsigned)a.ntiers;
@@ -639,7 +655,7 @@ pt_split_kernel(PtSplitArgs a) {
   const unsigned slot_mask = (1u << a.log_chunk) - 1u;
   const int lc = a.log_chunk;
   const unsigned d1 = a.d1;
-  pt_partition(E1 - E0, nd, a.dbits, a.X, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+  pt_partition<STABLE>(E1 - E0, nd, a.dbits, a.X, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
     const uint32_t c = __builtin_nontemporal_load(S + i);
     const unsigned row = __builtin_nontemporal_load(R + i);
     const unsigned k = c >> PT_CLASS_SHIFT;
@@ -706,7 +722,8 @@ struct PtRadixArgs {
   int last;                   // final pass: pad records behind the segment
   uint32_t zrec;
 };
-static __global__ void __launch_bounds__(PT_PTHREADS)
+template <bool STABLE>
+static __global__ void __launch_bounds__(PT_PTHREADS, 4)
 pt_radix_kernel(PtRadixArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = 1u << a.bits;
@@ -745,7 +762,7 @@ pt_radix_kernel(PtRadixArgs a) {
   }
   __syncthreads();
   const int shift = a.shift;
-  pt_partition(n, nd, a.bits, a.out, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+  pt_partition<STABLE>(n, nd, a.bits, a.out, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
     item = in[i];
     d = (item >> shift) & mask;
   });
@@ -774,6 +791,7 @@ pt_sizes_from_ptr_kernel(const eoff_t *__restrict__ ptr, unsigned n, eoff_t *__r
 static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   const auto t_begin = std::chrono::steady_clock::now();
   const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
+  const bool stable = gdn_option("GDN_PT_STABLE") != nullptr;  // ranks by ballot matching (see pt_partition)
   auto t_last = t_begin;
   auto phase = [&](const char *name) {  // GDN_PB_TRACE: wall time of every phase (synchronises: the timings perturb)
     if (!trace) return;
@@ -1129,8 +1147,9 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     sp.log_chunk = lc;
     sp.dbits = dbits;
     const size_t lds = pt_stage_bytes(nd_split);
-    GDN_HIP(hipFuncSetAttribute((const void *)pt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (n) hipLaunchKernelGGL(pt_split_kernel, dim3(nbins), dim3(PT_PTHREADS), lds, 0, sp);
+    auto *const kern = stable ? &pt_split_kernel<true> : &pt_split_kernel<false>;
+    GDN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (n) hipLaunchKernelGGL(kern, dim3(nbins), dim3(PT_PTHREADS), lds, 0, sp);
     GDN_HIP(hipGetLastError());
   }
   phase("pt_split");
@@ -1141,7 +1160,8 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   }
   phase("pt_tiles");
   // record tiers: (row, source) -> (source, row) inside every bin
-  if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)pt_radix_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS)));
+  auto *const kern_r = stable ? &pt_radix_kernel<true> : &pt_radix_kernel<false>;
+  if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)kern_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS)));
   for (int t = 0; t < ntiers; t++) {
     int nbits = 1;
     while ((1u << nbits) < ts.t[t].n_src) nbits++;
@@ -1161,7 +1181,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
       ra.bits = ps == 0 ? b1 : nbits - b1;
       ra.last = ps == passes - 1 ? 1 : 0;
       const size_t lds = pt_stage_bytes(1u << ra.bits);
-      hipLaunchKernelGGL(pt_radix_kernel, dim3(nbins), dim3(PT_PTHREADS), lds, 0, ra);
+      hipLaunchKernelGGL(kern_r, dim3(nbins), dim3(PT_PTHREADS), lds, 0, ra);
     }
     GDN_HIP(hipGetLastError());
   }
