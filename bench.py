@@ -65,7 +65,34 @@ def med_min(xs):
     return {"median": (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])), "min": xs[0], "n": n}
 
 
+def physical_cores():
+    """Physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo; SMT siblings count once."""
+    try:
+        cores, cur = set(), {}
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = [x.strip() for x in line.split(":", 1)]
+                cur[k] = v
+            elif not line.strip() and cur:
+                if "core id" in cur:
+                    cores.add((cur.get("physical id", "0"), cur["core id"]))
+                cur = {}
+        if cur and "core id" in cur:
+            cores.add((cur.get("physical id", "0"), cur["core id"]))
+        if cores:
+            return len(cores)
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
 def main():
+    # SURVEY 8d: the host baseline runs on all PHYSICAL cores, OMP_PROC_BIND=spread.  Set before any OpenMP runtime is
+    # loaded (torch brings one); a caller's own settings win.
+    n_phys = physical_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(n_phys))
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -309,7 +336,12 @@ def main():
                      "pb_expand_kernel<0> + pb_accumulate_kernel<PrOp, 0> (one iteration = both; <1> = the plan's placement search)",
                      "kernel_ms": k_avg_ms, "launches": klaunches,
                      "kernel_ms_parts": [kA_ms / max(klaunches, 1), kB_ms / max(klaunches, 1)],
-                     "algorithmic_bytes_per_launch": iter_bytes},
+                     "algorithmic_bytes_per_launch": iter_bytes,
+                     # the same model charged for the vertices the plan touches only (a squished plan iterates on the
+                     # live ones; the others keep the base score): 8 (m_live + 1) + 8 nnz + 16 m_live
+                     "frac_live_vertices": (((8 * (be.m_state + 1) + 8 * snnz.value + 16 * be.m_state) / (k_avg_ms * 1e-3) / 1e9
+                                             / HBM_PEAK_GBS) if (be.layout == 1 and getattr(be, "squished", False) and k_avg_ms > 0 and not multi)
+                                            else None)},
         "step_ms": med_min(rep_ms),
         "gteps_pr": value / 1e9, "pr_last_l1_change": last_err, "graph_build_s": t_build,
     }
@@ -382,17 +414,56 @@ def main():
             tp = time.time() - tp
             frac = min(1.0, max(1.0 / 64, (args.cpu_seconds / max(tp, 1e-3)) / 64))
             row_hi = max(1, int(m * frac))
+            scores[:] = np.float32(1.0) / np.float32(m)  # (the probe overwrote its rows: the sample starts from 1/m again)
             tc = time.time()
             orc.pr_iterate(gi, h_deg, scores, 1, row_lo=0, row_hi=row_hi)
             tc = time.time() - tc
             e_sample = int(h_rp[row_hi])
             out["cpu_baseline"] = {"value": e_sample / tc, "unit": "edges/s", "cores": cores, "kind": "port",
+                                   "physical_cores": n_phys, "logical_cpus": os.cpu_count(),
+                                   "omp_proc_bind": os.environ.get("OMP_PROC_BIND"), "omp_places": os.environ.get("OMP_PLACES"),
+                                   "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"),
                                    "sample": "1 pull iteration over rows [0,%d) of the same RMAT-%d graph "
                                              "(%d edges, %.1f%% of the graph) incl. the contrib pass over all "
                                              "vertices, OpenMP restatement of src/pr/omp_base.cc:23-34"
                                              % (row_hi, args.scale, e_sample, 100.0 * e_sample / nnz),
                                    "seconds": tc}
             log(f"[bench] cpu baseline: {out['cpu_baseline']} (download+prep {time.time() - t1 - tc:.1f} s)")
+            # parity of the timed plan with that CPU iteration on the rows it covered (the same start vector 1/m): how many
+            # rows lie beyond north_star's 1e-4 -- rows with >= 10^4 in-edges, where the reference's sequential fp32 sum
+            # drifts and the plan's exact fixed-point sum does not (bounded by tests/test_gpu_configs.py)
+            try:
+                if be.layout == 1 and not multi:
+                    pp = lambda t: C.c_void_p(t.data_ptr())
+                    ms_ = C.c_int32()
+                    _cabi.check(L.gdn_pr_plan_state_size(be.plan, C.byref(ms_)))
+                    start = torch.full((m,), 1.0 / m, dtype=torch.float32, device=device)
+                    state = torch.empty(ms_.value, dtype=torch.float32, device=device)
+                    cc = [torch.zeros(ms_.value + 4, dtype=torch.float32, device=device) for _ in range(2)]
+                    dd = torch.zeros(1, dtype=torch.float64, device=device)
+                    got = torch.empty(m, dtype=torch.float32, device=device)
+                    _cabi.check(L.gdn_pr_import_dev(be.plan, pp(start), pp(state), 0.85, None))
+                    _cabi.check(L.gdn_pr_contrib_dev(be.plan, pp(state), pp(cc[0]), None))
+                    _cabi.check(L.gdn_pr_pull_dev(be.plan, pp(cc[0]), pp(state), pp(cc[1]), pp(dd), 0.85, None))
+                    _cabi.check(L.gdn_pr_export_dev(be.plan, pp(state), pp(got), 0.85, None))
+                    torch.cuda.synchronize()
+                    g_rows = got[:row_hi].cpu().numpy()
+                    rel = np.abs(g_rows - scores[:row_hi]) / scores[:row_hi]
+                    off = np.nonzero(rel >= 1e-4)[0]
+                    indeg = np.diff(h_rp[:row_hi + 1].astype(np.int64))
+                    out["parity_note"] = {
+                        "rows_compared": int(row_hi), "tolerance": 1e-4, "rows_beyond_tolerance": int(len(off)),
+                        "max_rel": float(rel.max()) if row_hi else 0.0,
+                        "min_in_degree_of_those_rows": int(indeg[off].min()) if len(off) else None,
+                        "what": "one pull iteration of the timed plan vs the CPU restatement of src/pr/omp_base.cc:23-34 "
+                                "from scores 1/m, on the rows of the cpu_baseline sample; rows beyond 1e-4 are hub rows "
+                                "(>= 10^4 in-edges): the reference adds their contributions one by one in fp32, the plan "
+                                "adds them exactly (DESIGN 5); tests/test_gpu_configs.py asserts <= 500 such rows of all "
+                                "2^27 and max_rel <= 5e-4, and that the GPU value is the one an fp64 evaluation gives"}
+                    log(f"[bench] parity note: {out['parity_note']}")
+                    del start, state, cc, got
+            except Exception as e:
+                log(f"[bench] parity note skipped: {e}")
             del h_rp, h_ci, gi, scores
         except Exception as e:
             log(f"[bench] cpu baseline skipped: {e}")

@@ -203,7 +203,8 @@ def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc):
         # The one documented deviation: a row with very many in-edges.  The reference adds its contributions one by
         # one in fp32 and drifts; the plan accumulates them exactly (2^-62 fixed point).  Such rows must be hub rows, few, and
         # the GPU value must be the one that agrees with an fp64 evaluation.
-        assert len(off) < 2000, (it, len(off), float(rel.max()))
+        # (observed: 379 rows, up to 3e-4; bench.py prints the count of its sample as `parity_note`)
+        assert len(off) <= 500 and (len(off) == 0 or float(rel.max()) <= 5e-4), (it, len(off), float(rel.max()))
         if len(off):
             assert indeg[off].min() >= 10_000, (it, int(indeg[off].min()))
             with np.errstate(divide="ignore"):
