@@ -1394,6 +1394,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
 
 // the builder above behind a linkable name (gdn_pr.hip, gdn_spmv.hip); see PbTieredArgs
 int pb_build_tiered_run(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) { return pb_build_tiered(a, p, ts); }
+int pb_build_out_tiered_run(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp, PbOutTiers &ts) { return pb_build_out_tiered(a, p, Wp, ts); }
 
 extern "C" {
 

@@ -241,6 +241,58 @@ cc_finish_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, CcLinkVi
   gdn_expand_big_items(rowptr, big, vis);
 }
 
+// ---- out-edges only (no reverse graph): the skip of the giant component c made safe.  An edge whose two ends were in c's
+// tree when the sampling rounds ended needs no link -- trees only ever merge -- and such edges are nearly all of an R-MAT
+// graph; what must be linked are the edges with an end OUTSIDE c (the in-edges of a vertex outside c included, which is what
+// Afforest reads the reverse graph for).  One bit per vertex says "outside c" (2 MB at RMAT-24: the test of an edge's target
+// is a gather from the L2, not from a 64 MB label array), and the closing pass streams every edge but links few.
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_outside_bits_kernel(const int32_t *__restrict__ comp, int32_t m, const int32_t *__restrict__ c_ptr, unsigned long long *__restrict__ bits) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const int32_t c = *c_ptr;
+  const unsigned long long mask = __ballot(v < (unsigned)m && comp[v] != c);
+  if (gdn_lane() == 0 && v < (unsigned)m) bits[v >> 6] = mask;
+}
+struct CcLinkOutsideVis {
+  const vid_t *__restrict__ colidx;
+  int32_t *__restrict__ comp;
+  const unsigned long long *__restrict__ bits;
+  int32_t v;   // per-lane source vertex
+  int vout;    // per-lane: the source is outside c
+  __device__ __forceinline__ void begin_big(vid_t vv) {
+    v = vv;
+    vout = (int)((bits[(unsigned)vv >> 6] >> ((unsigned)vv & 63u)) & 1ull);
+  }
+  __device__ __forceinline__ void edge(int owner, eoff_t k, bool valid) {
+    const int32_t src = __shfl(v, owner, 64);
+    const int so = __shfl(vout, owner, 64);
+    const vid_t dst = valid ? colidx[k] : 0;
+    const bool need = valid && (so || ((bits[(unsigned)dst >> 6] >> ((unsigned)dst & 63u)) & 1ull));
+    cc_link_wave(need, src, dst, comp);
+  }
+};
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_finish_outside_kernel(const eoff_t *__restrict__ rowptr, int32_t m, int skip, ExpBigList big, CcLinkOutsideVis vis) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  eoff_t b = 0, e = 0;
+  vis.v = (int32_t)v;
+  vis.vout = 0;
+  if (v < (unsigned)m) {
+    b = rowptr[v];
+    e = rowptr[v + 1];
+    vis.vout = (int)((vis.bits[v >> 6] >> (v & 63u)) & 1ull);
+    if (e - b < big.min_deg) b = (b + (eoff_t)skip < e) ? b + skip : e;  // (see cc_finish_kernel)
+  }
+  gdn_expand_wave(b, e, (vid_t)v, big, vis, s_scan[threadIdx.x >> 6]);
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_finish_outside_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, CcLinkOutsideVis vis) {
+  vis.v = 0;
+  vis.vout = 0;
+  gdn_expand_big_items(rowptr, big, vis);
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK) cc_init_kernel(int32_t *__restrict__ comp, int32_t m) {
   const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (v < (unsigned)m) comp[v] = (int32_t)v;
@@ -327,6 +379,8 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   GDN_TRY(bigitems.alloc(bigcap));
   GDN_TRY(cnt.alloc(1));
   GDN_TRY(d_sample.alloc(nsample + 1));  // + the label of the giant component
+  DevBuf<unsigned long long> outside;    // out-edges only: one bit per vertex, "outside the giant component"
+  if (!gin) GDN_TRY(outside.alloc(((size_t)m + 63) / 64 + 1));
   st.prep_ms = tprep.stop_ms();
 
   tsolve.start();
@@ -364,9 +418,23 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   vis.comp = d_comp;
   vis.v = 0;
   vis.colidx = g->colidx;
-  // gin == nullptr (out-edges only): nobody is skipped (label -1 matches no vertex)
-  hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, gin ? d_sample.p + nsample : nullptr, neighbor_rounds, big, vis);
-  hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, vis);
+  const char *oe = gdn_option("GDN_CC_OUTSIDE");  // 0: the unfiltered closing pass of round 3 (A/B)
+  if (!gin && !(oe && oe[0] == '0')) {
+    // out-edges only: every edge is streamed, the ones with an end outside c are linked (see cc_outside_bits_kernel)
+    hipLaunchKernelGGL(cc_outside_bits_kernel, grid_m, blk, 0, 0, d_comp, m, d_sample.p + nsample, outside.p);
+    CcLinkOutsideVis ov;
+    ov.colidx = g->colidx;
+    ov.comp = d_comp;
+    ov.bits = outside.p;
+    ov.v = 0;
+    ov.vout = 0;
+    hipLaunchKernelGGL(cc_finish_outside_kernel, grid_m, blk, 0, 0, g->rowptr, m, neighbor_rounds, big, ov);
+    hipLaunchKernelGGL(cc_finish_outside_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, ov);
+  } else {
+    // gin == nullptr (out-edges only): nobody is skipped (label -1 matches no vertex)
+    hipLaunchKernelGGL(cc_finish_kernel, grid_m, blk, 0, 0, g->rowptr, m, gin ? d_sample.p + nsample : nullptr, neighbor_rounds, big, vis);
+    hipLaunchKernelGGL(cc_finish_big_kernel, dim3(1024), blk, 0, 0, g->rowptr, big, vis);
+  }
   if (gin && gin != g) {  // directed: the in-edges too (omp_afforest.cc:72-74)
     GDN_HIP(hipMemsetAsync(&cnt.p->big_count, 0, sizeof(unsigned), 0));
     vis.colidx = gin->colidx;

@@ -259,6 +259,31 @@ struct PbTieredArgs {
 // (repeat with src_count = nullptr); < 0 error
 int pb_build_tiered_run(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts);
 
+// ---- the same for an OUT-CSR (rows = sources) with one 32-bit value per edge: SSSP's blocked layout and its record tiers
+struct PbOutTiers {  // gdn_sssp.hip's record tiers (see gdn_sssp_plan)
+  int n = 0;
+  unsigned off[PB_MAX_REC_TIERS + 1] = {};  // first source of tier t in ids
+  DevBuf<uint32_t> ids;                     // tier sources, tier by tier, ascending ids inside a tier
+  DevBuf<uint32_t> rec;                     // records (index in the tier << 15 | row), tier-major then bin-major
+  DevBuf<uint8_t> w8;                       // their weights (nullable)
+  DevBuf<eoff_t> ptr;                       // n x nbins + 1
+  unsigned long long edges = 0;
+};
+struct PbOutArgs {
+  const gdn_graph *g = nullptr;   // out-CSR
+  const int32_t *weight = nullptr;
+  int log_chunk = 15, log_bin = 15;
+  unsigned pad = 32;
+  int log_group = 3;
+  int max_tiers = 0;              // 0: no record tiers
+  unsigned tier_min_deg = 8;
+  unsigned caps[PB_MAX_REC_TIERS] = {1u << 15, 1u << 17, 1u << 17, 1u << 17, 1u << 17};
+  bool want_w8 = false;
+};
+
+// GDN_OK; 1 = outside the builder's limits (nothing built: pb_build + sssp_build_tiers)
+int pb_build_out_tiered_run(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp, PbOutTiers &ts);
+
 // the rows with the most in-edges (gdn_build.hip): at most max_rows rows with >= min_deg in-edges each
 uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full);  // vertices per slice after round balancing
 int pb_pick_hub_rows(const gdn_graph *in_csr, unsigned max_rows, uint64_t min_deg, DevBuf<uint8_t> &dcls,

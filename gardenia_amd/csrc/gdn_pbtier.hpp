@@ -1219,3 +1219,851 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   }
   return GDN_OK;
 }
+
+// =====================================================================================================================
+// OUT-CSR orientation (SSSP's dense sweeps, gdn_sssp.hip): rows = SOURCES, columns = destinations, no vertex compaction,
+// one 32-bit value per edge (the weight) travels with it.  The same two-level split with the roles swapped -- a workgroup
+// per source CHUNK (a contiguous edge range of an out-CSR), digits = destination bins -- and the record tiers fall out of
+// the same passes: CSR order is source-major already, so the records of a (tier, bin) arrive sorted by source and need
+// no radix pass.  Replaces pb_build(rows_are_sources) + sssp_build_tiers: a full 7-pass sort of 8-byte keys, a binary
+// search per edge for its weight and a second pair of sorts for the tiers (RMAT-24: 25 ms of preparation).
+//   items   main layout: slot << 17 | row << 2 | bin & 3, value = weight          (level-1 digit: bin >> 2)
+//           tier t:      index << 15 | row,               value = weight & 255 | (bin & 31) << 8   (digit: D1 + t * DT + bin >> 5)
+// =====================================================================================================================
+#define PO_LOW 2    // bin bits left to the tile pass (slot 15 + row 15 + 2)
+#define PO_TLOW 5   // bin bits left to the tier pass (they ride in the value word)
+#define PO_ROW_BITS 15
+
+// per-row codes of an out-CSR: class << 29 | (class ? index in the tier : the row id itself)
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_src_assign_kernel(PtSrcArgs a, unsigned nb, const uint32_t *__restrict__ bc, uint32_t *__restrict__ smap, PtSrcOut o) {
+  __shared__ unsigned long long s_scan[GDN_WAVES_PER_BLOCK];
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  int cls[8];
+  unsigned long long pa = 0ull, pb = 0ull;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned s = base + (unsigned)i;
+    cls[i] = s < a.n ? pt_class_of(a, s) : PT_NCLS;
+    if (cls[i] < 3) pa += 1ull << (16 * cls[i]);
+    else if (cls[i] < PT_NCLS) pb += 1ull << (16 * (cls[i] - 3));
+  }
+  unsigned long long ta, tb;
+  const unsigned long long ea = gdn_block_excl_scan(pa, s_scan, &ta);
+  __syncthreads();
+  const unsigned long long eb = gdn_block_excl_scan(pb, s_scan, &tb);
+  unsigned run[PT_NCLS];
+#pragma unroll
+  for (int k = 0; k < PT_NCLS; k++) {
+    const unsigned long long e = k < 3 ? ea : eb;
+    run[k] = bc[(size_t)k * nb + blockIdx.x] + (unsigned)((e >> (16 * (k % 3))) & 0xFFFFull);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned s = base + (unsigned)i;
+    if (s >= a.n) continue;
+    const int k = cls[i];
+    unsigned code = s;  // class 0 (and rows without edges: never read)
+    if (k >= 1 && k < PT_NCLS) {
+      unsigned r = 0;
+#pragma unroll
+      for (int q = 1; q < PT_NCLS; q++)
+        if (k == q) r = run[q]++;
+      code = ((unsigned)k << PT_CLASS_SHIFT) | r;
+      o.ids[k - 1][r] = s;
+    }
+    smap[s] = code;
+  }
+}
+
+// degrees as the count array of the histogram / class kernels
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_degrees_kernel(const eoff_t *__restrict__ rowptr, unsigned m, int32_t *__restrict__ deg, uint32_t *__restrict__ cnt) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < m) {
+    const eoff_t d = rowptr[i + 1] - rowptr[i];
+    const uint32_t c = d > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)d;
+    deg[i] = (int32_t)c;
+    cnt[i] = c;
+  }
+}
+
+// rows with entries: compact list (row id and first edge of the k-th one), row-start bitmap, and for every chunk the
+// number of such rows in front of it
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_row_assign_kernel(const eoff_t *__restrict__ rowptr, unsigned m, const uint32_t *__restrict__ bc, int log_chunk,
+                     eoff_t *__restrict__ crp, uint32_t *__restrict__ nzrow, uint32_t *__restrict__ rowstart,
+                     uint32_t *__restrict__ chunk_k) {
+  __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK];
+  const unsigned base = blockIdx.x * PT_VTILE + threadIdx.x * 8u;
+  eoff_t st[9];
+  unsigned c = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const unsigned r = base + (unsigned)i;
+    st[i] = r <= m ? rowptr[r] : 0;
+  }
+  unsigned act = 0u;
+#pragma unroll
+  for (int i = 0; i < 8; i++)
+    if (base + (unsigned)i < m && st[i + 1] > st[i]) {
+      act |= 1u << i;
+      c++;
+    }
+  unsigned total;
+  unsigned k = bc[blockIdx.x] + gdn_block_excl_scan(c, s_scan, &total);
+  const unsigned cmask = (1u << log_chunk) - 1u;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const unsigned r = base + (unsigned)i;
+    if (r < m && (r & cmask) == 0u) chunk_k[r >> log_chunk] = k;
+    if (!((act >> i) & 1u)) continue;
+    crp[k] = st[i];
+    nzrow[k] = r;
+    atomicOr(&rowstart[st[i] >> 5], 1u << (st[i] & 31u));
+    k++;
+  }
+}
+
+// pass 1 over the edges, a workgroup per source chunk: S[e] = code of the edge's source, counts per (class, bin)
+struct PoCountArgs {
+  const eoff_t *rowptr;
+  const vid_t *colidx;
+  const uint32_t *smap;
+  const unsigned long long *rowstart;
+  const eoff_t *crp;
+  const uint32_t *nzrow, *chunk_k;
+  eoff_t n_nz;
+  unsigned m, nchunks, nbins, ncls;
+  int log_chunk, log_bin;
+  uint32_t *S;
+  uint32_t *cnt;  // ncls x nchunks x nbins
+};
+static __global__ void __launch_bounds__(PT_THREADS)
+po_count_kernel(PoCountArgs a) {
+  extern __shared__ unsigned s_cnt[];  // ncls x nbins
+  const unsigned c = blockIdx.x;
+  const unsigned nc = a.ncls * a.nbins;
+  for (unsigned i = threadIdx.x; i < nc; i += PT_THREADS) s_cnt[i] = 0u;
+  __syncthreads();
+  const unsigned r0 = c << a.log_chunk, r1 = (c + 1) << a.log_chunk < a.m ? (c + 1) << a.log_chunk : a.m;
+  const eoff_t E0 = a.rowptr[r0], E1 = a.rowptr[r1];
+  const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
+  if (E1 > E0) {
+    const eoff_t w0 = E0 >> 6, w1 = (E1 - 1) >> 6;
+    constexpr unsigned KW = PT_THREADS / 64;
+    const eoff_t per = (w1 - w0 + KW) / KW;
+    const eoff_t wa = w0 + (eoff_t)w * per, wb = wa + per < w1 + 1 ? wa + per : w1 + 1;
+    if (wa < wb) {
+      const eoff_t kb0 = a.chunk_k[c], kb1 = c + 1 < a.nchunks ? a.chunk_k[c + 1] : a.n_nz;
+      eoff_t x = wa << 6;
+      if (x < E0) x = E0;
+      eoff_t lo = kb0, hi = kb1;
+      while (lo < hi) {
+        const eoff_t mid = lo + ((hi - lo) >> 1);
+        if (a.crp[mid] < x) lo = mid + 1;
+        else hi = mid;
+      }
+      eoff_t rb = lo;
+      const unsigned long long le = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);
+      constexpr int UNR = 4;
+      for (eoff_t wi = wa; wi < wb; wi += UNR) {
+        unsigned long long bits[UNR];
+        vid_t col[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+          const eoff_t wj = wi + r, e = (wj << 6) + lane;
+          ok[r] = wj < wb && e >= E0 && e < E1;
+          bits[r] = wj < wb ? a.rowstart[wj] : 0ull;
+          col[r] = ok[r] ? __builtin_nontemporal_load(a.colidx + e) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < UNR; r++) {
+          const eoff_t wj = wi + r;
+          if (wj >= wb) break;
+          unsigned long long bt = bits[r];
+          if ((wj << 6) < E0) bt &= ~0ull << (E0 & 63u);
+          if (((wj + 1) << 6) > E1) bt &= ~0ull >> (64u - (unsigned)(E1 & 63u));
+          const eoff_t k = rb + (eoff_t)__popcll(bt & le) - 1;
+          rb += (eoff_t)__popcll(bt);
+          const eoff_t e = (wj << 6) + lane;
+          uint32_t code = 0u;
+          if (ok[r]) {
+            code = a.smap[a.nzrow[k]];
+            a.S[e] = code;
+          }
+          // one LDS atomic per run of equal (class, bin) in the wave
+          const unsigned key = ok[r] ? (code >> PT_CLASS_SHIFT) * a.nbins + ((unsigned)col[r] >> a.log_bin) : 0xFFFFFFFFu;
+          const unsigned prev = (unsigned)__shfl_up((int)key, 1, 64);
+          const bool head = lane == 0u || prev != key;
+          const unsigned long long heads = __ballot(head);
+          if (head && key != 0xFFFFFFFFu) {
+            const unsigned long long after = lane == 63u ? 0ull : heads >> (lane + 1u);
+            const unsigned len = after ? (unsigned)__ffsll((long long)after) : 64u - lane;
+            atomicAdd(&s_cnt[key], len);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned i = threadIdx.x; i < nc; i += PT_THREADS) {
+    const unsigned k = i / a.nbins, b = i - k * a.nbins;
+    a.cnt[((size_t)k * a.nchunks + c) * a.nbins + b] = s_cnt[i];
+  }
+}
+
+// offsets: padded tile sizes of the main layout in both orders, segment sizes of the split's output (per chunk: D1 main
+// digits, then DT per tier), and per (tier, bin) the exclusive prefix over the chunks
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_sizes_kernel(const uint32_t *__restrict__ cnt, unsigned nchunks, unsigned nbins, unsigned ntiers, unsigned pad, unsigned d1, unsigned dt,
+                uint32_t *__restrict__ psz_c, uint32_t *__restrict__ psz_b, uint32_t *__restrict__ segsz,
+                const uint32_t *__restrict__ tsz /*ntiers x nbins totals: the tier planes of cnt hold PREFIXES over the chunks*/) {
+  const unsigned long long t = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (t < (unsigned long long)nchunks * nbins) {  // chunk-major tile index
+    const unsigned c = (unsigned)(t / nbins), b = (unsigned)(t % nbins);
+    const uint32_t sz = (cnt[t] + (pad - 1u)) & ~(pad - 1u);
+    psz_c[t] = sz;
+    psz_b[(unsigned long long)b * nchunks + c] = sz;
+  }
+  const unsigned nd = d1 + ntiers * dt;
+  if (t < (unsigned long long)nchunks * nd) {
+    const unsigned c = (unsigned)(t / nd), d = (unsigned)(t % nd);
+    uint32_t s = 0;
+    if (d < d1) {
+      for (unsigned k = 0; k < (1u << PO_LOW); k++) {
+        const unsigned b = (d << PO_LOW) + k;
+        if (b < nbins) s += cnt[(unsigned long long)c * nbins + b];
+      }
+    } else {
+      const unsigned tt = (d - d1) / dt, h = (d - d1) % dt;
+      for (unsigned k = 0; k < (1u << PO_TLOW); k++) {
+        const unsigned b = (h << PO_TLOW) + k;
+        if (b < nbins) {
+          const uint32_t here = cnt[((unsigned long long)(1 + tt) * nchunks + c) * nbins + b];
+          const uint32_t next = c + 1 < nchunks ? cnt[((unsigned long long)(1 + tt) * nchunks + c + 1) * nbins + b] : tsz[(size_t)tt * nbins + b];
+          s += next - here;
+        }
+      }
+    }
+    segsz[t] = s;
+  }
+}
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_tier_prefix_kernel(uint32_t *__restrict__ cnt, unsigned nchunks, unsigned nbins, unsigned ntiers, uint32_t *__restrict__ tsz) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;  // (tier, bin)
+  if (i >= ntiers * nbins) return;
+  const unsigned t = i / nbins, b = i - t * nbins;
+  uint32_t acc = 0;
+  for (unsigned c = 0; c < nchunks; c++) {
+    uint32_t *p = cnt + ((unsigned long long)(1 + t) * nchunks + c) * nbins + b;
+    const uint32_t v = *p;
+    *p = acc;
+    acc += v;
+  }
+  tsz[i] = acc;
+}
+
+// (item, value) form of pt_partition: ranks by LDS atomics, both words staged
+struct PoStage {
+  uint32_t *stage, *vstage;
+  unsigned short *dig;
+  unsigned *wc, *start, *tot, *scr;
+  unsigned long long *goff;
+};
+__device__ __forceinline__ PoStage po_stage_carve(unsigned char *lds, unsigned nd) {
+  PoStage s;
+  s.stage = reinterpret_cast<uint32_t *>(lds);
+  s.vstage = s.stage + PT_STEP;
+  s.goff = reinterpret_cast<unsigned long long *>(lds + (size_t)PT_STEP * 8);
+  s.start = reinterpret_cast<unsigned *>(s.goff + nd);
+  s.tot = s.start + nd;
+  s.scr = s.tot + nd;
+  s.wc = s.scr + PT_WAVES + 2;
+  s.dig = reinterpret_cast<unsigned short *>(s.wc + (size_t)PT_WAVES * nd);
+  return s;
+}
+static inline size_t po_stage_bytes(unsigned nd) {
+  return (size_t)PT_STEP * 8 + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_WAVES * nd * 4 + (size_t)PT_STEP * 2 + 64;
+}
+template <class Load>
+__device__ __forceinline__ void po_partition(unsigned long long n, unsigned nd, uint32_t *__restrict__ out, uint32_t *__restrict__ out_v,
+                                             const PoStage &st, Load load) {
+  const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
+  unsigned *wcw = st.wc + (size_t)w * nd;
+  constexpr int IPT = PT_IPT / 2;  // two words per item: eight items per thread and half-step
+  for (unsigned long long base = 0; base < n; base += PT_STEP / 2) {
+    const unsigned cnt = (unsigned)(n - base < (unsigned long long)(PT_STEP / 2) ? n - base : (unsigned long long)(PT_STEP / 2));
+    uint32_t it[IPT], vv[IPT];
+    unsigned short dg[IPT], rk[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+      const unsigned i = w * (IPT * 64u) + (unsigned)j * 64u + lane;
+      it[j] = 0u;
+      vv[j] = 0u;
+      unsigned d = 0u;
+      if (i < cnt) load(base + i, it[j], vv[j], d);
+      dg[j] = (unsigned short)d;
+    }
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+      const unsigned i = w * (IPT * 64u) + (unsigned)j * 64u + lane;
+      rk[j] = i < cnt ? (unsigned short)atomicAdd(&wcw[dg[j]], 1u) : (unsigned short)0;
+    }
+    __syncthreads();
+    unsigned mine[2] = {0u, 0u};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const unsigned d = 2u * threadIdx.x + (unsigned)q;
+      if (d < nd) {
+        unsigned acc = 0u;
+#pragma unroll
+        for (int ww = 0; ww < PT_WAVES; ww++) {
+          const unsigned c = st.wc[(size_t)ww * nd + d];
+          st.wc[(size_t)ww * nd + d] = acc;
+          acc += c;
+        }
+        mine[q] = acc;
+        st.tot[d] = acc;
+      }
+    }
+    unsigned total;
+    const unsigned ex = pt_block_excl_scan(mine[0] + mine[1], st.scr, &total);
+    if (2u * threadIdx.x < nd) st.start[2u * threadIdx.x] = ex;
+    if (2u * threadIdx.x + 1u < nd) st.start[2u * threadIdx.x + 1u] = ex + mine[0];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+      const unsigned i = w * (IPT * 64u) + (unsigned)j * 64u + lane;
+      if (i < cnt) {
+        const unsigned d = dg[j];
+        const unsigned pos = st.start[d] + wcw[d] + rk[j];
+        st.stage[pos] = it[j];
+        st.vstage[pos] = vv[j];
+        st.dig[pos] = (unsigned short)d;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < IPT; j++) {
+      const unsigned pos = (unsigned)j * PT_PTHREADS + threadIdx.x;
+      if (pos < cnt) {
+        const unsigned d = st.dig[pos];
+        const unsigned long long at = st.goff[d] + (pos - st.start[d]);
+        out[at] = st.stage[pos];
+        out_v[at] = st.vstage[pos];
+      }
+    }
+    __syncthreads();
+    for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
+      st.goff[d] += st.tot[d];
+#pragma unroll
+      for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + d] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+struct PoSplitArgs {
+  const eoff_t *rowptr;
+  const vid_t *colidx;
+  const uint32_t *S;
+  const int32_t *weight;
+  const eoff_t *segoff;  // nchunks x nd (+1)
+  const uint32_t *order;
+  uint32_t *X, *XV;
+  unsigned m, d1, dt, ntiers;
+  int log_chunk, log_bin;
+};
+static __global__ void __launch_bounds__(PT_PTHREADS, 4)
+po_split_kernel(PoSplitArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+  const unsigned nd = a.d1 + a.ntiers * a.dt;
+  const PoStage st = po_stage_carve(s_raw, nd);
+  const unsigned c = a.order[blockIdx.x];
+  for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
+    st.goff[d] = a.segoff[(size_t)c * nd + d];
+#pragma unroll
+    for (int ww = 0; ww < PT_WAVES; ww++) st.wc[(size_t)ww * nd + d] = 0;
+  }
+  __syncthreads();
+  const unsigned r0 = c << a.log_chunk, r1 = (c + 1) << a.log_chunk < a.m ? (c + 1) << a.log_chunk : a.m;
+  const eoff_t E0 = a.rowptr[r0], E1 = a.rowptr[r1];
+  const uint32_t *S = a.S + E0;
+  const vid_t *col = a.colidx + E0;
+  const int32_t *wt = a.weight + E0;
+  const unsigned bmask = (1u << a.log_bin) - 1u, cmask = (1u << a.log_chunk) - 1u;
+  const int lb = a.log_bin;
+  const unsigned d1 = a.d1, dt = a.dt;
+  po_partition(E1 - E0, nd, a.X, a.XV, st, [&](unsigned long long i, uint32_t &item, uint32_t &val, unsigned &d) {
+    const uint32_t code = __builtin_nontemporal_load(S + i);
+    const unsigned dst = (unsigned)__builtin_nontemporal_load(col + i);
+    const unsigned wv = (unsigned)__builtin_nontemporal_load(wt + i);
+    const unsigned k = code >> PT_CLASS_SHIFT, bin = dst >> lb, row = dst & bmask;
+    if (k == 0u) {
+      d = bin >> PO_LOW;
+      item = ((code & cmask) << 17) | (row << PO_LOW) | (bin & ((1u << PO_LOW) - 1u));
+      val = wv;
+    } else {
+      d = d1 + (k - 1u) * dt + (bin >> PO_TLOW);
+      item = ((code & PT_IDX_MASK) << PO_ROW_BITS) | row;
+      val = (wv & 0xFFu) | ((bin & ((1u << PO_TLOW) - 1u)) << 8);
+    }
+  });
+}
+
+// level 2, a wave per (chunk, digit) segment.  Main digits: split by the last 2 bin bits into U / W (contiguous) and V (one run per
+// tile).  Tier digits: split by the last 5 bin bits into the (tier, bin) record streams behind the runs of the earlier chunks.
+struct PoTilesArgs {
+  const uint32_t *X, *XV;
+  const eoff_t *segoff;
+  const eoff_t *pu, *pv;       // main layout: tile offsets, chunk-major / bin-major
+  const eoff_t *tptr;          // ntiers x nbins (+1) record offsets
+  const uint32_t *tpre;        // (1 + t) x nchunks x nbins: records of (tier, bin) in the chunks in front (class 0 plane unused)
+  uint16_t *U, *V;
+  uint32_t *W;
+  uint32_t *rec;
+  uint8_t *w8;
+  unsigned nchunks, nbins, d1, dt, ntiers;
+};
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_tiles_kernel(PoTilesArgs a) {
+  const unsigned nd = a.d1 + a.ntiers * a.dt;
+  const unsigned long long seg = ((unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  if (seg >= (unsigned long long)a.nchunks * nd) return;
+  const unsigned c = (unsigned)(seg / nd), d = (unsigned)(seg % nd), lane = gdn_lane();
+  const eoff_t s0 = a.segoff[seg], s1 = a.segoff[seg + 1];
+  if (s1 == s0) return;
+  const unsigned long long lt = gdn_lanemask_lt();
+  if (d < a.d1) {
+    eoff_t offu = 0, offv = 0;
+    const unsigned bl = (d << PO_LOW) + (lane & ((1u << PO_LOW) - 1u));
+    if (bl < a.nbins) {
+      offu = a.pu[(unsigned long long)c * a.nbins + bl];
+      offv = a.pv[(unsigned long long)bl * a.nchunks + c];
+    }
+    unsigned basek[1 << PO_LOW];
+#pragma unroll
+    for (int k = 0; k < (1 << PO_LOW); k++) basek[k] = 0u;
+    constexpr int TU = 4;  // steps loaded ahead (a segment is a chain of dependent steps otherwise)
+    for (eoff_t i0 = s0; i0 < s1; i0 += 64 * TU) {
+      uint32_t items[TU], vals[TU];
+#pragma unroll
+      for (int q = 0; q < TU; q++) {
+        const eoff_t i = i0 + (eoff_t)q * 64 + lane;
+        items[q] = i < s1 ? __builtin_nontemporal_load(a.X + i) : 0u;
+        vals[q] = i < s1 ? __builtin_nontemporal_load(a.XV + i) : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < TU; q++) {
+        const eoff_t i = i0 + (eoff_t)q * 64 + lane;
+        if (i0 + (eoff_t)q * 64 >= s1) break;  // wave-uniform
+        const bool valid = i < s1;
+        const uint32_t item = items[q], val = vals[q];
+        const unsigned low = item & ((1u << PO_LOW) - 1u);
+        unsigned rank = 0u;
+#pragma unroll
+        for (int k = 0; k < (1 << PO_LOW); k++) {
+          const unsigned long long mk = __ballot(valid && low == (unsigned)k);
+          if (low == (unsigned)k) rank = basek[k] + (unsigned)__popcll(mk & lt);
+          basek[k] += (unsigned)__popcll(mk);
+        }
+        const eoff_t ou = (eoff_t)__shfl((long long)offu, (int)low, 64), ov = (eoff_t)__shfl((long long)offv, (int)low, 64);
+        if (valid) {
+          a.U[ou + rank] = (uint16_t)(item >> 17);
+          a.W[ou + rank] = val;
+          a.V[ov + rank] = (uint16_t)((item >> PO_LOW) & ((1u << PO_ROW_BITS) - 1u));
+        }
+      }
+    }
+    return;
+  }
+  // a tier segment: up to 32 bins
+  const unsigned t = (d - a.d1) / a.dt, h = (d - a.d1) % a.dt;
+  eoff_t off = 0;
+  const unsigned bl = (h << PO_TLOW) + (lane & ((1u << PO_TLOW) - 1u));
+  if (bl < a.nbins)
+    off = a.tptr[(unsigned long long)t * a.nbins + bl] + a.tpre[((unsigned long long)(1 + t) * a.nchunks + c) * a.nbins + bl];
+  unsigned mybase = 0u;  // lane k < 32: records of bin k of the segment written so far
+  constexpr int TU = 4;
+  for (eoff_t i0 = s0; i0 < s1; i0 += 64 * TU) {
+    uint32_t items[TU], vals[TU];
+#pragma unroll
+    for (int q = 0; q < TU; q++) {
+      const eoff_t i = i0 + (eoff_t)q * 64 + lane;
+      items[q] = i < s1 ? __builtin_nontemporal_load(a.X + i) : 0u;
+      vals[q] = i < s1 ? __builtin_nontemporal_load(a.XV + i) : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < TU; q++) {
+      const eoff_t i = i0 + (eoff_t)q * 64 + lane;
+      if (i0 + (eoff_t)q * 64 >= s1) break;  // wave-uniform
+      const bool valid = i < s1;
+      const uint32_t item = items[q], val = vals[q];
+      const unsigned low = (val >> 8) & ((1u << PO_TLOW) - 1u);
+      unsigned r = 0u, add = 0u;
+#pragma unroll
+      for (int k = 0; k < (1 << PO_TLOW); k++) {
+        const unsigned long long mk = __ballot(valid && low == (unsigned)k);
+        if (low == (unsigned)k) r = (unsigned)__popcll(mk & lt);
+        if (lane == (unsigned)k) add = (unsigned)__popcll(mk);
+      }
+      const unsigned before = (unsigned)__shfl((int)mybase, (int)low, 64);
+      const eoff_t o = (eoff_t)__shfl((long long)off, (int)low, 64);
+      if (valid) {
+        a.rec[o + before + r] = item;
+        if (a.w8) a.w8[o + before + r] = (uint8_t)(val & 0xFFu);
+      }
+      mybase += add;
+    }
+  }
+}
+
+// Tier thresholds of an out-CSR plan from the histograms of the out-degrees: tier t takes the sources with
+// thr[t] <= degree < thr[t-1], at most caps[t] of them, none below min_deg.  Degrees from 4095 on sit in one open bin of
+// the linear histogram (h_lin[4095]) -- a threshold up there is a quarter-octave bucket floor of h_log.
+static int po_choose_tiers(const unsigned *h_log, const unsigned *h_lin, unsigned min_deg, int max_tiers, const unsigned *caps,
+                           unsigned *thr) {
+  // candidate thresholds, descending, with the number of sources at or above each
+  std::vector<std::pair<unsigned, unsigned long long>> cand;
+  {
+    unsigned long long acc = 0;
+    for (int bk = PB_HUB_BUCKETS - 1; bk >= 0; bk--) {
+      acc += h_log[bk];
+      const unsigned fl = pb_hub_bucket_floor((unsigned)bk);
+      if (fl > PB_LIN_BINS - 1u && acc) cand.push_back(std::make_pair(fl, acc));
+    }
+    acc = 0;
+    for (unsigned d = PB_LIN_BINS - 1u; d >= 1u; d--) {
+      acc += h_lin[d];
+      if (d >= min_deg && acc) cand.push_back(std::make_pair(d, acc));
+    }
+  }
+  int nt = 0;
+  unsigned long long above = 0;
+  size_t i = 0;
+  for (int t = 0; t < max_tiers && i < cand.size(); t++) {
+    size_t best = cand.size();
+    while (i < cand.size() && cand[i].second - above <= caps[t]) best = i++;
+    if (best == cand.size() || cand[best].second == above) break;  // nothing fits (one degree holds more sources than a tier)
+    thr[nt++] = cand[best].first;
+    above = cand[best].second;
+  }
+  return nt;
+}
+
+// GDN_OK; 1 = outside the limits (nothing built)
+static int pb_build_out_tiered(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp, PbOutTiers &ts) {
+  const auto t_begin = std::chrono::steady_clock::now();
+  const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
+  auto t_last = t_begin;
+  auto phase = [&](const char *name) {
+    if (!trace) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[pb_build_out]   %-24s %8.3f ms\n", name, std::chrono::duration<double, std::milli>(now - t_last).count());
+    t_last = now;
+  };
+  const gdn_graph *g = a.g;
+  const unsigned m = (unsigned)g->m;
+  const unsigned long long n = g->nnz;
+  const int lc = a.log_chunk, lb = a.log_bin;
+  GDN_REQUIRE(lc >= 8 && lc <= 15 && lb >= 8 && lb <= PO_ROW_BITS, "out layout: log_chunk / log_bin");
+  const unsigned nchunks = (m + (1u << lc) - 1) >> lc, nbins = (m + (1u << lb) - 1) >> lb;
+  const unsigned d1 = (nbins + (1u << PO_LOW) - 1) >> PO_LOW, dt = (nbins + (1u << PO_TLOW) - 1) >> PO_TLOW;
+  int max_tiers = a.max_tiers > PB_MAX_REC_TIERS ? PB_MAX_REC_TIERS : a.max_tiers;
+  if (d1 + (unsigned)max_tiers * dt > PT_MAX_DIGITS || nchunks == 0 || nbins > 8192 || n == 0) return 1;
+  const unsigned grp = 1u << a.log_group;
+  const unsigned nbV = (m + PT_VTILE - 1) / PT_VTILE;
+  ts.n = 0;
+  ts.edges = 0;
+  PtArena A1;
+  {
+    size_t bytes = pt_pad256((size_t)m * 4) * 3 + pt_pad256((size_t)PT_NCLS * nbV * 4) + pt_pad256((size_t)nbV * 4) + 8192;
+    bytes += pt_pad256(((size_t)m + 2) * 8) + pt_pad256(((size_t)m + 2) * 4) + pt_pad256(((size_t)nchunks + 2) * 4);
+    bytes += pt_pad256(((size_t)(n >> 5) + 4) * 4) + pt_pad256((size_t)n * 4);
+    bytes += pt_pad256((PB_HUB_BUCKETS + PB_LIN_BINS + 64) * 4);
+    GDN_TRY(A1.init(bytes));
+  }
+  int32_t *deg = A1.get<int32_t>(m);
+  uint32_t *cnt16 = A1.get<uint32_t>(m), *smap = A1.get<uint32_t>(m);
+  uint32_t *bcS = A1.get<uint32_t>((size_t)PT_NCLS * nbV), *bcR = A1.get<uint32_t>(nbV), *totals = A1.get<uint32_t>(16);
+  unsigned *hist = A1.get<unsigned>(PB_HUB_BUCKETS + PB_LIN_BINS);
+  eoff_t *crp = A1.get<eoff_t>((size_t)m + 2);
+  uint32_t *nzrow = A1.get<uint32_t>((size_t)m + 2), *chunk_k = A1.get<uint32_t>((size_t)nchunks + 2);
+  uint32_t *rowstart = A1.get<uint32_t>((size_t)(n >> 5) + 4);
+  uint32_t *S = A1.get<uint32_t>(n);
+  PT_CHECK_PTR(S);
+  GDN_TRY(pt_zero(hist, (PB_HUB_BUCKETS + PB_LIN_BINS) * 4));
+  GDN_TRY(pt_zero(rowstart, ((size_t)(n >> 5) + 4) * 4));
+  hipLaunchKernelGGL(po_degrees_kernel, dim3(gdn_nblocks(m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, deg, cnt16);
+  if (max_tiers > 0) {
+    hipLaunchKernelGGL(pb_hub_hist_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, cnt16, (size_t)m, hist);
+    hipLaunchKernelGGL(pb_hub_hist_lin_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, cnt16, (size_t)m, hist + PB_HUB_BUCKETS);
+  }
+  hipLaunchKernelGGL(pt_row_count_kernel, dim3(nbV), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, bcR);
+  hipLaunchKernelGGL(pt_scan_rows_kernel, dim3(1), dim3(GDN_BLOCK), 0, 0, bcR, nbV, totals + 8);
+  GDN_HIP(hipGetLastError());
+  PtSrcArgs sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.src_count = deg;
+  sa.cnt16 = cnt16;
+  sa.n = m;
+  unsigned h_tot[16] = {};
+  if (max_tiers > 0) {
+    std::vector<unsigned> h_hist(PB_HUB_BUCKETS + PB_LIN_BINS);
+    GDN_HIP(hipMemcpy(h_hist.data(), hist, h_hist.size() * 4, hipMemcpyDeviceToHost));
+    sa.ntiers = po_choose_tiers(h_hist.data(), h_hist.data() + PB_HUB_BUCKETS, a.tier_min_deg < 1 ? 1u : a.tier_min_deg, max_tiers, a.caps, sa.thr);
+  }
+  GDN_HIP(hipMemcpy(h_tot + 8, totals + 8, 4, hipMemcpyDeviceToHost));
+  const eoff_t n_nz = h_tot[8];
+  hipLaunchKernelGGL(pt_src_count_kernel, dim3(nbV), dim3(GDN_BLOCK), 0, 0, sa, nbV, bcS);
+  hipLaunchKernelGGL(pt_scan_rows_kernel, dim3(PT_NCLS), dim3(GDN_BLOCK), 0, 0, bcS, nbV, totals);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipMemcpy(h_tot, totals, PT_NCLS * 4, hipMemcpyDeviceToHost));
+  while (sa.ntiers > 0 && h_tot[sa.ntiers] == 0) sa.ntiers--;
+  const unsigned ntiers = (unsigned)sa.ntiers;
+  unsigned n_ts = 0;
+  for (unsigned t = 0; t < ntiers; t++) {
+    if (h_tot[1 + t] > a.caps[t] || h_tot[1 + t] == 0) {
+      gdn_set_error("out layout: tier %u holds %u sources (cap %u)", t, h_tot[1 + t], a.caps[t]);
+      return GDN_ERR_INVALID;
+    }
+    ts.off[t] = n_ts;
+    n_ts += h_tot[1 + t];
+  }
+  ts.off[ntiers] = n_ts;
+  phase("degrees, classes");
+  const unsigned ncls = 1 + ntiers, nd = d1 + ntiers * dt;
+  const unsigned long long ntiles = (unsigned long long)nchunks * nbins;
+  p.m_local = g->m;
+  p.m_global = g->m;
+  p.log_chunk = lc;
+  p.log_bin = lb;
+  p.compact = false;
+  p.chunk_slots = 1u << lc;
+  p.log_group = a.log_group;
+  p.nchunks = nchunks;
+  p.nbins = nbins;
+  GDN_TRY(p.chunk_ptr.alloc((size_t)nchunks + 1));
+  GDN_TRY(p.bin_ptr.alloc((size_t)nbins + 1));
+  GDN_TRY(p.errflag.alloc(1));
+  GDN_HIP(hipMemsetAsync(p.errflag.p, 0, sizeof(unsigned), 0));
+  if (n_ts) GDN_TRY(ts.ids.alloc(n_ts));
+  if (ntiers) GDN_TRY(ts.ptr.alloc((size_t)ntiers * nbins + 1));
+  PtArena A2;
+  {
+    size_t bytes = pt_pad256((size_t)ncls * ntiles * 4) + pt_pad256(ntiles * 4) * 2 + pt_pad256((ntiles + 1) * 8) * 2;
+    bytes += pt_pad256((size_t)nchunks * nd * 4) + pt_pad256(((size_t)nchunks * nd + 1) * 8) + pt_pad256((size_t)(ntiers + 1) * nbins * 4);
+    bytes += pt_pad256(((size_t)nchunks + 2) * 8) * 2 + pt_pad256(((size_t)nbins + 2) * 8) + pt_pad256((size_t)nchunks * 4);
+    bytes += pt_pad256(((ntiles > (unsigned long long)nchunks * nd ? ntiles : (unsigned long long)nchunks * nd) / 2048 + 16) * 8);
+    GDN_TRY(A2.init(bytes, 2));
+  }
+  uint32_t *cnt = A2.get<uint32_t>((size_t)ncls * ntiles), *psz_c = A2.get<uint32_t>(ntiles), *psz_b = A2.get<uint32_t>(ntiles);
+  eoff_t *pu = A2.get<eoff_t>(ntiles + 1), *pv = A2.get<eoff_t>(ntiles + 1);
+  uint32_t *segsz = A2.get<uint32_t>((size_t)nchunks * nd);
+  eoff_t *segoff = A2.get<eoff_t>((size_t)nchunks * nd + 1);
+  uint32_t *tsz = A2.get<uint32_t>((size_t)(ntiers + 1) * nbins);
+  eoff_t *d_du = A2.get<eoff_t>((size_t)nchunks + 2), *chunk_sz = A2.get<eoff_t>((size_t)nchunks + 2), *d_dv = A2.get<eoff_t>((size_t)nbins + 2);
+  uint32_t *order = A2.get<uint32_t>(nchunks);
+  eoff_t *ws = A2.get<eoff_t>((ntiles > (unsigned long long)nchunks * nd ? ntiles : (unsigned long long)nchunks * nd) / 2048 + 16);
+  PT_CHECK_PTR(ws);
+  {
+    PtSrcOut so;
+    memset(&so, 0, sizeof(so));
+    for (unsigned t = 0; t < ntiers; t++) so.ids[t] = ts.ids.p + ts.off[t];
+    hipLaunchKernelGGL(po_src_assign_kernel, dim3(nbV), dim3(GDN_BLOCK), 0, 0, sa, nbV, bcS, smap, so);
+    hipLaunchKernelGGL(po_row_assign_kernel, dim3(nbV), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, bcR, lc, crp, nzrow, rowstart, chunk_k);
+    GDN_HIP(hipGetLastError());
+  }
+  {
+    PoCountArgs ca;
+    ca.rowptr = g->rowptr;
+    ca.colidx = g->colidx;
+    ca.smap = smap;
+    ca.rowstart = reinterpret_cast<const unsigned long long *>(rowstart);
+    ca.crp = crp;
+    ca.nzrow = nzrow;
+    ca.chunk_k = chunk_k;
+    ca.n_nz = n_nz;
+    ca.m = m;
+    ca.nchunks = nchunks;
+    ca.nbins = nbins;
+    ca.ncls = ncls;
+    ca.log_chunk = lc;
+    ca.log_bin = lb;
+    ca.S = S;
+    ca.cnt = cnt;
+    const size_t lds = (size_t)ncls * nbins * 4;
+    GDN_HIP(hipFuncSetAttribute((const void *)po_count_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds > 65536 ? lds : 65536)));
+    hipLaunchKernelGGL(po_count_kernel, dim3(nchunks), dim3(PT_THREADS), lds, 0, ca);
+    GDN_HIP(hipGetLastError());
+  }
+  phase("po_count");
+  eoff_t xlen = 0, n_te = 0;
+  if (ntiers) {
+    hipLaunchKernelGGL(po_tier_prefix_kernel, dim3(gdn_nblocks((uint64_t)ntiers * nbins)), dim3(GDN_BLOCK), 0, 0, cnt, nchunks, nbins, ntiers, tsz);
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(tsz, ts.ptr.p, (size_t)ntiers * nbins, ws, 0));
+    GDN_HIP(hipMemcpy(&n_te, ts.ptr.p + (size_t)ntiers * nbins, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  }
+  // tiles padded so that a tile's candidates are whole 128-byte lines where tiles are long (gdn_sssp.hip)
+  unsigned pad = a.pad;
+  if (pad == 0) {
+    const double avg_tile = (double)(n - n_te) / (double)ntiles;
+    pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
+  }
+  GDN_REQUIRE(pad >= grp && pad <= 128 && (pad & (pad - 1)) == 0, "out layout: pad");
+  {
+    const unsigned long long tt = ntiles > (unsigned long long)nchunks * nd ? ntiles : (unsigned long long)nchunks * nd;
+    // (po_sizes reads the per-chunk tier counts: po_tier_prefix has turned them into prefixes -- the segment sizes of the
+    // tiers are taken from differences)
+    hipLaunchKernelGGL(po_sizes_kernel, dim3(gdn_nblocks(tt)), dim3(GDN_BLOCK), 0, 0, cnt, nchunks, nbins, ntiers, pad, d1, dt, psz_c, psz_b, segsz, tsz);
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(psz_c, pu, (size_t)ntiles, ws, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(psz_b, pv, (size_t)ntiles, ws, 0));
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(segsz, segoff, (size_t)nchunks * nd, ws, 0));
+    hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(nchunks > nbins ? nchunks : nbins) + 1)), dim3(GDN_BLOCK), 0, 0, pu, pv,
+                       nchunks, nbins, p.chunk_ptr.p, p.bin_ptr.p);
+    GDN_HIP(hipGetLastError());
+  }
+  std::vector<eoff_t> cs((size_t)nchunks + 1), bs((size_t)nbins + 1);
+  GDN_HIP(hipMemcpy(cs.data(), p.chunk_ptr.p, cs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(bs.data(), p.bin_ptr.p, bs.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&xlen, segoff + (size_t)nchunks * nd, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  p.nnz = n - n_te;
+  ts.edges = n_te;
+  phase("offsets + readback");
+  eoff_t n_pad = 0;
+  std::vector<eoff_t> ca_((size_t)nchunks + 1, 0), ba((size_t)nbins + 1, 0);
+  {
+    std::vector<eoff_t> du(nchunks), dv(nbins);
+    auto pick_align = [](eoff_t total, unsigned parts) {
+      eoff_t al = 16;
+      while (al < 16384 && al * 32 <= total / (parts ? parts : 1)) al <<= 1;
+      return al;
+    };
+    const eoff_t al_c = pick_align(cs[nchunks], nchunks), al_b = pick_align(bs[nbins], nbins);
+    for (unsigned c = 0; c < nchunks; c++) {
+      du[c] = ca_[c] - cs[c];
+      ca_[c + 1] = (ca_[c] + (cs[c + 1] - cs[c]) + al_c - 1) & ~(al_c - 1);
+    }
+    for (unsigned b = 0; b < nbins; b++) {
+      dv[b] = ba[b] - bs[b];
+      ba[b + 1] = (ba[b] + (bs[b + 1] - bs[b]) + al_b - 1) & ~(al_b - 1);
+    }
+    n_pad = ca_[nchunks] > ba[nbins] ? ca_[nchunks] : ba[nbins];
+    GDN_HIP(hipMemcpyAsync(d_du, du.data(), du.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(d_dv, dv.data(), dv.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    hipLaunchKernelGGL(pb_shift_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu, pv, d_du, d_dv, nchunks, nbins);
+    GDN_HIP(hipMemcpyAsync(p.chunk_ptr.p, ca_.data(), ca_.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(p.bin_ptr.p, ba.data(), ba.size() * sizeof(eoff_t), hipMemcpyHostToDevice, 0));
+    // chunks by descending edge count (the launch order of the split): from the row offsets of the chunk starts
+    std::vector<uint32_t> co(nchunks);
+    for (unsigned c = 0; c < nchunks; c++) co[c] = c;
+    std::stable_sort(co.begin(), co.end(), [&](uint32_t x, uint32_t y) { return cs[x + 1] - cs[x] > cs[y + 1] - cs[y]; });
+    GDN_HIP(hipMemcpyAsync(order, co.data(), (size_t)nchunks * 4, hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipStreamSynchronize(0));
+  }
+  (void)chunk_sz;
+  p.n_pad = n_pad;
+  if ((n_pad >> a.log_group) + 1 > 0xFFFFFFFFull) {
+    gdn_set_error("out layout: more than 2^35 padded edges");
+    return GDN_ERR_INVALID;
+  }
+  PtArena A3;
+  GDN_TRY(A3.init(pt_pad256((size_t)xlen * 4) * 2 + 4096, 4));
+  uint32_t *X = A3.get<uint32_t>(xlen), *XV = A3.get<uint32_t>(xlen);
+  PT_CHECK_PTR(XV);
+  GDN_TRY(p.U.alloc(n_pad + grp));
+  GDN_TRY(p.V.alloc(n_pad + grp));
+  GDN_TRY(p.G.alloc((n_pad >> a.log_group) + 1));
+  GDN_TRY(Wp.alloc(n_pad + grp));
+  if (ntiers) {
+    GDN_TRY(ts.rec.alloc((size_t)n_te + 16));
+    if (a.want_w8) GDN_TRY(ts.w8.alloc((size_t)n_te + 16));
+  }
+  {
+    const unsigned long long fb = (n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(pb_fill_u16_kernel, dim3((unsigned)(fb > 262144ull ? 262144ull : fb)), dim3(GDN_BLOCK), 0, 0, p.U.p, n_pad + grp,
+                       (uint16_t)p.chunk_slots);
+    GDN_HIP(hipMemsetAsync(p.V.p, 0, (n_pad + grp) * sizeof(uint16_t), 0));
+    GDN_HIP(hipMemsetAsync(Wp.p, 0, (n_pad + grp) * sizeof(float), 0));
+    const unsigned long long ng = (n_pad >> a.log_group) + 1;
+    const unsigned long long fbg = (ng + GDN_BLOCK - 1) / GDN_BLOCK;
+    hipLaunchKernelGGL(pb_fill_u32_kernel, dim3((unsigned)(fbg > 262144ull ? 262144ull : fbg)), dim3(GDN_BLOCK), 0, 0, p.G.p, ng,
+                       (uint32_t)(n_pad >> a.log_group));
+  }
+  phase("arena 3 + arrays + fills");
+  {
+    PoSplitArgs sp;
+    sp.rowptr = g->rowptr;
+    sp.colidx = g->colidx;
+    sp.S = S;
+    sp.weight = a.weight;
+    sp.segoff = segoff;
+    sp.order = order;
+    sp.X = X;
+    sp.XV = XV;
+    sp.m = m;
+    sp.d1 = d1;
+    sp.dt = dt;
+    sp.ntiers = ntiers;
+    sp.log_chunk = lc;
+    sp.log_bin = lb;
+    const size_t lds = po_stage_bytes(nd);
+    GDN_HIP(hipFuncSetAttribute((const void *)po_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(po_split_kernel, dim3(nchunks), dim3(PT_PTHREADS), lds, 0, sp);
+    GDN_HIP(hipGetLastError());
+  }
+  phase("po_split");
+  {
+    PoTilesArgs ta;
+    ta.X = X;
+    ta.XV = XV;
+    ta.segoff = segoff;
+    ta.pu = pu;
+    ta.pv = pv;
+    ta.tptr = ntiers ? ts.ptr.p : nullptr;
+    ta.tpre = cnt;
+    ta.U = p.U.p;
+    ta.V = p.V.p;
+    ta.W = reinterpret_cast<uint32_t *>(Wp.p);
+    ta.rec = ntiers ? ts.rec.p : nullptr;
+    ta.w8 = (ntiers && a.want_w8) ? ts.w8.p : nullptr;
+    ta.nchunks = nchunks;
+    ta.nbins = nbins;
+    ta.d1 = d1;
+    ta.dt = dt;
+    ta.ntiers = ntiers;
+    const unsigned long long nseg = (unsigned long long)nchunks * nd;
+    hipLaunchKernelGGL(po_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, ta);
+    GDN_HIP(hipGetLastError());
+  }
+  phase("po_tiles");
+  hipLaunchKernelGGL(pb_groups_kernel, dim3(gdn_nblocks(ntiles)), dim3(GDN_BLOCK), 0, 0, pu, pv, psz_c, nchunks, nbins, p.G.p, 0, a.log_group);
+  GDN_HIP(hipGetLastError());
+  {
+    std::vector<uint32_t> co(nchunks), bo(nbins);
+    for (unsigned i = 0; i < nchunks; i++) co[i] = i;
+    for (unsigned i = 0; i < nbins; i++) bo[i] = i;
+    std::stable_sort(co.begin(), co.end(), [&](uint32_t x, uint32_t y) { return ca_[x + 1] - ca_[x] > ca_[y + 1] - ca_[y]; });
+    std::stable_sort(bo.begin(), bo.end(), [&](uint32_t x, uint32_t y) { return ba[x + 1] - ba[x] > ba[y + 1] - ba[y]; });
+    GDN_TRY(p.chunk_order.alloc(nchunks));
+    GDN_TRY(p.bin_order.alloc(nbins));
+    GDN_HIP(hipMemcpyAsync(p.chunk_order.p, co.data(), co.size() * 4, hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipMemcpyAsync(p.bin_order.p, bo.data(), bo.size() * 4, hipMemcpyHostToDevice, 0));
+    GDN_HIP(hipStreamSynchronize(0));
+  }
+  GDN_TRY(p.partial.alloc(nbins));
+  GDN_TRY(p.red_scratch.alloc(2 * ((size_t)nbins / 4096 + 2)));
+  ts.n = (int)ntiers;
+  GDN_HIP(hipDeviceSynchronize());
+  phase("groups + orders");
+  if (trace) {
+    fprintf(stderr, "[pb_build_out] edges %llu: main %llu padded %llu chunks %u bins %u", n, (unsigned long long)p.nnz, (unsigned long long)n_pad, nchunks, nbins);
+    for (unsigned t = 0; t < ntiers; t++) fprintf(stderr, ", tier %u: %u sources (degree >= %u)", t, h_tot[1 + t], sa.thr[t]);
+    fprintf(stderr, ", %llu tier edges; %.2f ms wall\n", (unsigned long long)n_te,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
+  }
+  return GDN_OK;
+}

@@ -1531,25 +1531,70 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       else if (p.w_max < 65536 && (force < 0 || force == 2)) p.w_bytes = 2;
       else p.w_bytes = 4;
     }
-    // record tiers (sssp_build_tiers): from 2^22 edges on, weights of at most 8 bits; bins of 2^14 rows then
+    // record tiers: from 2^22 edges on, weights of at most 8 bits
     DevBuf<uint8_t> cls;
     int lb = lg;
+    unsigned long long tiers_from = 1ull << 22;
+    if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_NNZ")) tiers_from = strtoull(e, nullptr, 10);  // (tests)
+    const bool want_tiers = p.w_bytes <= 1 && p.w_min >= 0 && g->nnz >= tiers_from;
+    bool built = false;
     {
-      unsigned long long tiers_from = 1ull << 22;
-      if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_NNZ")) tiers_from = strtoull(e, nullptr, 10);  // (tests)
-      if (p.w_bytes <= 1 && p.w_min >= 0 && g->nnz >= tiers_from) {
-        const int lbt = lg < SSSP_TIER_ROW_BITS ? lg : SSSP_TIER_ROW_BITS;  // a record keeps its row in 14 bits
+      // round 4: the blocked layout and the record tiers from one counting pass and one two-level split over the edges
+      // (pb_build_out_tiered, gdn_pbtier.hpp); GDN_PB_BUILDER=old: pb_build's sort of 8-byte keys + sssp_build_tiers
+      const char *be = gdn_option("GDN_PB_BUILDER"), *pe = gdn_option("GDN_SSSP_PAD");
+      if (!(be && be[0] == 'o')) {
+        PbOutArgs oa;
+        PbOutTiers ot;
+        oa.g = g;
+        oa.weight = d_weight;
+        oa.log_chunk = lg;
+        oa.log_bin = lb;
+        oa.pad = pe ? (unsigned)atoi(pe) : 0u;  // 0: by the average tile, see below
+        oa.log_group = 3;
+        const unsigned nbins = (unsigned)(((uint64_t)m + (1u << lb) - 1) >> lb);
+        unsigned min_deg = nbins / 4u < 8u ? 8u : nbins / 4u;  // a quarter of an edge per bin (profiles/r03_sssp_tiers.txt)
+        if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;
+        int max_tiers = SSSP_MAX_TIERS;
+        if (const char *e = gdn_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
+        oa.max_tiers = (want_tiers && m >= 2 && max_tiers > 0) ? max_tiers : 0;
+        oa.tier_min_deg = min_deg;
+        oa.caps[0] = SSSP_TIER0;
+        for (int t = 1; t < PB_MAX_REC_TIERS; t++) oa.caps[t] = SSSP_TIER_N;
+        oa.want_w8 = p.w_bytes == 1;
+        const int rc = pb_build_out_tiered_run(oa, p.pb, p.Wp, ot);
+        if (rc < 0) return rc;
+        if (rc == GDN_OK) {
+          built = true;
+          p.n_tiers = ot.n;
+          if (ot.n) {
+            for (int t = 0; t <= ot.n; t++) p.tier_off[t] = ot.off[t];
+            p.tier_ids.take(ot.ids);
+            p.tier_rec.take(ot.rec);
+            if (p.w_bytes == 1) p.tier_w.take(ot.w8);
+            p.tier_ptr.take(ot.ptr);
+            GDN_TRY(p.tier_tab.alloc(ot.off[ot.n]));
+            p.tier_edges = ot.edges;
+            if (gdn_option("GDN_SSSP_TRACE"))
+              fprintf(stderr, "[sssp] plan: %d record tiers, %u sources of >= %u out-edges, %llu edges (%.1f %% of the graph)\n", ot.n,
+                      ot.off[ot.n], min_deg, (unsigned long long)ot.edges, 100.0 * (double)ot.edges / (double)(g->nnz ? g->nnz : 1));
+          }
+        }
+      }
+    }
+    if (!built) {
+      if (want_tiers) {
+        const int lbt = lg < SSSP_TIER_ROW_BITS ? lg : SSSP_TIER_ROW_BITS;  // a record keeps its row in 15 bits
         GDN_TRY(sssp_build_tiers(p, g, d_weight, lbt, cls));
         if (p.n_tiers) lb = lbt;
       }
+      const double avg_tile = (double)(g->nnz - p.tier_edges) / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lb) + 1));
+      // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
+      // profiles/r03_sssp_layout_knobs.txt)
+      unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
+      if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
+      GDN_TRY(pb_build(g, m, lg, lb, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
+                       /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3, p.n_tiers ? cls.p : nullptr, 0));
     }
-    const double avg_tile = (double)(g->nnz - p.tier_edges) / ((double)(((uint64_t)m >> lg) + 1) * (double)(((uint64_t)m >> lb) + 1));
-    // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
-    // profiles/r03_sssp_layout_knobs.txt)
-    unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
-    if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
-    GDN_TRY(pb_build(g, m, lg, lb, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
-                     /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3, p.n_tiers ? cls.p : nullptr, 0));
     GDN_TRY(p.cand.alloc(p.pb.n_pad + 8));
     GDN_TRY(p.bad.alloc(1));
     GDN_HIP(hipMemset(p.bad.p, 0, 4));
