@@ -65,6 +65,23 @@ def med_min(xs):
     return {"median": (xs[n // 2] if n % 2 else 0.5 * (xs[n // 2 - 1] + xs[n // 2])), "min": xs[0], "n": n}
 
 
+def attach_traffic(roof, workload, scale, seconds):
+    """Counter-measured HBM bytes of one solve from profiles/<workload>_traffic.json (tools/traffic.sh: rocprofv3 FETCH_SIZE x 2 +
+    WRITE_SIZE passes of tools/traffic_run.py on this workload; NOT measured in this run) -> roofline.traffic and
+    roofline.frac_traffic = traffic / solve time / peak: the HBM utilisation, next to the model-based `frac`."""
+    roof["traffic"], roof["frac_traffic"], roof["traffic_source"] = None, None, None
+    f = os.path.join(ROOT, "profiles", "%s_traffic.json" % workload)
+    try:
+        tj = json.load(open(f))
+        if tj.get("scale") == scale and seconds > 0:
+            roof["traffic"] = tj["hbm_bytes_per_solve"]
+            roof["frac_traffic"] = tj["hbm_bytes_per_solve"] / seconds / 1e9 / HBM_PEAK_GBS
+            roof["traffic_source"] = "profiles/%s_traffic.json (%s), not this run" % (workload, tj.get("session", "session not recorded"))
+    except (OSError, ValueError, KeyError):
+        pass
+    return roof
+
+
 def physical_cores():
     """Physical cores of this host: distinct (physical id, core id) pairs of /proc/cpuinfo; SMT siblings count once."""
     try:
@@ -390,6 +407,11 @@ def main():
                                                     "its bottom-up levels, so frac can exceed 1 -- it compares with a "
                                                     "search that walks all edges, it is not an HBM utilisation "
                                                     "(per-level figures: profiles/r03_bfs_bottom_up.txt)"})
+                # counter traffic was taken on the FIRST source (tools/traffic_run.py): its own time is the divisor
+                first = sorted(r["ms"] for r in runs if r["source"] == runs[0]["source"])
+                attach_traffic(out["bfs"]["roofline"], "bfs", args.scale, first[(len(first) - 1) // 2] * 1e-3)
+                out["bfs"]["roofline"]["traffic_of_source"] = runs[0]["source"]
+                out["bfs"]["ms_by_source"] = {str(src_): sorted(r["ms"] for r in runs if r["source"] == src_) for src_ in sorted({r["source"] for r in runs})}
                 out["gteps_bfs"] = med["gteps"]
                 out["gteps_bfs_best"] = best["gteps"]
         except Exception as e:  # BFS is an extra; never lose the PR line
@@ -593,6 +615,7 @@ def bench_spmv(L, _cabi, graphio, torch, np, device, args):
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes, "model": "8(m+1) + 12 nnz + 8 m (SURVEY 8d)",
                         "kernel": "pb_expand_scaled_kernel + pb_accumulate_kernel<SpmvOp>"}}
+    attach_traffic(rec["roofline"], "spmv", args.spmv_scale, k_ms * 1e-3)
     # the one-shot drop-in on host arrays (what SpmvSolver binds to): upload, whatever it builds, one multiply
     try:
         h_rp, h_ci = np.empty(m + 1, np.uint64), np.empty(nnz, np.int32)
@@ -684,6 +707,7 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
                         "kernel_list_read_model": "4 B x the list elements the formulation that ran walks (one list per DAG "
                                                   "edge, from behind v in the forward form) + 12 nnz_dag + 16(m+1): what the "
                                                   "kernel requests, not what the model credits; counters: profiles/r03_tc_pmc.md"}}
+    attach_traffic(rec["roofline"], "tc", args.tc_scale, mm["median"] * 1e-3)
     # A/B: round 2's default (hash set, u- or v-centric on the reference's orientation, whichever probes less)
     try:
         _cabi.check(L.gdn_option_set(b"GDN_TC_FORM", b"a"))
@@ -772,6 +796,7 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "bytes_on_relaxed_edges": b_relaxed,
                                   "model_relaxed": "16 reached + 12 edges_relaxed + 4 m: every relaxation the solver made "
                                                    "(list passes: the out-edges of their list; a dense sweep: every edge)"}}
+        attach_traffic(rec[name]["roofline"], "sssp_unit" if name == "sssp_unit" else "sssp_u255", args.trav_scale, sec)
         # the one-shot drop-in on the resident graph (what SSSPSolver binds to: no plan handed in; from 2^24 edges on the
         # call builds the blocked layout itself and reports it as prep_ms)
         try:
@@ -805,6 +830,7 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "frac_one_pass": (b // max(st.iterations, 1)) / sec / 1e9 / HBM_PEAK_GBS,
                                   "model": "(8(m+1) + 8 nnz + 8 m) x passes (SURVEY 8d, CC per round; upper bound for "
                                            "Afforest's sampling passes)"}}
+        attach_traffic(rec[name]["roofline"], "cc" if rev is not None else "cc_out", args.trav_scale, sec)
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
     log(f"[bench] traversal: {rec}")
