@@ -58,6 +58,7 @@ PROTOTYPES = {
     "gdn_pr_delta_trace": (C.c_int, [_vp, _i32, C.POINTER(_i32), _vp, _vp, _vp]),
     "gdn_pr_delta_plan_free": (C.c_int, [_vp]),
     "gdn_pr_last_trace": (C.c_int, [_i32, C.POINTER(_i32), _vp]),
+    "gdn_pr_last_layout": (C.c_int, [C.POINTER(_i32)]),
     "gdn_pr_multi": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, C.c_float, C.c_double, _i32, _i32, _vp, _st]),
     "gdn_spmv_multi": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _st]),
     "gdn_multi_ranges": (C.c_int, [_i32, _vp, _i32, _vp, C.POINTER(_i32)]),

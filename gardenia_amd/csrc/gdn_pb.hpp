@@ -135,9 +135,17 @@ struct PbPlacer {
     int rc = GDN_OK;
     for (int k = 0; k < tries * mult && rc == GDN_OK; k++) {
       if (wall.stop_ms() > budget_ms) break;
+      // at most two rejected allocations are held at a time (six extra copies of a 4.4 GB array otherwise)
+      if (held.size() >= 2) {
+        delete held.front();
+        held.erase(held.begin());
+      }
       DevBuf<T> *old = new DevBuf<T>();
       held.push_back(old);
-      if (buf.move(old) != GDN_OK) break;  // no memory for a second copy: the array stays where it is
+      if (buf.move(old) != GDN_OK) {  // no memory for a second copy: the array stays where it is, and that is no error
+        gdn_set_error("%s", "");
+        break;
+      }
       double cur = 0;
       if ((rc = timed(&cur)) != GDN_OK) break;
       if (trace) fprintf(stderr, "[%s place] %-12s try %d: %.3f ms (best %.3f) at %p (was %p)\n", tag, name, k, cur, best, (void *)buf.p, (void *)old->p);

@@ -551,6 +551,15 @@ static int pr_solve_fused(const gdn_graph *g, const int32_t *d_deg, float *d_sco
 
 extern "C" {
 
+// layout of this thread's last gdn_pr solve: GDN_LAYOUT_CSR / GDN_LAYOUT_PB, -1 = none yet (the fused small-graph solve
+// counts as GDN_LAYOUT_CSR: it pulls over the caller's in-CSR)
+static thread_local int g_pr_last_layout = -1;
+int gdn_pr_last_layout(int32_t *layout) {
+  GDN_REQUIRE(layout != nullptr, "layout");
+  *layout = g_pr_last_layout;
+  return GDN_OK;
+}
+
 int gdn_pr_last_trace(int32_t capacity, int32_t *n, double *diff) {
   GDN_REQUIRE(n != nullptr && capacity >= 0 && (diff != nullptr || capacity == 0), "n / diff");
   *n = (int32_t)g_pr_trace.size();
@@ -966,7 +975,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int tries = 3;
     if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
     if (tries > 0) {
-      const int rcp = pr_plan_place(p, tries, 2500.0);
+      const int rcp = pr_plan_place(p, tries, 1200.0);  // (with the 0.13 s layout build of round 4 the whole plan stays under 1.5 s)
       if (rcp != GDN_OK) {
         delete p;
         return rcp;
@@ -1496,6 +1505,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       int fused = 0;
       if (want && (rc = pr_solve_fused(g, d_deg.p, d_scores.p, damping, epsilon, max_iter, &st, &fused))) break;
       if (fused) {
+        g_pr_last_layout = GDN_LAYOUT_CSR;
         if (hipMemcpy(scores, d_scores.p, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) {
           gdn_set_error("gdn_pr: download failed");
           rc = GDN_ERR_HIP;
@@ -1537,6 +1547,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     rc = gdn_pr_plan_create(g, d_deg.p, m, 0, layout, &plan);
     g_pr_no_place = false;
     if (rc) break;
+    g_pr_last_layout = plan->layout;
     int32_t ms = m;
     if ((rc = gdn_pr_plan_state_size(plan, &ms))) break;
     if ((rc = d_state.alloc(ms)) || (rc = d_c0.alloc(ms)) || (rc = d_c1.alloc(ms))) break;

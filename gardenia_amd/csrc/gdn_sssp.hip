@@ -1315,9 +1315,9 @@ struct gdn_sssp_plan {
 // RECORD TIERS of the dense sweeps.  PageRank's record tiers (gdn_pb.hpp) for a min-plus sweep: an edge of the blocked layout
 // costs 9.5 B per sweep (U 2 + G 0.5 + weight 1 + candidate 2 written, candidate 2 + V 2 read); an edge that leaves a source
 // of high out-degree is instead kept as a RECORD in the order phase B wants it (bin-major): 4 bytes (source index << 14 | row
-// in the bin) + 1 byte of weight, and the source's distance is looked up in a table refreshed per sweep (32 K entries for the
+// in the bin; 15 row bits) + 1 byte of weight, and the source's distance is looked up in a table refreshed per sweep (32 K entries for the
 // first tier, up to 256 K for the others: L2 resident).  Sources are ranked by out-degree; those with at least 1/16 edge per
-// bin (and 8) go into up to SSSP_MAX_TIERS tiers.  Needs weights of at most 8 bits (or all equal) and bins of 2^14 rows.
+// bin (and 8) go into up to SSSP_MAX_TIERS tiers.  Needs weights of at most 8 bits (or all equal) and bins of at most 2^15 rows.
 // ------------------------------------------------------------------------------------------
 int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
                        const unsigned long long **sorted);
@@ -2195,10 +2195,20 @@ int gdn_sssp_dev(const gdn_graph *g, const int32_t *d_weight, int32_t source, in
   // layouts for arrays rewritten in place.  GDN_SSSP_ONESHOT_DENSE_MIN moves the threshold (0 = never).
   unsigned long long dense_min = 1ull << 24;
   if (const char *e = gdn_option("GDN_SSSP_ONESHOT_DENSE_MIN")) dense_min = strtoull(e, nullptr, 10);
-  gdn_sssp_plan p;
-  // (no lists for the binned passes here: allocating them costs more than they save in ONE solve)
-  GDN_TRY(sssp_plan_init(p, g, d_weight, /*dense=*/dense_min != 0 && g->nnz >= dense_min, /*bins=*/false));
-  return sssp_run(p, source, delta, d_dist, stats);
+  const bool want_dense = dense_min != 0 && g->nnz >= dense_min;
+  {
+    gdn_sssp_plan p;
+    // (no lists for the binned passes here: allocating them costs more than they save in ONE solve)
+    const int rc = sssp_plan_init(p, g, d_weight, want_dense, /*bins=*/false);
+    if (rc == GDN_OK) return sssp_run(p, source, delta, d_dist, stats);
+    if (!(rc == GDN_ERR_OOM && want_dense)) return rc;
+  }
+  // the blocked layout (~10 B per edge + its build scratch) did not fit: the worklist-only plan needs none of it
+  // (the first plan and everything it held is released by now)
+  gdn_scratch_trim();
+  gdn_sssp_plan q;
+  GDN_TRY(sssp_plan_init(q, g, d_weight, /*dense=*/false, /*bins=*/false));
+  return sssp_run(q, source, delta, d_dist, stats);
 }
 
 // Host API: one call == SSSPSolver(g, source, weight, dist, delta) (src/sssp/main.cc:27).

@@ -116,6 +116,10 @@ def PRSolver(g: Graph, scores: np.ndarray, damping=K_DAMP, epsilon=EPSILON, max_
                                        float(epsilon), int(max_iter), C.byref(st)))
     out = st.as_dict()
     out["trace"] = pr_last_trace()
+    if not (devices is not None or n > 1):
+        lay = C.c_int32(-1)
+        _cabi.check(_cabi.lib().gdn_pr_last_layout(C.byref(lay)))
+        out["layout"] = {0: "csr", 1: "pb"}.get(lay.value, str(lay.value))
     return out
 
 

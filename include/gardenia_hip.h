@@ -88,6 +88,12 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
  * iterates (" %2d    %lf", src/pr/omp_base.cc:35; the only golden it ships is that trace,
  * test/reference/graph-pr.mtx.out:13-27).  *n = iterations recorded; the first min(*n, capacity) go to diff. */
 int gdn_pr_last_trace(int32_t capacity, int32_t *n, double *diff);
+/* The layout the calling thread's last gdn_pr ran on (GDN_LAYOUT_CSR or GDN_LAYOUT_PB below; -1 before the first call).
+ * gdn_pr picks it by predicted wall time -- the blocked layout costs ~100 ps per edge to build (stats.prep_ms) and saves
+ * ~8 ps per edge and iteration -- unless the option GDN_PR_LAYOUT forces c(sr) or p(b); GDN_PR_ONESHOT=solve: the blocked
+ * layout from 2^22 edges on whatever the iteration count.  No counterpart in the reference (src/pr/pr.h:31 has one
+ * layout per binary). */
+int gdn_pr_last_layout(int32_t *layout);
 
 /* PRSolver on `ngpus` devices of this node (SURVEY 8b `gdn_pr(..., int ngpus, gdn_stats*)`, 8e; supersedes the
  * edge-list slicing stub of include/graph_gpu.h:145-165 -- the reference has no multi-GPU hot path).  Same arguments

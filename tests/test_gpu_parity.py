@@ -1229,6 +1229,28 @@ def test_tc_golden(case, form, monkeypatch):
     assert total2 == int(d["total"])
 
 
+def test_pr_one_shot_takes_the_blocked_layout_from_2_22_edges_on(orc, monkeypatch):
+    """the PRSolver drop-in (gdn_pr, no plan handed in) runs the propagation-blocked layout by default on a graph of
+    >= 2^22 edges -- the layout build is ~100 ps per edge since round 4, a solve to 1e-4 saves more than that --; GDN_PR_LAYOUT
+    forces with c / p and means `auto` with anything else; small graphs stay on the caller's CSR."""
+    g = graphio.rmat_graph(19, 16, seed=5)
+    assert g.nnz >= 1 << 22
+    G = solvers.Graph(csr=g, need_reverse=True)
+    want, it, _ = orc.pr(graphio.transpose(g), np.diff(g.rowptr.astype(np.int64)).astype(np.int32))
+    for env, lay in ((None, "pb"), ("c", "csr"), ("p", "pb"), ("auto", "pb")):
+        if env is None:
+            monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+        else:
+            monkeypatch.setenv("GDN_PR_LAYOUT", env)
+        s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(G, s)
+        assert st["layout"] == lay and st["iterations"] == it and np.allclose(s, want, rtol=1e-4, atol=0), (env, st["layout"])
+    monkeypatch.delenv("GDN_PR_LAYOUT", raising=False)
+    small = graphio.rmat_graph(14, 8, seed=5)
+    s = np.full(small.m, np.float32(1.0) / np.float32(small.m), np.float32)
+    assert solvers.PRSolver(solvers.Graph(csr=small, need_reverse=True), s)["layout"] == "csr"
+
+
 @pytest.mark.parametrize("form", ["", "f"])
 def test_tc_oriented_input_that_is_no_dag_counts_like_the_reference_loop(orc, form, monkeypatch):
     """with oriented=1 the count runs on the caller's lists AS THEY ARE (src/tc/omp_base.cc:16-22 does not know
