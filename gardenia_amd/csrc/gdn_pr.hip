@@ -168,22 +168,40 @@ pr_count_sources_kernel(const int32_t *__restrict__ deg, int32_t m, unsigned lon
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_locality_sample_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int32_t row_base,
                           unsigned long long *__restrict__ out /* [0] edges sampled, [1] local ones */) {
-  const unsigned wid = (blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
-  const uint64_t row = (uint64_t)wid << 4;
-  if (row >= (uint64_t)m) return;
-  const eoff_t b = rowptr[row], e = rowptr[row + 1];
-  const long long me = (long long)row + row_base;
+  // waves stride over the sampled rows and keep their counts; ONE pair of atomics per workgroup (a pair per sampled row
+  // was 2 x 262 K atomics on one line at RMAT-22: 3 ms of a 4.5 ms layout build); at most 256 edges of a row are looked at
+  __shared__ unsigned long long s_n[GDN_WAVES_PER_BLOCK], s_l[GDN_WAVES_PER_BLOCK];
+  const unsigned nwaves = gridDim.x * GDN_WAVES_PER_BLOCK;
   unsigned long long n = 0, loc = 0;
-  for (eoff_t k = b + gdn_lane(); k < e; k += 64) {
-    const long long d = (long long)colidx[k] - me;
-    n++;
-    loc += (d < 65536 && d > -65536) ? 1u : 0u;
+  for (uint64_t wid = blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); (wid << 4) < (uint64_t)m; wid += nwaves) {
+    const uint64_t row = wid << 4;
+    const eoff_t b = rowptr[row];
+    eoff_t e = rowptr[row + 1];
+    if (e - b > 256) e = b + 256;
+    const long long me = (long long)row + row_base;
+    for (eoff_t k = b + gdn_lane(); k < e; k += 64) {
+      const long long d = (long long)colidx[k] - me;
+      n++;
+      loc += (d < 65536 && d > -65536) ? 1u : 0u;
+    }
   }
   n = gdn_wave_sum(n);
   loc = gdn_wave_sum(loc);
-  if (gdn_lane() == 0 && n) {
-    atomicAdd(out, n);
-    atomicAdd(out + 1, loc);
+  if (gdn_lane() == 0) {
+    s_n[threadIdx.x >> 6] = n;
+    s_l[threadIdx.x >> 6] = loc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long tn = 0, tl = 0;
+    for (int w = 0; w < GDN_WAVES_PER_BLOCK; w++) {
+      tn += s_n[w];
+      tl += s_l[w];
+    }
+    if (tn) {
+      atomicAdd(out, tn);
+      atomicAdd(out + 1, tl);
+    }
   }
 }
 
@@ -193,7 +211,8 @@ static bool pr_gather_is_local(const gdn_graph *g, int32_t row_base) {
   DevBuf<unsigned long long> acc;
   if (acc.alloc(2) != GDN_OK || hipMemset(acc.p, 0, 16) != hipSuccess) return false;
   const uint64_t sampled = ((uint64_t)g->m + 15) >> 4;
-  hipLaunchKernelGGL(pr_locality_sample_kernel, dim3(gdn_nblocks(sampled * 64)), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, g->m,
+  const unsigned nb = gdn_nblocks(sampled * 64);
+  hipLaunchKernelGGL(pr_locality_sample_kernel, dim3(nb > 2048u ? 2048u : nb), dim3(GDN_BLOCK), 0, 0, g->rowptr, g->colidx, g->m,
                      row_base, acc.p);
   unsigned long long h[2] = {0, 0};
   if (hipMemcpy(h, acc.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return false;
