@@ -52,6 +52,9 @@
 #define PB_MAX_LOG_BIN 14    // 16384 u64    = 128 KB of LDS
 #define PB_FIX_SHIFT 62
 #define PB_HR_THREADS 128    // threads of phase A that fold the hub-row edges while the others sweep
+#ifndef PB_IL_QUADS
+#define PB_IL_QUADS 2        // phase B, interleaved record streams: 16-byte record loads (= 4 table reads each) in flight per lane
+#endif
 
 struct PbPlan {
   int32_t m_local = 0;   // destination rows
@@ -208,7 +211,8 @@ struct PbMidArgs {  // kernel argument of phase B
   const uint32_t *rec[PB_MAX_REC_TIERS];
   const float *val[PB_MAX_REC_TIERS];      // n + 1 values (slot n = 0 for pad records)
   unsigned zrec[PB_MAX_REC_TIERS];         // the pad record: n << PB_MID_ROW_BITS
-  int form[PB_MAX_REC_TIERS];              // 0 record per lane, 1 four records per lane + table window (val: n + 4 slots)
+  int form[PB_MAX_REC_TIERS];              // 0 record per lane, 1 four records per lane + table window (val: n + 4 slots),
+                                           // 2 lane-interleaved blocks of 256 records: a 16-byte load = records l + 64 j
   const float *A[PB_MAX_REC_TIERS];        // nullable: per-record factor (SpMV's Ax in record order): value = table * A
   int n = 0;
 };
@@ -240,7 +244,8 @@ struct PbTierSet {
     uint64_t nnz = 0;
     DevBuf<uint32_t> ids;     // original (label) id of source k, ascending
     DevBuf<uint32_t> rec;     // bin-major records (source index << 14 | row), pad records = n_src << 14
-    DevBuf<eoff_t> bin_ptr;   // nbins + 1 record offsets (multiples of 16)
+    DevBuf<eoff_t> bin_ptr;   // nbins + 1 record offsets (multiples of 16; of 256 when interleaved)
+    bool interleaved = false; // blocks of 256 records stored lane-interleaved (pt_interleave_kernel): phase B form 2
   } t[PB_MAX_REC_TIERS];
   bool first_is_hub = false;  // t[0] is the hub tier (<= 2^15 sources), else the mid tiers start at t[0]
 };
@@ -261,6 +266,7 @@ struct PbTieredArgs {
   unsigned min16 = 1;
   int bin_balance_log = PB_MAX_LOG_BIN;
   bool alloc_vals = true;
+  bool interleave = false;  // mid-tier record streams in lane-interleaved blocks of 256 (PbTierSet::Tier::interleaved)
 };
 
 // GDN_OK; 1 = shape outside the builder's limits (nothing built: use pb_build); 2 = a column occurs whose src_count is 0
@@ -1210,6 +1216,38 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
     const pb_f32x4 *__restrict__ FA4 = reinterpret_cast<const pb_f32x4 *>(FA);
     const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
+    if (mid.form[t] == 2) {
+      // lane-interleaved blocks of 256 records (gdn_pbtier.hpp, pt_interleave_kernel; the stream is a whole number of
+      // blocks, so a wave's 64 quads are one block): quad l of a block = records l, 64 + l, 128 + l, 192 + l of the sorted
+      // stream.  A quarter of form 0's record loads, and table read j of the wave still covers 64 consecutive records.
+      // (per-record factors, when present, are stored in the same interleaved order)
+      constexpr int IU = PB_IL_QUADS;
+      for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)IU * PB_THREADS) {
+        pb_u32x4 rc[IU];
+        pb_f32x4 a[IU];
+        float f[IU][4];
+#pragma unroll
+        for (int r = 0; r < IU; r++) {
+          const unsigned i = i0 + (unsigned)r * PB_THREADS;
+          rc[r] = pb_u32x4{z, z, z, z};
+          a[r] = pb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+          if (i < nr4) {
+            rc[r] = __builtin_nontemporal_load(R4 + i);
+            if (FA4) a[r] = __builtin_nontemporal_load(FA4 + i);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < IU; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) f[r][j] = T[rc[r][j] >> PB_MID_ROW_BITS];
+#pragma unroll
+        for (int r = 0; r < IU; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            atomicAdd(&s_acc[rc[r][j] & RMASK], fx(FA4 ? gdn_fmul(f[r][j], a[r][j]) : f[r][j], rc[r][j] & RMASK));
+      }
+      continue;
+    }
     constexpr int MU = 4;
     for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)MU * PB_THREADS) {
       pb_u32x4 rc[MU];

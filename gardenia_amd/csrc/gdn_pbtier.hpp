@@ -442,6 +442,9 @@ pt_keygen_kernel(PtKeyArgs a) {
 }
 
 // ---- offsets --------------------------------------------------------------------------------------------------------
+struct PtTierPads {  // a tier's bin streams are padded to multiples of pad[t] records (a power of two)
+  unsigned pad[PB_MAX_REC_TIERS];
+};
 // padded tile sizes in both tile orders + the (unpadded) sizes of the (bin, 8 chunks) segments of pt_split's output
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pt_tile_sizes_kernel(const uint32_t *__restrict__ tile_cnt, unsigned nchunks, unsigned nbins, unsigned pad, unsigned d1,
@@ -464,10 +467,34 @@ pt_tile_sizes_kernel(const uint32_t *__restrict__ tile_cnt, unsigned nchunks, un
   }
 }
 static __global__ void __launch_bounds__(GDN_BLOCK)
-pt_tier_sizes_kernel(const uint32_t *__restrict__ tier_cnt, unsigned nbins, int ntiers, uint32_t *__restrict__ tsz /*ntiers x nbins*/) {
+pt_tier_sizes_kernel(const uint32_t *__restrict__ tier_cnt, unsigned nbins, int ntiers, uint32_t *__restrict__ tsz /*ntiers x nbins*/,
+                     PtTierPads pads) {
   const unsigned b = blockIdx.x * GDN_BLOCK + threadIdx.x;
   if (b >= nbins) return;
-  for (int t = 0; t < ntiers; t++) tsz[(size_t)t * nbins + b] = (tier_cnt[(size_t)b * 8 + t] + 15u) & ~15u;
+  for (int t = 0; t < ntiers; t++) tsz[(size_t)t * nbins + b] = (tier_cnt[(size_t)b * 8 + t] + (pads.pad[t] - 1u)) & ~(pads.pad[t] - 1u);
+}
+// Interleaved record streams (PbTierSet::Tier::interleaved): inside every block of 256 records (streams are padded to whole
+// blocks) record r of the sorted order sits at (r % 64) * 4 + r / 64, so that ONE 16-byte load per lane hands lane l the
+// records l, 64 + l, 128 + l, 192 + l -- phase B then issues a quarter of the record loads, and its j-th table read still
+// covers 64 CONSECUTIVE records of the source-sorted stream (four consecutive records per lane spread the 64 reads of an
+// instruction over four times as many table lines).  In place, a wave per block: all four loads of every lane have
+// returned before the wave's store issues.
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pt_interleave_kernel(uint32_t *__restrict__ rec, unsigned long long nblk) {
+  typedef unsigned pt_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned lane = gdn_lane();
+  for (unsigned long long q = (unsigned long long)blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); q < nblk;
+       q += (unsigned long long)gridDim.x * GDN_WAVES_PER_BLOCK) {
+    uint32_t *base = rec + q * 256ull;
+    pt_u32x4 v;
+    v.x = base[lane];
+    v.y = base[64u + lane];
+    v.z = base[128u + lane];
+    v.w = base[192u + lane];
+    __builtin_amdgcn_s_waitcnt(0);  // (the data dependence already makes the compiler wait; kept explicit)
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<pt_u32x4 *>(base)[lane] = v;
+  }
 }
 
 // ---- stable partition of a range of items by a digit, staged through LDS ---------------------------------------------
@@ -767,7 +794,7 @@ pt_radix_kernel(PtRadixArgs a) {
     d = (item >> shift) & mask;
   });
   if (a.last) {
-    const unsigned npad = (n + 15u) & ~15u;
+    const unsigned npad = (unsigned)(a.ptr[b + 1] - p0);  // the stream's padded length (pt_tier_sizes_kernel)
     for (unsigned i = n + threadIdx.x; i < npad; i += PT_PTHREADS) a.out[p0 + i] = a.zrec;
   }
 }
@@ -1031,7 +1058,12 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     hipLaunchKernelGGL(pb_ptrs_kernel, dim3(gdn_nblocks((uint64_t)(nchunks > nbins ? nchunks : nbins) + 1)), dim3(GDN_BLOCK), 0, 0, pu,
                        pv, nchunks, nbins, p.chunk_ptr.p, p.bin_ptr.p);
     if (ntiers) {
-      hipLaunchKernelGGL(pt_tier_sizes_kernel, dim3(gdn_nblocks(nbins)), dim3(GDN_BLOCK), 0, 0, tier_cnt, nbins, ntiers, tsz);
+      PtTierPads pads;
+      for (int t = 0; t < PB_MAX_REC_TIERS; t++) {
+        ts.t[t].interleaved = a.interleave && !(t == 0 && has_hub);
+        pads.pad[t] = ts.t[t].interleaved ? 256u : 16u;
+      }
+      hipLaunchKernelGGL(pt_tier_sizes_kernel, dim3(gdn_nblocks(nbins)), dim3(GDN_BLOCK), 0, 0, tier_cnt, nbins, ntiers, tsz, pads);
       for (int t = 0; t < ntiers; t++) GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(tsz + (size_t)t * nbins, ts.t[t].bin_ptr.p, nbins, ws, 0));
     }
     hipLaunchKernelGGL(pt_sizes_from_ptr_kernel, dim3(gdn_nblocks(nbins)), dim3(GDN_BLOCK), 0, 0, bin_e, nbins, bin_sz);
@@ -1182,6 +1214,11 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
       ra.last = ps == passes - 1 ? 1 : 0;
       const size_t lds = pt_stage_bytes(1u << ra.bits);
       hipLaunchKernelGGL(kern_r, dim3(nbins), dim3(PT_PTHREADS), lds, 0, ra);
+    }
+    if (ts.t[t].interleaved && tier_pad[t]) {
+      const unsigned long long nblk = (unsigned long long)tier_pad[t] >> 8;  // every stream is a whole number of blocks
+      const unsigned long long wb = (nblk + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK;
+      hipLaunchKernelGGL(pt_interleave_kernel, dim3((unsigned)(wb > 65536ull ? 65536ull : wb)), dim3(GDN_BLOCK), 0, 0, ts.t[t].rec.p, nblk);
     }
     GDN_HIP(hipGetLastError());
   }

@@ -41,6 +41,7 @@ struct gdn_pr_plan {
     DevBuf<uint32_t> ids;    // original id of source k (ascending)
     DevBuf<uint32_t> rec;    // bin-major records
     DevBuf<float> val;       // n + 1 values per iteration
+    bool il = false;         // rec in lane-interleaved blocks of 256 (PbTierSet::Tier::interleaved): phase B form 2
   } mid[PB_MAX_MID];
   // hub-ROW tier: the edges into the n_hr rows with the most in-edges (from non-hub sources) are summed by phase A in
   // LDS behind the chunk's slice; one partial sum per (chunk, hub row) replaces one value per edge
@@ -741,6 +742,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       ta.tiers = want_tiers;
       ta.max_mid = max_mid;
       ta.min16 = 1u;
+      {  // mid-tier record streams in lane-interleaved blocks (a quarter of phase B's record loads); GDN_PB_REC_IL=0: plain
+        const char *ie = gdn_option("GDN_PB_REC_IL");
+        ta.interleave = !(ie && ie[0] == '0');
+      }
       int rc = pb_build_tiered_run(ta, p->pb, ts);
       if (rc == 2 && !ta.colmap) {
         ta.src_count = nullptr;
@@ -770,6 +775,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
           mt.layout.bin_ptr.take(ts.t[t].bin_ptr);
           mt.layout.nnz = ts.t[t].nnz;
           mt.layout.nbins = p->pb.nbins;
+          mt.il = ts.t[t].interleaved;
           st = mt.val.alloc((size_t)mt.n + 4);
           p->n_mid_tiers = t - k + 1;
         }
@@ -1274,11 +1280,12 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     mid.val[mid.n] = plan->mid[t].val.p;
     mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
     mid.A[mid.n] = nullptr;
-    mid.form[mid.n++] = 0;
+    mid.form[mid.n++] = plan->mid[t].il ? 2 : 0;
   }
 #ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)
   if (const char *e = gdn_option("GDN_PB_MIDVAR"))
-    for (int t = 0; t < mid.n; t++) mid.form[t] = (atoi(e) >> t) & 1;
+    for (int t = 0; t < mid.n; t++)
+      if (mid.form[t] != 2) mid.form[t] = (atoi(e) >> t) & 1;  // (an interleaved stream can only be read as form 2)
 #endif
   // a bin belongs to the part that holds its FIRST row: after part j every row below its row_end is final
   const bool whole = first && last;

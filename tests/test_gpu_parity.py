@@ -335,9 +335,11 @@ def test_pr_mid_tiers_are_bitwise_neutral(orc, monkeypatch, world, parts):
     for k, v in TIER_ENV.items():
         monkeypatch.setenv(k, v)
     res = []
-    for hubs, mid in (("0", "0"), ("1", "0"), ("1", "2")):
+    # (il: the mid tiers' record streams in lane-interleaved blocks of 256 -- phase B form 2, the default -- or plain)
+    for hubs, mid, il in (("0", "0", "1"), ("1", "0", "1"), ("1", "2", "1"), ("1", "2", "0")):
         monkeypatch.setenv("GDN_PB_HUBS", hubs)
         monkeypatch.setenv("GDN_PB_MID", mid)
+        monkeypatch.setenv("GDN_PB_REC_IL", il)
         sh = solvers.ResidentPageRankShards(G, world, 1, parts=parts)
         nh, nt, ns, ne = C.c_int32(0), C.c_int32(0), C.c_int32(0), C.c_uint64(0)
         _cabi.check(_cabi.lib().gdn_pr_plan_hubs(sh.ranks[0]["plan"], C.byref(nh), None))
@@ -351,9 +353,9 @@ def test_pr_mid_tiers_are_bitwise_neutral(orc, monkeypatch, world, parts):
         scores, it2, err = sh.solve()
         sh.close()
         res.append((scores, it2, err))
-    assert res[0][1] == res[1][1] == res[2][1] == it
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], res[2][0])
-    assert res[0][2] == res[1][2] == res[2][2]
+    assert res[0][1] == res[1][1] == res[2][1] == res[3][1] == it
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][0], res[2][0]) and np.array_equal(res[0][0], res[3][0])
+    assert res[0][2] == res[1][2] == res[2][2] == res[3][2]
     np.testing.assert_allclose(res[2][0], want, rtol=REL_TOL, atol=0)
     assert abs(res[2][2] - trace[-1]) < 1e-6
 
