@@ -280,7 +280,9 @@ struct PbOutTiers {  // gdn_sssp.hip's record tiers (see gdn_sssp_plan)
   DevBuf<uint32_t> ids;                     // tier sources, tier by tier, ascending ids inside a tier
   DevBuf<uint32_t> rec;                     // records (index in the tier << 15 | row), tier-major then bin-major
   DevBuf<uint8_t> w8;                       // their weights (nullable)
-  DevBuf<eoff_t> ptr;                       // n x nbins + 1
+  DevBuf<eoff_t> ptr;                       // n x nbins + 1 (interleaved: every stream starts on a multiple of 256 records)
+  DevBuf<uint32_t> cnt;                     // interleaved only: n x nbins record counts (the streams are not padded with records)
+  bool interleaved = false;                 // the whole 256-record blocks of every stream (and of w8) are lane-interleaved
   unsigned long long edges = 0;
 };
 struct PbOutArgs {
@@ -293,6 +295,7 @@ struct PbOutArgs {
   unsigned tier_min_deg = 8;
   unsigned caps[PB_MAX_REC_TIERS] = {1u << 15, 1u << 17, 1u << 17, 1u << 17, 1u << 17};
   bool want_w8 = false;
+  bool interleave = false;        // record streams (and w8) in lane-interleaved blocks of 256, see pt_interleave_kernel
 };
 
 // GDN_OK; 1 = outside the builder's limits (nothing built: pb_build + sssp_build_tiers)

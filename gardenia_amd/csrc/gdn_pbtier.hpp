@@ -1502,6 +1502,37 @@ po_tier_prefix_kernel(uint32_t *__restrict__ cnt, unsigned nchunks, unsigned nbi
   tsz[i] = acc;
 }
 
+// interleaved streams of an out-CSR plan: padded stream sizes, and the in-place interleave of the whole 256-record blocks of
+// every (tier, bin) stream -- records as in pt_interleave_kernel, the weight bytes with the same permutation (a lane's
+// 32-bit word = the weights of its four records).  A workgroup per stream, a wave per block.
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_pad_sizes_kernel(const uint32_t *__restrict__ tsz, unsigned n, uint32_t *__restrict__ out) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) out[i] = (tsz[i] + 255u) & ~255u;
+}
+static __global__ void __launch_bounds__(GDN_BLOCK)
+po_interleave_kernel(uint32_t *__restrict__ rec, uint8_t *__restrict__ w8, const eoff_t *__restrict__ ptr, const uint32_t *__restrict__ cnt) {
+  typedef unsigned pt_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned lane = gdn_lane();
+  const eoff_t j0 = ptr[blockIdx.x];
+  const unsigned nblk = cnt[blockIdx.x] >> 8;
+  for (unsigned q = threadIdx.x >> 6; q < nblk; q += GDN_WAVES_PER_BLOCK) {
+    uint32_t *base = rec + j0 + (eoff_t)q * 256u;
+    pt_u32x4 v;
+    v.x = base[lane];
+    v.y = base[64u + lane];
+    v.z = base[128u + lane];
+    v.w = base[192u + lane];
+    unsigned wv = 0u;
+    uint8_t *wb = w8 ? w8 + j0 + (eoff_t)q * 256u : nullptr;
+    if (wb) wv = (unsigned)wb[lane] | ((unsigned)wb[64u + lane] << 8) | ((unsigned)wb[128u + lane] << 16) | ((unsigned)wb[192u + lane] << 24);
+    __builtin_amdgcn_s_waitcnt(0);  // every load of the wave has returned before its stores issue
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<pt_u32x4 *>(base)[lane] = v;
+    if (wb) reinterpret_cast<uint32_t *>(wb)[lane] = wv;
+  }
+}
+
 // (item, value) form of pt_partition: ranks by LDS atomics, both words staged
 struct PoStage {
   uint32_t *stage, *vstage;
@@ -1938,11 +1969,22 @@ static int pb_build_out_tiered(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp,
     GDN_HIP(hipGetLastError());
   }
   phase("po_count");
-  eoff_t xlen = 0, n_te = 0;
+  eoff_t xlen = 0, n_te = 0, n_te_pad = 0;
   if (ntiers) {
     hipLaunchKernelGGL(po_tier_prefix_kernel, dim3(gdn_nblocks((uint64_t)ntiers * nbins)), dim3(GDN_BLOCK), 0, 0, cnt, nchunks, nbins, ntiers, tsz);
     GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(tsz, ts.ptr.p, (size_t)ntiers * nbins, ws, 0));
     GDN_HIP(hipMemcpy(&n_te, ts.ptr.p + (size_t)ntiers * nbins, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    ts.interleaved = a.interleave;
+    if (a.interleave) {  // streams start on multiples of 256 records; the counts travel with the plan (no pad records)
+      const unsigned nst = ntiers * nbins;
+      DevBuf<uint32_t> tszp;
+      GDN_TRY(ts.cnt.alloc(nst));
+      GDN_TRY(tszp.alloc(nst));
+      GDN_HIP(hipMemcpyAsync(ts.cnt.p, tsz, (size_t)nst * 4, hipMemcpyDeviceToDevice, 0));
+      hipLaunchKernelGGL(po_pad_sizes_kernel, dim3(gdn_nblocks(nst)), dim3(GDN_BLOCK), 0, 0, tsz, nst, tszp.p);
+      GDN_TRY(gdn_exclusive_scan_u32_to_u64_ws(tszp.p, ts.ptr.p, (size_t)nst, ws, 0));
+      GDN_HIP(hipMemcpy(&n_te_pad, ts.ptr.p + (size_t)nst, sizeof(eoff_t), hipMemcpyDeviceToHost));
+    } else n_te_pad = n_te;
   }
   // tiles padded so that a tile's candidates are whole 128-byte lines where tiles are long (gdn_sssp.hip)
   unsigned pad = a.pad;
@@ -2016,8 +2058,8 @@ static int pb_build_out_tiered(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp,
   GDN_TRY(p.G.alloc((n_pad >> a.log_group) + 1));
   GDN_TRY(Wp.alloc(n_pad + grp));
   if (ntiers) {
-    GDN_TRY(ts.rec.alloc((size_t)n_te + 16));
-    if (a.want_w8) GDN_TRY(ts.w8.alloc((size_t)n_te + 16));
+    GDN_TRY(ts.rec.alloc((size_t)n_te_pad + 16));
+    if (a.want_w8) GDN_TRY(ts.w8.alloc((size_t)n_te_pad + 16));
   }
   {
     const unsigned long long fb = (n_pad + grp + GDN_BLOCK - 1) / GDN_BLOCK;
@@ -2074,6 +2116,10 @@ static int pb_build_out_tiered(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp,
     ta.ntiers = ntiers;
     const unsigned long long nseg = (unsigned long long)nchunks * nd;
     hipLaunchKernelGGL(po_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, ta);
+    GDN_HIP(hipGetLastError());
+  }
+  if (ntiers && ts.interleaved) {
+    hipLaunchKernelGGL(po_interleave_kernel, dim3(ntiers * nbins), dim3(GDN_BLOCK), 0, 0, ts.rec.p, a.want_w8 ? ts.w8.p : nullptr, ts.ptr.p, ts.cnt.p);
     GDN_HIP(hipGetLastError());
   }
   phase("po_tiles");

@@ -46,6 +46,8 @@ struct SsspTierArgs {  // what phase B needs (by value)
   const uint32_t *rec = nullptr;
   const uint8_t *w = nullptr;  // nullptr: every weight is w_uniform
   const eoff_t *ptr = nullptr;
+  const uint32_t *cnt = nullptr;  // nullable: records per (tier, bin) stream -- set when the whole 256-record blocks of every stream
+                                  // (and of w) are lane-interleaved (PbOutTiers::interleaved); nullptr: plain streams, count = ptr difference
   const unsigned *tab = nullptr;
   unsigned off[SSSP_MAX_TIERS] = {};
   unsigned w_uniform = 0;
@@ -424,13 +426,50 @@ sssp_pb_accumulate_kernel(int32_t m_dst, int log_bin, const eoff_t *__restrict__
   // records per lane spread them over four times as many lines and cost the sweep 0.66 instead of 0.6 ms)
   for (int t = 0; t < ta.n; t++) {
     const eoff_t j0 = ta.ptr[(size_t)t * ta.nbins + b];
-    const unsigned nr = (unsigned)(ta.ptr[(size_t)t * ta.nbins + b + 1] - j0);
+    const unsigned nr = ta.cnt ? ta.cnt[(size_t)t * ta.nbins + b] : (unsigned)(ta.ptr[(size_t)t * ta.nbins + b + 1] - j0);
     const unsigned *__restrict__ tab = ta.tab + ta.off[t];
     const uint32_t *__restrict__ R = ta.rec + j0;
     const uint8_t *__restrict__ W = ta.w ? ta.w + j0 : nullptr;
     constexpr int TU = 8;
     constexpr unsigned RMASK = (1u << SSSP_TIER_ROW_BITS) - 1u;
-    for (unsigned i0 = threadIdx.x; i0 < nr; i0 += (unsigned)TU * PB_THREADS) {
+    // interleaved streams: the whole blocks of 256 records with ONE 16-byte record load and ONE 4-byte weight load per lane
+    // and four records (lane l of a block holds records l, 64 + l, 128 + l, 192 + l of the sorted stream, so table read j of
+    // the wave still covers 64 consecutive records); a quarter of the record loads and of the weight loads of the plain form
+    const unsigned nfull = ta.cnt ? nr & ~255u : 0u;
+    {
+      const sssp_u32x4 *__restrict__ R4 = reinterpret_cast<const sssp_u32x4 *>(R);  // j0 is a multiple of 256
+      const uint32_t *__restrict__ W4 = reinterpret_cast<const uint32_t *>(W);
+      constexpr int IU = 2;
+      const unsigned nq = nfull >> 2;
+      for (unsigned i0 = threadIdx.x; i0 < nq; i0 += (unsigned)IU * PB_THREADS) {
+        sssp_u32x4 rc[IU];
+        unsigned wv[IU], d[IU][4];
+        bool on[IU];
+#pragma unroll
+        for (int r = 0; r < IU; r++) {
+          const unsigned i = i0 + (unsigned)r * PB_THREADS;
+          on[r] = i < nq;
+          rc[r] = sssp_u32x4{0u, 0u, 0u, 0u};
+          wv[r] = 0u;
+          if (on[r]) {
+            rc[r] = __builtin_nontemporal_load(R4 + i);
+            if (W4) wv[r] = __builtin_nontemporal_load(W4 + i);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < IU; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) d[r][j] = on[r] ? tab[rc[r][j] >> SSSP_TIER_ROW_BITS] : (unsigned)GDN_DIST_INF;
+#pragma unroll
+        for (int r = 0; r < IU; r++)
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const unsigned nd = d[r][j] + (W4 ? ((wv[r] >> (8 * j)) & 0xFFu) : ta.w_uniform);
+            if (d[r][j] < (unsigned)GDN_DIST_INF && nd < (unsigned)GDN_DIST_INF) atomicMin(&s_min[rc[r][j] & RMASK], nd);
+          }
+      }
+    }
+    for (unsigned i0 = nfull + threadIdx.x; i0 < nr; i0 += (unsigned)TU * PB_THREADS) {
       unsigned rc[TU], wv[TU], d[TU];
       bool on[TU];
 #pragma unroll
@@ -1293,6 +1332,7 @@ struct gdn_sssp_plan {
   DevBuf<uint32_t> tier_rec;                   // records, tier-major then bin-major
   DevBuf<uint8_t> tier_w;                      // their weights (w_bytes 1; none when all weights are equal)
   DevBuf<eoff_t> tier_ptr;                     // n_tiers x nbins + 1 offsets into tier_rec
+  DevBuf<uint32_t> tier_cnt;                   // interleaved streams only (SsspTierArgs::cnt): records per stream
   unsigned long long tier_edges = 0;
   DevBuf<unsigned> cand;   // candidate distances, bin-major (u16 or u32 per sweep)
   DevBuf<unsigned> improved;
@@ -1561,6 +1601,10 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
         oa.caps[0] = SSSP_TIER0;
         for (int t = 1; t < PB_MAX_REC_TIERS; t++) oa.caps[t] = SSSP_TIER_N;
         oa.want_w8 = p.w_bytes == 1;
+        {  // lane-interleaved record streams (a quarter of phase B's record and weight loads); GDN_SSSP_REC_IL=0: plain
+          const char *ie = gdn_option("GDN_SSSP_REC_IL");
+          oa.interleave = !(ie && ie[0] == '0');
+        }
         const int rc = pb_build_out_tiered_run(oa, p.pb, p.Wp, ot);
         if (rc < 0) return rc;
         if (rc == GDN_OK) {
@@ -1572,6 +1616,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
             p.tier_rec.take(ot.rec);
             if (p.w_bytes == 1) p.tier_w.take(ot.w8);
             p.tier_ptr.take(ot.ptr);
+            if (ot.interleaved) p.tier_cnt.take(ot.cnt);
             GDN_TRY(p.tier_tab.alloc(ot.off[ot.n]));
             p.tier_edges = ot.edges;
             if (gdn_option("GDN_SSSP_TRACE"))
@@ -1717,6 +1762,7 @@ static void sssp_launch_sweep(gdn_sssp_plan &p, int32_t m, int32_t *d_dist) {
     ta.rec = p.tier_rec.p;
     ta.w = p.w_bytes == 1 ? p.tier_w.p : nullptr;
     ta.ptr = p.tier_ptr.p;
+    ta.cnt = p.tier_cnt.p;  // nullptr for plain streams
     ta.tab = p.tier_tab.p;
     for (int t = 0; t < p.n_tiers; t++) ta.off[t] = p.tier_off[t];
     ta.w_uniform = p.w_bytes == 0 ? (unsigned)p.w_min : 0u;

@@ -1034,6 +1034,8 @@ def test_sssp_record_tiers_vs_oracle(orc, monkeypatch, capfd, scale, ef, floor, 
     monkeypatch.setenv("GDN_SSSP_TIER_MIN_DEG", floor)
     monkeypatch.setenv("GDN_SSSP_DENSE_IN", "100000")
     monkeypatch.setenv("GDN_SSSP_TRACE", "1")
+    # record streams in lane-interleaved blocks of 256 (the default) -- and plain, as before, in the scale-16 case
+    monkeypatch.setenv("GDN_SSSP_REC_IL", "0" if scale == 16 else "1")
     if tiers:
         monkeypatch.setenv("GDN_SSSP_TIERS", tiers)
     g = graphio.rmat_graph(scale, ef, seed=91)
