@@ -57,6 +57,7 @@
 #endif
 
 struct PbPlan {
+  bool v_il = false;     // V stored in lane-interleaved blocks of 512 edges (pb_v_interleave_kernel; every bin starts on a multiple of 512)
   int32_t m_local = 0;   // destination rows
   int32_t m_global = 0;  // source ids
   uint64_t nnz = 0;
@@ -215,6 +216,7 @@ struct PbMidArgs {  // kernel argument of phase B
                                            // 2 lane-interleaved blocks of 256 records: a 16-byte load = records l + 64 j
   const float *A[PB_MAX_REC_TIERS];        // nullable: per-record factor (SpMV's Ax in record order): value = table * A
   int n = 0;
+  int v_il = 0;                            // PbPlan::v_il: V in lane-interleaved blocks of 512 edges (one 16-byte load = the rows of two quads)
 };
 struct PbTierRefresh {  // kernel argument of phase A (PageRank): the tier tables are refreshed by the same launch
   const uint32_t *ids[PB_MAX_REC_TIERS];  // original id of source k
@@ -267,6 +269,7 @@ struct PbTieredArgs {
   int bin_balance_log = PB_MAX_LOG_BIN;
   bool alloc_vals = true;
   bool interleave = false;  // mid-tier record streams in lane-interleaved blocks of 256 (PbTierSet::Tier::interleaved)
+  bool v_interleave = false;  // V in lane-interleaved blocks of 512 edges when every bin starts on a multiple of 512 (PbPlan::v_il)
 };
 
 // GDN_OK; 1 = shape outside the builder's limits (nothing built: use pb_build); 2 = a column occurs whose src_count is 0
@@ -1063,23 +1066,47 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     atomicAdd(&s_acc[v.w], p3);
   };
   constexpr unsigned STEPU = (unsigned)UNR * PB_THREADS;
+  static_assert(UNR % 2 == 0, "the interleaved-V form pairs the quads of a step");
+  // Quad r of this thread in the step that starts at quad `sbase`.  Plain V: threadIdx.x + r * PB_THREADS.  Interleaved V
+  // (mid.v_il; the bin then starts and ends on multiples of 128 quads): a wave owns 128 consecutive quads per pair of r, lane l
+  // the quads l and 64 + l of them -- whose rows are ONE 16-byte word of V (pb_v_interleave_kernel): three vector-memory
+  // loads per 8 edges instead of four.
+  const bool vil = mid.v_il != 0;
+  auto qi = [&](unsigned sbase, int r) -> unsigned {
+    return vil ? sbase + (unsigned)(r >> 1) * (2u * PB_THREADS) + (w << 7) + ((unsigned)(r & 1) << 6) + lane
+               : sbase + threadIdx.x + (unsigned)r * PB_THREADS;
+  };
+  const pb_u16x8 *V8q = reinterpret_cast<const pb_u16x8 *>(Vq);
+  auto load_step = [&](unsigned sbase, pb_f32x4 (&x)[UNR], pb_u16x4 (&v)[UNR], bool full) {
+#pragma unroll
+    for (int r = 0; r < UNR; r++) {
+      const unsigned i = qi(sbase, r);
+      if (full || i < nq) x[r] = __builtin_nontemporal_load(Xq + i);
+    }
+    if (vil) {
+#pragma unroll
+      for (int pr = 0; pr < UNR / 2; pr++) {
+        const unsigned i0 = qi(sbase, 2 * pr);  // (valid together with i0 + 64: nq is a multiple of 128)
+        pb_u16x8 t = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (full || i0 < nq) t = __builtin_nontemporal_load(V8q + (((i0 - lane) >> 1) + lane));
+        v[2 * pr] = pb_u16x4{t[0], t[1], t[2], t[3]};
+        v[2 * pr + 1] = pb_u16x4{t[4], t[5], t[6], t[7]};
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < UNR; r++) {
+        const unsigned i = qi(sbase, r);
+        v[r] = load_rows(i, full || i < nq);
+      }
+    }
+  };
   unsigned sb = 0;  // first quad of the current step (wave-uniform)
   if (PB_DBG(32)) sb = nq;  // timing-only ablation: no main stream
   else if (nq >= STEPU) {
     // software pipeline over the full steps: the loads of step k+1 are in flight while step k is folded into LDS
-#pragma unroll
-    for (int r = 0; r < UNR; r++) {
-      const unsigned i = threadIdx.x + (unsigned)r * PB_THREADS;
-      xs[r] = __builtin_nontemporal_load(Xq + i);
-      vs[r] = load_rows(i, true);
-    }
+    load_step(0u, xs, vs, true);
     for (; sb + 2u * STEPU <= nq; sb += STEPU) {
-#pragma unroll
-      for (int r = 0; r < UNR; r++) {
-        const unsigned i = sb + STEPU + threadIdx.x + (unsigned)r * PB_THREADS;
-        nx[r] = __builtin_nontemporal_load(Xq + i);
-        nv[r] = load_rows(i, true);
-      }
+      load_step(sb + STEPU, nx, nv, true);
 #pragma unroll
       for (int r = 0; r < UNR; r++) fold(xs[r], vs[r]);
 #pragma unroll
@@ -1093,17 +1120,10 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     sb += STEPU;
   }
   // the last, partial step (q0 and q1 are multiples of 8 quads, so the 8 lanes of a group are valid together)
+  load_step(sb, xs, vs, false);
 #pragma unroll
   for (int r = 0; r < UNR; r++) {
-    const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
-    const bool ok = i < nq;
-    if (ok) xs[r] = __builtin_nontemporal_load(Xq + i);
-    vs[r] = load_rows(i, ok);
-  }
-#pragma unroll
-  for (int r = 0; r < UNR; r++) {
-    const unsigned i = sb + threadIdx.x + (unsigned)r * PB_THREADS;
-    if (i < nq) fold(xs[r], vs[r]);
+    if (qi(sb, r) < nq) fold(xs[r], vs[r]);
   }
   if (hub_ptr && !PB_DBG(16)) {
     // edges of hub sources: 4 B per edge (u16 hub index + u16 row), 8 edges per lane and step with 16-byte loads;

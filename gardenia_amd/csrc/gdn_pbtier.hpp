@@ -738,6 +738,24 @@ pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segof
   }
 }
 
+// V of a plan whose bins all start on multiples of 512 edges, in place: inside every block of 512 edges (128 quads of four
+// 16-bit rows) the 16-byte word l holds quad l and quad 64 + l (PbPlan::v_il; read by pb_accumulate_kernel's load_step).
+// A wave per block: every load of the wave has returned before its store issues.
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_v_interleave_kernel(uint16_t *__restrict__ V, unsigned long long nblk) {
+  typedef unsigned pt_u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned pt_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned lane = gdn_lane();
+  for (unsigned long long q = (unsigned long long)blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); q < nblk;
+       q += (unsigned long long)gridDim.x * GDN_WAVES_PER_BLOCK) {
+    pt_u32x2 *base = reinterpret_cast<pt_u32x2 *>(V + q * 512ull);
+    const pt_u32x2 lo = base[lane], hi = base[64u + lane];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<pt_u32x4 *>(base)[lane] = pt_u32x4{lo.x, lo.y, hi.x, hi.y};
+  }
+}
+
 // pt_radix: one stable pass over the records of every (bin) segment of ONE tier by bits [shift, shift + bits) of the record
 struct PtRadixArgs {
   const uint32_t *in;
@@ -1094,7 +1112,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   p.nnz = n0;
   phase("offsets + readback");
   // slice starts on aligned boundaries (see pb_build)
-  eoff_t n_pad = 0;
+  eoff_t n_pad = 0, al_b_used = 0;
   std::vector<eoff_t> ca((size_t)nchunks + 1, 0), ba((size_t)nbins + 1, 0);
   {
     std::vector<eoff_t> du(nchunks), dv(nbins);
@@ -1104,6 +1122,7 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
       return al;
     };
     const eoff_t al_c = pick_align(cs[nchunks], nchunks), al_b = pick_align(bs[nbins], nbins);
+    al_b_used = al_b;
     for (unsigned c = 0; c < nchunks; c++) {
       du[c] = ca[c] - cs[c];
       ca[c + 1] = (ca[c] + (cs[c + 1] - cs[c]) + al_c - 1) & ~(al_c - 1);
@@ -1189,6 +1208,16 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     const unsigned long long nseg = (unsigned long long)d1 * nbins;
     hipLaunchKernelGGL(pt_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, X, segoff, d1, nbins, nchunks, pu, pv, p.U.p, p.V.p);
     GDN_HIP(hipGetLastError());
+  }
+  p.v_il = false;
+  if (a.v_interleave && al_b_used >= 512 && ba[nbins] >= 512) {
+    // every bin starts (and ends) on a multiple of 512 edges: V in lane-interleaved blocks (phase B: one 16-byte load = the rows
+    // of the lane's two quads of a block)
+    const unsigned long long nblk = (unsigned long long)ba[nbins] >> 9;
+    const unsigned long long wb = (nblk + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK;
+    hipLaunchKernelGGL(pb_v_interleave_kernel, dim3((unsigned)(wb > 65536ull ? 65536ull : wb)), dim3(GDN_BLOCK), 0, 0, p.V.p, nblk);
+    GDN_HIP(hipGetLastError());
+    p.v_il = true;
   }
   phase("pt_tiles");
   // record tiers: (row, source) -> (source, row) inside every bin

@@ -745,6 +745,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       {  // mid-tier record streams in lane-interleaved blocks (a quarter of phase B's record loads); GDN_PB_REC_IL=0: plain
         const char *ie = gdn_option("GDN_PB_REC_IL");
         ta.interleave = !(ie && ie[0] == '0');
+        const char *ve = gdn_option("GDN_PB_V_IL");  // the same for the main stream's rows (PbPlan::v_il); 0: plain
+        ta.v_interleave = !(ve && ve[0] == '0');
       }
       int rc = pb_build_tiered_run(ta, p->pb, ts);
       if (rc == 2 && !ta.colmap) {
@@ -1282,6 +1284,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     mid.A[mid.n] = nullptr;
     mid.form[mid.n++] = plan->mid[t].il ? 2 : 0;
   }
+  mid.v_il = pb.v_il ? 1 : 0;
 #ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)
   if (const char *e = gdn_option("GDN_PB_MIDVAR"))
     for (int t = 0; t < mid.n; t++)

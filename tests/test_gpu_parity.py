@@ -698,6 +698,28 @@ def test_pr_is_bitwise_reproducible(monkeypatch):
     assert np.array_equal(runs[0], runs[1]) and np.array_equal(runs[0], runs[2])
 
 
+def test_pr_interleaved_streams_are_bitwise_neutral(orc, monkeypatch):
+    """The lane-interleaved forms of phase B's streams at a size where they are on by default -- V in blocks of 512 edges
+    (bins start on multiples of 512 from ~2^14 main-layout edges per bin on), the mid tiers' records in blocks of 256 --
+    against the plain forms: same bits, same iteration count, and within 1e-4 of the oracle."""
+    g = graphio.rmat_graph(20, 16, seed=5)
+    gi = graphio.transpose(g)
+    want, it, _ = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "p")
+    monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")
+    res = []
+    for v_il, rec_il in (("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")):
+        monkeypatch.setenv("GDN_PB_V_IL", v_il)
+        monkeypatch.setenv("GDN_PB_REC_IL", rec_il)
+        s = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(G, s)
+        res.append((s, st["iterations"]))
+    assert all(r[1] == it for r in res)
+    assert all(np.array_equal(res[0][0], r[0]) for r in res[1:])
+    np.testing.assert_allclose(res[0][0], want, rtol=REL_TOL, atol=0)
+
+
 def test_pr_hub_row_spanning_tiles(orc, pr_layout):
     # vertex 0 has 50000 in-neighbours: its row spans > 12 merge-path tiles.  The reference adds
     # such a row sequentially in fp32 (omp_base.cc:28-29), which by itself drifts ~6e-4 from the
