@@ -922,6 +922,61 @@ struct PbTracksLossy<T, decltype((void)T::kTrackLossy)> {
 #else
 #define PB_DBG(bits) false
 #endif
+// The whole 256-record blocks of every bin's record stream (ptr: nbins + 1 offsets, multiples of 4 records), and of the
+// per-record factors A (nullable), lane-interleaved in place for phase B's form 2: word l of a block = records l, 64 + l,
+// 128 + l, 192 + l.  A workgroup per bin, a wave per block (every load of the wave has returned before its stores issue).
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_stream_interleave_kernel(uint32_t *__restrict__ rec, float *__restrict__ A, const eoff_t *__restrict__ ptr) {
+  typedef unsigned pbi_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned lane = gdn_lane();
+  const eoff_t j0 = ptr[blockIdx.x];
+  const unsigned nblk = (unsigned)((ptr[blockIdx.x + 1] - j0) >> 8);
+  for (unsigned q = threadIdx.x >> 6; q < nblk; q += GDN_WAVES_PER_BLOCK) {
+    uint32_t *base = rec + j0 + (eoff_t)q * 256u;
+    pbi_u32x4 v = {base[lane], base[64u + lane], base[128u + lane], base[192u + lane]};
+    pb_f32x4 fa = {0.0f, 0.0f, 0.0f, 0.0f};
+    float *ab = A ? A + j0 + (eoff_t)q * 256u : nullptr;
+    if (ab) fa = pb_f32x4{ab[lane], ab[64u + lane], ab[128u + lane], ab[192u + lane]};
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<pbi_u32x4 *>(base)[lane] = v;
+    if (ab) reinterpret_cast<pb_f32x4 *>(ab)[lane] = fa;
+  }
+}
+// V of a plan whose bins all start on multiples of 512 edges, in place: inside every block of 512 edges (128 quads of four
+// 16-bit rows) the 16-byte word l holds quad l and quad 64 + l (PbPlan::v_il; read by pb_accumulate_kernel's load_step).
+// A wave per block.
+static __global__ void __launch_bounds__(GDN_BLOCK)
+pb_v_interleave_kernel(uint16_t *__restrict__ V, unsigned long long nblk) {
+  typedef unsigned pbi_u32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned pbi_u32x4 __attribute__((ext_vector_type(4)));
+  const unsigned lane = gdn_lane();
+  for (unsigned long long q = (unsigned long long)blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); q < nblk;
+       q += (unsigned long long)gridDim.x * GDN_WAVES_PER_BLOCK) {
+    pbi_u32x2 *base = reinterpret_cast<pbi_u32x2 *>(V + q * 512ull);
+    const pbi_u32x2 lo = base[lane], hi = base[64u + lane];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    reinterpret_cast<pbi_u32x4 *>(base)[lane] = pbi_u32x4{lo.x, lo.y, hi.x, hi.y};
+  }
+}
+// host side: interleaves p.V when every bin of the plan starts on a multiple of 512 edges (sets p.v_il); else leaves it
+static inline int pb_v_interleave(PbPlan &p) {
+  p.v_il = false;
+  if (p.nbins == 0 || p.n_pad < 512) return GDN_OK;
+  std::vector<eoff_t> bp((size_t)p.nbins + 1);
+  GDN_HIP(hipMemcpy(bp.data(), p.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+  for (eoff_t x : bp)
+    if (x & 511u) return GDN_OK;
+  const unsigned long long nblk = (unsigned long long)bp[p.nbins] >> 9;
+  if (nblk == 0) return GDN_OK;
+  const unsigned long long wb = (nblk + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK;
+  hipLaunchKernelGGL(pb_v_interleave_kernel, dim3((unsigned)(wb > 65536ull ? 65536ull : wb)), dim3(GDN_BLOCK), 0, 0, p.V.p, nblk);
+  GDN_HIP(hipGetLastError());
+  p.v_il = true;
+  return GDN_OK;
+}
+
 // phase B: acc[bin] = SUM fixed(vals) over the bin's contiguous range; then the fused epilogue of the rows (op).
 // TAG: 1 = the launches of a plan's placement search (PbPlacer) -- the same code under another name, so that a profiler's
 // per-kernel statistics of the iterations proper do not average in sweeps timed on allocations that were then dropped
@@ -1194,12 +1249,49 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
     const float *__restrict__ FA = mid.A[t] ? mid.A[t] + mid.ptr[t][b] : nullptr;  // per-record factors
     const unsigned z = mid.zrec[t];
     constexpr unsigned RMASK = (1u << PB_MID_ROW_BITS) - 1u;
-    if (mid.form[t] == 0) {
+    typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
+    if (mid.form[t] == 0 || mid.form[t] == 2) {
       const uint32_t *__restrict__ R = mid.rec[t] + mid.ptr[t][b];
       const unsigned nr = (unsigned)(mid.ptr[t][b + 1] - mid.ptr[t][b]);
+      // form 2: the stream's whole blocks of 256 records are lane-interleaved (pt_interleave_kernel / pb_stream_interleave_
+      // kernel): quad l of a block = records l, 64 + l, 128 + l, 192 + l of the sorted stream, so a wave's 64 quads are one
+      // block.  A quarter of form 0's record (and factor) loads, and table read j of the wave still covers 64 consecutive
+      // records.  Per-record factors, when present, are stored in the same order.  The rest of the stream (< 256 records)
+      // is plain and read as form 0.
+      const unsigned nfull = mid.form[t] == 2 ? nr & ~255u : 0u;
+      if (nfull) {
+        const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(R);
+        const pb_f32x4 *__restrict__ FA4 = reinterpret_cast<const pb_f32x4 *>(FA);
+        const unsigned nq4 = nfull >> 2;
+        constexpr int IU = PB_IL_QUADS;
+        for (unsigned i0 = threadIdx.x; i0 < nq4; i0 += (unsigned)IU * PB_THREADS) {
+          pb_u32x4 rc[IU];
+          pb_f32x4 a[IU];
+          float f[IU][4];
+#pragma unroll
+          for (int r = 0; r < IU; r++) {
+            const unsigned i = i0 + (unsigned)r * PB_THREADS;
+            rc[r] = pb_u32x4{z, z, z, z};
+            a[r] = pb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            if (i < nq4) {
+              rc[r] = __builtin_nontemporal_load(R4 + i);
+              if (FA4) a[r] = __builtin_nontemporal_load(FA4 + i);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < IU; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) f[r][j] = T[rc[r][j] >> PB_MID_ROW_BITS];
+#pragma unroll
+          for (int r = 0; r < IU; r++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+              atomicAdd(&s_acc[rc[r][j] & RMASK], fx(FA4 ? gdn_fmul(f[r][j], a[r][j]) : f[r][j], rc[r][j] & RMASK));
+        }
+      }
       constexpr int MUNR = 8;
       constexpr unsigned RSTEP = (unsigned)MUNR * PB_THREADS;
-      for (unsigned i0 = threadIdx.x; i0 < nr; i0 += RSTEP) {
+      for (unsigned i0 = nfull + threadIdx.x; i0 < nr; i0 += RSTEP) {
         uint32_t rc[MUNR];
         float f[MUNR], a[MUNR];
 #pragma unroll
@@ -1234,43 +1326,10 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
       }
       continue;
     }
-    typedef unsigned pb_u32x4 __attribute__((ext_vector_type(4)));
     typedef float pb_f32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // 4-byte aligned window
     const pb_u32x4 *__restrict__ R4 = reinterpret_cast<const pb_u32x4 *>(mid.rec[t] + mid.ptr[t][b]);
     const pb_f32x4 *__restrict__ FA4 = reinterpret_cast<const pb_f32x4 *>(FA);
     const unsigned nr4 = (unsigned)((mid.ptr[t][b + 1] - mid.ptr[t][b]) >> 2);
-    if (mid.form[t] == 2) {
-      // lane-interleaved blocks of 256 records (gdn_pbtier.hpp, pt_interleave_kernel; the stream is a whole number of
-      // blocks, so a wave's 64 quads are one block): quad l of a block = records l, 64 + l, 128 + l, 192 + l of the sorted
-      // stream.  A quarter of form 0's record loads, and table read j of the wave still covers 64 consecutive records.
-      // (per-record factors, when present, are stored in the same interleaved order)
-      constexpr int IU = PB_IL_QUADS;
-      for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)IU * PB_THREADS) {
-        pb_u32x4 rc[IU];
-        pb_f32x4 a[IU];
-        float f[IU][4];
-#pragma unroll
-        for (int r = 0; r < IU; r++) {
-          const unsigned i = i0 + (unsigned)r * PB_THREADS;
-          rc[r] = pb_u32x4{z, z, z, z};
-          a[r] = pb_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-          if (i < nr4) {
-            rc[r] = __builtin_nontemporal_load(R4 + i);
-            if (FA4) a[r] = __builtin_nontemporal_load(FA4 + i);
-          }
-        }
-#pragma unroll
-        for (int r = 0; r < IU; r++)
-#pragma unroll
-          for (int j = 0; j < 4; j++) f[r][j] = T[rc[r][j] >> PB_MID_ROW_BITS];
-#pragma unroll
-        for (int r = 0; r < IU; r++)
-#pragma unroll
-          for (int j = 0; j < 4; j++)
-            atomicAdd(&s_acc[rc[r][j] & RMASK], fx(FA4 ? gdn_fmul(f[r][j], a[r][j]) : f[r][j], rc[r][j] & RMASK));
-      }
-      continue;
-    }
     constexpr int MU = 4;
     for (unsigned i0 = threadIdx.x; i0 < nr4; i0 += (unsigned)MU * PB_THREADS) {
       pb_u32x4 rc[MU];

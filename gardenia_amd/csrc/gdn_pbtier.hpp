@@ -738,24 +738,6 @@ pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segof
   }
 }
 
-// V of a plan whose bins all start on multiples of 512 edges, in place: inside every block of 512 edges (128 quads of four
-// 16-bit rows) the 16-byte word l holds quad l and quad 64 + l (PbPlan::v_il; read by pb_accumulate_kernel's load_step).
-// A wave per block: every load of the wave has returned before its store issues.
-static __global__ void __launch_bounds__(GDN_BLOCK)
-pb_v_interleave_kernel(uint16_t *__restrict__ V, unsigned long long nblk) {
-  typedef unsigned pt_u32x2 __attribute__((ext_vector_type(2)));
-  typedef unsigned pt_u32x4 __attribute__((ext_vector_type(4)));
-  const unsigned lane = gdn_lane();
-  for (unsigned long long q = (unsigned long long)blockIdx.x * GDN_WAVES_PER_BLOCK + (threadIdx.x >> 6); q < nblk;
-       q += (unsigned long long)gridDim.x * GDN_WAVES_PER_BLOCK) {
-    pt_u32x2 *base = reinterpret_cast<pt_u32x2 *>(V + q * 512ull);
-    const pt_u32x2 lo = base[lane], hi = base[64u + lane];
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_wave_barrier();
-    reinterpret_cast<pt_u32x4 *>(base)[lane] = pt_u32x4{lo.x, lo.y, hi.x, hi.y};
-  }
-}
-
 // pt_radix: one stable pass over the records of every (bin) segment of ONE tier by bits [shift, shift + bits) of the record
 struct PtRadixArgs {
   const uint32_t *in;

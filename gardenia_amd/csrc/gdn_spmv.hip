@@ -35,6 +35,7 @@ struct gdn_spmv_plan {
     unsigned n = 0;
     DevBuf<uint32_t> ids, rec;
     DevBuf<float> val, Ax;
+    bool il = false;  // rec / Ax: whole 256-record blocks lane-interleaved (phase B form 2)
   } mid[PB_MAX_MID];
   bool pattern = false;  // PB layout of a 0/1 matrix: no Ax stream
   DevBuf<unsigned> mx;  // PB: [0] bits of max|Ax|, [1] bits of max|x| (per call), [2] rows to recompute (per call), [3] max row length
@@ -247,12 +248,16 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
     unsigned n_mid[PB_MAX_MID] = {};
+    // phase B's streams in lane-interleaved blocks (gdn_pb.hpp: PbPlan::v_il, PbMidArgs::form 2); GDN_PB_V_IL=0 / GDN_PB_REC_IL=0: plain
+    const char *vie = gdn_option("GDN_PB_V_IL"), *rie = gdn_option("GDN_PB_REC_IL");
+    const bool il_v = !(vie && vie[0] == '0') && !v_delta, il_streams = !(rie && rie[0] == '0');
     if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
       st = pb_pick_tiers(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
     if (st == GDN_OK)
       st = pb_build(csr, n_cols, lc, lb, p->pb, true, d_Ax, &p->Axp, compact, false, /*pad=*/32, /*log_group=*/5,
                     (p->n_hubs || n_mid[0]) ? cls.p : nullptr, 0, false, v_delta, nullptr, 0, false, false, PB_MAX_LOG_BIN,
                     &scratch);
+    if (st == GDN_OK && il_v) st = pb_v_interleave(p->pb);
     if (st == GDN_OK && p->n_hubs) {
       st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true, false,
                     nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
@@ -273,6 +278,12 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
         st = GDN_ERR_INVALID;
       }
       if (st == GDN_OK) st = pb_mid_finish(mt.layout, n_mid[t], mt.rec, p->pattern ? nullptr : &mt.Ax);
+      if (st == GDN_OK && il_streams && mt.layout.nbins) {
+        // the whole 256-record blocks of every bin's stream (records and factors) lane-interleaved: phase B form 2
+        hipLaunchKernelGGL(pb_stream_interleave_kernel, dim3(mt.layout.nbins), dim3(GDN_BLOCK), 0, 0, mt.rec.p,
+                           p->pattern ? nullptr : mt.Ax.p, mt.layout.bin_ptr.p);
+        mt.il = true;
+      }
       if (st == GDN_OK) st = mt.val.alloc((size_t)n_mid[t] + 4);
       if (st == GDN_OK) {
         mt.n = n_mid[t];
@@ -432,8 +443,9 @@ int gdn_spmv_dev(gdn_spmv_plan *plan, const float *d_Ax, const float *d_x, float
     mid.val[mid.n] = plan->mid[t].val.p;
     mid.A[mid.n] = plan->pattern ? nullptr : plan->mid[t].Ax.p;
     mid.zrec[mid.n] = plan->mid[t].n << PB_MID_ROW_BITS;
-    mid.form[mid.n++] = 0;
+    mid.form[mid.n++] = plan->mid[t].il ? 2 : 0;
   }
+  mid.v_il = pb.v_il ? 1 : 0;
   hipLaunchKernelGGL(spmv_scale_kernel, dim3(1), dim3(64), 0, s, plan->mx.p, plan->scale.p);
   if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 1], s));
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<SpmvOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, s,

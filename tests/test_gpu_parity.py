@@ -550,7 +550,8 @@ def test_pr_delta_coded_rows_are_bitwise_neutral(orc, monkeypatch, layout_env):
 
 @pytest.mark.parametrize("env", [{}, {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1"},
                                  {"GDN_PB_HUB_MIN_NNZ": "1000", "GDN_PB_HUB_MIN": "1", "GDN_PB_V8": "1"},
-                                 {"GDN_PB_COMPACT": "0"}, TIER_ENV])
+                                 {"GDN_PB_COMPACT": "0"}, TIER_ENV,
+                                 dict(TIER_ENV, GDN_PB_REC_IL="0", GDN_PB_V_IL="0")])  # (the last: plain, not lane-interleaved, streams)
 def test_spmv_pb_layout_variants(orc, monkeypatch, env):
     """SpMV on the propagation-blocked layout: compacted (default), with the hub tier forced on at this size (hub edges
     multiply x[hub] by their own Ax inside phase B), with delta-coded rows, and uncompacted -- all against the oracle,
@@ -570,7 +571,7 @@ def test_spmv_pb_layout_variants(orc, monkeypatch, env):
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sp = solvers.ResidentSpMV(G, Ax, layout=1)
-    if env is TIER_ENV:  # hubs + two mid tiers really are in use
+    if "GDN_PB_MID_CAP" in env:  # hubs + two mid tiers really are in use
         import ctypes as C
         from gardenia_amd import _cabi
         nh, nt, ne = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
