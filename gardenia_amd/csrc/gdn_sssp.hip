@@ -593,7 +593,28 @@ struct SsspSmallState {
   int max_dist;
   unsigned passes, buckets;
   unsigned long long relaxed_edges;  // out: out-degree sum of the NEAR lists the passes of this launch walked
+  // the bucket width the schedule works with (in / out): starts at the caller's delta and adapts at every bucket change --
+  // a bucket whose passes relaxed fewer than `light` edges was all latency, the next one is twice as wide; more than
+  // 8 x light: half (never below the caller's).  Distances do not depend on the widths (every bucket runs to its fixpoint).
+  long long delta_cur;
+  unsigned long long bucket_work;  // edges relaxed in the current bucket so far (in / out)
+  unsigned long long light;        // in: 0 = no adaptation (delta_cur stays)
+  unsigned light_run, adapt_after; // light buckets in a row so far (in / out); widening starts behind `adapt_after` of them: the
+                                   // handful of light buckets in front of an R-MAT search's heavy phases keep the caller's
+                                   // width (merged, they hand the dense sweeps a worse start: RMAT-24 2.9 -> 3.2 ms)
 };
+#define SSSP_DELTA_MAX (1ll << 24)
+__device__ __host__ inline long long sssp_adapt_delta(long long cur, long long floor_, unsigned long long work, unsigned long long light,
+                                                      unsigned &light_run, unsigned adapt_after) {
+  if (light == 0ull) return cur;
+  if (work < light) {
+    light_run++;
+    return (light_run > adapt_after && cur * 2 <= SSSP_DELTA_MAX) ? cur * 2 : cur;
+  }
+  light_run = 0u;
+  if (work > 8ull * light) return cur / 2 >= floor_ ? cur / 2 : floor_;
+  return cur;
+}
 
 // wave-aggregated slot reservation on an LDS counter (all lanes of the wave must call it; a lane per item serialises on
 // the one address: 34 K far entries cost 0.1 ms that way)
@@ -624,6 +645,11 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
   int pass = state->pass, status = 0;
   unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0;
   unsigned long long relaxed_edges = 0;
+  long long dlt = state->delta_cur;
+  unsigned long long bwork = state->bucket_work;
+  const unsigned long long light = state->light;
+  unsigned light_run = state->light_run;
+  const unsigned adapt_after = state->adapt_after;
   auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
   if (threadIdx.x == 0) {
     s_over = 0u;
@@ -636,6 +662,7 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
       ++pass;
       ++passes;
       relaxed_edges += near_edges;
+      bwork += near_edges;
       if (threadIdx.x == 0) {
         s_nn = 0u;
         s_nf = n_far;
@@ -724,7 +751,9 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
     // way; only when nothing moved does a second pass split at the bucket of that minimum (omp_base.cc:66-72 finds the
     // same bucket either way).
     vid_t *near_in = near_sel ? near1 : near0;
-    long long spec_lo = thr_hi, spec_hi = thr_hi + delta;
+    dlt = sssp_adapt_delta(dlt, (long long)delta, bwork, light, light_run, adapt_after);
+    bwork = 0ull;
+    long long spec_lo = thr_hi, spec_hi = thr_hi + dlt;
     for (;;) {
       vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
       if (threadIdx.x == 0) {
@@ -792,8 +821,9 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
         break;
       }
       thr_hi = spec_hi;  // that bucket was empty and everything kept lies behind it: nothing is stale against it
-      spec_lo = ((long long)mn / delta) * (long long)delta;
-      spec_hi = spec_lo + delta;
+      spec_lo = ((long long)mn / dlt) * dlt;  // (the caller's grid of buckets while the width is the caller's)
+      if (spec_lo < thr_hi) spec_lo = thr_hi;  // widths that changed on the way: never back into what has been settled
+      spec_hi = spec_lo + dlt;
     }
     if (n_near > max_v || near_edges > max_e) {
       status = 1;
@@ -815,6 +845,9 @@ sssp_small_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ c
     state->passes = passes;
     state->buckets = buckets;
     state->relaxed_edges = relaxed_edges;
+    state->delta_cur = dlt;
+    state->bucket_work = bwork;
+    state->light_run = light_run;
   }
 }
 
@@ -860,6 +893,11 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
   int pass = state->pass, status = 0;
   unsigned near_sel = state->near_sel, far_sel = state->far_sel, passes = 0, buckets = 0, ph = 0;
   unsigned long long relaxed_edges = 0;
+  long long dlt = state->delta_cur;
+  unsigned long long bwork = state->bucket_work;
+  const unsigned long long light = state->light;
+  unsigned light_run = state->light_run;
+  const unsigned adapt_after = state->adapt_after;
   int32_t maxd = 0;
   bool over = false;
   auto clamp = [](long long x) { return (int32_t)(x > GDN_DIST_INF ? GDN_DIST_INF : x); };
@@ -881,6 +919,7 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
       ++pass;
       ++passes;
       relaxed_edges += near_edges;
+      bwork += near_edges;
       const vid_t *near_in = near_sel ? near1 : near0;
       vid_t *near_out = near_sel ? near0 : near1;
       vid_t *far_cur = far_sel ? far1 : far0;
@@ -969,7 +1008,9 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
     }
     // one pass per bucket change wherever the bucket behind the old one is not empty (see sssp_small_kernel)
     vid_t *near_in = near_sel ? near1 : near0;
-    long long spec_lo = thr_hi, spec_hi = thr_hi + delta;
+    dlt = sssp_adapt_delta(dlt, (long long)delta, bwork, light, light_run, adapt_after);
+    bwork = 0ull;
+    long long spec_lo = thr_hi, spec_hi = thr_hi + dlt;
     for (;;) {
       vid_t *far_cur = far_sel ? far1 : far0, *far_nxt = far_sel ? far0 : far1;
       SsspCoopCnt *cur = begin_phase();
@@ -1023,8 +1064,9 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
         break;
       }
       thr_hi = spec_hi;  // that bucket was empty and everything kept lies behind it
-      spec_lo = ((long long)mn / delta) * (long long)delta;
-      spec_hi = spec_lo + delta;
+      spec_lo = ((long long)mn / dlt) * dlt;
+      if (spec_lo < thr_hi) spec_lo = thr_hi;
+      spec_hi = spec_lo + dlt;
     }
     if (n_near > max_v || near_edges > max_e) {
       status = 1;
@@ -1052,6 +1094,9 @@ sssp_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ co
     state->passes = passes;
     state->buckets = buckets;
     state->relaxed_edges = relaxed_edges;
+    state->delta_cur = dlt;
+    state->bucket_work = bwork;
+    state->light_run = light_run;
   }
 }
 
@@ -1839,6 +1884,21 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
     else coop_streak = 0;
   }
   if (p.coop_blocks == 0) coop_v = 0;
+  // Bucket width of the schedule (SsspSmallState::delta_cur): the caller's delta to begin with, doubled after a bucket whose
+  // passes relaxed fewer than `light` edges (such a bucket is all launch / barrier latency), halved after one of more than
+  // 8 x light, never below the caller's.  A lattice with U[1,255] weights: delta 16 as given 1.4 s and 79 K phases, 1024
+  // 0.2 s (profiles/r04_sssp_delta_sweep.txt); R-MAT does not care.  GDN_SSSP_ADAPT=0: the caller's width throughout.
+  long long delta_cur = delta;
+  unsigned long long bucket_work = 0;
+  unsigned light_run = 0, adapt_after = 4;
+  if (const char *e = gdn_option("GDN_SSSP_ADAPT_AFTER")) adapt_after = (unsigned)atoi(e);
+  unsigned long long light_small = 4096, light_coop = 1ull << 17, light_host = 1ull << 20;
+  if (const char *e = gdn_option("GDN_SSSP_ADAPT")) {
+    if (atoi(e) == 0) light_small = light_coop = light_host = 0;
+  }
+  if (const char *e = gdn_option("GDN_SSSP_LIGHT_SMALL")) light_small = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_option("GDN_SSSP_LIGHT_COOP")) light_coop = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_option("GDN_SSSP_LIGHT_HOST")) light_host = strtoull(e, nullptr, 10);
   for (;;) {
     if (n_near == 0 && n_far == 0) break;
     if (!pre_dense_done && (n_near > 0 || (small_v && n_far <= small_far))) {
@@ -1856,6 +1916,11 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         ss.pass = pass;
         ss.near_sel = near_in == p.near1.p ? 1u : 0u;
         ss.far_sel = far_cur == p.far1.p ? 1u : 0u;
+        ss.delta_cur = delta_cur;
+        ss.bucket_work = bucket_work;
+        ss.light = light_small;
+        ss.light_run = light_run;
+        ss.adapt_after = adapt_after;
         sssp_put(p.small.p, ss);
         hipLaunchKernelGGL(sssp_small_kernel, dim3(1), dim3(SSSP_SMALL_THREADS), 0, 0, g->rowptr, g->colidx, d_weight, d_dist,
                            p.stamp.p, p.in_far.p, p.near0.p, p.near1.p, p.far0.p, p.far1.p, cap, delta, small_v, small_e,
@@ -1876,6 +1941,9 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         thr_lo = ss.thr_lo;
         thr_hi = ss.thr_hi;
         pass = ss.pass;
+        delta_cur = ss.delta_cur;
+        bucket_work = ss.bucket_work;
+        light_run = ss.light_run;
         max_finite = ss.max_dist > max_finite ? ss.max_dist : max_finite;
         near_in = ss.near_sel ? p.near1.p : p.near0.p;
         near_out = ss.near_sel ? p.near0.p : p.near1.p;
@@ -1898,6 +1966,11 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       ss.pass = pass;
       ss.near_sel = near_in == p.near1.p ? 1u : 0u;
       ss.far_sel = far_cur == p.far1.p ? 1u : 0u;
+      ss.delta_cur = delta_cur;
+      ss.bucket_work = bucket_work;
+      ss.light = light_coop;
+      ss.light_run = light_run;
+      ss.adapt_after = adapt_after;
       SsspCoopCnt init[3];
       memset(init, 0, sizeof(init));
       for (int k = 0; k < 3; k++) init[k].min_far = GDN_DIST_INF;
@@ -1935,6 +2008,9 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       thr_lo = ss.thr_lo;
       thr_hi = ss.thr_hi;
       pass = ss.pass;
+      delta_cur = ss.delta_cur;
+      bucket_work = ss.bucket_work;
+      light_run = ss.light_run;
       max_finite = ss.max_dist > max_finite ? ss.max_dist : max_finite;
       near_in = ss.near_sel ? p.near1.p : p.near0.p;
       near_out = ss.near_sel ? p.near0.p : p.near1.p;
@@ -2087,6 +2163,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       ++pass;
       ++phases;
       relaxed_total += near_edges;
+      bucket_work += near_edges;
       h.near_count = 0;
       h.far_count = n_far;
       h.big_count = 0;
@@ -2161,8 +2238,11 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
     GDN_TRY(sssp_read(p, p.cnt.p, h));
     if (h.min_far == GDN_DIST_INF) break;  // only stale entries were left
     const int64_t old_hi = thr_hi;
-    thr_lo = ((int64_t)h.min_far / delta) * (int64_t)delta;
-    thr_hi = thr_lo + delta;
+    delta_cur = sssp_adapt_delta(delta_cur, (long long)delta, bucket_work, light_host, light_run, adapt_after);
+    bucket_work = 0;
+    thr_lo = ((int64_t)h.min_far / delta_cur) * (int64_t)delta_cur;
+    if (thr_lo < old_hi && old_hi < (int64_t)GDN_DIST_INF) thr_lo = old_hi;  // widths that changed: never back into what has been settled
+    thr_hi = thr_lo + delta_cur;
     hipLaunchKernelGGL(sssp_far_split_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
                        far_cur, n_far, d_dist,
                        clamp(old_hi), clamp(thr_hi), p.in_far.p, near_in, far_nxt, p.cnt.p, cap, g->rowptr);
