@@ -809,6 +809,13 @@ bc_maxdeg_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned long lon
   if (gdn_lane() == 0 && mx) atomicMax(out, mx);
 }
 
+// no record tiers in BC's layouts; only the form of V travels (PbPlan::v_il: lane-interleaved blocks of 512 edges)
+static inline PbMidArgs bc_mid_args(const PbPlan &pb) {
+  PbMidArgs mid = PbMidArgs();
+  mid.v_il = pb.v_il ? 1 : 0;
+  return mid;
+}
+
 static int bc_pb_sweep_fwd(gdn_bc_plan &p, int32_t level) {
   PbPlan &pb = p.fwd;
   const int32_t m = p.g->m;
@@ -825,7 +832,8 @@ static int bc_pb_sweep_fwd(gdn_bc_plan &p, int32_t level) {
   op.vec_ok = false;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<BcPcOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, 0, pb.m_local,
                      pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, pb.dst_bits.p,
-                     pb.bin_lo.p, op);
+                     pb.bin_lo.p, op, 0, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     bc_mid_args(pb));
   GDN_HIP(hipGetLastError());
   return GDN_OK;
 }
@@ -868,7 +876,8 @@ static int bc_pb_sweep_back(gdn_bc_plan &p, int32_t level, float *d_scores, bool
   op.vec_ok = false;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(pb_accumulate_kernel<BcBackOp>), dim3(pb.nbins), dim3(PB_THREADS), lds_b, 0, pb.m_local,
                      pb.log_bin, pb.bin_ptr.p, pb.bin_order.p, pb.V.p, pb.vals.p, pb.partial.p, pb.errflag.p, pb.dst_bits.p,
-                     pb.bin_lo.p, op);
+                     pb.bin_lo.p, op, 0, 0u, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     bc_mid_args(pb));
   GDN_HIP(hipGetLastError());
   *done = true;
   return GDN_OK;
@@ -907,6 +916,10 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     if ((st = pb_build(g, m, lc, lb, p->back, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
                        0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch)))
       break;
+    {  // V of both layouts in lane-interleaved blocks where the bins allow it (gdn_pb.hpp, PbPlan::v_il); GDN_PB_V_IL=0: plain
+      const char *vie = gdn_option("GDN_PB_V_IL");
+      if (!(vie && vie[0] == '0') && ((st = pb_v_interleave(p->fwd)) || (st = pb_v_interleave(p->back)))) break;
+    }
     const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     p->bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
     p->rowcap = (unsigned)(g->nnz / BC_BLOCK_ROW + 16);

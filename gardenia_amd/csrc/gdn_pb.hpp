@@ -248,6 +248,7 @@ struct PbTierSet {
     DevBuf<uint32_t> rec;     // bin-major records (source index << 14 | row), pad records = n_src << 14
     DevBuf<eoff_t> bin_ptr;   // nbins + 1 record offsets (multiples of 16; of 256 when interleaved)
     bool interleaved = false; // blocks of 256 records stored lane-interleaved (pt_interleave_kernel): phase B form 2
+    DevBuf<float> A;          // PbTieredArgs::edge_vals: the records' values, in record order (pad records: 0)
   } t[PB_MAX_REC_TIERS];
   bool first_is_hub = false;  // t[0] is the hub tier (<= 2^15 sources), else the mid tiers start at t[0]
 };
@@ -270,6 +271,10 @@ struct PbTieredArgs {
   bool alloc_vals = true;
   bool interleave = false;  // mid-tier record streams in lane-interleaved blocks of 256 (PbTierSet::Tier::interleaved)
   bool v_interleave = false;  // V in lane-interleaved blocks of 512 edges when every bin starts on a multiple of 512 (PbPlan::v_il)
+  // one 32-bit value per edge in CSR order (SpMV's Ax, nullable) and where the main layout's go: (*main_vals)[k] belongs to
+  // the edge whose source slot is U[k] (chunk-major tile order, 0 in the padding); the tiers' go to PbTierSet::Tier::A
+  const float *edge_vals = nullptr;
+  DevBuf<float> *main_vals = nullptr;
 };
 
 // GDN_OK; 1 = shape outside the builder's limits (nothing built: use pb_build); 2 = a column occurs whose src_count is 0

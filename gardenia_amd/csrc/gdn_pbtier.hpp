@@ -527,15 +527,21 @@ __device__ __forceinline__ unsigned pt_block_excl_scan(unsigned v, unsigned *scr
 }
 struct PtStage {
   uint32_t *stage;           // PT_STEP items in digit order
+  uint32_t *vstage;          // (value-carrying partitions: a second 32-bit word per item, e.g. SpMV's Ax) or nullptr
   unsigned short *dig;       // their digits
   unsigned *wc;              // PT_WAVES x nd: per wave and digit, count -> exclusive prefix over the waves
   unsigned *start, *tot;     // nd: first position of a digit in the staged order, its count in this step
   unsigned long long *goff;  // nd: where the digit's next item goes in `out`
   unsigned *scr;             // PT_WAVES + 1 (pt_block_excl_scan)
 };
-__device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned nd) {
+__device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned nd, bool val = false) {
   PtStage s;
   s.stage = reinterpret_cast<uint32_t *>(lds);
+  s.vstage = nullptr;
+  if (val) {
+    s.vstage = reinterpret_cast<uint32_t *>(lds + (size_t)PT_STEP * 4);
+    lds += (size_t)PT_STEP * 4;
+  }
   s.goff = reinterpret_cast<unsigned long long *>(lds + (size_t)PT_STEP * 4);
   s.start = reinterpret_cast<unsigned *>(s.goff + nd);
   s.tot = s.start + nd;
@@ -544,8 +550,8 @@ __device__ __forceinline__ PtStage pt_stage_carve(unsigned char *lds, unsigned n
   s.dig = reinterpret_cast<unsigned short *>(s.wc + (size_t)PT_WAVES * nd);
   return s;
 }
-static inline size_t pt_stage_bytes(unsigned nd) {
-  return (size_t)PT_STEP * 4 + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_STEP * 2 + (size_t)PT_WAVES * nd * 4 + 64;
+static inline size_t pt_stage_bytes(unsigned nd, bool val = false) {
+  return (size_t)PT_STEP * (val ? 8 : 4) + (size_t)nd * 16 + (PT_WAVES + 2) * 4 + (size_t)PT_STEP * 2 + (size_t)PT_WAVES * nd * 4 + 64;
 }
 // Walks items [0, n) in steps of PT_STEP.  load(i, item, digit) for i < n.  The caller has set st.goff[d] (behind a
 // barrier) and zeroed st.wc.  Every thread of the workgroup must call.
@@ -556,22 +562,25 @@ static inline size_t pt_stage_bytes(unsigned nd) {
 // documents it, and no result depends on the order inside a tile or a record stream).  STABLE = true (GDN_PT_STABLE=1):
 // ballot matching, the leader lane adds the group's count -- stable by construction, ~10 VALU instructions per digit bit
 // and item, and one LDS round trip per item in sequence (RMAT-27: pt_split 23.8 ms, pt_radix 31 ms).
-template <bool STABLE, class Load>
+// VAL: every item carries a second 32-bit word (load(i, item, digit, value)), written to vout at the item's position.
+template <bool STABLE, bool VAL, class Load>
 __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, int dbits, uint32_t *__restrict__ out,
-                                             const PtStage &st, Load load) {
+                                             uint32_t *__restrict__ vout, const PtStage &st, Load load) {
   const unsigned w = threadIdx.x >> 6, lane = gdn_lane();
   const unsigned long long lt = gdn_lanemask_lt();
   unsigned *wcw = st.wc + (size_t)w * nd;
   for (unsigned long long base = 0; base < n; base += PT_STEP) {
     const unsigned cnt = (unsigned)(n - base < (unsigned long long)PT_STEP ? n - base : (unsigned long long)PT_STEP);
-    uint32_t it[PT_IPT];
+    uint32_t it[PT_IPT], vl[VAL ? PT_IPT : 1];
     unsigned short dg[PT_IPT], rk[PT_IPT];
 #pragma unroll
     for (int j = 0; j < PT_IPT; j++) {
       const unsigned i = w * (PT_IPT * 64u) + (unsigned)j * 64u + lane;  // a wave owns 1024 consecutive items of the step
       it[j] = 0u;
       unsigned d = 0u;
-      if (i < cnt) load(base + i, it[j], d);
+      uint32_t v = 0u;
+      if (i < cnt) load(base + i, it[j], d, v);
+      if constexpr (VAL) vl[j] = v;
       dg[j] = (unsigned short)d;
     }
     if constexpr (STABLE) {
@@ -628,6 +637,7 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
         const unsigned d = dg[j];
         const unsigned pos = st.start[d] + wcw[d] + rk[j];
         st.stage[pos] = it[j];
+        if constexpr (VAL) st.vstage[pos] = vl[j];
         st.dig[pos] = (unsigned short)d;
       }
     }
@@ -638,6 +648,7 @@ __device__ __forceinline__ void pt_partition(unsigned long long n, unsigned nd, 
       if (pos < cnt) {
         const unsigned d = st.dig[pos];
         out[st.goff[d] + (pos - st.start[d])] = st.stage[pos];
+        if constexpr (VAL) vout[st.goff[d] + (pos - st.start[d])] = st.vstage[pos];
       }
     }
     __syncthreads();
@@ -660,15 +671,17 @@ struct PtSplitArgs {
   eoff_t tier_base[PB_MAX_REC_TIERS];     // where tier t's records start in X
   const uint32_t *order;                  // bins, largest first
   uint32_t *X;
+  const uint32_t *EV;                     // VAL: one 32-bit word per edge in CSR order (SpMV's Ax) ...
+  uint32_t *XV;                           // ... moved like the items, into XV
   unsigned d1;
   int ntiers, log_chunk, dbits;
 };
-template <bool STABLE>
+template <bool STABLE, bool VAL>
 static __global__ void __launch_bounds__(PT_PTHREADS, 4)
 pt_split_kernel(PtSplitArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = a.d1 + (unsigned)a.ntiers;
-  const PtStage st = pt_stage_carve(s_raw, nd);
+  const PtStage st = pt_stage_carve(s_raw, nd, VAL);
   const unsigned b = a.order[blockIdx.x];
   for (unsigned d = threadIdx.x; d < nd; d += PT_PTHREADS) {
     st.goff[d] = d < a.d1 ? a.segoff[(size_t)b * a.d1 + d] : a.tier_base[d - a.d1] + a.tier_ptr[d - a.d1][b];
@@ -682,9 +695,11 @@ pt_split_kernel(PtSplitArgs a) {
   const unsigned slot_mask = (1u << a.log_chunk) - 1u;
   const int lc = a.log_chunk;
   const unsigned d1 = a.d1;
-  pt_partition<STABLE>(E1 - E0, nd, a.dbits, a.X, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+  const uint32_t *EV = VAL ? a.EV + E0 : nullptr;
+  pt_partition<STABLE, VAL>(E1 - E0, nd, a.dbits, a.X, a.XV, st, [&](unsigned long long i, uint32_t &item, unsigned &d, uint32_t &val) {
     const uint32_t c = __builtin_nontemporal_load(S + i);
     const unsigned row = __builtin_nontemporal_load(R + i);
+    if constexpr (VAL) val = __builtin_nontemporal_load(EV + i);
     const unsigned k = c >> PT_CLASS_SHIFT;
     if (k == 0u) {
       const unsigned chunk = c >> lc;
@@ -701,7 +716,9 @@ pt_split_kernel(PtSplitArgs a) {
 static __global__ void __launch_bounds__(GDN_BLOCK)
 pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segoff, unsigned d1, unsigned nbins,
                 unsigned nchunks, const eoff_t *__restrict__ pu, const eoff_t *__restrict__ pv, uint16_t *__restrict__ U,
-                uint16_t *__restrict__ V) {
+                uint16_t *__restrict__ V,
+                // nullable: the items' value words (pt_split_kernel<., true>) and where they go -- next to U, chunk-major
+                const uint32_t *__restrict__ XV = nullptr, uint32_t *__restrict__ AU = nullptr) {
   const unsigned long long seg = ((unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
   if (seg >= (unsigned long long)d1 * nbins) return;
   const unsigned b = (unsigned)(seg / d1), d = (unsigned)(seg % d1), lane = gdn_lane();
@@ -722,6 +739,7 @@ pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segof
     const eoff_t i = i0 + lane;
     const bool valid = i < s1;
     const uint32_t item = valid ? __builtin_nontemporal_load(X + i) : 0u;
+    const uint32_t val = (valid && XV) ? __builtin_nontemporal_load(XV + i) : 0u;
     const unsigned low = item & ((1u << PT_LOW_BITS) - 1u);
     unsigned rank = 0u;
 #pragma unroll
@@ -734,6 +752,7 @@ pt_tiles_kernel(const uint32_t *__restrict__ X, const eoff_t *__restrict__ segof
     if (valid) {
       U[ou + rank] = (uint16_t)(item >> 17);
       V[ov + rank] = (uint16_t)((item >> PT_LOW_BITS) & ((1u << PB_MID_ROW_BITS) - 1u));
+      if (AU) AU[ou + rank] = val;
     }
   }
 }
@@ -748,13 +767,15 @@ struct PtRadixArgs {
   int tier, shift, bits;
   int last;                   // final pass: pad records behind the segment
   uint32_t zrec;
+  const uint32_t *vin;        // VAL: the records' value words (same offsets as the records)
+  uint32_t *vout;
 };
-template <bool STABLE>
+template <bool STABLE, bool VAL>
 static __global__ void __launch_bounds__(PT_PTHREADS, 4)
 pt_radix_kernel(PtRadixArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
   const unsigned nd = 1u << a.bits;
-  const PtStage st = pt_stage_carve(s_raw, nd);
+  const PtStage st = pt_stage_carve(s_raw, nd, VAL);
   const unsigned b = a.order[blockIdx.x];
   const eoff_t p0 = a.ptr[b];
   const unsigned n = a.tier_cnt[(size_t)b * 8 + a.tier];
@@ -789,13 +810,18 @@ pt_radix_kernel(PtRadixArgs a) {
   }
   __syncthreads();
   const int shift = a.shift;
-  pt_partition<STABLE>(n, nd, a.bits, a.out, st, [&](unsigned long long i, uint32_t &item, unsigned &d) {
+  const uint32_t *vin = VAL ? a.vin + p0 : nullptr;
+  pt_partition<STABLE, VAL>(n, nd, a.bits, a.out, a.vout, st, [&](unsigned long long i, uint32_t &item, unsigned &d, uint32_t &val) {
     item = in[i];
+    if constexpr (VAL) val = vin[i];
     d = (item >> shift) & mask;
   });
   if (a.last) {
     const unsigned npad = (unsigned)(a.ptr[b + 1] - p0);  // the stream's padded length (pt_tier_sizes_kernel)
-    for (unsigned i = n + threadIdx.x; i < npad; i += PT_PTHREADS) a.out[p0 + i] = a.zrec;
+    for (unsigned i = n + threadIdx.x; i < npad; i += PT_PTHREADS) {
+      a.out[p0 + i] = a.zrec;
+      if constexpr (VAL) a.vout[p0 + i] = 0u;  // the pad records' factor: 0.0f
+    }
   }
 }
 
@@ -1139,12 +1165,23 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     tier_base[t] = xlen;
     xlen += tier_pad[t];
   }
+  const bool with_vals = a.edge_vals != nullptr;
+  GDN_REQUIRE(!with_vals || a.main_vals, "layout build: edge values without a place for the main layout's");
   PtArena A3;
-  GDN_TRY(A3.init(pt_pad256((size_t)xlen * 4) + pt_pad256((size_t)(xlen - n0) * 4) + 4096, 4));
+  GDN_TRY(A3.init((pt_pad256((size_t)xlen * 4) + pt_pad256((size_t)(xlen - n0) * 4)) * (with_vals ? 2 : 1) + 4096, 4));
   uint32_t *X = A3.get<uint32_t>(xlen);
   uint32_t *TMP = A3.get<uint32_t>(xlen - n0);  // second buffer of the tiers' radix passes (laid out like X's tier part)
+  uint32_t *XV = with_vals ? A3.get<uint32_t>(xlen) : nullptr;         // the items' value words, laid out like X
+  uint32_t *TMPV = with_vals ? A3.get<uint32_t>(xlen - n0) : nullptr;  //   and like TMP
   PT_CHECK_PTR(X);
   PT_CHECK_PTR(TMP);
+  if (with_vals) {
+    PT_CHECK_PTR(XV);
+    PT_CHECK_PTR(TMPV);
+    GDN_TRY(a.main_vals->alloc(n_pad + grp));
+    GDN_HIP(hipMemsetAsync(a.main_vals->p, 0, (n_pad + grp) * sizeof(float), 0));
+    for (int t = 0; t < ntiers; t++) GDN_TRY(ts.t[t].A.alloc(tier_pad[t] + 16));
+  }
   GDN_TRY(p.U.alloc(n_pad + grp));
   GDN_TRY(p.V.alloc(n_pad + grp));
   GDN_TRY(p.G.alloc((n_pad >> a.log_group) + 1));
@@ -1175,12 +1212,15 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     }
     sp.order = order;
     sp.X = X;
+    sp.EV = reinterpret_cast<const uint32_t *>(a.edge_vals);
+    sp.XV = XV;
     sp.d1 = d1;
     sp.ntiers = ntiers;
     sp.log_chunk = lc;
     sp.dbits = dbits;
-    const size_t lds = pt_stage_bytes(nd_split);
-    auto *const kern = stable ? &pt_split_kernel<true> : &pt_split_kernel<false>;
+    const size_t lds = pt_stage_bytes(nd_split, with_vals);
+    auto *const kern = with_vals ? (stable ? &pt_split_kernel<true, true> : &pt_split_kernel<false, true>)
+                                 : (stable ? &pt_split_kernel<true, false> : &pt_split_kernel<false, false>);
     GDN_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (n) hipLaunchKernelGGL(kern, dim3(nbins), dim3(PT_PTHREADS), lds, 0, sp);
     GDN_HIP(hipGetLastError());
@@ -1188,7 +1228,8 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   phase("pt_split");
   if (n0) {
     const unsigned long long nseg = (unsigned long long)d1 * nbins;
-    hipLaunchKernelGGL(pt_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, X, segoff, d1, nbins, nchunks, pu, pv, p.U.p, p.V.p);
+    hipLaunchKernelGGL(pt_tiles_kernel, dim3(gdn_nblocks(nseg * 64)), dim3(GDN_BLOCK), 0, 0, X, segoff, d1, nbins, nchunks, pu, pv, p.U.p, p.V.p,
+                       (const uint32_t *)XV, with_vals ? reinterpret_cast<uint32_t *>(a.main_vals->p) : nullptr);
     GDN_HIP(hipGetLastError());
   }
   p.v_il = false;
@@ -1203,14 +1244,16 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   }
   phase("pt_tiles");
   // record tiers: (row, source) -> (source, row) inside every bin
-  auto *const kern_r = stable ? &pt_radix_kernel<true> : &pt_radix_kernel<false>;
-  if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)kern_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS)));
+  auto *const kern_r = with_vals ? (stable ? &pt_radix_kernel<true, true> : &pt_radix_kernel<false, true>)
+                                 : (stable ? &pt_radix_kernel<true, false> : &pt_radix_kernel<false, false>);
+  if (ntiers) GDN_HIP(hipFuncSetAttribute((const void *)kern_r, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pt_stage_bytes(PT_MAX_DIGITS, with_vals)));
   for (int t = 0; t < ntiers; t++) {
     int nbits = 1;
     while ((1u << nbits) < ts.t[t].n_src) nbits++;
     const int passes = nbits > 10 ? 2 : 1;
     const int b1 = passes == 2 ? (nbits + 1) / 2 : nbits;
     uint32_t *tmp = TMP + (tier_base[t] - n0);
+    uint32_t *tmpv = with_vals ? TMPV + (tier_base[t] - n0) : nullptr;
     PtRadixArgs ra;
     ra.ptr = ts.t[t].bin_ptr.p;
     ra.tier_cnt = tier_cnt;
@@ -1220,16 +1263,21 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
     for (int ps = 0; ps < passes; ps++) {
       ra.in = ps == 0 ? X + tier_base[t] : tmp;
       ra.out = ps == passes - 1 ? ts.t[t].rec.p : tmp;
+      ra.vin = with_vals ? (ps == 0 ? XV + tier_base[t] : tmpv) : nullptr;
+      ra.vout = with_vals ? (ps == passes - 1 ? reinterpret_cast<uint32_t *>(ts.t[t].A.p) : tmpv) : nullptr;
       ra.shift = PB_MID_ROW_BITS + (ps == 0 ? 0 : b1);
       ra.bits = ps == 0 ? b1 : nbits - b1;
       ra.last = ps == passes - 1 ? 1 : 0;
-      const size_t lds = pt_stage_bytes(1u << ra.bits);
+      const size_t lds = pt_stage_bytes(1u << ra.bits, with_vals);
       hipLaunchKernelGGL(kern_r, dim3(nbins), dim3(PT_PTHREADS), lds, 0, ra);
     }
     if (ts.t[t].interleaved && tier_pad[t]) {
       const unsigned long long nblk = (unsigned long long)tier_pad[t] >> 8;  // every stream is a whole number of blocks
       const unsigned long long wb = (nblk + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK;
       hipLaunchKernelGGL(pt_interleave_kernel, dim3((unsigned)(wb > 65536ull ? 65536ull : wb)), dim3(GDN_BLOCK), 0, 0, ts.t[t].rec.p, nblk);
+      if (with_vals)  // the values in the same interleaved order
+        hipLaunchKernelGGL(pt_interleave_kernel, dim3((unsigned)(wb > 65536ull ? 65536ull : wb)), dim3(GDN_BLOCK), 0, 0,
+                           reinterpret_cast<uint32_t *>(ts.t[t].A.p), nblk);
     }
     GDN_HIP(hipGetLastError());
   }

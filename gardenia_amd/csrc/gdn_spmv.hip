@@ -251,14 +251,77 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     // phase B's streams in lane-interleaved blocks (gdn_pb.hpp: PbPlan::v_il, PbMidArgs::form 2); GDN_PB_V_IL=0 / GDN_PB_REC_IL=0: plain
     const char *vie = gdn_option("GDN_PB_V_IL"), *rie = gdn_option("GDN_PB_REC_IL");
     const bool il_v = !(vie && vie[0] == '0') && !v_delta, il_streams = !(rie && rie[0] == '0');
-    if (compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0'))
+    const bool want_tiers = compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0');
+    // Round 4: the main layout, the record tiers and the values' places in both from ONE gather pass and LDS-staged splits
+    // that carry Ax along (pb_build_tiered_run with edge_vals, gdn_pbtier.hpp) instead of one sort of 8-byte keys per layout
+    // (pb_build + pb_mid_finish: RMAT-25 plan 0.23 s).  GDN_PB_BUILDER=old, delta-coded rows and uncompacted layouts keep the
+    // old builder, and so does a shape outside the new one's limits (rc 1).
+    bool built = false;
+    {
+      const char *be = gdn_option("GDN_PB_BUILDER");
+      if (!(be && be[0] == 'o') && compact && !v_delta && lb <= PB_MID_ROW_BITS) {
+        PbTieredArgs ta;
+        PbTierSet ts;
+        ta.rowptr = csr->rowptr;
+        ta.colidx = csr->colidx;
+        ta.m_raw = n_cols;
+        ta.m_rows = csr->m;
+        ta.m_global = n_cols;
+        ta.nnz = csr->nnz;
+        ta.src_count = nullptr;  // (column counts are not known here: exact marks + sampled degrees)
+        ta.log_chunk = lc;
+        ta.log_bin = lb;
+        ta.pad = 32;
+        ta.log_group = 5;
+        ta.tiers = want_tiers;
+        ta.max_mid = max_mid;
+        ta.min16 = 0;  // the default floor of a mid tier (PB_MID_MIN_PER_BIN16), as pb_pick_tiers below
+        ta.interleave = il_streams;
+        ta.v_interleave = il_v;
+        ta.edge_vals = p->pattern ? nullptr : d_Ax;
+        ta.main_vals = &p->Axp;
+        const int rc = pb_build_tiered_run(ta, p->pb, ts);
+        if (rc < 0) st = rc;
+        else if (rc == GDN_OK) {
+          built = true;
+          int k = 0;
+          if (ts.n > 0 && ts.first_is_hub) {
+            p->n_hubs = ts.t[0].n_src;
+            p->hub_ids.take(ts.t[0].ids);
+            p->hub_rec.take(ts.t[0].rec);
+            if (!p->pattern) p->hub_Ax.take(ts.t[0].A);
+            p->hub.bin_ptr.take(ts.t[0].bin_ptr);
+            p->hub.nnz = ts.t[0].nnz;
+            p->hub.nbins = p->pb.nbins;
+            p->hub.nchunks = 1;
+            st = p->hub_val.alloc(PB_HUB_SLOTS + 3);
+            p->has_hub = true;
+            k = 1;
+          }
+          for (int t = k; t < ts.n && st == GDN_OK; t++) {
+            gdn_spmv_plan::MidTier &mt = p->mid[t - k];
+            mt.n = ts.t[t].n_src;
+            mt.ids.take(ts.t[t].ids);
+            mt.rec.take(ts.t[t].rec);
+            if (!p->pattern) mt.Ax.take(ts.t[t].A);
+            mt.layout.bin_ptr.take(ts.t[t].bin_ptr);
+            mt.layout.nnz = ts.t[t].nnz;
+            mt.layout.nbins = p->pb.nbins;
+            mt.il = ts.t[t].interleaved;
+            st = mt.val.alloc((size_t)mt.n + 4);
+            p->n_mid_tiers = t - k + 1;
+          }
+        }
+      }
+    }
+    if (!built && st == GDN_OK && want_tiers)
       st = pb_pick_tiers(csr, n_cols, lb, cls, p->hub_ids, &p->n_hubs, max_mid, mid_ids, n_mid);
-    if (st == GDN_OK)
+    if (!built && st == GDN_OK)
       st = pb_build(csr, n_cols, lc, lb, p->pb, true, d_Ax, &p->Axp, compact, false, /*pad=*/32, /*log_group=*/5,
                     (p->n_hubs || n_mid[0]) ? cls.p : nullptr, 0, false, v_delta, nullptr, 0, false, false, PB_MAX_LOG_BIN,
                     &scratch);
-    if (st == GDN_OK && il_v) st = pb_v_interleave(p->pb);
-    if (st == GDN_OK && p->n_hubs) {
+    if (!built && st == GDN_OK && il_v) st = pb_v_interleave(p->pb);
+    if (!built && st == GDN_OK && p->n_hubs) {
       st = pb_build(csr, n_cols, PB_HUB_LOG, lb, p->hub, false, d_Ax, &p->hub_Ax, true, false, 16, 4, cls.p, 1, true, false,
                     nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
       if (st == GDN_OK && (p->hub.nchunks != 1 || p->hub.nbins != p->pb.nbins)) {
@@ -269,7 +332,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
       if (st == GDN_OK) st = pb_mid_finish(p->hub, p->n_hubs, p->hub_rec, &p->hub_Ax);
       if (st == GDN_OK) p->has_hub = true;
     }
-    for (int t = 0; t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
+    for (int t = 0; !built && t < PB_MAX_MID && st == GDN_OK && n_mid[t]; t++) {
       gdn_spmv_plan::MidTier &mt = p->mid[t];
       st = pb_build(csr, n_cols, 15, lb, mt.layout, false, d_Ax, &mt.Ax, true, false, 16, 4, cls.p, 2 + t, true, false, nullptr, 0,
                     false, false, PB_MAX_LOG_BIN, &scratch);
