@@ -1018,6 +1018,10 @@ bfs_btd_bin_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsBin
   }
 }
 
+// (round 4, measured and dropped: four CONSECUTIVE ids per lane -- one 16-byte load per item, the item's ids matched bin by bin
+// with one reservation per distinct bin, 16-byte stores: 3.17 ms against 2.07 for the level of RMAT-27's slow source.  A hub
+// row of 4 000 ids over 2^27 vertices puts 256 consecutive ids into ~16 bins, and the rounds -- one reservation each --
+// run one after the other where the four steps above have theirs in flight together; profiles/sessions/r04_33.sh)
 __global__ void __launch_bounds__(BFS_BTD_THREADS)
 bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigned *__restrict__ overflow, unsigned cap_each, int logb,
                      int32_t m, unsigned nwords_pad, unsigned *__restrict__ visited, unsigned *__restrict__ next_front,
@@ -1034,17 +1038,28 @@ bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigne
     unsigned n = cur[slot * 32];
     n = n < cap_each ? n : cap_each;
     const vid_t *__restrict__ src = buf + slot * cap_each;
-    constexpr int UNR = 4;
-    for (unsigned i0 = threadIdx.x; i0 < n; i0 += UNR * BFS_BTD_THREADS) {
-      vid_t id[UNR];
+    // four ids per lane and load (the order inside a list means nothing; lists start on 16-byte boundaries: cap_each is a
+    // multiple of 4), two loads in flight: a quarter of the vector-memory instructions of one id per lane
+    typedef int bfs_i32x4 __attribute__((ext_vector_type(4)));
+    const bfs_i32x4 *__restrict__ src4 = reinterpret_cast<const bfs_i32x4 *>(src);
+    const unsigned n4 = n >> 2;
+    constexpr int UNR = 2;
+    for (unsigned i0 = threadIdx.x; i0 < n4; i0 += UNR * BFS_BTD_THREADS) {
+      bfs_i32x4 id[UNR];
 #pragma unroll
       for (int r = 0; r < UNR; r++) {
         const unsigned i = i0 + (unsigned)r * BFS_BTD_THREADS;
-        id[r] = i < n ? __builtin_nontemporal_load(src + i) : -1;
+        id[r] = i < n4 ? __builtin_nontemporal_load(src4 + i) : bfs_i32x4{-1, -1, -1, -1};
       }
 #pragma unroll
       for (int r = 0; r < UNR; r++)
-        if (id[r] >= 0) atomicOr(&s_bits[((unsigned)id[r] & idmask) >> 5], 1u << ((unsigned)id[r] & 31u));
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (id[r][j] >= 0) atomicOr(&s_bits[((unsigned)id[r][j] & idmask) >> 5], 1u << ((unsigned)id[r][j] & 31u));
+    }
+    for (unsigned i = (n4 << 2) + threadIdx.x; i < n; i += BFS_BTD_THREADS) {  // the last n % 4 ids
+      const vid_t id1 = src[i];
+      atomicOr(&s_bits[((unsigned)id1 & idmask) >> 5], 1u << ((unsigned)id1 & 31u));
     }
   }
   __syncthreads();
