@@ -118,7 +118,10 @@ struct SsspVis {
 #define SSSP_RELAX_GRID 2048u  // 8 workgroups per CU: every wave slot taken, and at most 2048 closing reservations per list
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ near_in, unsigned n,
-                  int32_t thr_lo, ExpBigList big, SsspVis vis) {
+                  int32_t thr_lo, ExpBigList big, SsspVis vis,
+                  // nullable: the out-degree sum of the rows this pass expands is added here (the list came from a conversion
+                  // that did not sum it: the pass reads the row offsets anyway, the conversion paid two gathers per row)
+                  unsigned long long *list_edges = nullptr) {
   __shared__ unsigned s_scan[GDN_WAVES_PER_BLOCK][64];
   __shared__ vid_t s_stage[2][GDN_WAVES_PER_BLOCK][GDN_WL_STAGE];
   vis.near_st.strip = s_stage[0][threadIdx.x >> 6];
@@ -128,6 +131,7 @@ sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ n
   __shared__ unsigned s_tmp[GDN_WAVES_PER_BLOCK + 1];
   __shared__ unsigned long long s_tmp64[GDN_WAVES_PER_BLOCK];
   vis.near_edges = 0;
+  unsigned long long in_edges = 0;
   // persistent grid (<= SSSP_RELAX_GRID workgroups): the strips fill across the batches of a workgroup
   for (unsigned i0 = blockIdx.x * GDN_BLOCK; i0 < n; i0 += gridDim.x * GDN_BLOCK) {  // block-uniform trip count
     const unsigned i = i0 + threadIdx.x;
@@ -141,11 +145,16 @@ sssp_relax_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ n
       if (vis.du >= thr_lo) {
         b = rowptr[v];
         e = rowptr[v + 1];
+        in_edges += e - b;
       }
     }
     gdn_expand_wave(b, e, v, big, vis, s_scan[threadIdx.x >> 6]);
   }
   vis.finish(s_tmp, s_tmp64);
+  if (list_edges) {  // (uniform) one add per workgroup
+    __syncthreads();
+    gdn_block_add_u64(in_edges, list_edges, s_tmp64);
+  }
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -1132,7 +1141,7 @@ sssp_bitmap_to_queue(const unsigned *__restrict__ bits, unsigned nwords, int32_t
       if (v < (unsigned)m) {
         if (pos < cap) q[pos] = (vid_t)v;
         else cnt->overflow = 1u;
-        deg += rowptr[v + 1] - rowptr[v];
+        if (rowptr) deg += rowptr[v + 1] - rowptr[v];
       }
       pos++;
     }
@@ -1888,6 +1897,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   // passes relaxed fewer than `light` edges (such a bucket is all launch / barrier latency), halved after one of more than
   // 8 x light, never below the caller's.  A lattice with U[1,255] weights: delta 16 as given 1.4 s and 79 K phases, 1024
   // 0.2 s (profiles/r04_sssp_delta_sweep.txt); R-MAT does not care.  GDN_SSSP_ADAPT=0: the caller's width throughout.
+  bool edges_pending = false;  // near_edges of the current list is not known yet (0): the next host pass sums it
   long long delta_cur = delta;
   unsigned long long bucket_work = 0;
   unsigned light_run = 0, adapt_after = 4;
@@ -2140,13 +2150,22 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
           h.relaxed = imp_edges;
           if (trace) fprintf(stderr, "[sssp] %7.1f us worklist tail from the list of %u (%llu edges)\n", lap(), n_q, imp_edges);
         } else {
+          // a long list: its out-degree sum (two gathers per row: most of this conversion's time) is left to the first tail
+          // pass, which reads the row offsets anyway (edges_pending); nothing below decides anything on it for such a list
+          const bool lazy_edges = improved > 65536ull;
           memset(&h, 0, sizeof(h));
           h.min_far = GDN_DIST_INF;
           sssp_put(p.cnt.p, h);
           hipLaunchKernelGGL(sssp_bitmap_to_queue, dim3(SSSP_B2Q_BLOCKS), dim3(GDN_BLOCK), 0, 0, p.improved.p,
-                             p.nwords, m, near_in, p.cnt.p, cap, g->rowptr);
+                             p.nwords, m, near_in, p.cnt.p, cap, lazy_edges ? (const eoff_t *)nullptr : g->rowptr);
           GDN_TRY(sssp_read(p, p.cnt.p, h));
-          if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> queue of %u (%llu edges)\n", lap(), h.near_count, h.relaxed);
+          edges_pending = lazy_edges && h.near_count > 65536u;
+          if (lazy_edges && !edges_pending) {  // (cannot happen: the list holds exactly the improved rows)
+            gdn_set_error("gdn_sssp: the improved rows and their list disagree (internal error)");
+            return GDN_ERR_INVALID;
+          }
+          if (trace) fprintf(stderr, "[sssp] %7.1f us improved rows -> queue of %u (%llu edges%s)\n", lap(), h.near_count, h.relaxed,
+                             edges_pending ? ": summed by the first pass" : "");
         }
         n_near = h.near_count;
         n_far = 0;
@@ -2171,6 +2190,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       h.min_far = GDN_DIST_INF;
       h.max_dist = 0;
       h.relaxed = 0;
+      h.improved_edges = 0;
       sssp_put(p.cnt.p, h);
       SsspVis vis;
       vis.rowptr = g->rowptr;
@@ -2198,7 +2218,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       if (const char *e = gdn_option("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
       hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near) < SSSP_RELAX_GRID ? gdn_nblocks(n_near) : SSSP_RELAX_GRID),
                          dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
-                         n_near, clamp(thr_lo), big, vis);
+                         n_near, clamp(thr_lo), big, vis, edges_pending ? &p.cnt.p->improved_edges : (unsigned long long *)nullptr);
       hipLaunchKernelGGL(sssp_relax_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
       GDN_TRY(sssp_read(p, p.cnt.p, h));
       if (h.overflow) {
@@ -2210,6 +2230,10 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
                 (long long)thr_lo, (long long)thr_hi, n_near, near_edges, h.near_count, h.relaxed, h.far_count, h.big_count);
       max_finite = h.max_dist > max_finite ? h.max_dist : max_finite;
       light_streak++;
+      if (edges_pending) {  // the out-edges of the list this pass walked (see the conversion behind the sweeps)
+        relaxed_total += h.improved_edges;
+        edges_pending = false;
+      }
       if (pre_dense) {  // no lists were built: the sweeps take over from the distances
         pre_dense_done = true;
         n_near = 1;  // (placeholder: the dense branch does not read the list)
