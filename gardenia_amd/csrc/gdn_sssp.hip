@@ -172,31 +172,7 @@ sssp_relax_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, SsspVis
   vis.finish(s_tmp, s_tmp64);
 }
 
-// smallest distance parked in FAR that is still >= thr_hi (stale entries are ignored)
-__global__ void __launch_bounds__(GDN_BLOCK)
-sssp_far_min_kernel(const vid_t *__restrict__ far_in, unsigned n, const int32_t *__restrict__ dist,
-                    int32_t thr_hi, SsspCounters *cnt) {
-  // persistent grid, ONE atomic per workgroup (the counter is a single hot address)
-  __shared__ int32_t s_min[GDN_WAVES_PER_BLOCK];
-  int32_t d = GDN_DIST_INF;
-  for (unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += gridDim.x * GDN_BLOCK) {
-    const int32_t x = dist[far_in[i]];
-    if (x >= thr_hi && x < d) d = x;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const int32_t t = __shfl_xor(d, o, 64);
-    d = t < d ? t : d;
-  }
-  if (gdn_lane() == 0) s_min[threadIdx.x >> 6] = d;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int w = 1; w < GDN_WAVES_PER_BLOCK; w++) d = s_min[w] < d ? s_min[w] : d;
-    if (d != GDN_DIST_INF) atomicMin(&cnt->min_far, d);
-  }
-}
-
-// FAR -> {NEAR of the new bucket, FAR kept, dropped}
+// FAR -> {NEAR of the new bucket, FAR kept (and the smallest distance kept: the jump over empty buckets), dropped}
 __global__ void __launch_bounds__(GDN_BLOCK)
 sssp_far_split_kernel(const vid_t *__restrict__ far_in, unsigned n, const int32_t *__restrict__ dist,
                       int32_t old_hi, int32_t new_hi, unsigned *__restrict__ in_far, vid_t *__restrict__ near_out,
@@ -210,6 +186,7 @@ sssp_far_split_kernel(const vid_t *__restrict__ far_in, unsigned n, const int32_
   st_far.strip = s_far[threadIdx.x >> 6];
   st_far.n = 0;
   unsigned long long deg = 0;
+  int32_t dmin = GDN_DIST_INF;  // smallest distance of what stays in FAR (the host's jump over empty buckets)
   const unsigned stride = gridDim.x * GDN_BLOCK;
   for (unsigned i0 = blockIdx.x * GDN_BLOCK; i0 < n; i0 += stride) {  // wave-uniform trip count
     const unsigned i = i0 + threadIdx.x;
@@ -218,8 +195,10 @@ sssp_far_split_kernel(const vid_t *__restrict__ far_in, unsigned n, const int32_
     if (i < n) {
       w = far_in[i];
       const int32_t d = dist[w];
-      if (d >= new_hi) to_far = true;
-      else {
+      if (d >= new_hi) {
+        to_far = true;
+        dmin = d < dmin ? d : dmin;
+      } else {
         in_far[w] = 0u;
         to_near = d >= old_hi;
         if (to_near) deg += rowptr[w + 1] - rowptr[w];
@@ -232,6 +211,19 @@ sssp_far_split_kernel(const vid_t *__restrict__ far_in, unsigned n, const int32_
   gdn_wl_flush(st_far, far_out, &cnt->far_count, cap, &cnt->overflow);
   deg = gdn_wave_sum(deg);
   if (gdn_lane() == 0 && deg) atomicAdd(&cnt->relaxed, deg);
+  // one atomicMin per WORKGROUP (a single hot address)
+  __shared__ int32_t s_dmin[GDN_WAVES_PER_BLOCK];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t t = __shfl_xor(dmin, o, 64);
+    dmin = t < dmin ? t : dmin;
+  }
+  if (gdn_lane() == 0) s_dmin[threadIdx.x >> 6] = dmin;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < GDN_WAVES_PER_BLOCK; w++) dmin = s_dmin[w] < dmin ? s_dmin[w] : dmin;
+    if (dmin != GDN_DIST_INF) atomicMin(&cnt->min_far, dmin);
+  }
 }
 
 __global__ void sssp_seed_kernel(int32_t source, int32_t *dist, vid_t *near) {
@@ -590,7 +582,7 @@ sssp_weight_range_kernel(const int32_t *__restrict__ w, size_t n, int32_t *__res
 #define SSSP_SMALL_THREADS 1024
 #define SSSP_SMALL_V 512u
 #define SSSP_SMALL_E 8192ull
-#define SSSP_SMALL_FAR 65536u
+#define SSSP_SMALL_FAR 8192u   // (65536 until round 4: a longer FAR list changes buckets faster on the grid -- one speculative split, RMAT-24 U[1,255] 2.88 -> 2.82 ms)
 struct SsspSmallState {
   unsigned n_near, n_far;
   unsigned long long near_edges;
@@ -1875,6 +1867,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   // light phases run inside ONE workgroup (sssp_small_kernel); GDN_SSSP_SMALL=0 keeps every phase on the host loop, =2
   // forces every phase into it that fits the lists (tests)
   unsigned small_v = SSSP_SMALL_V, small_far = SSSP_SMALL_FAR;
+  if (const char *e = gdn_option("GDN_SSSP_SMALL_FAR")) small_far = (unsigned)atoi(e);  // FAR lists up to this long change buckets inside the one-workgroup kernel
   unsigned long long small_e = SSSP_SMALL_E;
   if (const char *e = gdn_option("GDN_SSSP_SMALL")) {
     if (atoi(e) == 0) small_v = 0;
@@ -2247,43 +2240,54 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       near_out = t;
       continue;
     }
-    // ---- next non-empty bucket (omp_base.cc:66-72 votes for the smallest non-empty bin)
-    h.near_count = 0;
-    h.far_count = 0;
-    h.big_count = 0;
-    h.overflow = 0;
-    h.min_far = GDN_DIST_INF;
-    h.max_dist = 0;
-    h.relaxed = 0;
-    sssp_put(p.cnt.p, h);
-    hipLaunchKernelGGL(sssp_far_min_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
-                       far_cur, n_far, d_dist,
-                       clamp(thr_hi), p.cnt.p);
-    GDN_TRY(sssp_read(p, p.cnt.p, h));
-    if (h.min_far == GDN_DIST_INF) break;  // only stale entries were left
-    const int64_t old_hi = thr_hi;
+    // ---- next non-empty bucket (omp_base.cc:66-72 votes for the smallest non-empty bin).  As inside the one-workgroup and
+    // cooperative kernels: the split is run at once for the bucket right BEHIND the old one and collects the minimum of what
+    // it keeps; only when nothing moved does a second pass split at the bucket of that minimum -- one launch and one read
+    // back per bucket change where the minimum-first order took two of each.
     delta_cur = sssp_adapt_delta(delta_cur, (long long)delta, bucket_work, light_host, light_run, adapt_after);
     bucket_work = 0;
-    thr_lo = ((int64_t)h.min_far / delta_cur) * (int64_t)delta_cur;
-    if (thr_lo < old_hi && old_hi < (int64_t)GDN_DIST_INF) thr_lo = old_hi;  // widths that changed: never back into what has been settled
-    thr_hi = thr_lo + delta_cur;
-    hipLaunchKernelGGL(sssp_far_split_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
-                       far_cur, n_far, d_dist,
-                       clamp(old_hi), clamp(thr_hi), p.in_far.p, near_in, far_nxt, p.cnt.p, cap, g->rowptr);
-    GDN_TRY(sssp_read(p, p.cnt.p, h));
-    if (h.overflow) {
-      gdn_set_error("gdn_sssp: device worklist overflow");
-      return GDN_ERR_OVERFLOW;
+    int64_t spec_lo = thr_hi, spec_hi = thr_hi + delta_cur;
+    bool finished = false;
+    for (;;) {
+      h.near_count = 0;
+      h.far_count = 0;
+      h.big_count = 0;
+      h.overflow = 0;
+      h.min_far = GDN_DIST_INF;
+      h.max_dist = 0;
+      h.relaxed = 0;
+      sssp_put(p.cnt.p, h);
+      hipLaunchKernelGGL(sssp_far_split_kernel, dim3(gdn_nblocks(n_far) < 2048u ? gdn_nblocks(n_far) : 2048u), dim3(GDN_BLOCK), 0, 0,
+                         far_cur, n_far, d_dist,
+                         clamp(thr_hi), clamp(spec_hi), p.in_far.p, near_in, far_nxt, p.cnt.p, cap, g->rowptr);
+      GDN_TRY(sssp_read(p, p.cnt.p, h));
+      if (h.overflow) {
+        gdn_set_error("gdn_sssp: device worklist overflow");
+        return GDN_ERR_OVERFLOW;
+      }
+      if (trace)
+        fprintf(stderr, "[sssp] %7.1f us split far %u for bucket [%lld,%lld): near %u (%llu edges) far %u (min %d)\n", lap(), n_far,
+                (long long)spec_lo, (long long)spec_hi, h.near_count, h.relaxed, h.far_count, h.min_far);
+      n_far = h.far_count;
+      vid_t *t = far_cur;
+      far_cur = far_nxt;
+      far_nxt = t;
+      if (h.near_count > 0 || n_far == 0) {
+        if (h.near_count > 0) {
+          thr_lo = spec_lo;
+          thr_hi = spec_hi;
+        }
+        n_near = h.near_count;
+        near_edges = h.relaxed;
+        finished = n_near == 0;  // only stale entries were left
+        break;
+      }
+      thr_hi = spec_hi;  // that bucket was empty and everything kept lies behind it: nothing is stale against it
+      spec_lo = ((int64_t)h.min_far / delta_cur) * (int64_t)delta_cur;
+      if (spec_lo < thr_hi) spec_lo = thr_hi;
+      spec_hi = spec_lo + delta_cur;
     }
-    if (trace)
-      fprintf(stderr, "[sssp] %7.1f us split far %u at min %d -> bucket [%lld,%lld): near %u (%llu edges) far %u\n", lap(), n_far, h.min_far,
-              (long long)thr_lo, (long long)thr_hi, h.near_count, h.relaxed, h.far_count);
-    n_near = h.near_count;
-    n_far = h.far_count;
-    near_edges = h.relaxed;
-    vid_t *t = far_cur;
-    far_cur = far_nxt;
-    far_nxt = t;
+    if (finished) break;
   }
   GDN_HIP(hipGetLastError());
   if (p.dense) {
