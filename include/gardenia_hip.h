@@ -126,7 +126,9 @@ int gdn_spmv_multi(int32_t m, uint64_t nnz, const uint64_t *Ap, const int32_t *A
 
 /* replaces SSSPSolver(Graph&, int source, DistT* weight, DistT* dist, int delta):
  * src/sssp/sssp.h:47; caller src/sssp/main.cc:27.  dist: in = kDistInf (INT_MAX,
- * sssp.h:46), out = shortest distance.  weight[nnz] parallel to colidx, delta >= 1. */
+ * sssp.h:46), out = shortest distance.  weight[nnz] parallel to colidx, delta >= 1: the bucket width the schedule starts
+ * with (src/sssp/omp_base.cc:12 takes it as a tuning parameter too); behind a run of light buckets the schedule widens it
+ * by itself (option GDN_SSSP_ADAPT=0: the caller's width throughout).  Distances are exact whatever the widths. */
 int gdn_sssp(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colidx,
              const int32_t *weight, int32_t source, int32_t delta, int32_t *dist, gdn_stats *stats);
 
