@@ -910,16 +910,37 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     if (const char *e = gdn_option("GDN_BC_LOG_BIN")) lb = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_BIN ? atoi(e) : lb;
     // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
     PbScratch scratch;
-    if ((st = pb_build(gin, m, lc, lb, p->fwd, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
-                       0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch)))
-      break;
-    if ((st = pb_build(g, m, lc, lb, p->back, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
-                       0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch)))
-      break;
-    {  // V of both layouts in lane-interleaved blocks where the bins allow it (gdn_pb.hpp, PbPlan::v_il); GDN_PB_V_IL=0: plain
-      const char *vie = gdn_option("GDN_PB_V_IL");
-      if (!(vie && vie[0] == '0') && ((st = pb_v_interleave(p->fwd)) || (st = pb_v_interleave(p->back)))) break;
-    }
+    // both layouts from the tiered builder's gather pass + LDS-staged splits (gdn_pbtier.hpp; no record tiers here: BC's
+    // values are not fixed-point codes of one table); outside its limits, or GDN_PB_BUILDER=old: pb_build's key sort
+    const char *vie = gdn_option("GDN_PB_V_IL"), *be = gdn_option("GDN_PB_BUILDER");
+    const bool v_il = !(vie && vie[0] == '0');
+    auto build_one = [&](const gdn_graph *src, PbPlan &out) -> int {
+      if (!(be && be[0] == 'o') && lb <= PB_MID_ROW_BITS) {
+        PbTieredArgs ta;
+        PbTierSet ts;
+        ta.rowptr = src->rowptr;
+        ta.colidx = src->colidx;
+        ta.m_raw = m;
+        ta.m_rows = m;
+        ta.m_global = m;
+        ta.nnz = src->nnz;
+        ta.src_count = nullptr;
+        ta.log_chunk = lc;
+        ta.log_bin = lb;
+        ta.pad = 32;
+        ta.log_group = 5;
+        ta.tiers = false;
+        ta.v_interleave = v_il;
+        const int rc = pb_build_tiered_run(ta, out, ts);
+        if (rc <= 0) return rc;  // built, or an error
+      }
+      const int rc = pb_build(src, m, lc, lb, out, true, nullptr, nullptr, /*compact=*/true, false, /*pad=*/32, /*log_group=*/5, nullptr,
+                              0, false, false, nullptr, 0, false, false, PB_MAX_LOG_BIN, &scratch);
+      if (rc != GDN_OK) return rc;
+      return v_il ? pb_v_interleave(out) : GDN_OK;  // V in lane-interleaved blocks where the bins allow it (PbPlan::v_il)
+    };
+    // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
+    if ((st = build_one(gin, p->fwd)) || (st = build_one(g, p->back))) break;
     const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;
     p->bigcap = (unsigned)(bigcap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : bigcap64);
     p->rowcap = (unsigned)(g->nnz / BC_BLOCK_ROW + 16);
