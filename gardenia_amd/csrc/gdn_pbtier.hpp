@@ -1756,6 +1756,7 @@ struct PoTilesArgs {
 };
 static __global__ void __launch_bounds__(GDN_BLOCK)
 po_tiles_kernel(PoTilesArgs a) {
+  __shared__ unsigned s_run[GDN_WAVES_PER_BLOCK][1 << PO_TLOW];
   const unsigned nd = a.d1 + a.ntiers * a.dt;
   const unsigned long long seg = ((unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
   if (seg >= (unsigned long long)a.nchunks * nd) return;
@@ -1812,7 +1813,15 @@ po_tiles_kernel(PoTilesArgs a) {
   const unsigned bl = (h << PO_TLOW) + (lane & ((1u << PO_TLOW) - 1u));
   if (bl < a.nbins)
     off = a.tptr[(unsigned long long)t * a.nbins + bl] + a.tpre[((unsigned long long)(1 + t) * a.nchunks + c) * a.nbins + bl];
-  unsigned mybase = 0u;  // lane k < 32: records of bin k of the segment written so far
+  // records of bin k of the segment written so far: a counter per bin in the wave's LDS row, and a record's place in its bin
+  // is ONE LDS atomic with return (round 4; a ballot per bin -- 32 of them per 64 records -- was most of this kernel's
+  // instructions).  Lanes of one instruction that share a bin take their slots in the order the LDS unit serialises them
+  // (lane order here, see pt_partition); nothing depends on it: the stream's order by source only keeps phase B's table
+  // reads together.
+  unsigned *run = s_run[threadIdx.x >> 6];
+  if (lane < (1u << PO_TLOW)) run[lane] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
   constexpr int TU = 4;
   for (eoff_t i0 = s0; i0 < s1; i0 += 64 * TU) {
     uint32_t items[TU], vals[TU];
@@ -1829,20 +1838,12 @@ po_tiles_kernel(PoTilesArgs a) {
       const bool valid = i < s1;
       const uint32_t item = items[q], val = vals[q];
       const unsigned low = (val >> 8) & ((1u << PO_TLOW) - 1u);
-      unsigned r = 0u, add = 0u;
-#pragma unroll
-      for (int k = 0; k < (1 << PO_TLOW); k++) {
-        const unsigned long long mk = __ballot(valid && low == (unsigned)k);
-        if (low == (unsigned)k) r = (unsigned)__popcll(mk & lt);
-        if (lane == (unsigned)k) add = (unsigned)__popcll(mk);
-      }
-      const unsigned before = (unsigned)__shfl((int)mybase, (int)low, 64);
       const eoff_t o = (eoff_t)__shfl((long long)off, (int)low, 64);
       if (valid) {
-        a.rec[o + before + r] = item;
-        if (a.w8) a.w8[o + before + r] = (uint8_t)(val & 0xFFu);
+        const unsigned before = atomicAdd(&run[low], 1u);
+        a.rec[o + before] = item;
+        if (a.w8) a.w8[o + before] = (uint8_t)(val & 0xFFu);
       }
-      mybase += add;
     }
   }
 }
