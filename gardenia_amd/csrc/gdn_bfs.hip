@@ -616,6 +616,223 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same step with the WAVE as the unit (round 4).  In bfs_bu_kernel a window is a workgroup's: four barriers and two or
+// three dependent round trips per 4 096 rows, sixteen windows one after the other per workgroup -- ~10 us per window
+// whatever is in it (a late level that discovers 27 K rows: 0.17 ms; measured with the two passes split into kernels: the
+// head pass alone 0.17 / 0.32 / 0.52 ms for the three levels of an RMAT-27 search, profiles/sessions/r04_48.sh).  Here a wave
+// owns 2 048 consecutive rows = 64 bitmap words, one per lane, and shares nothing with the other waves of its workgroup but
+// the hubs' frontier bits: no barrier after the prologue.  Per step: the words (fetched one step ahead); nothing open ->
+// 64 zero words out, next step (a late level is little else: one round trip per 2 048 rows); else the open rows into the
+// wave's LDS list (stage 0), heads (stage 1: every lane busy, the rows that stay open compacted to the front of the list),
+// the in-neighbour scan of those (stage 2), then the 64 next / visited words in one store each.
+// GDN_BFS_BU_FORM=window keeps bfs_bu_kernel.
+// ------------------------------------------------------------------------------------------
+#define BFS_BW_STEP 2048u  // rows per wave step (64 bitmap words, one per lane) = entries of the wave's list
+#ifndef BFS_BW_GROUP
+#define BFS_BW_GROUP 1u    // steps a wave takes together (their open rows share one pass through the stages when they fit the list).
+                           // Measured on RMAT-27: 8 -> a late level 0.13 -> 0.10 ms, but the heavy one 0.84 -> 0.92 (sessions/r04_50.sh): 1
+#endif
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx, int32_t m, unsigned m_pad,
+                   const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
+                   int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
+                   const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace) {
+  static_assert(BFS_BW_GROUP * BFS_BW_STEP <= 65536u, "a list entry is (step << 11 | row in step) in 16 bits");
+  __shared__ unsigned s_hf[BFS_HUBS / 32];
+  __shared__ unsigned short s_list[GDN_WAVES_PER_BLOCK][BFS_BW_STEP];
+  __shared__ unsigned s_bits[GDN_WAVES_PER_BLOCK][BFS_BW_GROUP * 64];
+  __shared__ unsigned long long s_red[4 * GDN_WAVES_PER_BLOCK];
+  const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
+  const bool hubs = hub_front[BFS_HUBS / 32] >= min_hubs;  // else: too few hubs in this frontier (uniform)
+  if (hubs)
+    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += GDN_BLOCK) s_hf[i] = hub_front[i];
+  __syncthreads();  // the only barrier
+  unsigned short *list = s_list[wave];
+  unsigned *bits = s_bits[wave];
+  const unsigned nsteps = m_pad / BFS_BW_STEP;  // (m_pad is a multiple of 2 048: nwords_pad of 64)
+  const unsigned ngroups = (nsteps + BFS_BW_GROUP - 1) / BFS_BW_GROUP;
+  const unsigned gw = blockIdx.x * GDN_WAVES_PER_BLOCK + wave, nw = gridDim.x * GDN_WAVES_PER_BLOCK;
+  unsigned long long awake = 0, scout = 0;
+  unsigned by_head = 0, probes = 0;
+  auto wave_sync = [&]() {  // LDS writes of the wave visible to the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // the n rows listed in `list` (entry = step in the group << 11 | row in the step) through stages 1 and 2; their discoveries
+  // go into `bits` (word = entry >> 5)
+  auto run_list = [&](unsigned gbase, unsigned n) {
+    // ---- stage 1: heads; the rows that stay open move to the front of the list (written behind what has been read)
+    unsigned nq = 0;  // uniform
+    for (unsigned i0 = 0; i0 < n; i0 += BFS_BU_UNR * 64u) {
+      unsigned rl[BFS_BU_UNR], code[BFS_BU_UNR], fw[BFS_BU_UNR];
+      unsigned long long rc[BFS_BU_UNR];
+      bool on[BFS_BU_UNR], found[BFS_BU_UNR];
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {
+        const unsigned i = i0 + (unsigned)r * 64u + lane;
+        on[r] = i < n;
+        rl[r] = on[r] ? list[i] : 0u;
+        rc[r] = BFS_NO_HUB;
+        if (on[r]) rc[r] = rec[gbase + rl[r]];
+        code[r] = (unsigned)rc[r];
+      }
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {  // heads outside the hub set: their frontier word
+        fw[r] = 0u;
+        if (code[r] != BFS_NO_HUB && (code[r] & BFS_HEAD_VERTEX)) fw[r] = front[(code[r] & ~BFS_HEAD_VERTEX) >> 5];
+      }
+      wave_sync();  // every lane holds its entries: the front of the list may be overwritten
+#pragma unroll
+      for (int r = 0; r < BFS_BU_UNR; r++) {
+        found[r] = on[r] && (code[r] < BFS_HUBS ? (hubs && ((s_hf[code[r] >> 5] >> (code[r] & 31u)) & 1u)) : (bool)((fw[r] >> (code[r] & 31u)) & 1u));
+        if (found[r]) {
+          depth[gbase + rl[r]] = next_level;
+          scout += rc[r] >> 32;
+          atomicOr(&bits[rl[r] >> 5], 1u << (rl[r] & 31u));
+          by_head++;
+        }
+        const bool wait = on[r] && !found[r];
+        const unsigned long long om = __ballot(wait);
+        if (wait) list[nq + (unsigned)__popcll(om & gdn_lanemask_lt())] = (unsigned short)rl[r];
+        nq += (unsigned)__popcll(om);
+      }
+    }
+    wave_sync();
+    // ---- stage 2: the rows still open, one per lane: their in-neighbours against the frontier
+    for (unsigned i = lane; i < nq; i += 64u) {
+      const unsigned rl = list[i], v = gbase + rl;
+      const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
+      bool found = false;
+      for (eoff_t k = rb; k < re; k++) {
+        const vid_t u = in_colidx[k];
+        probes++;
+        if ((front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u) {
+          found = true;
+          break;
+        }
+      }
+      if (found) {
+        depth[v] = next_level;
+        atomicOr(&bits[rl >> 5], 1u << (rl & 31u));
+        awake++;
+        scout += rec[v] >> 32;
+      }
+    }
+    wave_sync();
+  };
+  // the words of a group, fetched one group ahead (another wave's words never change under this one)
+  auto fetch = [&](unsigned g, unsigned (&w)[BFS_BW_GROUP]) {
+#pragma unroll
+    for (unsigned k = 0; k < BFS_BW_GROUP; k++) {
+      w[k] = ~0u;
+      const unsigned st = g * BFS_BW_GROUP + k;
+      if (g < ngroups && st < nsteps) {
+        const unsigned idx = st * 64u + lane, x = idx << 5;  // first row of the word
+        if (x < (unsigned)m) {
+          w[k] = visited[idx] | (noin ? noin[idx] : 0u);
+          if ((unsigned)m - x < 32u) w[k] |= ~0u << ((unsigned)m - x);  // rows past the last one
+        }
+      }
+    }
+  };
+  unsigned w_next[BFS_BW_GROUP];
+  fetch(gw, w_next);
+  for (unsigned g = gw; g < ngroups; g += nw) {  // wave-uniform trip count
+    const unsigned st0 = g * BFS_BW_GROUP, gbase = st0 * BFS_BW_STEP;
+    unsigned open[BFS_BW_GROUP];
+    unsigned c_tot = 0;
+#pragma unroll
+    for (unsigned k = 0; k < BFS_BW_GROUP; k++) {
+      open[k] = ~w_next[k];
+      c_tot += (unsigned)__popc(open[k]);
+    }
+    fetch(g + nw, w_next);
+    const unsigned incl = gdn_wave_incl_scan(c_tot);
+    const unsigned n = (unsigned)__shfl((int)incl, 63, 64);
+    if (n == 0u) {  // uniform: nothing open in 16 K rows
+#pragma unroll
+      for (unsigned k = 0; k < BFS_BW_GROUP; k++)
+        if (st0 + k < nsteps) next[(st0 + k) * 64u + lane] = 0u;
+      continue;
+    }
+#pragma unroll
+    for (unsigned k = 0; k < BFS_BW_GROUP; k++) bits[k * 64u + lane] = 0u;
+    if (n <= BFS_BW_STEP) {
+      // a light group (any late level): ALL its open rows in one list, one pass through the stages -- the chain of dependent
+      // round trips is paid once per 16 K rows
+      unsigned off = incl - c_tot;
+#pragma unroll
+      for (unsigned k = 0; k < BFS_BW_GROUP; k++) {
+        unsigned o = open[k];
+        while (o) {
+          const unsigned b = (unsigned)__ffs((int)o) - 1u;
+          o &= o - 1u;
+          list[off++] = (unsigned short)((k << 11) | (lane * 32u + b));
+        }
+      }
+      wave_sync();
+      run_list(gbase, n);
+    } else {
+      // a heavy group: step by step (ascending rows per list: the head records of a wave instruction lie together)
+#pragma unroll
+      for (unsigned k = 0; k < BFS_BW_GROUP; k++) {
+        const unsigned ck = (unsigned)__popc(open[k]);
+        const unsigned ik = gdn_wave_incl_scan(ck);
+        const unsigned nk = (unsigned)__shfl((int)ik, 63, 64);
+        if (nk == 0u) continue;  // uniform
+        unsigned off = ik - ck, o = open[k];
+        while (o) {
+          const unsigned b = (unsigned)__ffs((int)o) - 1u;
+          o &= o - 1u;
+          list[off++] = (unsigned short)((k << 11) | (lane * 32u + b));
+        }
+        wave_sync();
+        run_list(gbase, nk);
+      }
+    }
+#pragma unroll
+    for (unsigned k = 0; k < BFS_BW_GROUP; k++) {
+      if (st0 + k < nsteps) {
+        const unsigned word = bits[k * 64u + lane], idx = (st0 + k) * 64u + lane;
+        next[idx] = word;
+        if (word) visited[idx] |= word;  // (the word is this wave's alone during the kernel)
+      }
+    }
+    wave_sync();  // the list and the bits are reused by the next group
+  }
+  awake += by_head;
+  awake = gdn_wave_sum(awake);
+  scout = gdn_wave_sum(scout);
+  const unsigned long long bh = trace ? gdn_wave_sum((unsigned long long)by_head) : 0ull;
+  const unsigned long long pr = trace ? gdn_wave_sum((unsigned long long)probes) : 0ull;
+  if (lane == 0) {
+    s_red[wave] = awake;
+    s_red[GDN_WAVES_PER_BLOCK + wave] = scout;
+    s_red[2 * GDN_WAVES_PER_BLOCK + wave] = bh;
+    s_red[3 * GDN_WAVES_PER_BLOCK + wave] = pr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, sc = 0, b = 0, c = 0;
+    for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
+      a += s_red[i];
+      sc += s_red[GDN_WAVES_PER_BLOCK + i];
+      b += s_red[2 * GDN_WAVES_PER_BLOCK + i];
+      c += s_red[3 * GDN_WAVES_PER_BLOCK + i];
+    }
+    if (a) {
+      atomicAdd(&cnt->awake, a);
+      atomicAdd(&cnt->scout, sc);
+    }
+    if (b | c) {
+      atomicAdd(&cnt->bu_by_head, b);
+      atomicAdd(&cnt->bu_probes, c);
+    }
+  }
+}
+
 // the frontier a top-down level has just discovered, as a bitmap: the bits `visited` gained since the snapshot taken in
 // front of that level (16-byte accesses; nwords is a multiple of 64).  Replaces a memset + one atomicOr per queued vertex:
 // RMAT-27, 3-4.5 M vertices, 97-154 us -> 12 us + the 6 us snapshot
@@ -1461,6 +1678,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
             GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, 2 * sizeof(unsigned), 0));
             hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(BFS_HUBS / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p);
           }
+          const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
+          if (p.head.p && !(bfe && bfe[0] == 'w'))
+            hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, m,
+                               p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
+                               p.hub_front.p, hub_min, trace);
+          else
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                              p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
                              p.hub_front.p, hub_min, trace);
