@@ -344,6 +344,8 @@ bfs_hub_rank_kernel(const unsigned long long *__restrict__ sorted, int32_t m, un
 // walked whole, the few rows of millions of in-edges made the plan build 2.8 s longer.  (Measured and dropped: the three best hubs, 16 bits each, tested together -- with
 // 2^16 hub slots the heavy level of RMAT-27 1.26 -> 1.60 ms, profiles/r03_bfs_bottom_up.txt.)
 #define BFS_HEAD_VERTEX 0x80000000u
+#define BFS_REC_LONE (1ull << 63)                                      // rec: the head is the only in-neighbour
+#define BFS_REC_DEG(rc) ((unsigned long long)(((rc) >> 32) & 0x7FFFFFFFull))  // rec: the row's out-degree
 #define BFS_HEAD_SCAN 8192
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
@@ -369,7 +371,11 @@ bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restric
       unsigned code = best;
       if (best != BFS_NO_HUB && best >= BFS_HUBS) code = BFS_HEAD_VERTEX | (unsigned)(sorted[(size_t)m - 1 - best] & 0x7FFFFFFFull);
       const eoff_t d = out_rowptr[v + 1] - out_rowptr[v];
-      rec[v] = ((unsigned long long)d << 32) | code;
+      // bit 63 (out-degrees stay below 2^31): the head is the row's ONLY in-neighbour -- when it is not in the frontier the
+      // row cannot be discovered at this level, and the bottom-up step does not queue it for a scan (two row-offset gathers,
+      // a neighbour and a frontier word saved per such row and level)
+      const unsigned long long lone = (in_rowptr[v + 1] - in_rowptr[v] == 1) ? BFS_REC_LONE : 0ull;
+      rec[v] = lone | ((unsigned long long)d << 32) | code;
     }
   }
 }
@@ -473,7 +479,7 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
         depth[v] = next_level;
         atomicOr(&s_bits[wi][rl >> 5], 1u << (rl & 31u));
         awake++;
-        scout += rec ? (eoff_t)(rec[v] >> 32) : out_rowptr[v + 1] - out_rowptr[v];
+        scout += rec ? (eoff_t)BFS_REC_DEG(rec[v]) : out_rowptr[v + 1] - out_rowptr[v];
       }
     }
     __syncthreads();
@@ -560,14 +566,16 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
         found[r] = code[r] < BFS_HUBS ? (hubs && ((s_hf[code[r] >> 5] >> (code[r] & 31u)) & 1u)) : (bool)((fw[r] >> (code[r] & 31u)) & 1u);
         if (found[r]) {
           depth[base + rl[r]] = next_level;
-          scout += rc[r] >> 32;
+          scout += BFS_REC_DEG(rc[r]);
           atomicOr(&s_bits[nwin][rl[r] >> 5], 1u << (rl[r] & 31u));
           by_head++;
         }
       }
 #pragma unroll
       for (int r = 0; r < BFS_BU_UNR; r++) {
-        const bool wait = on[r] && !found[r];  // into the queue (one LDS reservation per wave)
+        // into the queue (one LDS reservation per wave) -- unless the head is the row's only in-neighbour and the test above was
+        // the real one (a hub head while this level reads no hub bits has not been tested: the scan does it)
+        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && (hubs || code[r] >= BFS_HUBS));
         const unsigned long long om = __ballot(wait);
         if (om) {
           const int first = __ffsll((long long)om) - 1;
@@ -689,11 +697,12 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         found[r] = on[r] && (code[r] < BFS_HUBS ? (hubs && ((s_hf[code[r] >> 5] >> (code[r] & 31u)) & 1u)) : (bool)((fw[r] >> (code[r] & 31u)) & 1u));
         if (found[r]) {
           depth[gbase + rl[r]] = next_level;
-          scout += rc[r] >> 32;
+          scout += BFS_REC_DEG(rc[r]);
           atomicOr(&bits[rl[r] >> 5], 1u << (rl[r] & 31u));
           by_head++;
         }
-        const bool wait = on[r] && !found[r];
+        // (a lone head outside the frontier: nothing left to scan -- if the head WAS tested: a hub head needs this level's hub bits)
+        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && (hubs || code[r] >= BFS_HUBS));
         const unsigned long long om = __ballot(wait);
         if (wait) list[nq + (unsigned)__popcll(om & gdn_lanemask_lt())] = (unsigned short)rl[r];
         nq += (unsigned)__popcll(om);
@@ -717,7 +726,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         depth[v] = next_level;
         atomicOr(&bits[rl >> 5], 1u << (rl & 31u));
         awake++;
-        scout += rec[v] >> 32;
+        scout += BFS_REC_DEG(rec[v]);
       }
     }
     wave_sync();
