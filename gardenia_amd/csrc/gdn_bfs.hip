@@ -32,8 +32,12 @@ struct BfsCounters {  // device, zeroed per level by the host-side memset
   unsigned long long bu_probes;                //            ... and in-neighbours probed for the others (GDN_BFS_TRACE)
 };
 
+#define BFS_REC_LONE (1ull << 63)                                      // head record: the head is the only in-neighbour
+#define BFS_REC_DEG(rc) ((unsigned long long)(((rc) >> 32) & 0x7FFFFFFFull))  // head record: the row's out-degree
 struct BfsTdVis {
   const eoff_t *__restrict__ rowptr;
+  const unsigned long long *__restrict__ rec;  // nullable: the plan's head records (bfs_hub_head_kernel): a discovered vertex's
+                                               // out-degree is ONE 8-byte gather there, two through the row offsets
   const vid_t *__restrict__ colidx;
   unsigned *__restrict__ visited;
   int32_t *__restrict__ depth;
@@ -58,7 +62,7 @@ struct BfsTdVis {
     }
     if (claim) {
       depth[dst] = next_level;
-      scout_local += rowptr[dst + 1] - rowptr[dst];
+      scout_local += rec ? (eoff_t)BFS_REC_DEG(rec[dst]) : rowptr[dst + 1] - rowptr[dst];
     }
     gdn_wl_push_staged(stage, outq, &cnt->next_count, cap, claim, dst, &cnt->overflow);
   }
@@ -344,8 +348,6 @@ bfs_hub_rank_kernel(const unsigned long long *__restrict__ sorted, int32_t m, un
 // walked whole, the few rows of millions of in-edges made the plan build 2.8 s longer.  (Measured and dropped: the three best hubs, 16 bits each, tested together -- with
 // 2^16 hub slots the heavy level of RMAT-27 1.26 -> 1.60 ms, profiles/r03_bfs_bottom_up.txt.)
 #define BFS_HEAD_VERTEX 0x80000000u
-#define BFS_REC_LONE (1ull << 63)                                      // rec: the head is the only in-neighbour
-#define BFS_REC_DEG(rc) ((unsigned long long)(((rc) >> 32) & 0x7FFFFFFFull))  // rec: the row's out-degree
 #define BFS_HEAD_SCAN 8192
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
@@ -1251,7 +1253,8 @@ bfs_btd_bin_big_kernel(const eoff_t *__restrict__ rowptr, ExpBigList big, BfsBin
 __global__ void __launch_bounds__(BFS_BTD_THREADS)
 bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigned *__restrict__ overflow, unsigned cap_each, int logb,
                      int32_t m, unsigned nwords_pad, unsigned *__restrict__ visited, unsigned *__restrict__ next_front,
-                     int32_t *__restrict__ depth, int32_t next_level, const eoff_t *__restrict__ out_rowptr, BfsCounters *cnt) {
+                     int32_t *__restrict__ depth, int32_t next_level, const eoff_t *__restrict__ out_rowptr, BfsCounters *cnt,
+                     const unsigned long long *__restrict__ rec = nullptr /* head records: out-degrees in one load */) {
   extern __shared__ unsigned s_bits[];  // 2^(logb - 5) words
   __shared__ unsigned long long s_red[2 * (BFS_BTD_THREADS / 64)];
   const unsigned bin = blockIdx.x, words = 1u << (logb - 5);
@@ -1315,7 +1318,7 @@ bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigne
         if (row < (size_t)m) {
           depth[row] = next_level;
           awake++;
-          scout += out_rowptr[row + 1] - out_rowptr[row];
+          scout += rec ? (eoff_t)BFS_REC_DEG(rec[row]) : out_rowptr[row + 1] - out_rowptr[row];
         }
       }
     }
@@ -1668,7 +1671,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           hipLaunchKernelGGL(bfs_btd_bin_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, bbig, bv);
           hipLaunchKernelGGL(bfs_btd_apply_kernel, dim3(p.btd_nbins), dim3(BFS_BTD_THREADS), (size_t)4 << (p.btd_logb - 5), 0,
                              p.btd_buf.p, p.btd_cur.p, p.btd_flag.p, p.btd_cap_each, p.btd_logb, m, p.nwords_pad, p.visited.p, nx, d_dist,
-                             level + 1, g->rowptr, p.cnt.p);
+                             level + 1, g->rowptr, p.cnt.p, (const unsigned long long *)p.head.p);
           unsigned flag = 0;
           GDN_HIP(hipMemcpy(&flag, p.btd_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
           if (flag) {  // a bin's list was too short for this frontier: nothing was applied; the sweep takes the level,
@@ -1835,6 +1838,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
       BfsTdVis vis;
       vis.rowptr = g->rowptr;
+      vis.rec = p.head.p;  // nullptr without heads
       vis.colidx = g->colidx;
       vis.visited = p.visited.p;
       vis.depth = d_dist;
