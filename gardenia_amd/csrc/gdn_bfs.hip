@@ -639,6 +639,9 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
 // GDN_BFS_BU_FORM=window keeps bfs_bu_kernel.
 // ------------------------------------------------------------------------------------------
 #define BFS_BW_STEP 2048u  // rows per wave step (64 bitmap words, one per lane) = entries of the wave's list
+#ifndef BFS_BW_GRID
+#define BFS_BW_GRID (256 * 4)  // what is resident at once (33 KB of LDS per workgroup); 2048 / 4096: 3 % slower (sessions/r04_60.sh)
+#endif
 #ifndef BFS_BW_GROUP
 #define BFS_BW_GROUP 1u    // steps a wave takes together (their open rows share one pass through the stages when they fit the list).
                            // Measured on RMAT-27: 8 -> a late level 0.13 -> 0.10 ms, but the heavy one 0.84 -> 0.92 (sessions/r04_50.sh): 1
@@ -1692,7 +1695,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           }
           const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
           if (p.head.p && !(bfe && bfe[0] == 'w'))
-            hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, m,
+            hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, m,
                                p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
                                p.hub_front.p, hub_min, trace);
           else
