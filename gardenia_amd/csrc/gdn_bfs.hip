@@ -639,6 +639,10 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
 // GDN_BFS_BU_FORM=window keeps bfs_bu_kernel.
 // ------------------------------------------------------------------------------------------
 #define BFS_BW_STEP 2048u  // rows per wave step (64 bitmap words, one per lane) = entries of the wave's list
+#ifndef BFS_BW_THREADS
+#define BFS_BW_THREADS 256
+#endif
+#define BFS_BW_WAVES (BFS_BW_THREADS / 64)
 #ifndef BFS_BW_GRID
 #define BFS_BW_GRID (256 * 4)  // what is resident at once (33 KB of LDS per workgroup); 2048 / 4096: 3 % slower (sessions/r04_60.sh)
 #endif
@@ -646,26 +650,26 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
 #define BFS_BW_GROUP 1u    // steps a wave takes together (their open rows share one pass through the stages when they fit the list).
                            // Measured on RMAT-27: 8 -> a late level 0.13 -> 0.10 ms, but the heavy one 0.84 -> 0.92 (sessions/r04_50.sh): 1
 #endif
-__global__ void __launch_bounds__(GDN_BLOCK)
+__global__ void __launch_bounds__(BFS_BW_THREADS)
 bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx, int32_t m, unsigned m_pad,
                    const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
                    const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace) {
   static_assert(BFS_BW_GROUP * BFS_BW_STEP <= 65536u, "a list entry is (step << 11 | row in step) in 16 bits");
   __shared__ unsigned s_hf[BFS_HUBS / 32];
-  __shared__ unsigned short s_list[GDN_WAVES_PER_BLOCK][BFS_BW_STEP];
-  __shared__ unsigned s_bits[GDN_WAVES_PER_BLOCK][BFS_BW_GROUP * 64];
-  __shared__ unsigned long long s_red[4 * GDN_WAVES_PER_BLOCK];
+  __shared__ unsigned short s_list[BFS_BW_WAVES][BFS_BW_STEP];
+  __shared__ unsigned s_bits[BFS_BW_WAVES][BFS_BW_GROUP * 64];
+  __shared__ unsigned long long s_red[4 * BFS_BW_WAVES];
   const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
   const bool hubs = hub_front[BFS_HUBS / 32] >= min_hubs;  // else: too few hubs in this frontier (uniform)
   if (hubs)
-    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += GDN_BLOCK) s_hf[i] = hub_front[i];
+    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += BFS_BW_THREADS) s_hf[i] = hub_front[i];
   __syncthreads();  // the only barrier
   unsigned short *list = s_list[wave];
   unsigned *bits = s_bits[wave];
   const unsigned nsteps = m_pad / BFS_BW_STEP;  // (m_pad is a multiple of 2 048: nwords_pad of 64)
   const unsigned ngroups = (nsteps + BFS_BW_GROUP - 1) / BFS_BW_GROUP;
-  const unsigned gw = blockIdx.x * GDN_WAVES_PER_BLOCK + wave, nw = gridDim.x * GDN_WAVES_PER_BLOCK;
+  const unsigned gw = blockIdx.x * BFS_BW_WAVES + wave, nw = gridDim.x * BFS_BW_WAVES;
   unsigned long long awake = 0, scout = 0;
   unsigned by_head = 0, probes = 0;
   auto wave_sync = [&]() {  // LDS writes of the wave visible to the wave
@@ -823,18 +827,18 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
   const unsigned long long pr = trace ? gdn_wave_sum((unsigned long long)probes) : 0ull;
   if (lane == 0) {
     s_red[wave] = awake;
-    s_red[GDN_WAVES_PER_BLOCK + wave] = scout;
-    s_red[2 * GDN_WAVES_PER_BLOCK + wave] = bh;
-    s_red[3 * GDN_WAVES_PER_BLOCK + wave] = pr;
+    s_red[BFS_BW_WAVES + wave] = scout;
+    s_red[2 * BFS_BW_WAVES + wave] = bh;
+    s_red[3 * BFS_BW_WAVES + wave] = pr;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned long long a = 0, sc = 0, b = 0, c = 0;
-    for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) {
+    for (int i = 0; i < BFS_BW_WAVES; i++) {
       a += s_red[i];
-      sc += s_red[GDN_WAVES_PER_BLOCK + i];
-      b += s_red[2 * GDN_WAVES_PER_BLOCK + i];
-      c += s_red[3 * GDN_WAVES_PER_BLOCK + i];
+      sc += s_red[BFS_BW_WAVES + i];
+      b += s_red[2 * BFS_BW_WAVES + i];
+      c += s_red[3 * BFS_BW_WAVES + i];
     }
     if (a) {
       atomicAdd(&cnt->awake, a);
@@ -1695,7 +1699,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           }
           const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
           if (p.head.p && !(bfe && bfe[0] == 'w'))
-            hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, m,
+            hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(BFS_BW_THREADS), 0, 0, gin->rowptr, gin->colidx, m,
                                p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
                                p.hub_front.p, hub_min, trace);
           else
