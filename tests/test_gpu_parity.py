@@ -2,6 +2,8 @@
 produced by the reference itself and (b) the CPU oracle on seeded inputs.  Bit-exact for BFS
 depths, SSSP distances, CC labels and TC counts; PageRank/SpMV within 1e-4 relative
 (BASELINE.json north_star)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1075,6 +1077,31 @@ def test_sssp_record_tiers_vs_oracle(orc, monkeypatch, capfd, scale, ef, floor, 
         want = orc.sssp_dijkstra(g, wt, s)
         dist, st = sp.run(s, delta)
         assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+    sp.close()
+
+
+def test_sssp_sweeps_that_change_their_candidate_width(orc, monkeypatch):
+    """The dense sweeps write 8-bit candidates while every distance + weight stays below 255 and 16-bit ones from then on,
+    into one buffer whose alignment gaps are never written and must read as "no path".  A sparse graph whose search passes
+    255 under sweeps entered early (graph 6000914 of the randomised sweep, tests/aids/fuzz_parity.py): the rows 0 of some
+    bins once took the bytes of old 8-bit candidates for 16-bit ones -- unreachable vertices came back with distances.
+    Twice on one plan: the second run starts narrow again on a buffer the first left wide."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.abspath(__file__)), "aids", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(6000914)
+    g = fz.random_graph(rng)
+    source = int(rng.integers(0, g.m))
+    wmax = int(rng.choice([2, 16, 256]))
+    wt = rng.integers(1, wmax, g.nnz).astype(np.int32)
+    monkeypatch.setenv("GDN_SSSP_DENSE_IN", "100000")
+    want = orc.sssp_dijkstra(g, wt, source)
+    assert want[want != 2147483647].max() > 255 and (want == 2147483647).any()
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    for _ in range(2):
+        dist, _ = sp.run(source, 1)
+        assert np.array_equal(dist, want), int((dist != want).sum())
     sp.close()
 
 
