@@ -50,6 +50,21 @@ def random_graph(rng):
     return graphio.build_csr(m, src.astype(np.int64), dst.astype(np.int64))
 
 
+def pr_agrees(it2, s, it, want, otr, tag):
+    """Iteration count and every score as the reference's -- except for a BORDERLINE stop: an L1 change that lands within 1e-8
+    of EPSILON may stop one side an iteration earlier (the same terms summed in another order differ in their last bits;
+    seeds 6000609 and 12000866 of the sweeps: the reference's changes 9.99995e-5 and 1.0000002e-4).  Such a run is accepted
+    on its iteration count +- 1, and says so."""
+    if it2 == it:
+        return bool(np.allclose(s, want, rtol=REL, atol=0))
+    borderline = any(abs(float(x) - 1e-4) < 1e-8 for x in otr[-2:])  # (the stop of either side)
+    if borderline and abs(it2 - it) == 1:
+        print(f"(borderline stop, {tag}: {it2} iterations against {it}, last changes of the reference "
+              f"{[float(x) for x in otr[-2:]]})", flush=True)
+        return True
+    return False
+
+
 STAGE = {}
 
 
@@ -86,10 +101,10 @@ def check(seed):
     assert np.array_equal(d, want), f"SSSP {tag} delta {delta}"
     t0 = lap("sssp", t0)
     # PageRank (vertices without out-edges divide by zero in the reference; their quotient is never read)
-    want, it, _ = orc.pr(gi, deg.astype(np.int32))
+    want, it, otr = orc.pr(gi, deg.astype(np.int32))
     s = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
     st = solvers.PRSolver(G, s)
-    assert st["iterations"] == it and np.allclose(s, want, rtol=REL, atol=0), f"PR {tag}"
+    assert pr_agrees(st["iterations"], s, it, want, otr, tag), f"PR {tag}: iterations {st['iterations']} vs {it}"
     t0 = lap("pr", t0)
     # delta PageRank
     want, it, wtr = orc.pr_delta(gi, g, push_div=8)
@@ -109,7 +124,18 @@ def check(seed):
     want = orc.spmv(gi, Ax, x, y0)
     y = y0.copy()
     solvers.SpmvSolver(G, Ax, x, y)
-    assert orc.spmv_max_rel_error(y, want) <= 5 * np.sqrt(np.finfo(np.float32).eps), f"SpMV {tag}"
+    if orc.spmv_max_rel_error(y, want) > 5 * np.sqrt(np.finfo(np.float32).eps):
+        # the reference's criterion (src/spmv/verifier.cc) compares two fp32 sums of one row relative to |a| + |b| + 3.5e-4: a
+        # row of thousands of products that cancel to ~0 fails it between ANY two summation orders (seed 11000533).  Then the
+        # fp64 value of the row decides: the library's entry must be at least as close to it as the reference's
+        rp = gi.rowptr.astype(np.int64)
+        prod = Ax.astype(np.float64) * x.astype(np.float64)[gi.colidx]
+        exact = y0.astype(np.float64) + np.add.reduceat(np.concatenate([prod, [0.0]]), np.minimum(rp[:-1], prod.size))  * (np.diff(rp) > 0)
+        bad = np.abs(y - want) / (np.abs(y) + np.abs(want) + np.sqrt(np.finfo(np.float32).eps)) > 5 * np.sqrt(np.finfo(np.float32).eps)
+        ours, theirs = np.abs(y.astype(np.float64) - exact)[bad], np.abs(want.astype(np.float64) - exact)[bad]
+        assert bool(np.all(ours <= theirs + 1e-7 * np.abs(exact[bad]) + 1e-12)), f"SpMV {tag}: {int(bad.sum())} rows beyond the criterion and further from fp64 than the reference"
+        print(f"(SpMV {tag}: {int(bad.sum())} cancelling row(s) beyond the reference's criterion, closer to fp64 than the reference: "
+              f"{float(ours.max()):.3g} against {float(theirs.max()):.3g})", flush=True)
     t0 = lap("spmv", t0)
     # CC: directed with reverse graph, directed without, symmetrized
     want, _ = orc.cc_sv(gs)
@@ -149,16 +175,9 @@ def check(seed):
         sh = solvers.ResidentPageRankShards(G, world, layout=layout, parts=parts)
         s, it2, _ = sh.solve()
         sh.close()
-        # An L1 change that lands within 1e-4 (relative) of EPSILON may stop one side an iteration earlier: sums of the same
-        # terms in another order differ in their last bits (seed 6000609: the reference's last change is 9.99995e-5).  Such a
-        # run is accepted on its iteration count +- 1; every other run must match in count and in every score.
-        borderline = any(abs(float(x) - 1e-4) < 1e-8 for x in otr[-2:])  # (the stop of either side)
-        if borderline and abs(it2 - it) == 1:
-            print(f"(borderline stop, {tag}: {it2} iterations against {it}, last change of the reference {float(otr[-1]):.9g})", flush=True)
-        else:
-            assert it2 == it and np.allclose(s, want, rtol=REL, atol=0), (
-                f"PR shards {tag} world {world} layout {layout} parts {parts}: iterations {it2} vs {it}, "
-                f"max rel {float(np.max(np.abs(s - want) / np.maximum(np.abs(want), 1e-30))):.3g}")
+        assert pr_agrees(it2, s, it, want, otr, tag), (
+            f"PR shards {tag} world {world} layout {layout} parts {parts}: iterations {it2} vs {it}, "
+            f"max rel {float(np.max(np.abs(s - want) / np.maximum(np.abs(want), 1e-30))):.3g}")
         lap("plans", t0)
     return m, g.nnz
 
