@@ -164,8 +164,8 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
   g->m = m;
   g->nnz = nnz;
   g->owned = true;
-  e = hipMalloc((void **)&g->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
-  if (e == hipSuccess) e = hipMalloc((void **)&g->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
+  e = gdn_plain_malloc((void **)&g->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&g->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
   if (e != hipSuccess) {
     gdn_set_error("csr_from_keys: %s", hipGetErrorString(e));
     gdn_graph_free(g);

@@ -62,6 +62,8 @@ const char *gdn_option(const char *name);
 // base -- an A/B knob for the placement spread of DESIGN.md 4.1 (streams that start at power-of-two-aligned bases
 // walk the memory channels in step).
 size_t gdn_alloc_stagger_next(size_t bytes);
+hipError_t gdn_plain_malloc(void **p, size_t bytes);  // hipMalloc / hipFree, fenced under GDN_ALLOC_FENCE=1 (gdn_graph.hip)
+hipError_t gdn_plain_free(void *p);
 
 // Short-lived device memory of a build (sort keys, the layout builder's arenas): a process-level cache of hipMalloc blocks
 // (gdn_graph.hip), NOT hipMalloc / hipFree per use.  Measured (profiles/r04_malloc_probe.txt, r04 sessions 3-5): a hipMalloc

@@ -32,8 +32,25 @@ const char *gdn_option(const char *name) {
   return it == m.end() ? nullptr : it->second.c_str();  // (the string lives until the option is set again)
 }
 
+// GDN_ALLOC_FENCE=1 (debugging, read once): every DevBuf / scratch allocation is its own block of whole 2 MB pages with the
+// buffer at its END (16-byte aligned), and the scratch cache is off -- a kernel that reads or writes past the end of a
+// buffer then leaves the mapping and faults on the spot instead of touching a neighbour (the GPU build has no address
+// sanitizer on this pool).  tests/aids/fuzz_parity.py and the parity suite run unchanged under it, only slower.
+bool gdn_alloc_fence() {
+  static const bool on = [] {
+    const char *e = gdn_option("GDN_ALLOC_FENCE");
+    return e && e[0] == '1';
+  }();
+  return on;
+}
+static size_t gdn_fence_offset(size_t bytes) {
+  const size_t page = (size_t)2 << 20, b16 = (bytes + 15) & ~(size_t)15;
+  return ((b16 + page - 1) & ~(page - 1)) - b16;
+}
+
 size_t gdn_alloc_stagger_next(size_t bytes) {
   static std::atomic<unsigned> k{0};
+  if (gdn_alloc_fence()) return gdn_fence_offset(bytes);
   if (bytes < (1u << 20)) return 0;
   const char *e = gdn_option("GDN_ALLOC_STAGGER");
   if (!e) return 0;
@@ -139,8 +156,54 @@ int gdn_scratch_malloc(void **p, size_t bytes, int site) {
   }
   return GDN_OK;
 }
+namespace {
+struct FenceMap {  // GDN_ALLOC_FENCE: fenced scratch pointer -> what hipMalloc returned
+  std::mutex mu;
+  std::map<void *, void *> base;
+};
+FenceMap &fence_map() {
+  static FenceMap *m = new FenceMap;  // (never destroyed: frees may run during process teardown)
+  return *m;
+}
+}  // namespace
+// hipMalloc / hipFree of the arrays that are not DevBufs (graphs, gdn_dev_alloc): plain calls unless the fence is on
+hipError_t gdn_plain_malloc(void **p, size_t bytes) {
+  if (!gdn_alloc_fence()) return hipMalloc(p, bytes ? bytes : 1);
+  const size_t off = gdn_fence_offset(bytes ? bytes : 1);
+  void *b = nullptr;
+  const hipError_t e = hipMalloc(&b, (bytes ? bytes : 1) + off);
+  if (e != hipSuccess) return e;
+  *p = static_cast<char *>(b) + off;
+  FenceMap &f = fence_map();
+  std::lock_guard<std::mutex> lk(f.mu);
+  f.base[*p] = b;
+  return hipSuccess;
+}
+hipError_t gdn_plain_free(void *p) {
+  if (!p) return hipSuccess;
+  if (gdn_alloc_fence()) {
+    FenceMap &f = fence_map();
+    std::lock_guard<std::mutex> lk(f.mu);
+    auto it = f.base.find(p);
+    if (it != f.base.end()) {
+      p = it->second;
+      f.base.erase(it);
+    }
+  }
+  return hipFree(p);
+}
 static int gdn_scratch_malloc_raw(void **p, size_t bytes) {
   *p = nullptr;
+  if (gdn_alloc_fence()) {
+    const hipError_t e = gdn_plain_malloc(p, bytes);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      *p = nullptr;
+      gdn_set_error("scratch allocation of %zu bytes -> %s", bytes, hipGetErrorString(e));
+      return GDN_ERR_OOM;
+    }
+    return GDN_OK;
+  }
   if (gdn_scratch_pooled()) {
     ScratchCache &c = scratch_cache();
     int dev = 0;
@@ -189,6 +252,10 @@ static int gdn_scratch_malloc_raw(void **p, size_t bytes) {
 // build runs on the null stream; a caller that used another stream synchronises it before the buffer goes out of scope).
 void gdn_scratch_free(void *p) {
   if (!p) return;
+  if (gdn_alloc_fence()) {
+    (void)gdn_plain_free(p);
+    return;
+  }
   ScratchCache &c = scratch_cache();
   std::vector<void *> evict;
   int dev = -1;
@@ -466,12 +533,12 @@ int gdn_dev_alloc(uint64_t bytes, void **d_ptr) {
   GDN_REQUIRE(d_ptr != nullptr, "d_ptr");
   *d_ptr = nullptr;
   GDN_TRY(gdn_require_device());
-  GDN_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+  GDN_HIP(gdn_plain_malloc(d_ptr, bytes));
   return GDN_OK;
 }
 
 int gdn_dev_free(void *d_ptr) {
-  if (d_ptr) GDN_HIP(hipFree(d_ptr));
+  if (d_ptr) GDN_HIP(gdn_plain_free(d_ptr));
   return GDN_OK;
 }
 
@@ -500,8 +567,8 @@ int gdn_graph_upload(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int3
   g->m = m;
   g->nnz = nnz;
   g->owned = true;
-  hipError_t e = hipMalloc((void **)&g->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
-  if (e == hipSuccess) e = hipMalloc((void **)&g->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
+  hipError_t e = gdn_plain_malloc((void **)&g->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&g->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
   if (e == hipSuccess) e = hipMemcpy(g->rowptr, rowptr, ((size_t)m + 1) * sizeof(eoff_t), hipMemcpyHostToDevice);
   if (e == hipSuccess && nnz) e = hipMemcpy(g->colidx, colidx, nnz * sizeof(vid_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -536,8 +603,8 @@ int gdn_graph_upload_rows(int32_t m, const uint64_t *rowptr, const int32_t *coli
   s->owned = true;
   DevBuf<eoff_t> raw;
   int st = raw.alloc((size_t)s->m + 1);
-  hipError_t e = st == GDN_OK ? hipMalloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t)) : hipErrorOutOfMemory;
-  if (e == hipSuccess) e = hipMalloc((void **)&s->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
+  hipError_t e = st == GDN_OK ? gdn_plain_malloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t)) : hipErrorOutOfMemory;
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&s->colidx, (nnz ? nnz : 1) * sizeof(vid_t));
   if (e == hipSuccess) e = hipMemcpy(raw.p, rowptr + row_lo, ((size_t)s->m + 1) * sizeof(eoff_t), hipMemcpyHostToDevice);
   if (e == hipSuccess && nnz) e = hipMemcpy(s->colidx, colidx + e0, nnz * sizeof(vid_t), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -584,8 +651,8 @@ int gdn_graph_wrap_dev(int32_t m, uint64_t nnz, const uint64_t *d_rowptr, const 
 int gdn_graph_free(gdn_graph *g) {
   if (!g) return GDN_OK;
   if (g->owned) {
-    if (g->rowptr) (void)hipFree(g->rowptr);
-    if (g->colidx) (void)hipFree(g->colidx);
+    if (g->rowptr) (void)gdn_plain_free(g->rowptr);
+    if (g->colidx) (void)gdn_plain_free(g->colidx);
   }
   delete g;
   return GDN_OK;
@@ -620,8 +687,8 @@ int gdn_graph_slice_rows(const gdn_graph *g, int32_t row_lo, int32_t row_hi, gdn
   s->m = row_hi - row_lo;
   s->nnz = ends[1] - ends[0];
   s->owned = true;
-  hipError_t e = hipMalloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t));
-  if (e == hipSuccess) e = hipMalloc((void **)&s->colidx, (s->nnz ? s->nnz : 1) * sizeof(vid_t));
+  hipError_t e = gdn_plain_malloc((void **)&s->rowptr, ((size_t)s->m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&s->colidx, (s->nnz ? s->nnz : 1) * sizeof(vid_t));
   if (e == hipSuccess && s->nnz)
     e = hipMemcpy(s->colidx, g->colidx + ends[0], s->nnz * sizeof(vid_t), hipMemcpyDeviceToDevice);
   if (e != hipSuccess) {

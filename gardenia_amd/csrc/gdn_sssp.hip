@@ -1523,7 +1523,7 @@ static int sssp_build_tiers(gdn_sssp_plan &p, const gdn_graph *g, const int32_t 
   GDN_HIP(hipMemset(degs.p, 0, ((size_t)n_ts + 1) * 4));
   hipLaunchKernelGGL(sssp_tier_assign_kernel, dim3(gdn_nblocks(n_ts)), dim3(GDN_BLOCK), 0, 0, sorted, m, n_ts, cls.p, p.tier_ids.p,
                      degs.p);
-  GDN_TRY(gdn_exclusive_scan_u32_to_u64(degs.p, offs.p, (size_t)n_ts + 1, 0));
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(degs.p, offs.p, (size_t)n_ts, 0));  // (writes n_ts + 1 offsets: offs[n_ts] = all edges)
   eoff_t n_e = 0;
   GDN_HIP(hipMemcpy(&n_e, offs.p + n_ts, sizeof(eoff_t), hipMemcpyDeviceToHost));
   if (n_e == 0) {

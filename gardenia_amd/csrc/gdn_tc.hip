@@ -598,8 +598,8 @@ static int tc_orient(const gdn_graph *g, gdn_graph **out) {
   d->m = m;
   d->nnz = nnz_dag;
   d->owned = true;
-  hipError_t e = hipMalloc((void **)&d->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
-  if (e == hipSuccess) e = hipMalloc((void **)&d->colidx, (nnz_dag ? nnz_dag : 1) * sizeof(vid_t));
+  hipError_t e = gdn_plain_malloc((void **)&d->rowptr, ((size_t)m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&d->colidx, (nnz_dag ? nnz_dag : 1) * sizeof(vid_t));
   if (e != hipSuccess) {
     gdn_set_error("gdn_tc: %s", hipGetErrorString(e));
     gdn_graph_free(d);
@@ -961,8 +961,8 @@ static int tc_copy_graph(const gdn_graph *g, gdn_graph **out) {  // an owned cop
   d->m = g->m;
   d->nnz = g->nnz;
   d->owned = true;
-  hipError_t e = hipMalloc((void **)&d->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t));
-  if (e == hipSuccess) e = hipMalloc((void **)&d->colidx, (g->nnz ? g->nnz : 1) * sizeof(vid_t));
+  hipError_t e = gdn_plain_malloc((void **)&d->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t));
+  if (e == hipSuccess) e = gdn_plain_malloc((void **)&d->colidx, (g->nnz ? g->nnz : 1) * sizeof(vid_t));
   if (e == hipSuccess) e = hipMemcpy(d->rowptr, g->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t), hipMemcpyDeviceToDevice);
   if (e == hipSuccess && g->nnz) e = hipMemcpy(d->colidx, g->colidx, g->nnz * sizeof(vid_t), hipMemcpyDeviceToDevice);
   if (e != hipSuccess) {

@@ -1,0 +1,13 @@
+# Round-4 session 85: graphs and gdn_dev_alloc arrays fenced too: sweeps + the suite under GDN_ALLOC_FENCE=1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r04s85
+mkdir -p $O; rm -rf $O/*
+export OMP_NUM_THREADS=4
+B="FUZZ_PLANS=1 FUZZ_TRACE=1 GDN_PB_BUILDER=old GDN_PR_LAYOUT=p GDN_SPMV_LAYOUT=p GDN_PRD_LAYOUT=p GDN_PB_HUB_MIN_NNZ=1 GDN_PB_HUB_MIN=8 GDN_PB_MID_CAP=300 GDN_BFS_HEADS_MIN_NNZ=1 GDN_BFS_HUB_MIN=0 GDN_BFS_BU_EDGE_DIV=1000000000 GDN_BFS_BTD=0 GDN_SSSP_TIER_MIN_NNZ=1 GDN_SSSP_TIER_MIN_DEG=2"
+T="FUZZ_PLANS=1 FUZZ_TRACE=1 GDN_PR_LAYOUT=p GDN_SPMV_LAYOUT=p GDN_PRD_LAYOUT=p GDN_PB_HUB_MIN_NNZ=1 GDN_PB_HUB_MIN=8 GDN_PB_MID_CAP=300 GDN_BFS_HEADS_MIN_NNZ=1 GDN_BFS_HUB_MIN=0 GDN_BFS_BU_EDGE_DIV=1000000000 GDN_SSSP_TIER_MIN_NNZ=1 GDN_SSSP_TIER_MIN_DEG=2"
+rep() { echo "$1: $(grep -B4 'Memory access fault' $O/$1.txt | head -5 | tr '\n' ' ' | cut -c1-300) $(tail -1 $O/$1.txt | cut -c1-100)"; }
+( env $B GDN_ALLOC_FENCE=1 timeout 2400 python3 tests/aids/fuzz_parity.py 200 26000001 > $O/old_fence.txt 2>&1; rep old_fence ) &
+( env $T GDN_ALLOC_FENCE=1 timeout 2400 python3 tests/aids/fuzz_parity.py 200 27000001 > $O/tiers_fence.txt 2>&1; rep tiers_fence ) &
+( env FUZZ_PLANS=1 FUZZ_TRACE=1 GDN_ALLOC_FENCE=1 timeout 2400 python3 tests/aids/fuzz_parity.py 200 32000001 > $O/def_fence.txt 2>&1; rep def_fence ) &
+( GDN_ALLOC_FENCE=1 timeout 2400 python3 -m pytest tests -m gpu -q -x -p no:cacheprovider > $O/suite_fence.txt 2>&1; echo "suite_fence: $(tail -3 $O/suite_fence.txt | tr '\n' ' ' | cut -c1-300)" ) &
+wait

@@ -1105,6 +1105,23 @@ def test_sssp_sweeps_that_change_their_candidate_width(orc, monkeypatch):
     sp.close()
 
 
+def test_old_builder_tiers_under_the_allocation_fence():
+    """GDN_ALLOC_FENCE=1 puts every device buffer at the end of its own block of whole 2 MB pages, so a kernel that leaves
+    a buffer faults instead of touching a neighbour.  The old layout builder with SSSP's record tiers forced on small
+    graphs once scanned one element too many (sssp_build_tiers wrote 8 bytes behind its offsets: a memory fault in about
+    one of two 600-graph sweeps, profiles/sessions/r04_82.sh; under the fence graph 26000002 faults at once).  The
+    option is read once per process: three graphs of that sweep in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FUZZ_PLANS="1", GDN_ALLOC_FENCE="1", GDN_PB_BUILDER="old", GDN_PR_LAYOUT="p", GDN_SPMV_LAYOUT="p",
+               GDN_PRD_LAYOUT="p", GDN_PB_HUB_MIN_NNZ="1", GDN_PB_HUB_MIN="8", GDN_PB_MID_CAP="300", GDN_BFS_HEADS_MIN_NNZ="1",
+               GDN_BFS_HUB_MIN="0", GDN_SSSP_TIER_MIN_NNZ="1", GDN_SSSP_TIER_MIN_DEG="2")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "aids", "fuzz_parity.py"), "3", "26000001"], env=env, cwd=os.path.dirname(here),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "every solver equal to the oracle" in r.stdout, (r.returncode, r.stdout[-400:], r.stderr[-800:])
+
+
 def test_sssp_wide_weights_keep_the_blocked_layout(orc, monkeypatch, capfd):
     """Weights beyond 8 bits do not fit a record: the plan builds no tiers and every edge stays in the blocked layout."""
     monkeypatch.setenv("GDN_SSSP_TIER_MIN_NNZ", "1")
