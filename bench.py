@@ -676,7 +676,8 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
         if i:
             ms.append(st.solve_ms)
     L.gdn_tc_plan_free(tplan)
-    form = {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward (rank-ordered DAG, walks start behind v)"}.get(st.reserved, "?")
+    form = {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward (rank-ordered DAG, walks start behind v)"}.get(st.reserved & 0xFF, "?")
+    core_ranks = st.reserved >> 8  # forward count: the top ranks counted on the core bit matrix (tc_core_count_kernel)
     mm = med_min(ms)
     gbs = nbytes.value / (mm["median"] * 1e-3) / 1e9
     # what the kernel itself reads: ONE list per DAG edge (4 B x the probes of the formulation that ran) + the row's own
@@ -688,12 +689,13 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
     if hasattr(L, "gdn_tc_probe_counts"):
         _cabi.check(L.gdn_tc_probe_counts(dag, pr_))
         # forward form: SUM_u C(d+(u), 2) = (SUM_u d+(u)^2 - nnz) / 2 list elements (the out-degrees do not depend on the labelling)
-        walked = (pr_[1] - nnz.value) // 2 if st.reserved == 3 else (pr_[1] if st.reserved == 1 else pr_[0])
+        walked = (pr_[1] - nnz.value) // 2 if (st.reserved & 0xFF) == 3 else (pr_[1] if st.reserved == 1 else pr_[0])
         read_b = 4 * walked + 12 * nnz.value + 16 * (m.value + 1)
         list_gbs = read_b / (mm["median"] * 1e-3) / 1e9
     rec = {"workload": "triangle count, %s, DAG orientation by degree (src/common/graph.cc:67)" % what,
            "vertices": m.value, "undirected_csr_entries": snnz.value, "dag_edges": nnz.value, "triangles": total.value,
            "orient_s": t_orient, "plan_build_s": t_tplan, "ms": mm, "gteps": nnz.value / (mm["median"] * 1e-3) / 1e9, "formulation": form,
+           "core_ranks": core_ranks,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes.value,
                         "model": "4 SUM_(u,v) (d+(u) + d+(v)) + 8 nnz_dag + 8(m+1) (SURVEY 8d, merge-equivalent)",

@@ -821,6 +821,213 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   return GDN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The CORE of the forward count (round 4).  On a skewed graph most look-ups concern the few thousand vertices of highest
+// rank: symmetrized RMAT-22, rank-ordered DAG -- 59 % of the forward count's look-ups have their middle vertex v among the
+// top 8192 ranks (0.2 % of the vertices), 72 % among the top 16384 (numbers: DESIGN 4.7).  A member of N+(v) outranks v, so
+// for such a v every candidate lies in the same K ranks: the adjacency AMONG the top K ranks is kept as a K x K BIT MATRIX
+// (row v = N+(v); 8 MB at K = 8192: L2 / MALL resident), and a look-up becomes one bit of a row AND.
+//   for every u:  C(u) = N+(u) restricted to the core (a suffix of the ascending list), B_u = its bitmap (one wave: K / 64
+//                 bits per lane, in registers);  triangles(u, v in core) = SUM over v in C(u) of popcount(row_v AND B_u)
+// -- row_v holds only ranks above v, so every pair (v < w) of C(u) is met once.  A step of the hash-set kernel settles 64
+// look-ups with a 256-byte list load, 64 bucket reads and ~25 instructions; a row AND settles K candidates with K / 8 bytes
+// of a coalesced, cached row and ~6 instructions per 4096 of them.  Rows are only read between the word of v itself and the
+// word of C(u)'s last member.  The u with fewer than TC_CORE_SMALL core neighbours test their C(|C|, 2) pairs bit by bit
+// instead (a row per v would be mostly zeros of B_u): 0.6 % of the look-ups.
+// The rows v below the core stay with tc_count_kernel (its row range ends where the core begins): the two parts add up to
+// the forward count, whatever K is.
+// ------------------------------------------------------------------------------------------
+#define TC_CORE_SMALL 32  // |C(u)| below this: pair tests (must be <= 64: one id per lane)
+
+// one wave per core row: its list as bits
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_core_adj_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, unsigned base, unsigned k_core, unsigned kw,
+                   unsigned long long *__restrict__ adj) {
+  const unsigned lane = gdn_lane();
+  const size_t nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
+  for (size_t i = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; i < (size_t)k_core; i += nwaves) {
+    const eoff_t b = rowptr[base + i], e = rowptr[base + i + 1];
+    for (eoff_t k = b + lane; k < e; k += 64) {
+      const unsigned j = (unsigned)colidx[k] - base;  // > i: lists ascend in rank
+      atomicOr(&adj[i * kw + (j >> 6)], 1ull << (j & 63u));
+    }
+  }
+}
+// the rows with at least two core neighbours: item = length class << 62 | |C(u)| << 32 | u (C(u) is the END of the row);
+// cls[c] = items with |C(u)| >= tc_core_class_min(c) -- the list is partitioned by class afterwards and handed out longest
+// class first, see tc_core_count_kernel (a full sort by |C(u)| was measured: it scatters the rows of a grab over the whole
+// column array, 7.0 -> 7.8 ms at K = 4096)
+#define TC_CORE_CLASSES 4
+__device__ __host__ constexpr unsigned tc_core_class_min(int c) { return c == 0 ? 256u : c == 1 ? 64u : c == 2 ? 16u : 2u; }
+__device__ __host__ constexpr unsigned tc_core_class_take(int c) { return c == 0 ? 1u : c == 1 ? 4u : c == 2 ? 16u : 64u; }
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_core_items_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned base,
+                     unsigned long long *__restrict__ items, unsigned *__restrict__ n_items, unsigned *__restrict__ cls) {
+  const unsigned u = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  unsigned n = 0;
+  if (u < (unsigned)m) {
+    const eoff_t b = rowptr[u];
+    const unsigned d = (unsigned)(rowptr[u + 1] - b);
+    unsigned lo = 0, hi = d;
+    while (lo < hi) {  // first position with a core id
+      const unsigned mid = (lo + hi) >> 1;
+      if ((unsigned)colidx[b + mid] < base) lo = mid + 1;
+      else hi = mid;
+    }
+    n = d - lo;
+  }
+  const bool keep = n >= 2u;
+  const unsigned long long mask = __ballot(keep);
+  if (mask == 0ull) return;
+  unsigned at = 0, kc[TC_CORE_CLASSES - 1];
+#pragma unroll
+  for (int c = 0; c + 1 < TC_CORE_CLASSES; c++) kc[c] = (unsigned)__popcll(__ballot(n >= tc_core_class_min(c)));
+  if (gdn_lane() == 0) {
+    at = atomicAdd(n_items, (unsigned)__popcll(mask));
+#pragma unroll
+    for (int c = 0; c + 1 < TC_CORE_CLASSES; c++)
+      if (kc[c]) atomicAdd(&cls[c], kc[c]);
+  }
+  at = __shfl(at, 0, 64) + (unsigned)__popcll(mask & gdn_lanemask_lt());
+  if (keep) {  // bits 62..63: 3 - class (the list is then partitioned by these two bits, stable: rows stay in order inside a class)
+    const unsigned code = n >= tc_core_class_min(0) ? 3u : n >= tc_core_class_min(1) ? 2u : n >= tc_core_class_min(2) ? 1u : 0u;
+    items[at] = ((unsigned long long)code << 62) | ((unsigned long long)n << 32) | u;
+  }
+}
+
+typedef unsigned tc_u32x2 __attribute__((ext_vector_type(2)));
+template <int R>  // K = 4096 R: R 64-bit words of a row (and of B_u) per lane
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const unsigned long long *__restrict__ items,
+                     unsigned *__restrict__ ctl, const unsigned long long *__restrict__ adj, unsigned base,
+                     unsigned long long *__restrict__ total, unsigned small) {
+  constexpr unsigned KW = 64u * R;
+  // rows per group: 4 / 2 / 1 / 1 -- the kernel runs in the registers tc_count_kernel leaves free (160 per lane and SIMD
+  // beside its 4 x 88): two waves per SIMD need <= 80 (R = 4 with four rows per group: 110 -- one wave per SIMD, 27 ms
+  // beside the hash-set kernel where alone it takes 12; with one: 51).  Two groups are in flight either way.
+  constexpr int G = R >= 3 ? 1 : R == 2 ? 2 : 4;
+  __shared__ unsigned long long s_bm[GDN_WAVES_PER_BLOCK][KW];
+  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
+  const unsigned *__restrict__ adj32 = reinterpret_cast<const unsigned *>(adj);
+  unsigned long long count = 0;
+  // The list is partitioned by length class, shortest class first, and handed out from its END, class by class (ctl: [0] items, [1 + c] the cursor of
+  // class c, [5 + c] the items of at least class c's length): 1 item per grab among the longest, 64 among the shortest --
+  // one atomic on a shared cursor per short item costs more than the item (a hot address serves ~50 M atomics / s), 64
+  // long items in one grab are the kernel's tail.  A grab's items and row ends are loaded by its lanes side by side.
+  const unsigned n_items = ctl[0];
+  int cls = 0;  // (wave-uniform)
+  for (;;) {
+    unsigned it0 = 0, lim = 0, take = 0;
+    for (; cls < TC_CORE_CLASSES; cls++) {
+      const unsigned first = cls == 0 ? 0u : ctl[5 + cls - 1];
+      lim = cls + 1 < TC_CORE_CLASSES ? ctl[5 + cls] : n_items;
+      take = tc_core_class_take(cls);
+      if (first >= lim) continue;
+      if (lane == 0) it0 = atomicAdd(&ctl[1 + cls], take);
+      it0 = first + (unsigned)__builtin_amdgcn_readfirstlane((int)it0);
+      if (it0 < lim) break;
+    }
+    if (cls >= TC_CORE_CLASSES) break;
+    take = lim - it0 < take ? lim - it0 : take;
+    eoff_t ej = 0;
+    unsigned nj = 0;
+    if (lane < take) {
+      const unsigned long long item = items[n_items - 1u - (it0 + lane)];
+      nj = (unsigned)(item >> 32) & 0x3FFFFFFFu;
+      ej = rowptr[(unsigned)(item & 0xFFFFFFFFull) + 1u];
+    }
+    for (unsigned jt = 0; jt < take; jt++) {
+      const unsigned n = (unsigned)__builtin_amdgcn_readlane((int)nj, (int)jt);
+      const eoff_t b = (((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(ej >> 32), (int)jt) << 32) |
+                        (unsigned)__builtin_amdgcn_readlane((int)ej, (int)jt)) - n;  // C(u) is the end of the row
+      unsigned cnt = 0;
+      if (n < small) {
+        // pairs (i < j): lane j tests bit c_j of row c_i, four rows in flight
+        const unsigned cj = lane < n ? (unsigned)colidx[b + lane] - base : 0u;
+        for (unsigned i0 = 0; i0 + 1u < n; i0 += 4u) {
+          unsigned wd[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const unsigned i = i0 + (unsigned)q;
+            const unsigned ci = (unsigned)__builtin_amdgcn_readlane((int)cj, (int)(i < 63u ? i : 63u));
+            wd[q] = (lane > i && lane < n) ? adj32[(size_t)ci * (2u * KW) + (cj >> 5)] : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) cnt += (wd[q] >> (cj & 31u)) & 1u;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; r++) s_bm[w][lane + 64u * r] = 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        unsigned c_last = 0;
+        for (unsigned k = lane; k < n; k += 64u) {
+          const unsigned c = (unsigned)colidx[b + k] - base;
+          atomicOr(&s_bm[w][c >> 6], 1ull << (c & 63u));
+          c_last = c;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long B[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) B[r] = s_bm[w][lane + 64u * r];
+        // words behind the one of C(u)'s last member are zero in B_u: not read
+        const unsigned w_hi = (unsigned)__builtin_amdgcn_readlane((int)c_last, (int)((n - 1u) & 63u)) >> 6;
+        // A row is read through a BUFFER descriptor of its useful words [w_lo, w_hi] (scalar registers): lanes whose word
+        // lies outside get zero from the bounds check, without a branch and without a memory access -- with predicated loads
+        // every load sat in its own basic block and a group of rows cost a full round trip before the next was issued.
+        // G rows per group, the next group's loads issued before this group's popcounts.
+        for (unsigned k0 = 0; k0 + 1u < n; k0 += 64u) {
+          const unsigned ck = k0 + lane < n ? (unsigned)colidx[b + k0 + lane] - base : 0u;
+          const unsigned kn = n - 1u - k0 < 64u ? n - 1u - k0 : 64u;  // (the last member closes nothing)
+          auto issue = [&](unsigned kk, tc_u32x2 (&x)[G][R]) {
+#pragma unroll
+            for (int q = 0; q < G; q++) {
+              const unsigned k = kk + (unsigned)q;
+              const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)ck, (int)(k < 63u ? k : 63u));
+              const unsigned w_lo = c >> 6;  // row c holds ranks above c only
+              const unsigned bytes = (k < kn && w_hi >= w_lo) ? (w_hi - w_lo + 1u) * 8u : 0u;
+              const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                  const_cast<unsigned long long *>(adj + (size_t)c * KW + w_lo), (short)0, (int)bytes, 0x00020000);
+              const unsigned off = (lane - w_lo) * 8u;  // (wraps for the words below w_lo: out of range)
+#pragma unroll
+              for (int r = 0; r < R; r++) x[q][r] = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)(off + 512u * (unsigned)r), 0, 0);
+            }
+          };
+          auto consume = [&](const tc_u32x2 (&x)[G][R]) {
+#pragma unroll
+            for (int q = 0; q < G; q++)
+#pragma unroll
+              for (int r = 0; r < R; r++)
+                cnt += (unsigned)__popc(x[q][r].x & (unsigned)B[r]) + (unsigned)__popc(x[q][r].y & (unsigned)(B[r] >> 32));
+          };
+          tc_u32x2 x0[G][R], x1[G][R];
+          issue(0u, x0);
+          for (unsigned kk = 0; kk < kn; kk += 2u * G) {
+            issue(kk + (unsigned)G, x1);
+            consume(x0);
+            issue(kk + 2u * G, x0);
+            consume(x1);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // B_u is rebuilt for the next item
+      }
+      count += cnt;
+    }
+  }
+  count = gdn_wave_sum(count);
+  if (lane == 0) s_red[w] = count;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) t += s_red[i];
+    if (t) atomicAdd(total, t);
+  }
+}
+
 // SURVEY 8d's merge-equivalent traffic of a count: SUM over DAG edges (u,v) of d+(u) + d+(v) (a merge intersect reads both lists)
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_model_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned long long *__restrict__ out) {
@@ -885,8 +1092,11 @@ int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes) {
 // triangles closed over the source rows [row_lo, row_hi) of an oriented graph (the light-row cursor starts at row_lo and
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
 // dag_in != nullptr: the v-centric count over the rows [row_lo, row_hi) of the TRANSPOSED DAG's row space (same vertices)
+struct gdn_tc_plan;
+static int tc_core_launch(gdn_tc_plan &p);
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
-                         const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr) {
+                         const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr,
+                         gdn_tc_plan *core = nullptr /* its core kernel is queued right behind tc_count_kernel's launch */) {
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
@@ -927,6 +1137,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
                      nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart);
+  if (core) GDN_TRY(tc_core_launch(*core));
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -949,12 +1160,98 @@ struct gdn_tc_plan {
   gdn_graph *dag_in = nullptr;  // its transpose (forward / v-centric), owned
   DevBuf<unsigned> nstart;      // forward: walk starts, parallel to dag_in->colidx
   int form = 0;                 // 0 u-centric, 1 v-centric, 2 binary search, 3 forward
+  // forward: the core (tc_core_count_kernel): the top core_k ranks as a bit matrix, the rows with >= 2 core neighbours
+  unsigned core_k = 0;                  // 0: no core
+  DevBuf<unsigned long long> core_adj;  // core_k x core_k bits
+  DevBuf<unsigned long long> core_items_a, core_items_b;  // the items, sorted by |C(u)| (the radix sort leaves them in one of the two)
+  const unsigned long long *core_items = nullptr;
+  DevBuf<unsigned> core_ctl;            // [0] items, [1..4] the class cursors, [5..7] items of at least a class's length
+  DevBuf<unsigned long long> core_total;
+  hipStream_t core_stream = nullptr;    // the core kernel runs BESIDE tc_count_kernel (which fills half of a CU's wave slots)
   double prep_ms = 0;
   ~gdn_tc_plan() {
+    if (core_stream) (void)hipStreamDestroy(core_stream);
     if (dag_in) gdn_graph_free(dag_in);
     if (dag) gdn_graph_free(dag);
   }
 };
+
+// GDN_TC_CORE: ranks of the core (4096, 8192, 12288 or 16384; 0 = none).  Default 16384 from 2^21 vertices on: symmetrized
+// R-MAT, count beside the hash-set kernel, K = 0 / 8192 / 12288 / 16384 -- scale 21: 7.2 / 7.2 / 6.8 / 6.5 ms, 22: 15.4 / 15.6 /
+// 13.9 / 12.3, 23: 32.0 / 25.9 / 20.9 / 21.5, 24: 84.5 / 70.3 / 58.1 / 53.4 (profiles/r04_tc_core.txt).
+static int tc_core_build(gdn_tc_plan &p) {
+  const gdn_graph *dag = p.dag;
+  unsigned k = dag->m >= (1 << 21) ? 16384u : 0u;
+  if (const char *e = gdn_option("GDN_TC_CORE")) k = (unsigned)atoi(e);
+  k = k >= 16384u ? 16384u : (k / 4096u) * 4096u;  // whole lanes x 64 bits: 4096, 8192, 12288 or 16384
+  if (k == 0u || (unsigned)dag->m < k + 64u) return GDN_OK;
+  const unsigned base = (unsigned)dag->m - k, kw = k / 64u;
+  GDN_TRY(p.core_adj.alloc((size_t)k * kw));
+  GDN_TRY(p.core_items_a.alloc((size_t)dag->m));
+  GDN_TRY(p.core_ctl.alloc(8));
+  GDN_TRY(p.core_total.alloc(1));
+  GDN_HIP(hipMemsetAsync(p.core_adj.p, 0, (size_t)k * kw * 8, 0));
+  GDN_HIP(hipMemsetAsync(p.core_ctl.p, 0, 32, 0));
+  hipLaunchKernelGGL(tc_core_adj_kernel, dim3(k / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, base, k, kw,
+                     p.core_adj.p);
+  hipLaunchKernelGGL(tc_core_items_kernel, dim3(gdn_nblocks((uint64_t)dag->m)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, dag->m,
+                     base, p.core_items_a.p, p.core_ctl.p, p.core_ctl.p + 5);
+  GDN_HIP(hipGetLastError());
+  unsigned n_items = 0;
+  GDN_HIP(hipMemcpy(&n_items, p.core_ctl.p, 4, hipMemcpyDeviceToHost));
+  if (n_items == 0) {  // no row reaches the core twice: nothing to count there
+    p.core_adj.release();
+    p.core_items_a.release();
+    return GDN_OK;
+  }
+  GDN_TRY(p.core_items_b.alloc((size_t)n_items));
+  GDN_TRY(gdn_radix_sort_u64(p.core_items_a.p, p.core_items_b.p, n_items, 62u, 64u, &p.core_items));  // by class, stable
+  if (p.core_items == p.core_items_a.p) p.core_items_b.release();
+  else p.core_items_a.release();
+  {  // GDN_TC_CORE_ASYNC=0 (A/B knob): the core kernel in front of tc_count_kernel on the null stream instead of beside it
+    const char *e = gdn_option("GDN_TC_CORE_ASYNC");
+    if (!(e && e[0] == '0')) {  // lowest priority: its workgroups take the wave slots tc_count_kernel's LDS budget leaves free
+      int lo_pri = 0, hi_pri = 0;
+      GDN_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+      GDN_HIP(hipStreamCreateWithPriority(&p.core_stream, hipStreamNonBlocking, lo_pri));
+    }
+  }
+  p.core_k = k;
+  return GDN_OK;
+}
+static int tc_core_launch(gdn_tc_plan &p) {
+  const gdn_graph *dag = p.dag;
+  const unsigned base = (unsigned)dag->m - p.core_k;
+  GDN_HIP(hipMemsetAsync(p.core_ctl.p + 1, 0, 16, p.core_stream));
+  GDN_HIP(hipMemsetAsync(p.core_total.p, 0, 8, p.core_stream));
+  // Two workgroups per CU: 8 waves of <= 56 registers and 2-8 KB of LDS each fit beside tc_count_kernel's four workgroups
+  // (133 KB of LDS, 4 x 88 registers per SIMD lane) whichever of the two kernels reaches a CU first -- a grid that can fill
+  // the machine does so when it starts first, and the hash-set kernel then waits for its END (measured: 31 instead of 23 ms
+  // in about half of the runs)
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  unsigned per_cu = 2;  // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more of them slow the hash-set kernel)
+  if (const char *e = gdn_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
+  if (!p.core_stream) per_cu = 8;  // GDN_TC_CORE_ASYNC=0: alone on the device
+  const dim3 grid((unsigned)cus * per_cu), block(GDN_BLOCK);
+  unsigned small = TC_CORE_SMALL;  // GDN_TC_CORE_SMALL (tuning knob, 2..64): core lists shorter than this take the pair tests
+  if (const char *e = gdn_option("GDN_TC_CORE_SMALL")) small = atoi(e) < 2 ? 2u : atoi(e) > 64 ? 64u : (unsigned)atoi(e);
+#define TC_CORE_LAUNCH(R)                                                                                                        \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(tc_core_count_kernel<R>), grid, block, 0, p.core_stream, dag->rowptr, dag->colidx, p.core_items, \
+                     p.core_ctl.p, p.core_adj.p, base, p.core_total.p, small)
+  if (p.core_k == 4096u) TC_CORE_LAUNCH(1);
+  else if (p.core_k == 8192u) TC_CORE_LAUNCH(2);
+  else if (p.core_k == 12288u) TC_CORE_LAUNCH(3);
+  else TC_CORE_LAUNCH(4);
+#undef TC_CORE_LAUNCH
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
 
 static int tc_copy_graph(const gdn_graph *g, gdn_graph **out) {  // an owned copy (the plan outlives the caller's handle)
   gdn_graph *d = new gdn_graph();
@@ -1009,6 +1306,7 @@ int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan)
       p->form = bs ? 2 : p->dag_in ? 1 : 0;
     }
   }
+  if (rc == GDN_OK && forward && p->dag_in) rc = tc_core_build(*p);
   if (rc != GDN_OK) {
     delete p;
     return rc;
@@ -1025,13 +1323,31 @@ int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats) {
   int rc = GDN_OK;
   *total = 0;
   if (plan->form == 3) {
-    if (plan->dag_in) rc = tc_count_rows(plan->dag, 0, plan->dag->m, total, st, plan->dag_in, false, plan->nstart.p);
+    if (plan->dag_in) {
+      HostTimer tall;
+      tall.start();
+      rc = tc_count_rows(plan->dag, 0, plan->dag->m - (int32_t)plan->core_k, total, st, plan->dag_in, false, plan->nstart.p,
+                         plan->core_k ? plan : nullptr);
+      if (plan->core_k && hipStreamSynchronize(plan->core_stream) != hipSuccess && rc == GDN_OK) {
+        gdn_set_error("gdn_tc: core count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = GDN_ERR_HIP;
+      }
+      if (rc == GDN_OK && plan->core_k) {
+        unsigned long long hc = 0;
+        if (hipMemcpy(&hc, plan->core_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess) {
+          gdn_set_error("gdn_tc: core count kernel failed: %s", hipGetErrorString(hipGetLastError()));
+          rc = GDN_ERR_HIP;
+        }
+        *total += hc;
+        st.solve_ms = tall.stop_ms() - st.prep_ms;  // (prep_ms so far: the allocations of tc_count_rows)
+      }
+    }
   } else {
     rc = tc_count_rows(plan->dag, 0, plan->dag->m, total, st, plan->dag_in, plan->form == 2);
   }
   st.prep_ms += plan->prep_ms;
   st.edges_traversed = plan->dag->nnz;  // TEPS = DAG edges / s, src/tc/gpu_base.cu:60
-  st.reserved = plan->form;
+  st.reserved = plan->form | (int)(plan->core_k << 8);  // (bits 8..: ranks of the forward count's core)
   if (stats) *stats = st;
   return rc;
 }

@@ -422,7 +422,10 @@ int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stat
  * `reserved` 3 = the FORWARD count -- vertices relabelled by degree rank, the DAG = edges to higher ranks, its transpose
  * and, per DAG edge u -> v, where the walk of N+(u) starts (behind v: a member of N+(v) outranks v), which halves the
  * look-ups; taken from 2^24 DAG edges on -- 0 / 1 = the hash-set count on the reference's orientation, u- / v-centric;
- * 2 = the wave-per-edge binary-search intersect; GDN_TC_FORM = f | a | u | v | bs forces one).  `csr` is a symmetric graph
+ * 2 = the wave-per-edge binary-search intersect; GDN_TC_FORM = f | a | u | v | bs forces one.  Bits 8.. of `reserved`, forward
+ * count only: the ranks of its CORE -- from 2^21 vertices on the look-ups whose middle vertex is among the top 16384 ranks
+ * are counted on a bit matrix of those ranks, beside the hash-set kernel; GDN_TC_CORE = 0 | 4096 | 8192 | 12288 | 16384).
+ * `csr` is a symmetric graph
  * (oriented == 0) or ANY acyclic orientation of one (oriented != 0); it is not referenced after the call.
  * gdn_tc_dev == create + count + free, the preparation in stats.prep_ms. */
 typedef struct gdn_tc_plan gdn_tc_plan;

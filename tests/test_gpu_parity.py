@@ -1342,6 +1342,62 @@ def test_tc_oriented_input_that_is_no_dag_counts_like_the_reference_loop(orc, fo
     assert total == orc.tc(dag) and st["reserved"] == (3 if form else st["reserved"])
 
 
+@pytest.mark.parametrize("core", ["4096", "8192", "12288", "16384"])
+@pytest.mark.parametrize("scale,ef,seed", [(13, 16, 41), (15, 32, 43), (17, 8, 44)])
+def test_tc_forward_core_vs_oracle(orc, scale, ef, seed, core, monkeypatch):
+    """The forward count with its CORE: the middle vertices v among the top K ranks are counted on the K x K bit matrix
+    (tc_core_count_kernel: a row AND per (u, v), pair tests for the u with few core neighbours), the rows below the core
+    by the hash-set kernel -- together the forward count, for every K (the default takes a core of 16384 ranks from
+    2^21 vertices on).  RMAT-13 with K = 8192 / 16384: the graph is smaller than the core + 64 -- no core, the plain forward count."""
+    monkeypatch.setenv("GDN_TC_FORM", "f")
+    monkeypatch.setenv("GDN_TC_CORE", core)
+    g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
+    want = orc.tc(orc.tc_orient(g))
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    has_core = g.m >= int(core) + 64
+    assert total == want and st["reserved"] & 0xFF == 3 and st["reserved"] >> 8 == (int(core) if has_core else 0), (total, want, st)
+    dag = orc.tc_orient(g)
+    total, st = solvers.TCSolver(solvers.Graph(csr=dag), oriented=True)
+    assert total == want and st["reserved"] >> 8 == (int(core) if has_core else 0)
+
+
+def test_tc_forward_core_dense_and_sparse_shapes(orc, monkeypatch):
+    """Shapes the core meets at its edges: a clique larger than the pair-test limit inside a sparse graph (every member's
+    core list takes the row path), a star forest (core neighbours but no triangle), a graph whose top ranks are ALL of
+    equal degree (ties broken by id), and one with exactly core + 64 vertices."""
+    monkeypatch.setenv("GDN_TC_FORM", "f")
+    monkeypatch.setenv("GDN_TC_CORE", "4096")
+    rng = np.random.default_rng(808)
+    m = 4096 + 64
+    cl = rng.choice(m, 150, replace=False)
+    a, b = np.meshgrid(cl, cl)
+    src = [a[a != b].ravel()]
+    dst = [b[a != b].ravel()]
+    hubs = rng.choice(m, 40, replace=False)  # stars: many leaves around a few centres
+    leaves = rng.integers(0, m, 6000)
+    hub_of = hubs[rng.integers(0, 40, 6000)]
+    keep = leaves != hub_of
+    src += [leaves[keep], hub_of[keep]]
+    dst += [hub_of[keep], leaves[keep]]
+    ring = np.arange(m)  # everybody has degree >= 4: two rings
+    for step in (1, 7):
+        src += [ring, (ring + step) % m]
+        dst += [(ring + step) % m, ring]
+    g = graphio.symmetrize(graphio.build_csr(m, np.concatenate(src).astype(np.int64), np.concatenate(dst).astype(np.int64)))
+    want = orc.tc(orc.tc_orient(g))
+    assert want > 150 * 149 * 148 // 6 - 1
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want and st["reserved"] >> 8 == 4096, (total, want)
+    for knob, value in (("GDN_TC_CORE_SMALL", "2"), ("GDN_TC_CORE_SMALL", "64"), ("GDN_TC_CORE_ASYNC", "0"), ("GDN_TC_CORE_WGS", "8")):
+        monkeypatch.setenv(knob, value)  # every core list as rows / the short ones as pairs; in front of the hash-set kernel
+        total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+        assert total == want and st["reserved"] >> 8 == 4096, (knob, value, total, want)
+        monkeypatch.delenv(knob)
+    monkeypatch.setenv("GDN_TC_CORE", "0")
+    total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
+    assert total == want and st["reserved"] == 3
+
+
 @pytest.mark.parametrize("scale,ef,seed", [(13, 16, 41), (16, 8, 42)])
 def test_tc_vs_oracle_rmat(orc, scale, ef, seed, monkeypatch):
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))

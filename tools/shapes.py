@@ -154,7 +154,7 @@ def run_shape(name, make):
     assert total2 == want
     if st2["solve_ms"] < st["solve_ms"]:
         st = st2
-    rec["tc"] = {"triangles": want, "count_ms": st["solve_ms"], "form": {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward"}.get(int(st["reserved"]), str(st["reserved"]))}
+    rec["tc"] = {"triangles": want, "count_ms": st["solve_ms"], "form": {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward"}.get(int(st["reserved"]) & 0xFF, str(st["reserved"]))}
     lap("tc")
     # ---- BC from one source within the reference verifier's tolerance
     sc = np.zeros(g.m, np.float32)
