@@ -691,7 +691,8 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
         # forward form: SUM_u C(d+(u), 2) = (SUM_u d+(u)^2 - nnz) / 2 list elements (the out-degrees do not depend on the labelling)
         walked = (pr_[1] - nnz.value) // 2 if (st.reserved & 0xFF) == 3 else (pr_[1] if st.reserved == 1 else pr_[0])
         read_b = 4 * walked + 12 * nnz.value + 16 * (m.value + 1)
-        list_gbs = read_b / (mm["median"] * 1e-3) / 1e9
+        # with the core only the walks around middle vertices BELOW the top ranks are walks of lists: the figure has no meaning then
+        list_gbs = None if core_ranks else read_b / (mm["median"] * 1e-3) / 1e9
     rec = {"workload": "triangle count, %s, DAG orientation by degree (src/common/graph.cc:67)" % what,
            "vertices": m.value, "undirected_csr_entries": snnz.value, "dag_edges": nnz.value, "triangles": total.value,
            "orient_s": t_orient, "plan_build_s": t_tplan, "ms": mm, "gteps": nnz.value / (mm["median"] * 1e-3) / 1e9, "formulation": form,
@@ -699,17 +700,35 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes.value,
                         "model": "4 SUM_(u,v) (d+(u) + d+(v)) + 8 nnz_dag + 8(m+1) (SURVEY 8d, merge-equivalent)",
-                        "kernel": "tc_count_kernel",
+                        "kernel": "tc_count_kernel" + (" beside tc_core_count_kernel (the look-ups around the top %d ranks on a bit matrix, DESIGN 4.7)" % core_ranks if core_ranks else ""),
                         "note": "the model counts what a MERGE intersect reads (both lists of every DAG edge, whole); the forward "
                                 "count walks one list per edge from behind v on -- a quarter of those elements -- so this "
                                 "fraction is a speed relative to the merge formulation and can exceed 1; the physical rate is "
                                 "kernel_list_read_frac",
                         "kernel_list_read_gbs": list_gbs,
-                        "kernel_list_read_frac": list_gbs / HBM_PEAK_GBS if list_gbs else None,
+                        "kernel_list_read_frac": list_gbs / HBM_PEAK_GBS if list_gbs else None,  # (None with the core)
                         "kernel_list_read_model": "4 B x the list elements the formulation that ran walks (one list per DAG "
                                                   "edge, from behind v in the forward form) + 12 nnz_dag + 16(m+1): what the "
                                                   "kernel requests, not what the model credits; counters: profiles/r03_tc_pmc.md"}}
     attach_traffic(rec["roofline"], "tc", args.tc_scale, mm["median"] * 1e-3)
+    # A/B: the forward count without its core (round 3's kernel: every look-up a list element against the hash set)
+    if core_ranks:
+        try:
+            _cabi.check(L.gdn_option_set(b"GDN_TC_CORE", b"0"))
+            tn, msn = C.c_uint64(0), []
+            pn_ = C.c_void_p()
+            _cabi.check(L.gdn_tc_plan_create(dag, 1, C.byref(pn_)))
+            for i in range(5):
+                sn = _cabi.GdnStats()
+                _cabi.check(L.gdn_tc_plan_count(pn_, C.byref(tn), C.byref(sn)))
+                if i:
+                    msn.append(sn.solve_ms)
+            L.gdn_tc_plan_free(pn_)
+            rec["ab_forward_without_core"] = {"ms": med_min(msn), "same_count": tn.value == total.value}
+        except Exception as e:
+            log(f"[bench] tc core A/B skipped: {e}")
+        finally:
+            L.gdn_option_set(b"GDN_TC_CORE", None)
     # A/B: round 2's default (hash set, u- or v-centric on the reference's orientation, whichever probes less)
     try:
         _cabi.check(L.gdn_option_set(b"GDN_TC_FORM", b"a"))
