@@ -1199,7 +1199,10 @@ static int tc_core_build(gdn_tc_plan &p) {
   GDN_HIP(hipGetLastError());
   unsigned n_items = 0;
   GDN_HIP(hipMemcpy(&n_items, p.core_ctl.p, 4, hipMemcpyDeviceToHost));
-  if (n_items == 0) {  // no row reaches the core twice: nothing to count there
+  // The core pays where the graph is skewed: symmetrized R-MAT, a third of the rows reach the top ranks twice.  Where hardly a
+  // row does (lattice, uniform random, small-world at 2^22-2^24 vertices: its launch and empty grabs cost 0.35 ms of a 3-12 ms
+  // count, sessions/r04_98.sh) the hash-set kernel keeps every row.  GDN_TC_CORE set: the caller's choice, whatever the graph.
+  if (n_items == 0 || (!gdn_option("GDN_TC_CORE") && n_items < (unsigned)dag->m / 64u)) {
     p.core_adj.release();
     p.core_items_a.release();
     return GDN_OK;
