@@ -18,7 +18,10 @@ src = os.path.join(ROOT, "gpurun_out", tag, w)
 
 def totals(counter, reps):
     agg = collections.defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(os.path.join(src, "%s_%d" % (counter, reps), "**", "*_counter_collection.csv"), recursive=True):
+    found = glob.glob(os.path.join(src, "%s_%d" % (counter, reps), "**", "*_counter_collection.csv"), recursive=True)
+    # gpurun MERGES every session's files into gpurun_out/: one pass = one process = one file, the newest is this session's
+    # (summing all of them counted a workload once per session that had profiled it)
+    for f in sorted(found, key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             agg[k][0] += float(r["Counter_Value"]) * 1024.0
