@@ -1093,7 +1093,8 @@ int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes) {
 // the kernel's vertex bound is row_hi: the count kernel itself does not know about ranges)
 // dag_in != nullptr: the v-centric count over the rows [row_lo, row_hi) of the TRANSPOSED DAG's row space (same vertices)
 struct gdn_tc_plan;
-static int tc_core_launch(gdn_tc_plan &p);
+static int tc_core_prepare(gdn_tc_plan &p);           // cursors and total zeroed on the null stream, the core stream waits for that
+static int tc_core_launch(gdn_tc_plan &p, bool tail);  // tail: the grid that takes what is left once tc_count_kernel is done
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
                          const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr,
                          gdn_tc_plan *core = nullptr /* its core kernel is queued right behind tc_count_kernel's launch */) {
@@ -1132,13 +1133,17 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned light = dag->m >= (1 << 21) ? 512u : 256u;  // rows up to this many neighbours: one wave, whole (see TC_LIGHT_MIN)
   if (core) light = 128u;  // beside the core kernel (its rows are gone, the tail is what is left): RMAT-23 512 / 256 / 128 -> 21.7 / 21.3 / 20.7 ms
   if (const char *e = gdn_option("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
+  if (core) GDN_TRY(tc_core_prepare(*core));
   hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
                      row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3, light);
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
                      nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart);
-  if (core) GDN_TRY(tc_core_launch(*core));
+  if (core) {
+    GDN_TRY(tc_core_launch(*core, false));  // beside tc_count_kernel, on the core's stream
+    GDN_TRY(tc_core_launch(*core, true));   // behind it, on this stream
+  }
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1169,9 +1174,11 @@ struct gdn_tc_plan {
   DevBuf<unsigned> core_ctl;            // [0] items, [1..4] the class cursors, [5..7] items of at least a class's length
   DevBuf<unsigned long long> core_total;
   hipStream_t core_stream = nullptr;    // the core kernel runs BESIDE tc_count_kernel (which fills half of a CU's wave slots)
+  hipEvent_t core_ready = nullptr;      // cursors zeroed (null stream) -> the core's stream may start
   double prep_ms = 0;
   ~gdn_tc_plan() {
     if (core_stream) (void)hipStreamDestroy(core_stream);
+    if (core_ready) (void)hipEventDestroy(core_ready);
     if (dag_in) gdn_graph_free(dag_in);
     if (dag) gdn_graph_free(dag);
   }
@@ -1218,20 +1225,30 @@ static int tc_core_build(gdn_tc_plan &p) {
       int lo_pri = 0, hi_pri = 0;
       GDN_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
       GDN_HIP(hipStreamCreateWithPriority(&p.core_stream, hipStreamNonBlocking, lo_pri));
+      GDN_HIP(hipEventCreateWithFlags(&p.core_ready, hipEventDisableTiming));
     }
   }
   p.core_k = k;
   return GDN_OK;
 }
-static int tc_core_launch(gdn_tc_plan &p) {
+static int tc_core_prepare(gdn_tc_plan &p) {
+  GDN_HIP(hipMemsetAsync(p.core_ctl.p + 1, 0, 16, 0));
+  GDN_HIP(hipMemsetAsync(p.core_total.p, 0, 8, 0));
+  if (p.core_stream) {
+    GDN_HIP(hipEventRecord(p.core_ready, 0));
+    GDN_HIP(hipStreamWaitEvent(p.core_stream, p.core_ready, 0));
+  }
+  return GDN_OK;
+}
+static int tc_core_launch(gdn_tc_plan &p, bool tail) {
   const gdn_graph *dag = p.dag;
   const unsigned base = (unsigned)dag->m - p.core_k;
-  GDN_HIP(hipMemsetAsync(p.core_ctl.p + 1, 0, 16, p.core_stream));
-  GDN_HIP(hipMemsetAsync(p.core_total.p, 0, 8, p.core_stream));
+  if (tail && !p.core_stream) return GDN_OK;  // GDN_TC_CORE_ASYNC=0: the one grid already runs behind tc_count_kernel
   // Two workgroups per CU: 8 waves of <= 56 registers and 2-8 KB of LDS each fit beside tc_count_kernel's four workgroups
   // (133 KB of LDS, 4 x 88 registers per SIMD lane) whichever of the two kernels reaches a CU first -- a grid that can fill
   // the machine does so when it starts first, and the hash-set kernel then waits for its END (measured: 31 instead of 23 ms
-  // in about half of the runs)
+  // in about half of the runs).  A TAIL grid (on the null stream behind tc_count_kernel, same work list) can finish what is
+  // left when the hash-set kernel is done with the whole device -- see below.
   int cus = 256;
   {
     int dev = 0;
@@ -1242,11 +1259,20 @@ static int tc_core_launch(gdn_tc_plan &p) {
   unsigned per_cu = 2;  // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more of them slow the hash-set kernel)
   if (const char *e = gdn_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
   if (!p.core_stream) per_cu = 8;  // GDN_TC_CORE_ASYNC=0: alone on the device
+  if (tail) {
+    // OFF by default (GDN_TC_CORE_TAIL = workgroups per CU): at RMAT-23 the core's grid is done (18.6 ms) before the hash-set
+    // kernel beside it (20.3 ms; alone 15.5), and a tail grid that finds an empty list still costs 0.34 ms behind it
+    // (profiles/sessions/r04_103.sh)
+    per_cu = 0;
+    if (const char *e = gdn_option("GDN_TC_CORE_TAIL")) per_cu = (unsigned)atoi(e);
+    if (per_cu == 0) return GDN_OK;
+  }
+  hipStream_t stream = tail ? nullptr : p.core_stream;
   const dim3 grid((unsigned)cus * per_cu), block(GDN_BLOCK);
   unsigned small = TC_CORE_SMALL;  // GDN_TC_CORE_SMALL (tuning knob, 2..64): core lists shorter than this take the pair tests
   if (const char *e = gdn_option("GDN_TC_CORE_SMALL")) small = atoi(e) < 2 ? 2u : atoi(e) > 64 ? 64u : (unsigned)atoi(e);
 #define TC_CORE_LAUNCH(R)                                                                                                        \
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(tc_core_count_kernel<R>), grid, block, 0, p.core_stream, dag->rowptr, dag->colidx, p.core_items, \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(tc_core_count_kernel<R>), grid, block, 0, stream, dag->rowptr, dag->colidx, p.core_items, \
                      p.core_ctl.p, p.core_adj.p, base, p.core_total.p, small)
   if (p.core_k == 4096u) TC_CORE_LAUNCH(1);
   else if (p.core_k == 8192u) TC_CORE_LAUNCH(2);

@@ -1388,7 +1388,7 @@ def test_tc_forward_core_dense_and_sparse_shapes(orc, monkeypatch):
     assert want > 150 * 149 * 148 // 6 - 1
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
     assert total == want and st["reserved"] >> 8 == 4096, (total, want)
-    for knob, value in (("GDN_TC_CORE_SMALL", "2"), ("GDN_TC_CORE_SMALL", "64"), ("GDN_TC_CORE_ASYNC", "0"), ("GDN_TC_CORE_WGS", "8")):
+    for knob, value in (("GDN_TC_CORE_SMALL", "2"), ("GDN_TC_CORE_SMALL", "64"), ("GDN_TC_CORE_ASYNC", "0"), ("GDN_TC_CORE_WGS", "8"), ("GDN_TC_CORE_TAIL", "6")):
         monkeypatch.setenv(knob, value)  # every core list as rows / the short ones as pairs; in front of the hash-set kernel
         total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
         assert total == want and st["reserved"] >> 8 == 4096, (knob, value, total, want)
