@@ -328,6 +328,16 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     const eoff_t cb = ub + (eoff_t)c0;
     vid_t x0 = 0;  // the first 64 ids of the pass: loaded once for the hash build and the clean-up
     if (lane < (unsigned)cn) x0 = colidx[cb + lane];
+    // the first 64 neighbours and their list bounds, requested BEFORE the set is built: behind the build's fence they were a
+    // third and fourth dependent round trip of every row (set ids -> neighbour ids -> bounds -> lists), and a light row is
+    // little more than that chain
+    eoff_t vb0 = 0, ve0 = 0;
+    if (vlo + lane < vhi) {
+      const vid_t v = (ncol == colidx && vlo == cb) ? x0 : ncol[vlo + lane];
+      vb0 = rowptr[v];
+      ve0 = rowptr[v + 1];
+      if (nstart) vb0 += nstart[vlo + lane];
+    }
     for (int i = lane; i < cn; i += 64) {  // build: integer LDS CAS, linear probing
       tc_insert(s_tab, i < 64 ? x0 : colidx[cb + i]);
     }
@@ -340,12 +350,15 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     for (eoff_t i0 = vlo; i0 < vhi; i0 += 64) {
 #endif
       const eoff_t i = i0 + lane;
-      eoff_t vb = 0, ve = 0;
-      if (i < vhi) {
-        const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
-        vb = rowptr[v];
-        ve = rowptr[v + 1];
-        if (nstart) vb += nstart[i];
+      eoff_t vb = vb0, ve = ve0;
+      if (i0 != vlo) {
+        vb = ve = 0;
+        if (i < vhi) {
+          const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
+          vb = rowptr[v];
+          ve = rowptr[v + 1];
+          if (nstart) vb += nstart[i];
+        }
       }
 #if defined(TC_ABL) && TC_ABL == 7  // timing-only ablation: neighbour ids + bounds loaded, lists not walked
       count += (unsigned long long)((ve - vb) & 1);
