@@ -95,10 +95,20 @@ keys_flag_kernel(const unsigned long long *__restrict__ keys, unsigned long long
   }
 }
 
+// Rows without a key take the offset of the next row that has one.  The thread of a row's first key fills the rows in
+// front of it -- a few, on the graphs of the bench; but a run of empty rows is ONE thread's loop, and the rank-ordered DAG
+// of the forward triangle count starts with every vertex of degree 0 (half of an R-MAT graph): 4 M stores by one thread,
+// 100 ms per CSR, 200 of the 240 ms of that plan build (profiles/sessions/r04_103.sh).  Runs of more than KEYS_GAP_LONG
+// rows are listed instead and filled by the whole grid (keys_fill_gaps_kernel).
+#define KEYS_GAP_LONG 256
+struct KeysGap {
+  unsigned long long first, last;  // rows [first, last]
+  eoff_t value;
+};
 __global__ void __launch_bounds__(GDN_BLOCK)
 keys_compact_kernel(const unsigned long long *__restrict__ keys, const unsigned *__restrict__ flag,
                     const eoff_t *__restrict__ pos, unsigned long long n, int32_t m, vid_t *__restrict__ colidx,
-                    eoff_t *__restrict__ rowptr) {
+                    eoff_t *__restrict__ rowptr, KeysGap *__restrict__ gaps, unsigned *__restrict__ n_gaps) {
   unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   for (; i < n; i += stride) {
@@ -107,9 +117,32 @@ keys_compact_kernel(const unsigned long long *__restrict__ keys, const unsigned 
     // row boundaries on the unfiltered sorted stream: rowptr[r] = #kept before the first key of row >= r
     const long long row = (long long)(k >> 32);
     const long long prev = (i > 0) ? (long long)(keys[i - 1] >> 32) : -1ll;
-    for (long long r = prev + 1; r <= row; r++) rowptr[r] = pos[i];
-    if (i + 1 == n)
-      for (long long r = row + 1; r <= (long long)m; r++) rowptr[r] = pos[n];
+    if (row - prev > KEYS_GAP_LONG) {
+      KeysGap g;
+      g.first = (unsigned long long)(prev + 1);
+      g.last = (unsigned long long)row;
+      g.value = pos[i];
+      gaps[atomicAdd(n_gaps, 1u)] = g;  // (at most m / KEYS_GAP_LONG + 1 of them: the list's capacity)
+    } else {
+      for (long long r = prev + 1; r <= row; r++) rowptr[r] = pos[i];
+    }
+    if (i + 1 == n && row < (long long)m) {  // the rows behind the last key
+      KeysGap g;
+      g.first = (unsigned long long)(row + 1);
+      g.last = (unsigned long long)m;
+      g.value = pos[n];
+      gaps[atomicAdd(n_gaps, 1u)] = g;
+    }
+  }
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+keys_fill_gaps_kernel(const KeysGap *__restrict__ gaps, const unsigned *__restrict__ n_gaps, eoff_t *__restrict__ rowptr) {
+  const unsigned long long tid = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  const unsigned ng = *n_gaps;
+  for (unsigned g = 0; g < ng; g++) {
+    const KeysGap gp = gaps[g];
+    for (unsigned long long r = gp.first + tid; r <= gp.last; r += stride) rowptr[r] = gp.value;
   }
 }
 
@@ -174,8 +207,19 @@ static int csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long lo
   if (n == 0) {
     hipLaunchKernelGGL(zero_rowptr_kernel, dim3(gdn_nblocks((uint64_t)m + 1)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m);
   } else {
+    DevBuf<KeysGap> gaps;
+    DevBuf<unsigned> n_gaps;
+    int rc = gaps.alloc_scratch((size_t)m / KEYS_GAP_LONG + 2);
+    if (rc == GDN_OK) rc = n_gaps.alloc_scratch(1);
+    if (rc != GDN_OK || hipMemsetAsync(n_gaps.p, 0, 4, 0) != hipSuccess) {
+      gdn_graph_free(g);
+      return rc != GDN_OK ? rc : GDN_ERR_HIP;
+    }
     hipLaunchKernelGGL(keys_compact_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, sorted, flag.p, pos.p, n, m, g->colidx,
-                       g->rowptr);
+                       g->rowptr, gaps.p, n_gaps.p);
+    hipLaunchKernelGGL(keys_fill_gaps_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, gaps.p, n_gaps.p, g->rowptr);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipDeviceSynchronize());  // (gaps / n_gaps go back to the scratch cache here)
   }
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());

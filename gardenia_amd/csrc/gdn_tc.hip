@@ -1232,13 +1232,19 @@ static int tc_core_build(gdn_tc_plan &p) {
   GDN_TRY(gdn_radix_sort_u64(p.core_items_a.p, p.core_items_b.p, n_items, 62u, 64u, &p.core_items));  // by class, stable
   if (p.core_items == p.core_items_a.p) p.core_items_b.release();
   else p.core_items_a.release();
-  {  // GDN_TC_CORE_ASYNC=0 (A/B knob): the core kernel in front of tc_count_kernel on the null stream instead of beside it
+  {  // GDN_TC_CORE_ASYNC=0 (A/B knob): the core kernel behind tc_count_kernel on the null stream instead of beside it
     const char *e = gdn_option("GDN_TC_CORE_ASYNC");
     if (!(e && e[0] == '0')) {  // lowest priority: its workgroups take the wave slots tc_count_kernel's LDS budget leaves free
       int lo_pri = 0, hi_pri = 0;
-      GDN_HIP(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-      GDN_HIP(hipStreamCreateWithPriority(&p.core_stream, hipStreamNonBlocking, lo_pri));
-      GDN_HIP(hipEventCreateWithFlags(&p.core_ready, hipEventDisableTiming));
+      if (hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess ||
+          hipStreamCreateWithPriority(&p.core_stream, hipStreamNonBlocking, lo_pri) != hipSuccess ||
+          hipEventCreateWithFlags(&p.core_ready, hipEventDisableTiming) != hipSuccess) {
+        // no second stream to be had: the same count, the core kernel behind the hash-set kernel (a full grid)
+        (void)hipGetLastError();
+        if (p.core_stream) (void)hipStreamDestroy(p.core_stream);
+        p.core_stream = nullptr;
+        p.core_ready = nullptr;
+      }
     }
   }
   p.core_k = k;

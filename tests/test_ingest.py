@@ -116,6 +116,37 @@ def test_device_builder_matches_numpy(m, n, seed, sym):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("where", ["front", "back", "middle", "islands"])
+def test_device_builder_with_long_runs_of_empty_rows(where):
+    """Rows without an edge take the offset of the next row that has one.  Short runs are filled by the thread of that row's
+    first key; a run of more than 256 rows is listed and filled by a grid of its own (keys_fill_gaps_kernel) -- one thread
+    storing 4 M offsets was 100 ms per CSR of the rank-ordered DAG of the forward triangle count, whose first half are the
+    vertices of degree 0.  Runs in front of the first edge, behind the last one, in the middle, and many of every length."""
+    m = 1 << 22
+    rng = np.random.default_rng(44)
+    if where == "islands":  # blocks of 1 .. 3000 vertices with edges among themselves, 1 .. 3000 empty rows between them
+        src, dst, v = [], [], 0
+        while v < m - 8000:
+            w = int(rng.integers(1, 3000))
+            e = rng.integers(v, v + w, 2 * w)
+            src.append(e)
+            dst.append(rng.integers(v, v + w, 2 * w))
+            v += w + int(rng.integers(1, 3000))
+        src, dst = np.concatenate(src), np.concatenate(dst)
+    else:
+        lo, hi = {"front": (m - 5000, m), "back": (0, 5000), "middle": (m // 2, m // 2 + 5000)}[where]
+        src = rng.integers(lo, hi, 100000)
+        dst = rng.integers(lo, hi, 100000)
+        if where == "middle":  # and one edge at either end
+            src = np.concatenate([src, [0, m - 1]])
+            dst = np.concatenate([dst, [m - 1, 0]])
+    for sym in (False, True):
+        got = graphio.build_csr_device(m, src, dst, sym)
+        s, d = (np.concatenate([src, dst]), np.concatenate([dst, src])) if sym else (src, dst)
+        assert same(got, graphio.build_csr(m, s, d)), (where, sym)
+
+
+@pytest.mark.gpu
 def test_device_builder_rejects_bad_ids():
     with pytest.raises(_cabi.GardeniaError) as ei:
         graphio.build_csr_device(4, np.array([0, 4]), np.array([1, 2]))
