@@ -924,8 +924,8 @@ tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict_
   const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
   const unsigned *__restrict__ adj32 = reinterpret_cast<const unsigned *>(adj);
   unsigned long long count = 0;
-  // The list is partitioned by length class, shortest class first, and handed out from its END, class by class (ctl: [0] items, [1 + c] the cursor of
-  // class c, [5 + c] the items of at least class c's length): 1 item per grab among the longest, 64 among the shortest --
+  // The list is partitioned by length class, shortest class first, and handed out from its END, class by class (ctl: [0]
+  // items, [1 + c] the cursor of class c, [5 + c] the items of at least class c's length): 1 item per grab among the longest, 64 among the shortest --
   // one atomic on a shared cursor per short item costs more than the item (a hot address serves ~50 M atomics / s), 64
   // long items in one grab are the kernel's tail.  A grab's items and row ends are loaded by its lanes side by side.
   const unsigned n_items = ctl[0];
@@ -1144,7 +1144,8 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
     return GDN_OK;
   }
   unsigned light = dag->m >= (1 << 21) ? 512u : 256u;  // rows up to this many neighbours: one wave, whole (see TC_LIGHT_MIN)
-  if (core) light = 128u;  // beside the core kernel (its rows are gone, the tail is what is left): RMAT-23 512 / 256 / 128 -> 21.7 / 21.3 / 20.7 ms
+  // beside the core kernel (its rows are gone, the tail is what is left): RMAT-23 512 / 256 / 128 -> 21.7 / 21.3 / 20.7 ms
+  if (core) light = 128u;
   if (const char *e = gdn_option("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
   if (core) GDN_TRY(tc_core_prepare(*core));
   hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
@@ -1275,7 +1276,8 @@ static int tc_core_launch(gdn_tc_plan &p, bool tail) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  unsigned per_cu = 2;  // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more of them slow the hash-set kernel)
+  // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more slow the hash-set kernel)
+  unsigned per_cu = 2;
   if (const char *e = gdn_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
   if (!p.core_stream) per_cu = 8;  // GDN_TC_CORE_ASYNC=0: alone on the device
   if (tail) {
