@@ -925,9 +925,10 @@ tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict_
   const unsigned *__restrict__ adj32 = reinterpret_cast<const unsigned *>(adj);
   unsigned long long count = 0;
   // The list is partitioned by length class, shortest class first, and handed out from its END, class by class (ctl: [0]
-  // items, [1 + c] the cursor of class c, [5 + c] the items of at least class c's length): 1 item per grab among the longest, 64 among the shortest --
-  // one atomic on a shared cursor per short item costs more than the item (a hot address serves ~50 M atomics / s), 64
-  // long items in one grab are the kernel's tail.  A grab's items and row ends are loaded by its lanes side by side.
+  // items, [1 + c] the cursor of class c, [5 + c] the items of at least class c's length): 1 item per grab among the
+  // longest, 64 among the shortest -- one atomic on a shared cursor per short item costs more than the item (a hot address
+  // serves ~50 M atomics / s), 64 long items in one grab are the kernel's tail.  A grab's items and row ends are loaded by
+  // its lanes side by side.
   const unsigned n_items = ctl[0];
   int cls = 0;  // (wave-uniform)
   for (;;) {
