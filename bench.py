@@ -104,12 +104,6 @@ def physical_cores():
 
 
 def main():
-    # SURVEY 8d: the host baseline runs on all PHYSICAL cores, OMP_PROC_BIND=spread.  Set before any OpenMP runtime is
-    # loaded (torch brings one); a caller's own settings win.
-    n_phys = physical_cores()
-    os.environ.setdefault("OMP_NUM_THREADS", str(n_phys))
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "cores")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -137,12 +131,30 @@ def main():
     ap.add_argument("--spmv-scale", type=int, default=25)
     ap.add_argument("--tc-scale", type=int, default=23)
     ap.add_argument("--trav-scale", type=int, default=24, help="R-MAT scale of the SSSP / CC block")
+    ap.add_argument("--standin-shrink", type=int, default=0,
+                    help="TEST ONLY: the LJ-like / Orkut-like stand-ins at 2^-k of their size (scale - k, draws >> k)")
     ap.add_argument("--reps", type=int, default=12, help="repetitions behind every median / min")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-converged-parity", action="store_true",
+                    help="skip parity_note.converged: the timed plan solved to epsilon 1e-4 against the CPU oracle's full solve "
+                         "(about a minute of host time at RMAT-27 on 128 cores)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
+
+    # SURVEY 8d: the host baseline runs on all PHYSICAL cores, OMP_PROC_BIND=spread.  Set before any OpenMP runtime is
+    # loaded (torch brings one); a caller's own settings win.
+    # Only the process that runs the CPU baseline takes them (rank 0 of an N = 1 job): the ranks of an N > 1 launch would
+    # each bind a full-machine thread team to the same cores -- they get their share of the cores instead.
+    n_phys = physical_cores()
+    n_ranks_here = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")) or 1)
+    if n_ranks_here <= 1:
+        os.environ.setdefault("OMP_NUM_THREADS", str(n_phys))
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
+    else:
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, n_phys // n_ranks_here)))
 
     import numpy as np
     import torch  # before libgardenia_hip: both must share ONE libamdhip64 (same SONAME)
@@ -483,6 +495,42 @@ def main():
                                 "adds them exactly (DESIGN 5); tests/test_gpu_configs.py asserts <= 500 such rows of all "
                                 "2^27 and max_rel <= 2.5e-3, and that the GPU value is the one an fp64 evaluation gives"}
                     log(f"[bench] parity note: {out['parity_note']}")
+                    # ---- the same at CONVERGENCE: the timed plan iterated to epsilon 1e-4 against the
+                    # oracle's own solve of the whole graph (src/pr/omp_base.cc:8-42, all rows, OpenMP on the host cores)
+                    if not args.no_converged_parity:
+                        tcv = time.time()
+                        want, it_cpu, trace_cpu = orc.pr(gi, h_deg)
+                        t_cpu_solve = time.time() - tcv
+                        _cabi.check(L.gdn_pr_import_dev(be.plan, pp(start), pp(state), 0.85, None))
+                        dead = C.c_double(0)
+                        _cabi.check(L.gdn_pr_import_diff(be.plan, C.byref(dead)))
+                        _cabi.check(L.gdn_pr_contrib_dev(be.plan, pp(state), pp(cc[0]), None))
+                        trace_gpu, it_gpu = [], 0
+                        for k in range(100):
+                            _cabi.check(L.gdn_pr_pull_dev(be.plan, pp(cc[k & 1]), pp(state), pp(cc[(k + 1) & 1]), pp(dd), 0.85, None))
+                            trace_gpu.append(float(dd.item()) + (dead.value if k == 0 else 0.0))
+                            it_gpu = k + 1
+                            if trace_gpu[-1] < 1e-4:
+                                break
+                        _cabi.check(L.gdn_pr_export_dev(be.plan, pp(state), pp(got), 0.85, None))
+                        torch.cuda.synchronize()
+                        g_all = got.cpu().numpy()
+                        relc = np.abs(g_all - want) / want
+                        offc = np.nonzero(relc >= 1e-4)[0]
+                        indeg_all = np.diff(h_rp.astype(np.int64))
+                        nt = min(len(trace_gpu), len(trace_cpu))
+                        out["parity_note"]["converged"] = {
+                            "iterations_gpu": it_gpu, "iterations_cpu": int(it_cpu), "rows_compared": int(m),
+                            "rows_beyond_tolerance_converged": int(len(offc)), "max_rel_converged": float(relc.max()),
+                            "min_in_degree_of_those_rows": int(indeg_all[offc].min()) if len(offc) else None,
+                            "trace_max_rel_diff": float(max(abs(a - b) / b for a, b in zip(trace_gpu[:nt], trace_cpu[:nt]))) if nt else None,
+                            "cpu_solve_s": t_cpu_solve,
+                            "what": "the timed plan iterated from 1/m until the L1 change < 1e-4 vs the CPU restatement of "
+                                    "src/pr/omp_base.cc:8-42 solving the whole graph; tests/test_gpu_fullsize.py asserts the "
+                                    "same through the PRSolver drop-in, and that GDN_PR_SUM=reference on the rows of >= 10^4 "
+                                    "in-edges leaves no row beyond 1e-4"}
+                        log(f"[bench] converged parity: {out['parity_note']['converged']}")
+                        del want, g_all, relc
                     del start, state, cc, got
             except Exception as e:
                 log(f"[bench] parity note skipped: {e}")
@@ -516,6 +564,10 @@ def main():
             out["pr_oneshot"] = bench_pr_oneshot(L, _cabi, graphio, np, args)
         except Exception as e:
             log(f"[bench] pr_oneshot block skipped: {e}")
+        try:
+            out["standins"] = bench_standins(L, _cabi, graphio, torch, np, device, args)
+        except Exception as e:
+            log(f"[bench] stand-in block skipped: {e}")
 
     if rank == 0:
         print(json.dumps(out), flush=True)
@@ -634,6 +686,23 @@ def bench_spmv(L, _cabi, graphio, torch, np, device, args):
                           "frac_solve_plus_prep": nbytes / ((st.solve_ms + st.prep_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS
                           if st.solve_ms + st.prep_ms > 0 else 0.0})
         rec["oneshot_gdn_spmv"] = shots
+        # the same call with GDN_SPMV_ONESHOT=solve: the blocked layout, its build in prep_ms -- the timing boundary of the
+        # reference's own blocked solver (segmenting() in front of the Timer, src/spmv/partition.cu:206,269-291); wall time
+        # (prep + solve) is worse than the default's, which is why it is an option
+        _cabi.check(L.gdn_option_set(b"GDN_SPMV_ONESHOT", b"solve"))
+        try:
+            st = _cabi.GdnStats()
+            h_y2 = np.zeros(m, np.float32)
+            _cabi.check(L.gdn_spmv(m, nnz, h_rp.ctypes.data_as(C.c_void_p), h_ci.ctypes.data_as(C.c_void_p),
+                                   h_Ax.ctypes.data_as(C.c_void_p), h_x.ctypes.data_as(C.c_void_p),
+                                   h_y2.ctypes.data_as(C.c_void_p), C.byref(st)))
+            rec["oneshot_gdn_spmv_blocked_layout"] = {
+                "option": "GDN_SPMV_ONESHOT=solve", "solve_ms": st.solve_ms, "prep_ms": st.prep_ms, "h2d_ms": st.h2d_ms,
+                "frac_solve": nbytes / (st.solve_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if st.solve_ms > 0 else 0.0,
+                "frac_solve_plus_prep": nbytes / ((st.solve_ms + st.prep_ms) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "max_rel_diff_vs_default_call": float((np.abs(h_y2 - h_y / 2) / np.maximum(np.abs(h_y2), 1e-30)).max())}
+        finally:
+            L.gdn_option_set(b"GDN_SPMV_ONESHOT", None)
     except Exception as e:
         log(f"[bench] spmv one-shot skipped: {e}")
     L.gdn_graph_free(g_in)
@@ -711,6 +780,17 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
                                                   "edge, from behind v in the forward form) + 12 nnz_dag + 16(m+1): what the "
                                                   "kernel requests, not what the model credits; counters: profiles/r03_tc_pmc.md"}}
     attach_traffic(rec["roofline"], "tc", args.tc_scale, mm["median"] * 1e-3)
+    # the one-shot drop-in on the resident DAG (what TCSolver binds to: no plan handed in; the preparation -- rank order, transpose,
+    # walk starts, core matrix -- is stats.prep_ms, the count stats.solve_ms)
+    try:
+        shots = []
+        for _ in range(3):
+            so, t1 = _cabi.GdnStats(), C.c_uint64(0)
+            _cabi.check(L.gdn_tc_dev(dag, 1, C.byref(t1), C.byref(so)))
+            shots.append({"prep_ms": so.prep_ms, "solve_ms": so.solve_ms, "same_count": t1.value == total.value})
+        rec["oneshot_gdn_tc_dev"] = shots
+    except Exception as e:
+        log(f"[bench] tc one-shot skipped: {e}")
     # A/B: the forward count without its core (round 3's kernel: every look-up a list element against the hash set)
     if core_ranks:
         try:
@@ -769,6 +849,109 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
         L.gdn_option_set(b"GDN_TC_FORM", None)
     L.gdn_graph_free(dag)
     log(f"[bench] tc: {rec}")
+    return rec
+
+
+def bench_standins(L, _cabi, graphio, torch, np, device, args):
+    """BASELINE configs 2 and 4 on graphs SHAPED like their inputs (graphio.LJ_LIKE / ORKUT_LIKE: gdn_rmat_build_ex with milder
+    quadrant probabilities and the ids without an edge dropped; soc-LiveJournal1 and com-Orkut themselves are wget lines,
+    datasets/test.mk:5,8): PageRank pull iteration on the LJ-like graph (resident plan, as the headline), triangle count on the
+    symmetrized Orkut-like graph.  Every tuning decision of rounds 3-4 was made on Graph500 R-MAT; these say what it is worth
+    on a flatter degree distribution without isolated vertices."""
+    rec = {}
+    shrink = lambda r: dict(r, scale=r["scale"] - args.standin_shrink, n_edges=r["n_edges"] >> args.standin_shrink)
+    # ---- PageRank, LJ-like
+    r = shrink(graphio.LJ_LIKE)
+    go, gi = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build_ex(r["scale"], r["n_edges"], *r["abc"], graphio.K_RAND_SEED, r["flags"], C.byref(go), C.byref(gi)))
+    m, nnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(gi, C.byref(m), C.byref(nnz), None, None))
+    m, nnz = m.value, nnz.value
+    deg = torch.empty(m, dtype=torch.int32, device=device)
+    _cabi.check(L.gdn_graph_degrees_dev(go, C.c_void_p(deg.data_ptr()), None))
+    indeg = torch.empty(m, dtype=torch.int32, device=device)
+    _cabi.check(L.gdn_graph_degrees_dev(gi, C.c_void_p(indeg.data_ptr()), None))
+    L.gdn_graph_free(go)
+    pp = lambda t: C.c_void_p(t.data_ptr())
+    t0 = time.time()
+    plan = C.c_void_p()
+    _cabi.check(L.gdn_pr_plan_create(gi, pp(deg), m, 0, _cabi.GDN_LAYOUT_PB_SQUISHED, C.byref(plan)))
+    t_plan = time.time() - t0
+    ms_ = C.c_int32()
+    _cabi.check(L.gdn_pr_plan_state_size(plan, C.byref(ms_)))
+    start = torch.full((m,), 1.0 / m, dtype=torch.float32, device=device)
+    state = torch.empty(ms_.value, dtype=torch.float32, device=device)
+    cc = [torch.zeros(ms_.value + 4, dtype=torch.float32, device=device) for _ in range(2)]
+    dd = torch.zeros(1, dtype=torch.float64, device=device)
+    _cabi.check(L.gdn_pr_import_dev(plan, pp(start), pp(state), 0.85, None))
+    _cabi.check(L.gdn_pr_contrib_dev(plan, pp(state), pp(cc[0]), None))
+    reps = max(args.reps, 10)
+    for k in range(3):
+        _cabi.check(L.gdn_pr_pull_dev(plan, pp(cc[k & 1]), pp(state), pp(cc[(k + 1) & 1]), pp(dd), 0.85, None))
+    torch.cuda.synchronize()
+    _cabi.check(L.gdn_pr_plan_kernel_time(plan, 1, reps, None, None))
+    for k in range(3, 3 + reps):
+        _cabi.check(L.gdn_pr_pull_dev(plan, pp(cc[k & 1]), pp(state), pp(cc[(k + 1) & 1]), pp(dd), 0.85, None))
+    tot, n = (C.c_double * 2)(0, 0), C.c_int32(0)
+    _cabi.check(L.gdn_pr_plan_kernel_time(plan, 0, 0, tot, C.byref(n)))
+    _cabi.check(L.gdn_pr_plan_check(plan))
+    k_ms = (tot[0] + tot[1]) / max(n.value, 1)
+    nbytes = int(L.gdn_pr_iter_bytes(plan))
+    nh, he = C.c_int32(0), C.c_uint64(0)
+    _cabi.check(L.gdn_pr_plan_hubs(plan, C.byref(nh), C.byref(he)))
+    mt, msrc, me = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+    _cabi.check(L.gdn_pr_plan_mid(plan, C.byref(mt), C.byref(msrc), C.byref(me)))
+    L.gdn_pr_plan_free(plan)
+    L.gdn_graph_free(gi)
+    gbs = nbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    rec["pr_lj_like"] = {"workload": "PageRank pull iteration, LJ-like stand-in (R-MAT scale %d, %d draws, a/b/c %s, ids without an "
+                                     "edge dropped)" % (r["scale"], r["n_edges"], r["abc"]),
+                         "vertices": m, "edges": nnz, "max_in_degree": int(indeg.max().item()), "max_out_degree": int(deg.max().item()),
+                         "plan_build_s": t_plan, "kernel_ms": k_ms, "kernel_ms_parts": [tot[0] / max(n.value, 1), tot[1] / max(n.value, 1)],
+                         "edges_per_s": nnz / (k_ms * 1e-3) if k_ms > 0 else 0.0,
+                         "record_tiers": {"hub_sources": nh.value, "hub_edges": he.value, "mid_tiers": mt.value,
+                                          "mid_sources": msrc.value, "mid_edges": me.value,
+                                          "share_of_edges": (he.value + me.value) / max(nnz, 1)},
+                         "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "algorithmic_bytes_per_launch": nbytes, "model": "8(m+1) + 8 nnz + 16 m (SURVEY 8d)"}}
+    del deg, indeg, start, state, cc
+    # ---- triangle count, Orkut-like
+    r = shrink(graphio.ORKUT_LIKE)
+    go, sym, dag = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_rmat_build_ex(r["scale"], r["n_edges"], *r["abc"], graphio.K_RAND_SEED, r["flags"], C.byref(go), None))
+    _cabi.check(L.gdn_graph_symmetrize(go, C.byref(sym)))
+    L.gdn_graph_free(go)
+    sm, snnz = C.c_int32(), C.c_uint64()
+    _cabi.check(L.gdn_graph_info(sym, C.byref(sm), C.byref(snnz), None, None))
+    sdeg = torch.empty(sm.value, dtype=torch.int32, device=device)
+    _cabi.check(L.gdn_graph_degrees_dev(sym, C.c_void_p(sdeg.data_ptr()), None))
+    _cabi.check(L.gdn_graph_orient(sym, C.byref(dag)))
+    L.gdn_graph_free(sym)
+    dn = C.c_uint64()
+    _cabi.check(L.gdn_graph_info(dag, None, C.byref(dn), None, None))
+    t0 = time.time()
+    tplan = C.c_void_p()
+    _cabi.check(L.gdn_tc_plan_create(dag, 1, C.byref(tplan)))
+    t_tplan = time.time() - t0
+    total, ms = C.c_uint64(0), []
+    for i in range(reps + 1):
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_tc_plan_count(tplan, C.byref(total), C.byref(st)))
+        if i:
+            ms.append(st.solve_ms)
+    L.gdn_tc_plan_free(tplan)
+    so, t1 = _cabi.GdnStats(), C.c_uint64(0)
+    _cabi.check(L.gdn_tc_dev(dag, 1, C.byref(t1), C.byref(so)))
+    L.gdn_graph_free(dag)
+    mm = med_min(ms)
+    rec["tc_orkut_like"] = {"workload": "triangle count, Orkut-like stand-in (R-MAT scale %d, %d draws, a/b/c %s, ids without an edge "
+                                        "dropped, symmetrized)" % (r["scale"], r["n_edges"], r["abc"]),
+                            "vertices": sm.value, "undirected_edges": snnz.value // 2, "max_degree": int(sdeg.max().item()),
+                            "dag_edges": dn.value, "triangles": total.value, "plan_build_s": t_tplan, "ms": mm,
+                            "gteps": dn.value / (mm["median"] * 1e-3) / 1e9, "formulation": st.reserved & 0xFF,
+                            "core_ranks": st.reserved >> 8,
+                            "oneshot_gdn_tc_dev": {"prep_ms": so.prep_ms, "solve_ms": so.solve_ms, "same_count": t1.value == total.value}}
+    log(f"[bench] stand-ins: {rec}")
     return rec
 
 

@@ -77,6 +77,7 @@ PROTOTYPES = {
     "gdn_cc": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_dev_alloc": (C.c_int, [_u64, _pp]),
     "gdn_dev_free": (C.c_int, [_vp]),
+    "gdn_dev_trim": (C.c_int, [C.POINTER(_u64)]),
     "gdn_dev_upload": (C.c_int, [_vp, _vp, _u64]),
     "gdn_dev_download": (C.c_int, [_vp, _vp, _u64]),
     "gdn_sort_u64_dev": (C.c_int, [_vp, _vp, _u64, _i32, _i32, _pp]),
@@ -92,6 +93,7 @@ PROTOTYPES = {
     "gdn_graph_from_edges": (C.c_int, [_i32, _u64, _vp, _vp, _i32, _pp]),
     "gdn_graph_download": (C.c_int, [_vp, _vp, _vp]),
     "gdn_rmat_build": (C.c_int, [_i32, _i32, _u64, _i32, _pp, _pp]),
+    "gdn_rmat_build_ex": (C.c_int, [_i32, _u64, C.c_double, C.c_double, C.c_double, _u64, _i32, _pp, _pp]),
     "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pp]),
     "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),

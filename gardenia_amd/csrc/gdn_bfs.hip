@@ -576,8 +576,9 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
 #pragma unroll
       for (int r = 0; r < BFS_BU_UNR; r++) {
         // into the queue (one LDS reservation per wave) -- unless the head is the row's only in-neighbour and the test above was
-        // the real one (a hub head while this level reads no hub bits has not been tested: the scan does it)
-        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && (hubs || code[r] >= BFS_HUBS));
+        // the real one (a hub head while this level reads no hub bits has not been tested: the scan does it; a row WITHOUT a
+        // head -- its only in-neighbour has no out-edge in the out-CSR, i.e. in_csr is not the exact transpose -- is scanned)
+        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && code[r] != BFS_NO_HUB && (hubs || code[r] >= BFS_HUBS));
         const unsigned long long om = __ballot(wait);
         if (om) {
           const int first = __ffsll((long long)om) - 1;
@@ -711,7 +712,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
           by_head++;
         }
         // (a lone head outside the frontier: nothing left to scan -- if the head WAS tested: a hub head needs this level's hub bits)
-        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && (hubs || code[r] >= BFS_HUBS));
+        const bool wait = on[r] && !found[r] && !((rc[r] & BFS_REC_LONE) && code[r] != BFS_NO_HUB && (hubs || code[r] >= BFS_HUBS));
         const unsigned long long om = __ballot(wait);
         if (wait) list[nq + (unsigned)__popcll(om & gdn_lanemask_lt())] = (unsigned short)rl[r];
         nq += (unsigned)__popcll(om);

@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned long long rmat_permute(unsigned long long x,
 // key = (row << 32) | col ; by_dst: row = dst (in-CSR) else row = src (out-CSR)
 __global__ void __launch_bounds__(GDN_BLOCK)
 rmat_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, int permute, int by_dst,
-                 unsigned long long *__restrict__ keys) {
+                 unsigned long long *__restrict__ keys, unsigned t_a = RMAT_TA, unsigned t_ab = RMAT_TAB,
+                 unsigned t_abc = RMAT_TABC) {
   unsigned long long e = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   for (; e < nedges; e += stride) {
@@ -66,12 +67,12 @@ rmat_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, 
       }
       src <<= 1;
       dst <<= 1;
-      if (r >= RMAT_TABC) {
+      if (r >= t_abc) {
         src |= 1ull;
         dst |= 1ull;
-      } else if (r >= RMAT_TAB) {
+      } else if (r >= t_ab) {
         src |= 1ull;
-      } else if (r >= RMAT_TA) {
+      } else if (r >= t_a) {
         dst |= 1ull;
       }
     }
@@ -80,6 +81,41 @@ rmat_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, 
       dst = rmat_permute(dst, scale, seed);
     }
     keys[e] = by_dst ? ((dst << 32) | src) : ((src << 32) | dst);
+  }
+}
+
+// ---- gdn_rmat_build_ex, GDN_RMAT_COMPACT: the ids that occur in no edge (self loops do not count) are dropped and the
+// others renumbered in ascending order -- "few isolated vertices", like the real graphs of BASELINE configs 2 and 4
+__global__ void __launch_bounds__(GDN_BLOCK)
+rmat_mark_ids_kernel(const unsigned long long *__restrict__ keys, unsigned long long n, unsigned *__restrict__ bits) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) {
+    const unsigned a = (unsigned)(keys[i] >> 32), b = (unsigned)(keys[i] & 0xFFFFFFFFull);
+    if (a == b) continue;
+    if (!((bits[a >> 5] >> (a & 31u)) & 1u)) atomicOr(&bits[a >> 5], 1u << (a & 31u));
+    if (!((bits[b >> 5] >> (b & 31u)) & 1u)) atomicOr(&bits[b >> 5], 1u << (b & 31u));
+  }
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+rmat_word_counts_kernel(const unsigned *__restrict__ bits, unsigned nwords, unsigned *__restrict__ cnt) {
+  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (w < nwords) cnt[w] = (unsigned)__popc(bits[w]);
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+rmat_relabel_kernel(unsigned long long *__restrict__ keys, unsigned long long n, const unsigned *__restrict__ bits,
+                    const eoff_t *__restrict__ word_base) {
+  unsigned long long i = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; i < n; i += stride) {
+    const unsigned a = (unsigned)(keys[i] >> 32), b = (unsigned)(keys[i] & 0xFFFFFFFFull);
+    if (a == b) {  // a self loop (dropped by csr_from_keys): any id inside the new range
+      keys[i] = 0ull;
+      continue;
+    }
+    const unsigned na = (unsigned)word_base[a >> 5] + (unsigned)__popc(bits[a >> 5] & ((1u << (a & 31u)) - 1u));
+    const unsigned nb = (unsigned)word_base[b >> 5] + (unsigned)__popc(bits[b >> 5] & ((1u << (b & 31u)) - 1u));
+    keys[i] = ((unsigned long long)na << 32) | nb;
   }
 }
 
@@ -1570,26 +1606,58 @@ int gdn_graph_symmetrize(const gdn_graph *g, gdn_graph **out) {
   return csr_from_keys(ka, kb, 2 * g->nnz, m, bits_for(m), out);
 }
 
-int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute, gdn_graph **out_csr,
-                   gdn_graph **in_csr) {
+int gdn_rmat_build_ex(int32_t scale, uint64_t n_edges, double a, double b, double c, uint64_t seed, int32_t flags,
+                      gdn_graph **out_csr, gdn_graph **in_csr) {
   GDN_REQUIRE(scale >= 1 && scale <= 30, "scale must be in [1,30]");
-  GDN_REQUIRE(edge_factor >= 1, "edge_factor");
+  GDN_REQUIRE(a > 0.0 && b >= 0.0 && c >= 0.0 && a + b + c <= 1.0, "quadrant probabilities");
   GDN_TRY(gdn_require_device());
   if (out_csr) *out_csr = nullptr;
   if (in_csr) *in_csr = nullptr;
-  const unsigned long long n = (unsigned long long)edge_factor << scale;
-  const int32_t m = (int32_t)(1u << scale);
+  const unsigned long long n = n_edges;
+  int32_t m = (int32_t)(1u << scale);
+  const bool permute = (flags & GDN_RMAT_PERMUTE) != 0, compact = (flags & GDN_RMAT_COMPACT) != 0;
+  // thresholds as in gardenia_amd/graphio.py: floor(p * 2^32) of the running sums (0.57 / 0.76 / 0.95 give RMAT_TA / _TAB / _TABC)
+  auto thr = [](double p) { return p >= 1.0 ? 0xFFFFFFFFu : (unsigned)(p * 4294967296.0); };
+  const unsigned t_a = thr(a), t_ab = thr(a + b), t_abc = thr(a + b + c);
+  DevBuf<unsigned> bits;       // compact: ids with an edge
+  DevBuf<eoff_t> word_base;    // compact: new id of the first set bit of every 32-id word
+  int32_t m_new = m;
   for (int which = 0; which < 2; which++) {
     gdn_graph **dst = which == 0 ? out_csr : in_csr;
     if (!dst) continue;
     DevBuf<unsigned long long> ka, kb;
-    GDN_TRY(ka.alloc_scratch(n));
-    GDN_TRY(kb.alloc_scratch(n));
+    GDN_TRY(ka.alloc_scratch(n ? n : 1));
+    GDN_TRY(kb.alloc_scratch(n ? n : 1));
     unsigned nb = (unsigned)((n + GDN_BLOCK - 1) / GDN_BLOCK > 262144ull ? 262144ull : (n + GDN_BLOCK - 1) / GDN_BLOCK);
+    if (nb == 0) nb = 1;
     hipLaunchKernelGGL(rmat_keys_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, (int)scale, n, (unsigned long long)seed,
-                       (int)permute, which, ka.p);
+                       (int)permute, which, ka.p, t_a, t_ab, t_abc);
     GDN_HIP(hipGetLastError());
-    int rc = csr_from_keys(ka, kb, n, m, scale, dst);
+    int rc = GDN_OK;
+    if (compact) {
+      if (!bits.p) {  // (both directions hold the same edges: the map is made once)
+        const unsigned nwords = (unsigned)(((uint64_t)m + 31) / 32);
+        DevBuf<unsigned> cnt;
+        rc = bits.alloc_scratch((size_t)nwords + 1);
+        if (rc == GDN_OK) rc = cnt.alloc_scratch((size_t)nwords + 1);
+        if (rc == GDN_OK) rc = word_base.alloc_scratch((size_t)nwords + 2);
+        if (rc == GDN_OK && hipMemsetAsync(bits.p, 0, ((size_t)nwords + 1) * 4, 0) != hipSuccess) rc = GDN_ERR_HIP;
+        if (rc == GDN_OK) {
+          hipLaunchKernelGGL(rmat_mark_ids_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, ka.p, n, bits.p);
+          hipLaunchKernelGGL(rmat_word_counts_kernel, dim3(gdn_nblocks((uint64_t)nwords)), dim3(GDN_BLOCK), 0, 0, bits.p, nwords,
+                             cnt.p);
+          rc = gdn_exclusive_scan_u32_to_u64(cnt.p, word_base.p, (size_t)nwords, 0);
+        }
+        eoff_t live = 0;
+        if (rc == GDN_OK && hipMemcpy(&live, word_base.p + nwords, sizeof(eoff_t), hipMemcpyDeviceToHost) != hipSuccess) rc = GDN_ERR_HIP;
+        if (rc == GDN_OK) m_new = live > 0 ? (int32_t)live : 1;
+      }
+      if (rc == GDN_OK) {
+        hipLaunchKernelGGL(rmat_relabel_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, ka.p, n, bits.p, word_base.p);
+        GDN_HIP(hipGetLastError());
+      }
+    }
+    if (rc == GDN_OK) rc = csr_from_keys(ka, kb, n, compact ? m_new : m, compact ? bits_for(m_new) : scale, dst);
     if (rc != GDN_OK) {
       if (out_csr && *out_csr) {
         gdn_graph_free(*out_csr);
@@ -1599,6 +1667,15 @@ int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t pe
     }
   }
   return GDN_OK;
+}
+
+int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute, gdn_graph **out_csr,
+                   gdn_graph **in_csr) {
+  GDN_REQUIRE(scale >= 1 && scale <= 30, "scale must be in [1,30]");
+  GDN_REQUIRE(edge_factor >= 1, "edge_factor");
+  // Graph500's quadrants (include/generator.h:88-90): the thresholds are exactly RMAT_TA / RMAT_TAB / RMAT_TABC
+  return gdn_rmat_build_ex(scale, (uint64_t)edge_factor << scale, 0.57, 0.19, 0.19, seed, permute ? GDN_RMAT_PERMUTE : 0, out_csr,
+                           in_csr);
 }
 
 }  // extern "C"

@@ -86,7 +86,7 @@ struct ScratchCache {
   std::multimap<size_t, void *> free_[kDevs];  // size -> block
   std::map<void *, std::pair<int, size_t>> live;  // block -> (device, size)
   size_t cached[kDevs] = {};
-  size_t keep = 64ull << 30;  // cached bytes per device beyond which the largest blocks go back (GDN_SCRATCH_KEEP_GB)
+  size_t keep = 32ull << 30;  // cached bytes per device beyond which the largest blocks go back (GDN_SCRATCH_KEEP_GB)
   ScratchCache() {
     if (const char *e = gdn_option("GDN_SCRATCH_KEEP_GB")) keep = (size_t)strtoull(e, nullptr, 10) << 30;
   }
@@ -167,11 +167,22 @@ FenceMap &fence_map() {
 }
 }  // namespace
 // hipMalloc / hipFree of the arrays that are not DevBufs (graphs, gdn_dev_alloc): plain calls unless the fence is on
+// (an allocation that fails while the scratch cache holds freed build blocks hands those back and tries again,
+// like DevBuf::alloc and gdn_scratch_malloc do)
+static hipError_t gdn_malloc_retry(void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipErrorOutOfMemory) {
+    (void)hipGetLastError();
+    gdn_scratch_trim();
+    e = hipMalloc(p, bytes);
+  }
+  return e;
+}
 hipError_t gdn_plain_malloc(void **p, size_t bytes) {
-  if (!gdn_alloc_fence()) return hipMalloc(p, bytes ? bytes : 1);
+  if (!gdn_alloc_fence()) return gdn_malloc_retry(p, bytes ? bytes : 1);
   const size_t off = gdn_fence_offset(bytes ? bytes : 1);
   void *b = nullptr;
-  const hipError_t e = hipMalloc(&b, (bytes ? bytes : 1) + off);
+  const hipError_t e = gdn_malloc_retry(&b, (bytes ? bytes : 1) + off);
   if (e != hipSuccess) return e;
   *p = static_cast<char *>(b) + off;
   FenceMap &f = fence_map();
@@ -539,6 +550,21 @@ int gdn_dev_alloc(uint64_t bytes, void **d_ptr) {
 
 int gdn_dev_free(void *d_ptr) {
   if (d_ptr) GDN_HIP(gdn_plain_free(d_ptr));
+  return GDN_OK;
+}
+
+int gdn_dev_trim(uint64_t *freed_bytes) {
+  if (freed_bytes) *freed_bytes = 0;
+  GDN_TRY(gdn_require_device());
+  uint64_t held = 0;
+  {
+    ScratchCache &c = scratch_cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    for (int d = 0; d < ScratchCache::kDevs; d++) held += c.cached[d];
+  }
+  GDN_HIP(hipDeviceSynchronize());  // (a cached block may still be read by work queued on the null stream)
+  gdn_scratch_trim();
+  if (freed_bytes) *freed_bytes = held;
   return GDN_OK;
 }
 

@@ -71,6 +71,16 @@ struct gdn_pr_plan {
   DevBuf<eoff_t> sq_rowptr;   // the relabelled in-CSR (kept while the plan lives only for the CSR of state rows)
   DevBuf<vid_t> sq_colidx;
   DevBuf<double> sq_diff;     // 1 double: L1 change of the dead vertices at the last import
+  // GDN_PR_SUM=reference (diagnostic): behind every pull the rows with >= ref_min_deg in-edges are summed
+  // AGAIN the way src/pr/omp_base.cc:27-33 sums them -- one fp32 add per in-edge, in CSR order, from the caller's in-CSR --
+  // and scores / next contrib / L1 change are rewritten from those sums.  With ref_min_deg = 0 every row is: the iteration
+  // then has the reference's bits, whatever layout the plan streams (pr_refsum_kernel).
+  bool ref_sum = false;
+  uint32_t ref_min_deg = 0;
+  const gdn_graph *ref_csr = nullptr;  // the caller's in-CSR: must outlive the plan in this mode
+  DevBuf<eoff_t> ref_cmap;             // squished plan: caller's vertex id -> state index
+  DevBuf<float> ref_old;               // the scores in front of the pull (the L1 change is recomputed against them)
+  DevBuf<double> ref_partial;          // per-workgroup L1 partial sums
 };
 
 struct PrOp {
@@ -126,6 +136,78 @@ struct PrOp {
     return d;
   }
 };
+
+// ---- GDN_PR_SUM=reference: the reference's summation order on demand (diagnostic).
+// One wavefront per row.  64 rows are examined at a time (lane l: the offsets of row w0 + l); the rows that qualify are
+// walked one after the other by the whole wave: 4 x 64 column ids and their contributions are fetched side by side, then
+// added ONE BY ONE in CSR order -- incoming_total += outgoing_contrib[src], src/pr/omp_base.cc:29-30 -- through
+// v_readlane; every lane carries the same running sum.  row_ids / cmap: a squished plan's state index -> caller's row,
+// caller's column id -> state index (both monotonic, so CSR order is the caller's).
+#define PR_REF_DEPTH 4
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_refsum_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const uint32_t *__restrict__ row_ids,
+                 const eoff_t *__restrict__ cmap, int32_t m_rows, uint32_t min_deg, const float *__restrict__ contrib_in,
+                 float *__restrict__ scores, float *__restrict__ contrib_out, const int32_t *__restrict__ out_degree,
+                 float base_score, float damping, const unsigned *__restrict__ skip) {
+  if (skip && *skip) return;
+  const unsigned lane = gdn_lane();
+  const uint64_t wave = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * GDN_BLOCK) >> 6;
+  for (uint64_t w0 = wave * 64; w0 < (uint64_t)m_rows; w0 += nwaves * 64) {
+    const uint64_t k = w0 + lane;
+    eoff_t lo = 0, hi = 0;
+    if (k < (uint64_t)m_rows) {
+      const uint64_t r = row_ids ? (uint64_t)row_ids[k] : k;
+      lo = rowptr[r];
+      hi = rowptr[r + 1];
+    }
+    unsigned long long todo = __ballot(k < (uint64_t)m_rows && hi - lo >= (eoff_t)min_deg);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const eoff_t e0 = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(lo >> 32), l) << 32) |
+                        (eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)lo, l);
+      const eoff_t e1 = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(hi >> 32), l) << 32) |
+                        (eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)hi, l);
+      float sum = 0.0f;
+      for (eoff_t e = e0; e < e1; e += 64 * PR_REF_DEPTH) {
+        float v[PR_REF_DEPTH];
+#pragma unroll
+        for (int d = 0; d < PR_REF_DEPTH; d++) {
+          const eoff_t ee = e + (eoff_t)(64 * d) + lane;
+          v[d] = 0.0f;
+          if (ee < e1) {
+            const vid_t c = colidx[ee];
+            v[d] = contrib_in[cmap ? (uint64_t)cmap[c] : (uint64_t)c];
+          }
+        }
+#pragma unroll
+        for (int d = 0; d < PR_REF_DEPTH; d++) {
+          const eoff_t left = e1 - (e + (eoff_t)(64 * d));
+          const int n = e + (eoff_t)(64 * d) >= e1 ? 0 : (left < 64 ? (int)left : 64);
+          for (int i = 0; i < n; i++) sum = gdn_fadd(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[d]), i)));
+        }
+      }
+      if (lane == 0) {
+        const uint64_t row = w0 + (uint64_t)l;
+        const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
+        scores[row] = new_score;
+        contrib_out[row] = __fdiv_rn(new_score, (float)out_degree[row]);
+      }
+    }
+  }
+}
+
+// L1 change of a pull recomputed from the vectors: partial[b] = SUM |scores - old| over workgroup b's rows, in double
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_refdiff_kernel(const float *__restrict__ scores, const float *__restrict__ old, int32_t m, double *__restrict__ partial) {
+  __shared__ double s_red[GDN_WAVES_PER_BLOCK];
+  double acc = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (uint64_t)m; i += (uint64_t)gridDim.x * GDN_BLOCK)
+    acc += (double)fabsf(gdn_fsub(scores[i], old[i]));
+  acc = gdn_block_sum(acc, s_red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = acc;
+}
+#define PR_REF_DIFF_BLOCKS 2048
 
 // bin and in-bin index of every hub row in the compacted main layout (bin_lo = first original row of a bin,
 // dst_bits = rows that have entries)
@@ -993,6 +1075,22 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     p->sq_colidx.release();
     p->sq_rowptr.release();
   }
+  // GDN_PR_SUM=reference (diagnostic): keep what pr_refsum_kernel reads -- the caller's in-CSR (by reference: it has to
+  // outlive the plan in this mode) and, for a squished plan, the id -> state index map
+  if (const char *e = gdn_option("GDN_PR_SUM")) {
+    if (e[0] == 'r') {
+      p->ref_sum = true;
+      p->ref_csr = raw_csr;
+      if (const char *d = gdn_option("GDN_PR_SUM_MIN_DEGREE")) p->ref_min_deg = (uint32_t)strtoul(d, nullptr, 10);
+      int rc2 = p->ref_old.alloc((size_t)p->m_local);
+      if (rc2 == GDN_OK) rc2 = p->ref_partial.alloc(PR_REF_DIFF_BLOCKS);
+      if (rc2 != GDN_OK) {
+        delete p;
+        return rc2;
+      }
+      if (p->squished) p->ref_cmap.take(cmap);
+    }
+  }
   // placement search (pr_plan_place).  GDN_PR_PLACE=<tries per array> (0 = off)
   // from 3 x 2^28 edges on: RMAT-26 (1.06 G edges) gains 4 % (1.93 -> 1.85 ms), RMAT-25 and RMAT-24 plans show no spread at all
   // (0.93 / 0.45 ms wherever they lie, profiles/r03_pb_placement.txt) -- it comes with allocations of several GB
@@ -1201,6 +1299,23 @@ static unsigned pb_first_bin_at(const PbPlan &pb, int64_t row) {
   return lo;
 }
 
+// GDN_PR_SUM=reference: the rows of >= ref_min_deg in-edges summed again in the reference's order, then the L1 change of
+// the whole pull recomputed from the vectors (the pull's own figure was taken before the rows changed)
+static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipStream_t s) {
+  const gdn_graph *g = plan->ref_csr;
+  hipLaunchKernelGGL(pr_refsum_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, s, g->rowptr, g->colidx,
+                     plan->squished ? plan->sq_ids.p : nullptr, plan->squished ? plan->ref_cmap.p : nullptr, plan->m_local,
+                     plan->ref_min_deg, op.contrib_in, op.scores, op.contrib_out, op.out_degree, op.base_score, op.damping,
+                     op.skip);
+  if (d_diff) {
+    hipLaunchKernelGGL(pr_refdiff_kernel, dim3(PR_REF_DIFF_BLOCKS), dim3(GDN_BLOCK), 0, s, op.scores, plan->ref_old.p,
+                       plan->m_local, plan->ref_partial.p);
+    hipLaunchKernelGGL(mp_reduce_f64, dim3(1), dim3(GDN_BLOCK), 0, s, plan->ref_partial.p, (uint32_t)PR_REF_DIFF_BLOCKS, d_diff);
+  }
+  GDN_HIP(hipGetLastError());
+  return GDN_OK;
+}
+
 int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
                          double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
                          void *stream) {
@@ -1218,9 +1333,15 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   op.skip = plan->skip_flag;
   op.vec_ok = ((reinterpret_cast<uintptr_t>(op.scores) | reinterpret_cast<uintptr_t>(op.contrib_out) |
                 reinterpret_cast<uintptr_t>(op.out_degree)) & 15u) == 0;
+  if (plan->ref_sum) {
+    GDN_REQUIRE(first && last, "GDN_PR_SUM=reference: whole-iteration pulls only (gdn_pr_pull_dev)");
+    GDN_HIP(hipMemcpyAsync(plan->ref_old.p, d_scores, (size_t)plan->m_local * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  }
   if (plan->layout == GDN_LAYOUT_CSR) {
     // the merge-path pass is not cut into parts: the FIRST part runs all rows, later parts are no-ops
-    return first ? mp_run(plan->mp, op, d_diff, (hipStream_t)stream) : GDN_OK;
+    if (!first) return GDN_OK;
+    GDN_TRY(mp_run(plan->mp, op, d_diff, (hipStream_t)stream));
+    return plan->ref_sum ? pr_ref_resum(plan, op, d_diff, (hipStream_t)stream) : GDN_OK;
   }
   // ---- propagation-blocked path: expand (per chunk, first part) then accumulate + fused update (per bin)
   PbPlan &pb = plan->pb;
@@ -1330,6 +1451,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
     }
   }
   GDN_HIP(hipGetLastError());
+  if (plan->ref_sum) return pr_ref_resum(plan, op, d_diff, s);
   return GDN_OK;
 }
 
@@ -1380,6 +1502,18 @@ int gdn_pr_plan_move(gdn_pr_plan *plan, uint32_t what) {
   GDN_REQUIRE(plan != nullptr, "plan");
   if (plan->layout == GDN_LAYOUT_CSR) return GDN_OK;
   GDN_HIP(hipDeviceSynchronize());
+  struct Tr {  // GDN_PR_PLACE_TRACE: where the arrays live after the move
+    gdn_pr_plan *p;
+    ~Tr() {
+      if (!gdn_option("GDN_PR_PLACE_TRACE")) return;
+      fprintf(stderr, "[pr move] vals %p + %zu  U %p + %zu  G %p + %zu  V %p + %zu", (void *)p->pb.vals.p, p->pb.vals.n * sizeof(*p->pb.vals.p),
+              (void *)p->pb.U.p, p->pb.U.n * sizeof(*p->pb.U.p), (void *)p->pb.G.p, p->pb.G.n * sizeof(*p->pb.G.p), (void *)p->pb.V.p,
+              p->pb.V.n * sizeof(*p->pb.V.p));
+      if (p->has_hub) fprintf(stderr, "  hub %p + %zu", (void *)p->hub_rec.p, p->hub_rec.n * 4);
+      for (int t = 0; t < p->n_mid_tiers; t++) fprintf(stderr, "  mid%d %p + %zu", t, (void *)p->mid[t].rec.p, p->mid[t].rec.n * 4);
+      fprintf(stderr, "\n");
+    }
+  } tr{plan};
   if (what & 1u) GDN_TRY(plan->pb.vals.move());
   if (what & 2u) GDN_TRY(plan->pb.U.move());
   if (what & 4u) GDN_TRY(plan->pb.G.move());
@@ -1530,7 +1664,8 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     // graphs of the CSR regime: the whole solve in one cooperative launch (GDN_PR_FUSED=0: the per-iteration loop)
     {
       const char *env = gdn_option("GDN_PR_LAYOUT"), *fz = gdn_option("GDN_PR_FUSED");
-      const bool want = fz ? fz[0] != '0' : (!(env && (env[0] == 'c' || env[0] == 'p')) && nnz < (1ull << 18));  // measured: 20 us per iteration against the loop's 27 at 0.23 M edges, 35 against 30 at 1 M
+      const char *rs = gdn_option("GDN_PR_SUM");  // (reference-order sums are a fix-up behind the per-iteration pull)
+      const bool want = (rs && rs[0] == 'r') ? false : fz ? fz[0] != '0' : (!(env && (env[0] == 'c' || env[0] == 'p')) && nnz < (1ull << 18));  // measured: 20 us per iteration against the loop's 27 at 0.23 M edges, 35 against 30 at 1 M
       int fused = 0;
       if (want && (rc = pr_solve_fused(g, d_deg.p, d_scores.p, damping, epsilon, max_iter, &st, &fused))) break;
       if (fused) {

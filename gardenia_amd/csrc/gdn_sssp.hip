@@ -2232,6 +2232,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       light_streak++;
       if (edges_pending) {  // the out-edges of the list this pass walked (see the conversion behind the sweeps)
         relaxed_total += h.improved_edges;
+        bucket_work += h.improved_edges;  // (sssp_adapt_delta must see the pass's real work, not the 0 it was queued with)
         edges_pending = false;
       }
       if (pre_dense) {  // no lists were built: the sweeps take over from the distances

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "gdn_expand.hpp"
 
 struct TcKeepVis {
@@ -1190,6 +1192,7 @@ struct gdn_tc_plan {
   DevBuf<unsigned long long> core_total;
   hipStream_t core_stream = nullptr;    // the core kernel runs BESIDE tc_count_kernel (which fills half of a CU's wave slots)
   hipEvent_t core_ready = nullptr;      // cursors zeroed (null stream) -> the core's stream may start
+  std::mutex count_mu;                  // the core's cursors and total belong to the plan: one count at a time
   double prep_ms = 0;
   ~gdn_tc_plan() {
     if (core_stream) (void)hipStreamDestroy(core_stream);
@@ -1370,6 +1373,7 @@ int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan)
 
 int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats) {
   GDN_REQUIRE(plan != nullptr && total != nullptr, "plan / total");
+  std::lock_guard<std::mutex> one_count(plan->count_mu);  // two threads counting on one plan take turns
   gdn_stats st;
   memset(&st, 0, sizeof(st));
   int rc = GDN_OK;

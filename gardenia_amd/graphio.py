@@ -210,14 +210,24 @@ def permute_id(v: np.ndarray, scale: int, seed: int) -> np.ndarray:
     return x
 
 
+def rmat_thresholds(a: float = 0.57, b: float = 0.19, c: float = 0.19) -> Tuple[int, int, int]:
+    """floor(p * 2^32) of the running quadrant sums, as gdn_rmat_build_ex computes them (doubles); (.57, .19, .19) give
+    RMAT_TA / RMAT_TAB / RMAT_TABC."""
+    thr = lambda p: 0xFFFFFFFF if p >= 1.0 else int(float(p) * 4294967296.0)
+    return thr(a), thr(float(a) + float(b)), thr(float(a) + float(b) + float(c))
+
+
 def rmat_edges(scale: int, edge_factor: int = 16, seed: int = K_RAND_SEED,
-               permute: bool = True, lo: int = 0, hi: Optional[int] = None
+               permute: bool = True, lo: int = 0, hi: Optional[int] = None,
+               abc: Optional[Tuple[float, float, float]] = None, n_edges: Optional[int] = None
                ) -> Tuple[np.ndarray, np.ndarray]:
     """Edges [lo,hi) of the R-MAT stream (src,dst as int64).  Edge e, level l draws
     r = hi32/lo32 of mix64(seed + e*GOLD + (l>>1)*M1); r<TA: (0,0); <TAB: dst bit;
-    <TABC: src bit; else both (include/generator.h:94-106)."""
-    total = edge_factor << scale
+    <TABC: src bit; else both (include/generator.h:94-106).  abc: other quadrant probabilities (gdn_rmat_build_ex);
+    n_edges: the stream's length when it is not edge_factor * 2^scale."""
+    total = (edge_factor << scale) if n_edges is None else int(n_edges)
     hi = total if hi is None else hi
+    ta, tab, tabc = (RMAT_TA, RMAT_TAB, RMAT_TABC) if abc is None else rmat_thresholds(*abc)
     e = np.arange(lo, hi, dtype=np.uint64)
     src = np.zeros(e.shape, dtype=np.uint64)
     dst = np.zeros(e.shape, dtype=np.uint64)
@@ -231,15 +241,45 @@ def rmat_edges(scale: int, edge_factor: int = 16, seed: int = K_RAND_SEED,
                 r = h >> np.uint64(32)
             src <<= np.uint64(1)
             dst <<= np.uint64(1)
-            dst |= ((r >= np.uint64(RMAT_TA)) & (r < np.uint64(RMAT_TAB))).astype(np.uint64)
-            src |= ((r >= np.uint64(RMAT_TAB)) & (r < np.uint64(RMAT_TABC))).astype(np.uint64)
-            both = (r >= np.uint64(RMAT_TABC)).astype(np.uint64)
+            dst |= ((r >= np.uint64(ta)) & (r < np.uint64(tab))).astype(np.uint64)
+            src |= ((r >= np.uint64(tab)) & (r < np.uint64(tabc))).astype(np.uint64)
+            both = (r >= np.uint64(tabc)).astype(np.uint64)
             src |= both
             dst |= both
     if permute:
         src = permute_id(src, scale, seed)
         dst = permute_id(dst, scale, seed)
     return src.astype(np.int64), dst.astype(np.int64)
+
+
+def rmat_graph_ex(scale: int, n_edges: int, abc: Tuple[float, float, float] = (0.57, 0.19, 0.19), seed: int = K_RAND_SEED,
+                  permute: bool = True, compact: bool = False) -> CSR:
+    """numpy twin of gdn_rmat_build_ex (include/gardenia_hip.h).  compact: the ids that occur in no edge (self loops do not
+    count) are dropped and the others renumbered in ascending order."""
+    src, dst = rmat_edges(scale, 0, seed, permute, abc=abc, n_edges=n_edges)
+    m = 1 << scale
+    if compact:
+        real = src != dst
+        live = np.zeros(m, bool)
+        live[src[real]] = True
+        live[dst[real]] = True
+        new_id = np.cumsum(live) - 1
+        src, dst = new_id[src[real]], new_id[dst[real]]
+        m = max(int(live.sum()), 1)
+    return build_csr(m, src, dst)
+
+
+# ---- stand-ins for the real graphs of BASELINE configs 2 and 4 (datasets/test.mk:5,8 are wget lines; no network here):
+# seeded, generated on the device by gdn_rmat_build_ex with the same arguments.  Recipes fitted in round 5 to the published
+# sizes (SNAP): soc-LiveJournal1 4 847 571 vertices / 68 993 773 directed edges, max in-degree 13 906, out 20 293;
+# com-Orkut 3 072 441 vertices / 117 185 083 undirected edges, max degree 33 313.  What comes out is in DESIGN.md 6.
+LJ_LIKE = dict(scale=23, n_edges=70_000_000, abc=(0.5, 0.2, 0.2), flags=3)          # directed
+ORKUT_LIKE = dict(scale=22, n_edges=118_000_000, abc=(0.45, 0.22, 0.22), flags=3)   # then symmetrized
+
+
+def standin_graph(recipe: dict, seed: int = K_RAND_SEED) -> CSR:
+    return rmat_graph_ex(recipe["scale"], recipe["n_edges"], recipe["abc"], seed, bool(recipe["flags"] & 1),
+                         bool(recipe["flags"] & 2))
 
 
 def rmat_graph(scale: int, edge_factor: int = 16, seed: int = K_RAND_SEED,

@@ -167,6 +167,12 @@ int gdn_cc(int32_t m, uint64_t nnz, const uint64_t *rowptr, const int32_t *colid
 /* Device buffers for callers of the _dev API that do not bring their own allocator (blocking). */
 int gdn_dev_alloc(uint64_t bytes, void **d_ptr);
 int gdn_dev_free(void *d_ptr);
+/* The library keeps the temporaries of its graph / layout builds in a process-level cache of device blocks (a fresh
+ * multi-GB hipMalloc stalls for seconds on this runtime when memory of that size was freed shortly before; up to
+ * GDN_SCRATCH_KEEP_GB = 32 GB per device stay cached).  gdn_dev_trim hands every cached block back to the driver -- for a
+ * caller that shares the device with another allocator (torch, a second library) and wants the memory; the library does so
+ * itself before it reports GDN_ERR_OOM.  *freed_bytes (nullable) = what went back.  Blocking. */
+int gdn_dev_trim(uint64_t *freed_bytes);
 int gdn_dev_upload(void *d_dst, const void *h_src, uint64_t bytes);
 int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes);
 
@@ -236,6 +242,16 @@ int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx);
  * Either output may be NULL. */
 int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute,
                    gdn_graph **out_csr, gdn_graph **in_csr);
+/* The same generator with its knobs open: n_edges draws (not a multiple of 2^scale necessarily), quadrant probabilities
+ * a / b / c (d = 1 - a - b - c; include/generator.h:88-90 fixes .57 / .19 / .19), flags GDN_RMAT_PERMUTE (ids shuffled,
+ * generator.h:52-62) and GDN_RMAT_COMPACT: the ids that occur in no edge are dropped and the others renumbered in ascending
+ * order, so the graph has few isolated vertices like the real graphs of BASELINE configs 2 and 4 (soc-LiveJournal1, com-Orkut,
+ * datasets/test.mk:5,8 -- wget lines); *_csr then have fewer than 2^scale rows (gdn_graph_info).  gardenia_amd/graphio.py
+ * (rmat_graph_ex, lj_like / orkut_like) holds the bit-identical numpy twin and the two stand-in recipes. */
+#define GDN_RMAT_PERMUTE 1
+#define GDN_RMAT_COMPACT 2
+int gdn_rmat_build_ex(int32_t scale, uint64_t n_edges, double a, double b, double c, uint64_t seed, int32_t flags,
+                      gdn_graph **out_csr, gdn_graph **in_csr);
 
 /* ------------------------------------------------------------------------------------------
  * _dev API -- PageRank (graph resident, vectors are device pointers)

@@ -80,7 +80,7 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     """BASELINE configs 3 and 4 and the BFS block ride on the N = 1 line (small scales here): ms median + min over >= 10
     repetitions, GB/s against SURVEY 8d's bytes, the one-shot drop-in next to the resident plan."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "3", "--warmup", "1", "--no-cpu",
-           "--spmv-scale", "20", "--tc-scale", "16", "--trav-scale", "18"]
+           "--spmv-scale", "20", "--tc-scale", "16", "--trav-scale", "18", "--standin-shrink", "5"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -107,3 +107,33 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     assert tc["ab_hash_set_unpruned"]["same_count"] is True and tc["plan_build_s"] > 0
     po = r["pr_oneshot"]
     assert po["csr"]["iterations"] == po["pb"]["iterations"] == po["auto"]["iterations"] > 1 and po["auto_picked"] in ("csr", "pb")
+    # round 5: the one-shot TCSolver drop-in beside the plan, and the blocks on the LJ-like / Orkut-like stand-ins
+    assert len(tc["oneshot_gdn_tc_dev"]) == 3 and all(x["same_count"] and x["solve_ms"] > 0 for x in tc["oneshot_gdn_tc_dev"])
+    si = r["standins"]
+    assert 0 < si["pr_lj_like"]["roofline"]["frac"] < 1 and si["pr_lj_like"]["max_in_degree"] > 100
+    assert si["pr_lj_like"]["roofline"]["algorithmic_bytes_per_launch"] == 8 * (si["pr_lj_like"]["vertices"] + 1) + 8 * si["pr_lj_like"]["edges"] + 16 * si["pr_lj_like"]["vertices"]
+    assert si["tc_orkut_like"]["triangles"] > 0 and si["tc_orkut_like"]["oneshot_gdn_tc_dev"]["same_count"] is True
+
+
+def test_bench_eight_ranks_on_one_device_match_single():
+    """The N = 8 geometry of bench.py (eight padded all-gather slots, `parts` from the smallest rank's bin count, nnz-balanced
+    ranges of the squished graph) has never met hardware with 8 GPUs: here its eight ranks share ONE device (gloo collectives) on
+    R-MAT scale 22 and must reproduce the single-GPU L1 change to the last bit."""
+    def run(extra, launcher=None):
+        cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py"), "--scale", "22", "--steps", "3", "--warmup", "1",
+                                                     "--no-bfs", "--no-cpu", "--no-extras"] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+
+    single = run([])
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    r = run(["--gpus", "8", "--share-device"], launcher)
+    assert r["n_gpus"] == 8 and "vertex-range x8 (balanced ranges" in r["config"]["partition"]
+    assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+    part = r["config"]["partition"]
+    edges = [int(x) for x in part[part.index("[") + 1:part.index("]")].split(",")]
+    assert len(edges) == 8 and sum(edges) == single["config"]["edges"]
+    assert max(edges) <= 1.02 * (sum(edges) / 8) + 70_000  # nnz-balanced: a rank is at most one hub row over its share
+    assert r["scaling"] == "strong" and r["value"] > 0

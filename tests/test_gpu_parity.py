@@ -180,6 +180,47 @@ def test_pr_vs_oracle_rmat(orc, scale, ef, seed, pr_layout):
     assert orc.pr_verify_error(g, scores) < 1e-4  # PRVerifier criterion, src/pr/verifier.cc:53
 
 
+@pytest.mark.parametrize("layout", ["csr", "pb", "pb_unsquished", "pb_tiers"])
+def test_pr_reference_sum_mode_has_the_reference_bits(orc, layout, monkeypatch):
+    """GDN_PR_SUM=reference (diagnostic): behind every pull the rows are summed again the way src/pr/omp_base.cc:27-33 sums
+    them -- one fp32 add per in-edge in CSR order.  The solve then has the oracle's BITS in every score, whatever layout the
+    plan streams: the order of the additions is the only thing in which the library's PageRank differs from the
+    reference's.  With GDN_PR_SUM_MIN_DEGREE only the rows with that many in-edges are re-summed."""
+    g = graphio.rmat_graph(15, 16, seed=44)
+    gi = graphio.transpose(g)
+    want, it, trace = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "csr" if layout == "csr" else "pb")
+    if layout == "pb_unsquished":
+        monkeypatch.setenv("GDN_PR_SQUISH", "0")
+    if layout == "pb_tiers":
+        monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")  # record tiers on a graph this small
+    plain = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st0 = solvers.PRSolver(G, plain)
+    assert st0["iterations"] == it
+    monkeypatch.setenv("GDN_PR_SUM", "reference")
+    scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st = solvers.PRSolver(G, scores)
+    assert st["layout"] == ("csr" if layout == "csr" else "pb")
+    assert st["iterations"] == it
+    assert np.array_equal(scores.view(np.uint32), want.view(np.uint32))  # bit for bit
+    np.testing.assert_allclose(st["trace"], trace, rtol=1e-9)  # (double sums of the same terms in another order)
+    # only the rows of >= 64 in-edges: those rows carry sequential sums (of inputs that differ in their last bits by now),
+    # the others the plan's own -- everything within 1e-4, and the run differs from the plain one
+    monkeypatch.setenv("GDN_PR_SUM_MIN_DEGREE", "64")
+    part = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    st2 = solvers.PRSolver(G, part)
+    assert st2["iterations"] == it
+    np.testing.assert_allclose(part, want, rtol=REL_TOL, atol=0)
+    indeg = np.diff(gi.rowptr.astype(np.int64))
+    small = indeg < 64
+    assert float((np.abs(part[small] - plain[small]) / plain[small]).max()) < 1e-5
+    monkeypatch.delenv("GDN_PR_SUM")
+    again = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+    solvers.PRSolver(G, again)
+    assert np.array_equal(again, plain)  # the mode leaves nothing behind
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_pr_sharded_data_path_on_one_device(orc, world, layout):
@@ -810,6 +851,28 @@ def test_spmv_vs_oracle_rmat(orc, scale, ef, seed):
     solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x, y1)
     solvers.SpmvSolver(solvers.Graph(csr=g, in_csr=gi), Ax, x * np.float32(2), y2)
     assert np.array_equal(y2, y1 * np.float32(2))
+
+
+def test_spmv_oneshot_on_the_blocked_layout_behind_an_option(orc, monkeypatch):
+    """GDN_SPMV_ONESHOT=solve: the one call builds the blocked layout (reported in prep_ms, like the reference's segmenting()
+    in front of its Timer, src/spmv/partition.cu:206,269-291) and multiplies on it; same result within the verifier's bound,
+    and the default call stays the merge-path pass without a build."""
+    g = graphio.rmat_graph(19, 16, seed=21)
+    gi = graphio.transpose(g)
+    assert gi.nnz >= 1 << 22
+    rng = np.random.default_rng(21)
+    Ax, x, y0 = rng.random(gi.nnz, dtype=np.float32), rng.random(gi.m, dtype=np.float32), rng.random(gi.m, dtype=np.float32)
+    want = orc.spmv(gi, Ax, x, y0)
+    G = solvers.Graph(csr=g, in_csr=gi)
+    y = y0.copy()
+    st0 = solvers.SpmvSolver(G, Ax, x, y)
+    np.testing.assert_allclose(y, want, rtol=REL_TOL, atol=0)
+    monkeypatch.setenv("GDN_SPMV_ONESHOT", "solve")
+    y2 = y0.copy()
+    st = solvers.SpmvSolver(G, Ax, x, y2)
+    np.testing.assert_allclose(y2, want, rtol=REL_TOL, atol=0)
+    assert orc.spmv_max_rel_error(y2, want) <= 5 * np.sqrt(np.finfo(np.float32).eps)
+    assert st["prep_ms"] > st0["prep_ms"] and st["edges_traversed"] == gi.nnz
 
 
 @pytest.mark.parametrize("layout", [0, 1])
