@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gardenia_amd import graphio, solvers  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 50000

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: E402
 
 from gardenia_amd import _cabi, graphio  # noqa: E402

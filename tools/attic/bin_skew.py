@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """How evenly do the in-edges of R-MAT scale S fall into 256 equal id ranges (the bins of the binned top-down BFS level)?"""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gardenia_amd import _cabi, graphio
 L = _cabi.lib()

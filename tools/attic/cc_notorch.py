@@ -1,6 +1,6 @@
 """CC timing through the C-ABI: R-MAT scale S (directed): Afforest with the reverse graph, without it, and SV rounds."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gardenia_amd import _cabi, graphio
 L = _cabi.lib()

@@ -1,6 +1,6 @@
 """BFS on an nx x nx lattice through the C-ABI (high diameter: the per-level cost is what is measured)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gardenia_amd import _cabi, graphio, solvers
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

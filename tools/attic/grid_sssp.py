@@ -1,6 +1,6 @@
 """SSSP on an nx x nx lattice with U[1,255] weights through the C-ABI (thousands of light buckets)."""
 import ctypes as C, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gardenia_amd import _cabi, graphio, solvers
 nx = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

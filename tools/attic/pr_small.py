@@ -5,7 +5,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from gardenia_amd import graphio, solvers  # noqa: E402
 
 # GDN_PR_BATCH=1 in the environment: the loop reads the L1 change back after every iteration (round 1's form)

@@ -1,6 +1,6 @@
 """Repro of a fuzz_parity SSSP-plan mismatch: python tools/sssp_fuzz_repro2.py <seed>  (same draws as tests/aids/fuzz_parity.py check())"""
 import importlib.util, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 spec = importlib.util.spec_from_file_location("fz", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "aids", "fuzz_parity.py"))
 fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
