@@ -159,6 +159,43 @@ struct PbPlacer {
     for (DevBuf<T> *h : held) delete h;
     return rc;
   }
+  // a new baseline (the caller changed what `timed` measures: another phase)
+  int rebase() { return timed(&best); }
+  // the same for an array whose CONTENTS are scratch of one iteration (PageRank's vals: written by phase A, read by phase B):
+  // a candidate is a fresh allocation, nothing is copied.  Rejected candidates stay allocated until the array is done (hipMalloc
+  // hands a freed block out again), at most `hold` of them.
+  template <typename T>
+  int search_fresh(DevBuf<T> &buf, const char *name, int n_tries, int hold) {
+    if (!buf.p || buf.n * sizeof(T) < min_bytes) return GDN_OK;
+    std::vector<DevBuf<T> *> held;
+    int rc = GDN_OK;
+    for (int k = 0; k < n_tries && rc == GDN_OK; k++) {
+      if (wall.stop_ms() > budget_ms) break;
+      if ((int)held.size() >= hold) {
+        delete held.front();
+        held.erase(held.begin());
+      }
+      DevBuf<T> *cand = new DevBuf<T>();
+      held.push_back(cand);
+      if (cand->alloc(buf.n) != GDN_OK) {  // no memory for another candidate: that is no error
+        gdn_set_error("%s", "");
+        break;
+      }
+      // (slots no launch writes -- alignment gaps between bins -- must read as zero, as in the array the builder made)
+      if (hipMemsetAsync(cand->p, 0, buf.n * sizeof(T), 0) != hipSuccess) {
+        (void)hipGetLastError();
+        break;
+      }
+      buf.swap(*cand);
+      double cur = 0;
+      if ((rc = timed(&cur)) != GDN_OK) break;
+      if (trace) fprintf(stderr, "[%s place] %-12s fresh %d: %.3f ms (best %.3f) at %p (was %p)\n", tag, name, k, cur, best, (void *)buf.p, (void *)cand->p);
+      if (cur < best * 0.997) best = cur;
+      else buf.swap(*cand);
+    }
+    for (DevBuf<T> *h : held) delete h;
+    return rc;
+  }
   void end() {
     (void)hipDeviceSynchronize();
     if (trace) fprintf(stderr, "[%s place] %.3f -> %.3f ms per sweep, %.0f ms spent\n", tag, first, best, wall.stop_ms());

@@ -1550,6 +1550,13 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
     it++;
     return gdn_pr_pull_dev(p, in, sc.p, out, diff.p, 0.85f, nullptr);
   };
+  // Round 5: what a candidate is timed on is the PHASE that streams the array (HIP events around expand / accumulate, as
+  // bench.py reads them), not the whole iteration -- phase A follows vals (1.00 <-> 1.18 ms, a fast block is about one
+  // hipMalloc in six, profiles/r05_pb_channels.md), phase B the record streams and V --, and the order is by what an array
+  // can gain: vals first.  vals is scratch of one iteration, so its candidates are fresh allocations without a copy
+  // (~4 ms each with two timed iterations; round 4 searched it LAST, behind 16 copies of record streams, and the 1.2 s
+  // budget was usually spent before it came up).
+  int phase = 2;  // 0 expand, 1 accumulate, 2 both
   PbPlacer pl;
   pl.tries = tries;
   pl.budget_ms = budget_ms;
@@ -1557,21 +1564,29 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
   pl.trace = gdn_option("GDN_PR_PLACE_TRACE") != nullptr;
   pl.timed = [&](double *out_ms) -> int {
     GDN_TRY(pull());
-    GDN_HIP(hipDeviceSynchronize());
-    t.start();
-    for (int k = 0; k < 3; k++) GDN_TRY(pull());
-    *out_ms = t.stop_ms() / 3.0;
+    const int n = 2;
+    GDN_TRY(gdn_pr_plan_kernel_time(p, 1, n, nullptr, nullptr));
+    for (int k = 0; k < n; k++) GDN_TRY(pull());
+    double tot[2] = {0, 0};
+    int32_t launches = 0;
+    GDN_TRY(gdn_pr_plan_kernel_time(p, 0, 0, tot, &launches));
+    if (launches < 1) launches = 1;
+    *out_ms = (phase == 0 ? tot[0] : phase == 1 ? tot[1] : tot[0] + tot[1]) / launches;
     return GDN_OK;
   };
   p->placing = true;
   int rc = pl.begin();
-  // cheapest first (a fresh allocation costs ~60 ms per GB in a process that has not touched the memory before): the record
-  // streams (~1 GB each, 0.03-0.1 ms of phase B each), then vals (4.4 GB, up to 0.19 ms of phase A), V, U
+  int vals_tries = 4 * tries;  // GDN_PR_PLACE_VALS=<candidates>
+  if (const char *e = gdn_option("GDN_PR_PLACE_VALS")) vals_tries = atoi(e);
+  phase = 0;
+  if (rc == GDN_OK) rc = pl.rebase();
+  if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8);
+  if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
+  phase = 1;
+  if (rc == GDN_OK) rc = pl.rebase();
   for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) rc = pl.search(p->mid[k].rec, "mid records");
   if (rc == GDN_OK && p->has_hub) rc = pl.search(p->hub_rec, "hub records");
-  if (rc == GDN_OK) rc = pl.search(p->pb.vals, "vals", 2);
   if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
-  if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
   pl.end();
   p->placing = false;
   if (rc != GDN_OK) return rc;

@@ -428,7 +428,8 @@ def test_pr_placement_search_is_bitwise_neutral(orc, monkeypatch, capfd, world, 
         log = capfd.readouterr().err
         assert ("[pr place]" in log) == (tries == "2"), log[-400:]
         if tries == "2":
-            for name in ("vals", "V", "mid records", "hub records", "U"):
+            assert "[pr place] %-12s fresh" % "vals" in log  # (scratch of one iteration: candidates are fresh allocations)
+            for name in ("V", "mid records", "hub records", "U"):
                 assert "[pr place] %-12s try" % name in log, name
         if tries == "hook":  # every array group of the finished plan into a fresh allocation
             for r in sh.ranks:
