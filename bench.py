@@ -984,6 +984,26 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
             if i:
                 ms.append(st.solve_ms)
         L.gdn_sssp_plan_free(plan)
+        ab_sweeps = None
+        if name == "sssp_unit" and st.reserved == 1:
+            # equal weights: the plan solves through the BFS plan (round 5, gdn_sssp.hip); the same solve on the blocked
+            # Bellman-Ford sweeps (what rounds 1-4 reported under this name) beside it
+            try:
+                _cabi.check(L.gdn_option_set(b"GDN_SSSP_UNIT_BFS", b"0"))
+                p2 = C.c_void_p()
+                _cabi.check(L.gdn_sssp_plan_create(go, C.c_void_p(w.data_ptr()), 1, C.byref(p2)))
+                ms2 = []
+                d2 = torch.empty(m, dtype=torch.int32, device=device)
+                for i in range(6):
+                    s2 = _cabi.GdnStats()
+                    _cabi.check(L.gdn_sssp_run(p2, src, delta, C.c_void_p(d2.data_ptr()), C.byref(s2)))
+                    if i:
+                        ms2.append(s2.solve_ms)
+                L.gdn_sssp_plan_free(p2)
+                ab_sweeps = {"ms": med_min(ms2), "phases": s2.iterations, "same_distances": bool((d2 == dist).all().item())}
+                del d2
+            finally:
+                L.gdn_option_set(b"GDN_SSSP_UNIT_BFS", None)
         reached = int((dist != 2147483647).sum().item())
         relaxed = int(st.last_error)  # SSSP: edges relaxed over the solve (include/gardenia_hip.h, gdn_stats)
         b = 16 * reached + 12 * st.edges_traversed + 4 * m
@@ -1000,7 +1020,11 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "bytes_on_relaxed_edges": b_relaxed,
                                   "model_relaxed": "16 reached + 12 edges_relaxed + 4 m: every relaxation the solver made "
                                                    "(list passes: the out-edges of their list; a dense sweep: every edge)"}}
-        attach_traffic(rec[name]["roofline"], "sssp_unit" if name == "sssp_unit" else "sssp_u255", args.trav_scale, sec)
+        if ab_sweeps is not None and st.reserved == 1:
+            rec[name]["route"] = "equal weights: direction-optimising BFS plan on the transpose, depths x weight (plan_build_s includes the transpose)"
+            rec[name]["ab_dense_sweeps"] = ab_sweeps
+        else:
+            attach_traffic(rec[name]["roofline"], "sssp_unit" if name == "sssp_unit" else "sssp_u255", args.trav_scale, sec)
         # the one-shot drop-in on the resident graph (what SSSPSolver binds to: no plan handed in; from 2^24 edges on the
         # call builds the blocked layout itself and reports it as prep_ms)
         try:

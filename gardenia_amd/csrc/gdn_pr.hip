@@ -1100,7 +1100,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int tries = 3;
     if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
     if (tries > 0) {
-      const int rcp = pr_plan_place(p, tries, 1200.0);  // (with the 0.13 s layout build of round 4 the whole plan stays under 1.5 s)
+      const int rcp = pr_plan_place(p, tries, 800.0);  // (vals: ~0.2 s for 12 candidates; the copies of phase B's streams take the rest)
       if (rcp != GDN_OK) {
         delete p;
         return rcp;
@@ -1581,12 +1581,21 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
   phase = 0;
   if (rc == GDN_OK) rc = pl.rebase();
   if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8);
-  if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
-  phase = 1;
-  if (rc == GDN_OK) rc = pl.rebase();
-  for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) rc = pl.search(p->mid[k].rec, "mid records");
-  if (rc == GDN_OK && p->has_hub) rc = pl.search(p->hub_rec, "hub records");
-  if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
+  // The arrays phase B streams (and U) are searched only on request (GDN_PR_PLACE_COPIES=1; every candidate is a copy, ~40 ms
+  // per GB-sized array): timed per phase they gain nothing worth 0.3 s of plan build -- 2.536 -> 2.524 ms and 2.611 -> 2.600 ms
+  // of phase B over 18 copies each in sessions r05_03 / r05_04, U 1.001 -> 0.994 ms (profiles/r05_pb_place_search.txt).
+  // Round 3's "phase B follows V and the record streams by 0.03-0.1 ms each" was measured on whole iterations.
+  const char *ce = gdn_option("GDN_PR_PLACE_COPIES");
+  if (ce && ce[0] == '1') {
+    phase = 1;
+    if (rc == GDN_OK) rc = pl.rebase();
+    for (int k = 0; k < p->n_mid_tiers && rc == GDN_OK; k++) rc = pl.search(p->mid[k].rec, "mid records");
+    if (rc == GDN_OK && p->has_hub) rc = pl.search(p->hub_rec, "hub records");
+    if (rc == GDN_OK) rc = pl.search(p->pb.V, "V");
+    phase = 0;
+    if (rc == GDN_OK) rc = pl.rebase();
+    if (rc == GDN_OK) rc = pl.search(p->pb.U, "U");
+  }
   pl.end();
   p->placing = false;
   if (rc != GDN_OK) return rc;
@@ -1693,6 +1702,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       }
     }
     tprep.start();
+    double pol_iters = 0, pol_csr_ms = 0, pol_pb_ms = 0;
     // the PB layout works on the live vertices only (GDN_LAYOUT_PB_SQUISHED; GDN_PR_SQUISH=0: the caller's vertex space)
     int32_t layout = GDN_LAYOUT_AUTO;
     {
@@ -1709,12 +1719,17 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       // GDN_PR_LAYOUT=c / p force a layout, anything else is this choice.
       const char *os_ = gdn_option("GDN_PR_ONESHOT");
       bool pb = nnz >= (1ull << 22);
-      if (pb && !(os_ && os_[0] == 's')) {
+      {
         double iters = 24.0;
         if (epsilon > 0.0 && epsilon < 1.0) iters = 24.0 * log(epsilon) / log(1e-4);
         if (!(epsilon > 0.0) || iters > (double)max_iter) iters = (double)max_iter;
         const double csr_ps = nnz >= (1ull << 28) ? 18.0 : 10.0, pb_ps = 2.3, build_ps = 100.0;
-        pb = iters * (csr_ps - pb_ps) > build_ps;
+        if (pb && !(os_ && os_[0] == 's')) pb = iters * (csr_ps - pb_ps) > build_ps;
+        // GDN_TRACE_POLICY=1: what the model predicted, next to what the solve then measured (the constants
+        // were fitted to R-MAT on one box -- this line is how they are checked on another graph family)
+        pol_iters = iters;
+        pol_csr_ms = iters * csr_ps * (double)nnz * 1e-9;
+        pol_pb_ms = (iters * pb_ps + build_ps) * (double)nnz * 1e-9;
       }
       const bool forced = env && (env[0] == 'c' || env[0] == 'p');
       if (pb && !forced && pr_gather_is_local(g, 0)) pb = false;  // lattice-like graphs: the merge-path layout is the faster one anyway
@@ -1796,6 +1811,12 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
     if ((rc = gdn_pr_plan_check(plan))) break;
     st.iterations = iter + 1;  // the reference prints iter+1 (omp_base.cc:39)
     st.last_error = diff;
+    if (gdn_option("GDN_TRACE_POLICY"))
+      fprintf(stderr, "[policy] gdn_pr: %llu edges, predicted %.0f iterations, merge-path %.2f ms, blocked %.2f ms (build included) -> %s;"
+              " measured: %d iterations, prep %.2f + solve %.2f = %.2f ms (%.1f ps per edge and iteration, build %.0f ps per edge)\n",
+              (unsigned long long)nnz, pol_iters, pol_csr_ms, pol_pb_ms, plan->layout == GDN_LAYOUT_CSR ? "merge-path" : "blocked",
+              iter + 1, st.prep_ms, st.solve_ms, st.prep_ms + st.solve_ms,
+              st.solve_ms * 1e9 / ((double)(nnz ? nnz : 1) * (iter + 1)), st.prep_ms * 1e9 / (double)(nnz ? nnz : 1));
     st.edges_traversed = nnz * (uint64_t)(iter < max_iter ? iter + 1 : max_iter);
     if (hipMemcpy(scores, d_scores.p, (size_t)m * 4, hipMemcpyDeviceToHost) != hipSuccess) {
       gdn_set_error("gdn_pr: download failed");

@@ -1398,7 +1398,30 @@ struct gdn_sssp_plan {
   DevBuf<SsspCounters> cnt;
   unsigned cap = 0, bigcap = 0, nwords = 0;
   double prep_ms = 0;
+  // ALL WEIGHTS EQUAL (the reference main's own input: src/sssp/main.cc:26 fills 1): shortest distances are hop counts times
+  // that weight, so a resident plan solves through the direction-optimising BFS plan (gdn_bfs.hip) on the transpose it
+  // builds once -- no bucket, no relaxation is repeated -- and converts depths to distances (sssp_depth_to_dist_kernel)
+  gdn_graph *bfs_gin = nullptr;
+  gdn_bfs_plan *bfs = nullptr;
+  int32_t bfs_w = 0;
+  gdn_sssp_plan() {}
+  gdn_sssp_plan(const gdn_sssp_plan &) = delete;
+  gdn_sssp_plan &operator=(const gdn_sssp_plan &) = delete;
+  ~gdn_sssp_plan() {
+    if (bfs) gdn_bfs_plan_free(bfs);
+    if (bfs_gin) gdn_graph_free(bfs_gin);
+  }
 };
+
+// depth (MYINFINITY = unreached) -> distance = depth x w (kDistInf = unreached, and beyond the int range like the relax kernels)
+__global__ void __launch_bounds__(GDN_BLOCK)
+sssp_depth_to_dist_kernel(int32_t *__restrict__ dist, int32_t m, int32_t w) {
+  const int32_t v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v >= m) return;
+  const int32_t d = dist[v];
+  const long long nd = (long long)d * (long long)w;
+  dist[v] = (d == GDN_MYINFINITY || nd >= (long long)GDN_DIST_INF) ? GDN_DIST_INF : (int32_t)nd;
+}
 
 // ------------------------------------------------------------------------------------------
 // RECORD TIERS of the dense sweeps.  PageRank's record tiers (gdn_pb.hpp) for a min-plus sweep: an edge of the blocked layout
@@ -2323,7 +2346,44 @@ int gdn_sssp_plan_create(const gdn_graph *g, const int32_t *d_weight, int32_t de
   *plan = nullptr;
   GDN_REQUIRE(g != nullptr && (d_weight != nullptr || g->nnz == 0), "graph / d_weight");
   gdn_sssp_plan *p = new gdn_sssp_plan();
-  const int rc = sssp_plan_init(*p, g, d_weight, dense != 0);
+  // equal weights >= 1 (from 2^22 edges on; GDN_SSSP_UNIT_BFS=0 never, =1 at any size): the BFS route -- the blocked layout
+  // of the sweeps is then not built at all
+  bool bfs_route = false;
+  int32_t w_all = 0;
+  {
+    const char *e = gdn_option("GDN_SSSP_UNIT_BFS");
+    const bool want = dense != 0 && g->nnz > 0 && !(e && e[0] == '0') && (g->nnz >= (1ull << 22) || (e && e[0] == '1'));
+    if (want) {
+      DevBuf<int32_t> rng;
+      if (rng.alloc(2) == GDN_OK) {
+        const int32_t init[2] = {0x7FFFFFFF, -0x7FFFFFFF - 1};
+        int32_t h[2] = {0, 1};
+        if (hipMemcpy(rng.p, init, 8, hipMemcpyHostToDevice) == hipSuccess) {
+          hipLaunchKernelGGL(sssp_weight_range_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, d_weight, (size_t)g->nnz, rng.p);
+          if (hipMemcpy(h, rng.p, 8, hipMemcpyDeviceToHost) == hipSuccess && h[0] == h[1] && h[0] >= 1) {
+            bfs_route = true;
+            w_all = h[0];
+          }
+        }
+      }
+    }
+  }
+  int rc = sssp_plan_init(*p, g, d_weight, dense != 0 && !bfs_route);
+  if (rc == GDN_OK && bfs_route) {
+    HostTimer tb;
+    tb.start();
+    int rb = gdn_graph_transpose(g, &p->bfs_gin);
+    if (rb == GDN_OK) rb = gdn_bfs_plan_create(g, p->bfs_gin, 1, &p->bfs);
+    if (rb == GDN_OK) {
+      p->bfs_w = w_all;
+      p->prep_ms += tb.stop_ms();
+    } else {  // no room for the transpose / the search plan: the sweeps after all
+      delete p;
+      gdn_scratch_trim();
+      p = new gdn_sssp_plan();
+      rc = sssp_plan_init(*p, g, d_weight, dense != 0);
+    }
+  }
   if (rc != GDN_OK) {
     delete p;
     return rc;
@@ -2341,6 +2401,22 @@ int gdn_sssp_run(gdn_sssp_plan *plan, int32_t source, int32_t delta, int32_t *d_
   GDN_REQUIRE(plan != nullptr && d_dist != nullptr, "plan / d_dist");
   GDN_REQUIRE(source >= 0 && source < plan->g->m, "source out of range");
   GDN_REQUIRE(delta >= 1, "delta must be >= 1");
+  if (plan->bfs) {  // equal weights: hop counts x weight (any delta gives these distances)
+    gdn_stats bs;
+    memset(&bs, 0, sizeof(bs));
+    GDN_TRY(gdn_bfs_run(plan->bfs, source, d_dist, &bs));  // (solve_ms: the search's own timed region)
+    HostTimer t;
+    t.start();
+    hipLaunchKernelGGL(sssp_depth_to_dist_kernel, dim3(gdn_nblocks((uint64_t)plan->g->m)), dim3(GDN_BLOCK), 0, 0, d_dist, plan->g->m,
+                       plan->bfs_w);
+    GDN_HIP(hipDeviceSynchronize());
+    bs.solve_ms += t.stop_ms();
+    bs.prep_ms = plan->prep_ms;
+    bs.last_error = (double)bs.edges_traversed;  // SSSP: edges relaxed -- every out-edge of a reached vertex once
+    bs.reserved = 1;                             // (include/gardenia_hip.h: 1 = solved through the BFS plan)
+    if (stats) *stats = bs;
+    return GDN_OK;
+  }
   return sssp_run(*plan, source, delta, d_dist, stats);
 }
 

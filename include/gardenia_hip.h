@@ -425,6 +425,10 @@ int gdn_sssp_dev(const gdn_graph *csr, const int32_t *d_weight, int32_t source, 
  * layout of the out-CSR with the weights in tile order: while the frontier is heavy the solver runs
  * Bellman-Ford sweeps over all edges (LDS min-reduction per destination bin) instead of worklist
  * passes, then finishes with a worklist.  Distances are the exact shortest distances either way. */
+/* Round 5: when ALL weights are equal (>= 1; the reference main's own input, src/sssp/main.cc:26 fills 1) and the graph has
+ * 2^22 edges or more, a dense plan solves through the direction-optimising BFS plan (gdn_bfs_plan_*) on the transpose it builds
+ * once, and multiplies the depths by the weight: the same distances, no relaxation repeated (stats.reserved = 1 says so;
+ * GDN_SSSP_UNIT_BFS=0 keeps the sweeps, =1 takes the route at any size). */
 typedef struct gdn_sssp_plan gdn_sssp_plan;
 int gdn_sssp_plan_create(const gdn_graph *csr, const int32_t *d_weight, int32_t dense, gdn_sssp_plan **plan);
 int gdn_sssp_plan_free(gdn_sssp_plan *plan);

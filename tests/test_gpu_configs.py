@@ -157,7 +157,7 @@ def test_rmat_build_ex_equals_its_numpy_twin(abc, flags):
     wi = graphio.transpose(want)
     assert gi.m == want.m and np.array_equal(gi.rowptr, wi.rowptr) and np.array_equal(gi.colidx, wi.colidx)
     if flags & 2:
-        assert ((g.degrees() + gi.degrees()) > 0).all() and g.m < (1 << 14)
+        assert ((g.degrees() + gi.degrees()) > 0).all() and g.m <= (1 << 14) and (g.m < (1 << 14) or abc[0] < 0.3)
     else:
         assert g.m == 1 << 14
 
@@ -270,7 +270,9 @@ def test_pagerank_summation_order_is_the_only_difference(orc, monkeypatch):
     scores, rel, off = solve()
     print("PR RMAT-24 converged (%d iterations): rows beyond 1e-4: %d, max rel %.3e, min in-degree of those rows %s; rows of >= 10^4 "
           "in-edges: %d" % (it, len(off), float(rel.max()), int(indeg[off].min()) if len(off) else None, int((indeg >= 10_000).sum())))
-    assert len(off) <= 2000 and float(rel.max()) <= 2.5e-3
+    # measured (round 5, session r05_01): 22 iterations, NO row beyond 1e-4 at convergence (max 1.7e-5) although 2 325 rows have
+    # >= 10^4 in-edges -- the drift of the reference's sequential sum peaks in the first iteration (equal terms), not here
+    assert len(off) <= 20 and float(rel.max()) <= 5e-4
     if len(off):
         assert int(indeg[off].min()) >= 10_000
     monkeypatch.setenv("GDN_PR_SUM", "reference")

@@ -192,9 +192,12 @@ def test_bfs_bench_sources_equal_the_oracle_at_full_size(big, big_host, orc):
     print("BFS RMAT-%d, bench sources %s: solve ms %s, all depths == oracle" % (SCALE, sources, ["%.2f" % x for x in ms]))
 
 
-# measured on RMAT-27 (round 5, first session with this test): see the assert; the bound is the measurement with headroom
-PR_CONVERGED_MAX_ROWS = int(os.environ.get("GDN_TEST_PR_CONVERGED_MAX_ROWS", "20000"))
-PR_CONVERGED_MAX_REL = float(os.environ.get("GDN_TEST_PR_CONVERGED_MAX_REL", "2.5e-3"))
+# measured on RMAT-27 (round 5, profiles/r05_fullsize_oracle_tests.txt): 20 iterations on both sides, ONE row of the 134 M beyond 1e-4
+# (1.35e-4; 902 890 in-edges), none with GDN_PR_SUM=reference on the hub rows (max 4.5e-6).  Far fewer than in the iteration from 1/m
+# (379 rows, tests/test_gpu_configs.py): 10^5..10^6 EQUAL terms are the worst case of a sequential fp32 sum, converged contributions differ.
+# The bounds are the measurement with headroom for another summation order of the oracle's OpenMP error reduction.
+PR_CONVERGED_MAX_ROWS = int(os.environ.get("GDN_TEST_PR_CONVERGED_MAX_ROWS", "50"))
+PR_CONVERGED_MAX_REL = float(os.environ.get("GDN_TEST_PR_CONVERGED_MAX_REL", "5e-4"))
 
 
 def test_pagerank_converged_vs_oracle_at_full_size(big, big_host, orc, monkeypatch):
@@ -280,14 +283,18 @@ def test_sssp_unit_weights_equal_bfs_depths():
     w = torch.ones(nnz, dtype=torch.int32, device=dev)
     dist = torch.empty(m, dtype=torch.int32, device=dev)
     depth = torch.empty(m, dtype=torch.int32, device=dev)
-    plan = C.c_void_p()
-    _cabi.check(L.gdn_sssp_plan_create(go, p(w), 1, C.byref(plan)))
     st = _cabi.GdnStats()
-    _cabi.check(L.gdn_sssp_run(plan, src, 1, p(dist), C.byref(st)))
-    L.gdn_sssp_plan_free(plan)
     _cabi.check(L.gdn_bfs_dev(go, gi, src, p(depth), C.byref(st)))
     depth = torch.where(depth == 1000000000, torch.full_like(depth, 2147483647), depth)
-    assert bool((dist == depth).all())
+    for route in (b"0", None):  # the dense sweeps (equal weights: no weight stream), then the default = the BFS route of round 5
+        _cabi.check(L.gdn_option_set(b"GDN_SSSP_UNIT_BFS", route))
+        plan = C.c_void_p()
+        _cabi.check(L.gdn_sssp_plan_create(go, p(w), 1, C.byref(plan)))
+        st = _cabi.GdnStats()
+        _cabi.check(L.gdn_sssp_run(plan, src, 1, p(dist), C.byref(st)))
+        L.gdn_sssp_plan_free(plan)
+        assert bool((dist == depth).all()), route
+    _cabi.check(L.gdn_option_set(b"GDN_SSSP_UNIT_BFS", None))
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
 

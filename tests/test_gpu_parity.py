@@ -420,6 +420,7 @@ def test_pr_placement_search_is_bitwise_neutral(orc, monkeypatch, capfd, world, 
     monkeypatch.setenv("GDN_PLACE_MIN_EDGES", "1")
     monkeypatch.setenv("GDN_PLACE_MIN_BYTES", "1")
     monkeypatch.setenv("GDN_PR_PLACE_TRACE", "1")
+    monkeypatch.setenv("GDN_PR_PLACE_COPIES", "1")  # (the copies of phase B's streams are searched on request only since round 5)
     res = []
     for tries in ("0", "2", "hook"):
         monkeypatch.setenv("GDN_PR_PLACE", "0" if tries == "hook" else tries)
@@ -1229,6 +1230,43 @@ def test_sssp_plan_stream_widths_and_fused_phases(orc, monkeypatch, wlo, whi, de
     dist = np.full(g.m, solvers.K_DIST_INF, np.int32)
     s = graphio.first_nonisolated(g)
     solvers.SSSPSolver(solvers.Graph(csr=g), s, wt, dist, delta)
+    assert np.array_equal(dist, orc.sssp_dijkstra(g, wt, s))
+
+
+@pytest.mark.parametrize("w", [1, 7, 1 << 27])
+def test_sssp_equal_weights_solve_through_the_bfs_plan(orc, monkeypatch, w):
+    """Equal weights (the reference main's own input: src/sssp/main.cc:26 fills 1): a resident plan of 2^22 edges or more solves
+    through the direction-optimising BFS plan on the transpose it builds and multiplies the depths by the weight
+    (GDN_SSSP_UNIT_BFS=1 forces the route at test size, =0 keeps the sweeps).  Same distances as Dijkstra and as the sweeps,
+    for any delta, unreached = kDistInf; a product beyond the int range reads "no path" like in the relax kernels."""
+    rng = np.random.default_rng(77)
+    m, src, dst = graphio.grid2d_edges(60, 60)
+    graphs = [graphio.rmat_graph(15, 16, seed=62), graphio.build_csr(m + 5, src, dst)]  # (+ 5 unreachable vertices)
+    for g in graphs:
+        wt = np.full(g.nnz, w, np.int32)
+        res = {}
+        for route in ("1", "0"):
+            monkeypatch.setenv("GDN_SSSP_UNIT_BFS", route)
+            sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+            res[route] = [sp.run(s, delta) for s, delta in ((graphio.first_nonisolated(g), 1), (int(np.argmax(g.degrees())), 16))]
+            sp.close()
+        for (d1, st1), (d0, st0), s in zip(res["1"], res["0"], (graphio.first_nonisolated(g), int(np.argmax(g.degrees())))):
+            assert np.array_equal(d1, d0)
+            assert st1["edges_traversed"] == st0["edges_traversed"]
+            if w < (1 << 20):
+                assert np.array_equal(d1, orc.sssp_dijkstra(g, wt, s))
+            else:  # depth x 2^27 leaves the int range from depth 16 on: those vertices read kDistInf on both routes
+                depth = orc.bfs_serial(g, s).astype(np.int64)
+                want = np.where((depth == solvers.MYINFINITY) | (depth * w >= solvers.K_DIST_INF), solvers.K_DIST_INF, depth * w)
+                assert np.array_equal(d1, want.astype(np.int32))
+    # mixed weights never take the route
+    monkeypatch.setenv("GDN_SSSP_UNIT_BFS", "1")
+    g = graphs[0]
+    wt = rng.integers(1, 3, size=g.nnz).astype(np.int32)
+    sp = solvers.ResidentSSSP(solvers.Graph(csr=g), wt, dense=True)
+    s = graphio.first_nonisolated(g)
+    dist, st = sp.run(s, 2)
+    sp.close()
     assert np.array_equal(dist, orc.sssp_dijkstra(g, wt, s))
 
 

@@ -23,6 +23,9 @@ for name in (sys.argv[1:] or ["uniform", "small_world"]):
     ho, hi = C.c_void_p(), C.c_void_p()
     if name == "rmat":
         _cabi.check(L.gdn_rmat_build(24, 16, graphio.K_RAND_SEED, 1, C.byref(ho), C.byref(hi)))
+    elif name.startswith("uniform") and name != "uniform":  # uniform<scale>: 2^scale vertices, 16 x 2^scale draws, generated on the device
+        sc = int(name[7:])
+        _cabi.check(L.gdn_rmat_build_ex(sc, 16 << sc, 0.25, 0.25, 0.25, graphio.K_RAND_SEED, 1, C.byref(ho), C.byref(hi)))
     else:
         m, src, dst = SHAPES[name]()
         g = graphio.build_csr_device(m, src, dst)
