@@ -411,18 +411,20 @@ def main():
                 out["bfs"] = dict(med, plan_build_s=t_bplan, ms_stats=med_min([r["ms"] for r in runs]), runs=len(runs),
                                   gteps_median=med["gteps"], gteps_best=best["gteps"],
                                   roofline={"bound": "hbm", "achieved": med["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": med["gbs"] / HBM_PEAK_GBS, "frac_best_run": best["gbs"] / HBM_PEAK_GBS,
+                                            "speed_vs_model": med["gbs"] / HBM_PEAK_GBS, "speed_vs_model_best_run": best["gbs"] / HBM_PEAK_GBS,
                                             "algorithmic_bytes": med["bytes"],
                                             "model": "SUM_reached (16 + 8 outdeg) + 4 m (SURVEY 8d)",
                                             "note": "the model charges every out-edge of the reached part (a top-down "
                                                     "search); the direction-optimizing search skips most of them in "
                                                     "its bottom-up levels, so frac can exceed 1 -- it compares with a "
-                                                    "search that walks all edges, it is not an HBM utilisation "
-                                                    "(per-level figures: profiles/r03_bfs_bottom_up.txt)"})
+                                                    "search that walks all edges, it is not an HBM utilisation: that is `frac` "
+                                                    "(= frac_traffic, counter bytes / time / peak; null where no counter session "
+                                                    "of this scale is committed) (per-level figures: profiles/r03_bfs_bottom_up.txt)"})
                 # counter traffic was taken on the FIRST source (tools/traffic_run.py): its own time is the divisor
                 first = sorted(r["ms"] for r in runs if r["source"] == runs[0]["source"])
                 attach_traffic(out["bfs"]["roofline"], "bfs", args.scale, first[(len(first) - 1) // 2] * 1e-3)
                 out["bfs"]["roofline"]["traffic_of_source"] = runs[0]["source"]
+                out["bfs"]["roofline"]["frac"] = out["bfs"]["roofline"]["frac_traffic"]  # the utilisation
                 out["bfs"]["ms_by_source"] = {str(src_): sorted(r["ms"] for r in runs if r["source"] == src_) for src_ in sorted({r["source"] for r in runs})}
                 out["gteps_bfs"] = med["gteps"]
                 out["gteps_bfs_best"] = best["gteps"]
@@ -744,6 +746,8 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
         _cabi.check(L.gdn_tc_plan_count(tplan, C.byref(total), C.byref(st)))
         if i:
             ms.append(st.solve_ms)
+    walked_plan = C.c_uint64(0)  # forward count: the list elements walked around middle vertices below the core
+    _cabi.check(L.gdn_tc_plan_walked_elements(tplan, C.byref(walked_plan)))
     L.gdn_tc_plan_free(tplan)
     form = {0: "u-centric", 1: "v-centric", 2: "binary search", 3: "forward (rank-ordered DAG, walks start behind v)"}.get(st.reserved & 0xFF, "?")
     core_ranks = st.reserved >> 8  # forward count: the top ranks counted on the core bit matrix (tc_core_count_kernel)
@@ -760,26 +764,32 @@ def bench_tc(L, _cabi, graphio, torch, np, device, args):
         # forward form: SUM_u C(d+(u), 2) = (SUM_u d+(u)^2 - nnz) / 2 list elements (the out-degrees do not depend on the labelling)
         walked = (pr_[1] - nnz.value) // 2 if (st.reserved & 0xFF) == 3 else (pr_[1] if st.reserved == 1 else pr_[0])
         read_b = 4 * walked + 12 * nnz.value + 16 * (m.value + 1)
-        # with the core only the walks around middle vertices BELOW the top ranks are walks of lists: the figure has no meaning then
-        list_gbs = None if core_ranks else read_b / (mm["median"] * 1e-3) / 1e9
+        # with the core only the walks around middle vertices BELOW the top ranks are walks of lists (gdn_tc_plan_walked_elements);
+        # the core kernel's row reads of the bit matrix are not in this figure (they are in `frac`, the counter bytes)
+        if core_ranks:
+            read_b = 4 * walked_plan.value + 12 * nnz.value + 16 * (m.value + 1)
+        list_gbs = read_b / (mm["median"] * 1e-3) / 1e9
     rec = {"workload": "triangle count, %s, DAG orientation by degree (src/common/graph.cc:67)" % what,
            "vertices": m.value, "undirected_csr_entries": snnz.value, "dag_edges": nnz.value, "triangles": total.value,
            "orient_s": t_orient, "plan_build_s": t_tplan, "ms": mm, "gteps": nnz.value / (mm["median"] * 1e-3) / 1e9, "formulation": form,
            "core_ranks": core_ranks,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "speed_vs_model": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes_per_launch": nbytes.value,
                         "model": "4 SUM_(u,v) (d+(u) + d+(v)) + 8 nnz_dag + 8(m+1) (SURVEY 8d, merge-equivalent)",
                         "kernel": "tc_count_kernel" + (" beside tc_core_count_kernel (the look-ups around the top %d ranks on a bit matrix, DESIGN 4.7)" % core_ranks if core_ranks else ""),
                         "note": "the model counts what a MERGE intersect reads (both lists of every DAG edge, whole); the forward "
-                                "count walks one list per edge from behind v on -- a quarter of those elements -- so this "
-                                "fraction is a speed relative to the merge formulation and can exceed 1; the physical rate is "
-                                "kernel_list_read_frac",
+                                "count walks one list per edge from behind v on -- a quarter of those elements -- so "
+                                "speed_vs_model is a speed relative to the merge formulation and can exceed 1; the HBM utilisation "
+                                "is `frac` (= frac_traffic: counter bytes / time / peak, null where no counter session of this "
+                                "scale is committed)",
                         "kernel_list_read_gbs": list_gbs,
-                        "kernel_list_read_frac": list_gbs / HBM_PEAK_GBS if list_gbs else None,  # (None with the core)
+                        "kernel_list_read_frac": list_gbs / HBM_PEAK_GBS if list_gbs else None,
+                        "list_elements_walked": walked_plan.value if (st.reserved & 0xFF) == 3 else None,
                         "kernel_list_read_model": "4 B x the list elements the formulation that ran walks (one list per DAG "
                                                   "edge, from behind v in the forward form) + 12 nnz_dag + 16(m+1): what the "
                                                   "kernel requests, not what the model credits; counters: profiles/r03_tc_pmc.md"}}
     attach_traffic(rec["roofline"], "tc", args.tc_scale, mm["median"] * 1e-3)
+    rec["roofline"]["frac"] = rec["roofline"]["frac_traffic"]
     # the one-shot drop-in on the resident DAG (what TCSolver binds to: no plan handed in; the preparation -- rank order, transpose,
     # walk starts, core matrix -- is stats.prep_ms, the count stats.solve_ms)
     try:
@@ -1020,6 +1030,10 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "bytes_on_relaxed_edges": b_relaxed,
                                   "model_relaxed": "16 reached + 12 edges_relaxed + 4 m: every relaxation the solver made "
                                                    "(list passes: the out-edges of their list; a dense sweep: every edge)"}}
+        if st.reserved == 1:  # solved as a BFS: the model charges every reached edge, the search skips most -- a speed, not a utilisation
+            roof = rec[name]["roofline"]
+            roof["speed_vs_model"] = roof.pop("frac")
+            roof["frac"] = None
         if ab_sweeps is not None and st.reserved == 1:
             rec[name]["route"] = "equal weights: direction-optimising BFS plan on the transpose, depths x weight (plan_build_s includes the transpose)"
             rec[name]["ab_dense_sweeps"] = ab_sweeps

@@ -142,6 +142,7 @@ PROTOTYPES = {
     "gdn_tc_plan_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
     "gdn_tc_plan_count": (C.c_int, [_vp, C.POINTER(_u64), _st]),
     "gdn_tc_plan_free": (C.c_int, [_vp]),
+    "gdn_tc_plan_walked_elements": (C.c_int, [_vp, C.POINTER(_u64)]),
     "gdn_tc_rows_dev": (C.c_int, [_vp, _i32, _i32, C.POINTER(_u64), _st]),
 }
 

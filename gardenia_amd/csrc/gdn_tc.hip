@@ -910,6 +910,29 @@ tc_core_items_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict_
   }
 }
 
+// List elements the forward count WALKS with a core of the ranks >= base: the look-ups around a middle vertex v < base.  Row u
+// with d out-neighbours of which the first n lie below base contributes SUM_{i < n} (d - 1 - i) = n (d - 1) - n (n - 1) / 2
+// (edge i of the ascending list starts its walk behind itself); the look-ups around v >= base are row ANDs of the bit matrix.
+__global__ void __launch_bounds__(GDN_BLOCK)
+tc_walked_elements_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned base,
+                          unsigned long long *__restrict__ out) {
+  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  unsigned long long acc = 0;
+  for (uint64_t u = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; u < (uint64_t)m; u += (uint64_t)gridDim.x * GDN_BLOCK) {
+    const eoff_t b = rowptr[u];
+    const unsigned long long d = rowptr[u + 1] - b;
+    unsigned long long lo = 0, hi = d;
+    while (lo < hi) {  // first position with an id >= base
+      const unsigned long long mid = (lo + hi) >> 1;
+      if ((unsigned)colidx[b + mid] < base) lo = mid + 1;
+      else hi = mid;
+    }
+    if (lo) acc += lo * (d - 1) - lo * (lo - 1) / 2;
+  }
+  acc = gdn_block_sum(acc, s_red);
+  if (threadIdx.x == 0 && acc) atomicAdd(out, acc);
+}
+
 typedef unsigned tc_u32x2 __attribute__((ext_vector_type(2)));
 template <int R>  // K = 4096 R: R 64-bit words of a row (and of B_u) per lane
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -1410,6 +1433,22 @@ int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats) {
 
 int gdn_tc_plan_free(gdn_tc_plan *plan) {
   delete plan;
+  return GDN_OK;
+}
+
+int gdn_tc_plan_walked_elements(const gdn_tc_plan *plan, uint64_t *elements) {
+  GDN_REQUIRE(plan != nullptr && elements != nullptr, "plan / elements");
+  *elements = 0;
+  if (plan->form != 3 || !plan->dag) return GDN_OK;  // (the other formulations: gdn_tc_probe_counts)
+  DevBuf<unsigned long long> acc;
+  GDN_TRY(acc.alloc(1));
+  GDN_HIP(hipMemset(acc.p, 0, 8));
+  const unsigned base = (unsigned)plan->dag->m - plan->core_k;
+  hipLaunchKernelGGL(tc_walked_elements_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, plan->dag->rowptr, plan->dag->colidx, plan->dag->m, base,
+                     acc.p);
+  unsigned long long h = 0;
+  GDN_HIP(hipMemcpy(&h, acc.p, 8, hipMemcpyDeviceToHost));
+  *elements = h;
   return GDN_OK;
 }
 

@@ -452,6 +452,10 @@ typedef struct gdn_tc_plan gdn_tc_plan;
 int gdn_tc_plan_create(const gdn_graph *csr, int32_t oriented, gdn_tc_plan **plan);
 int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats);
 int gdn_tc_plan_free(gdn_tc_plan *plan);
+/* List elements the forward count of this plan walks against its hash sets: the look-ups around the middle vertices BELOW the
+ * core's ranks (all of them without a core: (SUM d+(u)^2 - nnz) / 2); 0 for the other formulations.  4 bytes each are what
+ * tc_count_kernel requests from the lists -- bench.py's kernel_list_read_frac.  Blocking. */
+int gdn_tc_plan_walked_elements(const gdn_tc_plan *plan, uint64_t *elements);
 /* The DAG orientation alone (src/common/graph.cc:67-113, what `Graph g(prefix, USE_DAG)` hands to TCSolver), and the count
  * over the source rows [row_lo, row_hi) of an ORIENTED graph: the shard of a multi-GPU count -- every rank holds the DAG,
  * the ranges partition its rows (by DAG-edge count), the partial counts add up (gardenia_amd.sharded.ShardedTC).

@@ -84,14 +84,15 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert r["bfs"]["ms_stats"]["n"] >= 10 and 0 < r["bfs"]["roofline"]["frac"] < 1
+    assert r["bfs"]["ms_stats"]["n"] >= 10 and 0 < r["bfs"]["roofline"]["speed_vs_model"] < 1
+    assert r["bfs"]["roofline"]["frac"] is None  # (the counter-based utilisation: no counter session of this scale is committed)
     assert r["bfs"]["roofline"]["algorithmic_bytes"] == 16 * r["bfs"]["reached"] + 8 * r["bfs"]["edges_traversed"] + 4 * r["config"]["vertices"]
     sp = r["spmv"]
     assert sp["ms"]["n"] >= 10 and 0 < sp["roofline"]["frac"] < 1
     assert sp["roofline"]["algorithmic_bytes_per_launch"] == 8 * (sp["rows"] + 1) + 12 * sp["nnz"] + 8 * sp["rows"]
     assert len(sp["oneshot_gdn_spmv"]) == 2 and sp["oneshot_gdn_spmv"][0]["solve_ms"] > 0
     tc = r["tc"]
-    assert tc["ms"]["n"] >= 10 and tc["triangles"] > 0 and 0 < tc["roofline"]["frac"] < 1
+    assert tc["ms"]["n"] >= 10 and tc["triangles"] > 0 and 0 < tc["roofline"]["speed_vs_model"] < 1 and tc["roofline"]["frac"] is None
     assert tc["roofline"]["algorithmic_bytes_per_launch"] > 8 * tc["dag_edges"]
     tr = r["traversal"]
     for k in ("sssp_unit", "sssp_u1_255_delta16"):

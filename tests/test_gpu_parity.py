@@ -1251,14 +1251,16 @@ def test_sssp_equal_weights_solve_through_the_bfs_plan(orc, monkeypatch, w):
             res[route] = [sp.run(s, delta) for s, delta in ((graphio.first_nonisolated(g), 1), (int(np.argmax(g.degrees())), 16))]
             sp.close()
         for (d1, st1), (d0, st0), s in zip(res["1"], res["0"], (graphio.first_nonisolated(g), int(np.argmax(g.degrees())))):
-            assert np.array_equal(d1, d0)
-            assert st1["edges_traversed"] == st0["edges_traversed"]
+            depth = orc.bfs_serial(g, s).astype(np.int64)
+            in_range = bool(((depth == solvers.MYINFINITY) | (depth * w < solvers.K_DIST_INF)).all())
+            if in_range:  # (beyond the int range the reference's own `dist + w` is undefined: only the route's contract is checked)
+                assert np.array_equal(d1, d0)
+                assert st1["edges_traversed"] == st0["edges_traversed"]
             if w < (1 << 20):
                 assert np.array_equal(d1, orc.sssp_dijkstra(g, wt, s))
-            else:  # depth x 2^27 leaves the int range from depth 16 on: those vertices read kDistInf on both routes
-                depth = orc.bfs_serial(g, s).astype(np.int64)
-                want = np.where((depth == solvers.MYINFINITY) | (depth * w >= solvers.K_DIST_INF), solvers.K_DIST_INF, depth * w)
-                assert np.array_equal(d1, want.astype(np.int32))
+            # depth x 2^27 leaves the int range from depth 16 on: those vertices read kDistInf
+            want = np.where((depth == solvers.MYINFINITY) | (depth * w >= solvers.K_DIST_INF), solvers.K_DIST_INF, depth * w)
+            assert np.array_equal(d1, want.astype(np.int32))
     # mixed weights never take the route
     monkeypatch.setenv("GDN_SSSP_UNIT_BFS", "1")
     g = graphs[0]
@@ -1461,6 +1463,44 @@ def test_tc_forward_core_vs_oracle(orc, scale, ef, seed, core, monkeypatch):
     dag = orc.tc_orient(g)
     total, st = solvers.TCSolver(solvers.Graph(csr=dag), oriented=True)
     assert total == want and st["reserved"] >> 8 == (int(core) if has_core else 0)
+
+
+@pytest.mark.parametrize("core", ["0", "4096"])
+def test_tc_plan_walked_elements(monkeypatch, core):
+    """gdn_tc_plan_walked_elements (bench.py's kernel_list_read_frac): the list elements the forward count walks against its hash
+    sets = SUM over the DAG edges u -> v whose middle vertex v ranks below the core of the out-neighbours of u that outrank v;
+    without a core (SUM d+(u)^2 - nnz) / 2."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    monkeypatch.setenv("GDN_TC_FORM", "f")
+    monkeypatch.setenv("GDN_TC_CORE", core)
+    g = graphio.symmetrize(graphio.rmat_graph(14, 16, seed=45))
+    deg = g.degrees().astype(np.int64)
+    rank = np.empty(g.m, np.int64)
+    rank[np.lexsort((np.arange(g.m), deg))] = np.arange(g.m)  # (degree, id) order: src/common/graph.cc:80-81
+    src, dst = graphio.csr_to_coo(g)
+    keep = rank[dst] > rank[src]
+    ru, rv = rank[src[keep]], rank[dst[keep]]
+    order = np.lexsort((rv, ru))
+    ru, rv = ru[order], rv[order]
+    dplus = np.bincount(ru, minlength=g.m)
+    first = np.concatenate(([0], np.cumsum(dplus)[:-1]))
+    pos = np.arange(len(ru)) - first[ru]            # position of v in u's ascending list
+    base = g.m - int(core)
+    want = int((dplus[ru] - 1 - pos)[rv < base].sum())
+    if core == "0":
+        assert want == (int((dplus ** 2).sum()) - len(ru)) // 2
+    L = _cabi.lib()
+    h, plan = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(g.m, g.nnz, g.rowptr.ctypes.data_as(C.c_void_p), g.colidx.ctypes.data_as(C.c_void_p), C.byref(h)))
+    _cabi.check(L.gdn_tc_plan_create(h, 0, C.byref(plan)))
+    got = C.c_uint64(0)
+    _cabi.check(L.gdn_tc_plan_walked_elements(plan, C.byref(got)))
+    total, st = C.c_uint64(0), _cabi.GdnStats()
+    _cabi.check(L.gdn_tc_plan_count(plan, C.byref(total), C.byref(st)))
+    L.gdn_tc_plan_free(plan)
+    L.gdn_graph_free(h)
+    assert st.reserved >> 8 == int(core) and got.value == want > 0
 
 
 def test_tc_forward_core_dense_and_sparse_shapes(orc, monkeypatch):
