@@ -1073,6 +1073,22 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "model": "(8(m+1) + 8 nnz + 8 m) x passes (SURVEY 8d, CC per round; upper bound for "
                                            "Afforest's sampling passes)"}}
         attach_traffic(rec[name]["roofline"], "cc" if rev is not None else "cc_out", args.trav_scale, sec)
+    # the reference's fusion variant of CC (src/cc/fusion.cu:47: the Shiloach-Vishkin rounds inside one persistent kernel), for
+    # the record: it sweeps all edges once per round where Afforest sweeps them once in all
+    try:
+        _cabi.check(L.gdn_option_set(b"GDN_CC_SV", b"fused"))
+        ms = []
+        for i in range(4):
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_cc_dev(go, None, C.c_void_p(comp.data_ptr()), C.byref(st)))
+            if i:
+                ms.append(st.solve_ms)
+        rec["cc_sv_fused_kernel"] = {"ms": med_min(ms), "rounds": st.iterations, "ran_fused": st.reserved == 2,
+                                     "components": int((comp == torch.arange(m, dtype=torch.int32, device=device)).sum().item())}
+    except Exception as e:
+        log(f"[bench] fused SV skipped: {e}")
+    finally:
+        L.gdn_option_set(b"GDN_CC_SV", None)
     L.gdn_graph_free(go)
     L.gdn_graph_free(gi)
     log(f"[bench] traversal: {rec}")

@@ -97,12 +97,79 @@ __global__ void __launch_bounds__(GDN_BLOCK) cc_shortcut_kernel(int32_t *__restr
   comp[v] = c;
 }
 
-// ------------------------------------------------------------------------------------------
-// Afforest
-// ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int32_t cc_ld(const int32_t *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// ------------------------------------------------------------------------------------------
+// The "fusion" variant (src/cc/fusion.cu:47 cc_kernel: the whole Shiloach-Vishkin solve in ONE persistent kernel behind a
+// software grid barrier, include/gbar.h): hook over every edge, barrier, pointer jumping, barrier, until a round changes
+// nothing.  Cooperative grid, the ticket barrier of gdn_common.hpp; every label access is device-scope (the eight XCD L2s
+// are not coherent within a launch).  A wavefront takes 64 consecutive rows and walks their edges 64 at a time, row by row.
+// Kept for completeness of the reference's fusion row (GDN_CC_SV=fused): Afforest needs ONE sweep over the edges where
+// this needs ~5, so it is not the default (RMAT-24: DESIGN 4.6).
+// ctl: [0..2] the rotating "changed" flags of rounds i % 3, [3] rounds run.
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GDN_BLOCK)
+cc_sv_fused_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, int32_t *comp, unsigned *ctl,
+                   unsigned *bar) {
+  const unsigned lane = gdn_lane();
+  const uint64_t wave = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * GDN_BLOCK) >> 6;
+  const uint64_t tid = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x, nthreads = (uint64_t)gridDim.x * GDN_BLOCK;
+  for (unsigned round = 0;; round++) {
+    bool any = false;
+    for (uint64_t v0 = wave * 64; v0 < (uint64_t)m; v0 += nwaves * 64) {  // hook, src/cc/omp_base.cc:24-37
+      const uint64_t v = v0 + lane;
+      eoff_t b = 0, e = 0;
+      int32_t cv = 0;
+      if (v < (uint64_t)m) {
+        b = rowptr[v];
+        e = rowptr[v + 1];
+        cv = cc_ld(comp + v);
+      }
+      unsigned long long rows = __ballot(e > b);
+      while (rows) {
+        const int l = __ffsll((long long)rows) - 1;
+        rows &= rows - 1;
+        const eoff_t rb = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(b >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)b, l);
+        const eoff_t re = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(e >> 32), l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)e, l);
+        const int32_t cs = __builtin_amdgcn_readlane(cv, l);
+        for (eoff_t k = rb + lane; k < re; k += 64) {
+          const int32_t cd = cc_ld(comp + colidx[k]);
+          if (cs != cd) {
+            const int32_t high = cs > cd ? cs : cd, low = cs + (cd - high);
+            if (cc_ld(comp + high) == high) {  // omp_base.cc:33
+              atomicMin(comp + high, low);
+              any = true;
+            }
+          }
+        }
+      }
+    }
+    if (__ballot(any) && lane == 0) __hip_atomic_store(ctl + round % 3u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gdn_grid_barrier(bar, gridDim.x);
+    for (uint64_t v = tid; v < (uint64_t)m; v += nthreads) {  // shortcut, omp_base.cc:38-43
+      int32_t c = cc_ld(comp + v), cc2 = cc_ld(comp + c);
+      if (c != cc2) {
+        while (c != cc2) {
+          c = cc2;
+          cc2 = cc_ld(comp + c);
+        }
+        __hip_atomic_store(comp + v, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (tid == 0) {
+      __hip_atomic_store(ctl + (round + 1u) % 3u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next round's flag
+      __hip_atomic_store(ctl + 3, round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gdn_grid_barrier(bar, gridDim.x);
+    if (__hip_atomic_load(ctl + round % 3u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) break;  // (the same word for every workgroup)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Afforest
+// ------------------------------------------------------------------------------------------
 
 __device__ __forceinline__ void cc_link(int32_t u, int32_t v, int32_t *comp) {  // omp_afforest.cc:12-25
   int32_t p1 = cc_ld(comp + u), p2 = cc_ld(comp + v);
@@ -311,12 +378,47 @@ int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_st
   // sampling rounds, then ONE pass that links the remaining out-edges of EVERY vertex (a link whose two ends already
   // share a root costs two loads).  That is a single sweep over the edges instead of Shiloach-Vishkin's ~5 (RMAT-24:
   // 21.9 ms); GDN_CC_SV=1 keeps the SV rounds (the reference's src/cc/omp_base.cc algorithm) for comparison.
-  if (gin != nullptr || !gdn_option("GDN_CC_SV")) return cc_afforest(g, gin, d_comp, stats);
+  const char *sv = gdn_option("GDN_CC_SV");
+  if (!sv || sv[0] == '0') return cc_afforest(g, gin, d_comp, stats);
+  if (gin != nullptr && sv[0] != 'f') return cc_afforest(g, gin, d_comp, stats);
   const int32_t m = g->m;
   gdn_stats st;
   memset(&st, 0, sizeof(st));
   HostTimer tprep, tsolve;
   tprep.start();
+  if (sv[0] == 'f') {  // GDN_CC_SV=fused: the whole solve in one cooperative launch (cc_sv_fused_kernel)
+    int dev = 0, coop = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cc_sv_fused_kernel, GDN_BLOCK, 0) == hipSuccess && per_cu >= 1) {
+      DevBuf<unsigned> ctl, bar;
+      GDN_TRY(ctl.alloc(4));
+      GDN_TRY(bar.alloc(GDN_GBAR_WORDS));
+      st.prep_ms = tprep.stop_ms();
+      tsolve.start();
+      hipLaunchKernelGGL(cc_init_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, d_comp, m);
+      GDN_HIP(hipMemsetAsync(ctl.p, 0, 4 * sizeof(unsigned), 0));
+      GDN_HIP(hipMemsetAsync(bar.p, 0, GDN_GBAR_WORDS * sizeof(unsigned), 0));
+      const eoff_t *a_rowptr = g->rowptr;
+      const vid_t *a_colidx = g->colidx;
+      int32_t a_m = m;
+      int32_t *a_comp = d_comp;
+      unsigned *a_ctl = ctl.p, *a_bar = bar.p;
+      void *args[] = {&a_rowptr, &a_colidx, &a_m, &a_comp, &a_ctl, &a_bar};
+      // (one workgroup fewer per CU than the occupancy query admits, at most 4: MI355X_MICROARCH.md, residency)
+      const int k = per_cu > 4 ? 4 : (per_cu > 1 ? per_cu - 1 : 1);
+      GDN_HIP(hipLaunchCooperativeKernel((const void *)cc_sv_fused_kernel, dim3((unsigned)(cus * k)), dim3(GDN_BLOCK), args, 0, 0));
+      unsigned h[4] = {0, 0, 0, 0};
+      GDN_HIP(hipMemcpy(h, ctl.p, sizeof(h), hipMemcpyDeviceToHost));
+      st.solve_ms = tsolve.stop_ms();
+      st.iterations = (int32_t)h[3];
+      st.edges_traversed = g->nnz * (uint64_t)h[3];
+      st.reserved = 2;  // (2 = the fused Shiloach-Vishkin kernel ran)
+      if (stats) *stats = st;
+      return GDN_OK;
+    }
+    (void)hipGetLastError();  // no cooperative launch on this device: the rounds as launches, below
+  }
   DevBuf<unsigned long long> bigitems;
   DevBuf<CcCounters> cnt;
   const uint64_t bigcap64 = g->nnz / EXP_CHUNK + (uint64_t)m / 64 + 1024;

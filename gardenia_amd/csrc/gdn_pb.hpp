@@ -165,12 +165,14 @@ struct PbPlacer {
   // a candidate is a fresh allocation, nothing is copied.  Rejected candidates stay allocated until the array is done (hipMalloc
   // hands a freed block out again), at most `hold` of them.
   template <typename T>
-  int search_fresh(DevBuf<T> &buf, const char *name, int n_tries, int hold) {
+  int search_fresh(DevBuf<T> &buf, const char *name, int n_tries, int hold, double stop_ratio = 0.0) {
     if (!buf.p || buf.n * sizeof(T) < min_bytes) return GDN_OK;
     std::vector<DevBuf<T> *> held;
     int rc = GDN_OK;
+    double worst = best;  // slowest placement seen: a candidate below stop_ratio x that IS one of the fast blocks -- stop there
     for (int k = 0; k < n_tries && rc == GDN_OK; k++) {
       if (wall.stop_ms() > budget_ms) break;
+      if (stop_ratio > 0.0 && best < stop_ratio * worst) break;
       if ((int)held.size() >= hold) {
         delete held.front();
         held.erase(held.begin());
@@ -190,6 +192,7 @@ struct PbPlacer {
       double cur = 0;
       if ((rc = timed(&cur)) != GDN_OK) break;
       if (trace) fprintf(stderr, "[%s place] %-12s fresh %d: %.3f ms (best %.3f) at %p (was %p)\n", tag, name, k, cur, best, (void *)buf.p, (void *)cand->p);
+      if (cur > worst) worst = cur;
       if (cur < best * 0.997) best = cur;
       else buf.swap(*cand);
     }

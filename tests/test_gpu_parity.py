@@ -1345,6 +1345,26 @@ def test_cc_vs_oracle_rmat(orc, scale, ef, seed, variant):
     assert np.all(comp <= np.arange(g.m)) and np.all(comp[comp] == comp)
 
 
+@pytest.mark.parametrize("sv", ["1", "fused"])
+def test_cc_shiloach_vishkin_rounds_and_their_fused_kernel(orc, monkeypatch, sv):
+    """GDN_CC_SV=1: the reference's own algorithm (hook + pointer jumping until nothing changes, src/cc/omp_base.cc:19-44) as
+    launches; GDN_CC_SV=fused: the same rounds inside ONE cooperative kernel behind the grid barrier -- the counterpart of
+    src/cc/fusion.cu:47 cc_kernel.  Both end at the minimum-id labels of the oracle's SV fixpoint on directed (out-edges only),
+    symmetric and many-component graphs, a path of 3 000 vertices (many rounds) included."""
+    monkeypatch.setenv("GDN_CC_SV", sv)
+    rng = np.random.default_rng(91)
+    path = np.arange(2999)
+    graphs = [graphio.rmat_graph(15, 16, seed=92), graphio.symmetrize(graphio.rmat_graph(13, 4, seed=93)),
+              graphio.build_csr(3000, path, path + 1),
+              graphio.build_csr(5000, rng.integers(0, 5000, 3000), rng.integers(0, 5000, 3000))]
+    for g in graphs:
+        want, _ = orc.cc_sv(graphio.symmetrize(g))
+        comp = np.arange(g.m, dtype=np.int32)
+        st = solvers.CCSolver(solvers.Graph(csr=g), comp)
+        assert np.array_equal(comp, want)
+        assert st["iterations"] >= 2 and st["reserved"] == (2 if sv == "fused" else 0)
+
+
 def test_cc_many_small_components(orc):
     """No giant component: Afforest's sampled label covers almost nothing, every edge is walked."""
     n, k = 60000, 6  # 10000 cycles of 6 vertices + a long path
