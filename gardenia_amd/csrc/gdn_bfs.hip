@@ -639,6 +639,26 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
 // the in-neighbour scan of those (stage 2), then the 64 next / visited words in one store each.
 // GDN_BFS_BU_FORM=window keeps bfs_bu_kernel.
 // ------------------------------------------------------------------------------------------
+// ---- frontier filter of the bottom-up scan (round 5).  A row whose head is not in the frontier walks its in-neighbours and
+// tests each against the frontier bitmap: 2^27 bits = 16 MB, served beyond L2 at the L2-miss request rate (55 G/s; RMAT-27, the
+// level whose frontier is 70 K hubs: 70 M probes = 1.3 of its 1.87 ms).  While the frontier is SMALL (<= 2^20 vertices) a hashed
+// filter of 2^23 bits (1 MB: stays in every XCD's L2, 195 G probes/s) answers "not in the frontier" for all but
+// |frontier| / 2^23 of the probes; only those go on to the bitmap.
+#define BFS_FILT_LOG 23
+__device__ __forceinline__ unsigned bfs_filt_hash(unsigned u) { return (u * 2654435761u) >> (32 - BFS_FILT_LOG); }
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_filt_build_kernel(const unsigned *__restrict__ front, unsigned nwords, unsigned *__restrict__ filt) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= nwords) return;
+  unsigned w = front[i];
+  while (w) {
+    const unsigned b = (unsigned)__ffs((int)w) - 1u;
+    w &= w - 1u;
+    const unsigned h = bfs_filt_hash((i << 5) | b);
+    atomicOr(&filt[h >> 5], 1u << (h & 31u));
+  }
+}
+
 #define BFS_BW_STEP 2048u  // rows per wave step (64 bitmap words, one per lane) = entries of the wave's list
 #ifndef BFS_BW_THREADS
 #define BFS_BW_THREADS 256
@@ -655,7 +675,8 @@ __global__ void __launch_bounds__(BFS_BW_THREADS)
 bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx, int32_t m, unsigned m_pad,
                    const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
-                   const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace) {
+                   const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace,
+                   int scan_unr = 1, const unsigned *__restrict__ filt = nullptr) {
   static_assert(BFS_BW_GROUP * BFS_BW_STEP <= 65536u, "a list entry is (step << 11 | row in step) in 16 bits");
   __shared__ unsigned s_hf[BFS_HUBS / 32];
   __shared__ unsigned short s_list[BFS_BW_WAVES][BFS_BW_STEP];
@@ -724,9 +745,30 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
       const unsigned rl = list[i], v = gbase + rl;
       const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
       bool found = false;
+      if (scan_unr > 1) {
+        // four in-neighbours and their frontier words per round trip: a row that reaches this stage mostly FAILS (its head was
+        // not in the frontier), so the whole list is walked anyway -- one neighbour at a time that is two dependent loads each
+        for (eoff_t k = rb; k < re && !found; k += 4) {
+          vid_t u[4];
+          unsigned fw4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) u[j] = k + j < re ? in_colidx[k + j] : (vid_t)-1;
+#pragma unroll
+          for (int j = 0; j < 4; j++) fw4[j] = u[j] >= 0 ? front[(unsigned)u[j] >> 5] : 0u;
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            probes += u[j] >= 0 ? 1u : 0u;
+            found = found || ((fw4[j] >> ((unsigned)u[j] & 31u)) & 1u);
+          }
+        }
+      } else
       for (eoff_t k = rb; k < re; k++) {
         const vid_t u = in_colidx[k];
         probes++;
+        if (filt) {  // small frontier: its 1 MB hashed filter (L2 resident) first; most in-neighbours of a failing row stop here
+          const unsigned h = bfs_filt_hash((unsigned)u);
+          if (!((filt[h >> 5] >> (h & 31u)) & 1u)) continue;
+        }
         if ((front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u) {
           found = true;
           break;
@@ -1373,6 +1415,9 @@ struct gdn_bfs_plan {
   unsigned nwords = 0, nwords_pad = 0, qcap = 0, bigcap = 0;
   unsigned long long active_rows = 0;  // rows with in-edges (only they can be discovered)
   DevBuf<unsigned> noin;               // bitmap of the rows without in-edges (bottom-up steps skip them)
+  DevBuf<unsigned> filt;               // 2^BFS_FILT_LOG bits: hashed filter of a small frontier (bfs_filt_build_kernel)
+  unsigned hub_min_deg = 0;            // out-degree of the last hub
+  bool skewed = false;                 // ... >= 16 x the average degree: hub heads find most parents (bfs_plan_init)
   DevBuf<vid_t> hub_id;                // hub heads of the bottom-up step (bfs_bu_kernel): the BFS_HUBS vertices of highest
   DevBuf<unsigned long long> head;     //   out-degree, every row's out-degree | head (bfs_hub_head_kernel),
   DevBuf<unsigned> hub_front;          //   the hubs' frontier bits per level
@@ -1512,6 +1557,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_TRY(p.hub_id.alloc(BFS_HUBS));
       GDN_TRY(p.head.alloc((size_t)m));
       GDN_TRY(p.hub_front.alloc(BFS_HUBS / 32 + 2));  // + the count of hubs in the frontier (64 bits)
+      GDN_TRY(p.filt.alloc((size_t)1 << (BFS_FILT_LOG - 5)));
       hipLaunchKernelGGL(bfs_hub_keys_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, g->rowptr, m, ka.p);
       GDN_HIP(hipGetLastError());
       const unsigned long long *sorted = nullptr;
@@ -1522,7 +1568,18 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
                          hub_idx.p, sorted, p.head.p);
       GDN_HIP(hipGetLastError());
       GDN_HIP(hipDeviceSynchronize());
-      if (gdn_option("GDN_BFS_TRACE")) fprintf(stderr, "[bfs] plan: heads of the bottom-up step %.1f ms\n", th.stop_ms());
+      // how skewed the out-degrees are: the smallest degree among the hubs against the average (R-MAT-27: hundreds against 16;
+      // a uniform random graph: 35 against 16).  With heads that are real hubs the bottom-up step pays from an edge share of
+      // 1/8 on (bfs_run), without it is the worst engine there.
+      if ((unsigned)m > BFS_HUBS) {
+        unsigned long long key = 0;
+        GDN_HIP(hipMemcpy(&key, sorted + ((size_t)m - BFS_HUBS), sizeof(key), hipMemcpyDeviceToHost));
+        p.hub_min_deg = (unsigned)(key >> 32);
+        p.skewed = (unsigned long long)p.hub_min_deg * (unsigned long long)m >= 16ull * g->nnz;
+      }
+      if (gdn_option("GDN_BFS_TRACE"))
+        fprintf(stderr, "[bfs] plan: heads of the bottom-up step %.1f ms; the last of the %u hubs has out-degree %u (average %.1f): %s\n",
+                th.stop_ms(), BFS_HUBS, p.hub_min_deg, (double)g->nnz / (double)m, p.skewed ? "skewed" : "not skewed");
     }
   }
   GDN_HIP(hipDeviceSynchronize());
@@ -1573,10 +1630,25 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     btd_on = atoi(e) != 0;
     btd_force = atoi(e) == 2;
   }
-  int64_t bu_edge_div = 3;  // see the engine choice of a heavy level below (0 = off)
+  // see the engine choice of a heavy level below (0 = off).  Round 5: 8 on a graph with real hubs (gdn_bfs_plan::skewed) -- with
+  // head records, lone heads and the wave kernel the bottom-up step takes RMAT-27's 0.13-share level (source 5) in 1.87 ms where
+  // the binned level takes 2.05 (round 4, before those: 2.45; profiles/r05_bfs_bu_scan.txt); on a uniform random graph a step
+  // from 1/8 on costs 4.9 ms against 3.2 (profiles/r05_bfs_uniform26_trace.txt): there it stays at Beamer's 1/3
+  int64_t bu_edge_div = p.skewed && p.head.p ? 8 : 3;
   if (const char *e = gdn_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
   int64_t bu_stay = 256;
   if (const char *e = gdn_option("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
+  // in-neighbours per round trip of the bottom-up scan: 4 measured the same as 1 on RMAT-24 / 27 (session r05_08: the step is
+  // not bound by the lane-private scan loops) -- the knob stays for the next graph family
+  int bu_scan = 1;
+  if (const char *e = gdn_option("GDN_BFS_BU_SCAN")) bu_scan = atoi(e) > 1 ? 4 : 1;  // A/B knob
+  // largest frontier that gets the hashed filter (GDN_BFS_BU_FILTER=<vertices>, 0 = never) -- on graphs whose frontier bitmap
+  // is beyond an XCD's L2 (from 2^26 vertices = 8 MB on).  Measured (profiles/r05_bfs_bu_scan.txt): RMAT-27's hub-frontier level
+  // 1.865 -> 1.815 ms (source 5: 2.76 -> 2.69 ms), the other searches unchanged; RMAT-24, whose 2 MB bitmap IS L2 resident, pays
+  // the 10 us of the filter's build for nothing (+1.5 %) -- the probes are a small part of that level, its gathers of the failing
+  // rows' offsets and neighbour lists are the rest
+  int64_t filt_max = m >= (1 << 26) ? (1 << 20) : 0;
+  if (const char *e = gdn_option("GDN_BFS_BU_FILTER")) filt_max = atoll(e);
   unsigned hub_min = BFS_HUBS / 8;  // hubs a frontier must hold for the bottom-up step to read the heads
   if (const char *e = gdn_option("GDN_BFS_HUB_MIN")) hub_min = (unsigned)atoi(e);  // tuning knob
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
@@ -1699,10 +1771,19 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
             hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(BFS_HUBS / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p);
           }
           const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
-          if (p.head.p && !(bfe && bfe[0] == 'w'))
+          if (p.head.p && !(bfe && bfe[0] == 'w')) {
+            // frontier of at most 2^20 vertices (its size is the last level's discoveries): the hashed filter in front of the bitmap
+            const int64_t front_n = have_queue ? (int64_t)nfq : awake;
+            const unsigned *filt = nullptr;
+            if (p.filt.p && filt_max > 0 && front_n <= filt_max) {
+              GDN_HIP(hipMemsetAsync(p.filt.p, 0, (size_t)4 << (BFS_FILT_LOG - 5), 0));
+              hipLaunchKernelGGL(bfs_filt_build_kernel, dim3(gdn_nblocks(p.nwords_pad)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords_pad, p.filt.p);
+              filt = p.filt.p;
+            }
             hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(BFS_BW_THREADS), 0, 0, gin->rowptr, gin->colidx, m,
                                p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
-                               p.hub_front.p, hub_min, trace);
+                               p.hub_front.p, hub_min, trace, bu_scan, filt);
+          }
           else
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                              p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
