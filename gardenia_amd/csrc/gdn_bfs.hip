@@ -660,18 +660,25 @@ bfs_filt_build_kernel(const unsigned *__restrict__ front, unsigned nwords, unsig
 }
 
 #define BFS_BW_STEP 2048u  // rows per wave step (64 bitmap words, one per lane) = entries of the wave's list
+// Round 5: 512-thread workgroups held to 80 registers (BFS_BW_MINW 6): eight waves share one copy of the hubs' frontier bits
+// (16 KB), a workgroup takes 51 KB of LDS, three fit a CU = 24 waves where 256-thread workgroups at 97 registers gave 16.  The
+// step is a chain of dependent gathers per wave, so waves in flight are what it is made of: RMAT-27's hub-frontier level (source 5)
+// 2.66 -> 2.41 ms, the other searches and RMAT-24 -0 .. -2 % (sessions/r05_15.sh; a grid of 6 workgroups per CU: +3 %).
 #ifndef BFS_BW_THREADS
-#define BFS_BW_THREADS 256
+#define BFS_BW_THREADS 512
 #endif
 #define BFS_BW_WAVES (BFS_BW_THREADS / 64)
 #ifndef BFS_BW_GRID
-#define BFS_BW_GRID (256 * 4)  // what is resident at once (33 KB of LDS per workgroup); 2048 / 4096: 3 % slower (sessions/r04_60.sh)
+#define BFS_BW_GRID (256 * 3)  // what is resident at once (51 KB of LDS per workgroup); round 4, 256 threads: 2048 / 4096 workgroups 3 % slower (sessions/r04_60.sh)
 #endif
 #ifndef BFS_BW_GROUP
 #define BFS_BW_GROUP 1u    // steps a wave takes together (their open rows share one pass through the stages when they fit the list).
                            // Measured on RMAT-27: 8 -> a late level 0.13 -> 0.10 ms, but the heavy one 0.84 -> 0.92 (sessions/r04_50.sh): 1
 #endif
-__global__ void __launch_bounds__(BFS_BW_THREADS)
+#ifndef BFS_BW_MINW
+#define BFS_BW_MINW 6  // minimum waves per SIMD the register allocation is held to (3 workgroups of 512 threads per CU)
+#endif
+__global__ void __launch_bounds__(BFS_BW_THREADS, BFS_BW_MINW)
 bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx, int32_t m, unsigned m_pad,
                    const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
