@@ -39,11 +39,27 @@ shutil.copyfile(stats, os.path.join(out, f"{tag}_kernel_stats.csv"))
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(out, f"{tag}_kernel_stats.md"), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu --no-extras  (RMAT-27, PB layout)\n\n")
-    f.write("Session (one box, tools/profile_%s.sh)" % tag.split("_")[0] + ": %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n\n" % (session, tag))
+    f.write("Session (one box, tools/profile_%s.sh)" % tag.split("_")[0] + ": %s.  The unprofiled bench line of the same session: `profiles/%s_bench_same_session.json`.\n" % (session, tag))
+    try:
+        pl = json.loads([l for l in open(os.path.join(ROOT, SRC, "bench.json")) if l.startswith("{")][-1])
+        ur = json.loads([l for l in open(os.path.join(ROOT, SRC, "bench_under_rocprof.json")) if l.startswith("{")][-1])
+        f.write("HIP-event kernel time per iteration: unprofiled %.4f ms (A %.4f + B %.4f), under rocprofv3 %.4f ms; ms_per_step %.4f / %.4f.\n\n" % (
+            pl["roofline"]["kernel_ms"], pl["roofline"]["kernel_ms_parts"][0], pl["roofline"]["kernel_ms_parts"][1], ur["roofline"]["kernel_ms"],
+            pl["ms_per_step"], ur["ms_per_step"]))
+    except Exception as e:  # noqa
+        f.write("\n")
     f.write("| kernel | calls | total ms | avg ms | % |\n|---|---|---|---|---|\n")
     for r in rows[:22]:
         f.write(f"| `{r['Name'].split('(')[0][:80]}` | {r['Calls']} | {int(r['TotalDurationNs'])/1e6:.3f} | "
                 f"{float(r['AverageNs'])/1e6:.4f} | {r['Percentage']} |\n")
+if not glob.glob(os.path.join(ROOT, SRC, "fetch/*/*_counter_collection.csv")):
+    # no PMC passes in this session (tools/profile_r05.sh without PMC=1): the statistics and the bench lines only
+    for name in ("bench_under_rocprof.json", "bench.json", "session.txt"):
+        dst = {"bench.json": f"{tag}_bench_same_session.json", "bench_under_rocprof.json": f"{tag}_bench_under_rocprof.json",
+               "session.txt": f"{tag}_session.txt"}[name]
+        shutil.copyfile(os.path.join(ROOT, SRC, name), os.path.join(out, dst))
+    print(open(os.path.join(out, f"{tag}_kernel_stats.md")).read())
+    sys.exit(0)
 fetch = counters(SRC + "/fetch/*/*_counter_collection.csv")
 write = counters(SRC + "/write/*/*_counter_collection.csv")
 kern = {}
