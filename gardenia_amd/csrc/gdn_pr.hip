@@ -1583,7 +1583,9 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
   // (fast blocks run phase A at 1.00-1.01 ms, the others at 1.06-1.18: the search stops at the first candidate 7 % below the
   // slowest placement seen -- on average after six, each a 3.5 GB hipMalloc that waits for the driver to wipe pages whenever
   // another process has just freed that much: 2.0 s for twelve in session r05_06, 0.2 s on an idle box)
-  if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8, 0.93);
+  double stop_ratio = 0.93;  // GDN_PR_PLACE_STOP=0: every candidate is timed (measurement sessions)
+  if (const char *e = gdn_option("GDN_PR_PLACE_STOP")) stop_ratio = atof(e);
+  if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8, stop_ratio);
   // The arrays phase B streams (and U) are searched only on request (GDN_PR_PLACE_COPIES=1; every candidate is a copy, ~40 ms
   // per GB-sized array): timed per phase they gain nothing worth 0.3 s of plan build -- 2.536 -> 2.524 ms and 2.611 -> 2.600 ms
   // of phase B over 18 copies each in sessions r05_03 / r05_04, U 1.001 -> 0.994 ms (profiles/r05_pb_place_search.txt).
