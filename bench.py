@@ -1073,6 +1073,22 @@ def bench_traversal(L, _cabi, graphio, torch, np, device, args):
                                   "model": "(8(m+1) + 8 nnz + 8 m) x passes (SURVEY 8d, CC per round; upper bound for "
                                            "Afforest's sampling passes)"}}
         attach_traffic(rec[name]["roofline"], "cc" if rev is not None else "cc_out", args.trav_scale, sec)
+    # out-edges only with the reverse graph built INSIDE the call (GDN_CC_REVERSE=build): its build lands in prep_ms, the solve is
+    # the one with the giant-component skip -- wall time (prep + solve) is what the default avoids
+    try:
+        _cabi.check(L.gdn_option_set(b"GDN_CC_REVERSE", b"build"))
+        shots = []
+        for i in range(4):
+            st = _cabi.GdnStats()
+            _cabi.check(L.gdn_cc_dev(go, None, C.c_void_p(comp.data_ptr()), C.byref(st)))
+            if i:
+                shots.append({"solve_ms": st.solve_ms, "prep_ms": st.prep_ms})
+        rec["cc_out_edges_only"]["option_reverse_built_in_call"] = {
+            "shots": shots, "components": int((comp == torch.arange(m, dtype=torch.int32, device=device)).sum().item())}
+    except Exception as e:
+        log(f"[bench] cc with the reverse graph built in the call skipped: {e}")
+    finally:
+        L.gdn_option_set(b"GDN_CC_REVERSE", None)
     # the reference's fusion variant of CC (src/cc/fusion.cu:47: the Shiloach-Vishkin rounds inside one persistent kernel), for
     # the record: it sweeps all edges once per round where Afforest sweeps them once in all
     try:

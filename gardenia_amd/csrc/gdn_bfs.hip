@@ -316,6 +316,12 @@ bfs_td_coop_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
 #define BFS_HUBS (1u << 17)      // hubs tracked: their frontier bits are 16 KB of LDS per workgroup
 #endif
 #define BFS_NO_HUB 0xFFFFFFFFu
+// OUTER hubs (round 5): the ranks [BFS_HUBS, BFS_HUBS2) are named by rank in the head records as well and tested against a
+// frontier bitmap indexed by RANK (256 KB: resident in every XCD's L2) instead of the vertex-indexed one (16 MB at RMAT-27: a
+// 64-byte line from beyond L2 per probe).  R-MAT: 66 % of the rows have their head among the 2^17 inner hubs, 89 % among 2^21.
+#ifndef BFS_HUBS2
+#define BFS_HUBS2 (1u << 21)
+#endif
 // keys (out-degree << 32 | vertex) of every vertex, for the sort that ranks them
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_hub_keys_kernel(const eoff_t *__restrict__ out_rowptr, int32_t m, unsigned long long *__restrict__ keys) {
@@ -352,7 +358,7 @@ bfs_hub_rank_kernel(const unsigned long long *__restrict__ sorted, int32_t m, un
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in_colidx,
                     const eoff_t *__restrict__ out_rowptr, int32_t m, const unsigned *__restrict__ rank,
-                    const unsigned long long *__restrict__ sorted, unsigned long long *__restrict__ rec) {
+                    const unsigned long long *__restrict__ sorted, unsigned long long *__restrict__ rec, unsigned n_ranked = BFS_HUBS) {
   const unsigned lane = gdn_lane();
   const size_t nwaves = ((size_t)gridDim.x * GDN_BLOCK) >> 6;
   for (size_t v = ((size_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; v < (size_t)m; v += nwaves) {
@@ -371,7 +377,7 @@ bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restric
     }
     if (lane == 0) {
       unsigned code = best;
-      if (best != BFS_NO_HUB && best >= BFS_HUBS) code = BFS_HEAD_VERTEX | (unsigned)(sorted[(size_t)m - 1 - best] & 0x7FFFFFFFull);
+      if (best != BFS_NO_HUB && best >= n_ranked) code = BFS_HEAD_VERTEX | (unsigned)(sorted[(size_t)m - 1 - best] & 0x7FFFFFFFull);
       const eoff_t d = out_rowptr[v + 1] - out_rowptr[v];
       // bit 63 (out-degrees stay below 2^31): the head is the row's ONLY in-neighbour -- when it is not in the frontier the
       // row cannot be discovered at this level, and the bottom-up step does not queue it for a scan (two row-offset gathers,
@@ -383,11 +389,14 @@ bfs_hub_head_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restric
 }
 // this level's frontier bits of the hubs
 __global__ void __launch_bounds__(GDN_BLOCK)
-bfs_hub_front_kernel(const vid_t *__restrict__ hub_id, const unsigned *__restrict__ front, unsigned *__restrict__ hub_front) {
-  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;  // grid covers BFS_HUBS exactly
+bfs_hub_front_kernel(const vid_t *__restrict__ hub_id, const unsigned *__restrict__ front, unsigned *__restrict__ hub_front,
+                     unsigned *__restrict__ hub_front2 = nullptr) {
+  const unsigned k = blockIdx.x * GDN_BLOCK + threadIdx.x;  // grid covers the ranked hubs exactly (BFS_HUBS, or BFS_HUBS2 with outer hubs)
   const vid_t u = hub_id[k];
   const bool in = u >= 0 && ((front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u);
   const unsigned long long mask = __ballot(in);
+  if (hub_front2 && (gdn_lane() & 31u) == 0) hub_front2[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
+  if (k >= BFS_HUBS) return;  // (whole workgroups: BFS_HUBS is a multiple of the block size)
   if ((gdn_lane() & 31u) == 0) hub_front[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
   // word BFS_HUBS / 32 (zeroed by the host before): how many hubs the frontier holds -- the bottom-up step reads the
   // heads only when that is worth 4 bytes per open row
@@ -438,7 +447,9 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
               const unsigned *__restrict__ noin = nullptr,
               // hub heads (nullable, see above)
               const unsigned long long *__restrict__ rec = nullptr, const unsigned *__restrict__ hub_front = nullptr,
-              unsigned min_hubs = 0, bool trace = false) {
+              unsigned min_hubs = 0, bool trace = false,
+              // the outer hubs' frontier bits by rank (null when the head records name inner hubs only)
+              const unsigned *__restrict__ hub_front2 = nullptr) {
   static_assert(BFS_BU_STEP == 4096 && BFS_BU_WIN <= 16 && BFS_BU_Q >= BFS_BU_STEP && BFS_BU_WORDS <= GDN_BLOCK,
                 "queue entries keep the row in 12 bits, the window in 4; one window's open rows must fit the empty queue");
   __shared__ unsigned long long s_red[4 * GDN_WAVES_PER_BLOCK];
@@ -562,6 +573,7 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
       for (int r = 0; r < BFS_BU_UNR; r++) {  // heads outside the hub set: their frontier word
         fw[r] = 0u;
         if (code[r] != BFS_NO_HUB && (code[r] & BFS_HEAD_VERTEX)) fw[r] = front[(code[r] & ~BFS_HEAD_VERTEX) >> 5];
+        else if (code[r] != BFS_NO_HUB && code[r] >= BFS_HUBS) fw[r] = hub_front2[code[r] >> 5];  // an outer hub: its bit by rank
       }
 #pragma unroll
       for (int r = 0; r < BFS_BU_UNR; r++) {
@@ -683,7 +695,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
                    const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
                    const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace,
-                   int scan_unr = 1, const unsigned *__restrict__ filt = nullptr) {
+                   int scan_unr = 1, const unsigned *__restrict__ filt = nullptr, const unsigned *__restrict__ hub_front2 = nullptr) {
   static_assert(BFS_BW_GROUP * BFS_BW_STEP <= 65536u, "a list entry is (step << 11 | row in step) in 16 bits");
   __shared__ unsigned s_hf[BFS_HUBS / 32];
   __shared__ unsigned short s_list[BFS_BW_WAVES][BFS_BW_STEP];
@@ -728,6 +740,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
       for (int r = 0; r < BFS_BU_UNR; r++) {  // heads outside the hub set: their frontier word
         fw[r] = 0u;
         if (code[r] != BFS_NO_HUB && (code[r] & BFS_HEAD_VERTEX)) fw[r] = front[(code[r] & ~BFS_HEAD_VERTEX) >> 5];
+        else if (code[r] != BFS_NO_HUB && code[r] >= BFS_HUBS) fw[r] = hub_front2[code[r] >> 5];  // an outer hub: its bit by rank
       }
       wave_sync();  // every lane holds its entries: the front of the list may be overwritten
 #pragma unroll
@@ -1428,6 +1441,8 @@ struct gdn_bfs_plan {
   DevBuf<vid_t> hub_id;                // hub heads of the bottom-up step (bfs_bu_kernel): the BFS_HUBS vertices of highest
   DevBuf<unsigned long long> head;     //   out-degree, every row's out-degree | head (bfs_hub_head_kernel),
   DevBuf<unsigned> hub_front;          //   the hubs' frontier bits per level
+  DevBuf<unsigned> hub_front2;         //   the same by rank for all n_ranked hubs (outer hubs: read from L2, not LDS)
+  unsigned n_ranked = BFS_HUBS;        //   hubs named by rank in the head records
   // binned top-down levels (bfs_btd_*): nbins x BFS_BTD_SUB id lists of btd_cap_each entries, their counters, the flag
   DevBuf<vid_t> btd_buf;
   DevBuf<unsigned> btd_cur, btd_flag;
@@ -1561,7 +1576,13 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_TRY(ka.alloc((size_t)m));
       GDN_TRY(kb.alloc((size_t)m));
       GDN_TRY(hub_idx.alloc((size_t)m));
-      GDN_TRY(p.hub_id.alloc(BFS_HUBS));
+      // outer hubs where the vertex-indexed frontier bitmap is beyond an XCD's L2 (GDN_BFS_HUBS2=0: without)
+      {
+        const char *e2 = gdn_option("GDN_BFS_HUBS2");
+        p.n_ranked = (e2 ? e2[0] != '0' : (unsigned)m >= (1u << 26)) ? BFS_HUBS2 : BFS_HUBS;  // (=1 on a small graph: every head by rank)
+      }
+      GDN_TRY(p.hub_id.alloc(p.n_ranked));
+      if (p.n_ranked > BFS_HUBS) GDN_TRY(p.hub_front2.alloc(p.n_ranked / 32));
       GDN_TRY(p.head.alloc((size_t)m));
       GDN_TRY(p.hub_front.alloc(BFS_HUBS / 32 + 2));  // + the count of hubs in the frontier (64 bits)
       GDN_TRY(p.filt.alloc((size_t)1 << (BFS_FILT_LOG - 5)));
@@ -1569,10 +1590,10 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_HIP(hipGetLastError());
       const unsigned long long *sorted = nullptr;
       GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m, 32u, 64u, &sorted));
-      hipLaunchKernelGGL(bfs_hub_rank_kernel, dim3(gdn_nblocks((uint64_t)m > BFS_HUBS ? (uint64_t)m : (uint64_t)BFS_HUBS)), dim3(GDN_BLOCK), 0, 0, sorted, m, BFS_HUBS, p.hub_id.p,
+      hipLaunchKernelGGL(bfs_hub_rank_kernel, dim3(gdn_nblocks((uint64_t)m > p.n_ranked ? (uint64_t)m : (uint64_t)p.n_ranked)), dim3(GDN_BLOCK), 0, 0, sorted, m, p.n_ranked, p.hub_id.p,
                          hub_idx.p);
       hipLaunchKernelGGL(bfs_hub_head_kernel, dim3(256 * 16), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
-                         hub_idx.p, sorted, p.head.p);
+                         hub_idx.p, sorted, p.head.p, p.n_ranked);
       GDN_HIP(hipGetLastError());
       GDN_HIP(hipDeviceSynchronize());
       // how skewed the out-degrees are: the smallest degree among the hubs against the average (R-MAT-27: hundreds against 16;
@@ -1775,7 +1796,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         } else if (bottom_up) {
           if (p.head.p) {
             GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, 2 * sizeof(unsigned), 0));
-            hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(BFS_HUBS / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p);
+            hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(p.n_ranked / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p,
+                               p.hub_front2.p);
           }
           const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
           if (p.head.p && !(bfe && bfe[0] == 'w')) {
@@ -1789,12 +1811,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
             }
             hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(BFS_BW_THREADS), 0, 0, gin->rowptr, gin->colidx, m,
                                p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
-                               p.hub_front.p, hub_min, trace, bu_scan, filt);
+                               p.hub_front.p, hub_min, trace, bu_scan, filt, p.hub_front2.p);
           }
           else
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                              p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
-                             p.hub_front.p, hub_min, trace);
+                             p.hub_front.p, hub_min, trace, p.hub_front2.p);
         } else {
           hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
                              p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);

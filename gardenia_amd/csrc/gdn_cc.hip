@@ -379,6 +379,28 @@ int gdn_cc_dev(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp, gdn_st
   // share a root costs two loads).  That is a single sweep over the edges instead of Shiloach-Vishkin's ~5 (RMAT-24:
   // 21.9 ms); GDN_CC_SV=1 keeps the SV rounds (the reference's src/cc/omp_base.cc algorithm) for comparison.
   const char *sv = gdn_option("GDN_CC_SV");
+  if ((!sv || sv[0] == '0') && gin == nullptr) {
+    // GDN_CC_REVERSE=build: the reverse graph built inside the call (gdn_graph_transpose: the round-4 partition kernels) and
+    // charged to prep_ms, as the reference keeps its own graph preparation outside the Timer -- the solve then is the one
+    // WITH the reverse graph (its skip of the giant component).  Off by default: wall time (prep + solve) is lower without.
+    const char *rv = gdn_option("GDN_CC_REVERSE");
+    if (rv && rv[0] == 'b' && g->nnz > 0) {
+      HostTimer tbuild;
+      tbuild.start();
+      gdn_graph *rev = nullptr;
+      GDN_TRY(gdn_graph_transpose(g, &rev));
+      GDN_HIP(hipDeviceSynchronize());
+      const double build_ms = tbuild.stop_ms();
+      gdn_stats st;
+      memset(&st, 0, sizeof(st));
+      const int rc = cc_afforest(g, rev, d_comp, &st);
+      gdn_graph_free(rev);
+      st.prep_ms += build_ms;
+      st.reserved = 3;  // (3 = the reverse graph was built inside the call)
+      if (rc == GDN_OK && stats) *stats = st;
+      return rc;
+    }
+  }
   if (!sv || sv[0] == '0') return cc_afforest(g, gin, d_comp, stats);
   if (gin != nullptr && sv[0] != 'f') return cc_afforest(g, gin, d_comp, stats);
   const int32_t m = g->m;

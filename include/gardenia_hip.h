@@ -433,6 +433,9 @@ typedef struct gdn_sssp_plan gdn_sssp_plan;
 int gdn_sssp_plan_create(const gdn_graph *csr, const int32_t *d_weight, int32_t dense, gdn_sssp_plan **plan);
 int gdn_sssp_plan_free(gdn_sssp_plan *plan);
 int gdn_sssp_run(gdn_sssp_plan *plan, int32_t source, int32_t delta, int32_t *d_dist, gdn_stats *stats);
+/* in_csr == NULL (a directed graph, out-edges only): Afforest without the giant-component skip (one closing pass over every
+ * out-edge).  Option GDN_CC_REVERSE=build: the reverse graph is built inside the call (gdn_graph_transpose, charged to prep_ms)
+ * and the solve is the one with it (stats.reserved = 3); GDN_CC_SV=1 | fused: the reference's Shiloach-Vishkin rounds. */
 int gdn_cc_dev(const gdn_graph *csr, const gdn_graph *in_csr /*nullable*/, int32_t *d_comp,
                gdn_stats *stats);
 int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stats *stats);

@@ -63,12 +63,17 @@ def test_bfs_resident_dense_levels(orc, scale, ef, seed):
     bfs.close()
 
 
-@pytest.mark.parametrize("scale,ef,seed,hub_min", [(19, 16, 8, None), (19, 48, 9, "0"), (20, 8, 10, "100000")])
-def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed, hub_min):
+@pytest.mark.parametrize("scale,ef,seed,hub_min,outer", [(19, 16, 8, None, None), (19, 48, 9, "0", "0"), (20, 8, 10, "100000", None),
+                                                         (19, 16, 8, "0", "1"), (20, 8, 10, "100000", "1"), (22, 8, 12, None, "1")])
+def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed, hub_min, outer):
     """The bottom-up step's HEAD records (bfs_hub_head_kernel: every row's in-neighbour of highest out-degree, as a hub index
     tested against LDS bits or as a vertex id tested against the frontier bitmap, + the row's out-degree) exist from 2^24
     edges on; forced here at sizes the serial oracle walks, with the hub test always on / gated off / at its default: depths
-    and the traversed-edge count equal the oracle's from hub, leaf and late sources, and the trace shows the heads at work."""
+    and the traversed-edge count equal the oracle's from hub, leaf and late sources, and the trace shows the heads at work.
+    `outer` = GDN_BFS_HUBS2: the 2^21 highest out-degrees named by RANK and tested against the rank-indexed frontier bits
+    (default from 2^26 vertices on): below 2^21 vertices every head is a rank, at scale 22 ranks and vertex ids mix."""
+    if outer is not None:
+        monkeypatch.setenv("GDN_BFS_HUBS2", outer)
     monkeypatch.setenv("GDN_BFS_HEADS_MIN_NNZ", "1")
     monkeypatch.setenv("GDN_BFS_TRACE", "1")
     if hub_min is not None:
@@ -1363,6 +1368,26 @@ def test_cc_shiloach_vishkin_rounds_and_their_fused_kernel(orc, monkeypatch, sv)
         st = solvers.CCSolver(solvers.Graph(csr=g), comp)
         assert np.array_equal(comp, want)
         assert st["iterations"] >= 2 and st["reserved"] == (2 if sv == "fused" else 0)
+
+
+def test_cc_out_edges_only_with_the_reverse_graph_built_in_the_call(orc, monkeypatch):
+    """GDN_CC_REVERSE=build: a directed graph handed over without its reverse gets the transpose built inside gdn_cc_dev
+    (charged to prep_ms) and the solve WITH it; same minimum-id labels as the default, stats.reserved = 3."""
+    rng = np.random.default_rng(95)
+    graphs = [graphio.rmat_graph(16, 16, seed=96), graphio.build_csr(5000, rng.integers(0, 5000, 3000), rng.integers(0, 5000, 3000)),
+              graphio.build_csr(40, np.zeros(0, np.int64), np.zeros(0, np.int64))]
+    for g in graphs:
+        want, _ = orc.cc_sv(graphio.symmetrize(g))
+        plain = np.arange(g.m, dtype=np.int32)
+        st0 = solvers.CCSolver(solvers.Graph(csr=g), plain)
+        monkeypatch.setenv("GDN_CC_REVERSE", "build")
+        comp = np.arange(g.m, dtype=np.int32)
+        st = solvers.CCSolver(solvers.Graph(csr=g), comp)
+        monkeypatch.delenv("GDN_CC_REVERSE")
+        assert np.array_equal(comp, want) and np.array_equal(plain, want)
+        assert st0["reserved"] == 0 and st["reserved"] == (3 if g.nnz else 0)
+        if g.nnz:
+            assert st["prep_ms"] > 0
 
 
 def test_cc_many_small_components(orc):

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of BFS knobs on ONE resident plan (R-MAT scale S): per knob set the three bench sources, best of 3 untraced runs + one
-traced run (GDN_BFS_TRACE), depths compared with the first set's.  usage: bfs_ab.py <scale> "K1=V1,K2=V2" "K1=V3" ...  ("" = defaults)"""
+"""A/B of BFS knobs on ONE resident graph (R-MAT scale S; the plan is rebuilt under every knob set, so plan-build knobs such as
+GDN_BFS_HUBS2 count too): per knob set the three bench sources, best of 3 untraced runs + one traced run (GDN_BFS_TRACE),
+depths compared with the first set's.  usage: bfs_ab.py <scale> "K1=V1,K2=V2" "K1=V3" ...  ("" = defaults)"""
 import ctypes as C
 import os
 import sys
@@ -26,13 +27,13 @@ _cabi.check(L.gdn_dev_download(hdeg.ctypes.data_as(C.c_void_p), deg, 4 * (1 << 1
 sources = np.nonzero(hdeg > 0)[0][:3].tolist()
 dist = C.c_void_p()
 _cabi.check(L.gdn_dev_alloc(4 * m, C.byref(dist)))
-plan = C.c_void_p()
-_cabi.check(L.gdn_bfs_plan_create(go, gi, 1, C.byref(plan)))
 ref = {}
 for spec in sets:
     env = dict(kv.split("=") for kv in spec.split(",") if kv)
     for k, v in env.items():
         _cabi.check(L.gdn_option_set(k.encode(), v.encode()))
+    plan = C.c_void_p()
+    _cabi.check(L.gdn_bfs_plan_create(go, gi, 1, C.byref(plan)))
     line = []
     for s in sources:
         best = None
@@ -51,5 +52,6 @@ for spec in sets:
         ref.setdefault(s, crc)
         line.append("%d: %.3f ms%s" % (s, best, "" if crc == ref[s] else " DEPTHS DIFFER"))
     print("%-50s %s" % ("[" + spec + "]", "   ".join(line)), flush=True)
+    L.gdn_bfs_plan_free(plan)
     for k in env:
         _cabi.check(L.gdn_option_set(k.encode(), None))
