@@ -123,6 +123,11 @@ def main():
                          "out-edges (compact = auto)")
     ap.add_argument("--ranges", choices=["balanced", "equal"], default="balanced",
                     help="N > 1: vertex ranges of about nnz/N edges each (SURVEY 8e) or of equal vertex counts")
+    ap.add_argument("--gen", choices=["auto", "whole", "range"], default="auto",
+                    help="N > 1: every rank builds the whole graph and cuts its shard out (whole), or generates only the in-edges "
+                         "of its own destination range and the ranks all-reduce the degree vectors (range: gdn_rmat_build_range + "
+                         "gdn_pr_squish_range; no rank holds the whole graph; ranges of equal vertex counts of the permuted ids). "
+                         "auto = range for N > 1 on the blocked layout with the live-vertex relabelling, else whole")
     ap.add_argument("--no-squish", action="store_true",
                     help="keep the vertices without any edge in the per-iteration state (the caller's vertex space)")
     ap.add_argument("--no-bfs", action="store_true")
@@ -186,17 +191,47 @@ def main():
 
     # ---- synthetic input: R-MAT(scale, edge_factor), cleaned like the reference loader
     t0 = time.time()
-    g_out, g_in = C.c_void_p(), C.c_void_p()
-    _cabi.check(L.gdn_rmat_build(args.scale, args.edge_factor, graphio.K_RAND_SEED, 1, C.byref(g_out), C.byref(g_in)))
-    m, nnz = C.c_int32(), C.c_uint64()
-    _cabi.check(L.gdn_graph_info(g_in, C.byref(m), C.byref(nnz), None, None))
-    m, nnz = m.value, nnz.value
-    out_degree = torch.empty(m, dtype=torch.int32, device=device)
-    _cabi.check(L.gdn_graph_degrees_dev(g_out, C.c_void_p(out_degree.data_ptr()), None))
+    if args.no_squish:
+        os.environ["GDN_PR_SQUISH"] = "0"
+    squish_first = multi and args.layout != "csr" and os.environ.get("GDN_PR_SQUISH", "1") != "0"
+    gen_range = squish_first and (args.gen == "range" or (args.gen == "auto" and world > 1))
+    if args.gen == "range" and not gen_range:
+        raise SystemExit("bench.py: --gen range needs N > 1 (or --force-dist), the blocked layout and the live-vertex relabelling")
+    g_out = g_in = range_rows = None
+    if gen_range:
+        # every rank: the in-edges of ITS destination range only (all edge indices generated, the range's keys kept), its part of
+        # the out-degree count; the two degree vectors are completed by all-reduces -- no rank holds the whole graph
+        m = 1 << args.scale
+        if world > m:
+            raise SystemExit(f"bench.py: {world} ranks for {m} vertices -- every rank needs a row")
+        raw_bounds = [r * m // world for r in range(world + 1)]
+        v_lo, v_hi = raw_bounds[rank], raw_bounds[rank + 1]
+        out_degree = torch.zeros(m, dtype=torch.int32, device=device)
+        in_degree = torch.zeros(m, dtype=torch.int32, device=device)
+        range_rows = C.c_void_p()
+        _cabi.check(L.gdn_rmat_build_range(args.scale, args.edge_factor << args.scale, 0.57, 0.19, 0.19, graphio.K_RAND_SEED, 1,
+                                           v_lo, v_hi, C.byref(range_rows), C.c_void_p(out_degree.data_ptr())))
+        _cabi.check(L.gdn_graph_degrees_dev(range_rows, C.c_void_p(in_degree[v_lo:v_hi].data_ptr()), None))
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.all_reduce(out_degree)
+            dist.all_reduce(in_degree)
+        nnz = int(in_degree.sum(dtype=torch.int64).item())
+        if args.no_bfs is False or args.no_cpu is False or args.no_extras is False:
+            args.no_bfs = args.no_cpu = args.no_extras = True  # (blocks of the N = 1 line: they need the whole graph)
+    else:
+        g_out, g_in = C.c_void_p(), C.c_void_p()
+        _cabi.check(L.gdn_rmat_build(args.scale, args.edge_factor, graphio.K_RAND_SEED, 1, C.byref(g_out), C.byref(g_in)))
+        m, nnz = C.c_int32(), C.c_uint64()
+        _cabi.check(L.gdn_graph_info(g_in, C.byref(m), C.byref(nnz), None, None))
+        m, nnz = m.value, nnz.value
+        out_degree = torch.empty(m, dtype=torch.int32, device=device)
+        _cabi.check(L.gdn_graph_degrees_dev(g_out, C.c_void_p(out_degree.data_ptr()), None))
     torch.cuda.synchronize()
     t_build = time.time() - t0
     if rank == 0:
-        log(f"[bench] RMAT-{args.scale} x{args.edge_factor}: |V| {m} |E| {nnz} built on device in {t_build:.1f} s")
+        log(f"[bench] RMAT-{args.scale} x{args.edge_factor}: |V| {m} |E| {nnz} built on device in {t_build:.1f} s"
+            + (" (per rank: the in-edges of its own destination range)" if gen_range else ""))
     if world > m:
         raise SystemExit(f"bench.py: {world} ranks for {m} vertices -- every rank needs a row")  # every rank exits alike
 
@@ -205,12 +240,20 @@ def main():
     # that space -- of about nnz/N edges each -- and moved into the padded vertex space (gdn_graph_slice_padded) in which
     # every rank's slice of the contrib vector is an equal all-gather slot; N = 1: the plan squishes internally
     # (GDN_LAYOUT_PB_SQUISHED)
-    if args.no_squish:
-        os.environ["GDN_PR_SQUISH"] = "0"
-    squish_first = multi and args.layout != "csr" and os.environ.get("GDN_PR_SQUISH", "1") != "0"
     m_part, g_part, deg_part, sq = m, g_in, out_degree, None
     dead_diff = 0.0
-    if squish_first:
+    if gen_range:
+        rb, sb = (C.c_int32 * (world + 1))(*raw_bounds), (C.c_int32 * (world + 1))()
+        _cabi.check(L.gdn_pr_squish_range(range_rows, v_lo, C.c_void_p(in_degree.data_ptr()), C.c_void_p(out_degree.data_ptr()), m,
+                                          world + 1, rb, sb))
+        bl = list(sb)
+        m_part = bl[world]
+        live = (in_degree[v_lo:v_hi] > 0) | (out_degree[v_lo:v_hi] > 0)
+        deg_local = out_degree[v_lo:v_hi][live].contiguous()
+        del in_degree, live
+        base, start = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(m)), np.float32(1.0) / np.float32(m)
+        dead_diff = float(m - m_part) * float(abs(np.float32(base - start)))
+    elif squish_first:
         sq = C.c_void_p()
         _cabi.check(L.gdn_pr_squish_create(g_in, C.c_void_p(out_degree.data_ptr()), C.byref(sq)))
         ms_, gp = C.c_int32(0), C.c_void_p()
@@ -223,7 +266,13 @@ def main():
         base, start = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(m)), np.float32(1.0) / np.float32(m)
         dead_diff = float(m - m_part) * float(abs(np.float32(base - start)))
     part_nnz = None
-    if multi:
+    if gen_range:
+        chunk = padded_chunk(bl)
+        _cabi.check(L.gdn_graph_pad_columns(range_rows, world, sb, chunk))
+        shard = range_rows
+        b_lo, b_hi = bl[rank], bl[rank + 1]
+        m_space, lo, hi = chunk * world, rank * chunk, rank * chunk + (b_hi - b_lo)
+    elif multi:
         bounds = (C.c_int32 * (world + 1))()
         if args.ranges == "balanced":
             _cabi.check(L.gdn_graph_balanced_ranges(g_part, world, bounds))
@@ -355,9 +404,11 @@ def main():
                                "A=.57 B=.19 C=.19, seed 27491095, self loops+duplicates dropped)"
                                % (args.scale, args.edge_factor),
                    "vertices": m, "edges": nnz, "layout": layout_name, "plan_build_s": t_plan,
-                   "partition": "vertex-range x%d (%s ranges; edges per rank %s), RCCL all-gather of contrib (%s exchange, "
+                   "partition": "vertex-range x%d (%s; edges per rank %s), RCCL all-gather of contrib (%s exchange, "
                                 "%.0f MB received per rank and iteration) pipelined in %d row-range parts behind the pull "
-                                "kernels" % (world, args.ranges, part_nnz, pr.exchange, pr.exchanged_bytes() / 1e6, pr.parts)
+                                "kernels" % (world, "equal ranges of the permuted ids (every rank generated its own destination range, "
+                                             "the degree vectors were all-reduced)" if gen_range else args.ranges + " ranges", part_nnz,
+                                             pr.exchange, pr.exchanged_bytes() / 1e6, pr.parts)
                    if multi else "single GPU"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

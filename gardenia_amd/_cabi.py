@@ -66,6 +66,7 @@ PROTOTYPES = {
     "gdn_graph_validate": (C.c_int, [_vp, _i32]),
     "gdn_graph_balanced_ranges": (C.c_int, [_vp, _i32, _vp]),
     "gdn_graph_slice_padded": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _pp]),
+    "gdn_graph_pad_columns": (C.c_int, [_vp, _i32, _vp, _i32]),
     "gdn_spmv": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _vp, _vp, _st]),
     "gdn_sssp": (C.c_int, [_i32, _u64, _vp, _vp, _vp, _i32, _i32, _vp, _st]),
     "gdn_tc": (C.c_int, [_i32, _u64, _vp, _vp, _i32, C.POINTER(_u64), _st]),
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "gdn_graph_download": (C.c_int, [_vp, _vp, _vp]),
     "gdn_rmat_build": (C.c_int, [_i32, _i32, _u64, _i32, _pp, _pp]),
     "gdn_rmat_build_ex": (C.c_int, [_i32, _u64, C.c_double, C.c_double, C.c_double, _u64, _i32, _pp, _pp]),
+    "gdn_rmat_build_range": (C.c_int, [_i32, _u64, C.c_double, C.c_double, C.c_double, _u64, _i32, _i32, _i32, _pp, _vp]),
     "gdn_pr_plan_create": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _pp]),
     "gdn_pr_plan_layout": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32)]),
     "gdn_pr_plan_hubs": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_u64)]),
@@ -110,6 +112,7 @@ PROTOTYPES = {
     "gdn_pr_squish_export_dev": (C.c_int, [_vp, _vp, _vp, C.c_float, _vp]),
     "gdn_pr_squish_free": (C.c_int, [_vp]),
     "gdn_pr_squish_degrees_dev": (C.c_int, [_vp, _vp, _vp]),
+    "gdn_pr_squish_range": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "gdn_pr_plan_set_base": (C.c_int, [_vp, _i32]),
     "gdn_pr_plan_check": (C.c_int, [_vp]),
     "gdn_pr_plan_free": (C.c_int, [_vp]),

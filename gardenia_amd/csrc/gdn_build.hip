@@ -47,6 +47,37 @@ __device__ __forceinline__ unsigned long long rmat_permute(unsigned long long x,
   return x;
 }
 
+// edge number e of the stream: scale levels of the quadrant choice, 32 random bits each (two levels per 64-bit mix)
+__device__ __forceinline__ void rmat_edge(int scale, unsigned long long e, unsigned long long seed, int permute, unsigned t_a,
+                                          unsigned t_ab, unsigned t_abc, unsigned long long &src, unsigned long long &dst) {
+  const unsigned long long base = seed + e * 0x9E3779B97F4A7C15ull;
+  unsigned long long h = 0;
+  src = 0;
+  dst = 0;
+  for (int l = 0; l < scale; l++) {
+    unsigned r;
+    if ((l & 1) == 0) {
+      h = rmat_mix64(base + (unsigned long long)(l >> 1) * 0xBF58476D1CE4E5B9ull);
+      r = (unsigned)(h & 0xFFFFFFFFull);
+    } else {
+      r = (unsigned)(h >> 32);
+    }
+    src <<= 1;
+    dst <<= 1;
+    if (r >= t_abc) {
+      src |= 1ull;
+      dst |= 1ull;
+    } else if (r >= t_ab) {
+      src |= 1ull;
+    } else if (r >= t_a) {
+      dst |= 1ull;
+    }
+  }
+  if (permute) {
+    src = rmat_permute(src, scale, seed);
+    dst = rmat_permute(dst, scale, seed);
+  }
+}
 // key = (row << 32) | col ; by_dst: row = dst (in-CSR) else row = src (out-CSR)
 __global__ void __launch_bounds__(GDN_BLOCK)
 rmat_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, int permute, int by_dst,
@@ -55,33 +86,51 @@ rmat_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, 
   unsigned long long e = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
   for (; e < nedges; e += stride) {
-    const unsigned long long base = seed + e * 0x9E3779B97F4A7C15ull;
-    unsigned long long src = 0, dst = 0, h = 0;
-    for (int l = 0; l < scale; l++) {
-      unsigned r;
-      if ((l & 1) == 0) {
-        h = rmat_mix64(base + (unsigned long long)(l >> 1) * 0xBF58476D1CE4E5B9ull);
-        r = (unsigned)(h & 0xFFFFFFFFull);
-      } else {
-        r = (unsigned)(h >> 32);
-      }
-      src <<= 1;
-      dst <<= 1;
-      if (r >= t_abc) {
-        src |= 1ull;
-        dst |= 1ull;
-      } else if (r >= t_ab) {
-        src |= 1ull;
-      } else if (r >= t_a) {
-        dst |= 1ull;
-      }
-    }
-    if (permute) {
-      src = rmat_permute(src, scale, seed);
-      dst = rmat_permute(dst, scale, seed);
-    }
+    unsigned long long src, dst;
+    rmat_edge(scale, e, seed, permute, t_a, t_ab, t_abc, src, dst);
     keys[e] = by_dst ? ((dst << 32) | src) : ((src << 32) | dst);
   }
+}
+// gdn_rmat_build_range: the WHOLE stream is generated, only the in-CSR keys (dst << 32 | src) of the destinations [v_lo, v_hi) are
+// kept -- appended in any order (one reservation per wave; the sort that follows orders them), self loops left out.  keys ==
+// nullptr: count only (the first pass sizes the buffer of the second).
+__global__ void __launch_bounds__(GDN_BLOCK)
+rmat_range_keys_kernel(int scale, unsigned long long nedges, unsigned long long seed, int permute, unsigned t_a, unsigned t_ab,
+                       unsigned t_abc, unsigned v_lo, unsigned v_hi, unsigned long long *__restrict__ keys,
+                       unsigned long long *__restrict__ counter, unsigned long long capacity) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  const unsigned long long rounds = (nedges + stride - 1) / stride;  // (whole waves stay together for the ballots)
+  unsigned long long e = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  unsigned long long mine = 0;
+  for (unsigned long long it = 0; it < rounds; it++, e += stride) {
+    unsigned long long src = 0, dst = 0;
+    bool keep = false;
+    if (e < nedges) {
+      rmat_edge(scale, e, seed, permute, t_a, t_ab, t_abc, src, dst);
+      keep = dst >= v_lo && dst < v_hi && src != dst;
+    }
+    if (keys == nullptr) {
+      mine += keep ? 1ull : 0ull;
+      continue;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (mask == 0ull) continue;
+    unsigned long long at = 0;
+    if (gdn_lane() == (unsigned)(__ffsll((long long)mask) - 1)) at = atomicAdd(counter, (unsigned long long)__popcll(mask));
+    at = __shfl(at, __ffsll((long long)mask) - 1, 64) + (unsigned long long)__popcll(mask & gdn_lanemask_lt());
+    if (keep && at < capacity) keys[at] = (dst << 32) | src;
+  }
+  if (keys == nullptr) {
+    mine = gdn_wave_sum(mine);
+    if (gdn_lane() == 0 && mine) atomicAdd(counter, mine);
+  }
+}
+// out-degree contributions of a set of (unique) in-edges: deg[src] += 1
+__global__ void __launch_bounds__(GDN_BLOCK)
+out_degree_add_kernel(const vid_t *__restrict__ colidx, unsigned long long nnz, int32_t *__restrict__ deg) {
+  unsigned long long k = (unsigned long long)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  const unsigned long long stride = (unsigned long long)gridDim.x * GDN_BLOCK;
+  for (; k < nnz; k += stride) atomicAdd(&deg[colidx[k]], 1);
 }
 
 // ---- gdn_rmat_build_ex, GDN_RMAT_COMPACT: the ids that occur in no edge (self loops do not count) are dropped and the
@@ -1666,6 +1715,55 @@ int gdn_rmat_build_ex(int32_t scale, uint64_t n_edges, double a, double b, doubl
       return rc;
     }
   }
+  return GDN_OK;
+}
+
+int gdn_rmat_build_range(int32_t scale, uint64_t n_edges, double a, double b, double c, uint64_t seed, int32_t flags, int32_t v_lo,
+                         int32_t v_hi, gdn_graph **in_rows, int32_t *d_out_degree_partial) {
+  GDN_REQUIRE(scale >= 1 && scale <= 30, "scale must be in [1,30]");
+  GDN_REQUIRE(a > 0.0 && b >= 0.0 && c >= 0.0 && a + b + c <= 1.0, "quadrant probabilities");
+  GDN_REQUIRE((flags & ~GDN_RMAT_PERMUTE) == 0, "gdn_rmat_build_range: GDN_RMAT_PERMUTE is the only flag (compaction needs every range)");
+  const int32_t m = (int32_t)(1u << scale);
+  GDN_REQUIRE(in_rows != nullptr && v_lo >= 0 && v_lo < v_hi && v_hi <= m, "in_rows / 0 <= v_lo < v_hi <= 2^scale");
+  GDN_TRY(gdn_require_device());
+  *in_rows = nullptr;
+  auto thr = [](double p) { return p >= 1.0 ? 0xFFFFFFFFu : (unsigned)(p * 4294967296.0); };
+  const unsigned t_a = thr(a), t_ab = thr(a + b), t_abc = thr(a + b + c);
+  const unsigned long long n = n_edges;
+  unsigned nb = (unsigned)((n + GDN_BLOCK - 1) / GDN_BLOCK > 65536ull ? 65536ull : (n + GDN_BLOCK - 1) / GDN_BLOCK);
+  if (nb == 0) nb = 1;
+  DevBuf<unsigned long long> counter;
+  GDN_TRY(counter.alloc_scratch(1));
+  // pass 1: how many keys the range keeps; pass 2: the keys
+  unsigned long long kept = 0;
+  GDN_HIP(hipMemsetAsync(counter.p, 0, 8, 0));
+  hipLaunchKernelGGL(rmat_range_keys_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, (int)scale, n, (unsigned long long)seed,
+                     (int)((flags & GDN_RMAT_PERMUTE) != 0), t_a, t_ab, t_abc, (unsigned)v_lo, (unsigned)v_hi,
+                     (unsigned long long *)nullptr, counter.p, 0ull);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipMemcpy(&kept, counter.p, 8, hipMemcpyDeviceToHost));
+  DevBuf<unsigned long long> ka, kb;
+  GDN_TRY(ka.alloc_scratch(kept ? kept : 1));
+  GDN_TRY(kb.alloc_scratch(kept ? kept : 1));
+  GDN_HIP(hipMemsetAsync(counter.p, 0, 8, 0));
+  hipLaunchKernelGGL(rmat_range_keys_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, (int)scale, n, (unsigned long long)seed,
+                     (int)((flags & GDN_RMAT_PERMUTE) != 0), t_a, t_ab, t_abc, (unsigned)v_lo, (unsigned)v_hi, ka.p, counter.p, kept);
+  GDN_HIP(hipGetLastError());
+  // rows keep their global ids through the sort (a key whose row equals its column is a self loop there), the range is cut
+  // out of the offsets afterwards: 8 (m + 1) bytes of offsets beside the range's own edges
+  gdn_graph *whole = nullptr;
+  GDN_TRY(csr_from_keys(ka, kb, kept, m, scale, &whole));
+  gdn_graph *rows = nullptr;
+  const int rc = gdn_graph_slice_rows(whole, v_lo, v_hi, &rows);
+  gdn_graph_free(whole);
+  GDN_TRY(rc);
+  if (d_out_degree_partial && rows->nnz) {
+    hipLaunchKernelGGL(out_degree_add_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, rows->colidx, (unsigned long long)rows->nnz,
+                       d_out_degree_partial);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipDeviceSynchronize());
+  }
+  *in_rows = rows;
   return GDN_OK;
 }
 

@@ -780,6 +780,15 @@ int gdn_graph_slice_padded(const gdn_graph *g, int32_t world, const int32_t *bou
   return GDN_OK;
 }
 
+int gdn_graph_pad_columns(gdn_graph *shard, int32_t world, const int32_t *bounds, int32_t chunk) {
+  GDN_REQUIRE(shard != nullptr && bounds != nullptr, "shard / bounds");
+  GDN_REQUIRE(world >= 1 && world <= GDN_BLOCK, "world");
+  for (int32_t r = 0; r < world; r++)
+    GDN_REQUIRE(bounds[r] < bounds[r + 1] && bounds[r + 1] - bounds[r] <= chunk, "every range non-empty and at most chunk rows");
+  GDN_REQUIRE(bounds[0] == 0 && (int64_t)chunk * world <= 2147483647ll, "bounds start at 0; chunk * world must fit a vertex id");
+  return gdn_graph_pad_cols(shard, world, bounds, chunk);
+}
+
 int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx) {
   GDN_REQUIRE(g != nullptr, "graph");
   if (rowptr) GDN_HIP(hipMemcpy(rowptr, g->rowptr, ((size_t)g->m + 1) * sizeof(eoff_t), hipMemcpyDeviceToHost));

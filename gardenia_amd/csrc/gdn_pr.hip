@@ -344,6 +344,21 @@ pr_squish_cols_kernel(const vid_t *__restrict__ colidx, const eoff_t *__restrict
   for (; e < nnz; e += stride) out[e] = (vid_t)cmap[colidx[e]];
 }
 
+// gdn_pr_squish_range: liveness from the two degree vectors (no whole in-CSR at hand) ...
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_live_flags_deg_kernel(const int32_t *__restrict__ in_deg, const int32_t *__restrict__ out_deg, int32_t m, uint32_t *__restrict__ flag) {
+  const size_t v = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v < (size_t)m) flag[v] = (in_deg[v] > 0 || out_deg[v] > 0) ? 1u : 0u;
+}
+// ... and the offsets of the live rows of [v_lo, v_hi): a dead row has no in-edge, so the live rows' offsets are the old ones
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_squish_range_rows_kernel(const uint32_t *__restrict__ flag, const eoff_t *__restrict__ cmap, const eoff_t *__restrict__ rowptr,
+                            int32_t v_lo, int32_t n_rows, eoff_t *__restrict__ rowptr_c) {
+  const size_t i = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < (size_t)n_rows && flag[(size_t)v_lo + i]) rowptr_c[cmap[(size_t)v_lo + i] - cmap[v_lo]] = rowptr[i];
+  if (i == (size_t)n_rows) rowptr_c[cmap[(size_t)v_lo + i] - cmap[v_lo]] = rowptr[i];
+}
+
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_gather_state_kernel(const float *__restrict__ src, const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ dst) {
   const size_t k = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
@@ -1164,6 +1179,47 @@ int gdn_pr_squish_create(const gdn_graph *in_csr, const int32_t *d_out_degree, g
   q->graph.colidx = q->colidx.p;
   q->graph.owned = false;
   *out = q;
+  return GDN_OK;
+}
+
+int gdn_pr_squish_range(gdn_graph *rows, int32_t v_lo, const int32_t *d_in_degree, const int32_t *d_out_degree, int32_t m,
+                        int32_t n_bounds, const int32_t *raw_bounds, int32_t *state_bounds) {
+  GDN_REQUIRE(rows && d_in_degree && d_out_degree && m > 0, "null argument");
+  GDN_REQUIRE(rows->owned && v_lo >= 0 && (int64_t)v_lo + rows->m <= (int64_t)m, "an owned graph of the rows [v_lo, v_lo + rows) of m");
+  GDN_REQUIRE(n_bounds == 0 || (raw_bounds && state_bounds), "bounds");
+  DevBuf<uint32_t> flag;
+  DevBuf<eoff_t> cmap;
+  GDN_TRY(flag.alloc((size_t)m));
+  GDN_TRY(cmap.alloc((size_t)m + 1));
+  hipLaunchKernelGGL(pr_live_flags_deg_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, d_in_degree, d_out_degree, m, flag.p);
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(flag.p, cmap.p, (size_t)m, 0));
+  for (int32_t r = 0; r < n_bounds; r++) {
+    GDN_REQUIRE(raw_bounds[r] >= 0 && raw_bounds[r] <= m, "a bound outside [0, m]");
+    eoff_t v = 0;
+    GDN_HIP(hipMemcpy(&v, cmap.p + raw_bounds[r], sizeof(eoff_t), hipMemcpyDeviceToHost));
+    state_bounds[r] = (int32_t)v;
+  }
+  eoff_t c_lo = 0, c_hi = 0;
+  GDN_HIP(hipMemcpy(&c_lo, cmap.p + v_lo, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&c_hi, cmap.p + v_lo + rows->m, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  const int32_t n_live = (int32_t)(c_hi - c_lo);
+  eoff_t *rowptr_c = nullptr;
+  if (gdn_plain_malloc((void **)&rowptr_c, ((size_t)n_live + 1) * sizeof(eoff_t)) != hipSuccess) {
+    gdn_set_error("gdn_pr_squish_range: out of device memory");
+    return GDN_ERR_OOM;
+  }
+  hipLaunchKernelGGL(pr_squish_range_rows_kernel, dim3(gdn_nblocks((uint64_t)rows->m + 1)), dim3(GDN_BLOCK), 0, 0, flag.p, cmap.p,
+                     rows->rowptr, v_lo, rows->m, rowptr_c);
+  if (rows->nnz)  // (element-wise: in place)
+    hipLaunchKernelGGL(pr_squish_cols_kernel, dim3(65536), dim3(GDN_BLOCK), 0, 0, rows->colidx, cmap.p, rows->nnz, rows->colidx);
+  if (hipDeviceSynchronize() != hipSuccess) {
+    gdn_set_error("gdn_pr_squish_range: kernels failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)gdn_plain_free(rowptr_c);
+    return GDN_ERR_HIP;
+  }
+  (void)gdn_plain_free(rows->rowptr);
+  rows->rowptr = rowptr_c;
+  rows->m = n_live;
   return GDN_OK;
 }
 

@@ -227,6 +227,9 @@ int gdn_graph_balanced_ranges(const gdn_graph *g, int32_t world, int32_t *bounds
  * replicated per-vertex vector then starts at a multiple of chunk: equal all-gather slots for unequal ranges. */
 int gdn_graph_slice_padded(const gdn_graph *g, int32_t world, const int32_t *bounds, int32_t chunk, int32_t rank,
                            gdn_graph **out);
+/* The second half of gdn_graph_slice_padded on a shard that was never part of a whole graph (gdn_rmat_build_range +
+ * gdn_pr_squish_range): its column ids, in the vertex space `bounds` cuts, moved into the padded space -- in place. */
+int gdn_graph_pad_columns(gdn_graph *shard, int32_t world, const int32_t *bounds, int32_t chunk);
 /* Device ingest: edge list (host arrays, 0-based ids) -> resident CSR with the clean-up of the reference
  * loader (include/csr_graph.h:108 self loops dropped, :127 rows sorted ascending, :132-143 duplicates
  * dropped; symmetrize != 0 also inserts every reverse edge, :112-115).  One radix sort on the device
@@ -242,6 +245,16 @@ int gdn_graph_download(const gdn_graph *g, uint64_t *rowptr, int32_t *colidx);
  * Either output may be NULL. */
 int gdn_rmat_build(int32_t scale, int32_t edge_factor, uint64_t seed, int32_t permute,
                    gdn_graph **out_csr, gdn_graph **in_csr);
+/* ONE vertex range of gdn_rmat_build_ex's graph, for a rank of a sharded run that must not hold the whole graph (17 GB of keys
+ * at scale 27, 137 GB at scale 30): the in-CSR rows [v_lo, v_hi) -- row i = vertex v_lo + i, column ids global -- of exactly
+ * the graph gdn_rmat_build_ex(scale, n_edges, a, b, c, seed, flags) builds.  Every edge of the stream is generated (twice: a
+ * counting pass sizes the key buffer), only the keys whose destination lies in the range are kept, sorted and cleaned of
+ * duplicates as there: memory = the range's own edges + 8 (2^scale + 1) bytes of offsets.  d_out_degree_partial (nullable;
+ * int32[2^scale], zeroed by the caller) += 1 per kept edge at its source: summed over the ranges of a partition -- one
+ * all-reduce across the ranks -- it is the graph's out-degree vector (the DISTRIBUTED degree count).  flags: GDN_RMAT_PERMUTE
+ * only (compaction is a property of the whole graph: gdn_pr_squish_range below does it for the ranks together). */
+int gdn_rmat_build_range(int32_t scale, uint64_t n_edges, double a, double b, double c, uint64_t seed, int32_t flags,
+                         int32_t v_lo, int32_t v_hi, gdn_graph **in_rows, int32_t *d_out_degree_partial);
 /* The same generator with its knobs open: n_edges draws (not a multiple of 2^scale necessarily), quadrant probabilities
  * a / b / c (d = 1 - a - b - c; include/generator.h:88-90 fixes .57 / .19 / .19), flags GDN_RMAT_PERMUTE (ids shuffled,
  * generator.h:52-62) and GDN_RMAT_COMPACT: the ids that occur in no edge are dropped and the others renumbered in ascending
@@ -315,6 +328,13 @@ int gdn_pr_export_dev(gdn_pr_plan *plan, const float *d_state, float *d_scores, 
  * gdn_graph_slice_rows, build ordinary plans on the shards (d_degrees: out-degrees in state order) and tell them the
  * original vertex count with gdn_pr_plan_set_base (base score (1 - d) / m).  import: caller's m-entry scores -> state;
  * dead_diff (nullable, makes the call blocking) = L1 change of the vertices outside the state in the first iteration. */
+/* gdn_pr_squish_range: the same relabelling for a graph held as vertex ranges (gdn_rmat_build_range).  d_in_degree /
+ * d_out_degree: the WHOLE graph's degree vectors (int32[m], all-reduced by the caller); `rows` = the in-CSR rows
+ * [v_lo, v_lo + rows) with global column ids, relabelled IN PLACE: its rows become the live vertices of the range (a vertex
+ * is live when it has an edge in either direction), its column ids state ids (position among the live vertices, ascending).
+ * state_bounds[i] = live vertices below raw_bounds[i], i < n_bounds (raw range cuts -> state range cuts). */
+int gdn_pr_squish_range(gdn_graph *rows, int32_t v_lo, const int32_t *d_in_degree, const int32_t *d_out_degree, int32_t m,
+                        int32_t n_bounds, const int32_t *raw_bounds, int32_t *state_bounds);
 typedef struct gdn_pr_squish gdn_pr_squish;
 int gdn_pr_squish_create(const gdn_graph *in_csr, const int32_t *d_out_degree, gdn_pr_squish **sq);
 int gdn_pr_squish_info(const gdn_pr_squish *sq, int32_t *m_orig, int32_t *m_state, const gdn_graph **graph,

@@ -33,12 +33,14 @@ def _bench(extra, launcher=None):
 def test_bench_two_ranks_on_one_device_match_single():
     single = _bench([])
     res = {}
-    for ex, extra in (("dense", []), ("compact", []), ("compact", ["--no-squish"]), ("dense", ["--no-squish"])):
+    # (default for N > 1: every rank generates its own destination range, --gen range; --gen whole: the shard cut out of the whole graph)
+    for ex, extra in (("dense", []), ("compact", []), ("compact", ["--no-squish"]), ("dense", ["--no-squish"]), ("dense", ["--gen", "whole"])):
         launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", str(_free_port())]
         r = res[ex + " ".join(extra)] = _bench(["--gpus", "2", "--share-device", "--exchange", ex] + extra, launcher)
         assert r["n_gpus"] == 2 and ex + " exchange" in r["config"]["partition"]
-        assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == (not extra)
+        assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == ("--no-squish" not in extra)
+        assert ("every rank generated its own destination range" in r["config"]["partition"]) == (not extra)
         assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     assert "roofline" in single and single["roofline"]["frac"] > 0
     assert single["step_ms"]["n"] >= 10 and single["step_ms"]["min"] <= single["step_ms"]["median"]
@@ -53,7 +55,7 @@ def test_bench_starts_its_own_ranks_without_a_launcher():
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env_clean)
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert r["n_gpus"] == 2 and "vertex-range x2 (balanced ranges" in r["config"]["partition"]
+    assert r["n_gpus"] == 2 and "vertex-range x2 (equal ranges of the permuted ids" in r["config"]["partition"]
     single = _bench([])
     assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     # a failing child makes the parent fail too (exit code passed through)
@@ -67,13 +69,17 @@ def test_bench_equal_ranges_and_rccl_backend_with_one_rank():
     single = _bench([])
     launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                 "--master-port", str(_free_port())]
-    r = _bench(["--gpus", "2", "--share-device", "--ranges", "equal"], launcher)
-    assert "equal ranges" in r["config"]["partition"]
+    r = _bench(["--gpus", "2", "--share-device", "--ranges", "equal", "--gen", "whole"], launcher)
+    assert "(equal ranges;" in r["config"]["partition"]
     assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     for ex in ("dense", "compact"):
         f = _bench(["--force-dist", "--exchange", ex])
         assert f["n_gpus"] == 1 and "RCCL all-gather" in f["config"]["partition"] and ex + " exchange" in f["config"]["partition"]
         assert abs(f["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+    # the per-rank generation through the RCCL backend with this box's one rank
+    f = _bench(["--force-dist", "--gen", "range"])
+    assert f["n_gpus"] == 1 and "every rank generated its own destination range" in f["config"]["partition"]
+    assert abs(f["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
 
 
 def test_bench_line_carries_bfs_spmv_tc_blocks():
@@ -129,12 +135,18 @@ def test_bench_eight_ranks_on_one_device_match_single():
 
     single = run([])
     launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                "--master-port", str(_free_port())]
-    r = run(["--gpus", "8", "--share-device"], launcher)
-    assert r["n_gpus"] == 8 and "vertex-range x8 (balanced ranges" in r["config"]["partition"]
-    assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
-    part = r["config"]["partition"]
-    edges = [int(x) for x in part[part.index("[") + 1:part.index("]")].split(",")]
-    assert len(edges) == 8 and sum(edges) == single["config"]["edges"]
-    assert max(edges) <= 1.02 * (sum(edges) / 8) + 70_000  # nnz-balanced: a rank is at most one hub row over its share
-    assert r["scaling"] == "strong" and r["value"] > 0
+                "--master-port", "0"]
+    for gen in ("whole", "range"):
+        launcher[-1] = str(_free_port())
+        r = run(["--gpus", "8", "--share-device", "--gen", gen], launcher)
+        assert r["n_gpus"] == 8 and r["config"]["edges"] == single["config"]["edges"] and r["config"]["vertices"] == single["config"]["vertices"]
+        assert ("vertex-range x8 (balanced ranges" if gen == "whole" else "vertex-range x8 (equal ranges of the permuted ids") in r["config"]["partition"]
+        assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+        part = r["config"]["partition"]
+        edges = [int(x) for x in part[part.index("[") + 1:part.index("]")].split(",")]
+        assert len(edges) == 8 and sum(edges) == single["config"]["edges"]
+        if gen == "whole":
+            assert max(edges) <= 1.02 * (sum(edges) / 8) + 70_000  # nnz-balanced: a rank is at most one hub row over its share
+        else:
+            assert max(edges) <= 1.10 * (sum(edges) / 8)  # equal ranges of permuted ids: balanced as far as the hubs fall evenly
+        assert r["scaling"] == "strong" and r["value"] > 0

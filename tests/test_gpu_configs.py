@@ -162,6 +162,75 @@ def test_rmat_build_ex_equals_its_numpy_twin(abc, flags):
         assert g.m == 1 << 14
 
 
+@pytest.mark.parametrize("abc,permute,cuts", [((0.57, 0.19, 0.19), 1, (0, 5000, None, 11000, 1 << 14)), ((0.45, 0.22, 0.22), 0, (0, 1 << 13, 1 << 14)),
+                                               ((0.57, 0.19, 0.19), 1, (0, 1 << 14))])
+def test_rmat_build_range_gives_the_rows_of_the_whole_graph(abc, permute, cuts):
+    """gdn_rmat_build_range (one rank's destination range of the generator's graph, built without the whole graph): for every
+    range of a partition the in-CSR rows equal the whole in-CSR's rows, the out-degree contributions add up to the out-degree
+    vector, and gdn_pr_squish_range + gdn_graph_pad_columns turn the range into the shard gdn_pr_squish_create +
+    gdn_graph_slice_padded cut out of the whole graph (same bounds of the live-vertex space)."""
+    import torch
+    from gardenia_amd.sharded import padded_chunk
+    L = _cabi.lib()
+    scale, n_edges = 14, (9 << 14) + 777
+    m = 1 << scale
+    whole_out, whole_in = _device_standin(dict(scale=scale, n_edges=n_edges, abc=abc, flags=permute))
+    if None in cuts:  # a range of ONE vertex, a live one (a range without a live vertex has no shard: gdn_graph_pad_columns refuses it)
+        v = 5000 + int(np.nonzero((whole_in.degrees() + whole_out.degrees())[5000:] > 0)[0][0])
+        cuts = (0, v, v + 1, 11000, 1 << 14)
+    dev = torch.device("cuda", 0)
+    out_deg = torch.zeros(m, dtype=torch.int32, device=dev)
+    in_deg = torch.zeros(m, dtype=torch.int32, device=dev)
+    world = len(cuts) - 1
+    rows = []
+    for r in range(world):
+        h = C.c_void_p()
+        _cabi.check(L.gdn_rmat_build_range(scale, n_edges, *abc, graphio.K_RAND_SEED, permute, cuts[r], cuts[r + 1], C.byref(h),
+                                           C.c_void_p(out_deg.data_ptr())))
+        mm, nnz = C.c_int32(), C.c_uint64()
+        _cabi.check(L.gdn_graph_info(h, C.byref(mm), C.byref(nnz), None, None))
+        assert mm.value == cuts[r + 1] - cuts[r]
+        rp, ci = np.empty(mm.value + 1, np.uint64), np.empty(nnz.value, np.int32)
+        _cabi.check(L.gdn_graph_download(h, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+        lo, hi = int(whole_in.rowptr[cuts[r]]), int(whole_in.rowptr[cuts[r + 1]])
+        assert np.array_equal(rp, whole_in.rowptr[cuts[r]:cuts[r + 1] + 1] - np.uint64(lo)) and np.array_equal(ci, whole_in.colidx[lo:hi])
+        _cabi.check(L.gdn_graph_degrees_dev(h, C.c_void_p(in_deg[cuts[r]:cuts[r + 1]].data_ptr()), None))
+        rows.append(h)
+    torch.cuda.synchronize()
+    assert np.array_equal(out_deg.cpu().numpy(), whole_out.degrees()) and np.array_equal(in_deg.cpu().numpy(), whole_in.degrees())
+    # the relabelled, padded shard of every range == the one cut out of the whole squished graph
+    g_in = C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, whole_in.nnz, whole_in.rowptr.ctypes.data_as(C.c_void_p), whole_in.colidx.ctypes.data_as(C.c_void_p), C.byref(g_in)))
+    sq, gp, ms = C.c_void_p(), C.c_void_p(), C.c_int32()
+    _cabi.check(L.gdn_pr_squish_create(g_in, C.c_void_p(out_deg.data_ptr()), C.byref(sq)))
+    _cabi.check(L.gdn_pr_squish_info(sq, None, C.byref(ms), C.byref(gp), None))
+    rb, sb = (C.c_int32 * (world + 1))(*cuts), (C.c_int32 * (world + 1))()
+    for r in range(world):
+        _cabi.check(L.gdn_pr_squish_range(rows[r], cuts[r], C.c_void_p(in_deg.data_ptr()), C.c_void_p(out_deg.data_ptr()), m, world + 1, rb, sb))
+    live = ((whole_in.degrees() > 0) | (whole_out.degrees() > 0)).astype(np.int64)
+    assert list(sb) == [int(live[:c].sum()) for c in cuts] and sb[world] == ms.value
+    chunk = padded_chunk(list(sb))
+    for r in range(world):
+        _cabi.check(L.gdn_graph_pad_columns(rows[r], world, sb, chunk))
+        want = C.c_void_p()
+        _cabi.check(L.gdn_graph_slice_padded(gp, world, sb, chunk, r, C.byref(want)))
+        got = []
+        for h in (rows[r], want):
+            mm, nnz = C.c_int32(), C.c_uint64()
+            _cabi.check(L.gdn_graph_info(h, C.byref(mm), C.byref(nnz), None, None))
+            rp, ci = np.empty(mm.value + 1, np.uint64), np.empty(nnz.value, np.int32)
+            _cabi.check(L.gdn_graph_download(h, rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p)))
+            got.append((mm.value, rp, ci))
+            L.gdn_graph_free(h)
+        assert got[0][0] == got[1][0] == sb[r + 1] - sb[r]
+        assert np.array_equal(got[0][1], got[1][1]) and np.array_equal(got[0][2], got[1][2])
+    L.gdn_pr_squish_free(sq)
+    L.gdn_graph_free(g_in)
+    # compaction is a property of the whole graph: refused
+    h = C.c_void_p()
+    assert L.gdn_rmat_build_range(scale, n_edges, *abc, graphio.K_RAND_SEED, 3, 0, 10, C.byref(h), None) != 0
+
+
 def test_config2_standin_lj_like_pagerank(orc):
     """BASELINE config 2 on the LJ-LIKE stand-in (graphio.LJ_LIKE: ~5.9 M vertices, ~70 M directed edges, no isolated vertex,
     max degree ~2 x 10^4 -- soc-LiveJournal1 has 4.85 M / 69 M / 2 x 10^4) to convergence against the oracle."""
