@@ -452,6 +452,19 @@ def main():
                                      "gteps": st.edges_traversed / (st.solve_ms * 1e-3) / 1e9,
                                      "gbs": b / (st.solve_ms * 1e-3) / 1e9, "bytes": b})
                 log(f"[bench] BFS from {s}: {runs[-1] if runs else 'too small'}")
+            # what of that time is the per-search initialisation (the 4 m-byte fill of the distances, the bitmap clear, the seed):
+            # every BFSSolver of the reference does it in FRONT of its Timer (src/bfs/main.cc:21, linear_base.cu:50-63,
+            # omp_beamer.cc:119-134); here it is inside solve_ms.  Two events around it in a few extra searches (GDN_BFS_TIME_INIT)
+            init_ms = []
+            try:
+                _cabi.check(L.gdn_option_set(b"GDN_BFS_TIME_INIT", b"1"))
+                for s in nz[:3]:
+                    for _ in range(2):
+                        st = _cabi.GdnStats()
+                        _cabi.check(L.gdn_bfs_run(bplan, int(s), C.c_void_p(dist_buf.data_ptr()), C.byref(st)))
+                        init_ms.append(st.prep_ms)
+            finally:
+                L.gdn_option_set(b"GDN_BFS_TIME_INIT", None)
             L.gdn_bfs_plan_free(bplan)
             if runs:
                 # the line leads with the MEDIAN run (the search whose GTEPS is the median of all runs over the three
@@ -459,7 +472,14 @@ def main():
                 best = max(runs, key=lambda r: r["gteps"])
                 by = sorted(runs, key=lambda r: r["gteps"])
                 med = by[(len(by) - 1) // 2]
+                init_med = sorted(init_ms)[len(init_ms) // 2] if init_ms else None
                 out["bfs"] = dict(med, plan_build_s=t_bplan, ms_stats=med_min([r["ms"] for r in runs]), runs=len(runs),
+                                  init_ms_inside_solve=init_med,
+                                  gteps_on_the_reference_timer=(med["edges_traversed"] / ((med["ms"] - init_med) * 1e-3) / 1e9
+                                                                if init_med is not None and med["ms"] > init_med else None),
+                                  timer_note="ms / gteps include the per-search initialisation (distances filled, bitmaps cleared), "
+                                             "which the reference's BFSSolver does in front of its Timer; gteps_on_the_reference_timer "
+                                             "leaves init_ms_inside_solve (two HIP events, extra searches) out",
                                   gteps_median=med["gteps"], gteps_best=best["gteps"],
                                   roofline={"bound": "hbm", "achieved": med["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "speed_vs_model": med["gbs"] / HBM_PEAK_GBS, "speed_vs_model_best_run": best["gbs"] / HBM_PEAK_GBS,

@@ -1622,11 +1622,33 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   memset(&st, 0, sizeof(st));
   st.prep_ms = p.prep_ms;
   HostTimer tsolve;
-  // ---- timed region == omp_beamer.cc:128-148 plus the depth initialisation
+  // ---- timed region == omp_beamer.cc:128-148 PLUS the per-search initialisation, which every BFSSolver of the reference does in
+  // front of its Timer (the caller's distances(m, MYINFINITY), src/bfs/main.cc:21; linear_base.cu:50-63, omp_beamer.cc:119-134):
+  // solve_ms is a superset of what the reference times.  GDN_BFS_TIME_INIT=1 (bench.py's note) brackets the initialisation
+  // with two events and reports it in stats.prep_ms INSTEAD of the plan's build time; solve_ms stays the whole region.
+  const char *ti = gdn_option("GDN_BFS_TIME_INIT");
+  const bool time_init = ti && ti[0] == '1';
+  struct EvPair {
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EvPair() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  hipEvent_t &ev_a = ev.a, &ev_b = ev.b;
+  if (time_init && (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess)) {
+    gdn_set_error("gdn_bfs: hipEventCreate failed");
+    return GDN_ERR_HIP;
+  }
   tsolve.start();
+  // (the source's out-degree first: the read blocks, and behind the launches below it would wait for the 512 MB fill)
+  eoff_t srow[2];
+  GDN_HIP(hipMemcpy(srow, g->rowptr + source, sizeof(srow), hipMemcpyDeviceToHost));
+  if (time_init) GDN_HIP(hipEventRecord(ev_a, 0));
   GDN_TRY(gdn_fill_i32(d_dist, GDN_MYINFINITY, (size_t)m, 0));
   GDN_HIP(hipMemsetAsync(p.visited.p, 0, (size_t)p.nwords_pad * 4, 0));
   hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, 0, source, d_dist, p.visited.p, p.q0.p);
+  if (time_init) GDN_HIP(hipEventRecord(ev_b, 0));
 
   const int alpha = 15, beta = 18;   // omp_beamer.cc:111
   int alpha_dense = 32;              // a dense sweep costs about nnz/32 top-down edge visits
@@ -1634,8 +1656,6 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   vid_t *qin = p.q0.p, *qout = p.q1.p;
   unsigned nf = 1;
   int64_t edges_to_check = (int64_t)g->nnz;
-  eoff_t srow[2];
-  GDN_HIP(hipMemcpy(srow, g->rowptr + source, sizeof(srow), hipMemcpyDeviceToHost));
   int64_t scout_count = (int64_t)(srow[1] - srow[0]);
   int32_t level = 0;  // depth of the vertices in the current frontier
   int iter = 0;
@@ -1996,6 +2016,11 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   GDN_HIP(hipGetLastError());
   st.solve_ms = tsolve.stop_ms();
   st.iterations = iter;
+  if (time_init) {
+    float init_ms = 0.f;
+    GDN_HIP(hipEventElapsedTime(&init_ms, ev_a, ev_b));
+    st.prep_ms = init_ms;
+  }
   uint64_t te = 0;
   GDN_TRY(gdn_reached_edges(g, d_dist, GDN_MYINFINITY, &te));
   st.edges_traversed = te;

@@ -91,6 +91,7 @@ def test_bench_line_carries_bfs_spmv_tc_blocks():
     assert out.returncode == 0, out.stderr[-2000:]
     r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert r["bfs"]["ms_stats"]["n"] >= 10 and 0 < r["bfs"]["roofline"]["speed_vs_model"] < 1
+    assert 0 < r["bfs"]["init_ms_inside_solve"] < r["bfs"]["ms"] and r["bfs"]["gteps_on_the_reference_timer"] > r["bfs"]["gteps"]
     assert r["bfs"]["roofline"]["frac"] is None  # (the counter-based utilisation: no counter session of this scale is committed)
     assert r["bfs"]["roofline"]["algorithmic_bytes"] == 16 * r["bfs"]["reached"] + 8 * r["bfs"]["edges_traversed"] + 4 * r["config"]["vertices"]
     sp = r["spmv"]

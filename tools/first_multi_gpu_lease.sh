@@ -19,6 +19,10 @@ for g in 2 4 8; do
   timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port $((29500 + g)) \
       bench.py --gpus $g --scale 22 --steps 5 --warmup 2 --no-bfs --no-cpu --no-extras > $out/bench_s22_n$g.json 2> $out/bench_s22_n$g.err
   tail -c 600 $out/bench_s22_n$g.json; echo
+  # (the default generates every rank's destination range on its own; --gen whole = the shard cut out of the whole graph: same L1 change)
+  timeout 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $g --master-addr 127.0.0.1 --master-port $((29550 + g)) \
+      bench.py --gpus $g --scale 22 --steps 5 --warmup 2 --gen whole --no-bfs --no-cpu --no-extras > $out/bench_s22_whole_n$g.json 2> $out/bench_s22_whole_n$g.err
+  python3 -c "import json,sys; a,b=(json.loads([l for l in open(f) if l.startswith('{')][-1])['pr_last_l1_change'] for f in sys.argv[1:3]); print('range vs whole L1 change:', a, b, 'EQUAL' if abs(a-b) <= 1e-12*abs(b) else 'DIFFERENT')" $out/bench_s22_n$g.json $out/bench_s22_whole_n$g.json
 done
 timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu --no-extras --no-bfs > $out/bench_n1.json 2> $out/bench_n1.err
 for g in 2 4 8; do
