@@ -61,7 +61,7 @@ struct BfsTdVis {
       }
     }
     if (claim) {
-      depth[dst] = next_level;
+      if (depth) depth[dst] = next_level;  // (null: deferred -- the level's bitmap is visited ^ snapshot, bfs_depth_finish_kernel)
       scout_local += rec ? (eoff_t)BFS_REC_DEG(rec[dst]) : rowptr[dst + 1] - rowptr[dst];
     }
     gdn_wl_push_staged(stage, outq, &cnt->next_count, cap, claim, dst, &cnt->overflow);
@@ -695,8 +695,15 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
                    const unsigned *__restrict__ front, unsigned *__restrict__ next, unsigned *__restrict__ visited,
                    int32_t *__restrict__ depth, int32_t next_level, BfsCounters *cnt, const unsigned *__restrict__ noin,
                    const unsigned long long *__restrict__ rec, const unsigned *__restrict__ hub_front, unsigned min_hubs, bool trace,
-                   int scan_unr = 1, const unsigned *__restrict__ filt = nullptr, const unsigned *__restrict__ hub_front2 = nullptr) {
+                   int scan_unr = 1, const unsigned *__restrict__ filt = nullptr, const unsigned *__restrict__ hub_front2 = nullptr,
+                   // non-null: `rec` is the COMPACT copy (rows with in-edges only; see bfs_compact_rec_kernel), cbase its word offsets
+                   const unsigned *__restrict__ cbase = nullptr, const eoff_t *__restrict__ rowptr_c = nullptr) {
   static_assert(BFS_BW_GROUP * BFS_BW_STEP <= 65536u, "a list entry is (step << 11 | row in step) in 16 bits");
+  auto compact_id = [&](unsigned v) -> unsigned {  // (v is an open row: it has in-edges)
+    const unsigned wd = v >> 5;
+    return cbase[wd] + (unsigned)__popc(~noin[wd] & ((1u << (v & 31u)) - 1u));
+  };
+  auto rec_at = [&](unsigned v) -> unsigned long long { return cbase == nullptr ? rec[v] : rec[compact_id(v)]; };
   __shared__ unsigned s_hf[BFS_HUBS / 32];
   __shared__ unsigned short s_list[BFS_BW_WAVES][BFS_BW_STEP];
   __shared__ unsigned s_bits[BFS_BW_WAVES][BFS_BW_GROUP * 64];
@@ -733,7 +740,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         on[r] = i < n;
         rl[r] = on[r] ? list[i] : 0u;
         rc[r] = BFS_NO_HUB;
-        if (on[r]) rc[r] = rec[gbase + rl[r]];
+        if (on[r]) rc[r] = rec_at(gbase + rl[r]);
         code[r] = (unsigned)rc[r];
       }
 #pragma unroll
@@ -747,7 +754,7 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
       for (int r = 0; r < BFS_BU_UNR; r++) {
         found[r] = on[r] && (code[r] < BFS_HUBS ? (hubs && ((s_hf[code[r] >> 5] >> (code[r] & 31u)) & 1u)) : (bool)((fw[r] >> (code[r] & 31u)) & 1u));
         if (found[r]) {
-          depth[gbase + rl[r]] = next_level;
+          if (depth) depth[gbase + rl[r]] = next_level;  // (null: this level's depths are written from its bitmap at the end of the search)
           scout += BFS_REC_DEG(rc[r]);
           atomicOr(&bits[rl[r] >> 5], 1u << (rl[r] & 31u));
           by_head++;
@@ -763,7 +770,15 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
     // ---- stage 2: the rows still open, one per lane: their in-neighbours against the frontier
     for (unsigned i = lane; i < nq; i += 64u) {
       const unsigned rl = list[i], v = gbase + rl;
-      const eoff_t rb = in_rowptr[v], re = in_rowptr[v + 1];
+      eoff_t rb, re;
+      if (cbase == nullptr) {
+        rb = in_rowptr[v];
+        re = in_rowptr[v + 1];
+      } else {
+        const unsigned ci = compact_id(v);
+        rb = rowptr_c[ci];
+        re = rowptr_c[ci + 1u];
+      }
       bool found = false;
       if (scan_unr > 1) {
         // four in-neighbours and their frontier words per round trip: a row that reaches this stage mostly FAILS (its head was
@@ -795,10 +810,10 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         }
       }
       if (found) {
-        depth[v] = next_level;
+        if (depth) depth[v] = next_level;
         atomicOr(&bits[rl >> 5], 1u << (rl & 31u));
         awake++;
-        scout += BFS_REC_DEG(rec[v]);
+        scout += BFS_REC_DEG(rec_at(v));
       }
     }
     wave_sync();
@@ -1136,7 +1151,7 @@ bfs_pb_accumulate_kernel(int32_t m, int log_bin, const eoff_t *__restrict__ bin_
       if ((nb >> (lane & 31u)) & 1u) {
         const size_t row = ((size_t)w0 + i) * 32 + (lane & 31u);
         if (row < (size_t)m) {
-          depth[row] = next_level;
+          if (depth) depth[row] = next_level;  // (null: deferred, see bfs_depth_finish_kernel)
           awake++;
           scout += out_rowptr[row + 1] - out_rowptr[row];
         }
@@ -1386,7 +1401,7 @@ bfs_btd_apply_kernel(const vid_t *__restrict__ buf, unsigned *cur, const unsigne
       if ((nb >> (lane & 31u)) & 1u) {
         const size_t row = (w0 + i) * 32 + (lane & 31u);
         if (row < (size_t)m) {
-          depth[row] = next_level;
+          if (depth) depth[row] = next_level;  // (null: deferred, see bfs_depth_finish_kernel)
           awake++;
           scout += rec ? (eoff_t)BFS_REC_DEG(rec[row]) : out_rowptr[row + 1] - out_rowptr[row];
         }
@@ -1441,6 +1456,10 @@ struct gdn_bfs_plan {
   DevBuf<vid_t> hub_id;                // hub heads of the bottom-up step (bfs_bu_kernel): the BFS_HUBS vertices of highest
   DevBuf<unsigned long long> head;     //   out-degree, every row's out-degree | head (bfs_hub_head_kernel),
   DevBuf<unsigned> hub_front;          //   the hubs' frontier bits per level
+  DevBuf<unsigned long long> head_c;   //   the head records of the rows with in-edges only (compact copy for bfs_bu_wave_kernel)
+  DevBuf<unsigned> head_cbase;         //   ... and the offset of every 32-row word in it
+  DevBuf<eoff_t> in_rowptr_c;          //   ... and the in-CSR offsets of the same rows
+  DevBuf<unsigned> lvl;                //   BFS_DEFER_MAX frontier bitmaps kept per search (deferred depths, bfs_depth_finish_kernel)
   DevBuf<unsigned> hub_front2;         //   the same by rank for all n_ranked hubs (outer hubs: read from L2, not LDS)
   unsigned n_ranked = BFS_HUBS;        //   hubs named by rank in the head records
   // binned top-down levels (bfs_btd_*): nbins x BFS_BTD_SUB id lists of btd_cap_each entries, their counters, the flag
@@ -1462,6 +1481,97 @@ bfs_noin_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned nwords, u
     if (v >= (size_t)m || rowptr[v + 1] == rowptr[v]) word |= 1u << i;
   }
   noin[w] = word;
+}
+
+// DEFERRED depths (round 5).  A bottom-up level that discovers a third of the graph writes 4 bytes into almost every 64-byte
+// line of the distance array -- scattered over the level, each line fetched, merged and written back -- although the level's
+// frontier bitmap already says the same.  The wave kernel therefore leaves the distances alone (depth == nullptr) and its
+// `next` bitmap is kept (a pool of BFS_DEFER_MAX bitmaps the front / next pair walks through); the search ends with ONE
+// sequential pass: not visited -> unreached (this replaces the fill in front of the search), in kept bitmap k -> its level,
+// visited otherwise -> written by the level that found it (the light levels write as before).
+#define BFS_DEFER_MAX 8
+struct BfsLevelMaps {
+  const unsigned *bits[BFS_DEFER_MAX];
+  int32_t level[BFS_DEFER_MAX];
+  int n;
+};
+#define BFS_FINISH_UNR 4
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps, int32_t *__restrict__ depth, int32_t m, int32_t unreached) {
+  // four consecutive vertices per thread and trip (a nibble of one bitmap word, one 16-byte store), a grid that loops (with a
+  // thread per vertex the 524 288 workgroups of RMAT-27 were the cost: 0.55 ms for 512 MB), BFS_FINISH_UNR trips' words
+  // requested before the first is used (one trip at a time the pass waited a round trip per 16 bytes: 0.18-0.25 ms)
+  const size_t nquads = ((size_t)m + 3) / 4, stride = (size_t)gridDim.x * GDN_BLOCK;
+  const bool aligned = (reinterpret_cast<size_t>(depth) & 15u) == 0;
+  for (size_t q0 = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; q0 < nquads; q0 += BFS_FINISH_UNR * stride) {
+    unsigned vw[BFS_FINISH_UNR], mw[BFS_FINISH_UNR][BFS_DEFER_MAX];
+#pragma unroll
+    for (int u = 0; u < BFS_FINISH_UNR; u++) {
+      const size_t q = q0 + (size_t)u * stride;
+      const unsigned w = (unsigned)((q * 4) >> 5);
+      const bool on = q < nquads;
+      vw[u] = on ? visited[w] : 0u;
+      // (static indices: a run-time index into the by-value struct would put it into scratch memory)
+#pragma unroll
+      for (int k = 0; k < BFS_DEFER_MAX; k++) mw[u][k] = (on && k < maps.n) ? maps.bits[k][w] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < BFS_FINISH_UNR; u++) {
+      const size_t q = q0 + (size_t)u * stride;
+      if (q >= nquads) break;
+      const size_t v0 = q * 4;
+      const unsigned sh = (unsigned)(v0 & 31u);
+      const unsigned seen = (vw[u] >> sh) & 15u;
+      int32_t val[4] = {unreached, unreached, unreached, unreached};
+      unsigned write = ~seen & 15u;
+#pragma unroll
+      for (int k = 0; k < BFS_DEFER_MAX; k++) {
+        const unsigned bits = (mw[u][k] >> sh) & 15u;  // (0 beyond maps.n)
+        write |= bits;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if ((bits >> j) & 1u) val[j] = maps.level[k];
+      }
+      if (write == 15u && v0 + 4 <= (size_t)m && aligned) {
+        *reinterpret_cast<int4 *>(depth + v0) = make_int4(val[0], val[1], val[2], val[3]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (((write >> j) & 1u) && v0 + j < (size_t)m) depth[v0 + j] = val[j];
+      }
+    }
+  }
+}
+
+// COMPACT head records (round 5): 61 % of RMAT-27's rows have no in-edge and never reach the bottom-up step, but their 8-byte
+// records sit between the others' -- a level whose open rows are most of the live ones reads all 1.07 GB of lines for 0.42 GB of
+// records.  The wave kernel therefore reads a copy that holds the rows WITH in-edges only, in row order: record of row v at
+// cbase[v >> 5] + popcount(the live rows of v's 32-row word below v).
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_live_counts_kernel(const unsigned *__restrict__ noin, unsigned nwords, unsigned *__restrict__ cnt) {
+  const unsigned w = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (w < nwords) cnt[w] = (unsigned)__popc(~noin[w]);  // (rows past the last one count as rows without in-edges: bfs_noin_kernel)
+}
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_narrow_u64_kernel(const eoff_t *__restrict__ in, unsigned n, unsigned *__restrict__ out) {
+  const unsigned i = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i < n) out[i] = (unsigned)in[i];
+}
+// (the in-CSR offsets of the same rows ride along: a row without in-edges has an empty range, so entry i + 1 of the compact
+// offsets is also the end of live row i -- the scan of a row whose head failed reads them instead of 16 bytes of the 8 (m + 1))
+__global__ void __launch_bounds__(GDN_BLOCK)
+bfs_compact_rec_kernel(const unsigned long long *__restrict__ rec, const unsigned *__restrict__ noin, const unsigned *__restrict__ cbase,
+                       int32_t m, unsigned long long *__restrict__ rec_c, const eoff_t *__restrict__ in_rowptr,
+                       eoff_t *__restrict__ rowptr_c, unsigned n_live) {
+  const unsigned v = blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (v == 0u) rowptr_c[n_live] = in_rowptr[m];
+  if (v >= (unsigned)m) return;
+  const unsigned live = ~noin[v >> 5];
+  if ((live >> (v & 31u)) & 1u) {
+    const unsigned ci = cbase[v >> 5] + (unsigned)__popc(live & ((1u << (v & 31u)) - 1u));
+    rec_c[ci] = rec[v];
+    rowptr_c[ci] = in_rowptr[v];
+  }
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -1596,6 +1706,33 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
                          hub_idx.p, sorted, p.head.p, p.n_ranked);
       GDN_HIP(hipGetLastError());
       GDN_HIP(hipDeviceSynchronize());
+      {  // deferred depths (GDN_BFS_DEFER_DEPTH=0: without; default from 2^25 vertices on: at RMAT-24 the pass at the end costs what the levels save)
+        const char *ed = gdn_option("GDN_BFS_DEFER_DEPTH");
+        if (ed ? ed[0] != '0' : (unsigned)m >= (1u << 25)) GDN_TRY(p.lvl.alloc((size_t)BFS_DEFER_MAX * p.nwords_pad));
+      }
+      {  // the compact copy (GDN_BFS_REC_COMPACT=0: without; default from 2^25 vertices on: RMAT-24 measures the same with and without)
+        const char *ec = gdn_option("GDN_BFS_REC_COMPACT");
+        if (ec ? ec[0] != '0' : (unsigned)m >= (1u << 25)) {
+          DevBuf<unsigned> cnt;
+          DevBuf<eoff_t> scan;
+          GDN_TRY(cnt.alloc_scratch(p.nwords_pad));
+          GDN_TRY(scan.alloc_scratch((size_t)p.nwords_pad + 1));
+          hipLaunchKernelGGL(bfs_live_counts_kernel, dim3(gdn_nblocks(p.nwords_pad)), dim3(GDN_BLOCK), 0, 0, p.noin.p, p.nwords_pad, cnt.p);
+          GDN_TRY(gdn_exclusive_scan_u32_to_u64(cnt.p, scan.p, (size_t)p.nwords_pad, 0));
+          eoff_t n_live = 0;
+          GDN_HIP(hipMemcpy(&n_live, scan.p + p.nwords_pad, sizeof(eoff_t), hipMemcpyDeviceToHost));
+          GDN_TRY(p.head_cbase.alloc((size_t)p.nwords_pad + 1));
+          GDN_TRY(p.head_c.alloc((size_t)n_live + 1));
+          GDN_TRY(p.in_rowptr_c.alloc((size_t)n_live + 1));
+          hipLaunchKernelGGL(bfs_narrow_u64_kernel, dim3(gdn_nblocks((uint64_t)p.nwords_pad + 1)), dim3(GDN_BLOCK), 0, 0, scan.p,
+                             p.nwords_pad + 1u, p.head_cbase.p);
+          hipLaunchKernelGGL(bfs_compact_rec_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0,
+                             (const unsigned long long *)p.head.p, p.noin.p, p.head_cbase.p, m, p.head_c.p, gin->rowptr,
+                             p.in_rowptr_c.p, (unsigned)n_live);
+          GDN_HIP(hipGetLastError());
+          GDN_HIP(hipDeviceSynchronize());
+        }
+      }
       // how skewed the out-degrees are: the smallest degree among the hubs against the average (R-MAT-27: hundreds against 16;
       // a uniform random graph: 35 against 16).  With heads that are real hubs the bottom-up step pays from an edge share of
       // 1/8 on (bfs_run), without it is the worst engine there.
@@ -1625,18 +1762,20 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   // ---- timed region == omp_beamer.cc:128-148 PLUS the per-search initialisation, which every BFSSolver of the reference does in
   // front of its Timer (the caller's distances(m, MYINFINITY), src/bfs/main.cc:21; linear_base.cu:50-63, omp_beamer.cc:119-134):
   // solve_ms is a superset of what the reference times.  GDN_BFS_TIME_INIT=1 (bench.py's note) brackets the initialisation
-  // with two events and reports it in stats.prep_ms INSTEAD of the plan's build time; solve_ms stays the whole region.
+  // (and the pass that writes the deferred distances at the end) with events and reports it in stats.prep_ms INSTEAD of the
+  // plan's build time; solve_ms stays the whole region.
   const char *ti = gdn_option("GDN_BFS_TIME_INIT");
   const bool time_init = ti && ti[0] == '1';
-  struct EvPair {
-    hipEvent_t a = nullptr, b = nullptr;
-    ~EvPair() {
-      if (a) (void)hipEventDestroy(a);
-      if (b) (void)hipEventDestroy(b);
+  struct EvSet {
+    hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr;
+    ~EvSet() {
+      for (hipEvent_t e : {a, b, c, d})
+        if (e) (void)hipEventDestroy(e);
     }
   } ev;
   hipEvent_t &ev_a = ev.a, &ev_b = ev.b;
-  if (time_init && (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess)) {
+  if (time_init && (hipEventCreate(&ev_a) != hipSuccess || hipEventCreate(&ev_b) != hipSuccess || hipEventCreate(&ev.c) != hipSuccess ||
+                    hipEventCreate(&ev.d) != hipSuccess)) {
     gdn_set_error("gdn_bfs: hipEventCreate failed");
     return GDN_ERR_HIP;
   }
@@ -1645,7 +1784,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   eoff_t srow[2];
   GDN_HIP(hipMemcpy(srow, g->rowptr + source, sizeof(srow), hipMemcpyDeviceToHost));
   if (time_init) GDN_HIP(hipEventRecord(ev_a, 0));
-  GDN_TRY(gdn_fill_i32(d_dist, GDN_MYINFINITY, (size_t)m, 0));
+  const bool defer = p.lvl.p != nullptr && p.head.p != nullptr;  // (the pass at the end writes "unreached" too: no fill)
+  BfsLevelMaps maps;
+  maps.n = 0;
+  if (!defer) GDN_TRY(gdn_fill_i32(d_dist, GDN_MYINFINITY, (size_t)m, 0));
   GDN_HIP(hipMemsetAsync(p.visited.p, 0, (size_t)p.nwords_pad * 4, 0));
   hipLaunchKernelGGL(bfs_seed_kernel, dim3(1), dim3(64), 0, 0, source, d_dist, p.visited.p, p.q0.p);
   if (time_init) GDN_HIP(hipEventRecord(ev_b, 0));
@@ -1723,8 +1865,12 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   big.items = p.bigitems.p;
   big.capacity = p.bigcap;
   int32_t snap_level = -1;  // the level whose discoveries are visited ^ snap (-1: no snapshot)
+  unsigned *kept_front = nullptr;  // deferred depths: that difference, already made (a kept bitmap) ...
+  int32_t kept_front_level = -1;   // ... for this level
   // (levels of fewer frontier edges discover so little that the old conversion is as cheap as the snapshot)
   const int64_t snap_min_edges = 1 << 16;
+  int64_t td_defer_min = 1 << 20;  // frontier edges from which a top-down level defers its depths (a 16 MB bitmap pass against its writes)
+  if (const char *e = gdn_option("GDN_BFS_TD_DEFER_MIN")) td_defer_min = atoll(e);  // (tuning knob; huge = never)
   const bool trace = gdn_option("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
   HostTimer tl;
   auto lap = [&](const char *what, long long a, long long b) {
@@ -1742,7 +1888,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     if (p.dense && scout_count > heavy_from && (scout_count > (int64_t)(g->nnz / alpha_dense) || scout_count >= btd_min_edges)) {
       // ---- dense phase: bitmap levels while the frontier stays heavy
       light_streak = 0;
-      if (snap_level == level && p.snap.p) {  // the level before was a top-down one with a snapshot in front of it
+      unsigned *fr = p.front.p, *nx = p.next.p;
+      if (kept_front_level == level && kept_front) {  // the top-down level before left its depths to the end: its bitmap exists
+        fr = kept_front;
+      } else if (snap_level == level && p.snap.p) {  // the level before was a top-down one with a snapshot in front of it
         hipLaunchKernelGGL(bfs_bitmap_diff_kernel, dim3(gdn_nblocks(p.nwords_pad / 4)), dim3(GDN_BLOCK), 0, 0,
                            reinterpret_cast<const uint4 *>(p.visited.p), reinterpret_cast<const uint4 *>(p.snap.p),
                            reinterpret_cast<uint4 *>(p.front.p), p.nwords_pad / 4);
@@ -1750,7 +1899,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         GDN_HIP(hipMemsetAsync(p.front.p, 0, (size_t)p.nwords_pad * 4, 0));
         hipLaunchKernelGGL(bfs_queue_to_bitmap, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, qin, nf, p.front.p);
       }
-      unsigned *fr = p.front.p, *nx = p.next.p;
+      unsigned *const scratch[2] = {p.front.p, p.next.p};
       int64_t awake = 0;
       bool have_queue = true;  // qin / nfq hold the frontier as a vertex list (what the binned level expands)
       unsigned nfq = nf;
@@ -1772,6 +1921,18 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         bool btd = !bottom_up && btd_on && p.btd_max_edges && (uint64_t)scout_count <= p.btd_max_edges &&
                    (btd_force || 100 * scout_count + 5800000000ll < 21 * (int64_t)g->nnz);
         const char *engine = bottom_up ? "bottom-up" : "dense";
+        // deferred depths: this level's `next` bitmap goes into the pool and stays there, its kernels leave the distances alone
+        // (every engine of the dense phase but the window form of the bottom-up step, an A/B knob)
+        const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
+        const bool window_form = bfe && bfe[0] == 'w';
+        const bool keep = defer && maps.n < BFS_DEFER_MAX && !window_form;
+        if (keep) {
+          nx = p.lvl.p + (size_t)maps.n * p.nwords_pad;
+          maps.bits[maps.n] = nx;
+          maps.level[maps.n] = level + 1;
+          maps.n++;
+        }
+        int32_t *const d_out = keep ? (int32_t *)nullptr : d_dist;
         if (btd) {
           if (!have_queue) {  // the frontier exists as a bitmap only: list it
             hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr,
@@ -1798,7 +1959,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           hipLaunchKernelGGL(bfs_btd_bin_kernel, dim3(gdn_nblocks(nfq)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nfq, bbig, bv);
           hipLaunchKernelGGL(bfs_btd_bin_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, bbig, bv);
           hipLaunchKernelGGL(bfs_btd_apply_kernel, dim3(p.btd_nbins), dim3(BFS_BTD_THREADS), (size_t)4 << (p.btd_logb - 5), 0,
-                             p.btd_buf.p, p.btd_cur.p, p.btd_flag.p, p.btd_cap_each, p.btd_logb, m, p.nwords_pad, p.visited.p, nx, d_dist,
+                             p.btd_buf.p, p.btd_cur.p, p.btd_flag.p, p.btd_cap_each, p.btd_logb, m, p.nwords_pad, p.visited.p, nx, d_out,
                              level + 1, g->rowptr, p.cnt.p, (const unsigned long long *)p.head.p);
           unsigned flag = 0;
           GDN_HIP(hipMemcpy(&flag, p.btd_flag.p, sizeof(flag), hipMemcpyDeviceToHost));
@@ -1819,8 +1980,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
             hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(p.n_ranked / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p,
                                p.hub_front2.p);
           }
-          const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
-          if (p.head.p && !(bfe && bfe[0] == 'w')) {
+          if (p.head.p && !window_form) {
             // frontier of at most 2^20 vertices (its size is the last level's discoveries): the hashed filter in front of the bitmap
             const int64_t front_n = have_queue ? (int64_t)nfq : awake;
             const unsigned *filt = nullptr;
@@ -1830,8 +1990,9 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
               filt = p.filt.p;
             }
             hipLaunchKernelGGL(bfs_bu_wave_kernel, dim3(BFS_BW_GRID), dim3(BFS_BW_THREADS), 0, 0, gin->rowptr, gin->colidx, m,
-                               p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p, p.head.p,
-                               p.hub_front.p, hub_min, trace, bu_scan, filt, p.hub_front2.p);
+                               p.nwords_pad * 32u, fr, nx, p.visited.p, d_out, level + 1, p.cnt.p, p.noin.p,
+                               p.head_c.p ? p.head_c.p : p.head.p, p.hub_front.p, hub_min, trace, bu_scan, filt, p.hub_front2.p,
+                               p.head_cbase.p, p.in_rowptr_c.p);
           }
           else
           hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
@@ -1841,7 +2002,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           hipLaunchKernelGGL(bfs_pb_expand_kernel, dim3(p.pb.nchunks), dim3(PB_THREADS), 0, 0, fr, p.pb.log_chunk,
                              p.pb.chunk_ptr.p, p.pb.chunk_order.p, p.pb.U.p, p.pb.G.p, p.ebits.p);
           hipLaunchKernelGGL(bfs_pb_accumulate_kernel, dim3(p.pb.nbins), dim3(PB_THREADS), 0, 0, m, p.pb.log_bin,
-                             p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_dist, level + 1,
+                             p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_out, level + 1,
                              g->rowptr, p.cnt.p);
         }
         GDN_TRY(bfs_read_counters(p, h));
@@ -1852,9 +2013,8 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         awake = (int64_t)h.awake;
         scout_count = (int64_t)h.scout;
         visited_total += awake;
-        unsigned *t = fr;
-        fr = nx;
-        nx = t;
+        fr = nx;  // (a kept bitmap is never written again: the next level writes into a scratch one that is not its frontier)
+        nx = fr == scratch[0] ? scratch[1] : scratch[0];
         level++;
         have_queue = false;
         if (trace && bottom_up && !btd)
@@ -1991,12 +2151,27 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       // (rows of 64..511 edges walked one after the other by the few waves of such a level cost 0.35 ms on RMAT-27)
       big.min_deg = ((uint64_t)nf < 65536u && (uint64_t)nf + (uint64_t)scout_count / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
                         ? 64u : (unsigned)EXP_BIG;
+      bool td_keep = false;
       if (p.snap.p && scout_count >= snap_min_edges) {  // the next level may be a bitmap one: see bfs_bitmap_diff_kernel
         GDN_HIP(hipMemcpyAsync(p.snap.p, p.visited.p, (size_t)p.nwords_pad * 4, hipMemcpyDeviceToDevice, 0));
         snap_level = level + 1;
+        // deferred depths for a top-down level of some weight too (one scattered 4-byte write per discovery less): its bitmap is
+        // the difference to the snapshot, made right behind the level whatever the next one is
+        td_keep = defer && maps.n < BFS_DEFER_MAX && scout_count >= td_defer_min;
+        if (td_keep) vis.depth = nullptr;
       }
       hipLaunchKernelGGL(bfs_td_kernel, dim3(gdn_nblocks(nf)), dim3(GDN_BLOCK), 0, 0, g->rowptr, qin, nf, big, vis);
       hipLaunchKernelGGL(bfs_td_big_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, g->rowptr, big, vis);
+      if (td_keep) {
+        kept_front = p.lvl.p + (size_t)maps.n * p.nwords_pad;
+        kept_front_level = level + 1;
+        hipLaunchKernelGGL(bfs_bitmap_diff_kernel, dim3(gdn_nblocks(p.nwords_pad / 4)), dim3(GDN_BLOCK), 0, 0,
+                           reinterpret_cast<const uint4 *>(p.visited.p), reinterpret_cast<const uint4 *>(p.snap.p),
+                           reinterpret_cast<uint4 *>(kept_front), p.nwords_pad / 4);
+        maps.bits[maps.n] = kept_front;
+        maps.level[maps.n] = level + 1;
+        maps.n++;
+      }
       GDN_TRY(bfs_read_counters(p, h));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;
@@ -2013,6 +2188,18 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       return GDN_ERR_OVERFLOW;
     }
   }
+  if (defer) {  // the distances of the kept levels and of the vertices never reached, in one sequential pass
+    if (time_init) GDN_HIP(hipEventRecord(ev.c, 0));
+    unsigned fin_blocks = 8192;
+    if (const char *e = gdn_option("GDN_BFS_FINISH_BLOCKS")) fin_blocks = atoi(e) > 0 ? (unsigned)atoi(e) : fin_blocks;  // (tuning knob)
+    const unsigned need_blocks = gdn_nblocks(((uint64_t)m + 3) / 4);
+    hipLaunchKernelGGL(bfs_depth_finish_kernel, dim3(need_blocks < fin_blocks ? need_blocks : fin_blocks),
+                       dim3(GDN_BLOCK), 0, 0, p.visited.p, maps, d_dist, m,
+                       (int32_t)GDN_MYINFINITY);
+    if (time_init) GDN_HIP(hipEventRecord(ev.d, 0));
+    GDN_HIP(hipStreamSynchronize(0));
+    if (trace) fprintf(stderr, "[bfs] distances of %d kept levels + unreached written at the end  %.3f ms\n", maps.n, tl.stop_ms());
+  }
   GDN_HIP(hipGetLastError());
   st.solve_ms = tsolve.stop_ms();
   st.iterations = iter;
@@ -2020,6 +2207,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     float init_ms = 0.f;
     GDN_HIP(hipEventElapsedTime(&init_ms, ev_a, ev_b));
     st.prep_ms = init_ms;
+    if (defer) {  // (the pass that writes the distances at the end: omp_beamer.cc:165-169 does its own behind t.Stop())
+      GDN_HIP(hipEventElapsedTime(&init_ms, ev.c, ev.d));
+      st.prep_ms += init_ms;
+    }
   }
   uint64_t te = 0;
   GDN_TRY(gdn_reached_edges(g, d_dist, GDN_MYINFINITY, &te));

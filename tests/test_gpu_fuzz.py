@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("first_seed,blocked", [(1, False), (100001, False), (200001, True), (300001, "plans"),
-                                                (700001, "fused"), (800001, "heads"), (900001, "heads2")])
+                                                (700001, "fused"), (800001, "heads"), (900001, "heads2"), (1000001, "deferred")])
 def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
     env = dict(os.environ, OMP_NUM_THREADS="4")
     if blocked == "fused":  # every BFS level, every forward and every backward level of BC that fits, and PageRank's
@@ -22,8 +22,13 @@ def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
                    GDN_BC_SMALL_SCOUT="1000000000000", GDN_BC_BACK_NF="1024", GDN_BC_BACK_SCOUT="1000000000000",
                    GDN_PR_FUSED="1", GDN_PR_SMALL_M="16384", FUZZ_PLANS="1")
         blocked = False
-    if blocked == "heads2":  # ... and every head named by rank (the outer hubs of BFS's bottom-up step)
-        env.update(GDN_BFS_HUBS2="1")
+    if blocked == "deferred":  # BFS plans with head records whose heavy levels -- binned top-down forced below a third of the edges,
+        # dense sweeps, bottom-up steps -- all leave the distances to the pass at the end of the search (default from 2^25 vertices on)
+        env.update(FUZZ_PLANS="1", GDN_BFS_HEADS_MIN_NNZ="1", GDN_BFS_HUB_MIN="0", GDN_BFS_DEFER_DEPTH="1", GDN_BFS_REC_COMPACT="1", GDN_BFS_TD_DEFER_MIN="1",
+                   GDN_BFS_BTD="2", GDN_BFS_ALPHA_BTD="100000", GDN_BFS_BTD_MIN="1")
+        blocked = False
+    if blocked == "heads2":  # ... and every head named by rank (the outer hubs of BFS's bottom-up step), the records read from their compact copy
+        env.update(GDN_BFS_HUBS2="1", GDN_BFS_REC_COMPACT="1", GDN_BFS_DEFER_DEPTH="1")
         blocked = "heads"
     if blocked == "heads":  # the resident plans with every heavy BFS level on the bottom-up step and its head records
         # (normally from 2^24 edges on; hub test always on), and SSSP's sweeps with their record tiers (from 2^22 edges on)

@@ -74,6 +74,9 @@ def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed,
     (default from 2^26 vertices on): below 2^21 vertices every head is a rank, at scale 22 ranks and vertex ids mix."""
     if outer is not None:
         monkeypatch.setenv("GDN_BFS_HUBS2", outer)
+        monkeypatch.setenv("GDN_BFS_DEFER_DEPTH", outer)  # ... whose levels leave the distances to one pass at the end of the search
+        monkeypatch.setenv("GDN_BFS_TD_DEFER_MIN", "1")   # (top-down levels behind a snapshot too, whatever their weight)
+        monkeypatch.setenv("GDN_BFS_REC_COMPACT", outer)  # ... and the wave kernel on the compact copy of the records (default from 2^25 vertices on)
     monkeypatch.setenv("GDN_BFS_HEADS_MIN_NNZ", "1")
     monkeypatch.setenv("GDN_BFS_TRACE", "1")
     if hub_min is not None:

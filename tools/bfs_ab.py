@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of BFS knobs on ONE resident graph (R-MAT scale S; the plan is rebuilt under every knob set, so plan-build knobs such as
 GDN_BFS_HUBS2 count too): per knob set the three bench sources, best of 3 untraced runs + one traced run (GDN_BFS_TRACE),
-depths compared with the first set's.  usage: bfs_ab.py <scale> "K1=V1,K2=V2" "K1=V3" ...  ("" = defaults)"""
+depths compared with the first set's.  usage: bfs_ab.py <scale | u<scale>> "K1=V1,K2=V2" "K1=V3" ...  ("" = defaults; u26 = uniform random 2^26 x 16)"""
 import ctypes as C
 import os
 import sys
@@ -12,10 +12,14 @@ import numpy as np
 from gardenia_amd import _cabi, graphio
 
 L = _cabi.lib()
-scale = int(sys.argv[1]) if len(sys.argv) > 1 else 27
+arg = sys.argv[1] if len(sys.argv) > 1 else "27"  # "27": R-MAT scale 27; "u26": uniform random, 2^26 vertices x 16 draws each
+scale = int(arg.lstrip("u"))
 sets = sys.argv[2:] or [""]
 go, gi = C.c_void_p(), C.c_void_p()
-_cabi.check(L.gdn_rmat_build(scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+if arg.startswith("u"):
+    _cabi.check(L.gdn_rmat_build_ex(scale, 16 << scale, 0.25, 0.25, 0.25, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+else:
+    _cabi.check(L.gdn_rmat_build(scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
 m, nnz = C.c_int32(), C.c_uint64()
 _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), None, None))
 m = m.value
