@@ -9,7 +9,7 @@ mkdir -p $O; rm -rf $O/*
 ( date -u +"%Y-%m-%dT%H:%M:%SZ"; hostname; rocminfo 2>/dev/null | grep -m1 -i "uuid.*GPU" ) > $O/session.txt 2>&1
 for reps in 2 6; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${c}_$reps -- python3 tools/traffic_run.py $w $scale $reps > $O/${c}_$reps.log 2>&1
+    timeout 900 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/${c}_$reps -- python3 tools/traffic_run.py $w $scale $reps > $O/${c}_$reps.log 2>&1
   done
 done
 python3 tools/traffic_run.py $w $scale 6 > $O/plain.log 2>&1
