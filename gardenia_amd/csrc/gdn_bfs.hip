@@ -14,6 +14,10 @@
 // only cause a redundant atomic, never a wrong depth; next-frontier compaction is one
 // atomicAdd per wavefront (gdn_wl_push).  Depths are exact: every vertex is claimed once, in
 // the level in which it is first reached.
+// The resident plan (gdn_bfs_plan_*) adds, from the sizes on at which each was measured to pay: head records of the bottom-up
+// step (every row's in-neighbour of highest out-degree, hubs named by rank; a compact copy for the rows with in-edges),
+// a dense sweep and a binned top-down level for heavy frontiers, fused light levels, and DEFERRED depths -- heavy levels keep
+// their frontier bitmaps and one sequential pass writes the distances at the end (bfs_depth_finish_kernel).  DESIGN.md 4.4.
 #include <stdlib.h>
 #include <string.h>
 
