@@ -319,7 +319,8 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
 __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx,
                                                            const vid_t *__restrict__ ncol, eoff_t ub, eoff_t ue, eoff_t vlo,
                                                            eoff_t vhi, vid_t *s_tab, unsigned char *s_own,
-                                                           const unsigned *__restrict__ nstart = nullptr) {
+                                                           const unsigned *__restrict__ nstart = nullptr,
+                                                           const unsigned long long *__restrict__ nbound = nullptr) {
   const unsigned lane = gdn_lane();
   const int du = (int)(ue - ub);
   unsigned long long count = 0;
@@ -334,7 +335,13 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     // third and fourth dependent round trip of every row (set ids -> neighbour ids -> bounds -> lists), and a light row is
     // little more than that chain
     eoff_t vb0 = 0, ve0 = 0;
-    if (vlo + lane < vhi) {
+    if (nbound) {  // the forward form with packed walk bounds: no neighbour id, no row offsets
+      if (vlo + lane < vhi) {
+        const unsigned long long b = nbound[vlo + lane];
+        vb0 = b >> 24;
+        ve0 = vb0 + (b & 0xFFFFFFull);
+      }
+    } else if (vlo + lane < vhi) {
       const vid_t v = (ncol == colidx && vlo == cb) ? x0 : ncol[vlo + lane];
       vb0 = rowptr[v];
       ve0 = rowptr[v + 1];
@@ -355,7 +362,11 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
       eoff_t vb = vb0, ve = ve0;
       if (i0 != vlo) {
         vb = ve = 0;
-        if (i < vhi) {
+        if (i < vhi && nbound) {
+          const unsigned long long b = nbound[i];
+          vb = b >> 24;
+          ve = vb + (b & 0xFFFFFFull);
+        } else if (i < vhi) {
           const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
           vb = rowptr[v];
           ve = rowptr[v + 1];
@@ -424,7 +435,8 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
                 const vid_t *__restrict__ ncolidx, int32_t m,
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
                 unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
-                unsigned long long *__restrict__ total, unsigned light, const unsigned *__restrict__ nstart = nullptr) {
+                unsigned long long *__restrict__ total, unsigned light, const unsigned *__restrict__ nstart = nullptr,
+                const unsigned long long *__restrict__ nbound = nullptr) {
   __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
@@ -450,7 +462,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     const eoff_t nb0 = nrowptr[u], ne0 = nrowptr[u + 1];
     const eoff_t vlo = nb0 + (eoff_t)c * TC_SLICE;
     const eoff_t vhi = vlo + TC_SLICE < ne0 ? vlo + TC_SLICE : ne0;
-    count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w], nstart);
+    count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w], nstart, nbound);
   }
   // ---- light rows: 16 consecutive vertices per grab (one atomic per 16 rows)
   for (;;) {
@@ -474,7 +486,7 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       // nothing to close without a set or a neighbour; heavy rows are done
       if (ue == ub || dn == 0 || dn > light) continue;
       if (nrowptr == rowptr && dn < 2) continue;  // u-centric: a single out-neighbour closes no triangle
-      count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w], nstart);
+      count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, nb0, ne0, s_tab[w], s_own[w], nstart, nbound);
     }
   }
   count = gdn_block_sum(count, s_red);
@@ -700,6 +712,11 @@ struct TcStartVis {
   const vid_t *__restrict__ colidx;
   const vid_t *__restrict__ in_col;    // its transpose
   unsigned *__restrict__ nstart;
+  // nullable: the walk of slot j as ONE 8-byte word, (first element << 24) | elements -- the count kernel then reads it beside
+  // the neighbour ids instead of gathering the neighbour's two row offsets (a dependent round trip per 64 neighbours less);
+  // *nbound_bad is set when a walk does not fit the packing (2^24 elements, 2^40 offsets)
+  unsigned long long *__restrict__ nbound;
+  unsigned *__restrict__ nbound_bad;
   int32_t v;
   __device__ __forceinline__ void begin_big(vid_t vv) { v = vv; }
   __device__ __forceinline__ void edge(int owner, eoff_t j, bool valid) {
@@ -707,13 +724,19 @@ struct TcStartVis {
     if (valid) {
       const vid_t u = in_col[j];
       const eoff_t b = rowptr[u];
-      unsigned lo = 0, hi = (unsigned)(rowptr[u + 1] - b);
+      const unsigned du = (unsigned)(rowptr[u + 1] - b);
+      unsigned lo = 0, hi = du;
       while (lo < hi) {  // first position with an id > row
         const unsigned mid = (lo + hi) >> 1;
         if (colidx[b + mid] <= row) lo = mid + 1;
         else hi = mid;
       }
       nstart[j] = lo;
+      if (nbound) {
+        const unsigned long long first = b + lo, len = du - lo;
+        if (len >= (1ull << 24) || first >= (1ull << 40)) *nbound_bad = 1u;
+        nbound[j] = (first << 24) | (len & 0xFFFFFFull);
+      }
     }
   }
 };
@@ -747,7 +770,8 @@ int gdn_build_csr_from_keys(DevBuf<unsigned long long> &ka, DevBuf<unsigned long
 // counts, on WHATEVER directed graph it is given, the pairs (u -> v, w in N+(u) and N+(v)).  The two agree when every edge
 // of an oriented input ascends in the (degree, id) order and no entry repeats -- checked here, one flag and one count.
 // Returns 1 (nothing built) when it does not hold: the caller then counts on the caller's orientation as it is.
-static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_out, gdn_graph **in_out, DevBuf<unsigned> &nstart) {
+static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_out, gdn_graph **in_out, DevBuf<unsigned> &nstart,
+                            DevBuf<unsigned long long> &nbound) {
   const int32_t m = g->m;
   DevBuf<int32_t> deg;
   DevBuf<vid_t> newid;
@@ -807,6 +831,15 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   int rc = dag->nnz ? gdn_graph_transpose(dag, &din) : GDN_OK;
   if (rc == GDN_OK && din) {
     rc = nstart.alloc(din->nnz);
+    // GDN_TC_NBOUND=0: without the packed walk bounds (A/B); default from 2^26 DAG edges on (8 bytes per edge; RMAT-23 / 24 -1 .. -3 %, RMAT-22 the same)
+    const char *enb = gdn_option("GDN_TC_NBOUND");
+    const bool want_nbound = enb ? enb[0] != '0' : din->nnz >= (1ull << 26);
+    DevBuf<unsigned> nb_bad;
+    if (rc == GDN_OK && want_nbound) {
+      rc = nbound.alloc(din->nnz);
+      if (rc == GDN_OK) rc = nb_bad.alloc(1);
+      if (rc == GDN_OK && hipMemset(nb_bad.p, 0, 4) != hipSuccess) rc = GDN_ERR_HIP;
+    }
     if (rc == GDN_OK && hipMemset(cnt.p, 0, 8) != hipSuccess) {
       gdn_set_error("gdn_tc: hipMemset failed");
       rc = GDN_ERR_HIP;
@@ -817,12 +850,19 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
       sv.colidx = dag->colidx;
       sv.in_col = din->colidx;
       sv.nstart = nstart.p;
+      sv.nbound = nbound.p;
+      sv.nbound_bad = nb_bad.p;
       sv.v = 0;
       hipLaunchKernelGGL(tc_start_kernel, dim3(gdn_nblocks((uint64_t)m)), dim3(GDN_BLOCK), 0, 0, din->rowptr, m, big, sv);
       hipLaunchKernelGGL(tc_start_big_kernel, dim3(1024), dim3(GDN_BLOCK), 0, 0, din->rowptr, big, sv);
       if (hipMemcpy(ovf, cnt.p, 8, hipMemcpyDeviceToHost) != hipSuccess || ovf[1]) {
         gdn_set_error("gdn_tc: start kernel failed or work list overflow");
         rc = GDN_ERR_OVERFLOW;
+      }
+      if (rc == GDN_OK && nbound.p) {
+        unsigned bad = 0;
+        if (hipMemcpy(&bad, nb_bad.p, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GDN_ERR_HIP;
+        else if (bad) nbound.release();  // a walk that does not fit the packing: the kernel gathers the row offsets as before
       }
     }
   }
@@ -1136,7 +1176,8 @@ static int tc_core_prepare(gdn_tc_plan &p);           // cursors and total zeroe
 static int tc_core_launch(gdn_tc_plan &p, bool tail);  // tail: the grid that takes what is left once tc_count_kernel is done
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
                          const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr,
-                         gdn_tc_plan *core = nullptr /* its core kernel is queued right behind tc_count_kernel's launch */) {
+                         gdn_tc_plan *core = nullptr /* its core kernel is queued right behind tc_count_kernel's launch */,
+                         const unsigned long long *nbound = nullptr) {
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
   DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
@@ -1179,7 +1220,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
-                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart);
+                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart, nbound);
   if (core) {
     GDN_TRY(tc_core_launch(*core, false));  // beside tc_count_kernel, on the core's stream
     GDN_TRY(tc_core_launch(*core, true));   // behind it, on this stream
@@ -1205,6 +1246,7 @@ struct gdn_tc_plan {
   gdn_graph *dag = nullptr;     // the DAG the count runs on (owned): rank-ordered (forward) or the reference's orientation
   gdn_graph *dag_in = nullptr;  // its transpose (forward / v-centric), owned
   DevBuf<unsigned> nstart;      // forward: walk starts, parallel to dag_in->colidx
+  DevBuf<unsigned long long> nbound;  // forward: (first element << 24 | elements) of every walk, parallel to dag_in->colidx (may be absent)
   int form = 0;                 // 0 u-centric, 1 v-centric, 2 binary search, 3 forward
   // forward: the core (tc_core_count_kernel): the top core_k ranks as a bit matrix, the rows with >= 2 core neighbours
   unsigned core_k = 0;                  // 0: no core
@@ -1225,12 +1267,15 @@ struct gdn_tc_plan {
   }
 };
 
-// GDN_TC_CORE: ranks of the core (4096, 8192, 12288 or 16384; 0 = none).  Default 16384 from 2^21 vertices on: symmetrized
+// GDN_TC_CORE: ranks of the core (4096, 8192, 12288 or 16384; 0 = none).  Default from 2^21 vertices on, 8192 / 12288 / 16384
+// ranks from 2^21 / 2^22 / 2^24 vertices (round 4: 16384 throughout, on the numbers that follow): symmetrized
 // R-MAT, count beside the hash-set kernel, K = 0 / 8192 / 12288 / 16384 -- scale 21: 7.2 / 7.2 / 6.8 / 6.5 ms, 22: 15.4 / 15.6 /
 // 13.9 / 12.3, 23: 32.0 / 25.9 / 20.9 / 21.5, 24: 84.5 / 70.3 / 58.1 / 53.4 (profiles/r04_tc_core.txt).
 static int tc_core_build(gdn_tc_plan &p) {
   const gdn_graph *dag = p.dag;
-  unsigned k = dag->m >= (1 << 21) ? 16384u : 0u;
+  // (round 5, final binary, profiles/r05_tc_core_k.txt: K = 8192 / 12288 / 16384 -- RMAT-21 5.29 / 5.77 / 5.92 ms, Orkut-like stand-in
+  // (3.97 M vertices) 11.06 / 11.10 / 11.8, RMAT-22 10.5 / 9.63 / 10.1, RMAT-23 25.2 / 20.45 / 20.9, RMAT-24 - / 52.2 / 51.8)
+  unsigned k = dag->m >= (1 << 24) ? 16384u : dag->m >= (1 << 22) ? 12288u : dag->m >= (1 << 21) ? 8192u : 0u;
   if (const char *e = gdn_option("GDN_TC_CORE")) k = (unsigned)atoi(e);
   k = k >= 16384u ? 16384u : (k / 4096u) * 4096u;  // whole lanes x 64 bits: 4096, 8192, 12288 or 16384
   if (k == 0u || (unsigned)dag->m < k + 64u) return GDN_OK;
@@ -1365,7 +1410,7 @@ int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan)
   int rc = GDN_OK;
   bool forward = form == 'f';
   if (forward) {
-    rc = tc_forward_build(g, oriented != 0, &p->dag, &p->dag_in, p->nstart);
+    rc = tc_forward_build(g, oriented != 0, &p->dag, &p->dag_in, p->nstart, p->nbound);
     p->form = 3;
     if (rc == 1) {  // an oriented input that is not the reference's orientation of a simple graph: no re-ranking
       forward = false;
@@ -1406,7 +1451,7 @@ int gdn_tc_plan_count(gdn_tc_plan *plan, uint64_t *total, gdn_stats *stats) {
       HostTimer tall;
       tall.start();
       rc = tc_count_rows(plan->dag, 0, plan->dag->m - (int32_t)plan->core_k, total, st, plan->dag_in, false, plan->nstart.p,
-                         plan->core_k ? plan : nullptr);
+                         plan->core_k ? plan : nullptr, plan->nbound.p);
       if (plan->core_k && hipStreamSynchronize(plan->core_stream) != hipSuccess && rc == GDN_OK) {
         gdn_set_error("gdn_tc: core count kernel failed: %s", hipGetErrorString(hipGetLastError()));
         rc = GDN_ERR_HIP;

@@ -1503,6 +1503,9 @@ def test_tc_forward_core_vs_oracle(orc, scale, ef, seed, core, monkeypatch):
     2^21 vertices on).  RMAT-13 with K = 8192 / 16384: the graph is smaller than the core + 64 -- no core, the plain forward count."""
     monkeypatch.setenv("GDN_TC_FORM", "f")
     monkeypatch.setenv("GDN_TC_CORE", core)
+    # (the walks' packed bounds -- first element << 24 | elements, read beside the neighbour ids instead of two gathered row
+    # offsets; default from 2^24 DAG edges on -- with two of the four core sizes)
+    monkeypatch.setenv("GDN_TC_NBOUND", "1" if core in ("8192", "16384") else "0")
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
     want = orc.tc(orc.tc_orient(g))
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
@@ -1578,7 +1581,8 @@ def test_tc_forward_core_dense_and_sparse_shapes(orc, monkeypatch):
     assert want > 150 * 149 * 148 // 6 - 1
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
     assert total == want and st["reserved"] >> 8 == 4096, (total, want)
-    for knob, value in (("GDN_TC_CORE_SMALL", "2"), ("GDN_TC_CORE_SMALL", "64"), ("GDN_TC_CORE_ASYNC", "0"), ("GDN_TC_CORE_WGS", "8"), ("GDN_TC_CORE_TAIL", "6")):
+    for knob, value in (("GDN_TC_CORE_SMALL", "2"), ("GDN_TC_CORE_SMALL", "64"), ("GDN_TC_CORE_ASYNC", "0"), ("GDN_TC_CORE_WGS", "8"), ("GDN_TC_CORE_TAIL", "6"),
+                        ("GDN_TC_NBOUND", "1")):
         monkeypatch.setenv(knob, value)  # every core list as rows / the short ones as pairs; in front of the hash-set kernel
         total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
         assert total == want and st["reserved"] >> 8 == 4096, (knob, value, total, want)
