@@ -101,6 +101,30 @@ def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed,
     assert by_head > 0
 
 
+def test_bfs_deferred_depths_beyond_the_pool_of_kept_levels(orc, monkeypatch, capfd):
+    """Deferred depths keep at most BFS_DEFER_MAX = 8 level bitmaps per search; the levels after that write their depths as
+    before.  A sparse uniform random graph (2^20 vertices, average out-degree 2.5: ~20 levels, a dozen of them with a snapshot
+    in front) with every snapshot level deferred: the pool runs out, the trace says 8 kept levels, and the depths -- from kept
+    levels, from levels that wrote directly behind them and from the light ones -- equal the oracle's."""
+    for k, v in (("GDN_BFS_HEADS_MIN_NNZ", "1"), ("GDN_BFS_HUB_MIN", "0"), ("GDN_BFS_DEFER_DEPTH", "1"), ("GDN_BFS_TD_DEFER_MIN", "1"),
+                 ("GDN_BFS_REC_COMPACT", "1"), ("GDN_BFS_TRACE", "1")):
+        monkeypatch.setenv(k, v)
+    m, src, dst = graphio.uniform_edges(1 << 20, 5 << 19, seed=77)
+    g = graphio.build_csr(m, src, dst)
+    G = solvers.Graph(csr=g, need_reverse=True)
+    bfs = solvers.ResidentBFS(G, dense=True)
+    capfd.readouterr()
+    s = graphio.first_nonisolated(g)
+    dist, st = bfs.run(s)
+    log = capfd.readouterr().err
+    import re
+    kept = [int(x) for x in re.findall(r"distances of (\d+) kept levels", log)]
+    want = orc.bfs_serial(g, s)
+    assert np.array_equal(dist, want), int((dist != want).sum())
+    assert kept == [8] and int(want[want != solvers.MYINFINITY].max()) >= 12, (kept, log[-1500:])
+    bfs.close()
+
+
 def test_bfs_star_and_chain(orc):
     # a hub with 20000 out-neighbours (big-row path) feeding a chain (many tiny levels)
     n = 20001 + 300
