@@ -179,18 +179,37 @@ struct PbPlacer {
       }
       DevBuf<T> *cand = new DevBuf<T>();
       held.push_back(cand);
-      if (cand->alloc(buf.n) != GDN_OK) {  // no memory for another candidate: that is no error
+      // GDN_PLACE_OFFSETS=1 (diagnostic, profiles/r05_pb_place_offsets.txt): every candidate is 256 MB longer than the array and is
+      // timed at several offsets inside itself as well -- does a placement's speed belong to the ALLOCATION (its pages) or to
+      // the ADDRESS (an interleaving of its bits)?
+      const bool probe_offsets = gdn_option("GDN_PLACE_OFFSETS") != nullptr;
+      const size_t slack = probe_offsets ? ((size_t)256 << 20) / sizeof(T) : 0;
+      if (cand->alloc(buf.n + slack) != GDN_OK) {  // no memory for another candidate: that is no error
         gdn_set_error("%s", "");
         break;
       }
+      cand->n = buf.n;
       // (slots no launch writes -- alignment gaps between bins -- must read as zero, as in the array the builder made)
-      if (hipMemsetAsync(cand->p, 0, buf.n * sizeof(T), 0) != hipSuccess) {
+      if (hipMemsetAsync(cand->p, 0, (buf.n + slack) * sizeof(T), 0) != hipSuccess) {
         (void)hipGetLastError();
         break;
       }
       buf.swap(*cand);
       double cur = 0;
       if ((rc = timed(&cur)) != GDN_OK) break;
+      if (probe_offsets) {
+        T *const base = buf.p;
+        const size_t offs[] = {(size_t)4 << 10, (size_t)64 << 10, (size_t)2 << 20, ((size_t)2 << 20) + ((size_t)64 << 10), (size_t)32 << 20,
+                               (size_t)128 << 20, (size_t)256 << 20};
+        for (size_t ob : offs) {
+          buf.p = base + ob / sizeof(T);
+          double t = 0;
+          if ((rc = timed(&t)) != GDN_OK) break;
+          fprintf(stderr, "[%s place] %-12s fresh %d at %p + %9zu B: %.3f ms (at + 0: %.3f)\n", tag, name, k, (void *)base, ob, t, cur);
+        }
+        buf.p = base;
+        if (rc != GDN_OK) break;
+      }
       if (trace) fprintf(stderr, "[%s place] %-12s fresh %d: %.3f ms (best %.3f) at %p (was %p)\n", tag, name, k, cur, best, (void *)buf.p, (void *)cand->p);
       if (cur > worst) worst = cur;
       if (cur < best * 0.997) best = cur;

@@ -1115,7 +1115,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     int tries = 3;
     if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
     if (tries > 0) {
-      const int rcp = pr_plan_place(p, tries, 800.0);  // (vals: ~0.2 s for 12 candidates; the copies of phase B's streams take the rest)
+      double budget = 800.0;  // ms (vals: ~0.2 s for 12 candidates; the copies of phase B's streams take the rest)
+      if (const char *e = gdn_option("GDN_PR_PLACE_BUDGET_MS")) budget = atof(e);  // (measurement sessions)
+      const int rcp = pr_plan_place(p, tries, budget);
       if (rcp != GDN_OK) {
         delete p;
         return rcp;
