@@ -215,6 +215,18 @@ struct PbPlacer {
       if (cur < best * 0.997) best = cur;
       else buf.swap(*cand);
     }
+    if (gdn_option("GDN_PLACE_OFFSETS") && rc == GDN_OK) {
+      // ... and is it a property of the allocation at all, or of the MOMENT it was timed in?  Every candidate still held is
+      // timed once more, now that the search is over (seconds after the first ones were timed)
+      for (size_t i = 0; i < held.size() && rc == GDN_OK; i++) {
+        if (!held[i]->p || held[i]->p == buf.p) continue;
+        buf.swap(*held[i]);
+        double t = 0;
+        rc = timed(&t);
+        fprintf(stderr, "[%s place] %-12s held candidate at %p timed again at the end: %.3f ms\n", tag, name, (void *)buf.p, t);
+        buf.swap(*held[i]);
+      }
+    }
     for (DevBuf<T> *h : held) delete h;
     return rc;
   }
