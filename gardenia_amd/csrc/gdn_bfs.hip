@@ -1693,7 +1693,8 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       // outer hubs where the vertex-indexed frontier bitmap is beyond an XCD's L2 (GDN_BFS_HUBS2=0: without)
       {
         const char *e2 = gdn_option("GDN_BFS_HUBS2");
-        p.n_ranked = (e2 ? e2[0] != '0' : (unsigned)m >= (1u << 26)) ? BFS_HUBS2 : BFS_HUBS;  // (=1 on a small graph: every head by rank)
+        // (default from 2^27 vertices on: RMAT-27 -1.5 %, RMAT-26 +1..2 % -- the 2^21 probes that fill the rank bitmap per level)
+        p.n_ranked = (e2 ? e2[0] != '0' : (unsigned)m >= (1u << 27)) ? BFS_HUBS2 : BFS_HUBS;  // (=1 on a small graph: every head by rank)
       }
       GDN_TRY(p.hub_id.alloc(p.n_ranked));
       if (p.n_ranked > BFS_HUBS) GDN_TRY(p.hub_front2.alloc(p.n_ranked / 32));

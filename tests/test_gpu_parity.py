@@ -71,7 +71,7 @@ def test_bfs_bottom_up_heads_vs_oracle(orc, monkeypatch, capfd, scale, ef, seed,
     edges on; forced here at sizes the serial oracle walks, with the hub test always on / gated off / at its default: depths
     and the traversed-edge count equal the oracle's from hub, leaf and late sources, and the trace shows the heads at work.
     `outer` = GDN_BFS_HUBS2: the 2^21 highest out-degrees named by RANK and tested against the rank-indexed frontier bits
-    (default from 2^26 vertices on): below 2^21 vertices every head is a rank, at scale 22 ranks and vertex ids mix."""
+    (default from 2^27 vertices on): below 2^21 vertices every head is a rank, at scale 22 ranks and vertex ids mix."""
     if outer is not None:
         monkeypatch.setenv("GDN_BFS_HUBS2", outer)
         monkeypatch.setenv("GDN_BFS_DEFER_DEPTH", outer)  # ... whose levels leave the distances to one pass at the end of the search
