@@ -402,10 +402,8 @@ bfs_hub_front_kernel(const vid_t *__restrict__ hub_id, const unsigned *__restric
   if (hub_front2 && (gdn_lane() & 31u) == 0) hub_front2[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
   if (k >= BFS_HUBS) return;  // (whole workgroups: BFS_HUBS is a multiple of the block size)
   if ((gdn_lane() & 31u) == 0) hub_front[k >> 5] = (unsigned)(mask >> (gdn_lane() & 32u));
-  // word BFS_HUBS / 32 (zeroed by the host before): how many hubs the frontier holds -- the bottom-up step reads the
-  // heads only when that is worth 4 bytes per open row
-  __shared__ unsigned long long s_cnt[GDN_WAVES_PER_BLOCK];
-  gdn_block_add_u64(in ? 1ull : 0ull, reinterpret_cast<unsigned long long *>(hub_front + BFS_HUBS / 32), s_cnt);
+  // (how many hubs the frontier holds -- the bottom-up step uses the inner hubs' bits only when that is worth it -- is counted by
+  // the workgroups of the step themselves from the 16 KB they load anyway: a counter here cost a memset per level, round 5)
 }
 
 // Bottom-up step (omp_beamer.cc:13-31): a row not yet visited is discovered if one of its in-neighbours is in the frontier.
@@ -465,11 +463,21 @@ bfs_bu_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict__ in
   __shared__ unsigned s_wsum[GDN_WAVES_PER_BLOCK];
   __shared__ unsigned s_qn;
   const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
-  const bool hubs = rec && hub_front[BFS_HUBS / 32] >= min_hubs;  // else: too few hubs in this frontier (uniform)
-  if (hubs)
-    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += GDN_BLOCK) s_hf[i] = hub_front[i];
+  unsigned n_hub_bits = 0;
+  if (rec)
+    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += GDN_BLOCK) {
+      const unsigned wv = hub_front[i];
+      s_hf[i] = wv;
+      n_hub_bits += (unsigned)__popc(wv);
+    }
+  n_hub_bits = gdn_wave_sum(n_hub_bits);
+  if (lane == 0) s_wsum[wave] = n_hub_bits;
   if (threadIdx.x == 0) s_qn = 0u;
   __syncthreads();
+  n_hub_bits = 0;
+  for (int i = 0; i < GDN_WAVES_PER_BLOCK; i++) n_hub_bits += s_wsum[i];
+  const bool hubs = rec && n_hub_bits >= min_hubs;  // else: too few hubs in this frontier (uniform)
+  __syncthreads();  // (s_wsum is used again below)
   unsigned long long awake = 0, scout = 0;
   unsigned by_head = 0, probes = 0;
   unsigned nwin = 0;  // windows waiting (block-uniform)
@@ -713,10 +721,19 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
   __shared__ unsigned s_bits[BFS_BW_WAVES][BFS_BW_GROUP * 64];
   __shared__ unsigned long long s_red[4 * BFS_BW_WAVES];
   const unsigned lane = gdn_lane(), wave = threadIdx.x >> 6;
-  const bool hubs = hub_front[BFS_HUBS / 32] >= min_hubs;  // else: too few hubs in this frontier (uniform)
-  if (hubs)
-    for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += BFS_BW_THREADS) s_hf[i] = hub_front[i];
+  unsigned n_hub_bits = 0;
+  for (unsigned i = threadIdx.x; i < BFS_HUBS / 32; i += BFS_BW_THREADS) {
+    const unsigned wv = hub_front[i];
+    s_hf[i] = wv;
+    n_hub_bits += (unsigned)__popc(wv);
+  }
+  __shared__ unsigned s_hub_n[BFS_BW_WAVES];
+  n_hub_bits = gdn_wave_sum(n_hub_bits);
+  if (lane == 0) s_hub_n[wave] = n_hub_bits;
   __syncthreads();  // the only barrier
+  n_hub_bits = 0;
+  for (unsigned i = 0; i < BFS_BW_WAVES; i++) n_hub_bits += s_hub_n[i];
+  const bool hubs = n_hub_bits >= min_hubs;  // else: too few hubs in this frontier (uniform)
   unsigned short *list = s_list[wave];
   unsigned *bits = s_bits[wave];
   const unsigned nsteps = m_pad / BFS_BW_STEP;  // (m_pad is a multiple of 2 048: nwords_pad of 64)
@@ -1588,7 +1605,6 @@ bfs_count_rows_kernel(const eoff_t *__restrict__ rowptr, int32_t m, unsigned lon
 }
 
 // the per-level read back of the counters
-static int bfs_read_counters(gdn_bfs_plan &p, BfsCounters &h) { return p.mail.read(p.cnt.p, h); }
 
 static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *gin, bool dense) {
   HostTimer t;
@@ -1876,6 +1892,20 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   const int64_t snap_min_edges = 1 << 16;
   int64_t td_defer_min = 1 << 20;  // frontier edges from which a top-down level defers its depths (a 16 MB bitmap pass against its writes)
   if (const char *e = gdn_option("GDN_BFS_TD_DEFER_MIN")) td_defer_min = atoll(e);  // (tuning knob; huge = never)
+  // The level counters are ZEROED by the kernel that reads them back (GdnMailbox::read, zero = true): a level that follows a
+  // read-back needs no memset of its own -- one dispatch per level less (11 fills per RMAT-27 search before).  cnt_reset() is
+  // what a level calls before its kernels add to the counters: a memset only when the last thing that touched them was not a read.
+  bool cnt_clean = false;
+  auto cnt_reset = [&]() -> int {
+    if (!cnt_clean) GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+    cnt_clean = false;  // (the caller's kernels write them next)
+    return GDN_OK;
+  };
+  auto cnt_read = [&](BfsCounters &hc) -> int {
+    GDN_TRY(p.mail.read(p.cnt.p, hc, 0, true));
+    cnt_clean = true;
+    return GDN_OK;
+  };
   const bool trace = gdn_option("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
   const bool b2q_read = gdn_option("GDN_BFS_B2Q_READ") != nullptr;  // (A/B knob: read the length of a listed frontier back as before)
   HostTimer tl;
@@ -1911,7 +1941,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       unsigned nfq = nf;
       do {
         ++iter;
-        GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+        GDN_TRY(cnt_reset());
         // engine of this heavy level: the sweep over all in-edges, or -- once few rows are left to discover --
         // the bottom-up step over the unvisited rows (omp_beamer.cc:13-31)
         // the bottom-up step also wins while MANY rows are left when the frontier owns a large share p of all edges: an
@@ -1947,11 +1977,11 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
             if (awake > 0 && (uint64_t)awake <= (uint64_t)p.qcap && !b2q_read) {
               nfq = (unsigned)awake;
             } else {
-              GDN_TRY(bfs_read_counters(p, h));
+              GDN_TRY(cnt_read(h));
               nfq = h.next_count;
             }
             have_queue = true;
-            GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+            GDN_TRY(cnt_reset());
           }
           ExpBigList bbig;
           bbig.items = p.bigitems.p;
@@ -1977,7 +2007,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
           if (flag) {  // a bin's list was too short for this frontier: nothing was applied; the sweep takes the level,
             // and this search stays away from the binned engine
             GDN_HIP(hipMemsetAsync(p.btd_flag.p, 0, sizeof(unsigned), 0));
-            GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+            GDN_TRY(cnt_reset());
             btd = false;
             btd_on = false;
           } else {
@@ -1987,7 +2017,6 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         if (btd) {
         } else if (bottom_up) {
           if (p.head.p) {
-            GDN_HIP(hipMemsetAsync(p.hub_front.p + BFS_HUBS / 32, 0, 2 * sizeof(unsigned), 0));
             hipLaunchKernelGGL(bfs_hub_front_kernel, dim3(p.n_ranked / GDN_BLOCK), dim3(GDN_BLOCK), 0, 0, p.hub_id.p, fr, p.hub_front.p,
                                p.hub_front2.p);
           }
@@ -2016,7 +2045,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
                              p.pb.bin_ptr.p, p.pb.bin_order.p, p.pb.V.p, p.ebits.p, p.visited.p, nx, d_out, level + 1,
                              g->rowptr, p.cnt.p);
         }
-        GDN_TRY(bfs_read_counters(p, h));
+        GDN_TRY(cnt_read(h));
         if (h.overflow) {
           gdn_set_error("gdn_bfs: device worklist overflow");
           return GDN_ERR_OVERFLOW;
@@ -2031,7 +2060,11 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         if (trace && bottom_up && !btd)
         {
           unsigned nh = 0;
-          if (p.head.p) (void)hipMemcpy(&nh, p.hub_front.p + BFS_HUBS / 32, sizeof(nh), hipMemcpyDeviceToHost);
+          if (p.head.p) {
+            std::vector<unsigned> hw(BFS_HUBS / 32);
+            (void)hipMemcpy(hw.data(), p.hub_front.p, hw.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+            for (unsigned x : hw) nh += (unsigned)__builtin_popcount(x);
+          }
           fprintf(stderr, "[bfs]   bottom-up: %u hubs in the frontier, %llu rows by their hub head, %llu in-neighbours probed for the others\n",
                   nh, h.bu_by_head, h.bu_probes);
         }
@@ -2046,7 +2079,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         nf = 0;
         break;
       }
-      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+      GDN_TRY(cnt_reset());
       hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
       // the frontier is what the last level discovered: its size is known, the read-back of the list's length (a round trip of
@@ -2054,7 +2087,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       if ((uint64_t)awake <= (uint64_t)p.qcap && !b2q_read) {
         nf = (unsigned)awake;
       } else {
-        GDN_TRY(bfs_read_counters(p, h));
+        GDN_TRY(cnt_read(h));
         nf = h.next_count;
       }
       lap("bitmap2q", nf, 0);
@@ -2069,20 +2102,20 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       do {
         ++iter;
         old_awake = awake;
-        GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+        GDN_TRY(cnt_reset());
         hipLaunchKernelGGL(bfs_bu_kernel, dim3(BFS_BU_GRID), dim3(GDN_BLOCK), 0, 0, gin->rowptr, gin->colidx, g->rowptr, m,
                            p.nwords_pad * 32u, fr, nx, p.visited.p, d_dist, level + 1, p.cnt.p, p.noin.p);
-        GDN_TRY(bfs_read_counters(p, h));
+        GDN_TRY(cnt_read(h));
         awake = (int64_t)h.awake;
         unsigned *t = fr;
         fr = nx;
         nx = t;
         level++;
       } while (awake >= old_awake || awake > m / beta);
-      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+      GDN_TRY(cnt_reset());
       hipLaunchKernelGGL(bfs_bitmap_to_queue, dim3(gdn_nblocks(p.nwords, GDN_BLOCK * BFS_B2Q_WORDS)), dim3(GDN_BLOCK), 0, 0, fr, p.nwords, qin,
                          p.cnt.p, p.qcap);
-      GDN_TRY(bfs_read_counters(p, h));
+      GDN_TRY(cnt_read(h));
       nf = h.next_count;
       scout_count = 1;
     } else {
@@ -2150,7 +2183,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       // ---- top-down step (omp_beamer.cc:143-146)
       ++iter;
       edges_to_check -= scout_count;
-      GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BfsCounters), 0));
+      GDN_TRY(cnt_reset());
       BfsTdVis vis;
       vis.rowptr = g->rowptr;
       vis.rec = p.head.p;  // nullptr without heads
@@ -2189,7 +2222,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         maps.level[maps.n] = level + 1;
         maps.n++;
       }
-      GDN_TRY(bfs_read_counters(p, h));
+      GDN_TRY(cnt_read(h));
       nf = h.next_count;
       scout_count = (int64_t)h.scout;
       visited_total += (int64_t)nf;

@@ -263,8 +263,13 @@ struct DevBuf {
 // kernels, copies the struct into pinned host memory and then publishes a sequence number with system scope; the host spins
 // on the number.  GDN_MAILBOX=0 (or no pinned memory) falls back to the copy; a spin of more than two seconds falls back to
 // the synchronisation too, which then reports what went wrong.
-static __global__ void gdn_mailbox_kernel(const unsigned *__restrict__ src, unsigned nwords, unsigned *dst, unsigned seq) {
-  for (unsigned i = threadIdx.x; i < nwords; i += 64) __hip_atomic_store(dst + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// zero != 0: the struct is zeroed behind the copy -- counters that the next level adds to again need no memset of their own (a
+// dispatch per level less)
+static __global__ void gdn_mailbox_kernel(unsigned *__restrict__ src, unsigned nwords, unsigned *dst, unsigned seq, int zero) {
+  for (unsigned i = threadIdx.x; i < nwords; i += 64) {
+    __hip_atomic_store(dst + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (zero) src[i] = 0u;
+  }
   __threadfence_system();
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(dst, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -298,22 +303,24 @@ struct GdnMailbox {
     host[0] = 0;
   }
   template <typename T>
-  int read(const T *d_src, T &out, hipStream_t s = 0) {
+  int read(T *d_src, T &out, hipStream_t s = 0, bool zero = false) {
     static_assert(sizeof(T) <= kPayload && sizeof(T) % 4 == 0, "mailbox payload");
     if (!host) {
       GDN_HIP(hipMemcpy(&out, d_src, sizeof(T), hipMemcpyDeviceToHost));
+      if (zero) GDN_HIP(hipMemsetAsync(d_src, 0, sizeof(T), s));
       return GDN_OK;
     }
     if (!spin) {
       GDN_HIP(hipMemcpyAsync(host + 1, d_src, sizeof(T), hipMemcpyDeviceToHost, s));
       GDN_HIP(hipStreamSynchronize(s));
       memcpy(&out, host + 1, sizeof(T));
+      if (zero) GDN_HIP(hipMemsetAsync(d_src, 0, sizeof(T), s));
       return GDN_OK;
     }
     ++seq;
     if (seq == 0) ++seq;
-    hipLaunchKernelGGL(gdn_mailbox_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<const unsigned *>(d_src),
-                       (unsigned)(sizeof(T) / 4), dev, seq);
+    hipLaunchKernelGGL(gdn_mailbox_kernel, dim3(1), dim3(64), 0, s, reinterpret_cast<unsigned *>(d_src),
+                       (unsigned)(sizeof(T) / 4), dev, seq, zero ? 1 : 0);
     GDN_HIP(hipGetLastError());
     const volatile unsigned *flag = host;
     unsigned long long spins = 0;

@@ -1806,7 +1806,7 @@ static void sssp_put(T *d_dst, const T &v) {
 
 template <typename T>
 static int sssp_read(gdn_sssp_plan &p, const T *d_src, T &out) {
-  return p.mail.read(d_src, out);  // (GdnMailbox, gdn_common.hpp: no stream synchronisation per phase)
+  return p.mail.read(const_cast<T *>(d_src), out);  // (GdnMailbox, gdn_common.hpp: no stream synchronisation per phase)
 }
 
 template <typename CT>
