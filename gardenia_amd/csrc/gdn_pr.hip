@@ -1630,6 +1630,8 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
     GDN_TRY(gdn_pr_plan_kernel_time(p, 0, 0, tot, &launches));
     if (launches < 1) launches = 1;
     *out_ms = (phase == 0 ? tot[0] : phase == 1 ? tot[1] : tot[0] + tot[1]) / launches;
+    if (pl.trace && gdn_option("GDN_PR_PLACE_TRACE_AB"))  // (both phases of every timed placement, whatever it is judged on)
+      fprintf(stderr, "[pr place]   phase A %.3f ms, phase B %.3f ms\n", tot[0] / launches, tot[1] / launches);
     return GDN_OK;
   };
   p->placing = true;
