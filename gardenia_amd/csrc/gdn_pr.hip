@@ -1640,10 +1640,12 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
   if (const char *e = gdn_option("GDN_PR_PLACE_VALS")) vals_tries = atoi(e);
   phase = 0;
   if (rc == GDN_OK) rc = pl.rebase();
-  // (fast blocks run phase A at 1.00-1.01 ms, the others at 1.06-1.18: the search stops at the first candidate 7 % below the
+  // (fast blocks run phase A at 1.00-1.01 ms, the others at 1.06-1.18: the search stops at the first candidate 10 % below the
   // slowest placement seen -- on average after six, each a 3.5 GB hipMalloc that waits for the driver to wipe pages whenever
   // another process has just freed that much: 2.0 s for twelve in session r05_06, 0.2 s on an idle box)
-  double stop_ratio = 0.93;  // GDN_PR_PLACE_STOP=0: every candidate is timed (measurement sessions)
+  // (0.90, not 0.93: the classes are ~1.14 / 1.06 / 0.99 ms -- the middle one is 7 % below the slowest, only the fast one
+  // should end the search early, profiles/r05_pb_place_offsets.txt)
+  double stop_ratio = 0.90;  // GDN_PR_PLACE_STOP=0: every candidate is timed (measurement sessions)
   if (const char *e = gdn_option("GDN_PR_PLACE_STOP")) stop_ratio = atof(e);
   if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8, stop_ratio);
   // The arrays phase B streams (and U) are searched only on request (GDN_PR_PLACE_COPIES=1; every candidate is a copy, ~40 ms
