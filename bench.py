@@ -140,6 +140,10 @@ def main():
                     help="TEST ONLY: the LJ-like / Orkut-like stand-ins at 2^-k of their size (scale - k, draws >> k)")
     ap.add_argument("--reps", type=int, default=12, help="repetitions behind every median / min")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the baseline sample")
+    ap.add_argument("--no-refsum", action="store_true",
+                    help="skip pr_reference_sum: the same iteration under GDN_PR_SUM=reference (the rows of >= 10^4 in-edges re-summed "
+                         "in the reference's fp32 order), a second plan on the same graph, outside the timed region")
+    ap.add_argument("--refsum-min-degree", type=int, default=10000)
     ap.add_argument("--no-converged-parity", action="store_true",
                     help="skip parity_note.converged: the timed plan solved to epsilon 1e-4 against the CPU oracle's full solve "
                          "(about a minute of host time at RMAT-27 on 128 cores)")
@@ -217,8 +221,11 @@ def main():
             dist.all_reduce(out_degree)
             dist.all_reduce(in_degree)
         nnz = int(in_degree.sum(dtype=torch.int64).item())
-        if args.no_bfs is False or args.no_cpu is False or args.no_extras is False:
-            args.no_bfs = args.no_cpu = args.no_extras = True  # (blocks of the N = 1 line: they need the whole graph)
+        args.no_bfs = args.no_extras = True  # (blocks of the N = 1 line: they need the whole graph)
+        if "--ranges" in sys.argv and args.ranges == "balanced" and rank == 0:
+            log("[bench] warning: --ranges balanced has no effect with per-rank generation (--gen range): every rank owns an equal "
+                "vertex range of the permuted ids; the line reports the edge imbalance (config.edge_imbalance). --gen whole cuts "
+                "ranges of equal edge counts.")
     else:
         g_out, g_in = C.c_void_p(), C.c_void_p()
         _cabi.check(L.gdn_rmat_build(args.scale, args.edge_factor, graphio.K_RAND_SEED, 1, C.byref(g_out), C.byref(g_in)))
@@ -242,6 +249,8 @@ def main():
     # (GDN_LAYOUT_PB_SQUISHED)
     m_part, g_part, deg_part, sq = m, g_in, out_degree, None
     dead_diff = 0.0
+    deg_state_host = None  # rank 0 of an N > 1 job with a CPU leg: the out-degrees in the order of the sharded vertex space
+    want_cpu_multi = multi and rank == 0 and not args.no_cpu
     if gen_range:
         rb, sb = (C.c_int32 * (world + 1))(*raw_bounds), (C.c_int32 * (world + 1))()
         _cabi.check(L.gdn_pr_squish_range(range_rows, v_lo, C.c_void_p(in_degree.data_ptr()), C.c_void_p(out_degree.data_ptr()), m,
@@ -250,6 +259,8 @@ def main():
         m_part = bl[world]
         live = (in_degree[v_lo:v_hi] > 0) | (out_degree[v_lo:v_hi] > 0)
         deg_local = out_degree[v_lo:v_hi][live].contiguous()
+        if want_cpu_multi:
+            deg_state_host = out_degree[(in_degree > 0) | (out_degree > 0)].cpu().numpy()
         del in_degree, live
         base, start = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(m)), np.float32(1.0) / np.float32(m)
         dead_diff = float(m - m_part) * float(abs(np.float32(base - start)))
@@ -287,6 +298,8 @@ def main():
         b_lo, b_hi = bl[rank], bl[rank + 1]
         m_space, lo, hi = chunk * world, rank * chunk, rank * chunk + (b_hi - b_lo)
         deg_local = deg_part[b_lo:b_hi].contiguous()
+        if want_cpu_multi:
+            deg_state_host = deg_part.cpu().numpy()
     else:
         shard, chunk, m_space, lo, hi, deg_local = g_part, m_part, m_part, 0, m_part, deg_part
     sm, snnz = C.c_int32(), C.c_uint64()
@@ -332,7 +345,9 @@ def main():
     if multi:
         nb = torch.tensor([be.n_bins()], dtype=torch.int64, device=device)
         dist.all_reduce(nb, op=dist.ReduceOp.MIN)
-        parts = max(1, min(4, int(nb.item()) // 200)) if int(nb.item()) > 0 else 4
+        # (with tickets -- gdn_pr_pull_parts_dev -- the parts are ranges of ONE launch and cost no tail; they only set how
+        # early the exchange of a part can start: four of them wherever a part still holds a few dozen bins)
+        parts = max(1, min(4, int(nb.item()) // 32)) if int(nb.item()) > 0 else 4
     pr = ShardedPageRank(be, m_space, rank, world, dist if multi else None, exchange=exchange, parts=parts,
                          first_diff_extra=dead_diff, force_collectives=args.force_dist)
     pr.init_contrib()
@@ -425,6 +440,60 @@ def main():
         "step_ms": med_min(rep_ms),
         "gteps_pr": value / 1e9, "pr_last_l1_change": last_err, "graph_build_s": t_build,
     }
+    if multi:
+        # how many ranks the collective backend itself reports (the world the all-gathers ran over), and which backend
+        out["rccl_ranks"] = int(dist.get_world_size())
+        out["collective_backend"] = str(dist.get_backend()) + (" (= RCCL on ROCm)" if str(dist.get_backend()) == "nccl" else
+                                                               " (--share-device test mode: not RCCL)")
+        out["config"]["parts"] = pr.parts
+        out["config"]["bins_per_rank_min"] = int(nb.item())
+        if part_nnz:
+            out["config"]["edges_per_rank"] = part_nnz
+            out["config"]["edge_imbalance"] = max(part_nnz) * len(part_nnz) / max(sum(part_nnz), 1) - 1.0
+
+    # ---- the price of the contract-exact iteration: the same plan built under GDN_PR_SUM=reference with the
+    # rows of >= 10^4 in-edges re-summed in the order of src/pr/omp_base.cc:27-30 behind every pull (those rows then carry the
+    # reference's bits, and no row of RMAT-27 lies beyond north_star's 1e-4: tests/test_gpu_configs.py); outside the timed region
+    if rank == 0 and world == 1 and not multi and not args.no_refsum and be.layout == 1:
+        try:
+            _cabi.check(L.gdn_option_set(b"GDN_PR_SUM", b"reference"))
+            _cabi.check(L.gdn_option_set(b"GDN_PR_SUM_MIN_DEGREE", str(args.refsum_min_degree).encode()))
+            t0 = time.time()
+            be2 = HipPageRankBackend(torch, shard, deg_local, m_space, lo, hi, chunk, world, device,
+                                     layout={"auto": -1, "csr": 0, "pb": 1}[args.layout])
+            torch.cuda.synchronize()
+            t_plan2 = time.time() - t0
+            pr2 = ShardedPageRank(be2, m_space, 0, 1, None, parts=1)
+            pr2.init_contrib()
+            for _ in range(args.warmup):
+                pr2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pr2.step()
+            torch.cuda.synchronize()
+            ms2 = (time.perf_counter() - t1) * 1e3 / args.steps
+            rows_, longest_, entries_, groups_ = C.c_int32(0), C.c_int32(0), C.c_uint64(0), C.c_int32(0)
+            _cabi.check(L.gdn_pr_plan_refsum_info(be2.plan, C.byref(rows_), C.byref(longest_), C.byref(entries_), C.byref(groups_)))
+            be2.check()
+            out["pr_reference_sum"] = {
+                "ms_per_step": ms2, "frac": iter_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "default_ms_per_step": ms_per_step,
+                "min_in_degree": args.refsum_min_degree, "rows_resummed": rows_.value, "longest_row": longest_.value,
+                "entries_resummed": entries_.value, "launches_per_iteration_for_the_resum": groups_.value + 3,
+                "plan_build_s": t_plan2, "pr_last_l1_change": pr2.global_diff(),
+                "what": "the timed iteration with GDN_PR_SUM=reference GDN_PR_SUM_MIN_DEGREE=%d: behind the two kernels of the pull the "
+                        "rows of that many in-edges are summed again in the reference's order -- fp32, one addition per in-edge, CSR "
+                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^20 "
+                        "sources so that the gathered contributions stay in L2; scores / next contributions / L1 change of those rows "
+                        "are rewritten.  frac = SURVEY 8d's bytes of the plain iteration over this time." % args.refsum_min_degree}
+            log(f"[bench] pr_reference_sum: {out['pr_reference_sum']}")
+            be2.close()
+            del pr2, be2
+        except Exception as e:
+            log(f"[bench] pr_reference_sum skipped: {e}")
+        finally:
+            L.gdn_option_set(b"GDN_PR_SUM", None)
+            L.gdn_option_set(b"GDN_PR_SUM_MIN_DEGREE", None)
 
     # ---- BFS GTEPS on the same graph (single GPU: the N = 1 run carries it; BFS stays single-GPU per north_star, and the
     # other ranks of an N > 1 job would only wait in the final barrier for it), outside the timed region
@@ -455,7 +524,7 @@ def main():
             # what of that time is the per-search initialisation (the 4 m-byte fill of the distances, the bitmap clear, the seed):
             # every BFSSolver of the reference does it in FRONT of its Timer (src/bfs/main.cc:21, linear_base.cu:50-63,
             # omp_beamer.cc:119-134); here it is inside solve_ms.  Two events around it in a few extra searches (GDN_BFS_TIME_INIT)
-            init_ms = []
+            init_ms, finish_ms = [], []
             try:
                 _cabi.check(L.gdn_option_set(b"GDN_BFS_TIME_INIT", b"1"))
                 for s in nz[:3]:
@@ -463,6 +532,7 @@ def main():
                         st = _cabi.GdnStats()
                         _cabi.check(L.gdn_bfs_run(bplan, int(s), C.c_void_p(dist_buf.data_ptr()), C.byref(st)))
                         init_ms.append(st.prep_ms)
+                        finish_ms.append(st.last_error)
             finally:
                 L.gdn_option_set(b"GDN_BFS_TIME_INIT", None)
             L.gdn_bfs_plan_free(bplan)
@@ -473,13 +543,23 @@ def main():
                 by = sorted(runs, key=lambda r: r["gteps"])
                 med = by[(len(by) - 1) // 2]
                 init_med = sorted(init_ms)[len(init_ms) // 2] if init_ms else None
+                finish_med = sorted(finish_ms)[len(finish_ms) // 2] if finish_ms else None
+                # what the reference's Timer does not see: the initialisation in front of the search (init_med) and, of the
+                # closing pass, only the "unreached" fill it absorbed -- modelled as 4 m bytes at the 6.3 TB/s a plain stream
+                # reaches (MI355X_MICROARCH.md), never more than the pass took.  The depths of the kept heavy levels, which the
+                # pass also writes, stay inside: the reference writes them inside its Timer
+                fill_model = min(4.0 * m / 6.3e12 * 1e3, finish_med) if finish_med else 0.0
+                off_timer = (init_med + fill_model) if init_med is not None else None
                 out["bfs"] = dict(med, plan_build_s=t_bplan, ms_stats=med_min([r["ms"] for r in runs]), runs=len(runs),
-                                  init_ms_inside_solve=init_med,
-                                  gteps_on_the_reference_timer=(med["edges_traversed"] / ((med["ms"] - init_med) * 1e-3) / 1e9
-                                                                if init_med is not None and med["ms"] > init_med else None),
-                                  timer_note="ms / gteps include the per-search initialisation (distances filled, bitmaps cleared), "
-                                             "which the reference's BFSSolver does in front of its Timer; gteps_on_the_reference_timer "
-                                             "leaves init_ms_inside_solve (two HIP events, extra searches) out",
+                                  init_ms_inside_solve=init_med, depth_finish_pass_ms=finish_med, unreached_fill_modelled_ms=fill_model,
+                                  gteps_on_the_reference_timer=(med["edges_traversed"] / ((med["ms"] - off_timer) * 1e-3) / 1e9
+                                                                if off_timer is not None and med["ms"] > off_timer else None),
+                                  timer_note="ms / gteps include the per-search initialisation (bitmaps cleared, seed) and the closing pass "
+                                             "that writes the distances of the kept heavy levels AND the 'unreached' value (it replaces the "
+                                             "4 m-byte fill the reference's BFSSolver does in front of its Timer); "
+                                             "gteps_on_the_reference_timer leaves out init_ms_inside_solve and unreached_fill_modelled_ms "
+                                             "(4 m bytes at 6.3 TB/s, capped by the pass) only -- the rest of depth_finish_pass_ms writes "
+                                             "real depths and stays inside, as in the reference",
                                   gteps_median=med["gteps"], gteps_best=best["gteps"],
                                   roofline={"bound": "hbm", "achieved": med["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "speed_vs_model": med["gbs"] / HBM_PEAK_GBS, "speed_vs_model_best_run": best["gbs"] / HBM_PEAK_GBS,
@@ -608,6 +688,56 @@ def main():
             except Exception as e:
                 log(f"[bench] parity note skipped: {e}")
             del h_rp, h_ci, gi, scores
+        except Exception as e:
+            log(f"[bench] cpu baseline skipped: {e}")
+            out["cpu_baseline"] = None
+
+    # ---- CPU baseline of an N > 1 job (north_star: "the host-OpenMP baseline ... in the same run"): rank 0, its share of the
+    # host cores (OMP_NUM_THREADS above), the oracle's pull iteration on a bounded row sample of ITS shard -- the shard's rows
+    # in the padded vertex space, the contrib pass over all of that space, like the N = 1 leg
+    if want_cpu_multi and deg_state_host is not None:
+        try:
+            from oracle import binding as orc
+            t1 = time.time()
+            sm_, snnz_ = sm.value, snnz.value
+            h_rp = np.empty(sm_ + 1, np.uint64)
+            h_ci = np.empty(max(snnz_, 1), np.int32)
+            _cabi.check(L.gdn_graph_download(shard, h_rp.ctypes.data_as(C.c_void_p), h_ci.ctypes.data_as(C.c_void_p)))
+            rp_full = np.empty(m_space + 1, np.uint64)
+            rp_full[:lo] = 0
+            rp_full[lo:lo + sm_ + 1] = h_rp
+            rp_full[lo + sm_ + 1:] = h_rp[-1]
+            deg_pad = np.ones(m_space, np.int32)  # (pad slots: no edge names them)
+            for r in range(world):
+                deg_pad[r * chunk:r * chunk + (bl[r + 1] - bl[r])] = deg_state_host[bl[r]:bl[r + 1]]
+            gi = graphio.CSR(m_space, rp_full, h_ci[:snnz_])
+            scores = np.full(m_space, np.float32(1.0) / np.float32(m), np.float32)
+            # (torch.distributed.run exports OMP_NUM_THREADS=1 to its ranks unless the caller set it: rank 0 takes its share of
+            # the host's physical cores for this leg; GDN_BENCH_CPU_THREADS overrides)
+            orc.set_num_threads(int(os.environ.get("GDN_BENCH_CPU_THREADS", max(1, n_phys // max(n_ranks_here, 1)))))
+            cores = orc.num_threads()
+            probe_hi = lo + max(1, sm_ // 64)
+            tp = time.time()
+            orc.pr_iterate(gi, deg_pad, scores, 1, row_lo=lo, row_hi=probe_hi)
+            tp = time.time() - tp
+            frac = min(1.0, max(1.0 / 64, (args.cpu_seconds / max(tp, 1e-3)) / 64))
+            row_hi = lo + max(1, int(sm_ * frac))
+            scores[:] = np.float32(1.0) / np.float32(m)
+            tc = time.time()
+            orc.pr_iterate(gi, deg_pad, scores, 1, row_lo=lo, row_hi=row_hi)
+            tc = time.time() - tc
+            e_sample = int(h_rp[row_hi - lo])
+            out["cpu_baseline"] = {"value": e_sample / tc, "unit": "edges/s", "cores": cores, "kind": "port",
+                                   "physical_cores": n_phys, "logical_cpus": os.cpu_count(), "ranks_on_this_host": n_ranks_here,
+                                   "omp_num_threads_env": os.environ.get("OMP_NUM_THREADS"),
+                                   "sample": "rank 0 of %d, its share of the host's cores: 1 pull iteration over the first %d rows of ITS "
+                                             "shard of the same RMAT-%d graph (%d edges, %.1f%% of the shard, %.2f%% of the graph) incl. the "
+                                             "contrib pass over the whole padded vertex space, OpenMP restatement of "
+                                             "src/pr/omp_base.cc:23-34" % (world, row_hi - lo, args.scale, e_sample,
+                                                                            100.0 * e_sample / max(snnz_, 1), 100.0 * e_sample / max(nnz, 1)),
+                                   "seconds": tc}
+            log(f"[bench] cpu baseline (rank 0 of {world}): {out['cpu_baseline']} (download+prep {time.time() - t1 - tc:.1f} s)")
+            del h_rp, h_ci, rp_full, deg_pad, gi, scores
         except Exception as e:
             log(f"[bench] cpu baseline skipped: {e}")
             out["cpu_baseline"] = None

@@ -119,6 +119,9 @@ PROTOTYPES = {
     "gdn_pr_contrib_dev": (C.c_int, [_vp, _vp, _vp, _vp]),
     "gdn_pr_pull_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _vp]),
     "gdn_pr_pull_rows_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp]),
+    "gdn_pr_plan_refsum_info": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "gdn_pr_pull_parts_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _vp, _vp]),
+    "gdn_pr_wait_part_dev": (C.c_int, [_vp, _i32, _vp]),
     "gdn_pr_plan_kernel_time": (C.c_int, [_vp, _i32, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "gdn_pr_iter_bytes": (_u64, [_vp]),
     "gdn_spmv_plan_create": (C.c_int, [_vp, _vp, _i32, _pp]),

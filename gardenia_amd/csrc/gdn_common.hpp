@@ -125,6 +125,25 @@ struct DevBuf {
     p = reinterpret_cast<T *>(static_cast<char *>(base) + off);
     return GDN_OK;
   }
+  // an allocation the caller can do without (a placement candidate): no trim of the scratch cache, no error text, the HIP
+  // last-error cleared on failure, and refused while it would take more than half of the device's free memory
+  bool alloc_optional(size_t count) {
+    release();
+    if (count == 0) count = 1;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || count * sizeof(T) > free_b / 2) {
+      (void)hipGetLastError();
+      return false;
+    }
+    if (hipMalloc(&base, count * sizeof(T)) != hipSuccess) {
+      (void)hipGetLastError();
+      base = nullptr;
+      return false;
+    }
+    n = count;
+    p = static_cast<T *>(base);
+    return true;
+  }
   // the same contents in a FRESH allocation (made while the old one is still held, so it is other memory); `keep` gets the
   // old allocation instead of hipFree when the caller may want to go back (gdn_pr_plan_place: where hipMalloc puts a
   // streamed array moves a PageRank iteration by up to 8 %)

@@ -56,6 +56,22 @@
 #define PB_IL_QUADS 2        // phase B, interleaved record streams: 16-byte record loads (= 4 table reads each) in flight per lane
 #endif
 
+// TICKETS (gdn_pr_pull_parts_dev): an accumulate launch whose bins run part by part (launch index < end[j] = part j; the
+// order array lists the bins of part 0 first, largest first inside a part).  A workgroup that has finished its bin makes
+// its rows visible device-wide and adds 1 to ticket[32 * j]; a one-wave kernel on ANOTHER stream waits for a part's
+// count (pb_ticket_wait_kernel) -- the exchange of part j starts while parts j+1.. are still being accumulated, without
+// cutting the iteration into launches whose tails leave the chip idle (4 launches: phase B 2.53 -> 3.13 ms on RMAT-27,
+// profiles/r06_dist_one_rank.md).
+#define PB_MAX_PARTS 8
+#define PB_TICKET_STRIDE 32  // words: every counter on a 128-byte line of its own
+struct PbParts {
+  unsigned n = 0;
+  unsigned end[PB_MAX_PARTS] = {};
+  // how a workgroup's rows reach the other XCDs before its ticket: 0 = plain stores + one agent-scope release (an L2
+  // write-back) per workgroup, 1 = the op stored them write-through (sc1; PrOp::wt) and only the waves' stores are awaited
+  unsigned mode = 0;
+};
+
 struct PbPlan {
   bool v_il = false;     // V stored in lane-interleaved blocks of 512 edges (pb_v_interleave_kernel; every bin starts on a multiple of 512)
   int32_t m_local = 0;   // destination rows
@@ -184,10 +200,15 @@ struct PbPlacer {
       // the ADDRESS (an interleaving of its bits)?
       const bool probe_offsets = gdn_option("GDN_PLACE_OFFSETS") != nullptr;
       const size_t slack = probe_offsets ? ((size_t)256 << 20) / sizeof(T) : 0;
-      if (cand->alloc(buf.n + slack) != GDN_OK) {  // no memory for another candidate: that is no error
-        gdn_set_error("%s", "");
-        break;
+      // (optional: never at the price of the scratch cache or of more than half of the free memory; when memory is
+      // short the oldest held candidates go first, and a search that still finds none ends without an error)
+      bool got = cand->alloc_optional(buf.n + slack);
+      while (!got && held.size() > 1) {
+        delete held.front();
+        held.erase(held.begin());
+        got = cand->alloc_optional(buf.n + slack);
       }
+      if (!got) break;
       cand->n = buf.n;
       // (slots no launch writes -- alignment gaps between bins -- must read as zero, as in the array the builder made)
       if (hipMemsetAsync(cand->p, 0, (buf.n + slack) * sizeof(T), 0) != hipSuccess) {
@@ -1077,7 +1098,9 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
                      const unsigned *__restrict__ hrb_ptr = nullptr, const uint16_t *__restrict__ hrb_vl = nullptr,
                      const unsigned long long *__restrict__ hr_total = nullptr,
                      // mid tiers: per bin one stream of (source index, row) records per tier, values from the tier's table
-                     PbMidArgs mid = PbMidArgs()) {
+                     PbMidArgs mid = PbMidArgs(),
+                     // tickets (nullable; PbParts above): parts by launch index
+                     unsigned *__restrict__ ticket = nullptr, PbParts parts = PbParts()) {
   if (gdn_skip_launch(op)) return;
   extern __shared__ __attribute__((aligned(16))) unsigned long long s_acc[];
   __shared__ double s_red[PB_WAVES];
@@ -1460,11 +1483,42 @@ pb_accumulate_kernel(int32_t m_local, int log_bin, const eoff_t *__restrict__ bi
   if (bad) *errflag = 1u;
   dsum = gdn_wave_sum(dsum);
   if (lane == 0) s_red[w] = dsum;
+  // (tickets: every wave's row stores have left the wave before the barrier -- MI355X_MICROARCH.md, producer form)
+  if (ticket) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     double t = 0.0;
     for (int i = 0; i < PB_WAVES; i++) t += s_red[i];
     partial[b] = t;
+    if (ticket) {
+      // the workgroup's rows (plain stores, dirty in this XCD's L2) written back, THEN the count: the waiter's successor
+      // is a kernel launch of its own (acquire at its start)
+      if (parts.mode == 0u) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      unsigned j = 0;
+      while (j + 1u < parts.n && blockIdx.x >= parts.end[j]) j++;
+      __hip_atomic_fetch_add(ticket + PB_TICKET_STRIDE * j, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
+}
+
+// the waiter of a part's tickets: one lane polls (L2-served loads, asleep in between) until the counter has reached
+// `target` (wrap-safe), for at most ~4 s of device time -- then it raises *timeout instead of hanging the queue behind it
+static __global__ void pb_ticket_wait_kernel(const unsigned *ticket, unsigned target, unsigned *timeout) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  while ((int)(__hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+    __builtin_amdgcn_s_sleep(32);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+      __hip_atomic_store(timeout, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      break;
+    }
+  }
+}
+// the tickets of an iteration that ran as ONE kernel without them (merge-path layout): add[j] to counter j, behind it
+static __global__ void pb_ticket_add_kernel(unsigned *ticket, PbParts add) {
+  if (threadIdx.x < add.n) __hip_atomic_fetch_add(ticket + PB_TICKET_STRIDE * threadIdx.x, add.end[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif  // __HIPCC__

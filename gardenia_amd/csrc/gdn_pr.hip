@@ -18,6 +18,10 @@
 #include <math.h>
 
 #include "gdn_pb.hpp"
+#include "gdn_seqsum.hpp"
+
+int gdn_radix_sort_u64(unsigned long long *a, unsigned long long *b, unsigned long long n, unsigned begin_bit, unsigned end_bit,
+                       const unsigned long long **sorted);  // gdn_sort.hip
 
 struct gdn_pr_plan {
   bool placing = false;  // the placement search is running: its sweeps are launched under tagged kernel names
@@ -77,10 +81,21 @@ struct gdn_pr_plan {
   // then has the reference's bits, whatever layout the plan streams (pr_refsum_kernel).
   bool ref_sum = false;
   uint32_t ref_min_deg = 0;
-  const gdn_graph *ref_csr = nullptr;  // the caller's in-CSR: must outlive the plan in this mode
-  DevBuf<eoff_t> ref_cmap;             // squished plan: caller's vertex id -> state index
-  DevBuf<float> ref_old;               // the scores in front of the pull (the L1 change is recomputed against them)
-  DevBuf<double> ref_partial;          // per-workgroup L1 partial sums
+  // (the selected rows, longest first; their column ids in the plan's vertex space; per-row running sum and cursor)
+  DevBuf<uint32_t> ref_row, ref_deg, ref_cols, ref_sumbits, ref_pos;
+  DevBuf<eoff_t> ref_off;
+  uint32_t ref_n = 0, ref_n_long = 0, ref_longest = 0;
+  uint64_t ref_edges = 0;
+  int ref_glog = 20;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG)
+  DevBuf<float> ref_old;               // the selected rows' scores in front of the pull (the L1 change is corrected against them)
+  DevBuf<double> ref_partial;          // per-workgroup corrections of the L1 change
+  // gdn_pr_pull_parts_dev: one iteration = one launch per phase, its bins in part-major order with tickets (gdn_pb.hpp PbParts)
+  DevBuf<unsigned> tickets;            // PB_MAX_PARTS counters, PB_TICKET_STRIDE words apart, + 1 timeout word behind them
+  uint32_t ticket_target[PB_MAX_PARTS] = {};
+  int32_t ticket_parts = 0;            // parts of the last ticketed pull
+  std::vector<int32_t> parts_key;      // the row ends parts_order was made for
+  DevBuf<uint32_t> parts_order;        // nbins: the bins of part 0 first, largest first inside a part
+  PbParts parts_launch;                // launch-index end of every part
 };
 
 struct PrOp {
@@ -108,7 +123,8 @@ struct PrOp {
   __device__ __forceinline__ double fin(int32_t row, float sum, const Pre &p) const {
     const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
     scores[row] = new_score;
-    contrib_out[row] = __fdiv_rn(new_score, (float)p.deg);
+    if (wt) __hip_atomic_store(contrib_out + row, __fdiv_rn(new_score, (float)p.deg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else contrib_out[row] = __fdiv_rn(new_score, (float)p.deg);
     return (double)fabsf(gdn_fsub(new_score, p.old_score));
   }
   __device__ __forceinline__ double finish(int32_t row, float sum) const { return fin(row, sum, pre(row)); }
@@ -132,82 +148,178 @@ struct PrOp {
       d += (double)fabsf(gdn_fsub(new_score, p.old_score[c]));
     }
     *reinterpret_cast<pb_f32x4 *>(scores + row) = ns;
-    *reinterpret_cast<pb_f32x4 *>(contrib_out + row) = nc;
+    if (wt) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(contrib_out + row), "v"(nc) : "memory");
+    else *reinterpret_cast<pb_f32x4 *>(contrib_out + row) = nc;
     return d;
   }
+  // ticketed pulls (gdn_pr_pull_parts_dev): the next contributions -- what the ranks exchange -- are stored WRITE-THROUGH
+  // (sc1: the line leaves the XCD's L2 at once), so that a workgroup's ticket needs no L2 write-back in front of it
+  int wt = 0;
 };
 
-// ---- GDN_PR_SUM=reference: the reference's summation order on demand (diagnostic).
-// One wavefront per row.  64 rows are examined at a time (lane l: the offsets of row w0 + l); the rows that qualify are
-// walked one after the other by the whole wave: 4 x 64 column ids and their contributions are fetched side by side, then
-// added ONE BY ONE in CSR order -- incoming_total += outgoing_contrib[src], src/pr/omp_base.cc:29-30 -- through
-// v_readlane; every lane carries the same running sum.  row_ids / cmap: a squished plan's state index -> caller's row,
-// caller's column id -> state index (both monotonic, so CSR order is the caller's).
-#define PR_REF_DEPTH 4
+// ---- GDN_PR_SUM=reference: the reference's summation order on demand: the rows of >= ref_min_deg in-edges
+// ("selected" rows) are summed AGAIN the way src/pr/omp_base.cc:27-30 sums them -- one fp32 addition per in-edge, in CSR
+// order -- and their scores / next contributions / the L1 change rewritten from those sums.
+// Round 6: (1) the chain of dependent additions is gone -- a wave settles 512 additions with one scan (gdn_seqsum.hpp: the
+// same bits, proven element by element); (2) the gather of the contributions is no longer a stream of L2 misses: the
+// selected rows keep a copy of their column ids in the plan's own vertex space (ref_cols, ascending per row), the vertex
+// space is cut into GROUPS of 2^glog sources, and group g of ALL long rows is summed by launch g -- the 2-4 MB of
+// contributions a launch gathers from stay in the XCDs' L2s, the running sum and the cursor of a row wait in memory between
+// launches.  A row of 1.3 M in-edges is then ~60 short segments instead of one 5 ms chain.  Rows of <= PR_REF_SHORT edges
+// are summed whole by launch 0.
+#define PR_REF_N 8                       // elements per lane and block
+#define PR_REF_BLOCK (64 * PR_REF_N)     // 512 elements per wave step
+#define PR_REF_SHORT PR_REF_BLOCK
+struct PrRefRows {
+  const uint32_t *__restrict__ row;   // state row of selected row i (sorted by in-degree, descending)
+  const uint32_t *__restrict__ deg;   // its in-degree
+  const eoff_t *__restrict__ off;     // first entry in cols (a multiple of 8)
+  const uint32_t *__restrict__ cols;  // column ids in the plan's vertex space, ascending per row
+  uint32_t *__restrict__ sum;         // running sum (bit pattern); after the last launch: the row's sum
+  uint32_t *__restrict__ pos;         // entries of the row already added
+  uint32_t n;                         // selected rows
+  uint32_t n_long;                    // of them longer than PR_REF_SHORT (the first n_long)
+};
+
+// launch `g`: every long row adds its entries with column < limit (and >= the previous launch's limit: cols ascend);
+// launch 0 also takes the short rows whole.  One wave per row.
 __global__ void __launch_bounds__(GDN_BLOCK)
-pr_refsum_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const uint32_t *__restrict__ row_ids,
-                 const eoff_t *__restrict__ cmap, int32_t m_rows, uint32_t min_deg, const float *__restrict__ contrib_in,
-                 float *__restrict__ scores, float *__restrict__ contrib_out, const int32_t *__restrict__ out_degree,
-                 float base_score, float damping, const unsigned *__restrict__ skip) {
+pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip) {
   if (skip && *skip) return;
   const unsigned lane = gdn_lane();
-  const uint64_t wave = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * GDN_BLOCK) >> 6;
-  for (uint64_t w0 = wave * 64; w0 < (uint64_t)m_rows; w0 += nwaves * 64) {
-    const uint64_t k = w0 + lane;
-    eoff_t lo = 0, hi = 0;
-    if (k < (uint64_t)m_rows) {
-      const uint64_t r = row_ids ? (uint64_t)row_ids[k] : k;
-      lo = rowptr[r];
-      hi = rowptr[r + 1];
+  const uint64_t i = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
+  if (i >= nrows) return;
+  const uint32_t deg = rr.deg[i];
+  uint32_t p = g == 0 ? 0u : rr.pos[i], S = g == 0 ? 0u : rr.sum[i];
+  const uint32_t lim = (g == 0 && i >= rr.n_long) ? 0xFFFFFFFFu : limit;  // (short rows: everything now)
+  if (p >= deg) return;
+  typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
+  const pr_u32x4 *__restrict__ C4 = reinterpret_cast<const pr_u32x4 *>(rr.cols + rr.off[i]);
+  uint32_t j0 = p & ~(uint32_t)(PR_REF_BLOCK - 1);  // block of the cursor (blocks are aligned inside the row: 16-byte loads)
+  uint32_t x[PR_REF_N], nx[PR_REF_N];
+  // entries of block j0 that count: cursor <= j < deg and column < lim; the rest reads as +0 (the identity of the scan)
+  auto load = [&](uint32_t jb, uint32_t (&v)[PR_REF_N], unsigned &taken, bool &more) {
+    const uint32_t j = jb + lane * PR_REF_N;
+    pr_u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
+    if (j < deg) {  // (rows are padded to multiples of 8 entries)
+      c0 = __builtin_nontemporal_load(C4 + (j >> 2));
+      c1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
     }
-    unsigned long long todo = __ballot(k < (uint64_t)m_rows && hi - lo >= (eoff_t)min_deg);
-    while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const eoff_t e0 = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(lo >> 32), l) << 32) |
-                        (eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)lo, l);
-      const eoff_t e1 = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(hi >> 32), l) << 32) |
-                        (eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)hi, l);
-      float sum = 0.0f;
-      for (eoff_t e = e0; e < e1; e += 64 * PR_REF_DEPTH) {
-        float v[PR_REF_DEPTH];
+    const uint32_t c[PR_REF_N] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned mine = 0, beyond = 0;
 #pragma unroll
-        for (int d = 0; d < PR_REF_DEPTH; d++) {
-          const eoff_t ee = e + (eoff_t)(64 * d) + lane;
-          v[d] = 0.0f;
-          if (ee < e1) {
-            const vid_t c = colidx[ee];
-            v[d] = contrib_in[cmap ? (uint64_t)cmap[c] : (uint64_t)c];
-          }
-        }
-#pragma unroll
-        for (int d = 0; d < PR_REF_DEPTH; d++) {
-          const eoff_t left = e1 - (e + (eoff_t)(64 * d));
-          const int n = e + (eoff_t)(64 * d) >= e1 ? 0 : (left < 64 ? (int)left : 64);
-          for (int i = 0; i < n; i++) sum = gdn_fadd(sum, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[d]), i)));
-        }
-      }
-      if (lane == 0) {
-        const uint64_t row = w0 + (uint64_t)l;
-        const float new_score = gdn_fadd(base_score, gdn_fmul(damping, sum));
-        scores[row] = new_score;
-        contrib_out[row] = __fdiv_rn(new_score, (float)out_degree[row]);
-      }
+    for (int k = 0; k < PR_REF_N; k++) {
+      const bool in_row = j + (uint32_t)k >= p && j + (uint32_t)k < deg;
+      const bool ok = in_row && c[k] < lim;
+      v[k] = ok ? __float_as_uint(contrib_in[c[k]]) : 0u;
+      mine += ok ? 1u : 0u;
+      beyond += (in_row && !ok) ? 1u : 0u;
     }
+    taken = (unsigned)gdn_wave_sum((unsigned long long)mine);
+    more = __ballot(beyond != 0u) == 0ull && jb + PR_REF_BLOCK < deg;  // nothing of this block lies past the limit, and the row goes on
+  };
+  unsigned taken, ntaken = 0;
+  bool more, nmore = false;
+  load(j0, x, taken, more);
+  for (;;) {
+    if (more) load(j0 + PR_REF_BLOCK, nx, ntaken, nmore);  // the next block's gathers fly while this one is scanned
+    if (taken) S = seq_block<PR_REF_N>(S, x, lane);
+    p += taken;
+    if (!more) break;
+    j0 += PR_REF_BLOCK;
+#pragma unroll
+    for (int k = 0; k < PR_REF_N; k++) x[k] = nx[k];
+    taken = ntaken;
+    more = nmore;
+  }
+  if (lane == 0) {
+    rr.sum[i] = S;
+    rr.pos[i] = p;
   }
 }
 
-// L1 change of a pull recomputed from the vectors: partial[b] = SUM |scores - old| over workgroup b's rows, in double
+// the scores of the selected rows in front of the pull
 __global__ void __launch_bounds__(GDN_BLOCK)
-pr_refdiff_kernel(const float *__restrict__ scores, const float *__restrict__ old, int32_t m, double *__restrict__ partial) {
+pr_ref_old_kernel(const uint32_t *__restrict__ row, uint32_t n, const float *__restrict__ scores, float *__restrict__ old) {
+  for (uint64_t i = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * GDN_BLOCK) old[i] = scores[row[i]];
+}
+// ... and behind it: scores / next contributions from the reference-order sums, the change of the L1 change per workgroup
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_ref_apply_kernel(const uint32_t *__restrict__ row, const uint32_t *__restrict__ sum, const float *__restrict__ old, uint32_t n,
+                    float *__restrict__ scores, float *__restrict__ contrib_out, const int32_t *__restrict__ out_degree,
+                    float base_score, float damping, double *__restrict__ partial, const unsigned *__restrict__ skip) {
   __shared__ double s_red[GDN_WAVES_PER_BLOCK];
   double acc = 0.0;
-  for (uint64_t i = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < (uint64_t)m; i += (uint64_t)gridDim.x * GDN_BLOCK)
-    acc += (double)fabsf(gdn_fsub(scores[i], old[i]));
+  if (!(skip && *skip)) {
+    for (uint64_t i = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * GDN_BLOCK) {
+      const uint32_t r = row[i];
+      const float new_score = gdn_fadd(base_score, gdn_fmul(damping, __uint_as_float(sum[i])));
+      acc += (double)fabsf(gdn_fsub(new_score, old[i])) - (double)fabsf(gdn_fsub(scores[r], old[i]));
+      scores[r] = new_score;
+      contrib_out[r] = __fdiv_rn(new_score, (float)out_degree[r]);
+    }
+  }
   acc = gdn_block_sum(acc, s_red);
   if (threadIdx.x == 0) partial[blockIdx.x] = acc;
 }
-#define PR_REF_DIFF_BLOCKS 2048
+__global__ void pr_ref_adddiff_kernel(const double *__restrict__ partial, uint32_t n, double *__restrict__ diff) {
+  if (threadIdx.x || blockIdx.x) return;
+  double t = 0.0;
+  for (uint32_t i = 0; i < n; i++) t += partial[i];
+  *diff += t;
+}
+#define PR_REF_DIFF_BLOCKS 256
+
+// plan build of the mode: sort keys of the rows (selected: ~degree << 32 | state row; others: all ones), ...
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_ref_keys_kernel(const eoff_t *__restrict__ rowptr, const uint32_t *__restrict__ row_ids, int32_t m_rows, uint32_t min_deg,
+                   unsigned long long *__restrict__ keys, unsigned long long *__restrict__ count /* [0] selected, [1] long */) {
+  __shared__ unsigned long long s_tmp[GDN_WAVES_PER_BLOCK];
+  unsigned long long sel = 0, lng = 0;
+  for (uint64_t k = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; k < (uint64_t)m_rows; k += (uint64_t)gridDim.x * GDN_BLOCK) {
+    const uint64_t r = row_ids ? (uint64_t)row_ids[k] : k;
+    const eoff_t d = rowptr[r + 1] - rowptr[r];
+    const bool s = d >= (eoff_t)min_deg && d > 0 && d < 0xFFFFFFFFull;
+    keys[k] = s ? ((unsigned long long)(0xFFFFFFFFu - (uint32_t)d) << 32) | k : ~0ull;
+    sel += s ? 1u : 0u;
+    lng += (s && d > PR_REF_SHORT) ? 1u : 0u;
+  }
+  gdn_block_add_u64(sel, count, s_tmp);
+  gdn_block_add_u64(lng, count + 1, s_tmp);
+}
+// ... the sorted keys -> row, degree, padded length
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_ref_rows_kernel(const unsigned long long *__restrict__ keys, uint32_t n, uint32_t *__restrict__ row, uint32_t *__restrict__ deg,
+                   uint32_t *__restrict__ padded) {
+  const uint64_t i = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long k = keys[i];
+  const uint32_t d = 0xFFFFFFFFu - (uint32_t)(k >> 32);
+  row[i] = (uint32_t)k;
+  deg[i] = d;
+  padded[i] = (d + 7u) & ~7u;
+}
+// ... and the rows' column ids in the plan's vertex space (cmap: caller's id -> state index of a squished plan); a wave per row
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_ref_cols_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const uint32_t *__restrict__ row_ids,
+                   const eoff_t *__restrict__ cmap, const uint32_t *__restrict__ row, const uint32_t *__restrict__ deg,
+                   const eoff_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ cols) {
+  const unsigned lane = gdn_lane();
+  for (uint64_t i = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; i < n; i += ((uint64_t)gridDim.x * GDN_BLOCK) >> 6) {
+    const uint64_t r = row_ids ? (uint64_t)row_ids[row[i]] : (uint64_t)row[i];
+    const eoff_t e0 = rowptr[r], o = off[i];
+    const uint32_t d = deg[i], dp = (d + 7u) & ~7u;
+    for (uint32_t j = lane; j < dp; j += 64) {
+      uint32_t c = 0u;  // (pad entries: a valid index, never counted)
+      if (j < d) {
+        const vid_t v = colidx[e0 + j];
+        c = cmap ? (uint32_t)cmap[v] : (uint32_t)v;
+      }
+      cols[o + j] = c;
+    }
+  }
+}
 
 // bin and in-bin index of every hub row in the compacted main layout (bin_lo = first original row of a bin,
 // dst_bits = rows that have entries)
@@ -338,7 +450,7 @@ pr_squish_vertices_kernel(const uint32_t *__restrict__ flag, const eoff_t *__res
 }
 
 __global__ void __launch_bounds__(GDN_BLOCK)
-pr_squish_cols_kernel(const vid_t *__restrict__ colidx, const eoff_t *__restrict__ cmap, uint64_t nnz, vid_t *__restrict__ out) {
+pr_squish_cols_kernel(const vid_t *colidx, const eoff_t *__restrict__ cmap, uint64_t nnz, vid_t *out) {  // (out may BE colidx: gdn_pr_squish_range)
   size_t e = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * GDN_BLOCK;
   for (; e < nnz; e += stride) out[e] = (vid_t)cmap[colidx[e]];
@@ -696,6 +808,7 @@ static int pb_pick_log(int64_t n, int max_log, int slices_log) {
 }
 
 static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms);
+static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap);
 static thread_local bool g_pr_no_place = false;  // set by gdn_pr around its own plan: one solve does not pay for a search
 
 int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int32_t m_global,
@@ -834,6 +947,13 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       ta.src_count = in_csr->m == m_global ? d_out_degree : nullptr;
       ta.log_chunk = lc;
       ta.log_bin = lb;
+      // one 1024-thread workgroup of the accumulate phase fills a CU whatever its bin's size: the bins of a row shard
+      // (2^13 rows and fewer) are spread over whole rounds of workgroups as well -- RMAT-27 / 8: 793 bins = 3.1 rounds in the
+      // time of 4 (profiles/r06_shard_compute.md)
+      {
+        const char *be = gdn_option("GDN_PB_BALANCE_SHARDS");
+        if (!(be && be[0] == '0')) ta.bin_balance_log = lb;
+      }
       ta.pad = pad;
       ta.log_group = lg;
       ta.tiers = want_tiers;
@@ -1090,20 +1210,17 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     p->sq_colidx.release();
     p->sq_rowptr.release();
   }
-  // GDN_PR_SUM=reference (diagnostic): keep what pr_refsum_kernel reads -- the caller's in-CSR (by reference: it has to
-  // outlive the plan in this mode) and, for a squished plan, the id -> state index map
+  // GDN_PR_SUM=reference: the selected rows and their column ids in the plan's vertex space (pr_ref_build; the caller's in-CSR
+  // is only read here)
   if (const char *e = gdn_option("GDN_PR_SUM")) {
     if (e[0] == 'r') {
       p->ref_sum = true;
-      p->ref_csr = raw_csr;
       if (const char *d = gdn_option("GDN_PR_SUM_MIN_DEGREE")) p->ref_min_deg = (uint32_t)strtoul(d, nullptr, 10);
-      int rc2 = p->ref_old.alloc((size_t)p->m_local);
-      if (rc2 == GDN_OK) rc2 = p->ref_partial.alloc(PR_REF_DIFF_BLOCKS);
+      const int rc2 = pr_ref_build(p, raw_csr, p->squished ? cmap.p : nullptr);
       if (rc2 != GDN_OK) {
         delete p;
         return rc2;
       }
-      if (p->squished) p->ref_cmap.take(cmap);
     }
   }
   // placement search (pr_plan_place).  GDN_PR_PLACE=<tries per array> (0 = off)
@@ -1357,26 +1474,89 @@ static unsigned pb_first_bin_at(const PbPlan &pb, int64_t row) {
   return lo;
 }
 
-// GDN_PR_SUM=reference: the rows of >= ref_min_deg in-edges summed again in the reference's order, then the L1 change of
-// the whole pull recomputed from the vectors (the pull's own figure was taken before the rows changed)
+// GDN_PR_SUM=reference, behind a pull: the selected rows summed again in the reference's order -- one launch per group of
+// 2^ref_glog sources --, their scores / next contributions rewritten, the L1 change corrected by what that moved
 static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipStream_t s) {
-  const gdn_graph *g = plan->ref_csr;
-  hipLaunchKernelGGL(pr_refsum_kernel, dim3(256 * 8), dim3(GDN_BLOCK), 0, s, g->rowptr, g->colidx,
-                     plan->squished ? plan->sq_ids.p : nullptr, plan->squished ? plan->ref_cmap.p : nullptr, plan->m_local,
-                     plan->ref_min_deg, op.contrib_in, op.scores, op.contrib_out, op.out_degree, op.base_score, op.damping,
-                     op.skip);
-  if (d_diff) {
-    hipLaunchKernelGGL(pr_refdiff_kernel, dim3(PR_REF_DIFF_BLOCKS), dim3(GDN_BLOCK), 0, s, op.scores, plan->ref_old.p,
-                       plan->m_local, plan->ref_partial.p);
-    hipLaunchKernelGGL(mp_reduce_f64, dim3(1), dim3(GDN_BLOCK), 0, s, plan->ref_partial.p, (uint32_t)PR_REF_DIFF_BLOCKS, d_diff);
+  if (plan->ref_n == 0) return GDN_OK;
+  PrRefRows rr;
+  rr.row = plan->ref_row.p;
+  rr.deg = plan->ref_deg.p;
+  rr.off = plan->ref_off.p;
+  rr.cols = plan->ref_cols.p;
+  rr.sum = plan->ref_sumbits.p;
+  rr.pos = plan->ref_pos.p;
+  rr.n = plan->ref_n;
+  rr.n_long = plan->ref_n_long;
+  const uint64_t space = (uint64_t)plan->m_global;  // the index space of contrib_in
+  const uint32_t ngroups = plan->ref_n_long ? (uint32_t)((space + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1u;
+  for (uint32_t g = 0; g < ngroups; g++) {
+    const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
+    const uint32_t limit = g + 1 == ngroups ? 0xFFFFFFFFu : (uint32_t)((uint64_t)(g + 1) << plan->ref_glog);
+    hipLaunchKernelGGL(pr_refseg_kernel, dim3((nrows + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, g, limit,
+                       op.contrib_in, op.skip);
   }
+  hipLaunchKernelGGL(pr_ref_apply_kernel, dim3(PR_REF_DIFF_BLOCKS), dim3(GDN_BLOCK), 0, s, plan->ref_row.p, plan->ref_sumbits.p,
+                     plan->ref_old.p, plan->ref_n, op.scores, op.contrib_out, op.out_degree, op.base_score, op.damping,
+                     plan->ref_partial.p, op.skip);
+  if (d_diff) hipLaunchKernelGGL(pr_ref_adddiff_kernel, dim3(1), dim3(64), 0, s, plan->ref_partial.p, (uint32_t)PR_REF_DIFF_BLOCKS, d_diff);
   GDN_HIP(hipGetLastError());
   return GDN_OK;
 }
 
-int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
-                         double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
-                         void *stream) {
+// the build of that mode (plan create): rows selected and sorted by in-degree, their columns copied into the plan's space
+static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap) {
+  const int32_t m_rows = p->m_local;
+  if (m_rows <= 0) return GDN_OK;
+  DevBuf<unsigned long long> ka, kb, cnt;
+  GDN_TRY(ka.alloc_scratch((size_t)m_rows));
+  GDN_TRY(kb.alloc_scratch((size_t)m_rows));
+  GDN_TRY(cnt.alloc(2));
+  GDN_HIP(hipMemset(cnt.p, 0, 16));
+  const uint32_t *row_ids = p->squished ? p->sq_ids.p : nullptr;
+  hipLaunchKernelGGL(pr_ref_keys_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, row_ids, m_rows, p->ref_min_deg, ka.p, cnt.p);
+  GDN_HIP(hipGetLastError());
+  unsigned long long h[2] = {0, 0};
+  GDN_HIP(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
+  p->ref_n = (uint32_t)h[0];
+  p->ref_n_long = (uint32_t)h[1];
+  if (p->ref_n == 0) return GDN_OK;
+  const unsigned long long *sorted = nullptr;
+  GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m_rows, 32, 64, &sorted));  // (stable: equal degrees stay in row order)
+  const uint32_t n = p->ref_n;
+  DevBuf<uint32_t> padded;
+  GDN_TRY(p->ref_row.alloc(n));
+  GDN_TRY(p->ref_deg.alloc(n));
+  GDN_TRY(p->ref_off.alloc((size_t)n + 1));
+  GDN_TRY(p->ref_sumbits.alloc(n));
+  GDN_TRY(p->ref_pos.alloc(n));
+  GDN_TRY(p->ref_old.alloc(n));
+  GDN_TRY(p->ref_partial.alloc(PR_REF_DIFF_BLOCKS));
+  GDN_TRY(padded.alloc_scratch(n));
+  hipLaunchKernelGGL(pr_ref_rows_kernel, dim3(gdn_nblocks((uint64_t)n)), dim3(GDN_BLOCK), 0, 0, sorted, n, p->ref_row.p, p->ref_deg.p, padded.p);
+  GDN_HIP(hipGetLastError());
+  GDN_TRY(gdn_exclusive_scan_u32_to_u64(padded.p, p->ref_off.p, (size_t)n, 0));
+  eoff_t total = 0;
+  uint32_t longest = 0;
+  GDN_HIP(hipMemcpy(&total, p->ref_off.p + n, sizeof(eoff_t), hipMemcpyDeviceToHost));
+  GDN_HIP(hipMemcpy(&longest, p->ref_deg.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+  p->ref_edges = total;
+  p->ref_longest = longest;
+  GDN_TRY(p->ref_cols.alloc((size_t)total + 8));
+  hipLaunchKernelGGL(pr_ref_cols_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->colidx, row_ids, cmap, p->ref_row.p, p->ref_deg.p,
+                     p->ref_off.p, n, p->ref_cols.p);
+  GDN_HIP(hipGetLastError());
+  GDN_HIP(hipDeviceSynchronize());
+  if (const char *e = gdn_option("GDN_PR_SUM_GROUP_LOG")) p->ref_glog = atoi(e) >= 10 && atoi(e) <= 31 ? atoi(e) : p->ref_glog;
+  if (gdn_option("GDN_PR_SUM_TRACE"))
+    fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u longer than %d), %llu entries, longest %u, groups of 2^%d sources\n", p->ref_n,
+            p->ref_min_deg, p->ref_n_long, PR_REF_SHORT, (unsigned long long)total, longest, p->ref_glog);
+  return GDN_OK;
+}
+
+// parts != nullptr (gdn_pr_pull_parts_dev): the whole iteration, the accumulate launch in plan->parts_order with tickets
+static int pr_pull_impl(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                        double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
+                        void *stream, const PbParts *parts) {
   GDN_REQUIRE(plan && d_contrib_in && d_scores && d_contrib_out, "null argument");
   GDN_REQUIRE(d_contrib_in != d_contrib_out, "contrib_in and contrib_out must differ (Jacobi)");
   GDN_REQUIRE(row_begin >= 0 && row_begin <= row_end, "row range");
@@ -1391,14 +1571,21 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   op.skip = plan->skip_flag;
   op.vec_ok = ((reinterpret_cast<uintptr_t>(op.scores) | reinterpret_cast<uintptr_t>(op.contrib_out) |
                 reinterpret_cast<uintptr_t>(op.out_degree)) & 15u) == 0;
+  op.wt = (parts && parts->mode == 1u) ? 1 : 0;
   if (plan->ref_sum) {
     GDN_REQUIRE(first && last, "GDN_PR_SUM=reference: whole-iteration pulls only (gdn_pr_pull_dev)");
-    GDN_HIP(hipMemcpyAsync(plan->ref_old.p, d_scores, (size_t)plan->m_local * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (plan->ref_n)
+      hipLaunchKernelGGL(pr_ref_old_kernel, dim3(gdn_nblocks((uint64_t)plan->ref_n) < 4096u ? gdn_nblocks((uint64_t)plan->ref_n) : 4096u),
+                         dim3(GDN_BLOCK), 0, (hipStream_t)stream, plan->ref_row.p, plan->ref_n, d_scores, plan->ref_old.p);
   }
   if (plan->layout == GDN_LAYOUT_CSR) {
     // the merge-path pass is not cut into parts: the FIRST part runs all rows, later parts are no-ops
     if (!first) return GDN_OK;
     GDN_TRY(mp_run(plan->mp, op, d_diff, (hipStream_t)stream));
+    if (parts) {  // every part is ready when the one kernel is: its tickets are added behind it
+      hipLaunchKernelGGL(pb_ticket_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, plan->tickets.p, *parts);
+      GDN_HIP(hipGetLastError());
+    }
     return plan->ref_sum ? pr_ref_resum(plan, op, d_diff, (hipStream_t)stream) : GDN_OK;
   }
   // ---- propagation-blocked path: expand (per chunk, first part) then accumulate + fused update (per bin)
@@ -1476,7 +1663,7 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   auto *const kern_b = plan->placing ? &pb_accumulate_kernel<PrOp, 1> : &pb_accumulate_kernel<PrOp, 0>;
   if (b1 > b0)
     hipLaunchKernelGGL(kern_b, dim3(b1 - b0), dim3(PB_THREADS), lds_b, s, pb.m_local,
-                       pb.log_bin, pb.bin_ptr.p, whole ? pb.bin_order.p : nullptr, pb.V.p, pb.vals.p, pb.partial.p,
+                       pb.log_bin, pb.bin_ptr.p, parts ? plan->parts_order.p : (whole ? pb.bin_order.p : nullptr), pb.V.p, pb.vals.p, pb.partial.p,
                        pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
                        gdn_option("GDN_PB_DBG") ? atoi(gdn_option("GDN_PB_DBG")) : 0,
@@ -1486,7 +1673,8 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
                        b0, nullptr, nullptr, nullptr, nullptr,
                        pb.v8 ? pb.Vd.p : nullptr, pb.v8 ? pb.Vb.p : nullptr, nullptr,
                        plan->has_hr ? plan->hrb_ptr.p : nullptr, plan->has_hr ? plan->hrb_vl.p : nullptr,
-                       plan->has_hr ? plan->hr_total.p : nullptr, mid);
+                       plan->has_hr ? plan->hr_total.p : nullptr, mid, parts ? plan->tickets.p : nullptr,
+                       parts ? *parts : PbParts());
   if (last) {
     if (timed) {
       GDN_HIP(hipEventRecord(pb.ev[pb.ev_used + 2], s));
@@ -1510,6 +1698,75 @@ int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_
   }
   GDN_HIP(hipGetLastError());
   if (plan->ref_sum) return pr_ref_resum(plan, op, d_diff, s);
+  return GDN_OK;
+}
+
+int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                         double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
+                         void *stream) {
+  return pr_pull_impl(plan, d_contrib_in, d_scores, d_contrib_out, d_diff, damping, row_begin, row_end, flags, stream, nullptr);
+}
+
+// One iteration whose rows become final PART BY PART inside one launch per phase (gdn_pb.hpp, PbParts): part j = the local
+// rows below row_end[j] that are not in an earlier part (a bin belongs to the part that holds its first row, as in
+// gdn_pr_pull_rows_dev).  gdn_pr_wait_part_dev queues, on any OTHER stream, a one-wave kernel that ends when part j's rows of
+// the LAST pull queued here are final and visible -- work queued behind it there (the all-gather of those rows) overlaps the
+// accumulation of the later parts.
+int gdn_pr_pull_parts_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                          double *d_diff, float damping, int32_t n_parts, const int32_t *row_end, void *stream) {
+  GDN_REQUIRE(plan && row_end && n_parts >= 1 && n_parts <= PB_MAX_PARTS, "parts");
+  GDN_REQUIRE(!plan->skip_flag && !plan->ref_sum, "ticketed pulls: not inside gdn_pr's batched loop / GDN_PR_SUM=reference");
+  for (int j = 0; j < n_parts; j++) GDN_REQUIRE(row_end[j] >= (j ? row_end[j - 1] : 0), "row_end must ascend");
+  if (!plan->tickets.p) {
+    GDN_TRY(plan->tickets.alloc((size_t)PB_MAX_PARTS * PB_TICKET_STRIDE + PB_TICKET_STRIDE));
+    GDN_HIP(hipMemset(plan->tickets.p, 0, plan->tickets.n * sizeof(unsigned)));
+  }
+  PbParts inc;  // what this pull adds to every counter
+  inc.n = (unsigned)n_parts;
+  if (plan->layout == GDN_LAYOUT_CSR) {
+    for (int j = 0; j < n_parts; j++) inc.end[j] = 1u;
+  } else {
+    PbPlan &pb = plan->pb;
+    const std::vector<int32_t> key(row_end, row_end + n_parts);
+    if (key != plan->parts_key || !plan->parts_order.p) {
+      std::vector<eoff_t> bp((size_t)pb.nbins + 1);
+      GDN_HIP(hipMemcpy(bp.data(), pb.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> order(pb.nbins);
+      unsigned b0 = 0, k = 0;
+      for (int j = 0; j < n_parts; j++) {
+        const unsigned b1 = j == n_parts - 1 ? pb.nbins : pb_first_bin_at(pb, row_end[j]);
+        const unsigned first = k;
+        for (unsigned b = b0; b < b1; b++) order[k++] = b;
+        std::stable_sort(order.begin() + first, order.begin() + k,
+                         [&](uint32_t x, uint32_t y) { return bp[x + 1] - bp[x] > bp[y + 1] - bp[y]; });
+        plan->parts_launch.end[j] = k;
+        if (b1 > b0) b0 = b1;
+      }
+      plan->parts_launch.n = (unsigned)n_parts;
+      if (!plan->parts_order.p) GDN_TRY(plan->parts_order.alloc(pb.nbins ? pb.nbins : 1));
+      GDN_HIP(hipStreamSynchronize((hipStream_t)stream));  // (a launch that still reads the old order)
+      GDN_HIP(hipMemcpy(plan->parts_order.p, order.data(), order.size() * 4, hipMemcpyHostToDevice));
+      plan->parts_key = key;
+    }
+    for (int j = 0; j < n_parts; j++) inc.end[j] = plan->parts_launch.end[j] - (j ? plan->parts_launch.end[j - 1] : 0u);
+  }
+  PbParts launch = plan->layout == GDN_LAYOUT_CSR ? inc : plan->parts_launch;
+  {  // GDN_PR_TICKET_MODE: fence = an L2 write-back per workgroup, wt = write-through stores of the next contributions (default)
+    const char *e = gdn_option("GDN_PR_TICKET_MODE");
+    launch.mode = (e && e[0] == 'f') ? 0u : 1u;
+  }
+  GDN_TRY(pr_pull_impl(plan, d_contrib_in, d_scores, d_contrib_out, d_diff, damping, 0, plan->m_local,
+                       GDN_PR_PART_FIRST | GDN_PR_PART_LAST, stream, &launch));
+  for (int j = 0; j < n_parts; j++) plan->ticket_target[j] += inc.end[j];
+  plan->ticket_parts = n_parts;
+  return GDN_OK;
+}
+
+int gdn_pr_wait_part_dev(gdn_pr_plan *plan, int32_t part, void *stream) {
+  GDN_REQUIRE(plan && plan->tickets.p && part >= 0 && part < plan->ticket_parts, "no ticketed pull with such a part was queued");
+  hipLaunchKernelGGL(pb_ticket_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, plan->tickets.p + (size_t)PB_TICKET_STRIDE * part,
+                     plan->ticket_target[part], plan->tickets.p + (size_t)PB_TICKET_STRIDE * PB_MAX_PARTS);
+  GDN_HIP(hipGetLastError());
   return GDN_OK;
 }
 
@@ -1673,6 +1930,14 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
 
 int gdn_pr_plan_check(gdn_pr_plan *plan) {
   GDN_REQUIRE(plan != nullptr, "plan");
+  if (plan->tickets.p) {
+    unsigned late = 0;
+    GDN_HIP(hipMemcpy(&late, plan->tickets.p + (size_t)PB_TICKET_STRIDE * PB_MAX_PARTS, sizeof(late), hipMemcpyDeviceToHost));
+    if (late) {
+      gdn_set_error("gdn_pr_wait_part_dev: a part's tickets did not arrive within 4 s (was the pull it waits for ever queued?)");
+      return GDN_ERR_HIP;
+    }
+  }
   if (plan->layout != GDN_LAYOUT_PB) return GDN_OK;
   unsigned f = 0;
   GDN_HIP(hipMemcpy(&f, plan->pb.errflag.p, sizeof(f), hipMemcpyDeviceToHost));
@@ -1681,6 +1946,16 @@ int gdn_pr_plan_check(gdn_pr_plan *plan) {
                   "scores must be a probability vector -- use GDN_LAYOUT_CSR for other inputs");
     return GDN_ERR_OVERFLOW;
   }
+  return GDN_OK;
+}
+
+int gdn_pr_plan_refsum_info(const gdn_pr_plan *plan, int32_t *rows, int32_t *longest_row, uint64_t *entries, int32_t *groups) {
+  GDN_REQUIRE(plan != nullptr, "plan");
+  if (rows) *rows = (int32_t)plan->ref_n;
+  if (longest_row) *longest_row = (int32_t)plan->ref_longest;
+  if (entries) *entries = plan->ref_edges;
+  if (groups)
+    *groups = !plan->ref_sum ? 0 : (plan->ref_n_long ? (int32_t)(((uint64_t)plan->m_global + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1);
   return GDN_OK;
 }
 

@@ -181,23 +181,40 @@ class ShardedPageRank:
         return out
 
     def _gather_rows_async(self, which, r0, r1):
-        """All-gather rows [r0,r1) of every rank's slice (strided in the full vector: a list of views)."""
+        """All-gather rows [r0,r1) of every rank's slice (strided in the full vector: a list of views; with ONE rank the
+        part is one contiguous range and goes through the in-place form, which moves nothing)."""
         full = self.be.contrib_full(which)
+        if self.world == 1 and self._inplace:
+            return self.dist.all_gather_into_tensor(full[r0:r1], full[r0:r1], async_op=True)
         outs = [full[r * self.chunk + r0:r * self.chunk + r1] for r in range(self.world)]
         return self.dist.all_gather(outs, outs[self.rank], async_op=True)
+
+    def _pull_part(self, nxt, ranges, j):
+        """Queue the computation of pipeline part j and return the context in which its exchange is to be queued.
+        A backend with tickets (HipPageRankBackend: gdn_pr_pull_parts_dev) runs the whole iteration as ONE launch per phase
+        when part 0 is asked for -- its bins in part order -- and `part_ready(j)` is a side stream on which a one-wave kernel
+        waits for part j's tickets; other backends (the CPU test backends) compute part j now, on the current stream."""
+        import contextlib
+        r0, r1 = ranges[j]
+        if len(ranges) > 1 and hasattr(self.be, "pull_ticketed"):
+            if j == 0:
+                self.be.pull_ticketed(self.cur, nxt, self.damping, [r[1] for r in ranges])
+            return self.be.part_ready(j)
+        if len(ranges) > 1:
+            self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
+        else:
+            self.be.pull(self.cur, nxt, self.damping)
+        return contextlib.nullcontext()
 
     def _step_compact(self, nxt):
         full = self.be.contrib_full(nxt)
         ranges = self.part_ranges() if self.parts > 1 else [(0, self.chunk)]
         works = []
         for j, (r0, r1) in enumerate(ranges):
-            if self.parts > 1:
-                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
-            else:
-                self.be.pull(self.cur, nxt, self.damping)
-            cx = self._cx[j]
-            send = full.index_select(0, cx["my"])  # pad entries read the dummy slot
-            works.append((self.dist.all_gather_into_tensor(cx["recv"], send, async_op=True), send, cx))
+            with self._pull_part(nxt, ranges, j):
+                cx = self._cx[j]
+                send = full.index_select(0, cx["my"])  # pad entries read the dummy slot
+                works.append((self.dist.all_gather_into_tensor(cx["recv"], send, async_op=True), send, cx))
         for w, _send, cx in works:
             w.wait()
             cap = cx["my"].numel()
@@ -221,9 +238,9 @@ class ShardedPageRank:
             ranges = self.part_ranges()
             works = []
             for j, (r0, r1) in enumerate(ranges):
-                self.be.pull_rows(self.cur, nxt, self.damping, r0, r1, first=(j == 0), last=(j == len(ranges) - 1))
-                if r1 > r0:
-                    works.append(self._gather_rows_async(nxt, r0, r1))
+                with self._pull_part(nxt, ranges, j):
+                    if r1 > r0:
+                        works.append(self._gather_rows_async(nxt, r0, r1))
             for w in works:
                 w.wait()
         self.cur = nxt
@@ -257,6 +274,19 @@ class ShardedPageRank:
         return it + 1, err
 
 
+class _Entered:
+    """A context manager that has been entered already (HipPageRankBackend.part_ready): `with` only leaves it."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
 class HipPageRankBackend:
     """Local shard on one MI355X: torch device tensors + the _dev entry points of the C-ABI."""
 
@@ -273,6 +303,7 @@ class HipPageRankBackend:
         self.m_global = m_global
         n_full = chunk * world
         self.diff = torch.zeros(1, dtype=torch.float64, device=device)
+        self._side = None  # the stream the part waiters and the exchanges behind them are queued on (part_ready)
         self.plan = C.c_void_p()
         # a single rank that holds the whole graph works on the LIVE vertices only (GDN_LAYOUT_PB_SQUISHED: vertices without
         # any edge keep the base score and are left out of the per-iteration state; GDN_PR_SQUISH=0 keeps them in)
@@ -344,6 +375,31 @@ class HipPageRankBackend:
                                                      C.c_void_p(self.contribs[cout].data_ptr()),
                                                      C.c_void_p(self.diff.data_ptr()), float(damping), r0c, r1c, flags,
                                                      self._stream()))
+
+    def pull_ticketed(self, cin, cout, damping, row_ends):
+        """One iteration as ONE launch per phase whose rows become final part by part (gdn_pr_pull_parts_dev): row_ends[j]
+        ends part j (clipped to this rank's row count)."""
+        n = len(row_ends)
+        ends = (C.c_int32 * n)(*[min(int(r), self.m_local) for r in row_ends])
+        self._cabi.check(self.L.gdn_pr_pull_parts_dev(self.plan, C.c_void_p(self.contribs[cin].data_ptr()),
+                                                      C.c_void_p(self.scores.data_ptr()),
+                                                      C.c_void_p(self.contribs[cout].data_ptr()),
+                                                      C.c_void_p(self.diff.data_ptr()), float(damping), n, ends, self._stream()))
+
+    def part_ready(self, part: int):
+        """Context manager: inside it the current stream is this backend's side stream, on which a one-wave kernel has been
+        queued that ends when part `part` of the last pull_ticketed is final (gdn_pr_wait_part_dev) -- what is queued inside
+        (the exchange of the part) runs beside the accumulation of the later parts."""
+        if self._side is None:
+            self._side = self.torch.cuda.Stream(device=self.device)
+        ctx = self.torch.cuda.stream(self._side)
+        ctx.__enter__()
+        try:
+            self._cabi.check(self.L.gdn_pr_wait_part_dev(self.plan, int(part), C.c_void_p(self._side.cuda_stream)))
+        except BaseException:
+            ctx.__exit__(None, None, None)
+            raise
+        return _Entered(ctx)
 
     def n_bins(self) -> int:
         """Workgroups of the accumulate phase on this rank (0: CSR layout)."""

@@ -312,6 +312,14 @@ int gdn_pr_plan_move(gdn_pr_plan *plan, uint32_t what);
  * iteration into row-range parts (gdn_pr_pull_rows_dev) keeps every part at a whole wave of workgroups or more */
 int gdn_pr_plan_bins(const gdn_pr_plan *plan, int32_t *n_bins);
 int gdn_pr_plan_check(gdn_pr_plan *plan);
+/* Option GDN_PR_SUM=reference (read by gdn_pr_plan_create / gdn_pr): behind every pull the rows of at least
+ * GDN_PR_SUM_MIN_DEGREE in-edges (default 0: every row) are summed AGAIN in the order of src/pr/omp_base.cc:27-30 -- one fp32
+ * addition per in-edge, in CSR order -- and their scores, next contributions and the L1 change rewritten: those rows then carry
+ * the reference's bits (with every row selected the whole solve does).  The sums are evaluated by scans, not by a chain of
+ * additions, and group by group of 2^GDN_PR_SUM_GROUP_LOG sources (default 20) so that the gathered contributions stay in L2
+ * (csrc/gdn_seqsum.hpp).  This call reports what a plan of that mode re-sums: rows, the longest of them, entries
+ * (in-edges, rows padded to multiples of 8) and launches per pull; all 0 for a plan without the mode. */
+int gdn_pr_plan_refsum_info(const gdn_pr_plan *plan, int32_t *rows, int32_t *longest_row, uint64_t *entries, int32_t *groups);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* entries of the per-vertex state arrays (scores, contrib) the iteration calls of this plan work on: m_local, or the
  * live vertices of a GDN_LAYOUT_PB_SQUISHED plan */
@@ -365,6 +373,18 @@ int gdn_pr_pull_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_score
 int gdn_pr_pull_rows_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
                          double *d_diff, float damping, int32_t row_begin, int32_t row_end, int32_t flags,
                          void *stream);
+/* The same iteration with its rows becoming final PART BY PART inside ONE launch per phase (no launch tails between the
+ * parts: four row-range launches cost RMAT-27's accumulate phase 2.53 -> 3.13 ms on one rank).  row_end[j] (ascending, local
+ * rows) ends part j; the last part covers every remaining row.  The accumulate launch walks the bins of part 0 first
+ * (largest first inside a part); a workgroup that has finished a bin publishes its rows device-wide and adds a ticket to
+ * its part.  gdn_pr_wait_part_dev queues, on ANOTHER stream, a one-wave kernel that ends once part `part` of the pull
+ * queued LAST on this plan is final: scores[v] and contrib_out[row_base+v] for every v < row_end[part] -- whatever is queued
+ * behind it on that stream (the all-gather of those rows) overlaps the accumulation of the later parts.  A waiter gives up
+ * after ~4 s of device time and gdn_pr_plan_check then reports it.  n_parts <= 8.  Not available inside gdn_pr's own loop
+ * or under GDN_PR_SUM=reference.  (The reference has no counterpart: its multi-GPU vestige is include/graph_gpu.h:145-165.) */
+int gdn_pr_pull_parts_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d_scores, float *d_contrib_out,
+                          double *d_diff, float damping, int32_t n_parts, const int32_t *row_end, void *stream);
+int gdn_pr_wait_part_dev(gdn_pr_plan *plan, int32_t part, void *stream);
 /* Per-launch HIP-event timing of the iteration's kernels on the launch stream.  reset != 0 arms
  * it for up to max_launches launches; reset == 0 waits for the events and reports summed
  * durations in total_ms[2] (CSR: [0] = merge-path tile kernel; PB: [0] = expand, [1] =

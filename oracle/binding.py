@@ -100,6 +100,13 @@ def num_threads() -> int:
     return int(lib().orc_num_threads())
 
 
+def set_num_threads(n: int) -> None:
+    L = lib()
+    L.orc_set_num_threads.argtypes = [C.c_int]
+    L.orc_set_num_threads.restype = None
+    L.orc_set_num_threads(int(n))
+
+
 def bfs_serial(g, source):
     rp, ci = _g(g)
     dist = np.empty(g.m, dtype=np.int32)

@@ -54,6 +54,12 @@ int orc_num_threads(void) {
   return n;
 }
 
+// threads of the parallel regions from here on (bench.py's N > 1 CPU leg: torch.distributed.run exports OMP_NUM_THREADS=1 to
+// its ranks; rank 0 takes its share of the host's cores for the baseline instead)
+void orc_set_num_threads(int n) {
+  if (n > 0) omp_set_num_threads(n);
+}
+
 // ---------------------------------------------------------------------------------
 // BFS
 // ---------------------------------------------------------------------------------

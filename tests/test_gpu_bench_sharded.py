@@ -21,9 +21,9 @@ def _free_port():
     return p
 
 
-def _bench(extra, launcher=None):
+def _bench(extra, launcher=None, cpu=False):
     cmd = [sys.executable] + (launcher or []) + [os.path.join(ROOT, "bench.py"), "--scale", "20", "--steps", "4", "--warmup",
-                                                 "1", "--no-bfs", "--no-cpu", "--no-extras"] + extra
+                                                 "1", "--no-bfs", "--no-extras"] + (["--cpu-seconds", "0.5", "--no-converged-parity"] if cpu else ["--no-cpu"]) + extra
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
@@ -42,6 +42,11 @@ def test_bench_two_ranks_on_one_device_match_single():
         assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == ("--no-squish" not in extra)
         assert ("every rank generated its own destination range" in r["config"]["partition"]) == (not extra)
         assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+        # round 6: every N > 1 line says how many ranks the collective backend saw, which backend it was, and how the edges fell
+        assert r["rccl_ranks"] == 2 and r["collective_backend"].startswith("gloo") and r["config"]["parts"] >= 1
+        assert len(r["config"]["edges_per_rank"]) == 2 and sum(r["config"]["edges_per_rank"]) == single["config"]["edges"]
+        assert 0 <= r["config"]["edge_imbalance"] < 0.1
+    assert "rccl_ranks" not in single
     assert "roofline" in single and single["roofline"]["frac"] > 0
     assert single["step_ms"]["n"] >= 10 and single["step_ms"]["min"] <= single["step_ms"]["median"]
 
@@ -80,6 +85,23 @@ def test_bench_equal_ranges_and_rccl_backend_with_one_rank():
     f = _bench(["--force-dist", "--gen", "range"])
     assert f["n_gpus"] == 1 and "every rank generated its own destination range" in f["config"]["partition"]
     assert abs(f["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
+    assert f["rccl_ranks"] == 1 and f["collective_backend"].startswith("nccl") and f["config"]["edge_imbalance"] == 0.0
+
+
+def test_bench_lines_of_sharded_runs_carry_a_cpu_baseline():
+    """north_star: "1/2/4/8-GPU GTEPS and the host-OpenMP baseline (core count stated) reported in the same run" -- rank 0 of an
+    N > 1 job times the oracle's pull iteration on a bounded row sample of ITS shard with its share of the host's cores, for both
+    ways of making the shards; the one-rank RCCL line too."""
+    launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "0"]
+    for gen in ("range", "whole"):
+        launcher[-1] = str(_free_port())
+        r = _bench(["--gpus", "2", "--share-device", "--gen", gen], launcher, cpu=True)
+        cb = r["cpu_baseline"]
+        assert cb and cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and cb["ranks_on_this_host"] == 2
+        assert "rank 0 of 2" in cb["sample"] and cb["unit"] == "edges/s"
+        assert cb["cores"] == max(1, cb["physical_cores"] // 2)  # its share, whatever OMP_NUM_THREADS the launcher exported
+    f = _bench(["--force-dist", "--gen", "range"], cpu=True)
+    assert f["cpu_baseline"]["value"] > 0 and "rank 0 of 1" in f["cpu_baseline"]["sample"]
 
 
 def test_bench_line_carries_bfs_spmv_tc_blocks():

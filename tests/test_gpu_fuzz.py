@@ -24,7 +24,7 @@ def test_random_graphs_every_solver_equals_the_oracle(first_seed, blocked):
         blocked = False
     if blocked == "deferred":  # BFS plans with head records whose heavy levels -- binned top-down forced below a third of the edges,
         # dense sweeps, bottom-up steps -- all leave the distances to the pass at the end of the search (default from 2^25 vertices on)
-        env.update(FUZZ_PLANS="1", GDN_BFS_HEADS_MIN_NNZ="1", GDN_BFS_HUB_MIN="0", GDN_BFS_DEFER_DEPTH="1", GDN_BFS_REC_COMPACT="1", GDN_BFS_TD_DEFER_MIN="1",
+        env.update(FUZZ_PLANS="1", GDN_BFS_HEADS_MIN_NNZ="1", GDN_BFS_HUB_MIN="0", GDN_BFS_DEFER_DEPTH="1", GDN_BFS_REC_COMPACT="1", GDN_BFS_TD_DEFER_MIN="1", GDN_BFS_SNAP_MIN="1",
                    GDN_BFS_BTD="2", GDN_BFS_ALPHA_BTD="100000", GDN_BFS_BTD_MIN="1")
         blocked = False
     if blocked == "heads2":  # ... and every head named by rank (the outer hubs of BFS's bottom-up step), the records read from their compact copy

@@ -253,6 +253,69 @@ def test_pr_reference_sum_mode_has_the_reference_bits(orc, layout, monkeypatch):
     assert np.array_equal(again, plain)  # the mode leaves nothing behind
 
 
+@pytest.mark.parametrize("glog", ["10", "12", "31"])
+def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog):
+    """The kernel behind GDN_PR_SUM=reference (gdn_seqsum.hpp: scans of parity functions instead of a chain of additions, the
+    rows cut into groups of 2^glog sources that are summed launch by launch) on contributions chosen to hit every branch of
+    its arithmetic -- equal terms, exact ties, powers of two, zeros, denormals, terms above the running sum; then a negative
+    term and an infinity (the hardware path) --, on rows of 1 ... 9 000 in-edges: every score has the bits of
+    base + damping * (the contributions added one by one in fp32, in CSR order), src/pr/omp_base.cc:27-33."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    from test_seqsum_math import _case
+    L = _cabi.lib()
+    rng = np.random.default_rng(int(glog))
+    m = 9000
+    rows = [np.arange(1, m), rng.choice(m, 5000, replace=False), rng.choice(m, 700, replace=False), np.arange(0, m, 7)]
+    rows += [rng.choice(m, int(d), replace=False) for d in rng.integers(0, 40, m - len(rows))]
+    dst = np.concatenate([np.full(len(r), i) for i, r in enumerate(rows)])
+    src = np.concatenate(rows)
+    g = graphio.build_csr(m, src.astype(np.int64), dst.astype(np.int64))  # out-CSR of src -> dst
+    gi = graphio.transpose(g)
+    monkeypatch.setenv("GDN_PR_SUM", "reference")
+    monkeypatch.setenv("GDN_PR_SUM_GROUP_LOG", glog)
+    h, plan = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p), C.byref(h)))
+
+    def dev(a):
+        p = C.c_void_p()
+        _cabi.check(L.gdn_dev_alloc(a.nbytes, C.byref(p)))
+        _cabi.check(L.gdn_dev_upload(p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return p
+
+    def host(p, n, dt):
+        a = np.empty(n, dt)
+        _cabi.check(L.gdn_dev_download(a.ctypes.data_as(C.c_void_p), p, a.nbytes))
+        return a
+
+    deg = dev(np.maximum(g.degrees(), 1).astype(np.int32))
+    _cabi.check(L.gdn_pr_plan_create(h, deg, m, 0, 0, C.byref(plan)))  # merge-path layout: any float may be a contribution
+    base = np.float32((np.float32(1.0) - np.float32(0.85)) / np.float32(m))
+    for variant in ("finite", "weird"):
+        contrib = np.concatenate([_case(k, m // 9, rng)[:m // 9] for k in range(9)] + [np.zeros(m, np.float32)])[:m].astype(np.float32)
+        contrib = contrib[rng.permutation(m)]
+        if variant == "weird":
+            contrib[rng.integers(0, m, 3)] *= np.float32(-1.0)
+            contrib[int(rng.integers(0, m))] = np.inf
+        sc, c0, c1, diff = dev(np.full(m, 1.0 / m, np.float32)), dev(contrib), dev(np.zeros(m, np.float32)), dev(np.zeros(1, np.float64))
+        _cabi.check(L.gdn_pr_pull_dev(plan, c0, sc, c1, diff, 0.85, None))
+        got = host(sc, m, np.float32)
+        want = np.empty(m, np.float32)
+        with np.errstate(all="ignore"):
+            for r in range(m):
+                t = np.float32(0)
+                for v in contrib[gi.colidx[int(gi.rowptr[r]):int(gi.rowptr[r + 1])]]:
+                    t = np.float32(t + v)
+                want[r] = np.float32(base + np.float32(np.float32(0.85) * t))
+        same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), (variant, np.nonzero(~same)[0][:5], got[~same][:5], want[~same][:5])
+        for p in (sc, c0, c1, diff):
+            L.gdn_dev_free(p)
+    L.gdn_pr_plan_free(plan)
+    L.gdn_graph_free(h)
+    L.gdn_dev_free(deg)
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])
 @pytest.mark.parametrize("layout", [0, 1])
 def test_pr_sharded_data_path_on_one_device(orc, world, layout):
@@ -341,6 +404,64 @@ def test_pr_row_range_part_contract():
     L.gdn_graph_free(h)
     for p in (deg, sc, c0, c1, diff, sc2, c2):
         L.gdn_dev_free(p)
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_pr_ticketed_parts_contract(layout):
+    """gdn_pr_pull_parts_dev + gdn_pr_wait_part_dev: ONE launch per phase whose rows become final part by part.  A copy queued
+    on a second stream BEHIND part j's waiter (what the sharded driver does with its all-gather) sees scores and contrib_out
+    final for every row below row_end[j]; scores, contributions and the L1 change have the bits of the whole-iteration pull;
+    a second iteration reuses the counters (targets accumulate).  Blocked layout and merge-path layout (all parts at once)."""
+    import ctypes as C
+    import torch
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    g = graphio.rmat_graph(17, 16, seed=35)
+    gi = graphio.transpose(g)
+    m = g.m
+    h, plan = C.c_void_p(), C.c_void_p()
+    _cabi.check(L.gdn_graph_upload(m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p), C.byref(h)))
+    dev = torch.device("cuda", 0)
+    deg = torch.from_numpy(g.degrees().astype(np.int32)).to(dev)
+    pp = lambda t: C.c_void_p(t.data_ptr())
+    _cabi.check(L.gdn_pr_plan_create(h, pp(deg), m, 0, layout, C.byref(plan)))
+    init = torch.full((m,), 1.0 / m, dtype=torch.float32, device=dev)
+
+    def fresh():
+        return init.clone(), [torch.zeros(m, dtype=torch.float32, device=dev) for _ in range(2)], torch.zeros(1, dtype=torch.float64, device=dev)
+
+    # reference: two whole iterations
+    sc, cc, dd = fresh()
+    _cabi.check(L.gdn_pr_contrib_dev(plan, pp(sc), pp(cc[0]), None))
+    want = []
+    for k in range(2):
+        _cabi.check(L.gdn_pr_pull_dev(plan, pp(cc[k & 1]), pp(sc), pp(cc[(k + 1) & 1]), pp(dd), 0.85, None))
+        torch.cuda.synchronize()
+        want.append((sc.clone(), cc[(k + 1) & 1].clone(), float(dd.item())))
+    # the same two iterations ticketed, 5 uneven parts; behind every waiter a copy of the part's rows on the side stream
+    sc2, c2, d2 = fresh()
+    _cabi.check(L.gdn_pr_contrib_dev(plan, pp(sc2), pp(c2[0]), None))
+    ends = [1000, 1004, m // 3, m - 12345, m]
+    arr = (C.c_int32 * len(ends))(*ends)
+    side = torch.cuda.Stream(device=dev)
+    for k in range(2):
+        torch.cuda.synchronize()
+        _cabi.check(L.gdn_pr_pull_parts_dev(plan, pp(c2[k & 1]), pp(sc2), pp(c2[(k + 1) & 1]), pp(d2), 0.85, len(ends), arr, None))
+        snaps = []
+        with torch.cuda.stream(side):
+            for j, r1 in enumerate(ends):
+                _cabi.check(L.gdn_pr_wait_part_dev(plan, j, C.c_void_p(side.cuda_stream)))
+                snaps.append((sc2[:r1].clone(), c2[(k + 1) & 1][:r1].clone()))
+        torch.cuda.synchronize()
+        for j, r1 in enumerate(ends):
+            assert torch.equal(snaps[j][0], want[k][0][:r1]), (k, j)
+            assert torch.equal(snaps[j][1].view(torch.int32), want[k][1][:r1].view(torch.int32)), (k, j)
+        assert float(d2.item()) == want[k][2]
+    _cabi.check(L.gdn_pr_plan_check(plan))
+    with pytest.raises(RuntimeError):  # no such part
+        _cabi.check(L.gdn_pr_wait_part_dev(plan, len(ends), None))
+    L.gdn_pr_plan_free(plan)
+    L.gdn_graph_free(h)
 
 
 @pytest.mark.parametrize("world,parts", [(1, 1), (2, 3)])
