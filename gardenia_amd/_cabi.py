@@ -79,6 +79,7 @@ PROTOTYPES = {
     "gdn_dev_alloc": (C.c_int, [_u64, _pp]),
     "gdn_dev_free": (C.c_int, [_vp]),
     "gdn_dev_trim": (C.c_int, [C.POINTER(_u64)]),
+    "gdn_dev_reserve": (C.c_int, [_u64]),
     "gdn_dev_upload": (C.c_int, [_vp, _vp, _u64]),
     "gdn_dev_download": (C.c_int, [_vp, _vp, _u64]),
     "gdn_sort_u64_dev": (C.c_int, [_vp, _vp, _u64, _i32, _i32, _pp]),

@@ -906,13 +906,13 @@ int gdn_bc_plan_create(const gdn_graph *g, const gdn_graph *gin, gdn_bc_plan **p
     int lc = 10, lb = 10;
     while (lc < PB_MAX_LOG_CHUNK && ((int64_t)1 << (lc + 9)) < (int64_t)m) lc++;  // slice sizes as for PageRank (pb_pick_log)
     while (lb < PB_MAX_LOG_BIN && ((int64_t)1 << (lb + 9)) < (int64_t)m) lb++;
-    if (const char *e = gdn_option("GDN_BC_LOG_CHUNK")) lc = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_CHUNK ? atoi(e) : lc;  // tuning knobs
-    if (const char *e = gdn_option("GDN_BC_LOG_BIN")) lb = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_BIN ? atoi(e) : lb;
+    if (const char *e = gdn_xoption("GDN_BC_LOG_CHUNK")) lc = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_CHUNK ? atoi(e) : lc;  // tuning knobs
+    if (const char *e = gdn_xoption("GDN_BC_LOG_BIN")) lb = atoi(e) >= 10 && atoi(e) <= PB_MAX_LOG_BIN ? atoi(e) : lb;
     // forward: rows = destinations, columns = sources (the in-CSR); backward: rows = sources (the out-CSR)
     PbScratch scratch;
     // both layouts from the tiered builder's gather pass + LDS-staged splits (gdn_pbtier.hpp; no record tiers here: BC's
     // values are not fixed-point codes of one table); outside its limits, or GDN_PB_BUILDER=old: pb_build's key sort
-    const char *vie = gdn_option("GDN_PB_V_IL"), *be = gdn_option("GDN_PB_BUILDER");
+    const char *vie = gdn_test_option("GDN_PB_V_IL"), *be = gdn_option("GDN_PB_BUILDER");
     const bool v_il = !(vie && vie[0] == '0');
     auto build_one = [&](const gdn_graph *src, PbPlan &out) -> int {
       if (!(be && be[0] == 'o') && lb <= PB_MID_ROW_BITS) {
@@ -1015,7 +1015,7 @@ int gdn_bc_run(gdn_bc_plan *plan, int32_t source, float *d_scores, gdn_stats *st
   for (int d = 0; d < BC_MAX_LEVELS; d++)
     if (ls.count[d]) nlev = d + 1;
   uint64_t heavy_div = 16;  // a level is heavy (two blocked sweeps instead of atomics / gathers) from nnz / heavy_div out-edges on
-  if (const char *e = gdn_option("GDN_BC_HEAVY_DIV")) heavy_div = atoi(e) > 0 ? (uint64_t)atoi(e) : heavy_div;  // tuning knob
+  if (const char *e = gdn_xoption("GDN_BC_HEAVY_DIV")) heavy_div = atoi(e) > 0 ? (uint64_t)atoi(e) : heavy_div;  // tuning knob
   const uint64_t heavy = g->nnz / heavy_div + 1;
   GDN_HIP(hipMemsetAsync(p.pc.p, 0, (size_t)m * 4, 0));
   GDN_HIP(hipMemsetAsync(p.cnt.p, 0, sizeof(BcCounters), 0));
@@ -1134,15 +1134,15 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
   unsigned small_nf = 1024;
   unsigned long long small_scout = 8192;
-  if (const char *e = gdn_option("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
-  if (const char *e = gdn_option("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_test_option("GDN_BC_SMALL_NF")) small_nf = (unsigned)atoi(e);  // tuning / test knobs
+  if (const char *e = gdn_test_option("GDN_BC_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   DevBuf<BcSmallOut> small_out;
   if (small_nf) GDN_TRY(small_out.alloc(1));
   // levels of up to batch_nf vertices are queued fwd_batch at a time (1 = every level read back, the form for heavy levels)
   int fwd_batch = 8;
   unsigned batch_nf = 65536;
-  if (const char *e = gdn_option("GDN_BC_FWD_BATCH")) fwd_batch = atoi(e) > 0 ? atoi(e) : 1;  // tuning / test knobs
-  if (const char *e = gdn_option("GDN_BC_BATCH_NF")) batch_nf = (unsigned)atoi(e);
+  if (const char *e = gdn_xoption("GDN_BC_FWD_BATCH")) fwd_batch = atoi(e) > 0 ? atoi(e) : 1;  // tuning / test knobs
+  if (const char *e = gdn_xoption("GDN_BC_BATCH_NF")) batch_nf = (unsigned)atoi(e);
   DevBuf<unsigned> d_tails;
   GDN_TRY(d_tails.alloc((size_t)fwd_batch + 2));
   int mid_streak = 0;
@@ -1232,8 +1232,8 @@ int gdn_bc_dev(const gdn_graph *g, int32_t source, float *d_scores, gdn_stats *s
   // runs of light levels (at most back_nf vertices, back_scout out-edges each) stay inside one workgroup
   unsigned back_nf = BC_SMALL_THREADS;
   unsigned long long back_scout = 8192;
-  if (const char *e = gdn_option("GDN_BC_BACK_NF")) back_nf = std::min((unsigned)atoi(e), (unsigned)BC_SMALL_THREADS);  // tuning / test knobs
-  if (const char *e = gdn_option("GDN_BC_BACK_SCOUT")) back_scout = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_test_option("GDN_BC_BACK_NF")) back_nf = std::min((unsigned)atoi(e), (unsigned)BC_SMALL_THREADS);  // tuning / test knobs
+  if (const char *e = gdn_test_option("GDN_BC_BACK_SCOUT")) back_scout = strtoull(e, nullptr, 10);
   DevBuf<unsigned> d_lp;
   DevBuf<int32_t> d_next;
   if (back_nf && nlev >= 2) {

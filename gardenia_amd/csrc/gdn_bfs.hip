@@ -1630,12 +1630,12 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
     GDN_HIP(hipMemset(nact.p, 0, 8));
     hipLaunchKernelGGL(bfs_count_rows_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, gin->rowptr, m, nact.p);
     GDN_HIP(hipMemcpy(&p.active_rows, nact.p, 8, hipMemcpyDeviceToHost));
-    if (!(gdn_option("GDN_BFS_BTD") && atoi(gdn_option("GDN_BFS_BTD")) == 0)) {
+    if (!(gdn_test_option("GDN_BFS_BTD") && atoi(gdn_test_option("GDN_BFS_BTD")) == 0)) {
       // binned top-down levels: about 256 bins of up to 2^19 ids (more bins beyond 2^27 vertices); room for frontiers of
       // up to a third of the edges (beyond, the bottom-up step takes the level) with a factor 2 of slack per list
       int lb = 14;
       int64_t want_bins = 256;  // measured on RMAT-27 (278 M frontier edges): 512 bins 2.19 ms, 256 bins 2.03
-      if (const char *e = gdn_option("GDN_BFS_BTD_BINS")) want_bins = atoi(e) > 0 ? atoi(e) : want_bins;  // tuning knob
+      if (const char *e = gdn_xoption("GDN_BFS_BTD_BINS")) want_bins = atoi(e) > 0 ? atoi(e) : want_bins;  // tuning knob
       while (lb < BFS_BTD_MAX_LOGB && (want_bins << lb) < (int64_t)m) lb++;
       p.btd_logb = lb;
       p.btd_nbins = (unsigned)(((uint64_t)m + (1ull << lb) - 1) >> lb);
@@ -1692,11 +1692,11 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
                        p.noin.p);
     // hub heads: from 2^24 edges on (below, a level is a few hundred microseconds and the plan build should stay short);
     // GDN_BFS_HUB_HEADS=0 switches them off (A/B)
-    const char *hh = gdn_option("GDN_BFS_HUB_HEADS");
+    const char *hh = gdn_xoption("GDN_BFS_HUB_HEADS");
     unsigned long long heads_from = 1ull << 24;
-    if (const char *e = gdn_option("GDN_BFS_HEADS_MIN_NNZ")) heads_from = strtoull(e, nullptr, 10);  // (tests)
+    if (const char *e = gdn_test_option("GDN_BFS_HEADS_MIN_NNZ")) heads_from = strtoull(e, nullptr, 10);  // (tests)
     // (a graph with fewer vertices than a few times the hub slots gains nothing; the test knob lifts that too)
-    const bool enough = (unsigned)m >= 4u * BFS_HUBS || gdn_option("GDN_BFS_HEADS_MIN_NNZ") != nullptr;
+    const bool enough = (unsigned)m >= 4u * BFS_HUBS || gdn_test_option("GDN_BFS_HEADS_MIN_NNZ") != nullptr;
     if (dense && g->nnz >= heads_from && enough && m >= 2 && !(hh && hh[0] == '0')) {
       HostTimer th;
       GDN_HIP(hipDeviceSynchronize());
@@ -1708,7 +1708,7 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_TRY(hub_idx.alloc((size_t)m));
       // outer hubs where the vertex-indexed frontier bitmap is beyond an XCD's L2 (GDN_BFS_HUBS2=0: without)
       {
-        const char *e2 = gdn_option("GDN_BFS_HUBS2");
+        const char *e2 = gdn_test_option("GDN_BFS_HUBS2");
         // (default from 2^27 vertices on: RMAT-27 -1.5 %, RMAT-26 +1..2 % -- the 2^21 probes that fill the rank bitmap per level)
         p.n_ranked = (e2 ? e2[0] != '0' : (unsigned)m >= (1u << 27)) ? BFS_HUBS2 : BFS_HUBS;  // (=1 on a small graph: every head by rank)
       }
@@ -1728,11 +1728,11 @@ static int bfs_plan_init(gdn_bfs_plan &p, const gdn_graph *g, const gdn_graph *g
       GDN_HIP(hipGetLastError());
       GDN_HIP(hipDeviceSynchronize());
       {  // deferred depths (GDN_BFS_DEFER_DEPTH=0: without; default from 2^25 vertices on: at RMAT-24 the pass at the end costs what the levels save)
-        const char *ed = gdn_option("GDN_BFS_DEFER_DEPTH");
+        const char *ed = gdn_test_option("GDN_BFS_DEFER_DEPTH");
         if (ed ? ed[0] != '0' : (unsigned)m >= (1u << 25)) GDN_TRY(p.lvl.alloc((size_t)BFS_DEFER_MAX * p.nwords_pad));
       }
       {  // the compact copy (GDN_BFS_REC_COMPACT=0: without; default from 2^25 vertices on: RMAT-24 measures the same with and without)
-        const char *ec = gdn_option("GDN_BFS_REC_COMPACT");
+        const char *ec = gdn_test_option("GDN_BFS_REC_COMPACT");
         if (ec ? ec[0] != '0' : (unsigned)m >= (1u << 25)) {
           DevBuf<unsigned> cnt;
           DevBuf<eoff_t> scan;
@@ -1825,7 +1825,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int64_t visited_total = 1;  // discovered so far (the source included)
   int64_t bu_frac = 2;        // bottom-up engine once <= 1/bu_frac of the rows with in-edges are undiscovered (measured on
                               // RMAT-22..27: 2 beats 4 wherever a second heavy level follows the first, 1 loses)
-  if (const char *e = gdn_option("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
+  if (const char *e = gdn_xoption("GDN_BFS_BU_FRAC")) bu_frac = atoi(e) > 0 ? atoi(e) : (int64_t)1 << 40;  // tuning knob (0 = never)
   // a late level stays on the bottom-up engine while its frontier still scouts more than m / bu_stay edges: the step
   // costs a scan of two bitmaps plus the few undiscovered rows, a top-down step costs two divergent row-offset reads per
   // frontier vertex (RMAT-27: 4.8 M frontier vertices that discover 28 K = 0.48 ms top-down)
@@ -1835,9 +1835,9 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   uint64_t alpha_btd = (uint64_t)alpha_dense;
   int64_t btd_min_edges = 1 << 22;
   bool btd_on = true, btd_force = false;
-  if (const char *e = gdn_option("GDN_BFS_ALPHA_BTD")) alpha_btd = atoi(e) > 0 ? (uint64_t)atoi(e) : alpha_btd;  // tuning knobs
-  if (const char *e = gdn_option("GDN_BFS_BTD_MIN")) btd_min_edges = atoll(e);
-  if (const char *e = gdn_option("GDN_BFS_BTD")) {
+  if (const char *e = gdn_test_option("GDN_BFS_ALPHA_BTD")) alpha_btd = atoi(e) > 0 ? (uint64_t)atoi(e) : alpha_btd;  // tuning knobs
+  if (const char *e = gdn_test_option("GDN_BFS_BTD_MIN")) btd_min_edges = atoll(e);
+  if (const char *e = gdn_test_option("GDN_BFS_BTD")) {
     btd_on = atoi(e) != 0;
     btd_force = atoi(e) == 2;
   }
@@ -1846,29 +1846,29 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   // the binned level takes 2.05 (round 4, before those: 2.45; profiles/r05_bfs_bu_scan.txt); on a uniform random graph a step
   // from 1/8 on costs 4.9 ms against 3.2 (profiles/r05_bfs_uniform26_trace.txt): there it stays at Beamer's 1/3
   int64_t bu_edge_div = p.skewed && p.head.p ? 8 : 3;
-  if (const char *e = gdn_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
+  if (const char *e = gdn_test_option("GDN_BFS_BU_EDGE_DIV")) bu_edge_div = atoi(e);  // tuning knob
   int64_t bu_stay = 256;
-  if (const char *e = gdn_option("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
+  if (const char *e = gdn_xoption("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
   // in-neighbours per round trip of the bottom-up scan: 4 measured the same as 1 on RMAT-24 / 27 (session r05_08: the step is
   // not bound by the lane-private scan loops) -- the knob stays for the next graph family
   int bu_scan = 1;
-  if (const char *e = gdn_option("GDN_BFS_BU_SCAN")) bu_scan = atoi(e) > 1 ? 4 : 1;  // A/B knob
+  if (const char *e = gdn_xoption("GDN_BFS_BU_SCAN")) bu_scan = atoi(e) > 1 ? 4 : 1;  // A/B knob
   // largest frontier that gets the hashed filter (GDN_BFS_BU_FILTER=<vertices>, 0 = never) -- on graphs whose frontier bitmap
   // is beyond an XCD's L2 (from 2^26 vertices = 8 MB on).  Measured (profiles/r05_bfs_bu_scan.txt): RMAT-27's hub-frontier level
   // 1.865 -> 1.815 ms (source 5: 2.76 -> 2.69 ms), the other searches unchanged; RMAT-24, whose 2 MB bitmap IS L2 resident, pays
   // the 10 us of the filter's build for nothing (+1.5 %) -- the probes are a small part of that level, its gathers of the failing
   // rows' offsets and neighbour lists are the rest
   int64_t filt_max = m >= (1 << 26) ? (1 << 20) : 0;
-  if (const char *e = gdn_option("GDN_BFS_BU_FILTER")) filt_max = atoll(e);
+  if (const char *e = gdn_xoption("GDN_BFS_BU_FILTER")) filt_max = atoll(e);
   unsigned hub_min = BFS_HUBS / 8;  // hubs a frontier must hold for the bottom-up step to read the heads
-  if (const char *e = gdn_option("GDN_BFS_HUB_MIN")) hub_min = (unsigned)atoi(e);  // tuning knob
+  if (const char *e = gdn_test_option("GDN_BFS_HUB_MIN")) hub_min = (unsigned)atoi(e);  // tuning knob
   // frontiers of at most small_nf vertices and small_scout out-edges run fused in one workgroup (0 = never)
   // (measured: 1024 / 16384 made RMAT-20..24 searches 5-15 % slower -- 16 K edges on ONE CU are no faster than a launch
   // over all of them --, a 100 000-vertex chain 4.6x faster; the smaller limits keep the second without the first)
   unsigned small_nf = 256;
   unsigned long long small_scout = 2048;
-  if (const char *e = gdn_option("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
-  if (const char *e = gdn_option("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_test_option("GDN_BFS_SMALL_NF")) small_nf = (unsigned)atoi(e);                  // tuning knobs
+  if (const char *e = gdn_test_option("GDN_BFS_SMALL_SCOUT")) small_scout = strtoull(e, nullptr, 10);
   // light levels that outgrow the one workgroup go to the cooperative grid (bfs_td_coop_kernel) once `coop_streak` light
   // levels in a row say "high diameter" (an R-MAT search has 2-3 light levels on either side of its heavy ones and never
   // gets there; GDN_BFS_COOP=0 switches the path off, =1 takes it from the first light level: tests)
@@ -1890,9 +1890,9 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   int32_t kept_front_level = -1;   // ... for this level
   // (levels of fewer frontier edges discover so little that the old conversion is as cheap as the snapshot)
   int64_t snap_min_edges = 1 << 16;
-  if (const char *e = gdn_option("GDN_BFS_SNAP_MIN")) snap_min_edges = atoll(e);  // (test knob: small graphs reach the snapshot / td_keep path)
+  if (const char *e = gdn_test_option("GDN_BFS_SNAP_MIN")) snap_min_edges = atoll(e);  // (test knob: small graphs reach the snapshot / td_keep path)
   int64_t td_defer_min = 1 << 20;  // frontier edges from which a top-down level defers its depths (a 16 MB bitmap pass against its writes)
-  if (const char *e = gdn_option("GDN_BFS_TD_DEFER_MIN")) td_defer_min = atoll(e);  // (tuning knob; huge = never)
+  if (const char *e = gdn_test_option("GDN_BFS_TD_DEFER_MIN")) td_defer_min = atoll(e);  // (tuning knob; huge = never)
   // The level counters are ZEROED by the kernel that reads them back (GdnMailbox::read, zero = true): a level that follows a
   // read-back needs no memset of its own -- one dispatch per level less (11 fills per RMAT-27 search before).  cnt_reset() is
   // what a level calls before its kernels add to the counters: a memset only when the last thing that touched them was not a read.
@@ -1908,7 +1908,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     return GDN_OK;
   };
   const bool trace = gdn_option("GDN_BFS_TRACE") != nullptr;  // per-level timing to stderr (adds syncs)
-  const bool b2q_read = gdn_option("GDN_BFS_B2Q_READ") != nullptr;  // (A/B knob: read the length of a listed frontier back as before)
+  const bool b2q_read = gdn_xoption("GDN_BFS_B2Q_READ") != nullptr;  // (A/B knob: read the length of a listed frontier back as before)
   HostTimer tl;
   auto lap = [&](const char *what, long long a, long long b) {
     if (trace) fprintf(stderr, "[bfs] level %d %-10s nf/awake=%lld scout=%lld  %.3f ms\n", level, what, a, b, tl.stop_ms());
@@ -1960,7 +1960,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
         const char *engine = bottom_up ? "bottom-up" : "dense";
         // deferred depths: this level's `next` bitmap goes into the pool and stays there, its kernels leave the distances alone
         // (every engine of the dense phase but the window form of the bottom-up step, an A/B knob)
-        const char *bfe = gdn_option("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
+        const char *bfe = gdn_xoption("GDN_BFS_BU_FORM");  // window: the workgroup-per-window form (bfs_bu_kernel)
         const bool window_form = bfe && bfe[0] == 'w';
         const bool keep = defer && maps.n < BFS_DEFER_MAX && !window_form;
         if (keep) {
@@ -2242,7 +2242,7 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   if (defer) {  // the distances of the kept levels and of the vertices never reached, in one sequential pass
     if (time_init) GDN_HIP(hipEventRecord(ev.c, 0));
     unsigned fin_blocks = 8192;
-    if (const char *e = gdn_option("GDN_BFS_FINISH_BLOCKS")) fin_blocks = atoi(e) > 0 ? (unsigned)atoi(e) : fin_blocks;  // (tuning knob)
+    if (const char *e = gdn_xoption("GDN_BFS_FINISH_BLOCKS")) fin_blocks = atoi(e) > 0 ? (unsigned)atoi(e) : fin_blocks;  // (tuning knob)
     const unsigned need_blocks = gdn_nblocks(((uint64_t)m + 3) / 4);
     hipLaunchKernelGGL(bfs_depth_finish_kernel, dim3(need_blocks < fin_blocks ? need_blocks : fin_blocks),
                        dim3(GDN_BLOCK), 0, 0, p.visited.p, maps, d_dist, m,

@@ -810,7 +810,7 @@ void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint
   if (!hl) max_mid = 0;
   // a sampled count of c stands for about 16 c out-edges; a hub should have >= per_bin edges in an average bin
   uint64_t per_bin = PB_HUB_MIN_PER_BIN;
-  if (const char *e = gdn_option("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
+  if (const char *e = gdn_test_option("GDN_PB_HUB_MIN")) per_bin = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : per_bin;  // tuning knob
   // smallest bucket >= the bucket of `want` whose sources, up to (not including) bucket `top`, number at most `cap`;
   // PB_HUB_BUCKETS = none
   auto pick = [&](uint64_t want, unsigned top, uint64_t cap) -> unsigned {
@@ -831,9 +831,9 @@ void pb_choose_tiers(const unsigned *h, const unsigned *hl, uint64_t nbins, uint
   ta.thr[0] = bk0 < PB_HUB_BUCKETS ? pb_hub_bucket_floor(bk0) : 0xFFFFFFFFu;
   ta.ntiers = 1;
   uint64_t mid16 = min16 ? min16 : PB_MID_MIN_PER_BIN16;
-  if (const char *e = gdn_option("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
+  if (const char *e = gdn_xoption("GDN_PB_MID_MIN16")) mid16 = (uint64_t)atoi(e) > 0 ? (uint64_t)atoi(e) : mid16;  // tuning knob
   uint64_t mid_cap = PB_MID_MAX;  // GDN_PB_MID_CAP: test knob (fewer sources per tier, so that small graphs get two tiers)
-  if (const char *e = gdn_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
+  if (const char *e = gdn_test_option("GDN_PB_MID_CAP")) mid_cap = (uint64_t)atoi(e) > 0 && (uint64_t)atoi(e) < PB_MID_MAX ? (uint64_t)atoi(e) : mid_cap;
   if (max_mid > 0) {
     // mid tiers: consecutive count ranges [thr[t], thr[t-1]) below the hubs, each filled up to mid_cap sources, down
     // to the count that stands for mid16 / 16 edges per average bin
@@ -943,7 +943,7 @@ int pb_pick_tiers(const gdn_graph *g, int32_t m_global, int log_bin, DevBuf<uint
     if (t == 0) *n_hubs = n[0];
     else n_mid[t - 1] = n[t];
   }
-  if (gdn_option("GDN_PB_TRACE")) {
+  if (gdn_xoption("GDN_PB_TRACE")) {
     fprintf(stderr, "[pb_pick_tiers] bins %llu: hubs %u (sampled count >= %u)", (unsigned long long)nbins, n[0], ta.thr[0]);
     for (int t = 1; t < ta.ntiers; t++) fprintf(stderr, ", mid %d: %u (>= %u)", t, n[t], ta.thr[t]);
     fprintf(stderr, "\n");
@@ -1097,7 +1097,7 @@ int pb_order_bins_by_work(PbPlan &main, int n_tiers, const eoff_t *const *tier_b
   for (unsigned b = 0; b < nb; b++) bo[b] = b;
   std::stable_sort(bo.begin(), bo.end(), [&](uint32_t a, uint32_t b) { return work[a] > work[b]; });
   GDN_HIP(hipMemcpy(main.bin_order.p, bo.data(), (size_t)nb * 4, hipMemcpyHostToDevice));
-  if (gdn_option("GDN_PB_TRACE") && nb) {
+  if (gdn_xoption("GDN_PB_TRACE") && nb) {
     double mx = 0, sum = 0;
     for (unsigned b = 0; b < nb; b++) {
       sum += work[b];
@@ -1113,7 +1113,7 @@ uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full) {
   int ncu = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
   if (ncu <= 0) ncu = 256;
-  const char *be = gdn_option("GDN_PB_BALANCE");  // 0 switches the spreading off (A/B measurements)
+  const char *be = gdn_xoption("GDN_PB_BALANCE");  // 0 switches the spreading off (A/B measurements)
   const bool on = !(be && be[0] == '0');
   const uint64_t cap = 1ull << lg;
   const uint64_t ns = (n_act + cap - 1) >> lg;
@@ -1328,7 +1328,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     // alone -- 11-12 bits instead of ~58, two radix passes instead of eight.  (A caller's row with unsorted columns only
     // changes the order of one row's edges inside a tile, which nothing depends on.)  Not for the out-CSR form and the
     // (source, row) tile order, whose inner order CSR order does not give.
-    const bool by_chunk_only = !rows_are_sources && !src_major && !gdn_option("GDN_PB_FULL_SORT");
+    const bool by_chunk_only = !rows_are_sources && !src_major && !gdn_xoption("GDN_PB_FULL_SORT");
     const bool filtered = src_class || dst_class;
     if (!by_chunk_only && filtered && n_use * 2 < n && (ka.p && kb.p)) {
       // a class-filtered layout sorted on its whole key (the tiers: 9-24 % of the edges each): ONE pass on the sentinel
@@ -1411,7 +1411,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
       GDN_HIP(hipDeviceSynchronize());
     }
     p.n_pad = n_pad;
-    if (gdn_option("GDN_PB_TRACE")) {
+    if (gdn_xoption("GDN_PB_TRACE")) {
       eoff_t fill = 0;
       if (v_delta) (void)hipMemcpy(&fill, ds.p + n_use, sizeof(eoff_t), hipMemcpyDeviceToHost);
       fprintf(stderr, "[pb_build] edges %llu fillers %llu padded %llu (%.3f x) chunks %u bins %u pad %u group %u%s%s\n",
@@ -1443,7 +1443,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
                          p.nchunks, p.nbins, tsu.p, pu.p, pv.p, p.U.p, p.V.p, g->rowptr, g->colidx,
                          ev_out ? edge_vals_in : nullptr, ev_out,
 #ifdef GDN_EXPERIMENTS
-                         gdn_option("GDN_PB_TEST_RANDV") ? 1 : 0,  // TIMING-ONLY experiment: uniform row ids
+                         gdn_xoption("GDN_PB_TEST_RANDV") ? 1 : 0,  // TIMING-ONLY experiment: uniform row ids
 #else
                          0,
 #endif
@@ -1469,7 +1469,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     }
     int identity_g = 0;
 #ifdef GDN_EXPERIMENTS  // GDN_PB_IDENTITY=1: TIMING-ONLY experiment (sequential phase-A stores, wrong results)
-    identity_g = gdn_option("GDN_PB_IDENTITY") ? 1 : 0;
+    identity_g = gdn_xoption("GDN_PB_IDENTITY") ? 1 : 0;
 #endif
     {  // groups in the alignment gaps store their (neutral) values into the dump group behind the arrays
       const unsigned long long ng = (n_pad >> log_group) + 1;
@@ -1487,8 +1487,8 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
     GDN_HIP(hipMemcpy(cp.data(), p.chunk_ptr.p, cp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
     GDN_HIP(hipMemcpy(bp.data(), p.bin_ptr.p, bp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
 #ifdef GDN_EXPERIMENTS  // GDN_PB_UNIFORM=1: TIMING-ONLY, equal-sized chunk / bin ranges (wrong results)
-    if (gdn_option("GDN_PB_UNIFORM")) {
-      const eoff_t al = atoi(gdn_option("GDN_PB_UNIFORM")) > 1 ? (eoff_t)atoi(gdn_option("GDN_PB_UNIFORM")) - 1 : 15;
+    if (gdn_xoption("GDN_PB_UNIFORM")) {
+      const eoff_t al = atoi(gdn_xoption("GDN_PB_UNIFORM")) > 1 ? (eoff_t)atoi(gdn_xoption("GDN_PB_UNIFORM")) - 1 : 15;
       for (unsigned i = 0; i <= p.nchunks; i++) cp[i] = ((p.n_pad / p.nchunks) * i) & ~al;
       for (unsigned i = 0; i <= p.nbins; i++) bp[i] = ((p.n_pad / p.nbins) * i) & ~al;
       cp[p.nchunks] = bp[p.nbins] = p.n_pad;
@@ -1513,7 +1513,7 @@ int pb_build(const gdn_graph *g, int32_t m_global, int log_chunk, int log_bin, P
   GDN_TRY(p.partial.alloc(p.nbins));
   GDN_TRY(p.red_scratch.alloc(2 * ((size_t)p.nbins / 4096 + 2)));
   GDN_HIP(hipDeviceSynchronize());
-  if (gdn_option("GDN_PB_TRACE"))
+  if (gdn_xoption("GDN_PB_TRACE"))
     fprintf(stderr, "[pb_build] %.0f ms wall\n",
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return GDN_OK;

@@ -518,7 +518,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
     unsigned head = 0;
     if (r > 0 && (unsigned)m > (1u << 18)) {
       head = 1u << 14;
-      if (const char *e = gdn_option("GDN_CC_HEAD")) head = (unsigned)atoi(e) & ~(unsigned)(GDN_BLOCK - 1);  // tuning knob
+      if (const char *e = gdn_xoption("GDN_CC_HEAD")) head = (unsigned)atoi(e) & ~(unsigned)(GDN_BLOCK - 1);  // tuning knob
       if (head >= (unsigned)m) head = 0;
     }
     if (head) {
@@ -542,7 +542,7 @@ static int cc_afforest(const gdn_graph *g, const gdn_graph *gin, int32_t *d_comp
   vis.comp = d_comp;
   vis.v = 0;
   vis.colidx = g->colidx;
-  const char *oe = gdn_option("GDN_CC_OUTSIDE");  // 0: the unfiltered closing pass of round 3 (A/B)
+  const char *oe = gdn_xoption("GDN_CC_OUTSIDE");  // 0: the unfiltered closing pass of round 3 (A/B)
   if (!gin && !(oe && oe[0] == '0')) {
     // out-edges only: every edge is streamed, the ones with an end outside c are linked (see cc_outside_bits_kernel)
     hipLaunchKernelGGL(cc_outside_bits_kernel, grid_m, blk, 0, 0, d_comp, m, d_sample.p + nsample, outside.p);

@@ -55,7 +55,20 @@ void gdn_set_error(const char *fmt, ...);
 
 int gdn_require_device();
 // value of a library option: the environment variable `name` if set, else what gdn_option_set stored, else nullptr
+// Three classes of run-time options:
+//   gdn_option       PUBLIC options -- include/gardenia_hip.h lists every one of them next to gdn_option_set
+//   gdn_test_option  TEST HOOKS (thresholds that force a big-graph code path onto a small graph, layout variants the suite
+//                    compares bit for bit): honoured only while GDN_TEST_HOOKS=1 is set (tests/conftest.py sets it); a
+//                    production process does not read them
+//   gdn_xoption      A/B knobs of closed experiments and measurement sessions: compiled in only with -DGDN_EXPERIMENTS
+//                    (make EXPERIMENTS=1, tools/build_variant.sh); nullptr -- and their code paths dead -- in the shipped build
 const char *gdn_option(const char *name);
+const char *gdn_test_option(const char *name);
+#ifdef GDN_EXPERIMENTS
+#define gdn_xoption(name) gdn_option(name)
+#else
+#define gdn_xoption(name) (static_cast<const char *>(nullptr))
+#endif
 
 // Byte offset for the next large allocation (gdn_graph.hip).  0 unless the option GDN_ALLOC_STAGGER names a granule
 // (a multiple of 256 bytes): then the k-th buffer of >= 1 MiB starts (2k + 1) mod 127 granules behind its hipMalloc
@@ -70,6 +83,7 @@ hipError_t gdn_plain_free(void *p);
 // of 16 GB takes 0.8 - 4.8 s whenever memory of that size was freed shortly before (the driver hands freed pages out again
 // only after wiping them), and hipFree costs 0.16 ms of synchronisation whatever the size.  A freed block may still be in
 // use by work queued on the null stream; its next user queues behind that work.
+void *gdn_reserve_take(size_t bytes);  // the block gdn_dev_reserve set aside, if it holds `bytes` (then the caller's; hipFree)
 int gdn_scratch_malloc(void **p, size_t bytes, int site = 8);  // gdn_graph.hip (site: bit of GDN_SCRATCH_POISON_SITES)
 void gdn_scratch_free(void *p);
 void gdn_scratch_trim();  // the cache goes back to the driver
@@ -304,7 +318,7 @@ struct GdnMailbox {
   }
   void init() {
     if (host) return;
-    const char *e = gdn_option("GDN_MAILBOX");
+    const char *e = gdn_xoption("GDN_MAILBOX");
     spin = !(e && e[0] == '0');
     void *h = nullptr;
     if (hipHostMalloc(&h, kPayload + 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {

@@ -32,6 +32,11 @@ const char *gdn_option(const char *name) {
   return it == m.end() ? nullptr : it->second.c_str();  // (the string lives until the option is set again)
 }
 
+const char *gdn_test_option(const char *name) {
+  const char *h = gdn_option("GDN_TEST_HOOKS");
+  return (h && h[0] == '1') ? gdn_option(name) : nullptr;
+}
+
 // GDN_ALLOC_FENCE=1 (debugging, read once): every DevBuf / scratch allocation is its own block of whole 2 MB pages with the
 // buffer at its END (16-byte aligned), and the scratch cache is off -- a kernel that reads or writes past the end of a
 // buffer then leaves the mapping and faults on the spot instead of touching a neighbour (the GPU build has no address
@@ -52,7 +57,7 @@ size_t gdn_alloc_stagger_next(size_t bytes) {
   static std::atomic<unsigned> k{0};
   if (gdn_alloc_fence()) return gdn_fence_offset(bytes);
   if (bytes < (1u << 20)) return 0;
-  const char *e = gdn_option("GDN_ALLOC_STAGGER");
+  const char *e = gdn_xoption("GDN_ALLOC_STAGGER");
   if (!e) return 0;
   const size_t g = (size_t)strtoull(e, nullptr, 10) & ~(size_t)255;
   if (g == 0) return 0;
@@ -74,7 +79,7 @@ void gdn_set_error(const char *fmt, ...) {
 // GDN_SCRATCH_POOL=0 (read once): plain hipMalloc / hipFree instead (A/B knob)
 static bool gdn_scratch_pooled() {
   static const bool on = [] {
-    const char *e = gdn_option("GDN_SCRATCH_POOL");
+    const char *e = gdn_xoption("GDN_SCRATCH_POOL");
     return !(e && e[0] == '0');
   }();
   return on;
@@ -125,7 +130,7 @@ void gdn_scratch_trim() {
 // memory being zero (it is, from hipMalloc; a block of the pool holds whatever its last user left)
 static bool gdn_scratch_poison() {
   static const bool on = [] {
-    const char *e = gdn_option("GDN_SCRATCH_POISON");
+    const char *e = gdn_test_option("GDN_SCRATCH_POISON");
     return e && e[0] == '1';
   }();
   return on;
@@ -135,13 +140,13 @@ int gdn_scratch_malloc(void **p, size_t bytes, int site) {
   GDN_TRY(gdn_scratch_malloc_raw(p, bytes));
   if (gdn_scratch_poison()) {
     static const int sites = [] {
-      const char *e = gdn_option("GDN_SCRATCH_POISON_SITES");  // bit mask of the sites to poison (debugging)
+      const char *e = gdn_xoption("GDN_SCRATCH_POISON_SITES");  // bit mask of the sites to poison (debugging)
       return e ? atoi(e) : 0xFFFF;
     }();
     if (sites & site) {
       // GDN_SCRATCH_POISON_PART (debugging): "head:N" only the first N bytes, "tail:N" only the last N, "mid:A:B" bytes [A, B)
       size_t lo = 0, hi = bytes ? bytes : 1;
-      if (const char *e = gdn_option("GDN_SCRATCH_POISON_PART")) {
+      if (const char *e = gdn_xoption("GDN_SCRATCH_POISON_PART")) {
         if (!strncmp(e, "head:", 5)) hi = std::min(hi, (size_t)strtoull(e + 5, nullptr, 10));
         else if (!strncmp(e, "tail:", 5)) lo = hi - std::min(hi, (size_t)strtoull(e + 5, nullptr, 10));
         else if (!strncmp(e, "mid:", 4)) {
@@ -551,6 +556,35 @@ int gdn_dev_alloc(uint64_t bytes, void **d_ptr) {
 int gdn_dev_free(void *d_ptr) {
   if (d_ptr) GDN_HIP(gdn_plain_free(d_ptr));
   return GDN_OK;
+}
+
+// A block set aside at the START of a process, before any build has allocated and freed memory (where hipMalloc
+// puts a PageRank plan's `vals` moves its expand phase by 10-15 %, and the property belongs to the physical pages an allocation
+// gets -- does memory that has never been through a build's allocations behave alike?).  One block per process; the first
+// blocked PageRank plan whose `vals` fits takes it (gdn_reserve_take), its destructor frees it.
+static std::mutex g_reserve_mu;
+static void *g_reserve_p = nullptr;
+static size_t g_reserve_bytes = 0;
+int gdn_dev_reserve(uint64_t bytes) {
+  GDN_TRY(gdn_require_device());
+  std::lock_guard<std::mutex> lk(g_reserve_mu);
+  if (g_reserve_p) {
+    (void)hipFree(g_reserve_p);
+    g_reserve_p = nullptr;
+    g_reserve_bytes = 0;
+  }
+  if (bytes == 0) return GDN_OK;
+  GDN_HIP(hipMalloc(&g_reserve_p, bytes));
+  g_reserve_bytes = bytes;
+  return GDN_OK;
+}
+extern "C++" void *gdn_reserve_take(size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_reserve_mu);
+  if (!g_reserve_p || g_reserve_bytes < bytes) return nullptr;
+  void *p = g_reserve_p;
+  g_reserve_p = nullptr;
+  g_reserve_bytes = 0;
+  return p;
 }
 
 int gdn_dev_trim(uint64_t *freed_bytes) {

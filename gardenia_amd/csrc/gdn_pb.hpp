@@ -140,7 +140,7 @@ struct PbPlacer {
   HostTimer wall;
   double best = 0, first = 0;
   int begin() {
-    if (const char *e = gdn_option("GDN_PLACE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);
+    if (const char *e = gdn_test_option("GDN_PLACE_MIN_BYTES")) min_bytes = (size_t)strtoull(e, nullptr, 10);
     GDN_HIP(hipDeviceSynchronize());
     wall.start();
     GDN_TRY(timed(&best));  // (the first one also loads code objects in a fresh process)
@@ -198,7 +198,7 @@ struct PbPlacer {
       // GDN_PLACE_OFFSETS=1 (diagnostic, profiles/r05_pb_place_offsets.txt): every candidate is 256 MB longer than the array and is
       // timed at several offsets inside itself as well -- does a placement's speed belong to the ALLOCATION (its pages) or to
       // the ADDRESS (an interleaving of its bits)?
-      const bool probe_offsets = gdn_option("GDN_PLACE_OFFSETS") != nullptr;
+      const bool probe_offsets = gdn_xoption("GDN_PLACE_OFFSETS") != nullptr;
       const size_t slack = probe_offsets ? ((size_t)256 << 20) / sizeof(T) : 0;
       // (optional: never at the price of the scratch cache or of more than half of the free memory; when memory is
       // short the oldest held candidates go first, and a search that still finds none ends without an error)
@@ -236,7 +236,7 @@ struct PbPlacer {
       if (cur < best * 0.997) best = cur;
       else buf.swap(*cand);
     }
-    if (gdn_option("GDN_PLACE_OFFSETS") && rc == GDN_OK) {
+    if (gdn_xoption("GDN_PLACE_OFFSETS") && rc == GDN_OK) {
       // ... and is it a property of the allocation at all, or of the MOMENT it was timed in?  Every candidate still held is
       // timed once more, now that the search is over (seconds after the first ones were timed)
       for (size_t i = 0; i < held.size() && rc == GDN_OK; i++) {

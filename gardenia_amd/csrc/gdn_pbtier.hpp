@@ -843,8 +843,8 @@ pt_sizes_from_ptr_kernel(const eoff_t *__restrict__ ptr, unsigned n, eoff_t *__r
 // GDN_ERR_UNSUPPORTED-like: returns 1 (positive) when the shape is outside the limits above and nothing was built
 static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   const auto t_begin = std::chrono::steady_clock::now();
-  const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
-  const bool stable = gdn_option("GDN_PT_STABLE") != nullptr;  // ranks by ballot matching (see pt_partition)
+  const bool trace = gdn_xoption("GDN_PB_TRACE") != nullptr;
+  const bool stable = gdn_xoption("GDN_PT_STABLE") != nullptr;  // ranks by ballot matching (see pt_partition)
   auto t_last = t_begin;
   auto phase = [&](const char *name) {  // GDN_PB_TRACE: wall time of every phase (synchronises: the timings perturb)
     if (!trace) return;
@@ -1884,7 +1884,7 @@ static int po_choose_tiers(const unsigned *h_log, const unsigned *h_lin, unsigne
 // GDN_OK; 1 = outside the limits (nothing built)
 static int pb_build_out_tiered(const PbOutArgs &a, PbPlan &p, DevBuf<float> &Wp, PbOutTiers &ts) {
   const auto t_begin = std::chrono::steady_clock::now();
-  const bool trace = gdn_option("GDN_PB_TRACE") != nullptr;
+  const bool trace = gdn_xoption("GDN_PB_TRACE") != nullptr;
   auto t_last = t_begin;
   auto phase = [&](const char *name) {
     if (!trace) return;

@@ -167,9 +167,15 @@ struct PrOp {
 // contributions a launch gathers from stay in the XCDs' L2s, the running sum and the cursor of a row wait in memory between
 // launches.  A row of 1.3 M in-edges is then ~60 short segments instead of one 5 ms chain.  Rows of <= PR_REF_SHORT edges
 // are summed whole by launch 0.
+#ifdef GDN_EXPERIMENTS
+#define PR_REF_DBG(bit) (dbg & (bit))
+#else
+#define PR_REF_DBG(bit) false
+#endif
 #define PR_REF_N 8                       // elements per lane and block
 #define PR_REF_BLOCK (64 * PR_REF_N)     // 512 elements per wave step
 #define PR_REF_SHORT PR_REF_BLOCK
+#define PR_REF_DEPTH 1                   // blocks of contributions in flight per wave (pr_refseg_kernel)
 struct PrRefRows {
   const uint32_t *__restrict__ row;   // state row of selected row i (sorted by in-degree, descending)
   const uint32_t *__restrict__ deg;   // its in-degree
@@ -177,6 +183,7 @@ struct PrRefRows {
   const uint32_t *__restrict__ cols;  // column ids in the plan's vertex space, ascending per row
   uint32_t *__restrict__ sum;         // running sum (bit pattern); after the last launch: the row's sum
   uint32_t *__restrict__ pos;         // entries of the row already added
+  const float *__restrict__ zero;     // a +0.0f of the plan's own (what entries that do not count load)
   uint32_t n;                         // selected rows
   uint32_t n_long;                    // of them longer than PR_REF_SHORT (the first n_long)
 };
@@ -184,7 +191,8 @@ struct PrRefRows {
 // launch `g`: every long row adds its entries with column < limit (and >= the previous launch's limit: cols ascend);
 // launch 0 also takes the short rows whole.  One wave per row.
 __global__ void __launch_bounds__(GDN_BLOCK)
-pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip) {
+pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip,
+                 int dbg = 0 /* GDN_EXPERIMENTS: 1 = no scan, 2 = no gather (timing only, wrong sums) */) {
   if (skip && *skip) return;
   const unsigned lane = gdn_lane();
   const uint64_t i = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
@@ -196,42 +204,77 @@ pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restri
   if (p >= deg) return;
   typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
   const pr_u32x4 *__restrict__ C4 = reinterpret_cast<const pr_u32x4 *>(rr.cols + rr.off[i]);
-  uint32_t j0 = p & ~(uint32_t)(PR_REF_BLOCK - 1);  // block of the cursor (blocks are aligned inside the row: 16-byte loads)
-  uint32_t x[PR_REF_N], nx[PR_REF_N];
-  // entries of block j0 that count: cursor <= j < deg and column < lim; the rest reads as +0 (the identity of the scan)
-  auto load = [&](uint32_t jb, uint32_t (&v)[PR_REF_N], unsigned &taken, bool &more) {
-    const uint32_t j = jb + lane * PR_REF_N;
-    pr_u32x4 c0 = {0u, 0u, 0u, 0u}, c1 = {0u, 0u, 0u, 0u};
-    if (j < deg) {  // (rows are padded to multiples of 8 entries)
-      c0 = __builtin_nontemporal_load(C4 + (j >> 2));
-      c1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
-    }
+  // Blocks of PR_REF_BLOCK entries, aligned inside the row (16-byte loads).  A row's blocks are a CHAIN -- the running sum --
+  // so what a block costs must be its scan, not its memory round trips: straight-line loads (no branch around a load: the
+  // compiler then counts vmcnt instead of draining it).  Loads past the row's end read the next rows' ids (ref_cols carries
+  // the slack), gathers of entries that do not count read contrib_in[0]; both are masked.
+  uint32_t jb = p & ~(uint32_t)(PR_REF_BLOCK - 1);  // block of the cursor
+  auto load_cols = [&](uint32_t j0, pr_u32x4 &c0, pr_u32x4 &c1) {
+    const uint32_t j = j0 + lane * PR_REF_N;
+    c0 = __builtin_nontemporal_load(C4 + (j >> 2));
+    c1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
+  };
+  // the contributions of block j0 (as bit patterns; +0 for entries that do not count: in front of the cursor, behind the row's
+  // end, or of a later group), how many count, and whether the row goes on behind this block
+  auto gather = [&](uint32_t j0, const pr_u32x4 &c0, const pr_u32x4 &c1, uint32_t (&v)[PR_REF_N], unsigned &taken, bool &more) {
+    const uint32_t j = j0 + lane * PR_REF_N;
     const uint32_t c[PR_REF_N] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    unsigned mine = 0, beyond = 0;
+    // an interior block -- behind the cursor, in front of the row's end, its LAST id (ids ascend) inside this launch's group:
+    // every entry counts, nothing to test per entry
+    const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c1.w, 63);
+    if (j0 >= p && j0 + PR_REF_BLOCK <= deg && c_last < lim) {
+#pragma unroll
+      for (int k = 0; k < PR_REF_N; k++) v[k] = PR_REF_DBG(2) ? c[k] >> 9 : __float_as_uint(contrib_in[c[k]]);
+      taken = PR_REF_BLOCK;
+      more = j0 + PR_REF_BLOCK < deg;
+      return;
+    }
+    unsigned beyond = 0;
+    bool ok[PR_REF_N];
+    taken = 0;
 #pragma unroll
     for (int k = 0; k < PR_REF_N; k++) {
       const bool in_row = j + (uint32_t)k >= p && j + (uint32_t)k < deg;
-      const bool ok = in_row && c[k] < lim;
-      v[k] = ok ? __float_as_uint(contrib_in[c[k]]) : 0u;
-      mine += ok ? 1u : 0u;
-      beyond += (in_row && !ok) ? 1u : 0u;
+      ok[k] = in_row && c[k] < lim;
+      // (an entry that does not count loads the plan's own +0: nothing is done to a loaded value before the scan needs it, so
+      // the load can stay in flight across the scans of the blocks in front -- a select BEHIND the load would wait for it here)
+      const float *src = ok[k] ? contrib_in + c[k] : rr.zero;
+      v[k] = __float_as_uint(*src);
+      taken += (unsigned)__popcll(__ballot(ok[k]));  // (scalar: a ballot and a bit count)
+      beyond += (in_row && !ok[k]) ? 1u : 0u;
     }
-    taken = (unsigned)gdn_wave_sum((unsigned long long)mine);
-    more = __ballot(beyond != 0u) == 0ull && jb + PR_REF_BLOCK < deg;  // nothing of this block lies past the limit, and the row goes on
+    more = __ballot(beyond != 0u) == 0ull && j0 + PR_REF_BLOCK < deg;
   };
-  unsigned taken, ntaken = 0;
-  bool more, nmore = false;
-  load(j0, x, taken, more);
-  for (;;) {
-    if (more) load(j0 + PR_REF_BLOCK, nx, ntaken, nmore);  // the next block's gathers fly while this one is scanned
-    if (taken) S = seq_block<PR_REF_N>(S, x, lane);
-    p += taken;
-    if (!more) break;
-    j0 += PR_REF_BLOCK;
+  // Software pipeline of depth D: while block k is scanned, the contributions of blocks k + 1 .. k + D - 1 are in flight and
+  // those of block k + D are requested; the column ids run 2 D blocks ahead -- vmcnt retires in issue order, so the ids a
+  // gather needs must be OLDER than the gathers that are to stay in flight across it.  (Measured with D = 1: 2 us per block
+  // of a chain whose scan takes 0.6 -- the longest row's 1 763 blocks were 4 of the 5 ms of a re-sum.)  The main loop is
+  // unrolled over the 2 D ring slots so that every register index is a constant.
+  constexpr int D = PR_REF_DEPTH;
+  pr_u32x4 c[2 * D][2];
+  uint32_t v[D][PR_REF_N];
+  unsigned tk[D];
+  bool mr[D];
 #pragma unroll
-    for (int k = 0; k < PR_REF_N; k++) x[k] = nx[k];
-    taken = ntaken;
-    more = nmore;
+  for (int b = 0; b < 2 * D; b++) load_cols(jb + (uint32_t)b * PR_REF_BLOCK, c[b][0], c[b][1]);
+#pragma unroll
+  for (int b = 0; b < D; b++) gather(jb + (uint32_t)b * PR_REF_BLOCK, c[b][0], c[b][1], v[b], tk[b], mr[b]);
+  bool done = false;
+  while (!done) {
+#pragma unroll
+    for (int sl = 0; sl < 2 * D; sl++) {
+      if (!done) {
+        const int vs = sl % D;
+        if (PR_REF_DBG(1)) S ^= v[vs][0] + v[vs][7];
+        else if (tk[vs]) S = seq_block<PR_REF_N>(S, v[vs], lane);
+        p += tk[vs];
+        done = !mr[vs];
+        // block k + D into the slot just scanned, from the ids of ring slot (sl + D) mod 2 D; then the ids of block k + 2 D
+        gather(jb + (uint32_t)D * PR_REF_BLOCK, c[(sl + D) % (2 * D)][0], c[(sl + D) % (2 * D)][1], v[vs], tk[vs], mr[vs]);
+        load_cols(jb + (uint32_t)(2 * D) * PR_REF_BLOCK, c[sl][0], c[sl][1]);
+        jb += PR_REF_BLOCK;
+      }
+    }
   }
   if (lane == 0) {
     rr.sum[i] = S;
@@ -711,7 +754,7 @@ static int pr_solve_fused(const gdn_graph *g, const int32_t *d_deg, float *d_sco
   *done = 0;
   const int32_t m = g->m;
   unsigned small_m = 1024;  // measured (R-MAT, 16 edges per vertex): 10 us per iteration at 2^10 vertices, the grid form wins from 2^12 on
-  if (const char *e = gdn_option("GDN_PR_SMALL_M")) small_m = (unsigned)std::min(atoi(e), PR_SMALL_M);  // tuning / test knob
+  if (const char *e = gdn_test_option("GDN_PR_SMALL_M")) small_m = (unsigned)std::min(atoi(e), PR_SMALL_M);  // tuning / test knob
   const bool one_wg = (unsigned)m <= small_m;
   unsigned blocks = 1;
   if (one_wg) {
@@ -842,8 +885,8 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   // and the knobs the new builder does not serve (8-bit rows, hub rows, no compaction) take one pb_build per layout.
   bool tiered_builder = true;
   {
-    const char *be = gdn_option("GDN_PB_BUILDER"), *ve = gdn_option("GDN_PB_V8"), *re = gdn_option("GDN_PB_HUB_ROWS"),
-               *ce = gdn_option("GDN_PB_COMPACT");
+    const char *be = gdn_option("GDN_PB_BUILDER"), *ve = gdn_test_option("GDN_PB_V8"), *re = gdn_test_option("GDN_PB_HUB_ROWS"),
+               *ce = gdn_test_option("GDN_PB_COMPACT");
     if ((be && be[0] == 'o') || (ve && ve[0] == '1') || (re && re[0] == '1') || (ce && ce[0] == '0')) tiered_builder = false;
   }
   const gdn_graph *raw_csr = in_csr;  // the caller's graph (a squished plan relabels rows and columns)
@@ -902,30 +945,30 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
     int slices_log = in_csr->m == m_global ? 9 : 10;
-    if (const char *e = gdn_option("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    if (const char *e = gdn_xoption("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
     int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK, slices_log), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN, slices_log);
-    if (const char *e = gdn_option("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
-    if (const char *e = gdn_option("GDN_PB_LOG_BIN")) lb = atoi(e);
+    if (const char *e = gdn_test_option("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)
+    if (const char *e = gdn_xoption("GDN_PB_LOG_BIN")) lb = atoi(e);
     // vertex compaction on by default (GDN_PB_COMPACT=0 switches it off for A/B measurements)
-    const char *ce = gdn_option("GDN_PB_COMPACT");
+    const char *ce = gdn_test_option("GDN_PB_COMPACT");
     // tiles padded to 32 edges = whole 128-byte lines of vals (a line shared by two tiles is written by two
     // workgroups at different times: measured 3.9 -> 3.0 ms for phase A on RMAT-27), one G entry per 32 edges
     unsigned pad = 32;
     int lg = 5;
-    if (const char *e = gdn_option("GDN_PB_PAD")) pad = (unsigned)atoi(e);
-    if (const char *e = gdn_option("GDN_PB_LOG_GROUP")) lg = atoi(e);
+    if (const char *e = gdn_xoption("GDN_PB_PAD")) pad = (unsigned)atoi(e);
+    if (const char *e = gdn_xoption("GDN_PB_LOG_GROUP")) lg = atoi(e);
     const bool compact = !(ce && ce[0] == '0');
     // 8-bit delta-coded rows (PbPlan::v8) are OFF by default: they save 0.94 B/edge of phase B's reads but the decode
     // (3 DPP steps + unpack per quad) cost more than that on RMAT-27 (B 3.0 -> 3.5 ms); GDN_PB_V8=1 builds them
-    const char *ve = gdn_option("GDN_PB_V8");
+    const char *ve = gdn_test_option("GDN_PB_V8");
     const bool v_delta = pad >= 32 && ve && ve[0] == '1';
     DevBuf<uint8_t> cls;
     PbScratch scratch;  // the key buffers of the (up to four) layout builds below
-    const char *he = gdn_option("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
+    const char *he = gdn_test_option("GDN_PB_HUBS");  // 0 switches the hub tier off (A/B measurements)
     st = GDN_OK;
     uint64_t hub_min_nnz = 1ull << 24;  // below this the second layout does not pay for itself
-    if (const char *e = gdn_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
-    const char *me = gdn_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    if (const char *e = gdn_test_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    const char *me = gdn_test_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
     int max_mid = me ? atoi(me) : PB_MAX_MID;
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
@@ -951,8 +994,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       // (2^13 rows and fewer) are spread over whole rounds of workgroups as well -- RMAT-27 / 8: 793 bins = 3.1 rounds in the
       // time of 4 (profiles/r06_shard_compute.md)
       {
-        const char *be = gdn_option("GDN_PB_BALANCE_SHARDS");
-        if (!(be && be[0] == '0')) ta.bin_balance_log = lb;
+        // (measured in round 6, RMAT-27 / 8: 1024 bins instead of 793 -- accumulate phase 0.39-0.46 -> 0.43-0.46 ms: no gain, the
+        // rounds are uneven because the BINS are; opt-in)
+        const char *be = gdn_xoption("GDN_PB_BALANCE_SHARDS");
+        if (be && be[0] == '1') ta.bin_balance_log = lb;
       }
       ta.pad = pad;
       ta.log_group = lg;
@@ -960,9 +1005,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       ta.max_mid = max_mid;
       ta.min16 = 1u;
       {  // mid-tier record streams in lane-interleaved blocks (a quarter of phase B's record loads); GDN_PB_REC_IL=0: plain
-        const char *ie = gdn_option("GDN_PB_REC_IL");
+        const char *ie = gdn_test_option("GDN_PB_REC_IL");
         ta.interleave = !(ie && ie[0] == '0');
-        const char *ve = gdn_option("GDN_PB_V_IL");  // the same for the main stream's rows (PbPlan::v_il); 0: plain
+        const char *ve = gdn_test_option("GDN_PB_V_IL");  // the same for the main stream's rows (PbPlan::v_il); 0: plain
         ta.v_interleave = !(ve && ve[0] == '0');
       }
       int rc = pb_build_tiered_run(ta, p->pb, ts);
@@ -1024,7 +1069,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     DevBuf<uint8_t> dcls;
     // OFF by default (GDN_PB_HUB_ROWS=1 builds it): it takes 1.1 GB out of an iteration (phase B -0.2 ms) but phase A
     // pays the same back -- any wave of a CU that folds instead of streaming lowers the CU's bytes in flight
-    const char *re = gdn_option("GDN_PB_HUB_ROWS");
+    const char *re = gdn_test_option("GDN_PB_HUB_ROWS");
     const unsigned lds_static = 8704;             // s_bits + s_pref + s_scr of pb_expand_kernel, rounded up
     unsigned slots_assumed = 1u << lc;
     if (st == GDN_OK && compact && lc == PB_MAX_LOG_CHUNK && in_csr->nnz >= hub_min_nnz && re && re[0] == '1') {
@@ -1165,7 +1210,7 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
     return st;
   }
 #ifdef GDN_EXPERIMENTS  // GDN_PB_UNCACHED (A/B): bit0 record streams, bit1 V, bit2 vals, bit3 U + G in uncached memory
-  if (const char *e = gdn_option("GDN_PB_UNCACHED")) {
+  if (const char *e = gdn_xoption("GDN_PB_UNCACHED")) {
     const int mask = atoi(e);
     int rc2 = GDN_OK;
     if (layout != GDN_LAYOUT_CSR) {
@@ -1185,9 +1230,9 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   }
   // GDN_PB_VMM=<MiB>: vals (bit0 of GDN_PB_VMM_WHAT, default), U + G (bit1), V (bit2), record streams (bit3) re-homed into
   // ranges of shuffled physical chunks of that size
-  if (const char *e = gdn_option("GDN_PB_VMM")) {
+  if (const char *e = gdn_xoption("GDN_PB_VMM")) {
     const size_t chunk = (size_t)atoi(e) << 20;
-    const char *w = gdn_option("GDN_PB_VMM_WHAT");
+    const char *w = gdn_xoption("GDN_PB_VMM_WHAT");
     const int what = w ? atoi(w) : 1;
     int rc2 = GDN_OK;
     if (chunk && layout != GDN_LAYOUT_CSR) {
@@ -1223,17 +1268,33 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
       }
     }
   }
+  // a block reserved at the start of the process (gdn_dev_reserve) becomes the plan's `vals` (scratch of one iteration: no copy)
+  if (p->layout != GDN_LAYOUT_CSR && p->pb.vals.p) {
+    if (void *r = gdn_reserve_take(p->pb.vals.n * sizeof(float))) {
+      if (hipMemset(r, 0, p->pb.vals.n * sizeof(float)) == hipSuccess) {  // (alignment gaps between bins must read as zero)
+        DevBuf<float> nb;
+        nb.base = r;
+        nb.p = static_cast<float *>(r);
+        nb.n = p->pb.vals.n;
+        p->pb.vals.swap(nb);
+        if (gdn_option("GDN_PR_PLACE_TRACE")) fprintf(stderr, "[pr place] vals lives in the block reserved at process start (%p)\n", r);
+      } else {
+        (void)hipGetLastError();
+        (void)hipFree(r);
+      }
+    }
+  }
   // placement search (pr_plan_place).  GDN_PR_PLACE=<tries per array> (0 = off)
   // from 3 x 2^28 edges on: RMAT-26 (1.06 G edges) gains 4 % (1.93 -> 1.85 ms), RMAT-25 and RMAT-24 plans show no spread at all
   // (0.93 / 0.45 ms wherever they lie, profiles/r03_pb_placement.txt) -- it comes with allocations of several GB
   unsigned long long place_from = 3ull << 28;
-  if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
+  if (const char *e = gdn_test_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
   if (p->layout != GDN_LAYOUT_CSR && p->nnz >= place_from && !g_pr_no_place) {
     int tries = 3;
     if (const char *e = gdn_option("GDN_PR_PLACE")) tries = atoi(e);
     if (tries > 0) {
       double budget = 800.0;  // ms (vals: ~0.2 s for 12 candidates; the copies of phase B's streams take the rest)
-      if (const char *e = gdn_option("GDN_PR_PLACE_BUDGET_MS")) budget = atof(e);  // (measurement sessions)
+      if (const char *e = gdn_xoption("GDN_PR_PLACE_BUDGET_MS")) budget = atof(e);  // (measurement sessions)
       const int rcp = pr_plan_place(p, tries, budget);
       if (rcp != GDN_OK) {
         delete p;
@@ -1485,6 +1546,7 @@ static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipSt
   rr.cols = plan->ref_cols.p;
   rr.sum = plan->ref_sumbits.p;
   rr.pos = plan->ref_pos.p;
+  rr.zero = reinterpret_cast<const float *>(plan->ref_partial.p + PR_REF_DIFF_BLOCKS);  // (a zeroed double behind the partial sums)
   rr.n = plan->ref_n;
   rr.n_long = plan->ref_n_long;
   const uint64_t space = (uint64_t)plan->m_global;  // the index space of contrib_in
@@ -1493,7 +1555,7 @@ static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipSt
     const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
     const uint32_t limit = g + 1 == ngroups ? 0xFFFFFFFFu : (uint32_t)((uint64_t)(g + 1) << plan->ref_glog);
     hipLaunchKernelGGL(pr_refseg_kernel, dim3((nrows + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, g, limit,
-                       op.contrib_in, op.skip);
+                       op.contrib_in, op.skip, gdn_xoption("GDN_PR_REF_DBG") ? atoi(gdn_xoption("GDN_PR_REF_DBG")) : 0);
   }
   hipLaunchKernelGGL(pr_ref_apply_kernel, dim3(PR_REF_DIFF_BLOCKS), dim3(GDN_BLOCK), 0, s, plan->ref_row.p, plan->ref_sumbits.p,
                      plan->ref_old.p, plan->ref_n, op.scores, op.contrib_out, op.out_degree, op.base_score, op.damping,
@@ -1530,7 +1592,8 @@ static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap
   GDN_TRY(p->ref_sumbits.alloc(n));
   GDN_TRY(p->ref_pos.alloc(n));
   GDN_TRY(p->ref_old.alloc(n));
-  GDN_TRY(p->ref_partial.alloc(PR_REF_DIFF_BLOCKS));
+  GDN_TRY(p->ref_partial.alloc(PR_REF_DIFF_BLOCKS + 2));
+  GDN_HIP(hipMemset(p->ref_partial.p, 0, (PR_REF_DIFF_BLOCKS + 2) * sizeof(double)));
   GDN_TRY(padded.alloc_scratch(n));
   hipLaunchKernelGGL(pr_ref_rows_kernel, dim3(gdn_nblocks((uint64_t)n)), dim3(GDN_BLOCK), 0, 0, sorted, n, p->ref_row.p, p->ref_deg.p, padded.p);
   GDN_HIP(hipGetLastError());
@@ -1541,13 +1604,13 @@ static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap
   GDN_HIP(hipMemcpy(&longest, p->ref_deg.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
   p->ref_edges = total;
   p->ref_longest = longest;
-  GDN_TRY(p->ref_cols.alloc((size_t)total + 8));
+  GDN_TRY(p->ref_cols.alloc((size_t)total + (3 * PR_REF_DEPTH + 2) * PR_REF_BLOCK + 8));  // (the sum kernel's loads run up to 3 D blocks past a row)
   hipLaunchKernelGGL(pr_ref_cols_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->colidx, row_ids, cmap, p->ref_row.p, p->ref_deg.p,
                      p->ref_off.p, n, p->ref_cols.p);
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());
   if (const char *e = gdn_option("GDN_PR_SUM_GROUP_LOG")) p->ref_glog = atoi(e) >= 10 && atoi(e) <= 31 ? atoi(e) : p->ref_glog;
-  if (gdn_option("GDN_PR_SUM_TRACE"))
+  if (gdn_xoption("GDN_PR_SUM_TRACE"))
     fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u longer than %d), %llu entries, longest %u, groups of 2^%d sources\n", p->ref_n,
             p->ref_min_deg, p->ref_n_long, PR_REF_SHORT, (unsigned long long)total, longest, p->ref_glog);
   return GDN_OK;
@@ -1598,7 +1661,7 @@ static int pr_pull_impl(gdn_pr_plan *plan, const float *d_contrib_in, float *d_s
     if (timed) GDN_HIP(hipEventRecord(pb.ev[pb.ev_used], s));
     static unsigned split = 0;
     if (split == 0) {
-      const char *e = gdn_option("GDN_PB_SPLIT");
+      const char *e = gdn_xoption("GDN_PB_SPLIT");
       split = e ? (unsigned)atoi(e) : 1u;  // measured on RMAT-27: 1 -> 4.14 ms, 2 -> 4.23, 4 -> 4.53 (slice reload)
       if (split < 1 || split > 64) split = 1;
     }
@@ -1621,7 +1684,7 @@ static int pr_pull_impl(gdn_pr_plan *plan, const float *d_contrib_in, float *d_s
                        pb.log_chunk, pb.chunk_ptr.p, pb.chunk_order.p, pb.U.p, pb.G.p, pb.vals.p,
                        pb.compact ? pb.src_bits.p : nullptr, pb.compact ? pb.chunk_lo.p : nullptr, split, pb.log_group,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_AVAR: A/B knobs (bit0 non-temporal stores, bit1 scalar slice loader), same results
-                       gdn_option("GDN_PB_AVAR") ? atoi(gdn_option("GDN_PB_AVAR")) : 0,
+                       gdn_xoption("GDN_PB_AVAR") ? atoi(gdn_xoption("GDN_PB_AVAR")) : 0,
 #else
                        0,
 #endif
@@ -1652,7 +1715,7 @@ static int pr_pull_impl(gdn_pr_plan *plan, const float *d_contrib_in, float *d_s
   }
   mid.v_il = pb.v_il ? 1 : 0;
 #ifdef GDN_EXPERIMENTS  // GDN_PB_MIDVAR: bit t = form of record tier t (A/B measurements; same results)
-  if (const char *e = gdn_option("GDN_PB_MIDVAR"))
+  if (const char *e = gdn_xoption("GDN_PB_MIDVAR"))
     for (int t = 0; t < mid.n; t++)
       if (mid.form[t] != 2) mid.form[t] = (atoi(e) >> t) & 1;  // (an interleaved stream can only be read as form 2)
 #endif
@@ -1666,7 +1729,7 @@ static int pr_pull_impl(gdn_pr_plan *plan, const float *d_contrib_in, float *d_s
                        pb.log_bin, pb.bin_ptr.p, parts ? plan->parts_order.p : (whole ? pb.bin_order.p : nullptr), pb.V.p, pb.vals.p, pb.partial.p,
                        pb.errflag.p, pb.compact ? pb.dst_bits.p : nullptr, pb.compact ? pb.bin_lo.p : nullptr, op,
 #ifdef GDN_EXPERIMENTS  // GDN_PB_DBG: bit0 no LDS atomics, bit1 no epilogue (TIMING ONLY, wrong results), bit2 scalar epilogue
-                       gdn_option("GDN_PB_DBG") ? atoi(gdn_option("GDN_PB_DBG")) : 0,
+                       gdn_xoption("GDN_PB_DBG") ? atoi(gdn_xoption("GDN_PB_DBG")) : 0,
 #else
                        0,
 #endif
@@ -1752,7 +1815,7 @@ int gdn_pr_pull_parts_dev(gdn_pr_plan *plan, const float *d_contrib_in, float *d
   }
   PbParts launch = plan->layout == GDN_LAYOUT_CSR ? inc : plan->parts_launch;
   {  // GDN_PR_TICKET_MODE: fence = an L2 write-back per workgroup, wt = write-through stores of the next contributions (default)
-    const char *e = gdn_option("GDN_PR_TICKET_MODE");
+    const char *e = gdn_xoption("GDN_PR_TICKET_MODE");
     launch.mode = (e && e[0] == 'f') ? 0u : 1u;
   }
   GDN_TRY(pr_pull_impl(plan, d_contrib_in, d_scores, d_contrib_out, d_diff, damping, 0, plan->m_local,
@@ -1887,14 +1950,14 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
     GDN_TRY(gdn_pr_plan_kernel_time(p, 0, 0, tot, &launches));
     if (launches < 1) launches = 1;
     *out_ms = (phase == 0 ? tot[0] : phase == 1 ? tot[1] : tot[0] + tot[1]) / launches;
-    if (pl.trace && gdn_option("GDN_PR_PLACE_TRACE_AB"))  // (both phases of every timed placement, whatever it is judged on)
+    if (pl.trace && gdn_xoption("GDN_PR_PLACE_TRACE_AB"))  // (both phases of every timed placement, whatever it is judged on)
       fprintf(stderr, "[pr place]   phase A %.3f ms, phase B %.3f ms\n", tot[0] / launches, tot[1] / launches);
     return GDN_OK;
   };
   p->placing = true;
   int rc = pl.begin();
   int vals_tries = 4 * tries;  // GDN_PR_PLACE_VALS=<candidates>
-  if (const char *e = gdn_option("GDN_PR_PLACE_VALS")) vals_tries = atoi(e);
+  if (const char *e = gdn_xoption("GDN_PR_PLACE_VALS")) vals_tries = atoi(e);
   phase = 0;
   if (rc == GDN_OK) rc = pl.rebase();
   // (fast blocks run phase A at 1.00-1.01 ms, the others at 1.06-1.18: the search stops at the first candidate 10 % below the
@@ -1903,7 +1966,7 @@ static int pr_plan_place(gdn_pr_plan *p, int tries, double budget_ms) {
   // (0.90, not 0.93: the classes are ~1.14 / 1.06 / 0.99 ms -- the middle one is 7 % below the slowest, only the fast one
   // should end the search early, profiles/r05_pb_place_offsets.txt)
   double stop_ratio = 0.90;  // GDN_PR_PLACE_STOP=0: every candidate is timed (measurement sessions)
-  if (const char *e = gdn_option("GDN_PR_PLACE_STOP")) stop_ratio = atof(e);
+  if (const char *e = gdn_xoption("GDN_PR_PLACE_STOP")) stop_ratio = atof(e);
   if (rc == GDN_OK) rc = pl.search_fresh(p->pb.vals, "vals", vals_tries, 8, stop_ratio);
   // The arrays phase B streams (and U) are searched only on request (GDN_PR_PLACE_COPIES=1; every candidate is a copy, ~40 ms
   // per GB-sized array): timed per phase they gain nothing worth 0.3 s of plan build -- 2.536 -> 2.524 ms and 2.611 -> 2.600 ms
@@ -2059,7 +2122,7 @@ int gdn_pr(int32_t m, uint64_t nnz, const uint64_t *in_rowptr, const int32_t *in
       // every single solve at epsilon 1e-4) -- so the blocked layout wins from ~13 iterations on.  GDN_PR_ONESHOT=solve:
       // "blocked from 2^22 edges on" whatever the iteration count (best solve_ms, the number the reference's Timer prints);
       // GDN_PR_LAYOUT=c / p force a layout, anything else is this choice.
-      const char *os_ = gdn_option("GDN_PR_ONESHOT");
+      const char *os_ = gdn_xoption("GDN_PR_ONESHOT");
       bool pb = nnz >= (1ull << 22);
       {
         double iters = 24.0;

@@ -18,7 +18,9 @@
 //   negative values, inf, nan) takes the hardware path too: the result is the sequential fp32 sum in every case
 //   (tests/test_seqsum_math.py emulates exactly this on the CPU against numpy; tests/test_gpu_parity.py runs the kernel).
 #pragma once
+#include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #ifndef GDN_HD
 #ifdef __HIPCC__
@@ -34,25 +36,28 @@ struct SeqPair {
   uint32_t a0, a1;  // what the segment adds to an integer prefix of even / odd parity
 };
 
-// x (bit pattern) in units of the ulp of a running sum with biased exponent E (1..254): q and whether x sits exactly halfway
+// x (bit pattern) in units of the ulp of a running sum with biased exponent E (1..254): q = x / ulp rounded DOWN to an integer
+// plus 1 when the remainder exceeds one half, tie = the remainder IS one half.  A row's blocks are a chain and what a block
+// costs is this code, so it is float arithmetic that happens to be exact: y = x * 2^(150 - E) is x scaled by a power of two
+// (exact for every finite x: the product of a float and a power of two that neither overflows nor leaves the denormal range;
+// denormal RESULTS could round, but y < 1/2 then and the outcome q = 0, no tie is the same), floor(y) and y - floor(y) are exact.
+//   y not in [0, 2^23) -- x too large for this binade, negative, inf, nan --: q = SEQ_CLAMP, the hardware adds that element.
+// (-0 reads as +0: S + -0 = S for the positive S this is used with.)
 GDN_HD void seq_quant(uint32_t xb, uint32_t E, uint32_t &q, uint32_t &tie) {
-  const uint32_t ex = xb >> 23;  // sign and exponent
-  const uint32_t exn = ex ? ex : 1u;
-  const uint32_t mx = (xb & 0x7FFFFFu) | (ex ? 0x800000u : 0u);
-  const int d = (int)E - (int)exn;
-  tie = 0u;
-  if (ex >= 255u) {  // negative (or -0), inf, nan: the hardware adds it
-    q = SEQ_CLAMP;
-  } else if (d <= 0) {
-    const unsigned long long v = (unsigned long long)mx << (-d > 30 ? 30 : -d);
-    q = v >= SEQ_CLAMP ? SEQ_CLAMP : (uint32_t)v;
-  } else if (d >= 25) {
-    q = 0u;
-  } else {
-    const uint32_t rem = mx & ((1u << d) - 1u), half = 1u << (d - 1);
-    q = (mx >> d) + (rem > half ? 1u : 0u);
-    tie = rem == half ? 1u : 0u;
-  }
+#ifdef __HIP_DEVICE_COMPILE__
+  const float x = __uint_as_float(xb);
+  const float y = __builtin_amdgcn_ldexpf(x, 150 - (int)E);  // v_ldexp_f32
+  const float fl = __builtin_floorf(y), fr = y - fl;
+#else
+  float x;
+  memcpy(&x, &xb, 4);
+  const float y = ldexpf(x, 150 - (int)E);
+  const float fl = floorf(y), fr = y - fl;
+#endif
+  const bool in = y >= 0.0f && y < 8388608.0f;  // (false for nan)
+  const uint32_t qi = (uint32_t)(int)fl + (fr > 0.5f ? 1u : 0u);
+  q = in ? qi : SEQ_CLAMP;
+  tie = (in && fr == 0.5f) ? 1u : 0u;
 }
 
 // the segment followed by one element
@@ -91,12 +96,35 @@ __device__ __forceinline__ uint32_t seq_block(uint32_t S, const uint32_t (&x)[N]
           seq_push(p, q, tie);
         }
       }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {  // inclusive scan under composition
-        SeqPair f;
-        f.a0 = (uint32_t)__shfl_up((int)p.a0, o, 64);
-        f.a1 = (uint32_t)__shfl_up((int)p.a1, o, 64);
-        if (lane >= (unsigned)o) p = seq_compose(f, p);
+      // inclusive scan under composition: inside the rows of 16 lanes by DPP row_shr (a lane without a source reads the pair
+      // (0, 0) = the identity -- no select), across the four rows through the rows' totals in scalar registers
+#define SEQ_ROW_STEP(CTRL)                                                                       \
+  {                                                                                              \
+    SeqPair f;                                                                                   \
+    f.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a0, CTRL, 0xf, 0xf, true);            \
+    f.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a1, CTRL, 0xf, 0xf, true);            \
+    p = seq_compose(f, p);                                                                       \
+  }
+      SEQ_ROW_STEP(0x111)  // row_shr:1
+      SEQ_ROW_STEP(0x112)  // row_shr:2
+      SEQ_ROW_STEP(0x114)  // row_shr:4
+      SEQ_ROW_STEP(0x118)  // row_shr:8
+#undef SEQ_ROW_STEP
+      {
+        SeqPair t0, t1, t2;
+        t0.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 15);
+        t0.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 15);
+        t1.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 31);
+        t1.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 31);
+        t2.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 47);
+        t2.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 47);
+        const SeqPair t01 = seq_compose(t0, t1), t012 = seq_compose(t01, t2);
+        const unsigned row = lane >> 4;
+        SeqPair f = {0u, 0u};
+        f = row == 1u ? t0 : f;
+        f = row == 2u ? t01 : f;
+        f = row == 3u ? t012 : f;
+        p = seq_compose(f, p);
       }
       const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
       const uint32_t tot = P0 + ((P0 & 1u) ? p.a1 : p.a0);

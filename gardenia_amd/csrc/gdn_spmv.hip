@@ -234,23 +234,23 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
     // compacted like PageRank's layout (columns that occur / rows that have entries), rows of whole 128-byte lines;
     // GDN_PB_COMPACT=0 / GDN_PB_HUBS=0 switch the two refinements off (A/B measurements)
     int slices_log = csr->m == n_cols ? 9 : 10;
-    if (const char *e = gdn_option("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
+    if (const char *e = gdn_xoption("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
     const int lc = spmv_pick_log(n_cols, PB_MAX_LOG_CHUNK, slices_log), lb = spmv_pick_log(csr->m, PB_MAX_LOG_BIN, slices_log);
-    const char *ce = gdn_option("GDN_PB_COMPACT"), *he = gdn_option("GDN_PB_HUBS"), *ve = gdn_option("GDN_PB_V8");
+    const char *ce = gdn_test_option("GDN_PB_COMPACT"), *he = gdn_test_option("GDN_PB_HUBS"), *ve = gdn_test_option("GDN_PB_V8");
     const bool compact = !(ce && ce[0] == '0');
     const bool v_delta = ve && ve[0] == '1';  // off by default, see gdn_pr.hip
     uint64_t hub_min_nnz = 1ull << 24;
-    if (const char *e = gdn_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
+    if (const char *e = gdn_test_option("GDN_PB_HUB_MIN_NNZ")) hub_min_nnz = strtoull(e, nullptr, 10);  // test knob
     DevBuf<uint8_t> cls;
     PbScratch scratch;  // the key buffers of the layout builds below
     st = GDN_OK;
-    const char *me = gdn_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
+    const char *me = gdn_test_option("GDN_PB_MID");  // number of mid tiers (0 switches them off; A/B measurements)
     int max_mid = me ? atoi(me) : 2;  // two here (PageRank takes PB_MAX_MID): an SpMV record carries its Ax, 8 B per edge
     if (max_mid < 0 || lb > PB_MID_ROW_BITS) max_mid = 0;
     DevBuf<uint32_t> mid_ids[PB_MAX_MID];
     unsigned n_mid[PB_MAX_MID] = {};
     // phase B's streams in lane-interleaved blocks (gdn_pb.hpp: PbPlan::v_il, PbMidArgs::form 2); GDN_PB_V_IL=0 / GDN_PB_REC_IL=0: plain
-    const char *vie = gdn_option("GDN_PB_V_IL"), *rie = gdn_option("GDN_PB_REC_IL");
+    const char *vie = gdn_test_option("GDN_PB_V_IL"), *rie = gdn_test_option("GDN_PB_REC_IL");
     const bool il_v = !(vie && vie[0] == '0') && !v_delta, il_streams = !(rie && rie[0] == '0');
     const bool want_tiers = compact && csr->nnz >= hub_min_nnz && !(he && he[0] == '0');
     // Round 4: the main layout, the record tiers and the values' places in both from ONE gather pass and LDS-staged splits
@@ -394,7 +394,7 @@ int gdn_spmv_plan_create_cols(const gdn_graph *csr, const float *d_Ax, int32_t n
   // placement search (PbPlacer, gdn_pb.hpp) from 3 x 2^28 non-zeros on: three multiplies on scratch vectors per candidate.
   // GDN_SPMV_PLACE=<tries per array> (0 = off)
   unsigned long long place_from = 3ull << 28;  // (as for PageRank, gdn_pr.hip: below, plans show no placement spread)
-  if (const char *e = gdn_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
+  if (const char *e = gdn_test_option("GDN_PLACE_MIN_EDGES")) place_from = strtoull(e, nullptr, 10);  // (tests force the search)
   if (st == GDN_OK && p->layout == GDN_LAYOUT_PB && csr->nnz >= place_from && !g_spmv_no_place) {
     int tries = 3;
     if (const char *e = gdn_option("GDN_SPMV_PLACE")) tries = atoi(e);

@@ -1516,9 +1516,9 @@ static int sssp_build_tiers(gdn_sssp_plan &p, const gdn_graph *g, const int32_t 
   // 64: three tiers, 80 %, 3.33 -- phase B is bound by the issue side of the memory pipeline then, not by bytes;
   // profiles/r03_sssp_tiers.txt)
   unsigned min_deg = nbins / 4u < 8u ? 8u : nbins / 4u;
-  if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;  // test / tuning knob
+  if (const char *e = gdn_test_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;  // test / tuning knob
   int max_tiers = SSSP_MAX_TIERS;
-  if (const char *e = gdn_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
+  if (const char *e = gdn_test_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
   if (max_tiers <= 0 || m < 2) return GDN_OK;
   DevBuf<unsigned long long> ka, kb;
   GDN_TRY(ka.alloc((size_t)m));
@@ -1620,7 +1620,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
   if (dense && g->nnz > 0) {
     int lg = 10;
     while (lg < 15 && ((int64_t)1 << (lg + 9)) < (int64_t)m) lg++;
-    if (const char *e = gdn_option("GDN_SSSP_LOG")) lg = atoi(e) >= 10 && atoi(e) <= 15 ? atoi(e) : lg;  // tuning knob
+    if (const char *e = gdn_xoption("GDN_SSSP_LOG")) lg = atoi(e) >= 10 && atoi(e) <= 15 ? atoi(e) : lg;  // tuning knob
     // tiles padded so that a tile's candidates are whole 128-byte lines (a line shared by two tiles is written by two
     // workgroups at different times): 128 edges (u8 candidates) where tiles are long, 32 where the padding
     // would cost more than the partial lines
@@ -1635,7 +1635,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       GDN_HIP(hipMemcpy(h, rng.p, 8, hipMemcpyDeviceToHost));
       p.w_min = h[0];
       p.w_max = h[1];
-      const char *e = gdn_option("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
+      const char *e = gdn_test_option("GDN_SSSP_WBYTES");  // test / measurement knob: 4 keeps the int32 stream
       const int force = e ? atoi(e) : -1;
       if (p.w_min < 0) p.w_bytes = 4;  // negative weights: not narrowed (the solvers assume none, like the reference)
       else if (p.w_min == p.w_max && force < 0) p.w_bytes = 0;
@@ -1647,13 +1647,13 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     DevBuf<uint8_t> cls;
     int lb = lg;
     unsigned long long tiers_from = 1ull << 22;
-    if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_NNZ")) tiers_from = strtoull(e, nullptr, 10);  // (tests)
+    if (const char *e = gdn_test_option("GDN_SSSP_TIER_MIN_NNZ")) tiers_from = strtoull(e, nullptr, 10);  // (tests)
     const bool want_tiers = p.w_bytes <= 1 && p.w_min >= 0 && g->nnz >= tiers_from;
     bool built = false;
     {
       // round 4: the blocked layout and the record tiers from one counting pass and one two-level split over the edges
       // (pb_build_out_tiered, gdn_pbtier.hpp); GDN_PB_BUILDER=old: pb_build's sort of 8-byte keys + sssp_build_tiers
-      const char *be = gdn_option("GDN_PB_BUILDER"), *pe = gdn_option("GDN_SSSP_PAD");
+      const char *be = gdn_option("GDN_PB_BUILDER"), *pe = gdn_test_option("GDN_SSSP_PAD");
       if (!(be && be[0] == 'o')) {
         PbOutArgs oa;
         PbOutTiers ot;
@@ -1665,16 +1665,16 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
         oa.log_group = 3;
         const unsigned nbins = (unsigned)(((uint64_t)m + (1u << lb) - 1) >> lb);
         unsigned min_deg = nbins / 4u < 8u ? 8u : nbins / 4u;  // a quarter of an edge per bin (profiles/r03_sssp_tiers.txt)
-        if (const char *e = gdn_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;
+        if (const char *e = gdn_test_option("GDN_SSSP_TIER_MIN_DEG")) min_deg = atoi(e) > 0 ? (unsigned)atoi(e) : min_deg;
         int max_tiers = SSSP_MAX_TIERS;
-        if (const char *e = gdn_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
+        if (const char *e = gdn_test_option("GDN_SSSP_TIERS")) max_tiers = atoi(e) < SSSP_MAX_TIERS ? atoi(e) : SSSP_MAX_TIERS;
         oa.max_tiers = (want_tiers && m >= 2 && max_tiers > 0) ? max_tiers : 0;
         oa.tier_min_deg = min_deg;
         oa.caps[0] = SSSP_TIER0;
         for (int t = 1; t < PB_MAX_REC_TIERS; t++) oa.caps[t] = SSSP_TIER_N;
         oa.want_w8 = p.w_bytes == 1;
         {  // lane-interleaved record streams (a quarter of phase B's record and weight loads); GDN_SSSP_REC_IL=0: plain
-          const char *ie = gdn_option("GDN_SSSP_REC_IL");
+          const char *ie = gdn_test_option("GDN_SSSP_REC_IL");
           oa.interleave = !(ie && ie[0] == '0');
         }
         const int rc = pb_build_out_tiered_run(oa, p.pb, p.Wp, ot);
@@ -1708,7 +1708,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       // (64 against 32: RMAT-25 8.4 against 8.7 ms, RMAT-26 12.7 / 13.3, RMAT-27 -- 127 edges per tile -- 25.2 / 26.6,
       // profiles/r03_sssp_layout_knobs.txt)
       unsigned pad = avg_tile >= 1024.0 ? 128u : avg_tile >= 96.0 ? 64u : 32u;
-      if (const char *e = gdn_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
+      if (const char *e = gdn_test_option("GDN_SSSP_PAD")) pad = (unsigned)atoi(e);
       GDN_TRY(pb_build(g, m, lg, lb, p.pb, /*alloc_vals=*/false, reinterpret_cast<const float *>(d_weight), &p.Wp,
                        /*compact=*/false, /*rows_are_sources=*/true, pad, /*log_group=*/3, p.n_tiers ? cls.p : nullptr, 0));
     }
@@ -1742,7 +1742,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
     // destinations fall into ~60 different bins: one list reservation PER EDGE, each a dependent round trip through the
     // L2 in front of the store -- the binned BFS level got its 6 ps per edge from hub rows walked 256 edges at a time
     // with four reservations in flight, and a low-degree list has none of that.  3.65 -> 5.9 ms with the passes on.
-    const char *be = gdn_option("GDN_SSSP_BINS");
+    const char *be = gdn_test_option("GDN_SSSP_BINS");
     if (bins && be && be[0] == '1') {
       // lists of the binned relax passes: a pass runs while the improved rows own at most nnz / SSSP_BIN_FRAC out-edges;
       // room for SSSP_BIN_SLACK times the even share per list (destinations that crowd into few bins overflow a list:
@@ -1750,7 +1750,7 @@ static int sssp_plan_init(gdn_sssp_plan &p, const gdn_graph *g, const int32_t *d
       const uint64_t nb = (((uint64_t)m + (1u << SSSP_BIN_LOGB) - 1) >> SSSP_BIN_LOGB);
       uint64_t per = (g->nnz / SSSP_BIN_FRAC) * SSSP_BIN_SLACK / (nb * SSSP_BIN_SUB) + 1;
       per = per < 4096 ? 4096 : per;
-      if (const char *e = gdn_option("GDN_SSSP_BIN_CAP")) per = atoi(e) > 0 ? (uint64_t)atoi(e) : per;  // test knob: short lists overflow
+      if (const char *e = gdn_test_option("GDN_SSSP_BIN_CAP")) per = atoi(e) > 0 ? (uint64_t)atoi(e) : per;  // test knob: short lists overflow
       per = (per + 15) & ~(uint64_t)15;
       if (per < 0x7FFFFFFFull && m >= (1 << SSSP_BIN_LOGB)) {
         GDN_TRY(p.bin_buf.alloc((size_t)(nb * SSSP_BIN_SUB * per)));
@@ -1884,18 +1884,18 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   // rows improve per sweep (tuning knobs)
   bool pre_dense_done = false;
   unsigned long long dense_pre = 192;  // = dense_in x the growth of a frontier per pass this early (GDN_SSSP_DENSE_PRE)
-  if (const char *e = gdn_option("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
+  if (const char *e = gdn_xoption("GDN_SSSP_DENSE_PRE")) dense_pre = atoi(e) > 0 ? (unsigned long long)atoi(e) : 0ull;
   unsigned long long dense_in = 24, dense_out = 8;  // measured on RMAT-24, U[1,255]: m/256 -> m/16 took 7.2 / 9.2 ms to 6.2 / 7.5 ms
                                                      // (round 1); with this round's worklist passes m/16 -> m/8: delta 16
                                                      // 3.9 -> 3.66 ms, unit weights 1.74 -> 1.44 ms (m/4: 4.5 / 1.46)
   if (const char *e = gdn_option("GDN_SSSP_DENSE_IN")) dense_in = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_in;
-  if (const char *e = gdn_option("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
+  if (const char *e = gdn_test_option("GDN_SSSP_DENSE_OUT")) dense_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : dense_out;
   // light phases run inside ONE workgroup (sssp_small_kernel); GDN_SSSP_SMALL=0 keeps every phase on the host loop, =2
   // forces every phase into it that fits the lists (tests)
   unsigned small_v = SSSP_SMALL_V, small_far = SSSP_SMALL_FAR;
-  if (const char *e = gdn_option("GDN_SSSP_SMALL_FAR")) small_far = (unsigned)atoi(e);  // FAR lists up to this long change buckets inside the one-workgroup kernel
+  if (const char *e = gdn_xoption("GDN_SSSP_SMALL_FAR")) small_far = (unsigned)atoi(e);  // FAR lists up to this long change buckets inside the one-workgroup kernel
   unsigned long long small_e = SSSP_SMALL_E;
-  if (const char *e = gdn_option("GDN_SSSP_SMALL")) {
+  if (const char *e = gdn_test_option("GDN_SSSP_SMALL")) {
     if (atoi(e) == 0) small_v = 0;
     else if (atoi(e) == 2) {
       small_v = cap;
@@ -1920,14 +1920,14 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
   long long delta_cur = delta;
   unsigned long long bucket_work = 0;
   unsigned light_run = 0, adapt_after = 4;
-  if (const char *e = gdn_option("GDN_SSSP_ADAPT_AFTER")) adapt_after = (unsigned)atoi(e);
+  if (const char *e = gdn_xoption("GDN_SSSP_ADAPT_AFTER")) adapt_after = (unsigned)atoi(e);
   unsigned long long light_small = 4096, light_coop = 1ull << 17, light_host = 1ull << 20;
-  if (const char *e = gdn_option("GDN_SSSP_ADAPT")) {
+  if (const char *e = gdn_xoption("GDN_SSSP_ADAPT")) {
     if (atoi(e) == 0) light_small = light_coop = light_host = 0;
   }
-  if (const char *e = gdn_option("GDN_SSSP_LIGHT_SMALL")) light_small = strtoull(e, nullptr, 10);
-  if (const char *e = gdn_option("GDN_SSSP_LIGHT_COOP")) light_coop = strtoull(e, nullptr, 10);
-  if (const char *e = gdn_option("GDN_SSSP_LIGHT_HOST")) light_host = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_xoption("GDN_SSSP_LIGHT_SMALL")) light_small = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_xoption("GDN_SSSP_LIGHT_COOP")) light_coop = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_xoption("GDN_SSSP_LIGHT_HOST")) light_host = strtoull(e, nullptr, 10);
   for (;;) {
     if (n_near == 0 && n_far == 0) break;
     if (!pre_dense_done && (n_near > 0 || (small_v && n_far <= small_far))) {
@@ -2061,7 +2061,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
         // than m / dense_out rows improve.
         const bool use_bins = p.bin_nbins > 0;
         unsigned long long bin_out = 64;
-        if (const char *e = gdn_option("GDN_SSSP_BIN_OUT")) bin_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : bin_out;
+        if (const char *e = gdn_test_option("GDN_SSSP_BIN_OUT")) bin_out = atoi(e) > 0 ? (unsigned long long)atoi(e) : bin_out;
         bool have_queue = false;  // near_in holds the rows improved by the last step (n_q of them)
         unsigned n_q = 0;
         bool more;
@@ -2113,7 +2113,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
             // 8- / 16-bit candidates while every finite candidate (a finite distance + a weight) stays below 0xFF / 0xFFFF
             // (GDN_SSSP_CAND32 / GDN_SSSP_CAND16: test knobs that keep the wider form)
             const int64_t bound = (int64_t)max_finite + (int64_t)p.w_max;
-            cbits = gdn_option("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !gdn_option("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
+            cbits = gdn_test_option("GDN_SSSP_CAND32") ? 32 : (bound < 0xFF && !gdn_test_option("GDN_SSSP_CAND16")) ? 8 : bound < 0xFFFF ? 16 : 32;
             // (measured and dropped: Gauss-Seidel sweeps -- expand + accumulate per quarter of the bins, so that rows improved
             // in an earlier quarter are sources again inside the same sweep -- need 4 sweeps instead of 5 on RMAT-24 U[1,255],
             // but each costs 1.05 ms instead of 0.61: every partial launch reloads the whole distance slice)
@@ -2238,7 +2238,7 @@ static int sssp_run(gdn_sssp_plan &p, int32_t source, int32_t delta, int32_t *d_
       // after the other by the few waves of such a pass they cost 0.4 ms on RMAT-24; gdn_bfs.hip does the same)
       big.min_deg = ((uint64_t)n_near < 65536u && (uint64_t)n_near + near_edges / EXP_CHUNK + 1024u < (uint64_t)p.bigcap)
                         ? 64u : (unsigned)EXP_BIG;  // (on a 228 K-vertex list the item detour cost 0.42 ms instead of 0.28)
-      if (const char *e = gdn_option("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
+      if (const char *e = gdn_xoption("GDN_SSSP_MINDEG")) big.min_deg = (unsigned)atoi(e);
       hipLaunchKernelGGL(sssp_relax_kernel, dim3(gdn_nblocks(n_near) < SSSP_RELAX_GRID ? gdn_nblocks(n_near) : SSSP_RELAX_GRID),
                          dim3(GDN_BLOCK), 0, 0, g->rowptr, near_in,
                          n_near, clamp(thr_lo), big, vis, edges_pending ? &p.cnt.p->improved_edges : (unsigned long long *)nullptr);
@@ -2432,7 +2432,7 @@ int gdn_sssp_dev(const gdn_graph *g, const int32_t *d_weight, int32_t source, in
   // holds a plan (gdn_sssp_plan_create / gdn_sssp_run) -- keying a hidden cache on caller pointers would return stale
   // layouts for arrays rewritten in place.  GDN_SSSP_ONESHOT_DENSE_MIN moves the threshold (0 = never).
   unsigned long long dense_min = 1ull << 24;
-  if (const char *e = gdn_option("GDN_SSSP_ONESHOT_DENSE_MIN")) dense_min = strtoull(e, nullptr, 10);
+  if (const char *e = gdn_test_option("GDN_SSSP_ONESHOT_DENSE_MIN")) dense_min = strtoull(e, nullptr, 10);
   const bool want_dense = dense_min != 0 && g->nnz >= dense_min;
   {
     gdn_sssp_plan p;

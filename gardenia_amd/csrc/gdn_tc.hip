@@ -832,7 +832,7 @@ static int tc_forward_build(const gdn_graph *g, bool oriented, gdn_graph **dag_o
   if (rc == GDN_OK && din) {
     rc = nstart.alloc(din->nnz);
     // GDN_TC_NBOUND=0: without the packed walk bounds (A/B); default from 2^26 DAG edges on (8 bytes per edge; RMAT-23 / 24 -1 .. -3 %, RMAT-22 the same)
-    const char *enb = gdn_option("GDN_TC_NBOUND");
+    const char *enb = gdn_test_option("GDN_TC_NBOUND");
     const bool want_nbound = enb ? enb[0] != '0' : din->nnz >= (1ull << 26);
     DevBuf<unsigned> nb_bad;
     if (rc == GDN_OK && want_nbound) {
@@ -1213,7 +1213,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned light = dag->m >= (1 << 21) ? 512u : 256u;  // rows up to this many neighbours: one wave, whole (see TC_LIGHT_MIN)
   // beside the core kernel (its rows are gone, the tail is what is left): RMAT-23 512 / 256 / 128 -> 21.7 / 21.3 / 20.7 ms
   if (core) light = 128u;
-  if (const char *e = gdn_option("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
+  if (const char *e = gdn_xoption("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
   if (core) GDN_TRY(tc_core_prepare(*core));
   hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
                      row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3, light);
@@ -1306,7 +1306,7 @@ static int tc_core_build(gdn_tc_plan &p) {
   if (p.core_items == p.core_items_a.p) p.core_items_b.release();
   else p.core_items_a.release();
   {  // GDN_TC_CORE_ASYNC=0 (A/B knob): the core kernel behind tc_count_kernel on the null stream instead of beside it
-    const char *e = gdn_option("GDN_TC_CORE_ASYNC");
+    const char *e = gdn_test_option("GDN_TC_CORE_ASYNC");
     if (!(e && e[0] == '0')) {  // lowest priority: its workgroups take the wave slots tc_count_kernel's LDS budget leaves free
       int lo_pri = 0, hi_pri = 0;
       if (hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri) != hipSuccess ||
@@ -1350,20 +1350,20 @@ static int tc_core_launch(gdn_tc_plan &p, bool tail) {
   }
   // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more slow the hash-set kernel)
   unsigned per_cu = 2;
-  if (const char *e = gdn_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
+  if (const char *e = gdn_test_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
   if (!p.core_stream) per_cu = 8;  // GDN_TC_CORE_ASYNC=0: alone on the device
   if (tail) {
     // OFF by default (GDN_TC_CORE_TAIL = workgroups per CU): at RMAT-23 the core's grid is done (18.6 ms) before the hash-set
     // kernel beside it (20.3 ms; alone 15.5), and a tail grid that finds an empty list still costs 0.34 ms behind it
     // (profiles/sessions/r04_103.sh)
     per_cu = 0;
-    if (const char *e = gdn_option("GDN_TC_CORE_TAIL")) per_cu = (unsigned)atoi(e);
+    if (const char *e = gdn_test_option("GDN_TC_CORE_TAIL")) per_cu = (unsigned)atoi(e);
     if (per_cu == 0) return GDN_OK;
   }
   hipStream_t stream = tail ? nullptr : p.core_stream;
   const dim3 grid((unsigned)cus * per_cu), block(GDN_BLOCK);
   unsigned small = TC_CORE_SMALL;  // GDN_TC_CORE_SMALL (tuning knob, 2..64): core lists shorter than this take the pair tests
-  if (const char *e = gdn_option("GDN_TC_CORE_SMALL")) small = atoi(e) < 2 ? 2u : atoi(e) > 64 ? 64u : (unsigned)atoi(e);
+  if (const char *e = gdn_test_option("GDN_TC_CORE_SMALL")) small = atoi(e) < 2 ? 2u : atoi(e) > 64 ? 64u : (unsigned)atoi(e);
 #define TC_CORE_LAUNCH(R)                                                                                                        \
   hipLaunchKernelGGL(HIP_KERNEL_NAME(tc_core_count_kernel<R>), grid, block, 0, stream, dag->rowptr, dag->colidx, p.core_items, \
                      p.core_ctl.p, p.core_adj.p, base, p.core_total.p, small)

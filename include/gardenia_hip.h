@@ -53,12 +53,46 @@ typedef struct gdn_stats {
 } gdn_stats;
 
 const char *gdn_last_error(void);
-/* Library options.  Every tuning knob (layout choices, thresholds of the level / bucket / sweep choosers, test switches:
- * GDN_PR_LAYOUT, GDN_SSSP_DENSE_IN, GDN_BFS_COOP, GDN_TC_FORM, GDN_MULTI_EXCHANGE ...; DESIGN.md names them where they
- * act) is an option a caller sets here, process wide, before creating the plan or calling the solver it concerns
- * (value NULL = unset).  The environment variable of the same name OVERRIDES the stored value, so that a measurement or a
- * test can flip a knob without touching the caller.  Names start with "GDN_"; values are the strings the environment
- * would carry.  gdn_option_get copies the effective value ("" when unset). */
+/* Library options.  An option is set process wide before the plan is created or the solver called that it concerns
+ * (value NULL = unset); the environment variable of the same name OVERRIDES the stored value, so that a measurement or a test
+ * can flip one without touching the caller.  gdn_option_get copies the effective value ("" when unset).
+ *
+ * THE PUBLIC OPTIONS (all of them; round 6 cut the surface from 145 names to these):
+ *   layout / algorithm choices
+ *     GDN_PR_LAYOUT     csr | pb      PageRank plans and gdn_pr: merge-path CSR or the propagation-blocked layout (default: by size
+ *                                     and by the locality of the gather, gdn_pr_plan_create)
+ *     GDN_PR_SQUISH     0             keep vertices without any edge in the per-iteration state (default: squished out)
+ *     GDN_PR_FUSED      0 | 1         gdn_pr: the whole solve in one cooperative launch (default below 2^18 edges) or never / always
+ *     GDN_PR_BATCH      n             gdn_pr: iterations queued per convergence check on the device (default 8)
+ *     GDN_PR_SUM        reference     re-sum rows in the reference's fp32 order behind every pull (see gdn_pr_plan_refsum_info),
+ *     GDN_PR_SUM_MIN_DEGREE n           the rows of >= n in-edges (default 0 = every row),
+ *     GDN_PR_SUM_GROUP_LOG  k           in groups of 2^k sources per launch (default 20)
+ *     GDN_PRD_LAYOUT    csr | pb      layout of gdn_pr_delta's pull plan;  GDN_PRD_PUSH_DIV n  its push / pull switch (frontier edges < nnz / n)
+ *     GDN_SPMV_LAYOUT   csr | pb      SpMV plans;  GDN_SPMV_ONESHOT solve  gdn_spmv builds the blocked layout inside the call (prep_ms)
+ *     GDN_BFS_COOP      0 | 1         light BFS levels on the cooperative grid: never / from the first one (default: after 8 light levels)
+ *     GDN_BFS_ALPHA_DENSE n           a level goes to the bitmap engines from nnz / n frontier edges on (default 32)
+ *     GDN_SSSP_DENSE_IN n             gdn_sssp_run enters its dense sweeps at m / n frontier vertices;  GDN_SSSP_COOP 0 | 1 as GDN_BFS_COOP
+ *     GDN_SSSP_UNIT_BFS 0             equal-weight plans keep the sweeps instead of solving through the BFS plan
+ *     GDN_CC_SV         1 | fused     Shiloach-Vishkin rounds (src/cc/omp_base.cc) instead of Afforest, as launches or one cooperative kernel
+ *     GDN_CC_REVERSE    build         gdn_cc without a reverse graph builds one inside the call (prep_ms)
+ *     GDN_TC_FORM       f | a | u | v | bs   forward count on the rank-ordered DAG / the reference's orientation / binary-search intersect
+ *     GDN_TC_CORE       k             bit-matrix core of the forward count over the top k degree ranks (0 = none; default by graph size)
+ *     GDN_PB_BUILDER    old           layout builds through the round-3 key sort instead of the tiered builder
+ *   multi-GPU
+ *     GDN_MULTI_DEVICES "0,1,.."      devices of gdn_pr_multi / gdn_spmv_multi;  GDN_MULTI_EXCHANGE rccl | peer  their exchange
+ *   placement search of a plan's streamed arrays
+ *     GDN_PR_PLACE n / GDN_SPMV_PLACE n   candidates per array (0 = off);  GDN_PR_PLACE_COPIES 1  also the arrays that need a copy
+ *   memory
+ *     GDN_SCRATCH_KEEP_GB n           cap of the build-scratch cache per device (default 32)
+ *     GDN_ALLOC_FENCE   1             every buffer in a block of whole pages of its own, at its end (debugging: an overrun faults)
+ *   reports (stderr)
+ *     GDN_BFS_TRACE, GDN_SSSP_TRACE   per-level / per-phase timing;  GDN_BFS_TIME_INIT 1  stats.prep_ms = the per-search initialisation,
+ *                                     stats.last_error = the closing depth pass (ms)
+ *     GDN_PR_PLACE_TRACE, GDN_SPMV_PLACE_TRACE   the placement search, candidate by candidate;  GDN_TRACE_POLICY  gdn_pr's layout model
+ *   GDN_TEST_HOOKS=1 makes the library honour its ~50 test hooks (thresholds that force a big-graph code path onto a small graph,
+ *   layout variants the suite compares bit for bit; tests/conftest.py sets it, csrc/gdn_common.hpp names the classes).  The A/B
+ *   knobs of closed experiments exist only in builds with -DGDN_EXPERIMENTS (make -C gardenia_amd/csrc EXPERIMENTS=1,
+ *   tools/build_variant.sh). */
 int gdn_option_set(const char *name, const char *value);
 int gdn_option_get(const char *name, char *value, int32_t capacity);
 int gdn_device_count(int *count);
@@ -173,6 +207,10 @@ int gdn_dev_free(void *d_ptr);
  * caller that shares the device with another allocator (torch, a second library) and wants the memory; the library does so
  * itself before it reports GDN_ERR_OOM.  *freed_bytes (nullable) = what went back.  Blocking. */
 int gdn_dev_trim(uint64_t *freed_bytes);
+/* Sets a block of device memory aside (bytes 0: gives it back).  Called as the FIRST device call of a process -- before any
+ * build has allocated and freed memory -- it gives the first blocked PageRank plan whose per-iteration scratch (`vals`) fits
+ * a block of pages no build has used; the plan owns it from then on.  Measurement hook of DESIGN.md 4.1 (placement). */
+int gdn_dev_reserve(uint64_t bytes);
 int gdn_dev_upload(void *d_dst, const void *h_src, uint64_t bytes);
 int gdn_dev_download(void *h_dst, const void *d_src, uint64_t bytes);
 

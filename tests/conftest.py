@@ -1,6 +1,11 @@
 import os
 import sys
 
+# The suite forces big-graph code paths onto small graphs and compares layout variants bit for bit through TEST HOOKS of the
+# library (thresholds such as GDN_BFS_HEADS_MIN_NNZ, GDN_PB_HUB_MIN_NNZ ...).  A production process does not read them: they are
+# honoured only while GDN_TEST_HOOKS=1 (csrc/gdn_common.hpp, gdn_test_option); child processes of the tests inherit it.
+os.environ.setdefault("GDN_TEST_HOOKS", "1")
+
 import numpy as np
 import pytest
 

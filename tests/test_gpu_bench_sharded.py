@@ -37,7 +37,9 @@ def test_bench_two_ranks_on_one_device_match_single():
     for ex, extra in (("dense", []), ("compact", []), ("compact", ["--no-squish"]), ("dense", ["--no-squish"]), ("dense", ["--gen", "whole"])):
         launcher = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", str(_free_port())]
-        r = res[ex + " ".join(extra)] = _bench(["--gpus", "2", "--share-device", "--exchange", ex] + extra, launcher)
+        # (three parts: the ticketed pull -- one launch per phase, the exchange of a part behind its tickets -- at this size too)
+        r = res[ex + " ".join(extra)] = _bench(["--gpus", "2", "--share-device", "--exchange", ex, "--parts", "3"] + extra, launcher)
+        assert r["config"]["parts"] == 3
         assert r["n_gpus"] == 2 and ex + " exchange" in r["config"]["partition"]
         assert ("relabelled before the vertex-range cut" in r["config"]["layout"]) == ("--no-squish" not in extra)
         assert ("every rank generated its own destination range" in r["config"]["partition"]) == (not extra)
@@ -78,7 +80,7 @@ def test_bench_equal_ranges_and_rccl_backend_with_one_rank():
     assert "(equal ranges;" in r["config"]["partition"]
     assert abs(r["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     for ex in ("dense", "compact"):
-        f = _bench(["--force-dist", "--exchange", ex])
+        f = _bench(["--force-dist", "--exchange", ex, "--parts", "4"])
         assert f["n_gpus"] == 1 and "RCCL all-gather" in f["config"]["partition"] and ex + " exchange" in f["config"]["partition"]
         assert abs(f["pr_last_l1_change"] - single["pr_last_l1_change"]) <= 1e-12 * single["pr_last_l1_change"]
     # the per-rank generation through the RCCL backend with this box's one rank

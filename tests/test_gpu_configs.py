@@ -354,7 +354,7 @@ def test_pagerank_summation_order_is_the_only_difference(orc, monkeypatch):
     assert np.array_equal(scores3.view(np.uint32), want.view(np.uint32))
 
 
-def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc):
+def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc, monkeypatch):
     torch = pytest.importorskip("torch")
     L = _cabi.lib()
     dev = torch.device("cuda", 0)
@@ -400,6 +400,7 @@ def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc):
     assert dead_v.sum() > m // 3
     cur = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
     n_hub_rows = 0
+    inputs, wants = [], []
     for it in range(2):
         # the SAME input on both sides: iteration 2 starts from the oracle's iteration-1 scores
         gpu, gpu_err = gpu_iteration(cur)
@@ -425,8 +426,33 @@ def test_config5_pagerank_rmat27_two_iterations_vs_oracle(orc):
         # vertices without any edge sit at the base score on both sides, bit for bit
         assert np.array_equal(gpu[dead_v], want[dead_v])
         assert abs(gpu_err - cpu_err) <= 1e-4 * cpu_err
+        inputs.append(cur)
+        wants.append((want, cpu_err))
         cur = want
     print("rows beyond 1e-4 of the sequential fp32 sum (all hub rows, GPU == fp64):", n_hub_rows)
+    _cabi.check(L.gdn_pr_plan_check(plan))
+    L.gdn_pr_plan_free(plan)
+    # ---- the contract-exact mode: the same plan built under GDN_PR_SUM=reference with the rows of >= 10^4
+    # in-edges re-summed in the reference's order behind every pull (csrc/gdn_seqsum.hpp).  In BOTH iterations -- the first one,
+    # from 1/m, is where the 379 rows above live -- NO row lies beyond north_star's 1e-4, and every re-summed row has the
+    # oracle's bits.
+    monkeypatch.setenv("GDN_PR_SUM", "reference")
+    monkeypatch.setenv("GDN_PR_SUM_MIN_DEGREE", "10000")
+    plan = C.c_void_p()
+    _cabi.check(L.gdn_pr_plan_create(gi, p(deg), m, 0, _cabi.GDN_LAYOUT_PB_SQUISHED, C.byref(plan)))
+    rows_, longest_, entries_ = C.c_int32(0), C.c_int32(0), C.c_uint64(0)
+    _cabi.check(L.gdn_pr_plan_refsum_info(plan, C.byref(rows_), C.byref(longest_), C.byref(entries_), None))
+    hub = indeg >= 10_000
+    assert rows_.value == int(hub.sum()) and longest_.value == int(indeg.max()) and entries_.value >= int(indeg[hub].sum())
+    for it in range(2):
+        gpu, gpu_err = gpu_iteration(inputs[it])
+        want, cpu_err = wants[it]
+        rel = np.abs(gpu - want) / want
+        assert float(rel.max()) < 1e-4, (it, int((rel >= 1e-4).sum()), float(rel.max()))
+        assert np.array_equal(gpu[hub].view(np.uint32), want[hub].view(np.uint32)), it
+        assert abs(gpu_err - cpu_err) <= 1e-4 * cpu_err
+    print("GDN_PR_SUM=reference on the %d rows of >= 10^4 in-edges (longest %d): no row beyond 1e-4 in either iteration, those rows bit-equal"
+          % (rows_.value, longest_.value))
     _cabi.check(L.gdn_pr_plan_check(plan))
     L.gdn_pr_plan_free(plan)
     L.gdn_graph_free(gi)

@@ -19,19 +19,15 @@ def u2f(u):
 
 
 def seq_quant(xb, E):
-    ex = xb >> 23
-    exn = ex if ex else 1
-    mx = (xb & 0x7FFFFF) | (0x800000 if ex else 0)
-    d = E - exn
-    if ex >= 255:
+    """gdn_seqsum.hpp's seq_quant: float arithmetic that is exact -- x scaled by a power of two, its floor, the remainder"""
+    with np.errstate(all="ignore"):
+        y = np.ldexp(u2f(xb), 150 - E).astype(np.float32)
+        fl = np.floor(y)
+        fr = np.float32(y - fl)
+    inside = bool(y >= 0) and bool(y < np.float32(8388608.0))
+    if not inside:
         return CLAMP, 0
-    if d <= 0:
-        v = mx << min(-d, 30)
-        return (CLAMP if v >= CLAMP else v), 0
-    if d >= 25:
-        return 0, 0
-    rem, half = mx & ((1 << d) - 1), 1 << (d - 1)
-    return (mx >> d) + (1 if rem > half else 0), 1 if rem == half else 0
+    return int(fl) + (1 if fr > np.float32(0.5) else 0), 1 if fr == np.float32(0.5) else 0
 
 
 def seq_push(p, q, tie):

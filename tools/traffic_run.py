@@ -37,11 +37,12 @@ def first_sources(go, n):
 
 
 ms = []
-if what == "bfs":
+if what.startswith("bfs"):  # "bfs" = the first non-isolated source, "bfs:1" the second (RMAT-27: source 5, the slow one), ...
     go, gi = C.c_void_p(), C.c_void_p()
     _cabi.check(L.gdn_rmat_build(scale, 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
     _cabi.check(L.gdn_graph_info(go, C.byref(m), C.byref(nnz), None, None))
-    src = first_sources(go, 1)[0]
+    k = int(what.split(":")[1]) if ":" in what else 0
+    src = first_sources(go, k + 1)[k]
     dist = dev_alloc(4 * m.value)
     plan = C.c_void_p()
     _cabi.check(L.gdn_bfs_plan_create(go, gi, 1, C.byref(plan)))
