@@ -489,13 +489,14 @@ def main():
             out["pr_reference_sum"] = {
                 "ms_per_step": ms2, "frac": iter_bytes / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, "default_ms_per_step": ms_per_step,
                 "min_in_degree": args.refsum_min_degree, "rows_resummed": rows_.value, "longest_row": longest_.value,
-                "entries_resummed": entries_.value, "launches_per_iteration_for_the_resum": groups_.value + 3,
+                "entries_resummed": entries_.value, "launches_per_iteration_for_the_resum": groups_.value,
                 "plan_build_s": t_plan2, "pr_last_l1_change": pr2.global_diff(),
                 "what": "the timed iteration with GDN_PR_SUM=reference GDN_PR_SUM_MIN_DEGREE=%d: behind the two kernels of the pull the "
                         "rows of that many in-edges are summed again in the reference's order -- fp32, one addition per in-edge, CSR "
-                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^20 "
-                        "sources so that the gathered contributions stay in L2; scores / next contributions / L1 change of those rows "
-                        "are rewritten.  frac = SURVEY 8d's bytes of the plain iteration over this time." % args.refsum_min_degree}
+                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^22 "
+                        "sources so that the gathered contributions stay near, the longest rows on a workgroup each; scores / next "
+                        "contributions / L1 change of those rows are rewritten.  frac = SURVEY 8d's bytes of the plain iteration over "
+                        "this time." % args.refsum_min_degree}
             log(f"[bench] pr_reference_sum: {out['pr_reference_sum']}")
             be2.close()
             del pr2, be2

@@ -967,7 +967,11 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   }
   const int ntiers = sa.ntiers;
   // ---- slices (whole rounds of workgroups, see pb_build)
-  const uint64_t per_c = pb_slots_per_slice(n_src0, lc, PB_MAX_LOG_CHUNK), per_b = pb_slots_per_slice(n_dst, lb, a.bin_balance_log);
+  // (GDN_PB_BALANCE_ALL, experiments build: slices of ANY size spread over whole rounds of workgroups -- mid-size graphs, whose
+  // chunks are 2^14 sources and whose 366 workgroups are 1.43 rounds, tools/pr_midsize.py)
+  const bool bal_all = gdn_xoption("GDN_PB_BALANCE_ALL") != nullptr;
+  const uint64_t per_c = pb_slots_per_slice(n_src0, lc, bal_all ? lc : PB_MAX_LOG_CHUNK),
+                 per_b = pb_slots_per_slice(n_dst, lb, bal_all ? lb : a.bin_balance_log);
   unsigned nchunks = (unsigned)((n_src0 + per_c - 1) / per_c), nbins = (unsigned)((n_dst + per_b - 1) / per_b);
   if (nchunks == 0) nchunks = 1;
   if (nbins == 0) nbins = 1;

@@ -84,9 +84,16 @@ struct gdn_pr_plan {
   // (the selected rows, longest first; their column ids in the plan's vertex space; per-row running sum and cursor)
   DevBuf<uint32_t> ref_row, ref_deg, ref_cols, ref_sumbits, ref_pos;
   DevBuf<eoff_t> ref_off;
-  uint32_t ref_n = 0, ref_n_long = 0, ref_longest = 0;
+  uint32_t ref_n = 0, ref_n_long = 0, ref_n_vlong = 0, ref_longest = 0;
   uint64_t ref_edges = 0;
-  int ref_glog = 20;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG)
+  int ref_glog = 22;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG; RMAT-27: 2^20 / 2^22 / 2^24 / all = 4.3 / 4.0 / 5.2 / 6.3 ms per re-sum)
+  hipStream_t ref_stream = nullptr;    // the very long rows' workgroups run beside the other rows' waves (pr_ref_resum)
+  hipEvent_t ref_ev[2] = {nullptr, nullptr};
+  ~gdn_pr_plan() {
+    for (hipEvent_t e : ref_ev)
+      if (e) (void)hipEventDestroy(e);
+    if (ref_stream) (void)hipStreamDestroy(ref_stream);
+  }
   DevBuf<float> ref_old;               // the selected rows' scores in front of the pull (the L1 change is corrected against them)
   DevBuf<double> ref_partial;          // per-workgroup corrections of the L1 change
   // gdn_pr_pull_parts_dev: one iteration = one launch per phase, its bins in part-major order with tickets (gdn_pb.hpp PbParts)
@@ -186,6 +193,7 @@ struct PrRefRows {
   const float *__restrict__ zero;     // a +0.0f of the plan's own (what entries that do not count load)
   uint32_t n;                         // selected rows
   uint32_t n_long;                    // of them longer than PR_REF_SHORT (the first n_long)
+  uint32_t n_vlong;                   // of them so long that a workgroup takes the row (pr_refseg_wg_kernel; the first n_vlong)
 };
 
 // launch `g`: every long row adds its entries with column < limit (and >= the previous launch's limit: cols ascend);
@@ -195,7 +203,7 @@ pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restri
                  int dbg = 0 /* GDN_EXPERIMENTS: 1 = no scan, 2 = no gather (timing only, wrong sums) */) {
   if (skip && *skip) return;
   const unsigned lane = gdn_lane();
-  const uint64_t i = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6;
+  const uint64_t i = (uint64_t)rr.n_vlong + (((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6);  // (the rows behind the very long ones)
   const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
   if (i >= nrows) return;
   const uint32_t deg = rr.deg[i];
@@ -277,6 +285,129 @@ pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restri
     }
   }
   if (lane == 0) {
+    rr.sum[i] = S;
+    rr.pos[i] = p;
+  }
+}
+
+// The VERY long rows (segments of several blocks per launch: the first n_vlong rows): a workgroup of PR_REFW_WAVES waves per
+// row.  A round = one block per wave, all waves at once: each gathers its block and reduces it to ONE pair on the binade the
+// running sum is in (seq_block_pair); then every wave chains the round's pairs -- a dozen scalar operations per block -- and
+// holds the new running sum.  Where the chain meets the end of the binade (a few dozen times per row) the wave that owns the
+// block adds it exactly (seq_block), and the waves behind it redo their pairs on the new binade.  Measured before: one wave
+// per row paid ~2 us per block (ids -> contributions -> scan, a latency chain); RMAT-27's longest row has 29 blocks per
+// launch and set the duration of every one of the 61 launches.
+#define PR_REFW_WAVES 16
+#define PR_REFW_THREADS (64 * PR_REFW_WAVES)
+__global__ void __launch_bounds__(PR_REFW_THREADS)
+pr_refseg_wg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip) {
+  if (skip && *skip) return;
+  __shared__ uint32_t s_a0[2][PR_REFW_WAVES], s_a1[2][PR_REFW_WAVES], s_cnt[2][PR_REFW_WAVES], s_more[2][PR_REFW_WAVES], s_S;
+  const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
+  const uint64_t i = blockIdx.x;
+  const uint32_t deg = rr.deg[i];
+  uint32_t p = g == 0 ? 0u : rr.pos[i], S = g == 0 ? 0u : rr.sum[i];
+  if (p >= deg) return;
+  typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
+  const pr_u32x4 *__restrict__ C4 = reinterpret_cast<const pr_u32x4 *>(rr.cols + rr.off[i]);
+  const uint32_t jb0 = p & ~(uint32_t)(PR_REF_BLOCK - 1);
+  const uint32_t p0 = p;  // the cursor at the start (only the first block has entries in front of it)
+  unsigned par = 0;
+  // per wave: the ids of its block of round r + 2 are being loaded and the contributions of its block of round r + 1 gathered
+  // while round r is reduced and chained (16 waves with two rounds of memory in flight each)
+  auto load_ids = [&](uint32_t r, pr_u32x4 &a0, pr_u32x4 &a1) {
+    const uint32_t j = jb0 + (r * PR_REFW_WAVES + w) * PR_REF_BLOCK + lane * PR_REF_N;
+    a0 = __builtin_nontemporal_load(C4 + (j >> 2));
+    a1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
+  };
+  auto gather = [&](uint32_t r, const pr_u32x4 &a0, const pr_u32x4 &a1, uint32_t (&v)[PR_REF_N], unsigned &tk, bool &mr) {
+    const uint32_t j0 = jb0 + (r * PR_REFW_WAVES + w) * PR_REF_BLOCK, j = j0 + lane * PR_REF_N;
+    const uint32_t c[PR_REF_N] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    unsigned beyond = 0;
+    tk = 0;
+#pragma unroll
+    for (int k = 0; k < PR_REF_N; k++) {
+      const bool in_row = j + (uint32_t)k >= p0 && j + (uint32_t)k < deg;
+      const bool ok = in_row && c[k] < limit;
+      const float *src = ok ? contrib_in + c[k] : rr.zero;
+      v[k] = __float_as_uint(*src);
+      tk += (unsigned)__popcll(__ballot(ok));
+      beyond += (in_row && !ok) ? 1u : 0u;
+    }
+    mr = __ballot(beyond != 0u) == 0ull && j0 + PR_REF_BLOCK < deg;
+  };
+  pr_u32x4 c0, c1, n0, n1;
+  uint32_t x[PR_REF_N], nx[PR_REF_N];
+  unsigned taken, ntaken;
+  bool more, nmore;
+  load_ids(0, c0, c1);
+  load_ids(1, n0, n1);
+  gather(0, c0, c1, x, taken, more);
+  for (uint32_t r = 0;; r++) {
+    c0 = n0;
+    c1 = n1;
+    load_ids(r + 2, n0, n1);
+    gather(r + 1, c0, c1, nx, ntaken, nmore);
+    uint32_t E = S >> 23;
+    SeqPair t = {0u, 0u};
+    if (taken && E - 1u < 254u) t = seq_block_pair<PR_REF_N>(E, x, lane);
+    if (lane == 0) {
+      s_a0[par][w] = t.a0;
+      s_a1[par][w] = t.a1;
+      s_cnt[par][w] = taken;
+      s_more[par][w] = more ? 1u : 0u;
+    }
+    __syncthreads();
+    unsigned first = 0;
+    for (;;) {  // chain the round's pairs; every wave does, and ends with the same running sum
+      // (lane ww holds wave ww's pair: one LDS round trip, then scalar reads)
+      const uint32_t l_a0 = s_a0[par][lane & (PR_REFW_WAVES - 1)], l_a1 = s_a1[par][lane & (PR_REFW_WAVES - 1)],
+                     l_cnt = s_cnt[par][lane & (PR_REFW_WAVES - 1)];
+      unsigned wc = PR_REFW_WAVES;
+      for (unsigned ww = first; ww < PR_REFW_WAVES; ww++) {
+        if ((uint32_t)__builtin_amdgcn_readlane((int)l_cnt, ww) == 0u) continue;
+        const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
+        const uint32_t tot = P0 + ((P0 & 1u) ? (uint32_t)__builtin_amdgcn_readlane((int)l_a1, ww) : (uint32_t)__builtin_amdgcn_readlane((int)l_a0, ww));
+        if (E - 1u >= 254u || tot >= (1u << 24)) {
+          wc = ww;
+          break;
+        }
+        S = (E << 23) | (tot & 0x7FFFFFu);
+      }
+      if (wc == PR_REFW_WAVES) break;
+      if (w == wc) {  // the end of the binade (or a running sum that is not a normal number yet) lies in my block: added exactly
+        S = seq_block<PR_REF_N>(S, x, lane);
+        if (lane == 0) s_S = S;
+      }
+      __syncthreads();
+      S = s_S;
+      E = S >> 23;
+      first = wc + 1;
+      if (w >= first) {  // the blocks behind it: their pairs again, on the binade the sum is in now
+        SeqPair t2 = {0u, 0u};
+        if (taken && E - 1u < 254u) t2 = seq_block_pair<PR_REF_N>(E, x, lane);
+        if (lane == 0) {
+          s_a0[par][w] = t2.a0;
+          s_a1[par][w] = t2.a1;
+        }
+      }
+      __syncthreads();
+    }
+    bool done;
+    {
+      const unsigned l = lane & (PR_REFW_WAVES - 1);
+      const uint32_t cnt = lane < PR_REFW_WAVES ? s_cnt[par][l] : 0u;
+      done = __ballot(lane < PR_REFW_WAVES && s_more[par][l] == 0u) != 0ull;
+      p += (uint32_t)gdn_wave_sum(cnt);
+    }
+    if (done) break;
+    par ^= 1u;
+#pragma unroll
+    for (int k = 0; k < PR_REF_N; k++) x[k] = nx[k];
+    taken = ntaken;
+    more = nmore;
+  }
+  if (threadIdx.x == 0) {
     rr.sum[i] = S;
     rr.pos[i] = p;
   }
@@ -1551,11 +1682,27 @@ static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipSt
   rr.n_long = plan->ref_n_long;
   const uint64_t space = (uint64_t)plan->m_global;  // the index space of contrib_in
   const uint32_t ngroups = plan->ref_n_long ? (uint32_t)((space + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1u;
+  rr.n_vlong = plan->ref_n_vlong;
+  // the very long rows' workgroups (a latency chain per row, a few hundred workgroups) run BESIDE the other rows' waves (bound
+  // by the rate of their gathers): the two kinds of rows share nothing, so their launches go to two streams
+  hipStream_t sw = s;
+  if (rr.n_vlong && plan->ref_stream && plan->ref_ev[0] && plan->ref_ev[1]) {
+    sw = plan->ref_stream;
+    GDN_HIP(hipEventRecord(plan->ref_ev[0], s));
+    GDN_HIP(hipStreamWaitEvent(sw, plan->ref_ev[0], 0));
+  }
   for (uint32_t g = 0; g < ngroups; g++) {
-    const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
+    const uint32_t nrows = (g == 0 ? rr.n : rr.n_long) - rr.n_vlong;
     const uint32_t limit = g + 1 == ngroups ? 0xFFFFFFFFu : (uint32_t)((uint64_t)(g + 1) << plan->ref_glog);
+    if (rr.n_vlong)
+      hipLaunchKernelGGL(pr_refseg_wg_kernel, dim3(rr.n_vlong), dim3(PR_REFW_THREADS), 0, sw, rr, g, limit, op.contrib_in, op.skip);
+    if (nrows)
     hipLaunchKernelGGL(pr_refseg_kernel, dim3((nrows + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, g, limit,
                        op.contrib_in, op.skip, gdn_xoption("GDN_PR_REF_DBG") ? atoi(gdn_xoption("GDN_PR_REF_DBG")) : 0);
+  }
+  if (sw != s) {
+    GDN_HIP(hipEventRecord(plan->ref_ev[1], sw));
+    GDN_HIP(hipStreamWaitEvent(s, plan->ref_ev[1], 0));
   }
   hipLaunchKernelGGL(pr_ref_apply_kernel, dim3(PR_REF_DIFF_BLOCKS), dim3(GDN_BLOCK), 0, s, plan->ref_row.p, plan->ref_sumbits.p,
                      plan->ref_old.p, plan->ref_n, op.scores, op.contrib_out, op.out_degree, op.base_score, op.damping,
@@ -1604,15 +1751,35 @@ static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap
   GDN_HIP(hipMemcpy(&longest, p->ref_deg.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
   p->ref_edges = total;
   p->ref_longest = longest;
-  GDN_TRY(p->ref_cols.alloc((size_t)total + (3 * PR_REF_DEPTH + 2) * PR_REF_BLOCK + 8));  // (the sum kernel's loads run up to 3 D blocks past a row)
+  GDN_TRY(p->ref_cols.alloc((size_t)total + (size_t)(3 * PR_REFW_WAVES + 3 * PR_REF_DEPTH + 2) * PR_REF_BLOCK + 8));  // (the sum kernel's loads run up to 3 D blocks past a row)
   hipLaunchKernelGGL(pr_ref_cols_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->colidx, row_ids, cmap, p->ref_row.p, p->ref_deg.p,
                      p->ref_off.p, n, p->ref_cols.p);
   GDN_HIP(hipGetLastError());
   GDN_HIP(hipDeviceSynchronize());
   if (const char *e = gdn_option("GDN_PR_SUM_GROUP_LOG")) p->ref_glog = atoi(e) >= 10 && atoi(e) <= 31 ? atoi(e) : p->ref_glog;
+  {  // the very long rows: four blocks per launch or more (the rows are sorted by length: a prefix)
+    const uint64_t ngroups = ((uint64_t)p->m_global + (1ull << p->ref_glog) - 1) >> p->ref_glog;
+    uint64_t thr = 4ull * PR_REF_BLOCK * ngroups;
+    if (const char *e = gdn_test_option("GDN_PR_SUM_WG_MIN")) thr = strtoull(e, nullptr, 10);  // (test hook: small graphs reach the workgroup kernel)
+    const uint32_t look = n < 65536u ? n : 65536u;
+    std::vector<uint32_t> hd(look);
+    GDN_HIP(hipMemcpy(hd.data(), p->ref_deg.p, (size_t)look * 4, hipMemcpyDeviceToHost));
+    uint32_t nv = 0;
+    uint32_t cap = 256u;  // one workgroup per CU: every such row's chain runs at once
+    if (gdn_test_option("GDN_PR_SUM_WG_MIN")) cap = look;
+    while (nv < look && nv < cap && nv < p->ref_n_long && (uint64_t)hd[nv] >= thr) nv++;
+    p->ref_n_vlong = nv;
+    if (nv && (hipStreamCreateWithFlags(&p->ref_stream, hipStreamNonBlocking) != hipSuccess ||
+               hipEventCreateWithFlags(&p->ref_ev[0], hipEventDisableTiming) != hipSuccess ||
+               hipEventCreateWithFlags(&p->ref_ev[1], hipEventDisableTiming) != hipSuccess)) {
+      (void)hipGetLastError();  // (no second stream: everything on the caller's)
+      if (p->ref_stream) (void)hipStreamDestroy(p->ref_stream);
+      p->ref_stream = nullptr;
+    }
+  }
   if (gdn_xoption("GDN_PR_SUM_TRACE"))
-    fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u longer than %d), %llu entries, longest %u, groups of 2^%d sources\n", p->ref_n,
-            p->ref_min_deg, p->ref_n_long, PR_REF_SHORT, (unsigned long long)total, longest, p->ref_glog);
+    fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u longer than %d, %u of them on a workgroup each), %llu entries, longest %u, groups of 2^%d sources\n",
+            p->ref_n, p->ref_min_deg, p->ref_n_long, PR_REF_SHORT, p->ref_n_vlong, (unsigned long long)total, longest, p->ref_glog);
   return GDN_OK;
 }
 
@@ -2017,8 +2184,10 @@ int gdn_pr_plan_refsum_info(const gdn_pr_plan *plan, int32_t *rows, int32_t *lon
   if (rows) *rows = (int32_t)plan->ref_n;
   if (longest_row) *longest_row = (int32_t)plan->ref_longest;
   if (entries) *entries = plan->ref_edges;
-  if (groups)
-    *groups = !plan->ref_sum ? 0 : (plan->ref_n_long ? (int32_t)(((uint64_t)plan->m_global + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1);
+  if (groups) {  // launches per pull: the old scores, per group one for the waves' rows and one for the workgroups' rows, apply, L1
+    const int32_t ng = plan->ref_n_long ? (int32_t)(((uint64_t)plan->m_global + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1;
+    *groups = (!plan->ref_sum || plan->ref_n == 0) ? 0 : 3 + ng * (plan->ref_n_vlong ? 2 : 1);
+  }
   return GDN_OK;
 }
 

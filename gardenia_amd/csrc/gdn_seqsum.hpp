@@ -78,6 +78,57 @@ GDN_HD SeqPair seq_compose(const SeqPair &f, const SeqPair &g) {
 }
 
 #ifdef __HIPCC__
+// inclusive scan of the lanes' pairs under composition: inside the rows of 16 lanes by DPP row_shr (a lane without a source reads
+// the pair (0, 0) = the identity -- no select), across the four rows through the rows' totals in scalar registers
+__device__ __forceinline__ SeqPair seq_wave_scan(SeqPair p, unsigned lane) {
+#define SEQ_ROW_STEP(CTRL)                                                                       \
+  {                                                                                              \
+    SeqPair f;                                                                                   \
+    f.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a0, CTRL, 0xf, 0xf, true);            \
+    f.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a1, CTRL, 0xf, 0xf, true);            \
+    p = seq_compose(f, p);                                                                       \
+  }
+  SEQ_ROW_STEP(0x111)  // row_shr:1
+  SEQ_ROW_STEP(0x112)  // row_shr:2
+  SEQ_ROW_STEP(0x114)  // row_shr:4
+  SEQ_ROW_STEP(0x118)  // row_shr:8
+#undef SEQ_ROW_STEP
+  SeqPair t0, t1, t2;
+  t0.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 15);
+  t0.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 15);
+  t1.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 31);
+  t1.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 31);
+  t2.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 47);
+  t2.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 47);
+  const SeqPair t01 = seq_compose(t0, t1), t012 = seq_compose(t01, t2);
+  const unsigned row = lane >> 4;
+  SeqPair f = {0u, 0u};
+  f = row == 1u ? t0 : f;
+  f = row == 2u ? t01 : f;
+  f = row == 3u ? t012 : f;
+  return seq_compose(f, p);
+}
+
+// The block as ONE function: what its 64 x N elements add to a prefix of even / odd parity on the binade of exponent E --
+// valid as long as the prefix stays below 2^24 (the caller tests that on the total: every term is >= 0).  This is what lets
+// several waves work on consecutive blocks of one row at once: each computes its block's pair on the binade the row is in,
+// one cheap pass chains the pairs (pr_refseg_wg_kernel).
+template <int N>
+__device__ __forceinline__ SeqPair seq_block_pair(uint32_t E, const uint32_t (&x)[N], unsigned lane) {
+  SeqPair p = {0u, 0u};
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    uint32_t q, tie;
+    seq_quant(x[k], E, q, tie);
+    seq_push(p, q, tie);
+  }
+  p = seq_wave_scan(p, lane);
+  SeqPair t;
+  t.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 63);
+  t.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 63);
+  return t;
+}
+
 // One block of 64 x N elements in order (lane l holds elements N l .. N l + N - 1 as bit patterns), running sum S (bit
 // pattern, wave-uniform) -> the running sum behind the block.  All 64 lanes call it.
 template <int N>
@@ -96,36 +147,7 @@ __device__ __forceinline__ uint32_t seq_block(uint32_t S, const uint32_t (&x)[N]
           seq_push(p, q, tie);
         }
       }
-      // inclusive scan under composition: inside the rows of 16 lanes by DPP row_shr (a lane without a source reads the pair
-      // (0, 0) = the identity -- no select), across the four rows through the rows' totals in scalar registers
-#define SEQ_ROW_STEP(CTRL)                                                                       \
-  {                                                                                              \
-    SeqPair f;                                                                                   \
-    f.a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a0, CTRL, 0xf, 0xf, true);            \
-    f.a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p.a1, CTRL, 0xf, 0xf, true);            \
-    p = seq_compose(f, p);                                                                       \
-  }
-      SEQ_ROW_STEP(0x111)  // row_shr:1
-      SEQ_ROW_STEP(0x112)  // row_shr:2
-      SEQ_ROW_STEP(0x114)  // row_shr:4
-      SEQ_ROW_STEP(0x118)  // row_shr:8
-#undef SEQ_ROW_STEP
-      {
-        SeqPair t0, t1, t2;
-        t0.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 15);
-        t0.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 15);
-        t1.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 31);
-        t1.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 31);
-        t2.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 47);
-        t2.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 47);
-        const SeqPair t01 = seq_compose(t0, t1), t012 = seq_compose(t01, t2);
-        const unsigned row = lane >> 4;
-        SeqPair f = {0u, 0u};
-        f = row == 1u ? t0 : f;
-        f = row == 2u ? t01 : f;
-        f = row == 3u ? t012 : f;
-        p = seq_compose(f, p);
-      }
+      p = seq_wave_scan(p, lane);
       const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
       const uint32_t tot = P0 + ((P0 & 1u) ? p.a1 : p.a0);
       const unsigned long long cross = __ballot(lane >= start && tot >= (1u << 24));

@@ -253,12 +253,13 @@ def test_pr_reference_sum_mode_has_the_reference_bits(orc, layout, monkeypatch):
     assert np.array_equal(again, plain)  # the mode leaves nothing behind
 
 
-@pytest.mark.parametrize("glog", ["10", "12", "31"])
-def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog):
+@pytest.mark.parametrize("glog,wg_min", [("10", "1"), ("12", "4000"), ("31", "1"), ("11", "4000000000")])
+def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog, wg_min):
     """The kernel behind GDN_PR_SUM=reference (gdn_seqsum.hpp: scans of parity functions instead of a chain of additions, the
     rows cut into groups of 2^glog sources that are summed launch by launch) on contributions chosen to hit every branch of
     its arithmetic -- equal terms, exact ties, powers of two, zeros, denormals, terms above the running sum; then a negative
-    term and an infinity (the hardware path) --, on rows of 1 ... 9 000 in-edges: every score has the bits of
+    term and an infinity (the hardware path) --, on rows of 1 ... 9 000 in-edges, the long ones on a wave or on a workgroup
+    each: every score has the bits of
     base + damping * (the contributions added one by one in fp32, in CSR order), src/pr/omp_base.cc:27-33."""
     import ctypes as C
     from gardenia_amd import _cabi
@@ -274,6 +275,9 @@ def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog):
     gi = graphio.transpose(g)
     monkeypatch.setenv("GDN_PR_SUM", "reference")
     monkeypatch.setenv("GDN_PR_SUM_GROUP_LOG", glog)
+    # rows of at least wg_min in-edges are summed by a WORKGROUP each (16 waves chain the pairs of 16 blocks per round:
+    # pr_refseg_wg_kernel), the others by a wave each -- "1": every row longer than one block; "4000000000": none
+    monkeypatch.setenv("GDN_PR_SUM_WG_MIN", wg_min)
     h, plan = C.c_void_p(), C.c_void_p()
     _cabi.check(L.gdn_graph_upload(m, gi.nnz, gi.rowptr.ctypes.data_as(C.c_void_p), gi.colidx.ctypes.data_as(C.c_void_p), C.byref(h)))
 
@@ -404,6 +408,28 @@ def test_pr_row_range_part_contract():
     L.gdn_graph_free(h)
     for p in (deg, sc, c0, c1, diff, sc2, c2):
         L.gdn_dev_free(p)
+
+
+def test_pr_plan_takes_the_block_reserved_at_process_start(orc, capfd, monkeypatch):
+    """gdn_dev_reserve (measurement hook of DESIGN 4.1): a block set aside before any build becomes the per-iteration scratch
+    array of the first blocked PageRank plan that fits into it -- same scores; a block that is too small is left alone."""
+    import ctypes as C
+    from gardenia_amd import _cabi
+    L = _cabi.lib()
+    g = graphio.rmat_graph(15, 16, seed=45)
+    gi = graphio.transpose(g)
+    want, it, _ = orc.pr(gi, g.degrees())
+    G = solvers.Graph(csr=g, in_csr=gi)
+    monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
+    monkeypatch.setenv("GDN_PR_PLACE_TRACE", "1")
+    for nbytes, taken in ((64, False), (64 << 20, True)):
+        _cabi.check(L.gdn_dev_reserve(nbytes))
+        scores = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
+        st = solvers.PRSolver(G, scores)
+        assert st["iterations"] == it
+        np.testing.assert_allclose(scores, want, rtol=REL_TOL, atol=0)
+        assert ("reserved at process start" in capfd.readouterr().err) == taken
+    _cabi.check(L.gdn_dev_reserve(0))
 
 
 @pytest.mark.parametrize("layout", [0, 1])
