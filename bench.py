@@ -493,7 +493,7 @@ def main():
                 "plan_build_s": t_plan2, "pr_last_l1_change": pr2.global_diff(),
                 "what": "the timed iteration with GDN_PR_SUM=reference GDN_PR_SUM_MIN_DEGREE=%d: behind the two kernels of the pull the "
                         "rows of that many in-edges are summed again in the reference's order -- fp32, one addition per in-edge, CSR "
-                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^22 "
+                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^21 "
                         "sources so that the gathered contributions stay near, the longest rows on a workgroup each; scores / next "
                         "contributions / L1 change of those rows are rewritten.  frac = SURVEY 8d's bytes of the plain iteration over "
                         "this time." % args.refsum_min_degree}

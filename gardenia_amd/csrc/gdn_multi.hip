@@ -219,7 +219,10 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
     if (!S.use_rccl) {
       int32_t nbmin = S.n_bins[0];
       for (int q = 1; q < n; q++) nbmin = S.n_bins[q] < nbmin ? S.n_bins[q] : nbmin;
-      parts = nbmin >= 400 ? (nbmin / 200 > 4 ? 4 : nbmin / 200) : 1;
+      // (round 6: the parts are ranges of ONE launch -- gdn_pr_pull_parts_dev -- whose bins run largest-first only inside a
+      // part: a part should be two rounds of workgroups or more)
+      parts = nbmin >= 1024 ? (nbmin / 512 > 4 ? 4 : nbmin / 512) : 1;
+      if (const char *e = gdn_test_option("GDN_MULTI_PARTS")) parts = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : parts;  // (test hook)
       ev.resize((size_t)parts);
       for (int j = 0; j < parts; j++) MT_HIP(hipEventCreateWithFlags(&ev[(size_t)j], hipEventDisableTiming));
     }
@@ -269,13 +272,17 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
         MT_SYNC_OR_QUIT();
         all_gather(cout);
       } else {
+        // ONE launch per phase whose rows become final part by part (tickets); the copies of part j are queued on the copy
+        // stream behind the one-wave kernel that waits for part j's tickets, and overlap the accumulation of the later parts
+        int32_t ends[8];
         for (int j = 0; j < parts; j++) {
+          const int32_t r1 = (j == parts - 1) ? chunk : ((j + 1) * seg < chunk ? (j + 1) * seg : chunk);
+          ends[j] = r1 < ml ? r1 : ml;
+        }
+        MT_CHECK(gdn_pr_pull_parts_dev(plan, cin, d_scores.p, cout, d_diff.p, damping, parts, ends, nullptr));
+        for (int j = 0; j < parts && rc == GDN_OK; j++) {
           const int32_t r0 = j * seg < chunk ? j * seg : chunk, r1 = (j == parts - 1) ? chunk : ((j + 1) * seg < chunk ? (j + 1) * seg : chunk);
-          const int32_t a = r0 < ml ? r0 : ml, b = r1 < ml ? r1 : ml;
-          const int flags = (j == 0 ? GDN_PR_PART_FIRST : 0) | (j == parts - 1 ? GDN_PR_PART_LAST : 0);
-          MT_CHECK(gdn_pr_pull_rows_dev(plan, cin, d_scores.p, cout, d_diff.p, damping, a, b, flags, nullptr));
-          MT_HIP(hipEventRecord(ev[(size_t)j], nullptr));
-          MT_HIP(hipStreamWaitEvent(copy, ev[(size_t)j], 0));
+          MT_CHECK(gdn_pr_wait_part_dev(plan, j, copy));
           exchange(cout, r0, r1, copy);
         }
       }

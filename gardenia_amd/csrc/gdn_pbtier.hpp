@@ -969,8 +969,14 @@ static int pb_build_tiered(const PbTieredArgs &a, PbPlan &p, PbTierSet &ts) {
   // ---- slices (whole rounds of workgroups, see pb_build)
   // (GDN_PB_BALANCE_ALL, experiments build: slices of ANY size spread over whole rounds of workgroups -- mid-size graphs, whose
   // chunks are 2^14 sources and whose 366 workgroups are 1.43 rounds, tools/pr_midsize.py)
-  const bool bal_all = gdn_xoption("GDN_PB_BALANCE_ALL") != nullptr;
-  const uint64_t per_c = pb_slots_per_slice(n_src0, lc, bal_all ? lc : PB_MAX_LOG_CHUNK),
+  // Round 6: source CHUNKS of any size are spread over whole rounds (a chunk's workgroup fills a CU whatever its slice: 1024
+  // threads) -- the LJ-like stand-in's 366 chunks of 2^14 sources were 1.43 rounds of phase A in the time of two: 512 chunks,
+  // phase A 0.074 -> 0.058 ms, the iteration 0.177 -> 0.160 ms = 0.50 -> 0.55 of the roofline, gdn_pr 5.28 -> 4.87 ms
+  // (profiles/r06_pr_midsize.txt).  Bins keep their rule (the same spreading measured no gain for shards' bins).
+  const bool bal_all = gdn_xoption("GDN_PB_BALANCE_ALL") != nullptr;  // (experiments build: the bins too)
+  const char *bce = gdn_xoption("GDN_PB_BALANCE_CHUNKS");
+  const bool bal_chunks = !(bce && bce[0] == '0');
+  const uint64_t per_c = pb_slots_per_slice(n_src0, lc, (bal_all || bal_chunks) ? lc : PB_MAX_LOG_CHUNK),
                  per_b = pb_slots_per_slice(n_dst, lb, bal_all ? lb : a.bin_balance_log);
   unsigned nchunks = (unsigned)((n_src0 + per_c - 1) / per_c), nbins = (unsigned)((n_dst + per_b - 1) / per_b);
   if (nchunks == 0) nchunks = 1;

@@ -86,7 +86,7 @@ struct gdn_pr_plan {
   DevBuf<eoff_t> ref_off;
   uint32_t ref_n = 0, ref_n_long = 0, ref_n_vlong = 0, ref_longest = 0;
   uint64_t ref_edges = 0;
-  int ref_glog = 22;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG; RMAT-27: 2^20 / 2^22 / 2^24 / all = 4.3 / 4.0 / 5.2 / 6.3 ms per re-sum)
+  int ref_glog = 21;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG; RMAT-27, re-sum of 387 M entries: 2^21 3.4 ms, 2^22 3.8, 2^23 4.5, ungrouped 6.3)
   hipStream_t ref_stream = nullptr;    // the very long rows' workgroups run beside the other rows' waves (pr_ref_resum)
   hipEvent_t ref_ev[2] = {nullptr, nullptr};
   ~gdn_pr_plan() {

@@ -72,3 +72,24 @@ def test_options_api_roundtrip_and_environment_override(monkeypatch):
     assert L.gdn_option_set(b"GDN_PR_LAYOUT", None) == _cabi.GDN_OK
     assert L.gdn_option_get(b"GDN_PR_LAYOUT", buf, 64) == _cabi.GDN_OK and buf.value == b""
     assert L.gdn_option_set(b"PATH", b"x") == _cabi.GDN_ERR_INVALID
+
+
+def test_option_surface_is_the_documented_public_one():
+    """the shipped library reads three classes of options (csrc/gdn_common.hpp).  Every name it reads through
+    gdn_option -- the PUBLIC class -- is documented in include/gardenia_hip.h, and there are at most 40 of them; everything else
+    goes through gdn_test_option (honoured only under GDN_TEST_HOOKS=1) or gdn_xoption (compiled in only with -DGDN_EXPERIMENTS);
+    no name is read through two classes."""
+    import glob
+    import re
+    src = "".join(open(p).read() for p in glob.glob(os.path.join(ROOT, "gardenia_amd", "csrc", "*.h*")))
+    header = open(os.path.join(ROOT, "include", "gardenia_hip.h")).read()
+    public = set(re.findall(r'gdn_option\("(GDN_[A-Z0-9_]+)"\)', src))
+    hooks = set(re.findall(r'gdn_test_option\("(GDN_[A-Z0-9_]+)"\)', src))
+    exper = set(re.findall(r'gdn_xoption\("(GDN_[A-Z0-9_]+)"\)', src))
+    assert 20 <= len(public) <= 40, sorted(public)
+    missing = sorted(n for n in public if n not in header)
+    assert not missing, "public options without a line in include/gardenia_hip.h: %s" % missing
+    assert not (public & hooks) and not (public & exper) and not (hooks & exper), (public & hooks, public & exper, hooks & exper)
+    assert len(hooks) >= 40 and len(exper) >= 40
+    # the tests' own hooks are switched on by the conftest, not by the library's defaults
+    assert os.environ.get("GDN_TEST_HOOKS") == "1"

@@ -24,10 +24,13 @@ def _pr_graph(scale=15, ef=16, seed=41, cut=5):
     return g, graphio.transpose(g)
 
 
-@pytest.mark.parametrize("ranks", [2, 3, 5])
-def test_pr_multi_pb_bits_equal_single_device(orc, monkeypatch, ranks):
+@pytest.mark.parametrize("ranks,parts", [(2, "1"), (3, "3"), (5, "4"), (2, "8")])
+def test_pr_multi_pb_bits_equal_single_device(orc, monkeypatch, ranks, parts):
     monkeypatch.setenv("GDN_PR_LAYOUT", "pb")
     monkeypatch.setenv("GDN_PB_HUB_MIN_NNZ", "1")  # record tiers on the shards too
+    # (round 6: the exchange pipelined in `parts` row ranges of ONE ticketed launch per phase, gdn_pr_pull_parts_dev: every
+    # part's peer copies are queued behind the kernel that waits for its tickets)
+    monkeypatch.setenv("GDN_MULTI_PARTS", parts)
     g, gi = _pr_graph()
     G = solvers.Graph(csr=g, in_csr=gi)
     one = np.full(g.m, np.float32(1.0) / np.float32(g.m), np.float32)
