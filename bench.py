@@ -352,10 +352,11 @@ def main():
     if multi:
         nb = torch.tensor([be.n_bins()], dtype=torch.int64, device=device)
         dist.all_reduce(nb, op=dist.ReduceOp.MIN)
-        # (with tickets -- gdn_pr_pull_parts_dev -- the parts are ranges of ONE launch and cost no tail between them; but the bins of
-        # a part run largest-first only among themselves, so a part should be about two rounds of workgroups or more: RMAT-27 / 8 with
-        # four parts of ONE round each ran its accumulate phase 7 % slower than unparted, profiles/r06_shard_compute.md)
-        parts = max(1, min(4, int(nb.item()) // 512)) if int(nb.item()) >= 64 else (max(1, min(4, int(nb.item()) // 8)) if int(nb.item()) > 0 else 4)
+        # (with tickets -- gdn_pr_pull_parts_dev -- the parts are ranges of ONE launch and cost no tail between them.  The bins of a
+        # part run largest-first only among themselves: four parts of ONE round of workgroups each cost RMAT-27 / 8's accumulate
+        # phase 7 %, 0.03 ms -- but from N = 2 on the step is the EXCHANGE (0.5-1.6 ms a slice, profiles/r06_shard_compute.md), and
+        # every part that can leave early is worth a quarter of it: four parts wherever a part still holds half a round)
+        parts = max(1, min(4, int(nb.item()) // 128)) if int(nb.item()) > 0 else 4
     if multi and args.parts > 0:
         parts = min(args.parts, 8)
     pr = ShardedPageRank(be, m_space, rank, world, dist if multi else None, exchange=exchange, parts=parts,
@@ -493,10 +494,10 @@ def main():
                 "plan_build_s": t_plan2, "pr_last_l1_change": pr2.global_diff(),
                 "what": "the timed iteration with GDN_PR_SUM=reference GDN_PR_SUM_MIN_DEGREE=%d: behind the two kernels of the pull the "
                         "rows of that many in-edges are summed again in the reference's order -- fp32, one addition per in-edge, CSR "
-                        "order (src/pr/omp_base.cc:27-30) -- by scans of parity functions (csrc/gdn_seqsum.hpp), group by group of 2^21 "
-                        "sources so that the gathered contributions stay near, the longest rows on a workgroup each; scores / next "
-                        "contributions / L1 change of those rows are rewritten.  frac = SURVEY 8d's bytes of the plain iteration over "
-                        "this time." % args.refsum_min_degree}
+                        "order (src/pr/omp_base.cc:27-30): their contributions staged in row order through LDS slices of the contribution "
+                        "vector, then summed by scans of parity functions (csrc/gdn_seqsum.hpp), the longest rows on a workgroup each; "
+                        "scores / next contributions / L1 change of those rows are rewritten.  frac = SURVEY 8d's bytes of the plain "
+                        "iteration over this time." % args.refsum_min_degree}
             log(f"[bench] pr_reference_sum: {out['pr_reference_sum']}")
             be2.close()
             del pr2, be2

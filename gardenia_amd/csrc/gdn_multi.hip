@@ -219,9 +219,9 @@ void pr_rank(Shared &S, int r, int32_t m, const uint64_t *in_rowptr, const int32
     if (!S.use_rccl) {
       int32_t nbmin = S.n_bins[0];
       for (int q = 1; q < n; q++) nbmin = S.n_bins[q] < nbmin ? S.n_bins[q] : nbmin;
-      // (round 6: the parts are ranges of ONE launch -- gdn_pr_pull_parts_dev -- whose bins run largest-first only inside a
-      // part: a part should be two rounds of workgroups or more)
-      parts = nbmin >= 1024 ? (nbmin / 512 > 4 ? 4 : nbmin / 512) : 1;
+      // (round 6: the parts are ranges of ONE launch -- gdn_pr_pull_parts_dev --; four of them wherever a part still holds half
+      // a round of workgroups: the exchange, not the pull, is what a step waits for)
+      parts = nbmin >= 256 ? (nbmin / 128 > 4 ? 4 : nbmin / 128) : 1;
       if (const char *e = gdn_test_option("GDN_MULTI_PARTS")) parts = atoi(e) >= 1 && atoi(e) <= 8 ? atoi(e) : parts;  // (test hook)
       ev.resize((size_t)parts);
       for (int j = 0; j < parts; j++) MT_HIP(hipEventCreateWithFlags(&ev[(size_t)j], hipEventDisableTiming));

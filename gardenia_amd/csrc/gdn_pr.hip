@@ -81,12 +81,14 @@ struct gdn_pr_plan {
   // then has the reference's bits, whatever layout the plan streams (pr_refsum_kernel).
   bool ref_sum = false;
   uint32_t ref_min_deg = 0;
-  // (the selected rows, longest first; their column ids in the plan's vertex space; per-row running sum and cursor)
-  DevBuf<uint32_t> ref_row, ref_deg, ref_cols, ref_sumbits, ref_pos;
-  DevBuf<eoff_t> ref_off;
-  uint32_t ref_n = 0, ref_n_long = 0, ref_n_vlong = 0, ref_longest = 0;
+  // (the selected rows, longest first; their entries chunk-major as (local source id, place in hv); hv = the entries' contributions
+  // in row order, rewritten by the stage pass of every pull; per-row sums)
+  DevBuf<uint32_t> ref_row, ref_deg, ref_cdest, ref_sumbits;
+  DevBuf<uint16_t> ref_cu16;
+  DevBuf<eoff_t> ref_off, ref_cptr;
+  DevBuf<float> ref_hv;
+  uint32_t ref_n = 0, ref_n_vlong = 0, ref_longest = 0, ref_nchunks = 0;
   uint64_t ref_edges = 0;
-  int ref_glog = 21;                   // sources per group = 2^ref_glog (GDN_PR_SUM_GROUP_LOG; RMAT-27, re-sum of 387 M entries: 2^21 3.4 ms, 2^22 3.8, 2^23 4.5, ungrouped 6.3)
   hipStream_t ref_stream = nullptr;    // the very long rows' workgroups run beside the other rows' waves (pr_ref_resum)
   hipEvent_t ref_ev[2] = {nullptr, nullptr};
   ~gdn_pr_plan() {
@@ -166,206 +168,143 @@ struct PrOp {
 
 // ---- GDN_PR_SUM=reference: the reference's summation order on demand: the rows of >= ref_min_deg in-edges
 // ("selected" rows) are summed AGAIN the way src/pr/omp_base.cc:27-30 sums them -- one fp32 addition per in-edge, in CSR
-// order -- and their scores / next contributions / the L1 change rewritten from those sums.
-// Round 6: (1) the chain of dependent additions is gone -- a wave settles 512 additions with one scan (gdn_seqsum.hpp: the
-// same bits, proven element by element); (2) the gather of the contributions is no longer a stream of L2 misses: the
-// selected rows keep a copy of their column ids in the plan's own vertex space (ref_cols, ascending per row), the vertex
-// space is cut into GROUPS of 2^glog sources, and group g of ALL long rows is summed by launch g -- the 2-4 MB of
-// contributions a launch gathers from stay in the XCDs' L2s, the running sum and the cursor of a row wait in memory between
-// launches.  A row of 1.3 M in-edges is then ~60 short segments instead of one 5 ms chain.  Rows of <= PR_REF_SHORT edges
-// are summed whole by launch 0.
-#ifdef GDN_EXPERIMENTS
-#define PR_REF_DBG(bit) (dbg & (bit))
-#else
-#define PR_REF_DBG(bit) false
-#endif
+// order -- and their scores / next contributions / the L1 change rewritten from those sums.  Round 6, two passes per pull:
+//   STAGE  (pr_ref_stage_kernel) the contributions the selected rows read, fetched the way phase A fetches: a workgroup per
+//          chunk of 2^15 sources loads the chunk's slice of contrib_in into LDS (coalesced) and writes slice[local id] to the
+//          place of every selected-row entry whose source lies in the chunk -- hv, in ROW order (the plan keeps the entries
+//          chunk-major as (u16 local id, u32 place), built once).  No gather leaves the CU: a 4-byte gather from HBM / the
+//          Infinity Cache pulls a 64-byte line, 24.8 GB per iteration for RMAT-27's rows of >= 10^4 in-edges.
+//   SCAN   (pr_refscan_kernel / pr_refscan_wg_kernel) every row streams its values from hv and sums them in order -- not by
+//          a chain of dependent additions but by scans of parity functions (gdn_seqsum.hpp: the same bits): a wave per row,
+//          a WORKGROUP per very long row (16 waves reduce 16 blocks to pairs at once, one pass chains them: a lone wave pays
+//          a block's latency once per block, and RMAT-27's longest row has 1 763 of them).
 #define PR_REF_N 8                       // elements per lane and block
 #define PR_REF_BLOCK (64 * PR_REF_N)     // 512 elements per wave step
-#define PR_REF_SHORT PR_REF_BLOCK
-#define PR_REF_DEPTH 1                   // blocks of contributions in flight per wave (pr_refseg_kernel)
+#define PR_REF_LOG_CHUNK 15              // sources per staging chunk (128 KB of LDS)
+#define PR_REF_STAGE_THREADS 1024
 struct PrRefRows {
   const uint32_t *__restrict__ row;   // state row of selected row i (sorted by in-degree, descending)
   const uint32_t *__restrict__ deg;   // its in-degree
-  const eoff_t *__restrict__ off;     // first entry in cols (a multiple of 8)
-  const uint32_t *__restrict__ cols;  // column ids in the plan's vertex space, ascending per row
-  uint32_t *__restrict__ sum;         // running sum (bit pattern); after the last launch: the row's sum
-  uint32_t *__restrict__ pos;         // entries of the row already added
-  const float *__restrict__ zero;     // a +0.0f of the plan's own (what entries that do not count load)
+  const eoff_t *__restrict__ off;     // first entry of the row in hv (a multiple of 8)
+  const float *__restrict__ hv;       // the rows' contributions in row order (written by the stage pass of this pull)
+  uint32_t *__restrict__ sum;         // the row's sum (bit pattern)
   uint32_t n;                         // selected rows
-  uint32_t n_long;                    // of them longer than PR_REF_SHORT (the first n_long)
-  uint32_t n_vlong;                   // of them so long that a workgroup takes the row (pr_refseg_wg_kernel; the first n_vlong)
+  uint32_t n_vlong;                   // of them so long that a workgroup takes the row (the first n_vlong)
 };
 
-// launch `g`: every long row adds its entries with column < limit (and >= the previous launch's limit: cols ascend);
-// launch 0 also takes the short rows whole.  One wave per row.
-__global__ void __launch_bounds__(GDN_BLOCK)
-pr_refseg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip,
-                 int dbg = 0 /* GDN_EXPERIMENTS: 1 = no scan, 2 = no gather (timing only, wrong sums) */) {
+// STAGE: chunk c's slice of contrib_in into LDS, then hv[place] = slice[local id] for the chunk's entries
+__global__ void __launch_bounds__(PR_REF_STAGE_THREADS)
+pr_ref_stage_kernel(const float *__restrict__ contrib_in, uint32_t m_space, const eoff_t *__restrict__ cptr,
+                    const uint16_t *__restrict__ cu16, const uint32_t *__restrict__ cdest, float *__restrict__ hv,
+                    const unsigned *__restrict__ skip) {
   if (skip && *skip) return;
-  const unsigned lane = gdn_lane();
-  const uint64_t i = (uint64_t)rr.n_vlong + (((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6);  // (the rows behind the very long ones)
-  const uint32_t nrows = g == 0 ? rr.n : rr.n_long;
-  if (i >= nrows) return;
-  const uint32_t deg = rr.deg[i];
-  uint32_t p = g == 0 ? 0u : rr.pos[i], S = g == 0 ? 0u : rr.sum[i];
-  const uint32_t lim = (g == 0 && i >= rr.n_long) ? 0xFFFFFFFFu : limit;  // (short rows: everything now)
-  if (p >= deg) return;
-  typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
-  const pr_u32x4 *__restrict__ C4 = reinterpret_cast<const pr_u32x4 *>(rr.cols + rr.off[i]);
-  // Blocks of PR_REF_BLOCK entries, aligned inside the row (16-byte loads).  A row's blocks are a CHAIN -- the running sum --
-  // so what a block costs must be its scan, not its memory round trips: straight-line loads (no branch around a load: the
-  // compiler then counts vmcnt instead of draining it).  Loads past the row's end read the next rows' ids (ref_cols carries
-  // the slack), gathers of entries that do not count read contrib_in[0]; both are masked.
-  uint32_t jb = p & ~(uint32_t)(PR_REF_BLOCK - 1);  // block of the cursor
-  auto load_cols = [&](uint32_t j0, pr_u32x4 &c0, pr_u32x4 &c1) {
-    const uint32_t j = j0 + lane * PR_REF_N;
-    c0 = __builtin_nontemporal_load(C4 + (j >> 2));
-    c1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
-  };
-  // the contributions of block j0 (as bit patterns; +0 for entries that do not count: in front of the cursor, behind the row's
-  // end, or of a later group), how many count, and whether the row goes on behind this block
-  auto gather = [&](uint32_t j0, const pr_u32x4 &c0, const pr_u32x4 &c1, uint32_t (&v)[PR_REF_N], unsigned &taken, bool &more) {
-    const uint32_t j = j0 + lane * PR_REF_N;
-    const uint32_t c[PR_REF_N] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    // an interior block -- behind the cursor, in front of the row's end, its LAST id (ids ascend) inside this launch's group:
-    // every entry counts, nothing to test per entry
-    const uint32_t c_last = (uint32_t)__builtin_amdgcn_readlane((int)c1.w, 63);
-    if (j0 >= p && j0 + PR_REF_BLOCK <= deg && c_last < lim) {
+  extern __shared__ __attribute__((aligned(16))) float s_x[];
+  const uint32_t c = blockIdx.x;
+  const eoff_t e0 = cptr[c], e1 = cptr[c + 1];
+  if (e1 <= e0) return;
+  const uint32_t base = c << PR_REF_LOG_CHUNK;
+  const uint32_t n = m_space - base < (1u << PR_REF_LOG_CHUNK) ? m_space - base : (1u << PR_REF_LOG_CHUNK);
+  for (uint32_t i = threadIdx.x; i < n; i += PR_REF_STAGE_THREADS) s_x[i] = contrib_in[base + i];
+  __syncthreads();
+  constexpr int U = 4;
+  for (eoff_t e = e0 + threadIdx.x; e < e1; e += (eoff_t)U * PR_REF_STAGE_THREADS) {
+    uint32_t u[U], d[U];
 #pragma unroll
-      for (int k = 0; k < PR_REF_N; k++) v[k] = PR_REF_DBG(2) ? c[k] >> 9 : __float_as_uint(contrib_in[c[k]]);
-      taken = PR_REF_BLOCK;
-      more = j0 + PR_REF_BLOCK < deg;
-      return;
+    for (int k = 0; k < U; k++) {
+      const eoff_t ee = e + (eoff_t)k * PR_REF_STAGE_THREADS;
+      u[k] = ee < e1 ? (uint32_t)__builtin_nontemporal_load(cu16 + ee) : 0u;
+      d[k] = ee < e1 ? __builtin_nontemporal_load(cdest + ee) : 0xFFFFFFFFu;
     }
-    unsigned beyond = 0;
-    bool ok[PR_REF_N];
-    taken = 0;
 #pragma unroll
-    for (int k = 0; k < PR_REF_N; k++) {
-      const bool in_row = j + (uint32_t)k >= p && j + (uint32_t)k < deg;
-      ok[k] = in_row && c[k] < lim;
-      // (an entry that does not count loads the plan's own +0: nothing is done to a loaded value before the scan needs it, so
-      // the load can stay in flight across the scans of the blocks in front -- a select BEHIND the load would wait for it here)
-      const float *src = ok[k] ? contrib_in + c[k] : rr.zero;
-      v[k] = __float_as_uint(*src);
-      taken += (unsigned)__popcll(__ballot(ok[k]));  // (scalar: a ballot and a bit count)
-      beyond += (in_row && !ok[k]) ? 1u : 0u;
-    }
-    more = __ballot(beyond != 0u) == 0ull && j0 + PR_REF_BLOCK < deg;
-  };
-  // Software pipeline of depth D: while block k is scanned, the contributions of blocks k + 1 .. k + D - 1 are in flight and
-  // those of block k + D are requested; the column ids run 2 D blocks ahead -- vmcnt retires in issue order, so the ids a
-  // gather needs must be OLDER than the gathers that are to stay in flight across it.  (Measured with D = 1: 2 us per block
-  // of a chain whose scan takes 0.6 -- the longest row's 1 763 blocks were 4 of the 5 ms of a re-sum.)  The main loop is
-  // unrolled over the 2 D ring slots so that every register index is a constant.
-  constexpr int D = PR_REF_DEPTH;
-  pr_u32x4 c[2 * D][2];
-  uint32_t v[D][PR_REF_N];
-  unsigned tk[D];
-  bool mr[D];
-#pragma unroll
-  for (int b = 0; b < 2 * D; b++) load_cols(jb + (uint32_t)b * PR_REF_BLOCK, c[b][0], c[b][1]);
-#pragma unroll
-  for (int b = 0; b < D; b++) gather(jb + (uint32_t)b * PR_REF_BLOCK, c[b][0], c[b][1], v[b], tk[b], mr[b]);
-  bool done = false;
-  while (!done) {
-#pragma unroll
-    for (int sl = 0; sl < 2 * D; sl++) {
-      if (!done) {
-        const int vs = sl % D;
-        if (PR_REF_DBG(1)) S ^= v[vs][0] + v[vs][7];
-        else if (tk[vs]) S = seq_block<PR_REF_N>(S, v[vs], lane);
-        p += tk[vs];
-        done = !mr[vs];
-        // block k + D into the slot just scanned, from the ids of ring slot (sl + D) mod 2 D; then the ids of block k + 2 D
-        gather(jb + (uint32_t)D * PR_REF_BLOCK, c[(sl + D) % (2 * D)][0], c[(sl + D) % (2 * D)][1], v[vs], tk[vs], mr[vs]);
-        load_cols(jb + (uint32_t)(2 * D) * PR_REF_BLOCK, c[sl][0], c[sl][1]);
-        jb += PR_REF_BLOCK;
-      }
-    }
-  }
-  if (lane == 0) {
-    rr.sum[i] = S;
-    rr.pos[i] = p;
+    for (int k = 0; k < U; k++)
+      if (d[k] != 0xFFFFFFFFu) hv[d[k]] = s_x[u[k]];
   }
 }
 
-// The VERY long rows (segments of several blocks per launch: the first n_vlong rows): a workgroup of PR_REFW_WAVES waves per
-// row.  A round = one block per wave, all waves at once: each gathers its block and reduces it to ONE pair on the binade the
-// running sum is in (seq_block_pair); then every wave chains the round's pairs -- a dozen scalar operations per block -- and
-// holds the new running sum.  Where the chain meets the end of the binade (a few dozen times per row) the wave that owns the
-// block adds it exactly (seq_block), and the waves behind it redo their pairs on the new binade.  Measured before: one wave
-// per row paid ~2 us per block (ids -> contributions -> scan, a latency chain); RMAT-27's longest row has 29 blocks per
-// launch and set the duration of every one of the 61 launches.
+// the N values of a lane of block j0 of a row (bit patterns; +0 behind the row's end).  Two 16-byte loads, straight-line: the
+// addresses depend on nothing that is loaded, so the caller keeps as many blocks in flight as it likes.
+typedef float pr_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pr_ref_load(const pr_f32x4 *__restrict__ H4, uint32_t j0, unsigned lane, pr_f32x4 &a, pr_f32x4 &b) {
+  const uint32_t j = j0 + lane * PR_REF_N;
+  a = __builtin_nontemporal_load(H4 + (j >> 2));
+  b = __builtin_nontemporal_load(H4 + (j >> 2) + 1);
+}
+__device__ __forceinline__ void pr_ref_mask(const pr_f32x4 &a, const pr_f32x4 &b, uint32_t j0, unsigned lane, uint32_t deg,
+                                            uint32_t (&x)[PR_REF_N]) {
+  const uint32_t j = j0 + lane * PR_REF_N;
+  const float v[PR_REF_N] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int k = 0; k < PR_REF_N; k++) x[k] = j + (uint32_t)k < deg ? __float_as_uint(v[k]) : 0u;
+}
+
+// SCAN, a wave per row (the rows behind the very long ones)
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_refscan_kernel(PrRefRows rr, const unsigned *__restrict__ skip) {
+  if (skip && *skip) return;
+  const unsigned lane = gdn_lane();
+  const uint64_t i = (uint64_t)rr.n_vlong + (((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6);
+  if (i >= rr.n) return;
+  const uint32_t deg = rr.deg[i];
+  const pr_f32x4 *__restrict__ H4 = reinterpret_cast<const pr_f32x4 *>(rr.hv + rr.off[i]);
+  uint32_t S = 0u;
+  pr_f32x4 a0, b0, a1, b1, a2, b2;  // three blocks in flight (hv carries the slack behind the last row)
+  pr_ref_load(H4, 0u, lane, a0, b0);
+  pr_ref_load(H4, PR_REF_BLOCK, lane, a1, b1);
+  for (uint32_t j0 = 0; j0 < deg; j0 += PR_REF_BLOCK) {
+    pr_ref_load(H4, j0 + 2u * PR_REF_BLOCK, lane, a2, b2);
+    uint32_t x[PR_REF_N];
+    pr_ref_mask(a0, b0, j0, lane, deg, x);
+    S = seq_block<PR_REF_N>(S, x, lane);
+    a0 = a1;
+    b0 = b1;
+    a1 = a2;
+    b1 = b2;
+  }
+  if (lane == 0) rr.sum[i] = S;
+}
+
+// SCAN, a workgroup per very long row.  A round = one block per wave, all waves at once: each loads its block and reduces
+// it to ONE pair on the binade the running sum is in (seq_block_pair); then every wave chains the round's pairs -- a dozen
+// scalar operations per block -- and holds the new running sum.  Where the chain meets the end of the binade (a few dozen
+// times per row) the wave that owns the block adds it exactly (seq_block), and the waves behind it redo their pairs on the
+// new binade.
 #define PR_REFW_WAVES 16
 #define PR_REFW_THREADS (64 * PR_REFW_WAVES)
 __global__ void __launch_bounds__(PR_REFW_THREADS)
-pr_refseg_wg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__restrict__ contrib_in, const unsigned *__restrict__ skip) {
+pr_refscan_wg_kernel(PrRefRows rr, const unsigned *__restrict__ skip) {
   if (skip && *skip) return;
-  __shared__ uint32_t s_a0[2][PR_REFW_WAVES], s_a1[2][PR_REFW_WAVES], s_cnt[2][PR_REFW_WAVES], s_more[2][PR_REFW_WAVES], s_S;
+  __shared__ uint32_t s_a0[2][PR_REFW_WAVES], s_a1[2][PR_REFW_WAVES], s_S;
   const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
   const uint64_t i = blockIdx.x;
   const uint32_t deg = rr.deg[i];
-  uint32_t p = g == 0 ? 0u : rr.pos[i], S = g == 0 ? 0u : rr.sum[i];
-  if (p >= deg) return;
-  typedef unsigned pr_u32x4 __attribute__((ext_vector_type(4)));
-  const pr_u32x4 *__restrict__ C4 = reinterpret_cast<const pr_u32x4 *>(rr.cols + rr.off[i]);
-  const uint32_t jb0 = p & ~(uint32_t)(PR_REF_BLOCK - 1);
-  const uint32_t p0 = p;  // the cursor at the start (only the first block has entries in front of it)
+  const pr_f32x4 *__restrict__ H4 = reinterpret_cast<const pr_f32x4 *>(rr.hv + rr.off[i]);
+  uint32_t S = 0u;
   unsigned par = 0;
-  // per wave: the ids of its block of round r + 2 are being loaded and the contributions of its block of round r + 1 gathered
-  // while round r is reduced and chained (16 waves with two rounds of memory in flight each)
-  auto load_ids = [&](uint32_t r, pr_u32x4 &a0, pr_u32x4 &a1) {
-    const uint32_t j = jb0 + (r * PR_REFW_WAVES + w) * PR_REF_BLOCK + lane * PR_REF_N;
-    a0 = __builtin_nontemporal_load(C4 + (j >> 2));
-    a1 = __builtin_nontemporal_load(C4 + (j >> 2) + 1);
-  };
-  auto gather = [&](uint32_t r, const pr_u32x4 &a0, const pr_u32x4 &a1, uint32_t (&v)[PR_REF_N], unsigned &tk, bool &mr) {
-    const uint32_t j0 = jb0 + (r * PR_REFW_WAVES + w) * PR_REF_BLOCK, j = j0 + lane * PR_REF_N;
-    const uint32_t c[PR_REF_N] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-    unsigned beyond = 0;
-    tk = 0;
-#pragma unroll
-    for (int k = 0; k < PR_REF_N; k++) {
-      const bool in_row = j + (uint32_t)k >= p0 && j + (uint32_t)k < deg;
-      const bool ok = in_row && c[k] < limit;
-      const float *src = ok ? contrib_in + c[k] : rr.zero;
-      v[k] = __float_as_uint(*src);
-      tk += (unsigned)__popcll(__ballot(ok));
-      beyond += (in_row && !ok) ? 1u : 0u;
-    }
-    mr = __ballot(beyond != 0u) == 0ull && j0 + PR_REF_BLOCK < deg;
-  };
-  pr_u32x4 c0, c1, n0, n1;
-  uint32_t x[PR_REF_N], nx[PR_REF_N];
-  unsigned taken, ntaken;
-  bool more, nmore;
-  load_ids(0, c0, c1);
-  load_ids(1, n0, n1);
-  gather(0, c0, c1, x, taken, more);
-  for (uint32_t r = 0;; r++) {
-    c0 = n0;
-    c1 = n1;
-    load_ids(r + 2, n0, n1);
-    gather(r + 1, c0, c1, nx, ntaken, nmore);
+  const uint32_t round_len = PR_REFW_WAVES * PR_REF_BLOCK;
+  pr_f32x4 a0, b0, a1, b1, a2, b2;  // this wave's blocks of rounds r, r + 1, r + 2
+  pr_ref_load(H4, w * PR_REF_BLOCK, lane, a0, b0);
+  pr_ref_load(H4, round_len + w * PR_REF_BLOCK, lane, a1, b1);
+  for (uint32_t r0 = 0; r0 < deg; r0 += round_len) {
+    const uint32_t j0 = r0 + w * PR_REF_BLOCK;
+    pr_ref_load(H4, j0 + 2u * round_len, lane, a2, b2);
+    uint32_t x[PR_REF_N];
+    pr_ref_mask(a0, b0, j0, lane, deg, x);
+    const bool mine = j0 < deg;  // (wave-uniform)
     uint32_t E = S >> 23;
     SeqPair t = {0u, 0u};
-    if (taken && E - 1u < 254u) t = seq_block_pair<PR_REF_N>(E, x, lane);
+    if (mine && E - 1u < 254u) t = seq_block_pair<PR_REF_N>(E, x, lane);
     if (lane == 0) {
       s_a0[par][w] = t.a0;
       s_a1[par][w] = t.a1;
-      s_cnt[par][w] = taken;
-      s_more[par][w] = more ? 1u : 0u;
     }
     __syncthreads();
+    const unsigned nw = deg - r0 >= round_len ? (unsigned)PR_REFW_WAVES : (unsigned)((deg - r0 + PR_REF_BLOCK - 1) / PR_REF_BLOCK);  // blocks of this round
     unsigned first = 0;
     for (;;) {  // chain the round's pairs; every wave does, and ends with the same running sum
       // (lane ww holds wave ww's pair: one LDS round trip, then scalar reads)
-      const uint32_t l_a0 = s_a0[par][lane & (PR_REFW_WAVES - 1)], l_a1 = s_a1[par][lane & (PR_REFW_WAVES - 1)],
-                     l_cnt = s_cnt[par][lane & (PR_REFW_WAVES - 1)];
+      const uint32_t l_a0 = s_a0[par][lane & (PR_REFW_WAVES - 1)], l_a1 = s_a1[par][lane & (PR_REFW_WAVES - 1)];
       unsigned wc = PR_REFW_WAVES;
-      for (unsigned ww = first; ww < PR_REFW_WAVES; ww++) {
-        if ((uint32_t)__builtin_amdgcn_readlane((int)l_cnt, ww) == 0u) continue;
+      for (unsigned ww = first; ww < nw; ww++) {
         const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
         const uint32_t tot = P0 + ((P0 & 1u) ? (uint32_t)__builtin_amdgcn_readlane((int)l_a1, ww) : (uint32_t)__builtin_amdgcn_readlane((int)l_a0, ww));
         if (E - 1u >= 254u || tot >= (1u << 24)) {
@@ -385,7 +324,7 @@ pr_refseg_wg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__res
       first = wc + 1;
       if (w >= first) {  // the blocks behind it: their pairs again, on the binade the sum is in now
         SeqPair t2 = {0u, 0u};
-        if (taken && E - 1u < 254u) t2 = seq_block_pair<PR_REF_N>(E, x, lane);
+        if (mine && E - 1u < 254u) t2 = seq_block_pair<PR_REF_N>(E, x, lane);
         if (lane == 0) {
           s_a0[par][w] = t2.a0;
           s_a1[par][w] = t2.a1;
@@ -393,24 +332,13 @@ pr_refseg_wg_kernel(PrRefRows rr, uint32_t g, uint32_t limit, const float *__res
       }
       __syncthreads();
     }
-    bool done;
-    {
-      const unsigned l = lane & (PR_REFW_WAVES - 1);
-      const uint32_t cnt = lane < PR_REFW_WAVES ? s_cnt[par][l] : 0u;
-      done = __ballot(lane < PR_REFW_WAVES && s_more[par][l] == 0u) != 0ull;
-      p += (uint32_t)gdn_wave_sum(cnt);
-    }
-    if (done) break;
     par ^= 1u;
-#pragma unroll
-    for (int k = 0; k < PR_REF_N; k++) x[k] = nx[k];
-    taken = ntaken;
-    more = nmore;
+    a0 = a1;
+    b0 = b1;
+    a1 = a2;
+    b1 = b2;
   }
-  if (threadIdx.x == 0) {
-    rr.sum[i] = S;
-    rr.pos[i] = p;
-  }
+  if (threadIdx.x == 0) rr.sum[i] = S;
 }
 
 // the scores of the selected rows in front of the pull
@@ -448,19 +376,19 @@ __global__ void pr_ref_adddiff_kernel(const double *__restrict__ partial, uint32
 // plan build of the mode: sort keys of the rows (selected: ~degree << 32 | state row; others: all ones), ...
 __global__ void __launch_bounds__(GDN_BLOCK)
 pr_ref_keys_kernel(const eoff_t *__restrict__ rowptr, const uint32_t *__restrict__ row_ids, int32_t m_rows, uint32_t min_deg,
-                   unsigned long long *__restrict__ keys, unsigned long long *__restrict__ count /* [0] selected, [1] long */) {
+                   unsigned long long *__restrict__ keys, unsigned long long *__restrict__ count /* [0] selected rows, [1] their entries */) {
   __shared__ unsigned long long s_tmp[GDN_WAVES_PER_BLOCK];
-  unsigned long long sel = 0, lng = 0;
+  unsigned long long sel = 0, ent = 0;
   for (uint64_t k = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; k < (uint64_t)m_rows; k += (uint64_t)gridDim.x * GDN_BLOCK) {
     const uint64_t r = row_ids ? (uint64_t)row_ids[k] : k;
     const eoff_t d = rowptr[r + 1] - rowptr[r];
     const bool s = d >= (eoff_t)min_deg && d > 0 && d < 0xFFFFFFFFull;
     keys[k] = s ? ((unsigned long long)(0xFFFFFFFFu - (uint32_t)d) << 32) | k : ~0ull;
     sel += s ? 1u : 0u;
-    lng += (s && d > PR_REF_SHORT) ? 1u : 0u;
+    ent += s ? d : 0u;
   }
   gdn_block_add_u64(sel, count, s_tmp);
-  gdn_block_add_u64(lng, count + 1, s_tmp);
+  gdn_block_add_u64(ent, count + 1, s_tmp);
 }
 // ... the sorted keys -> row, degree, padded length
 __global__ void __launch_bounds__(GDN_BLOCK)
@@ -474,24 +402,41 @@ pr_ref_rows_kernel(const unsigned long long *__restrict__ keys, uint32_t n, uint
   deg[i] = d;
   padded[i] = (d + 7u) & ~7u;
 }
-// ... and the rows' column ids in the plan's vertex space (cmap: caller's id -> state index of a squished plan); a wave per row
+// ... the entries of the rows as sort keys (chunk of the source in the plan's vertex space << 32 | place in hv); the pad places
+// behind a row's end get the key of a chunk that does not exist and sort to the end.  cmap: caller's id -> state index of a
+// squished plan.  A wave per row.
 __global__ void __launch_bounds__(GDN_BLOCK)
-pr_ref_cols_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const uint32_t *__restrict__ row_ids,
-                   const eoff_t *__restrict__ cmap, const uint32_t *__restrict__ row, const uint32_t *__restrict__ deg,
-                   const eoff_t *__restrict__ off, uint32_t n, uint32_t *__restrict__ cols) {
+pr_ref_ckeys_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const uint32_t *__restrict__ row_ids,
+                    const eoff_t *__restrict__ cmap, const uint32_t *__restrict__ row, const uint32_t *__restrict__ deg,
+                    const eoff_t *__restrict__ off, uint32_t n, unsigned long long *__restrict__ keys, uint32_t *__restrict__ cols) {
   const unsigned lane = gdn_lane();
   for (uint64_t i = ((uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x) >> 6; i < n; i += ((uint64_t)gridDim.x * GDN_BLOCK) >> 6) {
     const uint64_t r = row_ids ? (uint64_t)row_ids[row[i]] : (uint64_t)row[i];
     const eoff_t e0 = rowptr[r], o = off[i];
     const uint32_t d = deg[i], dp = (d + 7u) & ~7u;
     for (uint32_t j = lane; j < dp; j += 64) {
-      uint32_t c = 0u;  // (pad entries: a valid index, never counted)
+      unsigned long long key = (0xFFFFull << 32) | (unsigned long long)(o + j);
+      uint32_t c = 0u;
       if (j < d) {
         const vid_t v = colidx[e0 + j];
         c = cmap ? (uint32_t)cmap[v] : (uint32_t)v;
+        key = ((unsigned long long)(c >> PR_REF_LOG_CHUNK) << 32) | (unsigned long long)(o + j);
       }
+      keys[o + j] = key;
       cols[o + j] = c;
     }
+  }
+}
+// ... and, from the keys sorted by chunk: place and local source id of every entry, the first entry of every chunk that has one
+__global__ void __launch_bounds__(GDN_BLOCK)
+pr_ref_cfill_kernel(const unsigned long long *__restrict__ keys, uint64_t n_real, const uint32_t *__restrict__ cols,
+                    uint32_t *__restrict__ cdest, uint16_t *__restrict__ cu16, eoff_t *__restrict__ cptr) {
+  for (uint64_t e = (uint64_t)blockIdx.x * GDN_BLOCK + threadIdx.x; e < n_real; e += (uint64_t)gridDim.x * GDN_BLOCK) {
+    const unsigned long long k = keys[e];
+    const uint32_t place = (uint32_t)k, chunk = (uint32_t)(k >> 32);
+    cdest[e] = place;
+    cu16[e] = (uint16_t)(cols[place] & ((1u << PR_REF_LOG_CHUNK) - 1u));
+    if (e == 0 || (uint32_t)(keys[e - 1] >> 32) != chunk) cptr[chunk] = e;
   }
 }
 
@@ -1666,40 +1611,37 @@ static unsigned pb_first_bin_at(const PbPlan &pb, int64_t row) {
   return lo;
 }
 
-// GDN_PR_SUM=reference, behind a pull: the selected rows summed again in the reference's order -- one launch per group of
-// 2^ref_glog sources --, their scores / next contributions rewritten, the L1 change corrected by what that moved
+// GDN_PR_SUM=reference, behind a pull: the selected rows summed again in the reference's order -- the stage pass (their
+// contributions into hv through LDS slices), the scans (waves / workgroups, side by side on two streams) --, their scores /
+// next contributions rewritten, the L1 change corrected by what that moved
 static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipStream_t s) {
   if (plan->ref_n == 0) return GDN_OK;
+  static bool attr_set = false;
+  const size_t lds = sizeof(float) << PR_REF_LOG_CHUNK;
+  if (!attr_set) {
+    GDN_HIP(hipFuncSetAttribute((const void *)pr_ref_stage_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(pr_ref_stage_kernel, dim3(plan->ref_nchunks), dim3(PR_REF_STAGE_THREADS), lds, s, op.contrib_in, (uint32_t)plan->m_global,
+                     plan->ref_cptr.p, plan->ref_cu16.p, plan->ref_cdest.p, plan->ref_hv.p, op.skip);
   PrRefRows rr;
   rr.row = plan->ref_row.p;
   rr.deg = plan->ref_deg.p;
   rr.off = plan->ref_off.p;
-  rr.cols = plan->ref_cols.p;
+  rr.hv = plan->ref_hv.p;
   rr.sum = plan->ref_sumbits.p;
-  rr.pos = plan->ref_pos.p;
-  rr.zero = reinterpret_cast<const float *>(plan->ref_partial.p + PR_REF_DIFF_BLOCKS);  // (a zeroed double behind the partial sums)
   rr.n = plan->ref_n;
-  rr.n_long = plan->ref_n_long;
-  const uint64_t space = (uint64_t)plan->m_global;  // the index space of contrib_in
-  const uint32_t ngroups = plan->ref_n_long ? (uint32_t)((space + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1u;
   rr.n_vlong = plan->ref_n_vlong;
-  // the very long rows' workgroups (a latency chain per row, a few hundred workgroups) run BESIDE the other rows' waves (bound
-  // by the rate of their gathers): the two kinds of rows share nothing, so their launches go to two streams
+  // the very long rows' workgroups (a chain per row) run BESIDE the other rows' waves: the two kinds of rows share nothing
   hipStream_t sw = s;
   if (rr.n_vlong && plan->ref_stream && plan->ref_ev[0] && plan->ref_ev[1]) {
     sw = plan->ref_stream;
     GDN_HIP(hipEventRecord(plan->ref_ev[0], s));
     GDN_HIP(hipStreamWaitEvent(sw, plan->ref_ev[0], 0));
   }
-  for (uint32_t g = 0; g < ngroups; g++) {
-    const uint32_t nrows = (g == 0 ? rr.n : rr.n_long) - rr.n_vlong;
-    const uint32_t limit = g + 1 == ngroups ? 0xFFFFFFFFu : (uint32_t)((uint64_t)(g + 1) << plan->ref_glog);
-    if (rr.n_vlong)
-      hipLaunchKernelGGL(pr_refseg_wg_kernel, dim3(rr.n_vlong), dim3(PR_REFW_THREADS), 0, sw, rr, g, limit, op.contrib_in, op.skip);
-    if (nrows)
-    hipLaunchKernelGGL(pr_refseg_kernel, dim3((nrows + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, g, limit,
-                       op.contrib_in, op.skip, gdn_xoption("GDN_PR_REF_DBG") ? atoi(gdn_xoption("GDN_PR_REF_DBG")) : 0);
-  }
+  if (rr.n_vlong) hipLaunchKernelGGL(pr_refscan_wg_kernel, dim3(rr.n_vlong), dim3(PR_REFW_THREADS), 0, sw, rr, op.skip);
+  if (rr.n > rr.n_vlong)
+    hipLaunchKernelGGL(pr_refscan_kernel, dim3((rr.n - rr.n_vlong + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, op.skip);
   if (sw != s) {
     GDN_HIP(hipEventRecord(plan->ref_ev[1], sw));
     GDN_HIP(hipStreamWaitEvent(s, plan->ref_ev[1], 0));
@@ -1712,62 +1654,89 @@ static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipSt
   return GDN_OK;
 }
 
-// the build of that mode (plan create): rows selected and sorted by in-degree, their columns copied into the plan's space
+// the build of that mode (plan create): rows selected and sorted by in-degree; their entries as (chunk, place) keys, sorted by
+// chunk -> the chunk-major arrays of the stage pass
 static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap) {
   const int32_t m_rows = p->m_local;
   if (m_rows <= 0) return GDN_OK;
-  DevBuf<unsigned long long> ka, kb, cnt;
-  GDN_TRY(ka.alloc_scratch((size_t)m_rows));
-  GDN_TRY(kb.alloc_scratch((size_t)m_rows));
-  GDN_TRY(cnt.alloc(2));
-  GDN_HIP(hipMemset(cnt.p, 0, 16));
   const uint32_t *row_ids = p->squished ? p->sq_ids.p : nullptr;
-  hipLaunchKernelGGL(pr_ref_keys_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, row_ids, m_rows, p->ref_min_deg, ka.p, cnt.p);
-  GDN_HIP(hipGetLastError());
   unsigned long long h[2] = {0, 0};
-  GDN_HIP(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
-  p->ref_n = (uint32_t)h[0];
-  p->ref_n_long = (uint32_t)h[1];
-  if (p->ref_n == 0) return GDN_OK;
   const unsigned long long *sorted = nullptr;
-  GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m_rows, 32, 64, &sorted));  // (stable: equal degrees stay in row order)
+  {
+    DevBuf<unsigned long long> ka, kb, cnt;
+    GDN_TRY(ka.alloc_scratch((size_t)m_rows));
+    GDN_TRY(kb.alloc_scratch((size_t)m_rows));
+    GDN_TRY(cnt.alloc(2));
+    GDN_HIP(hipMemset(cnt.p, 0, 16));
+    hipLaunchKernelGGL(pr_ref_keys_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, row_ids, m_rows, p->ref_min_deg, ka.p, cnt.p);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipMemcpy(h, cnt.p, 16, hipMemcpyDeviceToHost));
+    p->ref_n = (uint32_t)h[0];
+    if (p->ref_n == 0) return GDN_OK;
+    GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)m_rows, 32, 64, &sorted));  // (stable: equal degrees stay in row order)
+    const uint32_t n = p->ref_n;
+    DevBuf<uint32_t> padded;
+    GDN_TRY(p->ref_row.alloc(n));
+    GDN_TRY(p->ref_deg.alloc(n));
+    GDN_TRY(p->ref_off.alloc((size_t)n + 1));
+    GDN_TRY(p->ref_sumbits.alloc(n));
+    GDN_TRY(p->ref_old.alloc(n));
+    GDN_TRY(p->ref_partial.alloc(PR_REF_DIFF_BLOCKS));
+    GDN_TRY(padded.alloc_scratch(n));
+    hipLaunchKernelGGL(pr_ref_rows_kernel, dim3(gdn_nblocks((uint64_t)n)), dim3(GDN_BLOCK), 0, 0, sorted, n, p->ref_row.p, p->ref_deg.p, padded.p);
+    GDN_HIP(hipGetLastError());
+    GDN_TRY(gdn_exclusive_scan_u32_to_u64(padded.p, p->ref_off.p, (size_t)n, 0));
+    GDN_HIP(hipDeviceSynchronize());
+  }
   const uint32_t n = p->ref_n;
-  DevBuf<uint32_t> padded;
-  GDN_TRY(p->ref_row.alloc(n));
-  GDN_TRY(p->ref_deg.alloc(n));
-  GDN_TRY(p->ref_off.alloc((size_t)n + 1));
-  GDN_TRY(p->ref_sumbits.alloc(n));
-  GDN_TRY(p->ref_pos.alloc(n));
-  GDN_TRY(p->ref_old.alloc(n));
-  GDN_TRY(p->ref_partial.alloc(PR_REF_DIFF_BLOCKS + 2));
-  GDN_HIP(hipMemset(p->ref_partial.p, 0, (PR_REF_DIFF_BLOCKS + 2) * sizeof(double)));
-  GDN_TRY(padded.alloc_scratch(n));
-  hipLaunchKernelGGL(pr_ref_rows_kernel, dim3(gdn_nblocks((uint64_t)n)), dim3(GDN_BLOCK), 0, 0, sorted, n, p->ref_row.p, p->ref_deg.p, padded.p);
-  GDN_HIP(hipGetLastError());
-  GDN_TRY(gdn_exclusive_scan_u32_to_u64(padded.p, p->ref_off.p, (size_t)n, 0));
   eoff_t total = 0;
   uint32_t longest = 0;
   GDN_HIP(hipMemcpy(&total, p->ref_off.p + n, sizeof(eoff_t), hipMemcpyDeviceToHost));
   GDN_HIP(hipMemcpy(&longest, p->ref_deg.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
-  p->ref_edges = total;
+  GDN_REQUIRE(total < 0xFFFF0000ull, "GDN_PR_SUM=reference: more than 2^32 entries in the selected rows (raise GDN_PR_SUM_MIN_DEGREE)");
+  const uint64_t n_real = h[1];
+  p->ref_edges = n_real;
   p->ref_longest = longest;
-  GDN_TRY(p->ref_cols.alloc((size_t)total + (size_t)(3 * PR_REFW_WAVES + 3 * PR_REF_DEPTH + 2) * PR_REF_BLOCK + 8));  // (the sum kernel's loads run up to 3 D blocks past a row)
-  hipLaunchKernelGGL(pr_ref_cols_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->colidx, row_ids, cmap, p->ref_row.p, p->ref_deg.p,
-                     p->ref_off.p, n, p->ref_cols.p);
-  GDN_HIP(hipGetLastError());
-  GDN_HIP(hipDeviceSynchronize());
-  if (const char *e = gdn_option("GDN_PR_SUM_GROUP_LOG")) p->ref_glog = atoi(e) >= 10 && atoi(e) <= 31 ? atoi(e) : p->ref_glog;
-  {  // the very long rows: four blocks per launch or more (the rows are sorted by length: a prefix)
-    const uint64_t ngroups = ((uint64_t)p->m_global + (1ull << p->ref_glog) - 1) >> p->ref_glog;
-    uint64_t thr = 4ull * PR_REF_BLOCK * ngroups;
+  p->ref_nchunks = (uint32_t)(((uint64_t)p->m_global + (1u << PR_REF_LOG_CHUNK) - 1) >> PR_REF_LOG_CHUNK);
+  GDN_REQUIRE(p->ref_nchunks < 0xFFFFu, "GDN_PR_SUM=reference: vertex space beyond 2^31");
+  // hv: the rows' places + what the scans' loads run ahead of a row's end (three rounds of a workgroup)
+  GDN_TRY(p->ref_hv.alloc((size_t)total + (size_t)(3 * PR_REFW_WAVES + 4) * PR_REF_BLOCK + 8));
+  GDN_HIP(hipMemset(p->ref_hv.p, 0, p->ref_hv.n * sizeof(float)));
+  GDN_TRY(p->ref_cdest.alloc((size_t)n_real + 1));
+  GDN_TRY(p->ref_cu16.alloc((size_t)n_real + 1));
+  GDN_TRY(p->ref_cptr.alloc((size_t)p->ref_nchunks + 1));
+  {
+    DevBuf<unsigned long long> ka, kb;
+    DevBuf<uint32_t> cols;
+    GDN_TRY(ka.alloc_scratch((size_t)total + 1));
+    GDN_TRY(kb.alloc_scratch((size_t)total + 1));
+    GDN_TRY(cols.alloc_scratch((size_t)total + 1));
+    hipLaunchKernelGGL(pr_ref_ckeys_kernel, dim3(2048), dim3(GDN_BLOCK), 0, 0, csr->rowptr, csr->colidx, row_ids, cmap, p->ref_row.p, p->ref_deg.p,
+                       p->ref_off.p, n, ka.p, cols.p);
+    GDN_HIP(hipGetLastError());
+    GDN_TRY(gdn_radix_sort_u64(ka.p, kb.p, (unsigned long long)total, 32, 48, &sorted));  // (stable: places ascend inside a chunk)
+    GDN_HIP(hipMemset(p->ref_cptr.p, 0xFF, ((size_t)p->ref_nchunks + 1) * sizeof(eoff_t)));
+    hipLaunchKernelGGL(pr_ref_cfill_kernel, dim3(4096), dim3(GDN_BLOCK), 0, 0, sorted, n_real, cols.p, p->ref_cdest.p, p->ref_cu16.p, p->ref_cptr.p);
+    GDN_HIP(hipGetLastError());
+    GDN_HIP(hipDeviceSynchronize());
+  }
+  {  // chunks without an entry start where the next one starts
+    std::vector<eoff_t> cp((size_t)p->ref_nchunks + 1);
+    GDN_HIP(hipMemcpy(cp.data(), p->ref_cptr.p, cp.size() * sizeof(eoff_t), hipMemcpyDeviceToHost));
+    cp[p->ref_nchunks] = n_real;
+    for (size_t c = p->ref_nchunks; c-- > 0;)
+      if (cp[c] == ~(eoff_t)0) cp[c] = cp[c + 1];
+    GDN_HIP(hipMemcpy(p->ref_cptr.p, cp.data(), cp.size() * sizeof(eoff_t), hipMemcpyHostToDevice));
+  }
+  {  // the very long rows: four rounds of a workgroup or more (the rows are sorted by length: a prefix), at most one per CU
+    uint64_t thr = 4ull * PR_REFW_WAVES * PR_REF_BLOCK;
     if (const char *e = gdn_test_option("GDN_PR_SUM_WG_MIN")) thr = strtoull(e, nullptr, 10);  // (test hook: small graphs reach the workgroup kernel)
     const uint32_t look = n < 65536u ? n : 65536u;
     std::vector<uint32_t> hd(look);
     GDN_HIP(hipMemcpy(hd.data(), p->ref_deg.p, (size_t)look * 4, hipMemcpyDeviceToHost));
-    uint32_t nv = 0;
-    uint32_t cap = 256u;  // one workgroup per CU: every such row's chain runs at once
+    uint32_t nv = 0, cap = 256u;
     if (gdn_test_option("GDN_PR_SUM_WG_MIN")) cap = look;
-    while (nv < look && nv < cap && nv < p->ref_n_long && (uint64_t)hd[nv] >= thr) nv++;
+    while (nv < look && nv < cap && (uint64_t)hd[nv] >= thr) nv++;
     p->ref_n_vlong = nv;
     if (nv && (hipStreamCreateWithFlags(&p->ref_stream, hipStreamNonBlocking) != hipSuccess ||
                hipEventCreateWithFlags(&p->ref_ev[0], hipEventDisableTiming) != hipSuccess ||
@@ -1778,8 +1747,8 @@ static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap
     }
   }
   if (gdn_xoption("GDN_PR_SUM_TRACE"))
-    fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u longer than %d, %u of them on a workgroup each), %llu entries, longest %u, groups of 2^%d sources\n",
-            p->ref_n, p->ref_min_deg, p->ref_n_long, PR_REF_SHORT, p->ref_n_vlong, (unsigned long long)total, longest, p->ref_glog);
+    fprintf(stderr, "[pr refsum] %u rows of >= %u in-edges (%u of them on a workgroup each), %llu entries in %u chunks, longest %u\n", p->ref_n,
+            p->ref_min_deg, p->ref_n_vlong, (unsigned long long)n_real, p->ref_nchunks, longest);
   return GDN_OK;
 }
 
@@ -2184,10 +2153,7 @@ int gdn_pr_plan_refsum_info(const gdn_pr_plan *plan, int32_t *rows, int32_t *lon
   if (rows) *rows = (int32_t)plan->ref_n;
   if (longest_row) *longest_row = (int32_t)plan->ref_longest;
   if (entries) *entries = plan->ref_edges;
-  if (groups) {  // launches per pull: the old scores, per group one for the waves' rows and one for the workgroups' rows, apply, L1
-    const int32_t ng = plan->ref_n_long ? (int32_t)(((uint64_t)plan->m_global + (1ull << plan->ref_glog) - 1) >> plan->ref_glog) : 1;
-    *groups = (!plan->ref_sum || plan->ref_n == 0) ? 0 : 3 + ng * (plan->ref_n_vlong ? 2 : 1);
-  }
+  if (groups) *groups = (!plan->ref_sum || plan->ref_n == 0) ? 0 : 4 + (plan->ref_n_vlong ? 1 : 0) + (plan->ref_n > plan->ref_n_vlong ? 1 : 0);
   return GDN_OK;
 }
 

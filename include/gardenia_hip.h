@@ -65,8 +65,7 @@ const char *gdn_last_error(void);
  *     GDN_PR_FUSED      0 | 1         gdn_pr: the whole solve in one cooperative launch (default below 2^18 edges) or never / always
  *     GDN_PR_BATCH      n             gdn_pr: iterations queued per convergence check on the device (default 8)
  *     GDN_PR_SUM        reference     re-sum rows in the reference's fp32 order behind every pull (see gdn_pr_plan_refsum_info),
- *     GDN_PR_SUM_MIN_DEGREE n           the rows of >= n in-edges (default 0 = every row),
- *     GDN_PR_SUM_GROUP_LOG  k           in groups of 2^k sources per launch (default 21)
+ *     GDN_PR_SUM_MIN_DEGREE n           the rows of >= n in-edges (default 0 = every row)
  *     GDN_PRD_LAYOUT    csr | pb      layout of gdn_pr_delta's pull plan;  GDN_PRD_PUSH_DIV n  its push / pull switch (frontier edges < nnz / n)
  *     GDN_SPMV_LAYOUT   csr | pb      SpMV plans;  GDN_SPMV_ONESHOT solve  gdn_spmv builds the blocked layout inside the call (prep_ms)
  *     GDN_BFS_COOP      0 | 1         light BFS levels on the cooperative grid: never / from the first one (default: after 8 light levels)
@@ -353,10 +352,11 @@ int gdn_pr_plan_check(gdn_pr_plan *plan);
 /* Option GDN_PR_SUM=reference (read by gdn_pr_plan_create / gdn_pr): behind every pull the rows of at least
  * GDN_PR_SUM_MIN_DEGREE in-edges (default 0: every row) are summed AGAIN in the order of src/pr/omp_base.cc:27-30 -- one fp32
  * addition per in-edge, in CSR order -- and their scores, next contributions and the L1 change rewritten: those rows then carry
- * the reference's bits (with every row selected the whole solve does).  The sums are evaluated by scans, not by a chain of
- * additions, and group by group of 2^GDN_PR_SUM_GROUP_LOG sources (default 21) so that the gathered contributions stay in L2
- * (csrc/gdn_seqsum.hpp).  This call reports what a plan of that mode re-sums: rows, the longest of them, entries
- * (in-edges, rows padded to multiples of 8) and launches per pull; all 0 for a plan without the mode. */
+ * the reference's bits (with every row selected the whole solve does).  Two passes per pull: the contributions those rows read
+ * are staged in row order through LDS slices of the contribution vector (no gather leaves a CU), then every row is summed by
+ * scans of parity functions, not by a chain of additions (csrc/gdn_seqsum.hpp).  The plan keeps 10 bytes per
+ * selected in-edge.  This call reports what a plan of that mode re-sums: rows, the longest of them, entries (in-edges) and
+ * launches per pull; all 0 for a plan without the mode. */
 int gdn_pr_plan_refsum_info(const gdn_pr_plan *plan, int32_t *rows, int32_t *longest_row, uint64_t *entries, int32_t *groups);
 int gdn_pr_plan_free(gdn_pr_plan *plan);
 /* entries of the per-vertex state arrays (scores, contrib) the iteration calls of this plan work on: m_local, or the

@@ -253,10 +253,10 @@ def test_pr_reference_sum_mode_has_the_reference_bits(orc, layout, monkeypatch):
     assert np.array_equal(again, plain)  # the mode leaves nothing behind
 
 
-@pytest.mark.parametrize("glog,wg_min", [("10", "1"), ("12", "4000"), ("31", "1"), ("11", "4000000000")])
-def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog, wg_min):
-    """The kernel behind GDN_PR_SUM=reference (gdn_seqsum.hpp: scans of parity functions instead of a chain of additions, the
-    rows cut into groups of 2^glog sources that are summed launch by launch) on contributions chosen to hit every branch of
+@pytest.mark.parametrize("wg_min", ["1", "4000", "4000000000"])
+def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, wg_min):
+    """The kernels behind GDN_PR_SUM=reference (the stage pass: contributions through LDS slices into row order; the scans:
+    gdn_seqsum.hpp's parity functions instead of a chain of additions) on contributions chosen to hit every branch of
     its arithmetic -- equal terms, exact ties, powers of two, zeros, denormals, terms above the running sum; then a negative
     term and an infinity (the hardware path) --, on rows of 1 ... 9 000 in-edges, the long ones on a wave or on a workgroup
     each: every score has the bits of
@@ -265,7 +265,7 @@ def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog, wg_min
     from gardenia_amd import _cabi
     from test_seqsum_math import _case
     L = _cabi.lib()
-    rng = np.random.default_rng(int(glog))
+    rng = np.random.default_rng(len(wg_min))
     m = 9000
     rows = [np.arange(1, m), rng.choice(m, 5000, replace=False), rng.choice(m, 700, replace=False), np.arange(0, m, 7)]
     rows += [rng.choice(m, int(d), replace=False) for d in rng.integers(0, 40, m - len(rows))]
@@ -274,7 +274,6 @@ def test_pr_reference_order_sums_of_adversarial_values(monkeypatch, glog, wg_min
     g = graphio.build_csr(m, src.astype(np.int64), dst.astype(np.int64))  # out-CSR of src -> dst
     gi = graphio.transpose(g)
     monkeypatch.setenv("GDN_PR_SUM", "reference")
-    monkeypatch.setenv("GDN_PR_SUM_GROUP_LOG", glog)
     # rows of at least wg_min in-edges are summed by a WORKGROUP each (16 waves chain the pairs of 16 blocks per round:
     # pr_refseg_wg_kernel), the others by a wave each -- "1": every row longer than one block; "4000000000": none
     monkeypatch.setenv("GDN_PR_SUM_WG_MIN", wg_min)

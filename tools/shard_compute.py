@@ -130,7 +130,7 @@ for N in [int(x) for x in args.n.split(",")]:
             c.fill_(1.0 / m / 16.0)
         be.contrib(0)
         nb = be.n_bins()
-        parts = max(1, min(4, nb // 512))  # (bench.py's rule)
+        parts = max(1, min(4, nb // 128))  # (bench.py's rule)
         a1, b1, w1 = time_pulls(be, args.steps, 0)
         a4, b4, w4 = time_pulls(be, args.steps, parts, chunk)
         ib = be.iter_bytes()
