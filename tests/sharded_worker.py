@@ -67,6 +67,30 @@ class NumpyBackend:
             self.diff[0] = self._acc
 
 
+class TicketedNumpyBackend(NumpyBackend):
+    """The contract of gdn_pr_pull_parts_dev / gdn_pr_wait_part_dev on the CPU: pull_ticketed computes the WHOLE iteration at once
+    (as the one launch per phase does) but publishes a part's rows only when part_ready(j) is entered -- until then the rows of
+    that part hold a poison value in the vector the ranks exchange.  An exchange queued outside its part's context, or before
+    it, would ship the poison and the scores would not equal the oracle's."""
+
+    def pull_ticketed(self, cin, cout, damping, row_ends):
+        ml = self.hi - self.lo
+        self.pull_rows(cin, cout, damping, 0, ml, True, True)
+        out = self.contribs[cout].numpy()
+        self._held, self._ends, self._cout = out[self.lo:self.hi].copy(), [min(int(r), ml) for r in row_ends], cout
+        out[self.lo:self.hi] = np.float32(-7.0)
+        self._released = 0
+
+    def part_ready(self, part):
+        import contextlib
+        assert part == self._released, "parts are released in order"
+        r0 = self._ends[part - 1] if part else 0
+        r1 = self._ends[part]
+        self.contribs[self._cout].numpy()[self.lo + r0:self.lo + r1] = self._held[r0:r1]
+        self._released += 1
+        return contextlib.nullcontext()
+
+
 def main():
     scale, ef, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -77,6 +101,7 @@ def main():
     src, dst = graphio.csr_to_coo(g)
     g = graphio.build_csr(m, src[keep], dst[keep])
     gi = graphio.transpose(g)
+    Backend = TicketedNumpyBackend if os.environ.get("GDN_TEST_TICKETS") == "1" else NumpyBackend
     if os.environ.get("GDN_TEST_BALANCED") == "1":
         # nnz-balanced ranges in the padded vertex space (what bench.py --gpus N and gdn_pr_multi do)
         ranges = edge_balanced_ranges(gi.rowptr, world, min_rows=1)
@@ -84,13 +109,13 @@ def main():
         chunk = padded_chunk(bounds)
         blo, bhi = ranges[rank]
         lo, hi = rank * chunk, rank * chunk + (bhi - blo)
-        be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world, row0=blo, colidx=pad_columns(gi.colidx, bounds, chunk))
+        be = Backend(gi, g.degrees(), m, lo, hi, chunk, world, row0=blo, colidx=pad_columns(gi.colidx, bounds, chunk))
         m_space = chunk * world
         if rank == 0:
             np.save(f"{out}.bounds.npy", np.array(bounds))
     else:
         lo, hi, chunk = vertex_range(rank, world, m)
-        be = NumpyBackend(gi, g.degrees(), m, lo, hi, chunk, world)
+        be = Backend(gi, g.degrees(), m, lo, hi, chunk, world)
         m_space = m
     parts = int(os.environ.get("GDN_TEST_PARTS", "4"))
     pr = ShardedPageRank(be, m_space, rank, world, dist, parts=parts, exchange=os.environ.get("GDN_TEST_EXCHANGE", "auto"))

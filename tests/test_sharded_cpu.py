@@ -48,12 +48,16 @@ def test_part_ranges_cover_the_chunk_and_agree_across_ranks():
     assert ShardedPageRank(B(), 100, 0, 1, dist=None, parts=4).parts == 1  # a single rank is never cut
 
 
-@pytest.mark.parametrize("world,parts,exchange,balanced",
-                         [(2, 4, "dense", 0), (3, 4, "dense", 0), (2, 1, "dense", 0), (3, 7, "dense", 0),
-                          (2, 4, "compact", 0), (3, 3, "compact", 0), (2, 1, "compact", 0),
-                          (2, 4, "dense", 1), (3, 3, "compact", 1), (3, 1, "dense", 1)])
-def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange, balanced):
-    """balanced = 1: nnz-balanced vertex ranges in the padded vertex space, as bench.py --gpus N cuts them."""
+@pytest.mark.parametrize("world,parts,exchange,balanced,tickets",
+                         [(2, 4, "dense", 0, 0), (3, 4, "dense", 0, 0), (2, 1, "dense", 0, 0), (3, 7, "dense", 0, 0),
+                          (2, 4, "compact", 0, 0), (3, 3, "compact", 0, 0), (2, 1, "compact", 0, 0),
+                          (2, 4, "dense", 1, 0), (3, 3, "compact", 1, 0), (3, 1, "dense", 1, 0),
+                          (2, 4, "dense", 0, 1), (3, 3, "compact", 1, 1), (3, 5, "dense", 1, 1)])
+def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange, balanced, tickets):
+    """balanced = 1: nnz-balanced vertex ranges in the padded vertex space, as bench.py --gpus N cuts them.
+    tickets = 1 (round 6): the backend computes the whole iteration at once and releases a part's rows only inside
+    part_ready(j) -- the driver's contract with gdn_pr_pull_parts_dev / gdn_pr_wait_part_dev: every exchange is queued inside
+    its part's context, after the part was released (sharded_worker.TicketedNumpyBackend poisons what is not released)."""
     scale, ef = 8, 8
     out = str(tmp_path / "pr")
     port = _free_port()
@@ -61,7 +65,7 @@ def test_sharded_pagerank_gloo(orc, tmp_path, world, parts, exchange, balanced):
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), OMP_NUM_THREADS="1", GDN_TEST_PARTS=str(parts), GDN_TEST_EXCHANGE=exchange,
-                   GDN_TEST_BALANCED=str(balanced))
+                   GDN_TEST_BALANCED=str(balanced), GDN_TEST_TICKETS=str(tickets))
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_worker.py"),
                                        str(scale), str(ef), out], env=env))
     for p in procs:
