@@ -1117,6 +1117,14 @@ uint64_t pb_slots_per_slice(uint64_t n_act, int lg, int lg_full) {
   const bool on = !(be && be[0] == '0');
   const uint64_t cap = 1ull << lg;
   const uint64_t ns = (n_act + cap - 1) >> lg;
+  // fewer slices than CUs (and at least 1024 slots each): exactly ONE round of smaller slices (round 6; GDN_PB_FILL_ROUND=0 in
+  // an experiments build keeps the cap)
+  const char *fe = gdn_xoption("GDN_PB_FILL_ROUND");
+  if (on && lg == lg_full && ns < (uint64_t)ncu && n_act >= (uint64_t)ncu * 1024u && !(fe && fe[0] == '0')) {
+    uint64_t per1 = (n_act + (uint64_t)ncu - 1) / (uint64_t)ncu;
+    per1 = (per1 + 3) & ~3ull;
+    return per1 < cap ? per1 : cap;
+  }
   if (!on || lg != lg_full || ns <= (uint64_t)ncu) return cap;
   const uint64_t rounds = (ns + (uint64_t)ncu - 1) / (uint64_t)ncu;
   uint64_t per = (n_act + rounds * ncu - 1) / (rounds * ncu);

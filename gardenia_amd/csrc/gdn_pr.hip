@@ -1020,7 +1020,10 @@ int gdn_pr_plan_create(const gdn_graph *in_csr, const int32_t *d_out_degree, int
   if (layout == GDN_LAYOUT_CSR) {
     st = mp_plan_build(p->mp, in_csr, 0);
   } else {
-    int slices_log = in_csr->m == m_global ? 9 : 10;
+    // (round 6: whole graphs 2^8 -- with fewer slices than CUs filled up to exactly one round, pb_slots_per_slice --: ONE round
+    // of large chunks beats two of half-size ones on mid-size graphs: LJ-like 0.542 -> 0.565 of the roofline, R-MAT-22 0.600 ->
+    // 0.614, R-MAT-24 / 25 / 27 unchanged (their slices are full-size anyway), profiles/r06_pr_midsize.txt)
+    int slices_log = in_csr->m == m_global ? 8 : 10;
     if (const char *e = gdn_xoption("GDN_PB_SLICES_LOG")) slices_log = atoi(e) >= 6 && atoi(e) <= 12 ? atoi(e) : slices_log;  // tuning knob
     int lc = pb_pick_log(m_global, PB_MAX_LOG_CHUNK, slices_log), lb = pb_pick_log(in_csr->m, PB_MAX_LOG_BIN, slices_log);
     if (const char *e = gdn_test_option("GDN_PB_LOG_CHUNK")) lc = atoi(e);  // tuning knobs (tools/)

@@ -1,7 +1,7 @@
 # Round-6 session 12 (run again as session 19 on the later code): the whole GPU suite, config 2 size, the full default bench line
 # spread over whole rounds), then config 2's size again and the full default bench line
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-O=gpurun_out/r06s12
+O=gpurun_out/r06s19
 mkdir -p $O; rm -rf $O/*
 timeout 120 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 2400 python3 -m pytest tests -x -q -m gpu --durations=8 > $O/pytest_all.txt 2>&1; grep -E "FAILED|passed|failed|Error" $O/pytest_all.txt | head; grep -E "s call" $O/pytest_all.txt | head -8
@@ -10,7 +10,7 @@ GARDENIA_HIP_LIB=$GRAFT_REPO_ROOT/gardenia_amd/lib/var_exp/libgardenia_hip.so ti
 timeout 1500 python3 bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.log; tail -2 $O/bench.log | cut -c1-300
 python3 - <<'PY'
 import json
-r = json.loads([l for l in open("gpurun_out/r06s12/bench.json") if l.startswith("{")][-1])
+r = json.loads([l for l in open("gpurun_out/r06s19/bench.json") if l.startswith("{")][-1])
 print("ms/step %.3f frac %.3f" % (r["ms_per_step"], r["roofline"]["frac"]), "refsum", {k: r["pr_reference_sum"][k] for k in ("ms_per_step", "frac", "rows_resummed", "longest_row")} if r.get("pr_reference_sum") else None)
 print("bfs", r["bfs"]["ms_by_source"], r["bfs"].get("gteps_on_the_reference_timer"), r["bfs"].get("depth_finish_pass_ms"), r["bfs"].get("unreached_fill_modelled_ms"))
 print("spmv", r["spmv"]["ms"], r["spmv"]["roofline"]["frac"]); print("tc", r["tc"]["ms"]); print("oneshot", r["pr_oneshot"]["pb"], r["pr_oneshot"]["auto"])

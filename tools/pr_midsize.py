@@ -12,9 +12,12 @@ from gardenia_amd import _cabi, graphio
 
 L = _cabi.lib()
 sets = sys.argv[1:] or [""]
-r = graphio.LJ_LIKE
 go, gi = C.c_void_p(), C.c_void_p()
-_cabi.check(L.gdn_rmat_build_ex(r["scale"], r["n_edges"], *r["abc"], graphio.K_RAND_SEED, r["flags"], C.byref(go), C.byref(gi)))
+if os.environ.get("PR_MIDSIZE_RMAT"):  # an R-MAT graph of that scale instead of the LJ-like stand-in
+    _cabi.check(L.gdn_rmat_build(int(os.environ["PR_MIDSIZE_RMAT"]), 16, graphio.K_RAND_SEED, 1, C.byref(go), C.byref(gi)))
+else:
+    r = graphio.LJ_LIKE
+    _cabi.check(L.gdn_rmat_build_ex(r["scale"], r["n_edges"], *r["abc"], graphio.K_RAND_SEED, r["flags"], C.byref(go), C.byref(gi)))
 m, nnz = C.c_int32(), C.c_uint64()
 _cabi.check(L.gdn_graph_info(gi, C.byref(m), C.byref(nnz), None, None))
 m, nnz = m.value, nnz.value
@@ -34,7 +37,7 @@ h_deg = np.empty(m, np.int32)
 _cabi.check(L.gdn_dev_download(h_deg.ctypes.data_as(C.c_void_p), deg, 4 * m))
 L.gdn_graph_free(go)
 init = np.full(m, np.float32(1.0) / np.float32(m), np.float32)
-print("LJ-like stand-in: %d vertices, %d edges" % (m, nnz))
+print("%s: %d vertices, %d edges" % ("R-MAT-" + os.environ["PR_MIDSIZE_RMAT"] if os.environ.get("PR_MIDSIZE_RMAT") else "LJ-like stand-in", m, nnz))
 for spec in sets:
     env = dict(kv.split("=") for kv in spec.split(",") if kv)
     for k, v in env.items():
