@@ -1741,7 +1741,11 @@ static int pr_ref_build(gdn_pr_plan *p, const gdn_graph *csr, const eoff_t *cmap
     if (gdn_test_option("GDN_PR_SUM_WG_MIN")) cap = look;
     while (nv < look && nv < cap && (uint64_t)hd[nv] >= thr) nv++;
     p->ref_n_vlong = nv;
-    if (nv && (hipStreamCreateWithFlags(&p->ref_stream, hipStreamNonBlocking) != hipSuccess ||
+    // (highest priority: the few hundred workgroups of the very long rows are a latency chain each and must not queue behind
+    // the 20 K waves of the other rows, which are launched beside them and fill every CU's wave slots)
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (nv && (hipStreamCreateWithPriority(&p->ref_stream, hipStreamNonBlocking, prio_greatest) != hipSuccess ||
                hipEventCreateWithFlags(&p->ref_ev[0], hipEventDisableTiming) != hipSuccess ||
                hipEventCreateWithFlags(&p->ref_ev[1], hipEventDisableTiming) != hipSuccess)) {
       (void)hipGetLastError();  // (no second stream: everything on the caller's)
