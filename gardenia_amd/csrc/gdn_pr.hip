@@ -271,7 +271,7 @@ pr_refscan_kernel(PrRefRows rr, const unsigned *__restrict__ skip) {
 #define PR_REFW_WAVES 16
 #define PR_REFW_THREADS (64 * PR_REFW_WAVES)
 __global__ void __launch_bounds__(PR_REFW_THREADS)
-pr_refscan_wg_kernel(PrRefRows rr, const unsigned *__restrict__ skip) {
+pr_refscan_wg_kernel(PrRefRows rr, const unsigned *__restrict__ skip, int dbg = 0 /* GDN_EXPERIMENTS: 1 no pairs, 2 no chain (timing only) */) {
   if (skip && *skip) return;
   __shared__ uint32_t s_a0[2][PR_REFW_WAVES], s_a1[2][PR_REFW_WAVES], s_S;
   const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
@@ -292,26 +292,52 @@ pr_refscan_wg_kernel(PrRefRows rr, const unsigned *__restrict__ skip) {
     const bool mine = j0 < deg;  // (wave-uniform)
     uint32_t E = S >> 23;
     SeqPair t = {0u, 0u};
+#ifdef GDN_EXPERIMENTS
+    if (dbg & 1) {
+      t.a0 = t.a1 = x[0] & 1023u;
+    } else
+#endif
     if (mine && E - 1u < 254u) t = seq_block_pair<PR_REF_N>(E, x, lane);
     if (lane == 0) {
       s_a0[par][w] = t.a0;
       s_a1[par][w] = t.a1;
     }
     __syncthreads();
+#ifdef GDN_EXPERIMENTS
+    if (dbg & 2) {
+      S = ((S + s_a0[par][lane & 15u]) & 0x7FFFFFu) | 0x30000000u;
+      S = (uint32_t)__builtin_amdgcn_readfirstlane((int)S);
+      par ^= 1u;
+      a0 = a1;
+      b0 = b1;
+      a1 = a2;
+      b1 = b2;
+      continue;
+    }
+#endif
     const unsigned nw = deg - r0 >= round_len ? (unsigned)PR_REFW_WAVES : (unsigned)((deg - r0 + PR_REF_BLOCK - 1) / PR_REF_BLOCK);  // blocks of this round
     unsigned first = 0;
     for (;;) {  // chain the round's pairs; every wave does, and ends with the same running sum
-      // (lane ww holds wave ww's pair: one LDS round trip, then scalar reads)
-      const uint32_t l_a0 = s_a0[par][lane & (PR_REFW_WAVES - 1)], l_a1 = s_a1[par][lane & (PR_REFW_WAVES - 1)];
+      // The chain is itself a composition of parity functions: lane ww holds wave ww's pair (the identity in front of `first`
+      // and behind the round's last block), four DPP steps give every prefix, one ballot finds the first block in which the
+      // prefix leaves the binade.  (Chained block after block by scalar code this was 2.2 of a round's 4 us: 16 waves x 16
+      // dependent steps, sessions/r06_20.sh.)
+      const bool in_chain = lane >= first && lane < nw;
+      SeqPair lp;
+      lp.a0 = in_chain ? s_a0[par][lane & (PR_REFW_WAVES - 1)] : 0u;
+      lp.a1 = in_chain ? s_a1[par][lane & (PR_REFW_WAVES - 1)] : 0u;
+      lp = seq_row_scan(lp);
+      const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
+      const uint32_t tot = P0 + ((P0 & 1u) ? lp.a1 : lp.a0);
+      const bool normal = E - 1u < 254u;
+      const unsigned long long cross = __ballot(in_chain && (!normal || tot >= (1u << 24)));
       unsigned wc = PR_REFW_WAVES;
-      for (unsigned ww = first; ww < nw; ww++) {
-        const uint32_t P0 = (S & 0x7FFFFFu) | 0x800000u;
-        const uint32_t tot = P0 + ((P0 & 1u) ? (uint32_t)__builtin_amdgcn_readlane((int)l_a1, ww) : (uint32_t)__builtin_amdgcn_readlane((int)l_a0, ww));
-        if (E - 1u >= 254u || tot >= (1u << 24)) {
-          wc = ww;
-          break;
-        }
-        S = (E << 23) | (tot & 0x7FFFFFu);
+      if (cross) {
+        wc = (unsigned)__ffsll((long long)cross) - 1u;
+        const uint32_t Pb = wc ? (uint32_t)__builtin_amdgcn_readlane((int)tot, wc - 1u) : P0;  // (lanes in front of `first` hold P0)
+        if (normal) S = (E << 23) | (Pb & 0x7FFFFFu);
+      } else if (nw > first && normal) {
+        S = (E << 23) | ((uint32_t)__builtin_amdgcn_readlane((int)tot, nw - 1u) & 0x7FFFFFu);
       }
       if (wc == PR_REFW_WAVES) break;
       if (w == wc) {  // the end of the binade (or a running sum that is not a normal number yet) lies in my block: added exactly
@@ -1642,7 +1668,9 @@ static int pr_ref_resum(gdn_pr_plan *plan, const PrOp &op, double *d_diff, hipSt
     GDN_HIP(hipEventRecord(plan->ref_ev[0], s));
     GDN_HIP(hipStreamWaitEvent(sw, plan->ref_ev[0], 0));
   }
-  if (rr.n_vlong) hipLaunchKernelGGL(pr_refscan_wg_kernel, dim3(rr.n_vlong), dim3(PR_REFW_THREADS), 0, sw, rr, op.skip);
+  if (rr.n_vlong)
+    hipLaunchKernelGGL(pr_refscan_wg_kernel, dim3(rr.n_vlong), dim3(PR_REFW_THREADS), 0, sw, rr, op.skip,
+                       gdn_xoption("GDN_PR_REF_DBG") ? atoi(gdn_xoption("GDN_PR_REF_DBG")) : 0);
   if (rr.n > rr.n_vlong)
     hipLaunchKernelGGL(pr_refscan_kernel, dim3((rr.n - rr.n_vlong + GDN_WAVES_PER_BLOCK - 1) / GDN_WAVES_PER_BLOCK), dim3(GDN_BLOCK), 0, s, rr, op.skip);
   if (sw != s) {

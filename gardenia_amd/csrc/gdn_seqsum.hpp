@@ -80,7 +80,8 @@ GDN_HD SeqPair seq_compose(const SeqPair &f, const SeqPair &g) {
 #ifdef __HIPCC__
 // inclusive scan of the lanes' pairs under composition: inside the rows of 16 lanes by DPP row_shr (a lane without a source reads
 // the pair (0, 0) = the identity -- no select), across the four rows through the rows' totals in scalar registers
-__device__ __forceinline__ SeqPair seq_wave_scan(SeqPair p, unsigned lane) {
+// ... inside every row of 16 lanes (four DPP steps)
+__device__ __forceinline__ SeqPair seq_row_scan(SeqPair p) {
 #define SEQ_ROW_STEP(CTRL)                                                                       \
   {                                                                                              \
     SeqPair f;                                                                                   \
@@ -93,6 +94,10 @@ __device__ __forceinline__ SeqPair seq_wave_scan(SeqPair p, unsigned lane) {
   SEQ_ROW_STEP(0x114)  // row_shr:4
   SEQ_ROW_STEP(0x118)  // row_shr:8
 #undef SEQ_ROW_STEP
+  return p;
+}
+__device__ __forceinline__ SeqPair seq_wave_scan(SeqPair p, unsigned lane) {
+  p = seq_row_scan(p);
   SeqPair t0, t1, t2;
   t0.a0 = (uint32_t)__builtin_amdgcn_readlane((int)p.a0, 15);
   t0.a1 = (uint32_t)__builtin_amdgcn_readlane((int)p.a1, 15);
