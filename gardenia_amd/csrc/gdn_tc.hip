@@ -398,6 +398,39 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
 // (the limit is a launch argument: measured on symmetrized R-MAT, count kernel only, limit 64 / 256 / 512: scale 19
 // 2.00 / 1.85 / 2.17 ms, scale 21 10.4 / 10.08 / 9.76, scale 23 68.8 / 66.3 / 66.3 -- fewer set rebuilds and item grabs
 // with a higher limit, until whole rows on single waves make the tail of a small graph)
+// Work items are handed out by atomic counters, and a counter all 4096 resident waves share is a queue: device-scope atomics on
+// ONE address retire at ~100 M/s (they are executed behind the XCDs' L2s), so the 524 K batch grabs + the item grabs of an
+// RMAT-23 count were ~8 ms of atomics -- the kernel with its walks ablated away still took 8.1 of its 15.5 ms
+// (profiles/r06_tc_ablation.md).  TC_NCUR counters, 128 bytes apart: unit B belongs to counter B mod TC_NCUR (its k-th unit is
+// B = k TC_NCUR + c), a wave starts at the counter its number selects and moves on when one runs dry; every counter is seen dry
+// at most once by a wave, after TC_NCUR of those everything is handed out.  Units keep their order inside a counter (rows are
+// degree-ranked: the long ones come last on every counter alike).
+#ifndef TC_NCUR
+#define TC_NCUR 64
+#endif
+#define TC_CUR_STRIDE 32  // words between two counters
+#ifndef TC_BATCH
+#define TC_BATCH 16  // light rows per grab (<= 63: the batch's row offsets are one load)
+#endif
+struct TcGrab {
+  unsigned *cur;
+  unsigned c, dry;
+  __device__ __forceinline__ TcGrab(unsigned *cursors, unsigned wave) : cur(cursors), c(wave % TC_NCUR), dry(0) {}
+  // the next unit of [0, n), ~0u when all are handed out (wave-uniform)
+  __device__ __forceinline__ unsigned next(unsigned n, unsigned lane) {
+    while (dry < TC_NCUR) {
+      unsigned k = 0;
+      if (lane == 0) k = atomicAdd(&cur[c * TC_CUR_STRIDE], 1u);
+      k = (unsigned)__builtin_amdgcn_readfirstlane((int)k);
+      const unsigned long long unit = (unsigned long long)k * TC_NCUR + c;
+      if (unit < n) return (unsigned)unit;
+      c = (c + 1u) % TC_NCUR;
+      dry++;
+    }
+    return ~0u;
+  }
+};
+
 #define TC_LIGHT_MIN 64
 #ifndef TC_SLICE
 #define TC_SLICE 512  // (256 -> 512: 2 % faster, fewer set rebuilds; 1024 the same)
@@ -434,9 +467,9 @@ __global__ void __launch_bounds__(GDN_BLOCK, TC_WAVES_PER_EU)
 tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const eoff_t *__restrict__ nrowptr,
                 const vid_t *__restrict__ ncolidx, int32_t m,
                 const unsigned long long *__restrict__ items, const unsigned *__restrict__ n_items_p,
-                unsigned *__restrict__ cursors /* [0] next heavy item, [1] next light vertex */,
+                unsigned *__restrict__ cursors /* TC_NCUR heavy-item cursors, then TC_NCUR light-batch cursors (tc_grab) */,
                 unsigned long long *__restrict__ total, unsigned light, const unsigned *__restrict__ nstart = nullptr,
-                const unsigned long long *__restrict__ nbound = nullptr) {
+                const unsigned long long *__restrict__ nbound = nullptr, int32_t row_lo = 0) {
   __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
   __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
@@ -451,11 +484,11 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
 #else
   const unsigned n_items = *n_items_p;
 #endif
+  const unsigned gw = blockIdx.x * GDN_WAVES_PER_BLOCK + w;
+  TcGrab hg(cursors, gw);
   for (;;) {
-    unsigned it = 0;
-    if (lane == 0) it = atomicAdd(&cursors[0], 1u);
-    it = __shfl(it, 0, 64);
-    if (it >= n_items) break;
+    const unsigned it = hg.next(n_items, lane);
+    if (it == ~0u) break;
     const unsigned long long item = items[it];
     const unsigned u = (unsigned)(item & 0xFFFFFFFFull), c = (unsigned)(item >> 32);
     const eoff_t ub = rowptr[u], ue = rowptr[u + 1];
@@ -465,15 +498,16 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
     count += tc_row_slice(rowptr, colidx, ncolidx, ub, ue, vlo, vhi, s_tab[w], s_own[w], nstart, nbound);
   }
   // ---- light rows: 16 consecutive vertices per grab (one atomic per 16 rows)
+  const unsigned n_batches = ((unsigned)(m - row_lo) + TC_BATCH - 1u) / TC_BATCH;
+  TcGrab lg(cursors + TC_NCUR * TC_CUR_STRIDE, gw);
   for (;;) {
-    unsigned u0 = 0;
-    if (lane == 0) u0 = atomicAdd(&cursors[1], 16u);
-    u0 = __shfl(u0, 0, 64);
 #if defined(TC_ABL) && TC_ABL == 3  // timing-only ablation: no light rows
     break;
 #endif
-    if (u0 >= (unsigned)m) break;
-    const unsigned u1 = u0 + 16u < (unsigned)m ? u0 + 16u : (unsigned)m;
+    const unsigned bt = lg.next(n_batches, lane);
+    if (bt == ~0u) break;
+    const unsigned u0 = (unsigned)row_lo + bt * TC_BATCH;
+    const unsigned u1 = u0 + TC_BATCH < (unsigned)m ? u0 + TC_BATCH : (unsigned)m;
     eoff_t rp = 0, np = 0;  // the 17 row offsets of the batch in one load (per array)
     if (u0 + lane <= u1) {
       rp = rowptr[u0 + lane];
@@ -913,8 +947,15 @@ tc_core_adj_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ 
 // class first, see tc_core_count_kernel (a full sort by |C(u)| was measured: it scatters the rows of a grab over the whole
 // column array, 7.0 -> 7.8 ms at K = 4096)
 #define TC_CORE_CLASSES 4
+#define TC_CORE_CUR 64  // word of the control block where the classes' work counters start (TC_NCUR per class)
+#define TC_CORE_CTL_WORDS (TC_CORE_CUR + TC_CORE_CLASSES * TC_NCUR * TC_CUR_STRIDE)
 __device__ __host__ constexpr unsigned tc_core_class_min(int c) { return c == 0 ? 256u : c == 1 ? 64u : c == 2 ? 16u : 2u; }
-__device__ __host__ constexpr unsigned tc_core_class_take(int c) { return c == 0 ? 1u : c == 1 ? 4u : c == 2 ? 16u : 64u; }
+#ifndef TC_CORE_TAKE_SHIFT
+#define TC_CORE_TAKE_SHIFT 0
+#endif
+__device__ __host__ constexpr unsigned tc_core_class_take(int c) {
+  return c == 0 ? 1u : (c == 1 ? 4u : c == 2 ? 16u : 64u) >> TC_CORE_TAKE_SHIFT;
+}
 __global__ void __launch_bounds__(GDN_BLOCK)
 tc_core_items_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, int32_t m, unsigned base,
                      unsigned long long *__restrict__ items, unsigned *__restrict__ n_items, unsigned *__restrict__ cls) {
@@ -995,17 +1036,23 @@ tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict_
   // serves ~50 M atomics / s), 64 long items in one grab are the kernel's tail.  A grab's items and row ends are loaded by
   // its lanes side by side.
   const unsigned n_items = ctl[0];
+  const unsigned gw = blockIdx.x * GDN_WAVES_PER_BLOCK + w;
   int cls = 0;  // (wave-uniform)
+  TcGrab grab(ctl + TC_CORE_CUR, gw);  // a class's grabs go over TC_NCUR counters like tc_count_kernel's (round 6)
   for (;;) {
     unsigned it0 = 0, lim = 0, take = 0;
     for (; cls < TC_CORE_CLASSES; cls++) {
       const unsigned first = cls == 0 ? 0u : ctl[5 + cls - 1];
       lim = cls + 1 < TC_CORE_CLASSES ? ctl[5 + cls] : n_items;
       take = tc_core_class_take(cls);
-      if (first >= lim) continue;
-      if (lane == 0) it0 = atomicAdd(&ctl[1 + cls], take);
-      it0 = first + (unsigned)__builtin_amdgcn_readfirstlane((int)it0);
-      if (it0 < lim) break;
+      if (first < lim) {
+        const unsigned unit = grab.next((lim - first + take - 1u) / take, lane);
+        if (unit != ~0u) {
+          it0 = first + unit * take;
+          break;
+        }
+      }
+      grab = TcGrab(ctl + TC_CORE_CUR + (unsigned)(cls + 1) * (TC_NCUR * TC_CUR_STRIDE), gw);
     }
     if (cls >= TC_CORE_CLASSES) break;
     take = lim - it0 < take ? lim - it0 : take;
@@ -1180,17 +1227,16 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
                          const unsigned long long *nbound = nullptr) {
   const gdn_graph *nb_graph = dag_in ? dag_in : dag;  // where a row's neighbours come from
   DevBuf<unsigned long long> d_total, d_items;  // triangle count; (slice << 32 | row) items of the heavy rows
-  DevBuf<unsigned> d_ctl;                       // [0] heavy-item cursor, [1] light-vertex cursor, [2] #items, [3] overflow
+  DevBuf<unsigned> d_ctl;                       // [2] #items, [3] overflow, from [64]: the work counters of tc_count_kernel (TcGrab)
   const uint64_t cap64 = dag->nnz / TC_LIGHT_MIN + 1024;  // a heavy row of du > light >= TC_LIGHT_MIN ids yields ceil(du / TC_SLICE) <= du / TC_LIGHT_MIN items
   const unsigned cap = (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64);
   HostTimer tprep, tsolve;
   tprep.start();
   GDN_TRY(d_total.alloc(1));
   GDN_TRY(d_items.alloc(cap));
-  GDN_TRY(d_ctl.alloc(4));
-  const unsigned ctl0[4] = {0u, (unsigned)row_lo, 0u, 0u};
+  GDN_TRY(d_ctl.alloc(64 + 2 * TC_NCUR * TC_CUR_STRIDE));  // (tc_bs_count_kernel: [0] its cursor)
   GDN_HIP(hipMemset(d_total.p, 0, 8));
-  GDN_HIP(hipMemcpy(d_ctl.p, ctl0, 16, hipMemcpyHostToDevice));
+  GDN_HIP(hipMemset(d_ctl.p, 0, (64 + 2 * TC_NCUR * TC_CUR_STRIDE) * sizeof(unsigned)));
   st.prep_ms += tprep.stop_ms();
   *total = 0;
   if (row_hi <= row_lo) return GDN_OK;
@@ -1220,7 +1266,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
   hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
-                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p, d_total.p, light, nstart, nbound);
+                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p + 64, d_total.p, light, nstart, nbound, row_lo);
   if (core) {
     GDN_TRY(tc_core_launch(*core, false));  // beside tc_count_kernel, on the core's stream
     GDN_TRY(tc_core_launch(*core, true));   // behind it, on this stream
@@ -1253,7 +1299,7 @@ struct gdn_tc_plan {
   DevBuf<unsigned long long> core_adj;  // core_k x core_k bits
   DevBuf<unsigned long long> core_items_a, core_items_b;  // the items, sorted by |C(u)| (the radix sort leaves them in one of the two)
   const unsigned long long *core_items = nullptr;
-  DevBuf<unsigned> core_ctl;            // [0] items, [1..4] the class cursors, [5..7] items of at least a class's length
+  DevBuf<unsigned> core_ctl;            // [0] items, [5..7] items of at least a class's length, from [TC_CORE_CUR]: the classes' work counters
   DevBuf<unsigned long long> core_total;
   hipStream_t core_stream = nullptr;    // the core kernel runs BESIDE tc_count_kernel (which fills half of a CU's wave slots)
   hipEvent_t core_ready = nullptr;      // cursors zeroed (null stream) -> the core's stream may start
@@ -1282,7 +1328,7 @@ static int tc_core_build(gdn_tc_plan &p) {
   const unsigned base = (unsigned)dag->m - k, kw = k / 64u;
   GDN_TRY(p.core_adj.alloc((size_t)k * kw));
   GDN_TRY(p.core_items_a.alloc((size_t)dag->m));
-  GDN_TRY(p.core_ctl.alloc(8));
+  GDN_TRY(p.core_ctl.alloc(TC_CORE_CTL_WORDS));
   GDN_TRY(p.core_total.alloc(1));
   GDN_HIP(hipMemsetAsync(p.core_adj.p, 0, (size_t)k * kw * 8, 0));
   GDN_HIP(hipMemsetAsync(p.core_ctl.p, 0, 32, 0));
@@ -1324,7 +1370,7 @@ static int tc_core_build(gdn_tc_plan &p) {
   return GDN_OK;
 }
 static int tc_core_prepare(gdn_tc_plan &p) {
-  GDN_HIP(hipMemsetAsync(p.core_ctl.p + 1, 0, 16, 0));
+  GDN_HIP(hipMemsetAsync(p.core_ctl.p + TC_CORE_CUR, 0, (TC_CORE_CTL_WORDS - TC_CORE_CUR) * sizeof(unsigned), 0));
   GDN_HIP(hipMemsetAsync(p.core_total.p, 0, 8, 0));
   if (p.core_stream) {
     GDN_HIP(hipEventRecord(p.core_ready, 0));

@@ -1,0 +1,32 @@
+# Round-6 session 23: the core kernel's class counters striped too; K, core workgroups per CU, batch and take variants on the new scheduling
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r06s23
+mkdir -p $O; rm -rf $O/*
+export GDN_TEST_HOOKS=1
+timeout 1200 python3 -m pytest tests -x -q -m gpu -k "tc or triangle" > $O/pytest.txt 2>&1; tail -3 $O/pytest.txt
+for v in base b8 take1 take2; do
+  if [ $v = base ]; then unset GARDENIA_HIP_LIB; else export GARDENIA_HIP_LIB=$PWD/gardenia_amd/lib/var_$v/libgardenia_hip.so; fi
+  for mode in beside alone; do
+    spec=""; [ $mode = alone ] && spec="GDN_TC_CORE_ASYNC=0"
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/$v.$mode -- python3 tools/tc_knob_ab.py 23 5 "$spec" > $O/$v.$mode.txt 2>&1
+  done
+done
+unset GARDENIA_HIP_LIB
+timeout 900 python3 tools/tc_knob_ab.py 23 6 "" "GDN_TC_CORE=8192" "GDN_TC_CORE=16384" "GDN_TC_CORE_WGS=3" "GDN_TC_CORE_WGS=1" "GDN_TC_CORE=16384,GDN_TC_CORE_WGS=3" > $O/k23.txt 2>&1; grep -v "^$" $O/k23.txt | tail -13
+timeout 900 python3 tools/tc_knob_ab.py orkut 6 "" "GDN_TC_CORE=4096" "GDN_TC_CORE=12288" "GDN_TC_CORE_WGS=3" > $O/korkut.txt 2>&1; tail -9 $O/korkut.txt
+timeout 900 python3 tools/tc_knob_ab.py 22 6 "" "GDN_TC_CORE=8192" "GDN_TC_CORE=16384" > $O/k22.txt 2>&1; tail -7 $O/k22.txt
+timeout 900 python3 tools/tc_knob_ab.py 21 6 "" "GDN_TC_CORE=4096" "GDN_TC_CORE=12288" > $O/k21.txt 2>&1; tail -7 $O/k21.txt
+timeout 900 python3 tools/tc_knob_ab.py 24 4 "" "GDN_TC_CORE=12288" "GDN_TC_CORE=20480" > $O/k24.txt 2>&1; tail -7 $O/k24.txt
+python3 - <<'PY'
+import glob, csv
+O = "gpurun_out/r06s23"
+for v in ("base", "b8", "take1", "take2"):
+    for mode in ("beside", "alone"):
+        line = [l for l in open("%s/%s.%s.txt" % (O, v, mode)) if "count median" in l]
+        out = "%-7s %-6s %s" % (v, mode, line[-1].split("]")[1].split(" G dag")[0].strip() if line else "failed")
+        for f in glob.glob("%s/%s.%s/*/*_kernel_stats.csv" % (O, v, mode)):
+            for r in csv.DictReader(open(f)):
+                if r["Name"].startswith("tc_count") or "tc_core_count" in r["Name"]:
+                    out += " | %s avg %.3f ms (%s)" % (r["Name"].split("(")[0][-22:], float(r["AverageNs"]) / 1e6, r["Calls"])
+        print(out)
+PY
