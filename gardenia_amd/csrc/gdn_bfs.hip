@@ -21,6 +21,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+// the top-down kernels' staging strips: 1024 entries per wave (16 KB per workgroup) instead of the library's 256 -- a flush is one
+// reservation on the queue's tail, and a line serves 88 M of those per second (tools/atomic_probe.hip): a level that discovers
+// 4.5 M vertices was 0.437 ms with 256, 0.396 with 512, 0.362 with 1024 (RMAT-27, profiles/sessions/r06_27.sh)
+#define GDN_WL_STAGE 1024
 #include "gdn_expand.hpp"
 #include "gdn_pb.hpp"
 

@@ -221,7 +221,11 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
         rem &= rem - 1ull;
         const eoff_t ob = ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(vb >> 32), owner) << 32) |
                           (unsigned)__builtin_amdgcn_readlane((int)vb, owner);
+#if defined(TC_ABL) && TC_ABL == 8  // timing-only ablation: every long list read from one 1 MB window (what the walks cost when L2 serves them)
+        s_base = colidx + (ob & 0x3FFFFull);
+#else
         s_base = colidx + ob;
+#endif
         s_len = (unsigned)__builtin_amdgcn_readlane((int)deg, owner);
         s_off = 0u;
       }
@@ -1321,7 +1325,8 @@ static int tc_core_build(gdn_tc_plan &p) {
   const gdn_graph *dag = p.dag;
   // (round 5, final binary, profiles/r05_tc_core_k.txt: K = 8192 / 12288 / 16384 -- RMAT-21 5.29 / 5.77 / 5.92 ms, Orkut-like stand-in
   // (3.97 M vertices) 11.06 / 11.10 / 11.8, RMAT-22 10.5 / 9.63 / 10.1, RMAT-23 25.2 / 20.45 / 20.9, RMAT-24 - / 52.2 / 51.8)
-  unsigned k = dag->m >= (1 << 24) ? 16384u : dag->m >= (1 << 22) ? 12288u : dag->m >= (1 << 21) ? 8192u : 0u;
+  // (round 6: 8192 ranks already from 2^19 vertices -- RMAT-19 / 20 without / 4096 / 8192: 1.47 / 0.96 / 0.92 and 2.87 / 1.52 / 1.29 ms)
+  unsigned k = dag->m >= (1 << 24) ? 16384u : dag->m >= (1 << 22) ? 12288u : dag->m >= (1 << 19) ? 8192u : 0u;
   if (const char *e = gdn_option("GDN_TC_CORE")) k = (unsigned)atoi(e);
   k = k >= 16384u ? 16384u : (k / 4096u) * 4096u;  // whole lanes x 64 bits: 4096, 8192, 12288 or 16384
   if (k == 0u || (unsigned)dag->m < k + 64u) return GDN_OK;
@@ -1451,7 +1456,9 @@ int gdn_tc_plan_create(const gdn_graph *g, int32_t oriented, gdn_tc_plan **plan)
   // below that); u / v one of the two; bs the wave-per-edge binary-search intersect
   const char *e = gdn_option("GDN_TC_FORM");
   const uint64_t dag_edges = oriented ? g->nnz : g->nnz / 2;
-  const char form = e ? e[0] : (dag_edges >= (1ull << 24) ? 'f' : 'a');
+  // (round 6, on the striped work counters, forward + core / the reference's orientation: RMAT-18 0.65 / 0.73 ms, RMAT-19 0.92 / 1.44,
+  // RMAT-20 1.29 / 3.10 -- profiles/r06_tc_counters.md; the forward count from 2^22 DAG edges on, 2^24 before)
+  const char form = e ? e[0] : (dag_edges >= (1ull << 22) ? 'f' : 'a');
   gdn_tc_plan *p = new gdn_tc_plan();
   int rc = GDN_OK;
   bool forward = form == 'f';

@@ -522,7 +522,7 @@ int gdn_tc_dev(const gdn_graph *csr, int32_t oriented, uint64_t *total, gdn_stat
  * (src/tc/gpu_base.cu:52-58).  gdn_tc_plan_create prepares the formulation the count will run (stats of a count:
  * `reserved` 3 = the FORWARD count -- vertices relabelled by degree rank, the DAG = edges to higher ranks, its transpose
  * and, per DAG edge u -> v, where the walk of N+(u) starts (behind v: a member of N+(v) outranks v), which halves the
- * look-ups; taken from 2^24 DAG edges on -- 0 / 1 = the hash-set count on the reference's orientation, u- / v-centric;
+ * look-ups; taken from 2^22 DAG edges on -- 0 / 1 = the hash-set count on the reference's orientation, u- / v-centric;
  * 2 = the wave-per-edge binary-search intersect; GDN_TC_FORM = f | a | u | v | bs forces one.  Bits 8.. of `reserved`, forward
  * count only: the ranks of its CORE -- from 2^21 vertices on the look-ups whose middle vertex is among the top 16384 ranks
  * are counted on a bit matrix of those ranks, beside the hash-set kernel; GDN_TC_CORE = 0 | 4096 | 8192 | 12288 | 16384).

@@ -1648,7 +1648,7 @@ def test_pr_one_shot_takes_the_blocked_layout_from_2_22_edges_on(orc, monkeypatc
 def test_tc_oriented_input_that_is_no_dag_counts_like_the_reference_loop(orc, form, monkeypatch):
     """with oriented=1 the count runs on the caller's lists AS THEY ARE (src/tc/omp_base.cc:16-22 does not know
     whether they are an orientation): a directed graph with 2-cycles and cyclic triangles gives the reference loop's total,
-    also when the forward form is asked for (the default from 2^24 DAG edges on) -- its precondition check (every edge
+    also when the forward form is asked for (the default from 2^22 DAG edges on) -- its precondition check (every edge
     ascends in the (degree, id) order, no entry repeats) sends such an input to the count on the given lists."""
     if form:
         monkeypatch.setenv("GDN_TC_FORM", form)
@@ -1674,7 +1674,7 @@ def test_tc_forward_core_vs_oracle(orc, scale, ef, seed, core, monkeypatch):
     monkeypatch.setenv("GDN_TC_FORM", "f")
     monkeypatch.setenv("GDN_TC_CORE", core)
     # (the walks' packed bounds -- first element << 24 | elements, read beside the neighbour ids instead of two gathered row
-    # offsets; default from 2^24 DAG edges on -- with two of the four core sizes)
+    # offsets; default from 2^22 DAG edges on -- with two of the four core sizes)
     monkeypatch.setenv("GDN_TC_NBOUND", "1" if core in ("8192", "16384") else "0")
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
     want = orc.tc(orc.tc_orient(g))
@@ -1767,8 +1767,8 @@ def test_tc_vs_oracle_rmat(orc, scale, ef, seed, monkeypatch):
     g = graphio.symmetrize(graphio.rmat_graph(scale, ef, seed=seed))
     want = orc.tc(orc.tc_orient(g))
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
-    assert total == want and st["reserved"] in (0, 1)  # below 2^24 DAG edges: the hash-set count on the reference's orientation
-    monkeypatch.setenv("GDN_TC_FORM", "f")  # the forward count (the default from 2^24 DAG edges on)
+    assert total == want and st["reserved"] in (0, 1)  # below 2^22 DAG edges: the hash-set count on the reference's orientation
+    monkeypatch.setenv("GDN_TC_FORM", "f")  # the forward count (the default from 2^22 DAG edges on)
     total, st = solvers.TCSolver(solvers.Graph(csr=g, symmetrize=True))
     assert total == want and st["reserved"] == 3
     dag = orc.tc_orient(g)
