@@ -80,6 +80,7 @@ tc_rowptr_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restrict__ p
 #endif
 #define TC_HASH (2 * TC_CAP)   // open-addressing slots per wave (load factor <= 0.5)
 #define TC_EMPTY (-1)
+#define TC_NOKEY (-2)  // a key no set holds (ids are >= 0): what a position past its list's end looks up (TcSet::count_fast)
 
 #define TC_HASH_BITS (TC_CAP == 1024 ? 11 : TC_CAP == 512 ? 10 : TC_CAP == 256 ? 9 : 8)
 static_assert((1 << TC_HASH_BITS) == TC_HASH, "TC_CAP must be 128, 256, 512 or 1024");
@@ -148,6 +149,49 @@ struct TcSet {
     }
     return c;  // wave total (the same in every lane)
   }
+  // The same look-ups WITHOUT lane masks for the list ends, for the chunk stream of the long lists (round 6).  With its work
+  // counters out of the way (profiles/r06_tc_counters.md) the kernel turned out to be bound by neither bytes nor round trips --
+  // every long list served from a 1 MB window: 10.6 instead of 10.8 ms -- but by instruction ISSUE at four waves per SIMD: 37
+  // scalar and 30 vector instructions per chunk of 64 look-ups, and a SIMD issues one of each per four cycles (scalar 65 %,
+  // vector 52 % of the kernel's cycles).  Here a position past its list's end carries a key no set holds (TC_NOKEY) instead of
+  // a cleared mask bit -- the scalar iterator computes no masks -- and hits are counted per LANE, one add with the hit mask as
+  // carry, instead of a popcount and an add on the scalar unit; the caller sums the lanes once per walk.  (All-vector forms --
+  // min(slot ^ key) == 0, the pending test as an AND-reduction -- were measured first: 17 scalar but 37-45 vector instructions
+  // per chunk, hash-set kernel alone 11.8 / 10.1 ms, the Orkut-like count 3.7 % slower: sessions r06_30, r06_32.)
+  template <int N>
+  __device__ __forceinline__ void count_fast(const vid_t (&w)[N], unsigned &cl) const {
+    unsigned hb[N];
+    tc_i32x4 b[N];
+    unsigned long long pend[N];
+#pragma unroll
+    for (int r = 0; r < N; r++) {
+      hb[r] = tc_bucket(w[r]);
+      b[r] = *reinterpret_cast<const tc_i32x4 *>(table + 4u * hb[r]);
+    }
+    unsigned long long any = 0ull;
+#pragma unroll
+    for (int r = 0; r < N; r++) {
+      const unsigned long long hit = __ballot(b[r].x == w[r]) | __ballot(b[r].y == w[r]) | __ballot(b[r].z == w[r]) |
+                                     __ballot(b[r].w == w[r]);
+      asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(cl) : "s"(hit) : "vcc");  // cl += this lane's bit of `hit`
+      pend[r] = __ballot(b[r].w != TC_EMPTY) & ~hit;  // bucket full and not found: look in the next one
+      any |= pend[r];
+    }
+    if (__builtin_expect(any != 0ull, 0)) {  // (one look-up in ~300 at the usual loads: every second step of 256)
+#pragma unroll
+      for (int r = 0; r < N; r++) {
+        if (pend[r]) pend[r] &= __ballot(w[r] != TC_NOKEY);  // positions past a list's end (all in ONE bucket) are not followed
+        while (pend[r]) {  // uniform
+          hb[r] = (hb[r] + 1u) & (TC_BUCKETS - 1);
+          b[r] = *reinterpret_cast<const tc_i32x4 *>(table + 4u * hb[r]);
+          const unsigned long long hit = (__ballot(b[r].x == w[r]) | __ballot(b[r].y == w[r]) | __ballot(b[r].z == w[r]) |
+                                          __ballot(b[r].w == w[r])) & pend[r];
+          asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(cl) : "s"(hit) : "vcc");
+          pend[r] = __ballot(b[r].w != TC_EMPTY) & pend[r] & ~hit;
+        }
+      }
+    }
+  }
 };
 
 // insert / remove one key (each lane its own; keys of one list are distinct)
@@ -215,7 +259,7 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
     unsigned long long rem = __ballot(nch > 0u);  // lists not started yet (scalar)
     const vid_t *s_base = colidx;                 // current list (scalar)
     unsigned s_len = 1u, s_off = 1u;              // its length and the position of the next chunk (s_off >= s_len: finished)
-    auto next_chunk = [&](vid_t &w, unsigned long long &vm) {
+    auto next_chunk = [&](vid_t &w) {
       if (s_off >= s_len && rem) {  // uniform: the next list
         const int owner = __ffsll((long long)rem) - 1;
         rem &= rem - 1ull;
@@ -229,28 +273,26 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
         s_len = (unsigned)__builtin_amdgcn_readlane((int)deg, owner);
         s_off = 0u;
       }
-      const unsigned left = s_off < s_len ? s_len - s_off : 0u;  // scalar
-      vm = left >= 64u ? ~0ull : ((1ull << left) - 1ull);
       const unsigned o = s_off + lane;
-      w = s_base[o < s_len ? o : s_len - 1u];
-      s_off = left ? s_off + 64u : s_off;
+      const vid_t x = s_base[o < s_len ? o : s_len - 1u];
+      w = o < s_len ? x : TC_NOKEY;  // (past the end: a key no set holds -- no lane masks in the look-ups, TcSet::count_fast)
+      s_off = s_off < s_len ? s_off + 64u : s_off;
     };
-    auto load_step = [&](vid_t (&w)[TC_UNR], unsigned long long (&vm)[TC_UNR]) {
+    auto load_step = [&](vid_t (&w)[TC_UNR]) {
 #pragma unroll
-      for (int r = 0; r < TC_UNR; r++) next_chunk(w[r], vm[r]);
+      for (int r = 0; r < TC_UNR; r++) next_chunk(w[r]);
     };
     if (total_s) {
       vid_t w0[TC_UNR], w1[TC_UNR];
-      unsigned long long m0[TC_UNR], m1[TC_UNR];
-      unsigned cw = 0;  // wave total
-      load_step(w0, m0);
+      unsigned cl = 0;  // hits of this lane
+      load_step(w0);
       for (unsigned q0 = 0; q0 < total_s; q0 += 2 * TC_UNR) {
-        load_step(w1, m1);
-        cw += set.count(w0, m0);
-        load_step(w0, m0);
-        cw += set.count(w1, m1);
+        load_step(w1);
+        set.count_fast(w0, cl);
+        load_step(w0);
+        set.count_fast(w1, cl);
       }
-      if (lane == 0) count += cw;
+      count += cl;  // (per lane: the caller's block sum takes every lane's count)
     }
     if (nch) deg = 0;
   }
