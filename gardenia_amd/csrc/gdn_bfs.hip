@@ -792,7 +792,91 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
       }
     }
     wave_sync();
-    // ---- stage 2: the rows still open, one per lane: their in-neighbours against the frontier
+#if defined(BFS_ABL) && BFS_ABL == 1  // timing-only ablation: no stage 2 at all
+    nq = 0;
+#endif
+    // ---- stage 2: the rows still open: their in-neighbours against the frontier
+    // FLAT form (scan_unr == 0, the default since round 6): the in-edges of 64 open rows as ONE list, 64 of them per wave step,
+    // whichever rows they belong to (owner of a position: binary search over the lanes' running degree sums, six shuffles) --
+    // every step is one round trip of independent gathers.  With a row per lane each lane walked its own list, one dependent
+    // load per in-neighbour, and a wave step lasted as long as its LONGEST row: on the 0.13-share level of RMAT-27's slow source
+    // (38 M open rows of ~3 in-neighbours, 35 M of them failing) that loop alone was 0.95 of the level's 1.34 ms, the probes
+    // 0.03 (compile-time ablations, profiles/r06_bfs_slow_source.md).  A row found in one step is skipped in the next.
+    if (scan_unr == 0) {
+      constexpr unsigned CAP = 1u << 24;  // in-edges of a row the flat pass takes (the sum over 64 rows stays below 2^32); the rest: below
+      // (four steps of gathers in flight and the next 64 rows' offsets requested ahead were measured: the same on RMAT-27, 5 % slower
+      // on RMAT-22 -- sessions r06_35 / r06_36; the step is no chain of round trips any more)
+      for (unsigned i0 = 0; i0 < nq; i0 += 64u) {  // uniform
+        const unsigned i = i0 + lane;
+        const bool on = i < nq;
+        const unsigned rl = on ? list[i] : 0u, v = gbase + rl;
+        eoff_t rb = 0, re = 0;
+        if (on) {
+          if (cbase == nullptr) {
+            rb = in_rowptr[v];
+            re = in_rowptr[v + 1];
+          } else {
+            const unsigned ci = compact_id(v);
+            rb = rowptr_c[ci];
+            re = rowptr_c[ci + 1u];
+          }
+        }
+#if defined(BFS_ABL) && BFS_ABL == 2
+        re = rb;
+#endif
+        const unsigned d = re - rb < (eoff_t)CAP ? (unsigned)(re - rb) : CAP;
+        const unsigned incl = gdn_wave_incl_scan(d), excl = incl - d;
+        const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+        unsigned long long fmask = 0ull;  // lanes whose row has been found (uniform)
+        for (unsigned t0 = 0; t0 < total; t0 += 64u) {
+          const unsigned idx = t0 + lane;
+          const bool valid = idx < total;
+          unsigned owner = 0;  // lanes whose running sum is <= idx = the first lane whose sum exceeds it
+#pragma unroll
+          for (unsigned sft = 32u; sft > 0u; sft >>= 1) {
+            const unsigned at = (unsigned)__shfl((int)incl, (int)((owner + sft - 1u) & 63u), 64);
+            if (at <= idx && owner + sft <= 63u) owner += sft;
+          }
+          const eoff_t ob = __shfl(rb, (int)owner, 64);
+          const unsigned oe = (unsigned)__shfl((int)excl, (int)owner, 64);
+          bool hit = false;
+          if (valid && !((fmask >> owner) & 1ull)) {
+            const vid_t u = in_colidx[ob + (eoff_t)(idx - oe)];
+            probes++;
+#if defined(BFS_ABL) && BFS_ABL == 3
+            hit = u == (vid_t)-5;
+#else
+            bool pass = true;
+            if (filt) {  // small frontier: its 1 MB hashed filter (L2 resident) first; most in-neighbours of a failing row stop here
+              const unsigned h = bfs_filt_hash((unsigned)u);
+              pass = (filt[h >> 5] >> (h & 31u)) & 1u;
+            }
+            if (pass) hit = (front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u;
+#endif
+          }
+          unsigned long long hm = __ballot(hit);
+          while (hm) {  // (the owners of the hits: a few per step)
+            const int l = __ffsll((long long)hm) - 1;
+            hm &= hm - 1ull;
+            fmask |= 1ull << (unsigned)__builtin_amdgcn_readlane((int)owner, l);
+          }
+        }
+        bool found = on && ((fmask >> lane) & 1ull);
+        if (on && !found && re - rb > (eoff_t)CAP) {  // (a row of more than 2^24 in-edges: the rest of its list, one by one)
+          for (eoff_t k = rb + CAP; k < re && !found; k++) {
+            const vid_t u = in_colidx[k];
+            probes++;
+            found = (front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u;
+          }
+        }
+        if (found) {
+          if (depth) depth[v] = next_level;
+          atomicOr(&bits[rl >> 5], 1u << (rl & 31u));
+          awake++;
+          scout += BFS_REC_DEG(rec_at(v));
+        }
+      }
+    } else
     for (unsigned i = lane; i < nq; i += 64u) {
       const unsigned rl = list[i], v = gbase + rl;
       eoff_t rb, re;
@@ -805,6 +889,10 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         re = rowptr_c[ci + 1u];
       }
       bool found = false;
+#if defined(BFS_ABL) && BFS_ABL == 2  // timing-only ablation: the open rows' offsets are loaded, nothing is scanned
+      found = (re - rb) == 0x7FFFFFFFull;
+      re = rb;
+#endif
       if (scan_unr > 1) {
         // four in-neighbours and their frontier words per round trip: a row that reaches this stage mostly FAILS (its head was
         // not in the frontier), so the whole list is walked anyway -- one neighbour at a time that is two dependent loads each
@@ -825,6 +913,10 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
       for (eoff_t k = rb; k < re; k++) {
         const vid_t u = in_colidx[k];
         probes++;
+#if defined(BFS_ABL) && BFS_ABL == 3  // timing-only ablation: the in-neighbours are loaded, nothing is probed
+        found = found || u == (vid_t)-5;
+        continue;
+#endif
         if (filt) {  // small frontier: its 1 MB hashed filter (L2 resident) first; most in-neighbours of a failing row stop here
           const unsigned h = bfs_filt_hash((unsigned)u);
           if (!((filt[h >> 5] >> (h & 31u)) & 1u)) continue;
@@ -1855,8 +1947,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
   if (const char *e = gdn_xoption("GDN_BFS_BU_STAY")) bu_stay = atoi(e) > 0 ? atoi(e) : bu_stay;  // tuning knob
   // in-neighbours per round trip of the bottom-up scan: 4 measured the same as 1 on RMAT-24 / 27 (session r05_08: the step is
   // not bound by the lane-private scan loops) -- the knob stays for the next graph family
-  int bu_scan = 1;
-  if (const char *e = gdn_xoption("GDN_BFS_BU_SCAN")) bu_scan = atoi(e) > 1 ? 4 : 1;  // A/B knob
+  // (round 6: 0 = the FLAT scan, all in-edges of 64 open rows as one list -- see bfs_bu_wave_kernel's second stage; the lane-private
+  // loops stay behind the knob: 1 = an in-neighbour per round trip, 4 = four)
+  int bu_scan = 0;
+  if (const char *e = gdn_xoption("GDN_BFS_BU_SCAN")) bu_scan = atoi(e) > 1 ? 4 : atoi(e) == 1 ? 1 : 0;  // A/B knob
   // largest frontier that gets the hashed filter (GDN_BFS_BU_FILTER=<vertices>, 0 = never) -- on graphs whose frontier bitmap
   // is beyond an XCD's L2 (from 2^26 vertices = 8 MB on).  Measured (profiles/r05_bfs_bu_scan.txt): RMAT-27's hub-frontier level
   // 1.865 -> 1.815 ms (source 5: 2.76 -> 2.69 ms), the other searches unchanged; RMAT-24, whose 2 MB bitmap IS L2 resident, pays
