@@ -1627,10 +1627,16 @@ bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps,
       const size_t q = q0 + (size_t)u * stride;
       const unsigned w = (unsigned)((q * 4) >> 5);
       const bool on = q < nquads;
+#if defined(BFS_ABL) && BFS_ABL == 4  // timing-only ablation: no bitmap is read (the pass as a plain fill)
+      vw[u] = 0u;
+#pragma unroll
+      for (int k = 0; k < BFS_DEFER_MAX; k++) mw[u][k] = 0u;
+#else
       vw[u] = on ? visited[w] : 0u;
       // (static indices: a run-time index into the by-value struct would put it into scratch memory)
 #pragma unroll
       for (int k = 0; k < BFS_DEFER_MAX; k++) mw[u][k] = (on && k < maps.n) ? maps.bits[k][w] : 0u;
+#endif
     }
 #pragma unroll
     for (int u = 0; u < BFS_FINISH_UNR; u++) {

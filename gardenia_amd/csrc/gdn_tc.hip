@@ -503,6 +503,9 @@ tc_heavy_items_kernel(const eoff_t *__restrict__ rowptr, const eoff_t *__restric
   }
 }
 
+#ifdef TC_NUM_VGPR  // A/B (tools/build_variant.sh): the hash-set kernel held to this many vector registers (what is left of a SIMD's 512 is the core kernel's)
+__attribute__((amdgpu_num_vgpr(TC_NUM_VGPR)))
+#endif
 __global__ void __launch_bounds__(GDN_BLOCK, TC_WAVES_PER_EU)
 // Two formulations, same total.  u-centric (nrowptr == rowptr, ncolidx == colidx; the reference's loop, src/tc/omp_base.cc:
 // 16-22): row u, set N+(u), neighbours v in N+(u), the elements of N+(v) are looked up -- SUM over edges of d+(v) probes.
