@@ -825,43 +825,58 @@ bfs_bu_wave_kernel(const eoff_t *__restrict__ in_rowptr, const vid_t *__restrict
         re = rb;
 #endif
         const unsigned d = re - rb < (eoff_t)CAP ? (unsigned)(re - rb) : CAP;
-        const unsigned incl = gdn_wave_incl_scan(d), excl = incl - d;
-        const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
-        unsigned long long fmask = 0ull;  // lanes whose row has been found (uniform)
-        for (unsigned t0 = 0; t0 < total; t0 += 64u) {
-          const unsigned idx = t0 + lane;
-          const bool valid = idx < total;
-          unsigned owner = 0;  // lanes whose running sum is <= idx = the first lane whose sum exceeds it
+        // in ROUNDS: every open row puts its next `quota` in-edges into the round's list, the quota doubles from round to round
+        // (4, 8, 16, ...).  A row that finds a parent stops there -- with all in-edges of a row in one list a row of 16
+        // in-neighbours paid 16 probes where the frontier owns a quarter of the edges and 4 find a parent (a uniform random
+        // graph's heavy level as a bottom-up step: 6.2 ms against the lane-private loop's 2.9, session r06_44) -- and a long
+        // failing row is through in log2 rounds; the failing rows of ~3 in-neighbours of an R-MAT level take one round as before.
+        unsigned pos = 0, quota = 4u;
+        bool found = false;
+        for (;;) {
+          const unsigned left = d - pos;
+          const unsigned q = (!found && left) ? (left < quota ? left : quota) : 0u;
+          if (__ballot(q != 0u) == 0ull) break;
+          const unsigned incl = gdn_wave_incl_scan(q), excl = incl - q;
+          const unsigned total = (unsigned)__shfl((int)incl, 63, 64);
+          unsigned long long fmask = 0ull;  // lanes whose row has been found in this round (uniform)
+          for (unsigned t0 = 0; t0 < total; t0 += 64u) {
+            const unsigned idx = t0 + lane;
+            const bool valid = idx < total;
+            unsigned owner = 0;  // lanes whose running sum is <= idx = the first lane whose sum exceeds it
 #pragma unroll
-          for (unsigned sft = 32u; sft > 0u; sft >>= 1) {
-            const unsigned at = (unsigned)__shfl((int)incl, (int)((owner + sft - 1u) & 63u), 64);
-            if (at <= idx && owner + sft <= 63u) owner += sft;
-          }
-          const eoff_t ob = __shfl(rb, (int)owner, 64);
-          const unsigned oe = (unsigned)__shfl((int)excl, (int)owner, 64);
-          bool hit = false;
-          if (valid && !((fmask >> owner) & 1ull)) {
-            const vid_t u = in_colidx[ob + (eoff_t)(idx - oe)];
-            probes++;
-#if defined(BFS_ABL) && BFS_ABL == 3
-            hit = u == (vid_t)-5;
-#else
-            bool pass = true;
-            if (filt) {  // small frontier: its 1 MB hashed filter (L2 resident) first; most in-neighbours of a failing row stop here
-              const unsigned h = bfs_filt_hash((unsigned)u);
-              pass = (filt[h >> 5] >> (h & 31u)) & 1u;
+            for (unsigned sft = 32u; sft > 0u; sft >>= 1) {
+              const unsigned at = (unsigned)__shfl((int)incl, (int)((owner + sft - 1u) & 63u), 64);
+              if (at <= idx && owner + sft <= 63u) owner += sft;
             }
-            if (pass) hit = (front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u;
+            const eoff_t ob = __shfl(rb, (int)owner, 64);
+            const unsigned oe = (unsigned)__shfl((int)excl, (int)owner, 64) - (unsigned)__shfl((int)pos, (int)owner, 64);
+            bool hit = false;
+            if (valid && !((fmask >> owner) & 1ull)) {
+              const vid_t u = in_colidx[ob + (eoff_t)(idx - oe)];
+              probes++;
+#if defined(BFS_ABL) && BFS_ABL == 3
+              hit = u == (vid_t)-5;
+#else
+              bool pass = true;
+              if (filt) {  // small frontier: its 1 MB hashed filter (L2 resident) first; most in-neighbours of a failing row stop here
+                const unsigned h = bfs_filt_hash((unsigned)u);
+                pass = (filt[h >> 5] >> (h & 31u)) & 1u;
+              }
+              if (pass) hit = (front[(unsigned)u >> 5] >> ((unsigned)u & 31u)) & 1u;
 #endif
+            }
+            unsigned long long hm = __ballot(hit);
+            while (hm) {  // (the owners of the hits: a few per step)
+              const int l = __ffsll((long long)hm) - 1;
+              hm &= hm - 1ull;
+              fmask |= 1ull << (unsigned)__builtin_amdgcn_readlane((int)owner, l);
+            }
           }
-          unsigned long long hm = __ballot(hit);
-          while (hm) {  // (the owners of the hits: a few per step)
-            const int l = __ffsll((long long)hm) - 1;
-            hm &= hm - 1ull;
-            fmask |= 1ull << (unsigned)__builtin_amdgcn_readlane((int)owner, l);
-          }
+          found = found || ((fmask >> lane) & 1ull);
+          pos += q;
+          quota = quota < (1u << 20) ? quota << 1 : quota;
         }
-        bool found = on && ((fmask >> lane) & 1ull);
+        found = on && found;
         if (on && !found && re - rb > (eoff_t)CAP) {  // (a row of more than 2^24 in-edges: the rest of its list, one by one)
           for (eoff_t k = rb + CAP; k < re && !found; k++) {
             const vid_t u = in_colidx[k];

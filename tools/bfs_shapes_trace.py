@@ -17,6 +17,8 @@ KNOBS = [("default", {}),
          ("no early bottom-up (share rule off)", {"GDN_BFS_BU_EDGE_DIV": "0"}),
          ("no binned level", {"GDN_BFS_BTD": "0"}),
          ("bottom-up from 1/8 of the edges", {"GDN_BFS_BU_EDGE_DIV": "8"}),
+         ("bottom-up from 1/5 of the edges", {"GDN_BFS_BU_EDGE_DIV": "5"}),
+         ("bottom-up from 1/4 of the edges", {"GDN_BFS_BU_EDGE_DIV": "4"}),
          ("dense from nnz/64", {"GDN_BFS_ALPHA_DENSE": "64"}),
          ("dense from nnz/128, heavy = dense", {"GDN_BFS_ALPHA_DENSE": "128", "GDN_BFS_BU_FRAC": "0", "GDN_BFS_BU_EDGE_DIV": "0", "GDN_BFS_BTD": "0"})]
 for name in (sys.argv[1:] or ["uniform", "small_world"]):
