@@ -54,6 +54,7 @@ struct BfsTdVis {
   unsigned cap;
   int32_t next_level;
   unsigned long long scout_local;
+  bool blind = false;  // no read of the bitmap in front of the atomic (see edge())
   GdnWlStage stage;  // per-wave LDS strip of discovered vertices (one atomicAdd on next_count per flush)
   __device__ __forceinline__ void begin_big(vid_t) {}
   __device__ __forceinline__ void edge(int, eoff_t k, bool valid) {
@@ -62,7 +63,10 @@ struct BfsTdVis {
     if (valid) {
       dst = __builtin_nontemporal_load(colidx + k);
       const unsigned bit = 1u << (dst & 31);
-      const unsigned w = visited[dst >> 5];
+      // the plain read in front of the atomic keeps the edges of visited vertices (and the thousands of edges into one hub: a
+      // line serves 88 M atomics/s) off the atomic unit.  Where hardly anything is visited yet and no vertex is hot -- the early
+      // levels of a graph without hubs -- it is a gather for nothing: `blind` (host: !skewed and < 1/8 of the rows visited)
+      const unsigned w = blind ? 0u : visited[dst >> 5];
       if (!(w & bit)) {
         const unsigned old = atomicOr(&visited[dst >> 5], bit);
         claim = !(old & bit);
@@ -2315,6 +2319,10 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
       vis.cap = p.qcap;
       vis.next_level = level + 1;
       vis.scout_local = 0;
+      {  // GDN_BFS_TD_BLIND (test hook): 0 never, 1 always
+        const char *eb = gdn_test_option("GDN_BFS_TD_BLIND");
+        vis.blind = eb ? eb[0] == '1' : (!p.skewed && p.head.p != nullptr && visited_total * 8 < (int64_t)p.active_rows);
+      }
       big.count = &p.cnt.p->big_count;
       big.overflow = &p.cnt.p->overflow;
       // a small frontier of long rows: hand every row of a wave's width or more to the persistent item kernel

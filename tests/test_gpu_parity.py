@@ -125,6 +125,26 @@ def test_bfs_deferred_depths_beyond_the_pool_of_kept_levels(orc, monkeypatch, ca
     bfs.close()
 
 
+@pytest.mark.parametrize("blind", ["0", "1"])
+def test_bfs_top_down_without_the_read_in_front_of_the_atomic(orc, monkeypatch, blind):
+    """Top-down levels claim a vertex with an atomic OR on the visited bitmap; the plain read in front of it is skipped (`blind`)
+    in the early levels of a graph without hubs (default rule: not skewed and < 1/8 of the rows visited).  Forced on / off here
+    on an R-MAT graph (hubs: thousands of edges race for one word) and a uniform one: depths and traversed edges as the oracle's."""
+    monkeypatch.setenv("GDN_BFS_TD_BLIND", blind)
+    monkeypatch.setenv("GDN_BFS_HEADS_MIN_NNZ", "1")
+    m, src, dst = graphio.uniform_edges(1 << 16, 1 << 20, seed=5)
+    for g in (graphio.rmat_graph(15, 16, seed=9), graphio.build_csr(m, src, dst)):
+        G = solvers.Graph(csr=g, need_reverse=True)
+        bfs = solvers.ResidentBFS(G, dense=True)
+        deg = g.degrees()
+        for s in (graphio.first_nonisolated(g), int(np.argmax(deg))):
+            dist, st = bfs.run(s)
+            want = orc.bfs_serial(g, s)
+            assert np.array_equal(dist, want), (s, int((dist != want).sum()))
+            assert st["edges_traversed"] == int(deg[want != solvers.MYINFINITY].astype(np.int64).sum())
+        bfs.close()
+
+
 def test_bfs_star_and_chain(orc):
     # a hub with 20000 out-neighbours (big-row path) feeding a chain (many tiny levels)
     n = 20001 + 300
