@@ -1632,6 +1632,9 @@ struct BfsLevelMaps {
   int n;
 };
 #define BFS_FINISH_UNR 4
+// NMAPS = maps.n (compile time: the kernel is VALU-bound on choosing a level per vertex -- with loops over all BFS_DEFER_MAX slots it
+// took 0.196 ms where a plain fill of the same 537 MB takes 0.078, profiles/r06_bfs_slow_source.md; a search keeps 3-5 levels)
+template <int NMAPS>
 __global__ void __launch_bounds__(GDN_BLOCK)
 bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps, int32_t *__restrict__ depth, int32_t m, int32_t unreached) {
   // four consecutive vertices per thread and trip (a nibble of one bitmap word, one 16-byte store), a grid that loops (with a
@@ -1640,7 +1643,7 @@ bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps,
   const size_t nquads = ((size_t)m + 3) / 4, stride = (size_t)gridDim.x * GDN_BLOCK;
   const bool aligned = (reinterpret_cast<size_t>(depth) & 15u) == 0;
   for (size_t q0 = (size_t)blockIdx.x * GDN_BLOCK + threadIdx.x; q0 < nquads; q0 += BFS_FINISH_UNR * stride) {
-    unsigned vw[BFS_FINISH_UNR], mw[BFS_FINISH_UNR][BFS_DEFER_MAX];
+    unsigned vw[BFS_FINISH_UNR], mw[BFS_FINISH_UNR][NMAPS > 0 ? NMAPS : 1];
 #pragma unroll
     for (int u = 0; u < BFS_FINISH_UNR; u++) {
       const size_t q = q0 + (size_t)u * stride;
@@ -1649,12 +1652,12 @@ bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps,
 #if defined(BFS_ABL) && BFS_ABL == 4  // timing-only ablation: no bitmap is read (the pass as a plain fill)
       vw[u] = 0u;
 #pragma unroll
-      for (int k = 0; k < BFS_DEFER_MAX; k++) mw[u][k] = 0u;
+      for (int k = 0; k < NMAPS; k++) mw[u][k] = 0u;
 #else
       vw[u] = on ? visited[w] : 0u;
       // (static indices: a run-time index into the by-value struct would put it into scratch memory)
 #pragma unroll
-      for (int k = 0; k < BFS_DEFER_MAX; k++) mw[u][k] = (on && k < maps.n) ? maps.bits[k][w] : 0u;
+      for (int k = 0; k < NMAPS; k++) mw[u][k] = on ? maps.bits[k][w] : 0u;
 #endif
     }
 #pragma unroll
@@ -1667,8 +1670,8 @@ bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps,
       int32_t val[4] = {unreached, unreached, unreached, unreached};
       unsigned write = ~seen & 15u;
 #pragma unroll
-      for (int k = 0; k < BFS_DEFER_MAX; k++) {
-        const unsigned bits = (mw[u][k] >> sh) & 15u;  // (0 beyond maps.n)
+      for (int k = 0; k < NMAPS; k++) {
+        const unsigned bits = (mw[u][k] >> sh) & 15u;
         write |= bits;
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -2371,9 +2374,27 @@ static int bfs_run(gdn_bfs_plan &p, int32_t source, int32_t *d_dist, gdn_stats *
     unsigned fin_blocks = 8192;
     if (const char *e = gdn_xoption("GDN_BFS_FINISH_BLOCKS")) fin_blocks = atoi(e) > 0 ? (unsigned)atoi(e) : fin_blocks;  // (tuning knob)
     const unsigned need_blocks = gdn_nblocks(((uint64_t)m + 3) / 4);
-    hipLaunchKernelGGL(bfs_depth_finish_kernel, dim3(need_blocks < fin_blocks ? need_blocks : fin_blocks),
-                       dim3(GDN_BLOCK), 0, 0, p.visited.p, maps, d_dist, m,
-                       (int32_t)GDN_MYINFINITY);
+    const dim3 fgrid(need_blocks < fin_blocks ? need_blocks : fin_blocks);
+#define BFS_FINISH_LAUNCH(N)                                                                                               \
+  case N:                                                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(bfs_depth_finish_kernel<N>), fgrid, dim3(GDN_BLOCK), 0, 0, p.visited.p, maps, d_dist, m, \
+                       (int32_t)GDN_MYINFINITY);                                                                           \
+    break;
+    static_assert(BFS_DEFER_MAX == 8, "one instance of the closing pass per number of kept levels");
+    switch (maps.n) {
+      BFS_FINISH_LAUNCH(0)
+      BFS_FINISH_LAUNCH(1)
+      BFS_FINISH_LAUNCH(2)
+      BFS_FINISH_LAUNCH(3)
+      BFS_FINISH_LAUNCH(4)
+      BFS_FINISH_LAUNCH(5)
+      BFS_FINISH_LAUNCH(6)
+      BFS_FINISH_LAUNCH(7)
+      default:
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(bfs_depth_finish_kernel<8>), fgrid, dim3(GDN_BLOCK), 0, 0, p.visited.p, maps, d_dist, m,
+                           (int32_t)GDN_MYINFINITY);
+    }
+#undef BFS_FINISH_LAUNCH
     if (time_init) GDN_HIP(hipEventRecord(ev.d, 0));
     GDN_HIP(hipStreamSynchronize(0));
     if (trace) fprintf(stderr, "[bfs] distances of %d kept levels + unreached written at the end  %.3f ms\n", maps.n, tl.stop_ms());
