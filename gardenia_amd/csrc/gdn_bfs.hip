@@ -1673,9 +1673,12 @@ bfs_depth_finish_kernel(const unsigned *__restrict__ visited, BfsLevelMaps maps,
       for (int k = 0; k < NMAPS; k++) {
         const unsigned bits = (mw[u][k] >> sh) & 15u;
         write |= bits;
+        const int32_t lv = maps.level[k];
 #pragma unroll
-        for (int j = 0; j < 4; j++)
-          if ((bits >> j) & 1u) val[j] = maps.level[k];
+        for (int j = 0; j < 4; j++) {  // (bit j as an all-ones / all-zeros mask, the level blended in: two instructions per vertex and map)
+          const int32_t t = __builtin_amdgcn_sbfe((int)bits, j, 1);
+          val[j] = (val[j] & ~t) | (lv & t);
+        }
       }
       if (write == 15u && v0 + 4 <= (size_t)m && aligned) {
         *reinterpret_cast<int4 *>(depth + v0) = make_int4(val[0], val[1], val[2], val[3]);

@@ -226,7 +226,12 @@ __device__ __forceinline__ void tc_remove(vid_t *tab, vid_t x) {
 #define TC_LONG 48  // lists at least this long are walked in 64-element chunks, shorter ones packed
 #endif
 #ifndef TC_WAVES_PER_EU
-#define TC_WAVES_PER_EU 4  // LDS allows 4 workgroups per CU; measured: 8 waves/SIMD with 4 KB sets is slower
+// LDS allows 4 workgroups per CU (8 waves/SIMD with 4 KB sets measured slower).  The kernel is nevertheless COMPILED for five
+// waves per SIMD, with its LDS arrays dynamic so that the compiler does not see the LDS cap and honours the bound (round 6,
+// profiles/r06_tc_counters.md section 7): beside the core kernel the count is 15 % faster on R-MAT graphs (RMAT-23 12.7 ->
+// 10.85 ms, RMAT-24 31.8 -> 28.5) and 1 % slower on the Orkut-like one; each kernel ALONE takes the same time in both
+// builds, and both builds allocate 93 vector registers -- what the bound changes is how the two kernels share a CU.
+#define TC_WAVES_PER_EU 5
 #endif
 
 // Walk the out-neighbour lists [vb,ve) held one per lane (vb == ve for idle lanes) and count the elements that
@@ -234,11 +239,10 @@ __device__ __forceinline__ void tc_remove(vid_t *tab, vid_t x) {
 // the lengths; the owner of a packed position comes from start markers dropped into LDS instead of the 6-step
 // binary search of gdn_expand.hpp: the kernel was VALU bound on that search) with TC_UNR independent positions
 // per lane, so TC_UNR global loads and LDS probes overlap.
-__device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restrict__ colidx, eoff_t vb, eoff_t ve,
+__device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restrict__ colidx, eoff_t vb, unsigned deg,
                                                             const TcSet &set, unsigned char *s_own) {
   const unsigned lane = gdn_lane();
   unsigned long long count = 0;
-  unsigned deg = (unsigned)(ve - vb);
   {  // Lists of TC_LONG elements or more, cut into 64-element CHUNKS; the chunks of all of them form one stream that is
      // walked TC_UNR chunks per step, with the NEXT step's loads issued before this step's probes (two steps in flight per
      // wave).  Walking one list at a time in 512-slot steps left 45-60 % of the slots empty (the lists of a degree-ordered
@@ -380,18 +384,20 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     // the first 64 neighbours and their list bounds, requested BEFORE the set is built: behind the build's fence they were a
     // third and fourth dependent round trip of every row (set ids -> neighbour ids -> bounds -> lists), and a light row is
     // little more than that chain
-    eoff_t vb0 = 0, ve0 = 0;
+    eoff_t vb0 = 0;    // (a walk as its first element and its length: a register less per walk than two offsets, and the kernel
+    unsigned vd0 = 0;  // is held to 96 of them, see tc_count_rows)
     if (nbound) {  // the forward form with packed walk bounds: no neighbour id, no row offsets
       if (vlo + lane < vhi) {
         const unsigned long long b = nbound[vlo + lane];
         vb0 = b >> 24;
-        ve0 = vb0 + (b & 0xFFFFFFull);
+        vd0 = (unsigned)(b & 0xFFFFFFull);
       }
     } else if (vlo + lane < vhi) {
       const vid_t v = (ncol == colidx && vlo == cb) ? x0 : ncol[vlo + lane];
       vb0 = rowptr[v];
-      ve0 = rowptr[v + 1];
+      const eoff_t e0 = rowptr[v + 1];
       if (nstart) vb0 += nstart[vlo + lane];
+      vd0 = (unsigned)(e0 - vb0);
     }
     for (int i = lane; i < cn; i += 64) {  // build: integer LDS CAS, linear probing
       tc_insert(s_tab, i < 64 ? x0 : colidx[cb + i]);
@@ -405,24 +411,27 @@ __device__ __forceinline__ unsigned long long tc_row_slice(const eoff_t *__restr
     for (eoff_t i0 = vlo; i0 < vhi; i0 += 64) {
 #endif
       const eoff_t i = i0 + lane;
-      eoff_t vb = vb0, ve = ve0;
+      eoff_t vb = vb0;
+      unsigned vd = vd0;
       if (i0 != vlo) {
-        vb = ve = 0;
+        vb = 0;
+        vd = 0;
         if (i < vhi && nbound) {
           const unsigned long long b = nbound[i];
           vb = b >> 24;
-          ve = vb + (b & 0xFFFFFFull);
+          vd = (unsigned)(b & 0xFFFFFFull);
         } else if (i < vhi) {
           const vid_t v = (ncol == colidx && i0 == cb) ? x0 : ncol[i];
           vb = rowptr[v];
-          ve = rowptr[v + 1];
+          const eoff_t e1 = rowptr[v + 1];
           if (nstart) vb += nstart[i];
+          vd = (unsigned)(e1 - vb);
         }
       }
 #if defined(TC_ABL) && TC_ABL == 7  // timing-only ablation: neighbour ids + bounds loaded, lists not walked
-      count += (unsigned long long)((ve - vb) & 1);
+      count += (unsigned long long)(vd & 1u);
 #else
-      count += tc_walk_lists(colidx, vb, ve, set, s_own);
+      count += tc_walk_lists(colidx, vb, vd, set, s_own);
 #endif
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -519,9 +528,12 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
                 unsigned *__restrict__ cursors /* TC_NCUR heavy-item cursors, then TC_NCUR light-batch cursors (tc_grab) */,
                 unsigned long long *__restrict__ total, unsigned light, const unsigned *__restrict__ nstart = nullptr,
                 const unsigned long long *__restrict__ nbound = nullptr, int32_t row_lo = 0) {
-  __shared__ __attribute__((aligned(16))) vid_t s_tab[GDN_WAVES_PER_BLOCK][TC_HASH];
-  __shared__ unsigned char s_own[GDN_WAVES_PER_BLOCK][64 * TC_UNR];  // start markers of the packed lists (0 = none)
-  __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
+  // (dynamic LDS: see TC_WAVES_PER_EU)  per wave: the hash set, the start markers of the packed lists (0 = none); a reduction word
+  extern __shared__ __attribute__((aligned(16))) unsigned char tc_dyn[];
+  vid_t(*s_tab)[TC_HASH] = reinterpret_cast<vid_t(*)[TC_HASH]>(tc_dyn);
+  unsigned long long *s_red = reinterpret_cast<unsigned long long *>(tc_dyn + sizeof(vid_t) * GDN_WAVES_PER_BLOCK * TC_HASH);
+  unsigned char(*s_own)[64 * TC_UNR] =
+      reinterpret_cast<unsigned char(*)[64 * TC_UNR]>(tc_dyn + sizeof(vid_t) * GDN_WAVES_PER_BLOCK * TC_HASH + 8 * GDN_WAVES_PER_BLOCK);
   const unsigned lane = gdn_lane();
   const unsigned w = threadIdx.x >> 6;
   unsigned long long count = 0;
@@ -563,8 +575,12 @@ tc_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ col
       np = nrowptr == rowptr ? rp : nrowptr[u0 + lane];
     }
     for (unsigned u = u0; u < u1; u++) {
-      const eoff_t ub = __shfl(rp, (int)(u - u0), 64), ue = __shfl(rp, (int)(u - u0) + 1, 64);
-      const eoff_t nb0 = __shfl(np, (int)(u - u0), 64), ne0 = __shfl(np, (int)(u - u0) + 1, 64);
+      // (the row's four offsets are wave-uniform: read into scalar registers, not shuffled into vector ones)
+      auto lane_u64 = [](eoff_t x, unsigned l) -> eoff_t {
+        return ((eoff_t)(unsigned)__builtin_amdgcn_readlane((int)(x >> 32), (int)l) << 32) | (unsigned)__builtin_amdgcn_readlane((int)x, (int)l);
+      };
+      const eoff_t ub = lane_u64(rp, u - u0), ue = lane_u64(rp, u - u0 + 1u);
+      const eoff_t nb0 = lane_u64(np, u - u0), ne0 = lane_u64(np, u - u0 + 1u);
       const eoff_t dn = ne0 - nb0;
       // nothing to close without a set or a neighbour; heavy rows are done
       if (ue == ub || dn == 0 || dn > light) continue;
@@ -1064,8 +1080,11 @@ tc_walked_elements_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__rest
 }
 
 typedef unsigned tc_u32x2 __attribute__((ext_vector_type(2)));
+#ifndef TC_CORE_WPE
+#define TC_CORE_WPE 1
+#endif
 template <int R>  // K = 4096 R: R 64-bit words of a row (and of B_u) per lane
-__global__ void __launch_bounds__(GDN_BLOCK)
+__global__ void __launch_bounds__(GDN_BLOCK, TC_CORE_WPE)
 tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict__ colidx, const unsigned long long *__restrict__ items,
                      unsigned *__restrict__ ctl, const unsigned long long *__restrict__ adj, unsigned base,
                      unsigned long long *__restrict__ total, unsigned small) {
@@ -1270,6 +1289,9 @@ int gdn_tc_probe_counts(const gdn_graph *dag, uint64_t *probes) {
 struct gdn_tc_plan;
 static int tc_core_prepare(gdn_tc_plan &p);           // cursors and total zeroed on the null stream, the core stream waits for that
 static int tc_core_launch(gdn_tc_plan &p, bool tail);  // tail: the grid that takes what is left once tc_count_kernel is done
+// the heavy rows' work items of a plan's count: made by its first count, kept (they depend on the DAG and the limit only)
+static int tc_plan_heavy_items(gdn_tc_plan &p, const gdn_graph *dag, const gdn_graph *nb_graph, int32_t row_lo, int32_t row_hi,
+                               unsigned light, unsigned cap, unsigned long long **items, unsigned **ctl);
 static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, uint64_t *total, gdn_stats &st,
                          const gdn_graph *dag_in = nullptr, bool binary_search = false, const unsigned *nstart = nullptr,
                          gdn_tc_plan *core = nullptr /* its core kernel is queued right behind tc_count_kernel's launch */,
@@ -1282,7 +1304,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   HostTimer tprep, tsolve;
   tprep.start();
   GDN_TRY(d_total.alloc(1));
-  GDN_TRY(d_items.alloc(cap));
+  if (!core) GDN_TRY(d_items.alloc(cap));
   GDN_TRY(d_ctl.alloc(64 + 2 * TC_NCUR * TC_CUR_STRIDE));  // (tc_bs_count_kernel: [0] its cursor)
   GDN_HIP(hipMemset(d_total.p, 0, 8));
   GDN_HIP(hipMemset(d_ctl.p, 0, (64 + 2 * TC_NCUR * TC_CUR_STRIDE) * sizeof(unsigned)));
@@ -1310,12 +1332,19 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   if (core) light = 128u;
   if (const char *e = gdn_xoption("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);  // tuning knob
   if (core) GDN_TRY(tc_core_prepare(*core));
-  hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
-                     row_hi, d_items.p, cap, d_ctl.p + 2, d_ctl.p + 3, light);
+  unsigned long long *items_p = d_items.p;
+  unsigned *ictl = d_ctl.p;  // [2] #items, [3] overflow
+  if (core) {
+    GDN_TRY(tc_plan_heavy_items(*core, dag, nb_graph, row_lo, row_hi, light, cap, &items_p, &ictl));
+  } else {
+    hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks(rows)), dim3(GDN_BLOCK), 0, 0, dag->rowptr, nb_graph->rowptr, row_lo,
+                       row_hi, items_p, cap, ictl + 2, ictl + 3, light);
+  }
   unsigned nb = gdn_nblocks(rows, GDN_WAVES_PER_BLOCK * 16);
   if (nb > 256 * 8) nb = 256 * 8;  // persistent: up to 8 workgroups per CU pulling work items
-  hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), 0, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
-                     nb_graph->colidx, row_hi, d_items.p, d_ctl.p + 2, d_ctl.p + 64, d_total.p, light, nstart, nbound, row_lo);
+  const size_t tc_lds = sizeof(vid_t) * GDN_WAVES_PER_BLOCK * TC_HASH + 8 * GDN_WAVES_PER_BLOCK + (size_t)GDN_WAVES_PER_BLOCK * 64 * TC_UNR;
+  hipLaunchKernelGGL(tc_count_kernel, dim3(nb), dim3(GDN_BLOCK), tc_lds, 0, dag->rowptr, dag->colidx, nb_graph->rowptr,
+                     nb_graph->colidx, row_hi, items_p, ictl + 2, d_ctl.p + 64, d_total.p, light, nstart, nbound, row_lo);
   if (core) {
     GDN_TRY(tc_core_launch(*core, false));  // beside tc_count_kernel, on the core's stream
     GDN_TRY(tc_core_launch(*core, true));   // behind it, on this stream
@@ -1323,7 +1352,7 @@ static int tc_count_rows(const gdn_graph *dag, int32_t row_lo, int32_t row_hi, u
   unsigned long long h = 0;
   unsigned ctl[4] = {0, 0, 0, 0};
   if (hipMemcpy(&h, d_total.p, 8, hipMemcpyDeviceToHost) != hipSuccess ||
-      hipMemcpy(ctl, d_ctl.p, 16, hipMemcpyDeviceToHost) != hipSuccess) {
+      hipMemcpy(ctl, ictl, 16, hipMemcpyDeviceToHost) != hipSuccess) {
     gdn_set_error("gdn_tc: count kernel failed: %s", hipGetErrorString(hipGetLastError()));
     return GDN_ERR_HIP;
   }
@@ -1353,6 +1382,11 @@ struct gdn_tc_plan {
   hipStream_t core_stream = nullptr;    // the core kernel runs BESIDE tc_count_kernel (which fills half of a CU's wave slots)
   hipEvent_t core_ready = nullptr;      // cursors zeroed (null stream) -> the core's stream may start
   std::mutex count_mu;                  // the core's cursors and total belong to the plan: one count at a time
+  // the heavy rows' work items of tc_count_kernel (tc_plan_heavy_items): [2] of the control words = their number, [3] = overflow
+  DevBuf<unsigned long long> items;
+  DevBuf<unsigned> items_ctl;
+  unsigned items_light = 0;
+  int32_t items_lo = -1, items_hi = -1;
   double prep_ms = 0;
   ~gdn_tc_plan() {
     if (core_stream) (void)hipStreamDestroy(core_stream);
@@ -1361,6 +1395,24 @@ struct gdn_tc_plan {
     if (dag) gdn_graph_free(dag);
   }
 };
+
+static int tc_plan_heavy_items(gdn_tc_plan &p, const gdn_graph *dag, const gdn_graph *nb_graph, int32_t row_lo, int32_t row_hi,
+                               unsigned light, unsigned cap, unsigned long long **items, unsigned **ctl) {
+  if (!p.items.p || p.items_light != light || p.items_lo != row_lo || p.items_hi != row_hi) {
+    GDN_TRY(p.items.alloc(cap));
+    GDN_TRY(p.items_ctl.alloc(4));
+    GDN_HIP(hipMemsetAsync(p.items_ctl.p, 0, 16, 0));
+    hipLaunchKernelGGL(tc_heavy_items_kernel, dim3(gdn_nblocks((uint64_t)(row_hi - row_lo))), dim3(GDN_BLOCK), 0, 0, dag->rowptr,
+                       nb_graph->rowptr, row_lo, row_hi, p.items.p, cap, p.items_ctl.p + 2, p.items_ctl.p + 3, light);
+    GDN_HIP(hipGetLastError());
+    p.items_light = light;
+    p.items_lo = row_lo;
+    p.items_hi = row_hi;
+  }
+  *items = p.items.p;
+  *ctl = p.items_ctl.p;
+  return GDN_OK;
+}
 
 // GDN_TC_CORE: ranks of the core (4096, 8192, 12288 or 16384; 0 = none).  Default from 2^21 vertices on, 8192 / 12288 / 16384
 // ranks from 2^21 / 2^22 / 2^24 vertices (round 4: 16384 throughout, on the numbers that follow): symmetrized
@@ -1417,6 +1469,15 @@ static int tc_core_build(gdn_tc_plan &p) {
     }
   }
   p.core_k = k;
+  {  // the heavy rows' items of the hash-set kernel now (not by the first count: see tc_core_launch on who starts first)
+    unsigned light = 128u;  // (tc_count_rows beside a core)
+    if (const char *e = gdn_xoption("GDN_TC_LIGHT")) light = std::max((unsigned)atoi(e), (unsigned)TC_LIGHT_MIN);
+    const uint64_t cap64 = dag->nnz / TC_LIGHT_MIN + 1024;
+    unsigned long long *it = nullptr;
+    unsigned *ct = nullptr;
+    GDN_TRY(tc_plan_heavy_items(p, dag, p.dag_in ? p.dag_in : dag, 0, dag->m - (int32_t)k, light,
+                                (unsigned)(cap64 > 0x7FFFFFFFull ? 0x7FFFFFFFull : cap64), &it, &ct));
+  }
   return GDN_OK;
 }
 static int tc_core_prepare(gdn_tc_plan &p) {
@@ -1432,11 +1493,12 @@ static int tc_core_launch(gdn_tc_plan &p, bool tail) {
   const gdn_graph *dag = p.dag;
   const unsigned base = (unsigned)dag->m - p.core_k;
   if (tail && !p.core_stream) return GDN_OK;  // GDN_TC_CORE_ASYNC=0: the one grid already runs behind tc_count_kernel
-  // Two workgroups per CU: 8 waves of <= 56 registers and 2-8 KB of LDS each fit beside tc_count_kernel's four workgroups
-  // (133 KB of LDS, 4 x 88 registers per SIMD lane) whichever of the two kernels reaches a CU first -- a grid that can fill
-  // the machine does so when it starts first, and the hash-set kernel then waits for its END (measured: 31 instead of 23 ms
-  // in about half of the runs).  A TAIL grid (on the null stream behind tc_count_kernel, same work list) can finish what is
-  // left when the hash-set kernel is done with the whole device -- see below.
+  // A few workgroups per CU: waves of <= 56 registers and 2-8 KB of LDS each beside tc_count_kernel's four workgroups (133 KB
+  // of LDS).  Which of the two kernels reaches a CU first decides how they share it -- a grid that can fill the machine does
+  // so when it starts first, and the hash-set kernel then waits for its END (round 4: 31 instead of 23 ms in about half of the
+  // runs).  Since round 6 the hash-set kernel is queued FIRST (its heavy-row items are the plan's, nothing runs in front of it).
+  // A TAIL grid (on the null stream behind tc_count_kernel, same work list) can finish what is left when the hash-set kernel
+  // is done with the whole device -- see below.
   int cus = 256;
   {
     int dev = 0;
@@ -1444,8 +1506,10 @@ static int tc_core_launch(gdn_tc_plan &p, bool tail) {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
       cus = prop.multiProcessorCount;
   }
-  // (measured 2 / 3 / 4 at RMAT-23: K = 12288 20.9 / 23.4 / 25.5 ms, K = 16384 21.5 / 24.5 / 26.5: more slow the hash-set kernel)
-  unsigned per_cu = 2;
+  // (rounds 4-5, under the single work counters: 2 / 3 / 4 at RMAT-23 20.9 / 23.4 / 25.5 ms.  Round 6, striped counters, the hash-set
+  // kernel compiled for five waves per SIMD and starting first (its items come from the plan): 2 / 3 / 4 -> RMAT-23 11.65 / 11.18 /
+  // 10.85 ms, RMAT-21 2.24 / 2.13 / 2.11, RMAT-24 28.9 / 28.7 / 28.5, Orkut-like 6.84 / 6.83 / 6.81: four)
+  unsigned per_cu = 4;
   if (const char *e = gdn_test_option("GDN_TC_CORE_WGS")) per_cu = atoi(e) > 0 ? (unsigned)atoi(e) : per_cu;  // (tuning knob)
   if (!p.core_stream) per_cu = 8;  // GDN_TC_CORE_ASYNC=0: alone on the device
   if (tail) {
