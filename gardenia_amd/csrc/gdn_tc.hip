@@ -1423,7 +1423,9 @@ static int tc_core_build(gdn_tc_plan &p) {
   // (round 5, final binary, profiles/r05_tc_core_k.txt: K = 8192 / 12288 / 16384 -- RMAT-21 5.29 / 5.77 / 5.92 ms, Orkut-like stand-in
   // (3.97 M vertices) 11.06 / 11.10 / 11.8, RMAT-22 10.5 / 9.63 / 10.1, RMAT-23 25.2 / 20.45 / 20.9, RMAT-24 - / 52.2 / 51.8)
   // (round 6: 8192 ranks already from 2^19 vertices -- RMAT-19 / 20 without / 4096 / 8192: 1.47 / 0.96 / 0.92 and 2.87 / 1.52 / 1.29 ms)
-  unsigned k = dag->m >= (1 << 24) ? 16384u : dag->m >= (1 << 22) ? 12288u : dag->m >= (1 << 19) ? 8192u : 0u;
+  // (session r06_56, the two kernels sharing a CU as they do now: RMAT-22 8192 / 12288 / 16384 4.61 / 5.12 / 5.61 ms, RMAT-23 15.1 / 11.0 / 11.5,
+  // RMAT-24 - / 32.2 / 29.1, RMAT-21 4096 / 8192 / 12288 2.50 / 2.10 / 2.53: 12288 ranks from 2^23 vertices on)
+  unsigned k = dag->m >= (1 << 24) ? 16384u : dag->m >= (1 << 23) ? 12288u : dag->m >= (1 << 19) ? 8192u : 0u;
   if (const char *e = gdn_option("GDN_TC_CORE")) k = (unsigned)atoi(e);
   k = k >= 16384u ? 16384u : (k / 4096u) * 4096u;  // whole lanes x 64 bits: 4096, 8192, 12288 or 16384
   if (k == 0u || (unsigned)dag->m < k + 64u) return GDN_OK;

@@ -289,7 +289,7 @@ def test_config4_triangle_count_orkut_sized(orc):
     assert st["edges_traversed"] == dag.nnz
     assert st["reserved"] & 0xFF == 3 and st["reserved"] >> 8 in (0, 8192, 12288, 16384)  # the forward count; R-MAT: with its core
     if gs.m == 1 << 23:
-        assert st["reserved"] >> 8 == 12288  # (8192 / 12288 / 16384 ranks from 2^21 / 2^22 / 2^24 vertices)
+        assert st["reserved"] >> 8 == 12288  # (8192 / 12288 / 16384 ranks from 2^19 / 2^23 / 2^24 vertices)
     total2, _ = solvers.TCSolver(solvers.Graph(csr=dag), oriented=True)  # the DAG handed over like `Graph g(prefix, USE_DAG)`
     assert total2 == want
 
