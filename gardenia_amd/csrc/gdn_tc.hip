@@ -97,7 +97,9 @@ typedef int tc_i32x4 __attribute__((ext_vector_type(4)));
 #define TC_BUCKETS (TC_HASH / 4)
 // (a 24-bit multiply -- v_mul_u32_u24 is full rate where v_mul_lo_u32 is quarter rate -- of the id folded onto itself was
 // measured: 3 % SLOWER on RMAT-21 / 23, it spreads the ids less evenly over the buckets)
-#ifdef TC_HASH_XOR  // A/B (tools/build_variant.sh): two full-rate instructions instead of the quarter-rate 32-bit multiply
+#ifdef TC_HASH_MUL24  // A/B: the full-rate 24-bit multiply (ids below 2^24)
+__device__ __forceinline__ unsigned tc_bucket(vid_t w) { return __umul24((unsigned)w, 0x9E3779u) >> (32 - (TC_HASH_BITS - 2)); }
+#elif defined(TC_HASH_XOR)  // A/B (tools/build_variant.sh): two full-rate instructions instead of the quarter-rate 32-bit multiply
 __device__ __forceinline__ unsigned tc_bucket(vid_t w) { return (((unsigned)w >> 9) ^ (unsigned)w) & (TC_BUCKETS - 1u); }
 #else
 __device__ __forceinline__ unsigned tc_bucket(vid_t w) { return ((unsigned)w * 2654435761u) >> (32 - (TC_HASH_BITS - 2)); }
@@ -278,6 +280,8 @@ __device__ __forceinline__ unsigned long long tc_walk_lists(const vid_t *__restr
         s_off = 0u;
       }
       const unsigned o = s_off + lane;
+      // (the clamp as one v_min_u32 against the scalar instead of compare + select, and the bucket hash as a full-rate 24-bit
+      // multiply, were measured on one box: + 0.7 % and + 9 % -- session r06_60; fewer instructions are not always fewer cycles here)
       const vid_t x = s_base[o < s_len ? o : s_len - 1u];
       w = o < s_len ? x : TC_NOKEY;  // (past the end: a key no set holds -- no lane masks in the look-ups, TcSet::count_fast)
       s_off = s_off < s_len ? s_off + 64u : s_off;
