@@ -228,11 +228,13 @@ __device__ __forceinline__ void tc_remove(vid_t *tab, vid_t x) {
 #define TC_LONG 48  // lists at least this long are walked in 64-element chunks, shorter ones packed
 #endif
 #ifndef TC_WAVES_PER_EU
-// LDS allows 4 workgroups per CU (8 waves/SIMD with 4 KB sets measured slower).  The kernel is nevertheless COMPILED for five
-// waves per SIMD, with its LDS arrays dynamic so that the compiler does not see the LDS cap and honours the bound (round 6,
-// profiles/r06_tc_counters.md section 7): beside the core kernel the count is 15 % faster on R-MAT graphs (RMAT-23 12.7 ->
-// 10.85 ms, RMAT-24 31.8 -> 28.5) and 1 % slower on the Orkut-like one; each kernel ALONE takes the same time in both
-// builds, and both builds allocate 93 vector registers -- what the bound changes is how the two kernels share a CU.
+// LDS allows 4 workgroups per CU (8 waves/SIMD with 4 KB sets measured slower).  The kernel's LDS arrays are DYNAMIC, so that the
+// compiler does not see that cap, and the bound asked for is five waves per SIMD (round 6, profiles/r06_tc_counters.md section 7):
+// beside the core kernel the count is 15 % faster on R-MAT graphs than with the same arrays static (RMAT-23 12.7 -> 10.8 ms,
+// RMAT-24 31.8 -> 28.5; 1 % slower on the Orkut-like graph); each kernel ALONE takes the same time in both builds and both
+// allocate 93 vector registers.  With the arrays dynamic the bound itself hardly matters at 93 registers (4 / 5: 10.80 / 10.77 ms;
+// 6 = 80 registers and spills: RMAT-23 10.57 but Orkut-like 7.50 against 6.79, session r06_68) -- what the static arrays change in
+// the code object was not tracked down.
 #define TC_WAVES_PER_EU 5
 #endif
 
