@@ -229,12 +229,13 @@ __device__ __forceinline__ void tc_remove(vid_t *tab, vid_t x) {
 #endif
 #ifndef TC_WAVES_PER_EU
 // LDS allows 4 workgroups per CU (8 waves/SIMD with 4 KB sets measured slower).  The kernel's LDS arrays are DYNAMIC, so that the
-// compiler does not see that cap, and the bound asked for is five waves per SIMD (round 6, profiles/r06_tc_counters.md section 7):
-// beside the core kernel the count is 15 % faster on R-MAT graphs than with the same arrays static (RMAT-23 12.7 -> 10.8 ms,
-// RMAT-24 31.8 -> 28.5; 1 % slower on the Orkut-like graph); each kernel ALONE takes the same time in both builds and both
-// allocate 93 vector registers.  With the arrays dynamic the bound itself hardly matters at 93 registers (4 / 5: 10.80 / 10.77 ms;
-// 6 = 80 registers and spills: RMAT-23 10.57 but Orkut-like 7.50 against 6.79, session r06_68) -- what the static arrays change in
-// the code object was not tracked down.
+// compiler does not see that cap, and the bound asked for is five waves per SIMD: the code object then allocates 93 vector
+// registers (.vgpr_count, llvm-readelf --notes) where the build with static arrays -- the compiler takes what four waves allow --
+// allocates 97.  Registers come in blocks of 8: four hash-set waves of 96 leave 128 of a SIMD's 512 to the core kernel, TWO of its
+// waves of 56; four of 104 leave 96, ONE.  Beside the core kernel the count is 15 % faster on R-MAT graphs (RMAT-23 12.7 -> 10.8 ms,
+// RMAT-24 31.8 -> 28.5; Orkut-like 1 % slower), each kernel ALONE takes the same time in both builds (round 6,
+// profiles/r06_tc_counters.md section 7).  Bounds 4 / 5 / 6 with dynamic arrays: 93 / 93 / 80 registers, RMAT-23 10.80 / 10.77 /
+// 10.57 ms, Orkut-like 6.79 / 6.79 / 7.50 (spills at 80), session r06_68.  KEEP THE KERNEL AT <= 96 REGISTERS.
 #define TC_WAVES_PER_EU 5
 #endif
 

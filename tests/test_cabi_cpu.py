@@ -93,3 +93,35 @@ def test_option_surface_is_the_documented_public_one():
     assert len(hooks) >= 40 and len(exper) >= 40
     # the tests' own hooks are switched on by the conftest, not by the library's defaults
     assert os.environ.get("GDN_TEST_HOOKS") == "1"
+
+
+def test_tc_hash_set_kernel_leaves_a_simd_room_for_two_core_waves(tmp_path):
+    """tc_count_kernel runs four waves per SIMD (LDS) beside tc_core_count_kernel's waves of <= 56 vector registers: at <= 96 registers
+    (allocated in blocks of 8) a SIMD's 512 hold two core waves beside them, at 104 one -- RMAT-23 10.8 against 12.7 ms
+    (profiles/r06_tc_counters.md section 7).  The code object's own count (.vgpr_count), not the compiler's remark, is what decides."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not (os.path.exists(hipcc) and os.path.exists(llvm + "/clang-offload-bundler") and os.path.exists(llvm + "/llvm-readelf")):
+        pytest.skip("no ROCm toolchain")
+    src = os.path.join(ROOT, "gardenia_amd", "csrc", "gdn_tc.hip")
+    obj, co = str(tmp_path / "tc.o"), str(tmp_path / "tc.co")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-c", src, "-o", obj],
+                   check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    subprocess.run([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + obj, "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                    "--output=" + co], check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    notes = subprocess.run([llvm + "/llvm-readelf", "--notes", co], check=True, stdout=subprocess.PIPE, text=True).stdout
+    found = {}
+    for block in notes.split("- .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", block)
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", block)
+        if name and vg:
+            found[name.group(1)] = int(vg.group(1))
+    count = [v for k, v in found.items() if k.startswith("_Z15tc_count_kernel")]
+    core = [v for k, v in found.items() if "tc_core_count_kernel" in k]
+    assert count and len(core) == 4, sorted(found)
+    assert count[0] <= 96, count
+    assert max(core) <= 64, core
+    assert 4 * ((count[0] + 7) // 8 * 8) + 2 * ((max(core[:3]) + 7) // 8 * 8) <= 512  # K <= 12288: two waves of the core kernel fit
