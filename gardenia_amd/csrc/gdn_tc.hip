@@ -1088,7 +1088,7 @@ tc_walked_elements_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__rest
 
 typedef unsigned tc_u32x2 __attribute__((ext_vector_type(2)));
 #ifndef TC_CORE_WPE
-#define TC_CORE_WPE 1
+#define TC_CORE_WPE 8  // <= 64 vector registers: two waves of this kernel fit a SIMD beside four of tc_count_kernel's (see TC_WAVES_PER_EU)
 #endif
 template <int R>  // K = 4096 R: R 64-bit words of a row (and of B_u) per lane
 __global__ void __launch_bounds__(GDN_BLOCK, TC_CORE_WPE)
@@ -1096,10 +1096,25 @@ tc_core_count_kernel(const eoff_t *__restrict__ rowptr, const vid_t *__restrict_
                      unsigned *__restrict__ ctl, const unsigned long long *__restrict__ adj, unsigned base,
                      unsigned long long *__restrict__ total, unsigned small) {
   constexpr unsigned KW = 64u * R;
-  // rows per group: 4 / 2 / 1 / 1 -- the kernel runs in the registers tc_count_kernel leaves free (160 per lane and SIMD
-  // beside its 4 x 88): two waves per SIMD need <= 80 (R = 4 with four rows per group: 110 -- one wave per SIMD, 27 ms
-  // beside the hash-set kernel where alone it takes 12; with one: 51).  Two groups are in flight either way.
-  constexpr int G = R >= 3 ? 1 : R == 2 ? 2 : 4;
+  // rows per group: 4 / 2 / 2 / 1 -- the kernel runs in the registers tc_count_kernel leaves free (128 per lane and SIMD beside its
+  // 4 x 96: two waves of <= 64; rounds 4-5, 160 free beside 4 x 88: R = 4 with four rows per group, 110 registers, ran one wave per
+  // SIMD: 27 ms beside the hash-set kernel where alone it takes 12).  Two groups are in flight either way.  Round 6, once the register budget beside the hash-set kernel was understood (two
+  // waves of <= 64): K = 12288 with TWO rows per group (64 registers, 5 spilled) RMAT-23 10.80 -> 10.17 ms -- with 70 registers
+  // and no bound only one wave fits: 11.5; K = 8192 with three (64, 2 spilled): the same as two; K = 16384 with two (20 spilled):
+  // RMAT-24 28.8 -> 29.3; K = 4096 with six: the same (sessions r06_69, r06_70)
+#ifndef TC_CORE_G3
+#define TC_CORE_G3 2
+#endif
+#ifndef TC_CORE_G2
+#define TC_CORE_G2 2
+#endif
+#ifndef TC_CORE_G4
+#define TC_CORE_G4 1
+#endif
+#ifndef TC_CORE_G1
+#define TC_CORE_G1 4
+#endif
+  constexpr int G = R >= 4 ? TC_CORE_G4 : R == 3 ? TC_CORE_G3 : R == 2 ? TC_CORE_G2 : TC_CORE_G1;
   __shared__ unsigned long long s_bm[GDN_WAVES_PER_BLOCK][KW];
   __shared__ unsigned long long s_red[GDN_WAVES_PER_BLOCK];
   const unsigned lane = gdn_lane(), w = threadIdx.x >> 6;
